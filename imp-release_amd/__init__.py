@@ -1,0 +1,10 @@
+"""imp-release_amd: MI355X-native (gfx950) implementation of the IMP / EIMP matching hot path.
+
+Python host code mirroring the reference's ``GM`` / ``DGNNS`` / ``AdaGMN`` surface
+(nets/gm.py, nets/gms.py, nets/adgm.py) over hand-written HIP kernels reached through the C-ABI
+library ``csrc/libimp_hip.so`` (declared in ``include/imp_hip.h``).  There is no CPU fallback:
+every compute entry point raises if the HIP library is missing.
+
+Import as ``imp_release_amd`` (alias package next to this directory).
+"""
+__version__ = '0.1.0'

@@ -1,0 +1,148 @@
+"""Deterministic synthetic weights and inputs for the IMP/EIMP matching hot path.
+
+No pretrained weights or datasets exist in this environment, so parity and
+benchmarks are pinned on *seeded synthetic* state_dicts and SuperPoint-like inputs.  Everything
+here is numpy (PCG64) so that the very same tensors can be regenerated on the GPU box without
+shipping 77 MB of weights or any reference file.
+
+The key schema follows the reference's ``state_dict`` (probed from
+``nets/gm.py:58-75``, ``nets/layers.py:59-90,100-107,139-149,182-198``):
+
+* ``bin_score`` ()
+* ``kenc.encoder.{0,3,6,9,12}.{weight,bias}``
+* non-shared layer i : ``gnn.layers.i.attn.proj.{0,1,2}.*``, ``gnn.layers.i.attn.merge.*``,
+  ``gnn.layers.i.mlp.{0,3}.*``
+* shared layer i     : ``gnn.layers.i.proj.*``, ``gnn.layers.i.merge.*``, ``gnn.layers.i.mlp.{0,3}.*``
+* ``final_proj.{0..n_layers-1}.*``
+* with ``norm_fn='bn'``: ``...encoder.{1,4,7,10}`` / ``...mlp.1`` get
+  ``weight,bias,running_mean,running_var,num_batches_tracked``.
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+DEFAULT_CONFIG = {
+    # mirrors nets/gm.py:30-44 (values only; the reference file is not imported here)
+    'descriptor_dim': 256,
+    'weights': 'indoor',
+    'keypoint_encoder': [32, 64, 128, 256],
+    'GNN_layers': ['self', 'cross'] * 9,
+    'sinkhorn_iterations': 20,
+    'match_threshold': 0.2,
+    'with_pose': False,
+    'n_layers': 9,
+    'n_min_tokens': 256,
+    'with_sinkhorn': True,
+    'ac_fn': 'relu',
+    'norm_fn': 'bn',
+}
+
+
+def sharing_pattern(n_gnn_layers: int, model: str):
+    """Which GNN layers re-use the previous iteration's attention (nets/gms.py:17, nets/adgm.py:18)."""
+    if model == 'GM':
+        return [False] * n_gnn_layers
+    pat = [False, False] * 2 + [False, False, True, True] * 21
+    return pat[:n_gnn_layers]
+
+
+def _rng_for(seed: int, key: str) -> np.random.Generator:
+    # independent stream per tensor name: order of generation never matters
+    return np.random.Generator(np.random.PCG64([seed, zlib.crc32(key.encode())]))
+
+
+def _conv(sd, seed, prefix, cout, cin, zero_bias=False, gain=1.0):
+    bound = gain / np.sqrt(cin)
+    w = _rng_for(seed, prefix + '.weight').uniform(-bound, bound, size=(cout, cin, 1))
+    b = _rng_for(seed, prefix + '.bias').uniform(-bound, bound, size=(cout,))
+    if zero_bias:
+        b[:] = 0.0
+    sd[prefix + '.weight'] = w.astype(np.float32)
+    sd[prefix + '.bias'] = b.astype(np.float32)
+
+
+def _bn(sd, seed, prefix, c):
+    sd[prefix + '.weight'] = _rng_for(seed, prefix + '.weight').uniform(0.5, 1.5, size=(c,)).astype(np.float32)
+    sd[prefix + '.bias'] = _rng_for(seed, prefix + '.bias').uniform(-0.2, 0.2, size=(c,)).astype(np.float32)
+    sd[prefix + '.running_mean'] = _rng_for(seed, prefix + '.rm').uniform(-0.3, 0.3, size=(c,)).astype(np.float32)
+    sd[prefix + '.running_var'] = _rng_for(seed, prefix + '.rv').uniform(0.5, 1.5, size=(c,)).astype(np.float32)
+    sd[prefix + '.num_batches_tracked'] = np.array(0, dtype=np.int64)
+
+
+def make_state_dict(config: dict, model: str = 'GM', seed: int = 0, bin_score: float = 1.0,
+                    gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+    """numpy state_dict with the reference key schema; uniform(+-gain/sqrt(fan_in)) like torch's default
+    Conv1d init, last kenc / MLP biases zero as in nets/layers.py:86,145,191,198."""
+    cfg = {**DEFAULT_CONFIG, **config}
+    D = cfg['descriptor_dim']
+    names = cfg['GNN_layers']
+    norm = cfg['norm_fn']
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    sd['bin_score'] = np.array(bin_score, dtype=np.float32)
+    chans = [3] + list(cfg['keypoint_encoder']) + [D]
+    for i in range(1, len(chans)):
+        last = i == len(chans) - 1
+        _conv(sd, seed, f'kenc.encoder.{3 * (i - 1)}', chans[i], chans[i - 1], zero_bias=last, gain=gain)
+        if not last and norm == 'bn':
+            _bn(sd, seed, f'kenc.encoder.{3 * (i - 1) + 1}', chans[i])
+    shared = sharing_pattern(len(names), model)
+    for li in range(len(names)):
+        p = f'gnn.layers.{li}'
+        if shared[li]:
+            _conv(sd, seed, p + '.proj', D, D, gain=gain)
+            _conv(sd, seed, p + '.merge', D, D, gain=gain)
+        else:
+            _conv(sd, seed, p + '.attn.merge', D, D, gain=gain)
+            for j in range(3):
+                _conv(sd, seed, p + f'.attn.proj.{j}', D, D, gain=gain)
+        _conv(sd, seed, p + '.mlp.0', 2 * D, 2 * D, gain=gain)
+        if norm == 'bn':
+            _bn(sd, seed, p + '.mlp.1', 2 * D)
+        _conv(sd, seed, p + '.mlp.3', D, 2 * D, zero_bias=True, gain=gain)
+    for i in range(cfg['n_layers']):
+        _conv(sd, seed, f'final_proj.{i}', D, D, gain=gain)
+    return sd
+
+
+def make_pair(n0: int, n1: int, desc_dim: int = 256, seed: int = 0, batch: int = 1,
+              width: int = 640, height: int = 480):
+    """SuperPoint-like synthetic inputs: kpts ~ U(image), scores ~ U(0,1),
+    descriptors = L2-normalised N(0,1).  Returns a dict of float32 numpy arrays with the
+    reference's ``data`` keys (nets/gm.py:147-149) plus ``image_shape`` = (B,3,H,W)."""
+    out = {}
+    for side, n in ((0, n0), (1, n1)):
+        g = _rng_for(seed, f'pair.side{side}')
+        kp = g.uniform(0.0, 1.0, size=(batch, n, 2)) * np.array([width, height], dtype=np.float64)
+        sc = g.uniform(0.0, 1.0, size=(batch, n))
+        de = g.standard_normal(size=(batch, n, desc_dim))
+        de /= np.maximum(np.linalg.norm(de, axis=-1, keepdims=True), 1e-12)
+        out[f'keypoints{side}'] = kp.astype(np.float32)
+        out[f'scores{side}'] = sc.astype(np.float32)
+        out[f'descriptors{side}'] = de.astype(np.float32)
+    out['image_shape'] = (batch, 3, height, width)
+    return out
+
+
+def make_correlated_pair(n0: int, n1: int, desc_dim: int = 256, seed: int = 0, batch: int = 1,
+                         overlap: float = 0.6, noise: float = 0.25, width: int = 640, height: int = 480):
+    """Like make_pair but image 1 re-observes a fraction of image 0's keypoints (shifted position,
+    perturbed descriptor) so that a matcher with random weights still sees structure: used to get
+    non-trivial match sets / pooling behaviour in tests."""
+    out = make_pair(n0, n1, desc_dim, seed, batch, width, height)
+    g = _rng_for(seed, 'pair.corr')
+    k = int(min(n0, n1) * overlap)
+    for b in range(batch):
+        src = g.permutation(n0)[:k]
+        dst = g.permutation(n1)[:k]
+        d = out['descriptors0'][b, src] + noise * g.standard_normal(size=(k, desc_dim)).astype(np.float32) / np.sqrt(desc_dim)
+        d /= np.maximum(np.linalg.norm(d, axis=-1, keepdims=True), 1e-12)
+        out['descriptors1'][b, dst] = d.astype(np.float32)
+        sh = out['keypoints0'][b, src] + g.normal(0, 2.0, size=(k, 2)).astype(np.float32) + np.array([12.0, -7.0], dtype=np.float32)
+        sh[:, 0] = np.clip(sh[:, 0], 0, width - 1)
+        sh[:, 1] = np.clip(sh[:, 1], 0, height - 1)
+        out['keypoints1'][b, dst] = sh
+        out['scores1'][b, dst] = np.clip(out['scores0'][b, src] + 0.05 * g.standard_normal(size=k), 0.01, 0.99).astype(np.float32)
+    return out

@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the *imported reference* (/root/reference) on CPU.
+
+Runs only in the build container (the reference does not exist on the GPU box and nothing at
+test/bench time reads it).  Inputs and weights are regenerated from seeds by
+``imp_release_amd.synthetic`` so a fixture holds only: the case spec (JSON) and the reference's
+outputs.  The script also checks ``oracle/imp_oracle.py`` against the reference on every case and
+prints the max deviations (the oracle's parity pin).
+
+Harness-side shims (no reference file is modified or copied):
+  * ``torch.ones(device='cuda')`` -> cpu        (nets/layers.py:41-44 hard-codes 'cuda')
+  * ``cv2`` stub module + ``estimate_pose -> None`` for eval/matching.py (cv2 is not installed;
+    with no pose the iterative loops never exit early, so all 15 iterations are exercised)
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = '/root/reference'
+sys.path.insert(0, REF)
+
+_ones = torch.ones
+
+
+def _ones_cpu(*a, **k):
+    if str(k.get('device', '')) == 'cuda':
+        k['device'] = 'cpu'
+    return _ones(*a, **k)
+
+
+torch.ones = _ones_cpu
+cv2 = types.ModuleType('cv2')
+cv2.USAC_MAGSAC = 38
+cv2.RANSAC = 8
+sys.modules['cv2'] = cv2
+
+from nets.gm import GM            # noqa: E402  (reference)
+from nets.gms import DGNNS        # noqa: E402
+from nets.adgm import AdaGMN      # noqa: E402
+import eval.matching as ref_matching  # noqa: E402
+
+ref_matching.estimate_pose = lambda **k: None
+
+from imp_release_amd import synthetic  # noqa: E402
+from oracle import imp_oracle as orc   # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+REF_CLS = {'GM': GM, 'DGNNS': DGNNS, 'AdaGMN': AdaGMN}
+
+
+def eval_config(**over):
+    cfg = {'descriptor_dim': 256, 'sinkhorn_iterations': 20, 'match_threshold': 0.2, 'with_sinkhorn': True,
+           'n_layers': 15, 'GNN_layers': ['self', 'cross'] * 15, 'ac_fn': 'relu', 'norm_fn': 'in',
+           'n_min_tokens': 256}                       # eval/eval_imp.py:259-270
+    cfg.update(over)
+    if 'n_layers' in over and 'GNN_layers' not in over:
+        cfg['GNN_layers'] = ['self', 'cross'] * over['n_layers']
+    return cfg
+
+
+def build(spec):
+    cfg = eval_config(**spec['config'])
+    sd_np = synthetic.make_state_dict(cfg, model=spec['model'], seed=spec['wseed'],
+                                      bin_score=spec.get('bin_score', 1.0), gain=spec.get('gain', 1.0))
+    ref = REF_CLS[spec['model']](cfg).eval()
+    ref.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=True)
+    oracle = orc.MatcherOracle(cfg, sd_np, model=spec['model'])
+    mk = synthetic.make_correlated_pair if spec.get('correlated', True) else synthetic.make_pair
+    pair = mk(spec['n0'], spec['n1'], desc_dim=cfg['descriptor_dim'], seed=spec['dseed'], batch=spec.get('batch', 1))
+    data = {k: torch.from_numpy(v) for k, v in pair.items() if k != 'image_shape'}
+    shp = pair['image_shape']
+    data['image0'] = torch.zeros(shp)
+    data['image1'] = torch.zeros(shp)
+    return cfg, ref, oracle, data
+
+
+def maxdiff(a, b):
+    return float((a.double() - b.double()).abs().max()) if a.numel() else 0.0
+
+
+def save(name, spec, arrays, report):
+    arrays = {k: np.asarray(v) for k, v in arrays.items()}
+    arrays['spec_json'] = np.frombuffer(json.dumps(spec).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(GOLD, name + '.npz'), **arrays)
+    sz = os.path.getsize(os.path.join(GOLD, name + '.npz'))
+    print(f'[golden] {name:28s} {sz / 1024:7.1f} KiB  {report}')
+
+
+def score_probes(score):
+    s = score[0] if score.dim() == 3 else score
+    return {'score_rowsum': s.sum(-1).numpy(), 'score_colsum': s.sum(-2).numpy(),
+            'score_corner': s[:8, :8].numpy(), 'score_last_row': s[-1, :16].numpy()}
+
+
+def case_produce(name, spec):
+    cfg, ref, oracle, data = build(spec)
+    kw = dict(spec.get('call', {}))
+    with torch.no_grad():
+        r = ref.produce_matches(data, **kw)
+        o = oracle.produce_matches(data, **{k: v for k, v in kw.items()})
+    arrays = {}
+    n_it = len(r['indices0'])
+    rep = []
+    for i in range(n_it):
+        arrays[f'indices0_{i}'] = r['indices0'][i].numpy()
+        arrays[f'mscores0_{i}'] = r['mscores0'][i].numpy()
+        same = bool((r['indices0'][i] == o['indices0'][i]).all())
+        rep.append((same, maxdiff(r['mscores0'][i], o['mscores0'][i])))
+    if 'scores' in r:
+        sc = r['scores'][-1]
+        arrays.update(score_probes(sc))
+        rep.append(('score', maxdiff(sc, o['scores'][-1])))
+    arrays['n_emitted'] = np.array(n_it)
+    nm = int((r['indices0'][-1] >= 0).sum())
+    ok = all(x[0] is True for x in rep if isinstance(x[0], bool))
+    save(name, spec, arrays, f'emitted={n_it} matches_last={nm} oracle_idx_equal={ok} '
+                             f'max|dms|={max(x[1] for x in rep):.2e}')
+    assert ok, f'oracle index mismatch in {name}'
+
+
+def case_run(name, spec):
+    cfg, ref, oracle, data = build(spec)
+    nk0 = orc.normalize_keypoints(data['keypoints0'], data['image0'].shape)
+    nk1 = orc.normalize_keypoints(data['keypoints1'], data['image1'].shape)
+    rd = {'desc1': data['descriptors0'], 'desc2': data['descriptors1'],
+          'x1': torch.cat([nk0, data['scores0'][..., None]], -1), 'x2': torch.cat([nk1, data['scores1'][..., None]], -1)}
+    with torch.no_grad():
+        r = ref(rd, mode=1)
+        o = oracle.run(rd)
+    arrays = {}
+    if 'p' in r:
+        arrays.update(score_probes(r['p']))
+        rep = f"max|dp|={maxdiff(r['p'], o['p']):.2e}"
+    else:
+        arrays['index0'] = r['index0'].numpy()
+        arrays['index1'] = r['index1'].numpy()
+        ok = bool(torch.equal(r['index0'], o['index0']) and torch.equal(r['index1'], o['index1']))
+        rep = f"n={r['index0'].numel()} oracle_equal={ok}"
+        assert ok
+    save(name, spec, arrays, rep)
+
+
+def case_loop(name, spec, uncertainty):
+    """eval/matching.py loops with the pose step stubbed out (estimate_pose -> None)."""
+    cfg, ref, oracle, data = build(spec)
+    d = dict(data)
+    d['pts0_cpu'] = data['keypoints0'][0].numpy()
+    d['pts1_cpu'] = data['keypoints1'][0].numpy()
+    d['K0'] = d['K1'] = np.eye(3)
+    d['T_0to1'] = np.eye(4)
+    # record the reference's per-valid-iteration matches by wrapping compute_matches
+    trace = []
+    orig_cm = ref.compute_matches
+
+    def rec_cm(scores, p=0.2):
+        out = orig_cm(scores=scores, p=p)
+        trace.append((scores.shape[1] - 1, scores.shape[2] - 1, out[0][0].clone(), out[2][0].clone()))
+        return out
+
+    ref.compute_matches = rec_cm
+    with torch.no_grad():
+        if uncertainty:
+            ret = ref_matching.matching_iterative_uncertainty(d, ref, 15, 0.1, 25, 1.0, {'pose': 1.5}, method=38,
+                                                              with_uncertainty=False)
+            p0, p1, _, _, i0, m0, R, t, nit = ret
+        else:
+            i0, m0, R, t, nit = ref_matching.matching_iterative(d, ref, 15, 0.1, 25, 1.0, {'pose': 1.5}, method=38)
+            p0, p1 = d['pts0_cpu'], d['pts1_cpu']
+        otrace = []
+        o = orc.matching_iterative(data, oracle, nI=15, match_ratio=0.1, min_kpts=25, estimate_pose=None,
+                                   uncertainty=uncertainty, trace=otrace)
+    arrays = {'indices0': i0, 'mscores0': m0, 'n_iter': np.array(nit),
+              'pts0_final': p0, 'pts1_final': p1}
+    traj = []
+    ok = True
+    for k, (n0, n1, ti, tm) in enumerate(trace[:-1]):        # last entry = final p=0.2 call
+        arrays[f'it{k}_indices0'] = ti.numpy()
+        arrays[f'it{k}_mscores0'] = tm.numpy()
+        traj.append((n0, n1))
+        ok &= bool(torch.equal(ti, otrace[k]['indices0']))
+    arrays['trajectory'] = np.array(traj)
+    ok &= bool(np.array_equal(i0, o['indices0'].numpy()))
+    kp0 = data['keypoints0'][0].numpy()[o['keep0'].numpy()]
+    ok &= bool(np.array_equal(kp0, p0))
+    save(name, spec, arrays, f'n_iter={nit} traj={traj} matches={int((i0 >= 0).sum())} oracle_equal={ok} '
+                             f'max|dms|={np.abs(m0 - o["mscores0"].numpy()).max():.2e}')
+    assert ok, name
+
+
+def case_pool_edges(name):
+    """AdaGMN.pool on hand-built inputs: small side (<= n_min_tokens), empty pids, even-count median."""
+    cfg = eval_config(n_layers=1)
+    ref = AdaGMN(cfg).eval()
+    g = torch.Generator().manual_seed(7)
+    arrays, spec = {}, {'kind': 'pool_edges', 'seed': 7}
+    subcases = [('small0', 200, 300, 0.2, 256), ('both', 300, 310, 0.2, 256), ('empty', 300, 310, 50.0, 256),
+                ('even', 301, 299, 0.05, 0), ('nmin0', 40, 50, 0.2, 0)]
+    ok = True
+    for tag, n0, n1, th, nmin in subcases:
+        score = torch.rand(1, n0 + 1, n1 + 1, generator=g) * (2.0 / max(n0, n1))
+        # a few confident rows/cols
+        idx = torch.randperm(min(n0, n1), generator=g)[:n0 // 3]
+        score[0, idx, idx] += 0.5
+        p00 = torch.softmax(torch.randn(1, 4, n0, n0, generator=g) * 2, -1)
+        p01 = torch.softmax(torch.randn(1, 4, n1, n0, generator=g) * 2, -1)
+        p11 = torch.softmax(torch.randn(1, 4, n1, n1, generator=g) * 2, -1)
+        p10 = torch.softmax(torch.randn(1, 4, n0, n1, generator=g) * 2, -1)
+        r0, r1 = ref.pool(score, p00, p01, p11, p10, mscore_th=th, uncertainty_ratio=1.0, n_min_tokens=nmin)
+        o0, o1 = orc.pool(score, p00, p01, p11, p10, mscore_th=th, uncertainty_ratio=1.0, n_min_tokens=nmin)
+        for side, r, o in ((0, r0, o0), (1, r1, o1)):
+            arrays[f'{tag}_ids{side}'] = np.array([-1]) if r is None else r.numpy()
+            ok &= (r is None and o is None) or (r is not None and o is not None and torch.equal(r, o))
+        arrays[f'{tag}_dims'] = np.array([n0, n1, nmin])
+        arrays[f'{tag}_th'] = np.array(th)
+    save(name, spec, arrays, f'oracle_equal={ok}')
+    assert ok
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    # (1) GM one-shot, BASELINE config shape (L=9, T=100, only_last) at small N + ragged pair
+    case_produce('gm_l9_t100_n256', dict(model='GM', config=dict(n_layers=9, sinkhorn_iterations=100),
+                                         wseed=1, dseed=11, n0=256, n1=256, call=dict(p=0.2, only_last=True)))
+    case_produce('gm_l9_t100_ragged', dict(model='GM', config=dict(n_layers=9, sinkhorn_iterations=100),
+                                           wseed=1, dseed=12, n0=300, n1=307, call=dict(p=0.2, only_last=True)))
+    # all iterations emitted, batch 2, uncorrelated inputs
+    case_produce('gm_l3_alliters_b2', dict(model='GM', config=dict(n_layers=3), wseed=2, dseed=13, n0=130, n1=97,
+                                           batch=2, correlated=False, call=dict(p=0.2, only_last=False)))
+    # GM default norm_fn='bn' (nets/gm.py:43) + leaky relu
+    case_produce('gm_l2_bn_lrelu', dict(model='GM', config=dict(n_layers=2, norm_fn='bn', ac_fn='lrelu'), wseed=3,
+                                        dseed=14, n0=160, n1=150, call=dict(p=0.2, only_last=True)))
+    case_produce('gm_l2_gelu', dict(model='GM', config=dict(n_layers=2, ac_fn='gelu'), wseed=3,
+                                    dseed=15, n0=64, n1=70, call=dict(p=0.2, only_last=True)))
+    # (2) DGNNS = IMP, eval config (L=15, T=20), config-1 analogue
+    case_produce('dgnns_l15_t20_n512', dict(model='DGNNS', config=dict(), wseed=4, dseed=16, n0=512, n1=519,
+                                            call=dict(p=0.2, only_last=True)))
+    case_produce('dgnns_l5_alliters', dict(model='DGNNS', config=dict(n_layers=5), wseed=4, dseed=17, n0=200, n1=180,
+                                           call=dict(p=0.2, only_last=False)))
+    # (3) D=128 (SIFT) variant: eval/eval_imp.py:260
+    case_produce('gm_l3_d128', dict(model='GM', config=dict(n_layers=3, descriptor_dim=128), wseed=5, dseed=18,
+                                    n0=140, n1=150, call=dict(p=0.2, only_last=True)))
+    # (4) dual softmax scorer
+    case_produce('dgnns_l4_dualsoftmax', dict(model='DGNNS', config=dict(n_layers=4, with_sinkhorn=False), wseed=6,
+                                              dseed=19, n0=220, n1=210, call=dict(p=0.2, only_last=True)))
+    # (5) AdaGMN masked produce_matches (bin_score 5 so that pooling prunes)
+    case_produce('adagmn_masked_l9', dict(model='AdaGMN', config=dict(n_layers=9), wseed=7, dseed=20, n0=420, n1=400,
+                                          bin_score=5.0, call=dict(p=0.2)))
+    # run() API (mode=1)
+    case_run('gm_run_l2', dict(model='GM', config=dict(n_layers=2), wseed=8, dseed=21, n0=90, n1=80))
+    # NOTE DGNNS.run raises KeyError('keypoints0') in the reference itself (nets/gms.py:293 -> :142), so the
+    # index0/index1 flavour of run() is pinned with AdaGMN (nets/adgm.py:607-635).
+    case_run('adagmn_run_l5', dict(model='AdaGMN', config=dict(n_layers=5), wseed=8, dseed=22, n0=150, n1=140))
+    # (6) iterative loops, pose stubbed
+    case_loop('imp_loop_n400', dict(model='DGNNS', config=dict(), wseed=9, dseed=23, n0=400, n1=380), False)
+    case_loop('eimp_loop_sliced_n1024', dict(model='AdaGMN', config=dict(), wseed=9, dseed=24, n0=1024, n1=1000,
+                                             bin_score=5.0), True)
+    # (7) pool edge cases
+    case_pool_edges('pool_edges')
+
+
+if __name__ == '__main__':
+    main()
