@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Benchmark of the IMP matching hot path on MI355X (contract: one JSON line on rank 0).
+
+Workload (BASELINE.json metric / configs[2], SURVEY.md §8d "C3"): GM one-shot matcher, 9 self+cross
+iterations, 100 Sinkhorn iterations, only_last, N = M = 2048 synthetic SuperPoint-like keypoints per
+image, 4 pairs per GPU (batch 32 over 8 GPUs); weak scaling: every rank processes its own 4 pairs per
+step, no data-path collective, one RCCL all-gather of the per-pair results at the end of the step.
+A "step" = produce_matches over the rank's batch with inputs already resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--kpts 2048] [--pairs-per-gpu 4]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Extra objects on the JSON line:
+  roofline      dominant kernel = attn_f32_kernel (60 % of the pair's FLOPs): algorithmic FLOPs per launch
+                (4*N*M*D per image side) / average launch duration measured with HIP events on
+                the launch stream; peak = fp32-input MFMA 157.3 TFLOP/s (MI355X_MICROARCH.md)
+  cpu_baseline  the oracle (torch-CPU fp32 restatement of the reference, validated against it) timed on this
+                host's cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def eval_config(n_layers, sinkhorn_iterations):
+    return {'descriptor_dim': 256, 'sinkhorn_iterations': sinkhorn_iterations, 'match_threshold': 0.2,
+            'with_sinkhorn': True, 'n_layers': n_layers, 'GNN_layers': ['self', 'cross'] * n_layers,
+            'ac_fn': 'relu', 'norm_fn': 'in', 'n_min_tokens': 256}
+
+
+def cpu_baseline(cfg, sd, kpts, budget_s=18.0):
+    """oracle/ is test infrastructure: used here ONLY as the timed CPU baseline, never on the product path."""
+    from imp_release_amd import synthetic
+    from oracle import imp_oracle as orc
+    threads = torch.get_num_threads()
+    o = orc.MatcherOracle(cfg, sd, 'GM')
+    pair = synthetic.make_correlated_pair(kpts, kpts, seed=1000)
+    data = {k: torch.from_numpy(v) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        o.produce_matches(data, p=0.2, only_last=True)          # warm-up pair (also bounds the sample)
+        first = time.perf_counter() - t0
+        n, t0 = 0, time.perf_counter()
+        while True:
+            o.produce_matches(data, p=0.2, only_last=True)
+            n += 1
+            el = time.perf_counter() - t0
+            if el + first > budget_s or n >= 16:
+                break
+    return {'value': n / el, 'unit': 'image-pairs/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{n} pair(s) after 1 warm-up, N={kpts}, L={cfg["n_layers"]}, T={cfg["sinkhorn_iterations"]}, '
+                      f'oracle/imp_oracle.py under torch {torch.__version__} CPU fp32, {threads} threads'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--kpts', type=int, default=2048)
+    ap.add_argument('--pairs-per-gpu', type=int, default=4)
+    ap.add_argument('--iters', type=int, default=9)
+    ap.add_argument('--sinkhorn', type=int, default=100)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}')
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the matching hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    import imp_release_amd as P
+    from imp_release_amd import dist as pdist, synthetic
+
+    cfg = eval_config(args.iters, args.sinkhorn)
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=0)
+    model = P.GM(cfg).eval()
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    model = model.to(dev)
+
+    B, N = args.pairs_per_gpu, args.kpts
+    n_total = B * world
+    s, e = pdist.shard_range(n_total, rank, world)           # this rank's pairs (seed = base + pair id)
+    pairs = [synthetic.make_correlated_pair(N, N, seed=100 + pid) for pid in range(s, e)]
+    data = {k: torch.from_numpy(np.concatenate([p[k] for p in pairs], 0)).to(dev)
+            for k in pairs[0] if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pairs[0]['image_shape'], device=dev)
+
+    def step():
+        with torch.no_grad():
+            out = model.produce_matches(data, p=0.2, only_last=True)
+            return pdist.all_gather_matches(out['indices0'][-1], out['mscores0'][-1], n_total)
+
+    for _ in range(args.warmup):
+        res = step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    assert res[0].shape[0] == n_total
+    n_matched = int((res[0] >= 0).sum())
+
+    # roofline leg of the dominant kernel, measured live with HIP events on the launch stream
+    ctx = model._ensure_ctx()
+    attn_ms = ctx.time_attention(B, N, 10)
+    attn_flops = 4.0 * N * N * 256 * 2 * B            # 4*N*M*D per image side (QK^T + PV), 2 sides, B pairs
+    achieved = attn_flops / (attn_ms * 1e-3) / 1e12
+    sk_ms = ctx.time_sinkhorn(B, N, 20)
+    sk_bytes = B * (N + 1) * ((N + 1 + 3) // 4 * 4) * 4.0
+    layer_sides = 4 * args.iters
+    pair_flops = (4 * args.iters * (20 * 256 ** 2 * N + 4 * N * N * 256) + 2 * 2 * N * 108640 + 4 * 256 ** 2 * N
+                  + 2 * N * N * 256 + args.sinkhorn * 4 * (N + 1) ** 2)
+
+    if rank == 0:
+        line = {
+            'metric': 'image-pairs/s (N=2048 kpts, 9 self+cross iters, 100 Sinkhorn)',
+            'value': n_total * args.steps / elapsed, 'unit': 'image-pairs/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'GM one-shot matcher (nets/gm.py produce_matches only_last): N=M={N} keypoints, '
+                                   f'{args.iters} self+cross iterations, {args.sinkhorn} Sinkhorn iterations, '
+                                   f'{B} pairs per GPU (BASELINE configs[2]: batch 32 over 8 GPUs), norm_fn=in, '
+                                   f'seeded random weights',
+                       'pairs_per_gpu': B, 'keypoints': N, 'parallelism': f'pair-sharded x{world}',
+                       'matched_keypoints': n_matched},
+            'roofline': {'bound': 'mfma', 'kernel': 'attn_f32_kernel<64,4>', 'achieved': achieved,
+                         'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
+                         'traffic': None, 'launch_ms': attn_ms, 'flops_per_launch': attn_flops,
+                         'launches_per_step': layer_sides // 2,
+                         'whole_path_tflops': pair_flops * n_total * args.steps / elapsed / 1e12 / world,
+                         'sinkhorn_rowpass': {'bound': 'hbm', 'launch_ms': sk_ms, 'bytes_per_launch': sk_bytes,
+                                              'achieved_GBs': sk_bytes / (sk_ms * 1e-3) / 1e9, 'peak_GBs': PEAK_HBM_GBS}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(cfg, sd, N)
+        else:
+            line['cpu_baseline'] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

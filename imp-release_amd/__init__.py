@@ -8,3 +8,19 @@ every compute entry point raises if the HIP library is missing.
 Import as ``imp_release_amd`` (alias package next to this directory).
 """
 __version__ = '0.1.0'
+
+from . import synthetic  # noqa: F401,E402  (numpy only)
+
+
+def __getattr__(name):
+    # torch-dependent modules are imported lazily so that `synthetic` stays usable without them
+    if name in ('GM', 'DGNNS', 'AdaGMN', 'AttentionHandle'):
+        from . import modules
+        return getattr(modules, name)
+    if name in ('matching_iterative', 'matching_iterative_uncertainty'):
+        from . import matching
+        return getattr(matching, name)
+    if name in ('modules', 'matching', 'dist', '_lib'):
+        import importlib
+        return importlib.import_module('.' + name, __name__)
+    raise AttributeError(name)

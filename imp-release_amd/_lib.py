@@ -1,0 +1,341 @@
+"""ctypes binding of ``csrc/libimp_hip.so`` (C-ABI declared in ``include/imp_hip.h``).
+
+PyTorch is used only as plumbing here: device memory (``tensor.data_ptr()``) and the current HIP
+stream.  There is NO fallback: if the shared library is missing every compute entry point raises
+``HipLibraryMissing`` (the product path never routes through ``oracle/`` or torch ops).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libimp_hip.so')
+
+MODEL_IDS = {'GM': 0, 'DGNNS': 1, 'AdaGMN': 2}
+NORM_IDS = {'in': 0, 'bn': 1}
+ACT_IDS = {'relu': 0, 'gelu': 1, 'lrelu': 2}
+
+# every symbol include/imp_hip.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    'imp_last_error', 'imp_version', 'imp_create', 'imp_destroy', 'imp_load_tensor', 'imp_finalize_weights',
+    'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
+    'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
+    'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear',
+    'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn',
+]
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class ImpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f'libimp_hip error {code}: {msg}')
+        self.code = code
+
+
+class ImpConfig(C.Structure):
+    _fields_ = [('model', C.c_int32), ('descriptor_dim', C.c_int32), ('n_gnn_layers', C.c_int32),
+                ('n_layers', C.c_int32), ('kenc_channels', C.c_int32 * 8), ('norm_fn', C.c_int32),
+                ('ac_fn', C.c_int32), ('max_batch', C.c_int32), ('max_keypoints', C.c_int32),
+                ('layer_is_cross', C.c_int32 * 128)]
+
+
+_lib = None
+
+
+def build_library(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 build of the library (cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.run(['make', '-C', os.path.join(_HERE, 'csrc'), '-j8'] + (['-B'] if force else []), check=True)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'(or `make -C imp-release_amd/csrc`).  There is no CPU fallback for the matching hot path.')
+    L = C.CDLL(LIB_PATH)
+    L.imp_last_error.restype = C.c_char_p
+    L.imp_version.restype = C.c_char_p
+    L.imp_key_name.restype = C.c_char_p
+    L.imp_key_name.argtypes = [C.c_void_p, C.c_int]
+    L.imp_num_keys.argtypes = [C.c_void_p]
+    L.imp_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(ImpConfig), C.c_int]
+    L.imp_destroy.argtypes = [C.c_void_p]
+    L.imp_load_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]
+    L.imp_finalize_weights.argtypes = [C.c_void_p]
+    P, I, F = C.c_void_p, C.c_int, C.c_float
+    L.imp_normalize_keypoints.argtypes = [P, P, I, I, F, F, P, P]
+    L.imp_encode_keypoints.argtypes = [P, I, I, I, P, P, P, P, P, P, P, P, P]
+    L.imp_forward_layer.argtypes = [P, I, I, I, I, P, P, P, P, P, P, P]
+    L.imp_attention_prob.argtypes = [P, I, P, P]
+    L.imp_attention_received.argtypes = [P, I, P, P]
+    L.imp_compute_distance.argtypes = [P, I, I, I, I, P, P, P, P]
+    L.imp_compute_score.argtypes = [P, I, I, I, P, F, I, I, P, P]
+    L.imp_compute_matches.argtypes = [P, I, I, I, P, F, P, P, P, P, P]
+    L.imp_pool.argtypes = [P, I, I, P, F, F, I, P, P, P, P]
+    L.imp_score_mass.argtypes = [P, I, I, P, P, P, P]
+    L.imp_pool_select.argtypes = [P, I, P, P, P, F, P, P, P]
+    L.imp_gather_rows.argtypes = [P, I, I, I, I, P, P, P, P]
+    L.imp_match_pair.argtypes = [P, I, I, I, P, P, P, P, P, P, F, F, F, I, I, F, P, P, P, P, P, P]
+    L.imp_op_linear.argtypes = [P, I, I, I, P, P, P, P, P]
+    L.imp_op_attention.argtypes = [P, I, I, I, I, P, P, P, P, P, P]
+    L.imp_time_attention.argtypes = [P, I, I, I, C.POINTER(C.c_float), P]
+    L.imp_time_sinkhorn.argtypes = [P, I, I, I, C.POINTER(C.c_float), P]
+    _lib = L
+    return L
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise ValueError(f'{name} must live on the GPU (got {t.device}); libimp_hip has no CPU path')
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class Context:
+    """Owns one ``imp_ctx`` (packed weights + workspace) on one device."""
+
+    def __init__(self, config: dict, model: str, device: torch.device, max_batch: int = 0, max_keypoints: int = 0):
+        self.L = lib()
+        cfg = ImpConfig()
+        cfg.model = MODEL_IDS[model]
+        cfg.descriptor_dim = int(config['descriptor_dim'])
+        names = list(config['GNN_layers'])
+        cfg.n_gnn_layers = len(names)
+        cfg.n_layers = int(config['n_layers'])
+        kc = list(config['keypoint_encoder'])
+        if len(kc) > 7:
+            raise ValueError('keypoint_encoder: at most 7 hidden layers')
+        for i, v in enumerate(kc):
+            cfg.kenc_channels[i] = int(v)
+        if config['norm_fn'] not in NORM_IDS or config['ac_fn'] not in ACT_IDS:
+            raise ValueError("norm_fn must be 'in'|'bn' and ac_fn 'relu'|'gelu'|'lrelu'")
+        cfg.norm_fn = NORM_IDS[config['norm_fn']]
+        cfg.ac_fn = ACT_IDS[config['ac_fn']]
+        cfg.max_batch = max_batch
+        cfg.max_keypoints = max_keypoints
+        for i, nm in enumerate(names):
+            if nm not in ('self', 'cross'):
+                raise ValueError(f'unknown GNN layer name {nm!r}')
+            cfg.layer_is_cross[i] = 1 if nm == 'cross' else 0
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise ValueError('imp_release_amd needs a GPU device; there is no CPU path')
+        self.handle = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self._check(self.L.imp_create(C.byref(self.handle), C.byref(cfg), idx))
+        self.D = cfg.descriptor_dim
+
+    def _check(self, rc):
+        if rc != 0:
+            raise ImpError(rc, self.L.imp_last_error().decode())
+
+    def close(self):
+        if getattr(self, 'handle', None) and self.handle.value:
+            self.L.imp_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights ------------------------------------------------------------------------------
+    def keys(self):
+        return [self.L.imp_key_name(self.handle, i).decode() for i in range(self.L.imp_num_keys(self.handle))]
+
+    def load_state_dict(self, sd):
+        want = set(self.keys())
+        for k, v in sd.items():
+            if k not in want:
+                if k.endswith('num_batches_tracked'):
+                    continue
+                raise KeyError(f'unexpected state_dict key {k}')
+            t = torch.as_tensor(v).detach().to('cpu', torch.float32).contiguous()
+            shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+            self._check(self.L.imp_load_tensor(self.handle, k.encode(), C.c_void_p(t.data_ptr()), shape, t.dim()))
+        self._check(self.L.imp_finalize_weights(self.handle))
+
+    # -- ops ----------------------------------------------------------------------------------
+    def normalize_keypoints(self, kpts, width, height):
+        kpts = _f32(kpts, 'kpts')
+        out = torch.empty_like(kpts)
+        B, n = kpts.shape[0], kpts.shape[1]
+        self._check(self.L.imp_normalize_keypoints(self.handle, _ptr(kpts), B, n, float(width), float(height),
+                                                   _ptr(out), _stream()))
+        return out
+
+    def encode_keypoints(self, nk0, sc0, nk1, sc1, desc0=None, desc1=None):
+        nk0, sc0, nk1, sc1 = _f32(nk0, 'kpts0'), _f32(sc0, 'scores0'), _f32(nk1, 'kpts1'), _f32(sc1, 'scores1')
+        B, n0, n1 = nk0.shape[0], nk0.shape[1], nk1.shape[1]
+        d0 = None if desc0 is None else _f32(desc0, 'desc0')
+        d1 = None if desc1 is None else _f32(desc1, 'desc1')
+        o0 = torch.empty(B, n0, self.D, device=nk0.device, dtype=torch.float32)
+        o1 = torch.empty(B, n1, self.D, device=nk0.device, dtype=torch.float32)
+        self._check(self.L.imp_encode_keypoints(self.handle, B, n0, n1, _ptr(nk0), _ptr(sc0), _ptr(d0), _ptr(o0),
+                                                _ptr(nk1), _ptr(sc1), _ptr(d1), _ptr(o1), _stream()))
+        return o0, o1
+
+    def forward_layer(self, layer_i, desc0, desc1, mask0=None, mask1=None, inplace=False):
+        desc0, desc1 = _f32(desc0, 'desc0'), _f32(desc1, 'desc1')
+        B, n0, n1 = desc0.shape[0], desc0.shape[1], desc1.shape[1]
+        o0 = desc0 if inplace else torch.empty_like(desc0)
+        o1 = desc1 if inplace else torch.empty_like(desc1)
+        if mask0 is not None:
+            mask0 = mask0.to(torch.uint8).contiguous()
+        if mask1 is not None:
+            mask1 = mask1.to(torch.uint8).contiguous()
+        self._check(self.L.imp_forward_layer(self.handle, layer_i, B, n0, n1, _ptr(desc0), _ptr(desc1), _ptr(o0),
+                                             _ptr(o1), _ptr(mask0), _ptr(mask1), _stream()))
+        return o0, o1
+
+    def attention_prob(self, which, B, nq, nk, device):
+        out = torch.empty(B, 4, nq, nk, device=device, dtype=torch.float32)
+        self._check(self.L.imp_attention_prob(self.handle, which, _ptr(out), _stream()))
+        return out
+
+    def attention_received(self, which, B, nk, device):
+        out = torch.empty(B, nk, device=device, dtype=torch.float32)
+        self._check(self.L.imp_attention_received(self.handle, which, _ptr(out), _stream()))
+        return out
+
+    def compute_distance(self, layer_id, desc0, desc1):
+        desc0, desc1 = _f32(desc0, 'desc0'), _f32(desc1, 'desc1')
+        B, n0, n1 = desc0.shape[0], desc0.shape[1], desc1.shape[1]
+        dist = torch.empty(B, n0, n1, device=desc0.device, dtype=torch.float32)
+        self._check(self.L.imp_compute_distance(self.handle, layer_id, B, n0, n1, _ptr(desc0), _ptr(desc1),
+                                                _ptr(dist), _stream()))
+        return dist
+
+    def compute_score(self, dist, bin_score, iterations, with_sinkhorn=True):
+        dist = _f32(dist, 'dist')
+        B, n0, n1 = dist.shape
+        scores = torch.empty(B, n0 + 1, n1 + 1, device=dist.device, dtype=torch.float32)
+        self._check(self.L.imp_compute_score(self.handle, B, n0, n1, _ptr(dist), float(bin_score), int(iterations),
+                                             1 if with_sinkhorn else 0, _ptr(scores), _stream()))
+        return scores
+
+    def compute_matches(self, scores, p):
+        scores = _f32(scores, 'scores')
+        B, n0, n1 = scores.shape[0], scores.shape[1] - 1, scores.shape[2] - 1
+        dev = scores.device
+        i0 = torch.empty(B, n0, device=dev, dtype=torch.int64)
+        i1 = torch.empty(B, n1, device=dev, dtype=torch.int64)
+        m0 = torch.empty(B, n0, device=dev, dtype=torch.float32)
+        m1 = torch.empty(B, n1, device=dev, dtype=torch.float32)
+        self._check(self.L.imp_compute_matches(self.handle, B, n0, n1, _ptr(scores), float(p), _ptr(i0), _ptr(i1),
+                                               _ptr(m0), _ptr(m1), _stream()))
+        return i0, i1, m0, m1
+
+    def pool(self, scores, mscore_th, uncertainty_ratio, n_min_tokens):
+        """-> (ids0 | None, ids1 | None); ONE host sync to read the two kept counts (shapes change)."""
+        scores = _f32(scores, 'scores')
+        n0, n1 = scores.shape[1] - 1, scores.shape[2] - 1
+        dev = scores.device
+        ids0 = torch.empty(n0, device=dev, dtype=torch.int64)
+        ids1 = torch.empty(n1, device=dev, dtype=torch.int64)
+        counts = torch.empty(4, device=dev, dtype=torch.int32)
+        self._check(self.L.imp_pool(self.handle, n0, n1, _ptr(scores), float(mscore_th), float(uncertainty_ratio),
+                                    int(n_min_tokens), _ptr(ids0), _ptr(ids1), _ptr(counts), _stream()))
+        c = counts.tolist()
+        return (ids0[:c[0]] if c[0] >= 0 else None), (ids1[:c[2]] if c[2] >= 0 else None)
+
+    def score_mass(self, scores):
+        scores = _f32(scores, 'scores')
+        n0, n1 = scores.shape[-2] - 1, scores.shape[-1] - 1
+        m0 = torch.empty(n0, device=scores.device, dtype=torch.float32)
+        m1 = torch.empty(n1, device=scores.device, dtype=torch.float32)
+        self._check(self.L.imp_score_mass(self.handle, n0, n1, _ptr(scores), _ptr(m0), _ptr(m1), _stream()))
+        return m0, m1
+
+    def pool_select(self, mass, a_self, a_cross, thr):
+        mass, a_self, a_cross = _f32(mass, 'mass'), _f32(a_self, 'a_self'), _f32(a_cross, 'a_cross')
+        n = mass.numel()
+        ids = torch.empty(n, device=mass.device, dtype=torch.int64)
+        counts = torch.empty(2, device=mass.device, dtype=torch.int32)
+        self._check(self.L.imp_pool_select(self.handle, n, _ptr(mass), _ptr(a_self), _ptr(a_cross), float(thr),
+                                           _ptr(ids), _ptr(counts), _stream()))
+        c = counts.tolist()
+        return ids[:c[0]] if c[0] >= 0 else None
+
+    def gather_rows(self, x, ids):
+        x = _f32(x, 'x')
+        ids = ids.to(torch.int64).contiguous()
+        B, n_in, dim = x.shape
+        out = torch.empty(B, ids.numel(), dim, device=x.device, dtype=torch.float32)
+        self._check(self.L.imp_gather_rows(self.handle, B, n_in, ids.numel(), dim, _ptr(x), _ptr(ids), _ptr(out),
+                                           _stream()))
+        return out
+
+    def match_pair(self, kpts0, sc0, desc0, kpts1, sc1, desc1, width, height, bin_score, iterations, with_sinkhorn,
+                   p, want_scores=False, want_side1=False, out=None):
+        kpts0, sc0, desc0 = _f32(kpts0, 'kpts0'), _f32(sc0, 'scores0'), _f32(desc0, 'desc0')
+        kpts1, sc1, desc1 = _f32(kpts1, 'kpts1'), _f32(sc1, 'scores1'), _f32(desc1, 'desc1')
+        B, n0, n1 = kpts0.shape[0], kpts0.shape[1], kpts1.shape[1]
+        dev = kpts0.device
+        if out is None:
+            out = {'indices0': torch.empty(B, n0, device=dev, dtype=torch.int64),
+                   'mscores0': torch.empty(B, n0, device=dev, dtype=torch.float32)}
+            if want_side1:
+                out['indices1'] = torch.empty(B, n1, device=dev, dtype=torch.int64)
+                out['mscores1'] = torch.empty(B, n1, device=dev, dtype=torch.float32)
+            if want_scores:
+                out['scores'] = torch.empty(B, n0 + 1, n1 + 1, device=dev, dtype=torch.float32)
+        self._check(self.L.imp_match_pair(
+            self.handle, B, n0, n1, _ptr(kpts0), _ptr(sc0), _ptr(desc0), _ptr(kpts1), _ptr(sc1), _ptr(desc1),
+            float(width), float(height), float(bin_score), int(iterations), 1 if with_sinkhorn else 0, float(p),
+            _ptr(out['indices0']), _ptr(out['mscores0']), _ptr(out.get('indices1')), _ptr(out.get('mscores1')),
+            _ptr(out.get('scores')), _stream()))
+        return out
+
+    def op_linear(self, x, W, bias=None):
+        x, W = _f32(x, 'x'), _f32(W, 'W')
+        M, K = x.shape
+        N = W.shape[0]
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        b = None if bias is None else _f32(bias, 'bias')
+        self._check(self.L.imp_op_linear(self.handle, M, N, K, _ptr(x), _ptr(W), _ptr(b), _ptr(y), _stream()))
+        return y
+
+    def op_attention(self, qkv_q, qkv_kv, key_mask=None, want_lse=True):
+        qkv_q, qkv_kv = _f32(qkv_q, 'qkv_q'), _f32(qkv_kv, 'qkv_kv')
+        B, nq, D3 = qkv_q.shape
+        nk, D = qkv_kv.shape[1], D3 // 3
+        out = torch.empty(B, nq, D, device=qkv_q.device, dtype=torch.float32)
+        lse = torch.empty(B, 4, nq, device=qkv_q.device, dtype=torch.float32) if want_lse else None
+        km = None if key_mask is None else key_mask.to(torch.uint8).contiguous()
+        self._check(self.L.imp_op_attention(self.handle, B, nq, nk, D, _ptr(qkv_q), _ptr(qkv_kv), _ptr(km), _ptr(out),
+                                            _ptr(lse), _stream()))
+        return out, lse
+
+    def time_attention(self, batch, n, reps):
+        ms = C.c_float()
+        self._check(self.L.imp_time_attention(self.handle, batch, n, reps, C.byref(ms), _stream()))
+        return ms.value
+
+    def time_sinkhorn(self, batch, n, iterations):
+        ms = C.c_float()
+        self._check(self.L.imp_time_sinkhorn(self.handle, batch, n, iterations, C.byref(ms), _stream()))
+        return ms.value

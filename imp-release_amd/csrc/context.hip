@@ -1,0 +1,888 @@
+// libimp_hip.so: context, weight packing and kernel orchestration behind the C-ABI of include/imp_hip.h.
+// Host-side C++ only (no torch); every launch goes to the caller's stream and nothing here synchronises
+// the host except imp_create / imp_finalize_weights / imp_reserve (allocation + upload) and imp_time_*.
+#include "../../include/imp_hip.h"
+#include "imp_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(IMP_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));             \
+    } while (0)
+
+struct HostTensor { std::vector<float> data; std::vector<int64_t> shape; };
+struct Linear { float* W = nullptr; float* b = nullptr; int out = 0, in = 0; };
+struct NormC { float* mean = nullptr; float* rstd = nullptr; float* gamma = nullptr; float* beta = nullptr; int c = 0; };
+struct GnnLayer {
+    bool cross = false, shared = false;
+    Linear proj;     // non-shared: packed [3D][D] (q|k|v, head-major rows); shared: value projection [D][D]
+    Linear merge;    // [D][D], input columns head-major
+    Linear mlp0;     // [2D][2D]
+    NormC bn;        // only norm_fn == 'bn'
+    Linear mlp3;     // [D][2D]
+};
+struct AttnCache {   // cached operands of the last non-shared layer of a kind (self / cross)
+    bool valid = false;
+    int batch = 0, n[2] = {0, 0};
+    bool masked[2] = {false, false};   // key mask of image 0 / image 1 in effect when it was computed
+};
+
+}  // namespace
+
+struct imp_ctx {
+    imp_config cfg{};
+    int device = 0, D = 0, dh = 0;
+    std::vector<std::string> schema;
+    std::map<std::string, HostTensor> raw;
+    bool finalized = false;
+    float bin_score = 1.f;
+    std::vector<void*> allocs_w, allocs_ws;
+    // packed weights
+    std::vector<Linear> kenc;
+    std::vector<NormC> kenc_bn;
+    std::vector<GnnLayer> layers;
+    std::vector<Linear> final_proj;
+    // workspace (capacity: cap_b pairs x cap_n keypoints per image)
+    int cap_b = 0, cap_n = 0, kenc_maxc = 0;
+    float *qkv[2][2] = {}, *lse[2][2] = {};         // [kind: 0 self, 1 cross][side]
+    uint8_t* cmask[2][2] = {};                       // [kind][image] cached key masks
+    float *attn_out[2] = {}, *msg[2] = {}, *hid[2] = {}, *stats[2] = {};
+    float *kbuf[2][2] = {};                          // keypoint-encoder ping-pong per side
+    float *descw[2] = {}, *mdesc[2] = {}, *nkp[2] = {};
+    float* dist = nullptr;
+    OtBuffers ot{};
+    float *max0 = nullptr, *max1 = nullptr, *colpart_v = nullptr;
+    int *arg0 = nullptr, *arg1 = nullptr, *colpart_i = nullptr;
+    float *colsum[4] = {}, *amass[4] = {}, *mass[2] = {};
+    AttnCache cache[2];
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(imp_ctx* c, std::vector<void*>& pool, T** out, size_t count) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, count * sizeof(T) + 64);
+    if (e != hipSuccess) return fail(IMP_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    pool.push_back(p);
+    *out = static_cast<T*>(p);
+    return IMP_OK;
+}
+void free_pool(std::vector<void*>& pool) {
+    for (void* p : pool) (void)hipFree(p);
+    pool.clear();
+}
+
+std::string kname(const char* fmt, int a, int b = 0) {
+    char buf[128];
+    snprintf(buf, sizeof buf, fmt, a, b);
+    return buf;
+}
+bool layer_shared(const imp_config& cfg, int li) {
+    if (cfg.model == IMP_MODEL_GM) return false;
+    if (li < 4) return false;                 // [F,F]*2 + [F,F,T,T]*21   nets/gms.py:17, nets/adgm.py:18
+    return ((li - 4) & 3) >= 2;
+}
+int n_kenc(const imp_config& cfg) {
+    int n = 0;
+    while (n < 8 && cfg.kenc_channels[n] > 0) ++n;
+    return n;
+}
+
+void build_schema(imp_ctx* c) {
+    const imp_config& cfg = c->cfg;
+    std::vector<std::string>& s = c->schema;
+    s.clear();
+    s.push_back("bin_score");
+    const int nk = n_kenc(cfg);
+    for (int i = 0; i <= nk; ++i) {
+        s.push_back(kname("kenc.encoder.%d.weight", 3 * i));
+        s.push_back(kname("kenc.encoder.%d.bias", 3 * i));
+        if (i < nk && cfg.norm_fn == IMP_NORM_BN)
+            for (const char* f : {"weight", "bias", "running_mean", "running_var"})
+                s.push_back(kname("kenc.encoder.%d.", 3 * i + 1) + f);
+    }
+    for (int li = 0; li < cfg.n_gnn_layers; ++li) {
+        const std::string p = kname("gnn.layers.%d", li);
+        if (layer_shared(cfg, li)) {
+            for (const char* f : {".proj.weight", ".proj.bias", ".merge.weight", ".merge.bias"}) s.push_back(p + f);
+        } else {
+            for (const char* f : {".attn.merge.weight", ".attn.merge.bias"}) s.push_back(p + f);
+            for (int j = 0; j < 3; ++j) {
+                s.push_back(p + kname(".attn.proj.%d.weight", j));
+                s.push_back(p + kname(".attn.proj.%d.bias", j));
+            }
+        }
+        for (const char* f : {".mlp.0.weight", ".mlp.0.bias", ".mlp.3.weight", ".mlp.3.bias"}) s.push_back(p + f);
+        if (cfg.norm_fn == IMP_NORM_BN)
+            for (const char* f : {".mlp.1.weight", ".mlp.1.bias", ".mlp.1.running_mean", ".mlp.1.running_var"})
+                s.push_back(p + f);
+    }
+    for (int i = 0; i < cfg.n_layers; ++i) {
+        s.push_back(kname("final_proj.%d.weight", i));
+        s.push_back(kname("final_proj.%d.bias", i));
+    }
+}
+
+int upload(imp_ctx* c, float** dst, const std::vector<float>& host) {
+    int rc = dev_alloc(c, c->allocs_w, dst, host.size());
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(*dst, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    return IMP_OK;
+}
+const HostTensor* get(imp_ctx* c, const std::string& key, int64_t numel) {
+    auto it = c->raw.find(key);
+    if (it == c->raw.end()) { g_err = "missing state_dict key: " + key; return nullptr; }
+    if ((int64_t)it->second.data.size() != numel) {
+        g_err = "state_dict tensor " + key + " has " + std::to_string(it->second.data.size()) + " elements, expected " +
+                std::to_string(numel);
+        return nullptr;
+    }
+    return &it->second;
+}
+// plain [out][in] linear
+int pack_linear(imp_ctx* c, const std::string& prefix, int out, int in, Linear* L) {
+    const HostTensor* w = get(c, prefix + ".weight", (int64_t)out * in);
+    const HostTensor* b = get(c, prefix + ".bias", out);
+    if (!w || !b) return IMP_E_KEY;
+    L->out = out; L->in = in;
+    int rc = upload(c, &L->W, w->data);
+    if (rc) return rc;
+    return upload(c, &L->b, b->data);
+}
+// head permutation: reference channel c = d*H + h  ->  packed channel h*dh + d   (nets/layers.py:119-120)
+inline int ref_channel(int packed, int dh) { return (packed % dh) * IMP_NUM_HEADS + packed / dh; }
+
+int pack_norm(imp_ctx* c, const std::string& prefix, int ch, NormC* N) {
+    const HostTensor* g = get(c, prefix + ".weight", ch);
+    const HostTensor* b = get(c, prefix + ".bias", ch);
+    const HostTensor* rm = get(c, prefix + ".running_mean", ch);
+    const HostTensor* rv = get(c, prefix + ".running_var", ch);
+    if (!g || !b || !rm || !rv) return IMP_E_KEY;
+    std::vector<float> rstd(ch);
+    for (int i = 0; i < ch; ++i) rstd[i] = 1.0f / std::sqrt(rv->data[i] + 1e-3f);   // eps = 1e-3 nets/layers.py:70
+    N->c = ch;
+    int rc;
+    if ((rc = upload(c, &N->mean, rm->data))) return rc;
+    if ((rc = upload(c, &N->rstd, rstd))) return rc;
+    if ((rc = upload(c, &N->gamma, g->data))) return rc;
+    return upload(c, &N->beta, b->data);
+}
+
+int ensure_workspace(imp_ctx* c, int batch, int n) {
+    if (batch <= c->cap_b && n <= c->cap_n) return IMP_OK;
+    if (batch < c->cap_b) batch = c->cap_b;
+    if (n < c->cap_n) n = c->cap_n;
+    HIP_TRY(hipDeviceSynchronize());
+    free_pool(c->allocs_ws);
+    c->cap_b = c->cap_n = 0;
+    c->cache[0].valid = c->cache[1].valid = false;
+    const size_t B = batch, N = n, D = c->D;
+    const size_t tiles = (N + 63) / 64;
+    int rc = 0;
+    for (int k = 0; k < 2 && !rc; ++k)
+        for (int s = 0; s < 2 && !rc; ++s) {
+            rc = dev_alloc(c, c->allocs_ws, &c->qkv[k][s], B * N * 3 * D);
+            if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->lse[k][s], B * IMP_NUM_HEADS * N);
+            if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->cmask[k][s], B * N);
+        }
+    for (int s = 0; s < 2 && !rc; ++s) {
+        rc = dev_alloc(c, c->allocs_ws, &c->attn_out[s], B * N * D);
+        if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->msg[s], B * N * D);
+        if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->hid[s], B * N * 2 * D);
+        if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->stats[s], B * tiles * 2 * D * 2 + 2 * B * tiles * (size_t)c->kenc_maxc * 2);
+        if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->kbuf[s][0], B * N * (size_t)c->kenc_maxc);
+        if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->kbuf[s][1], B * N * (size_t)c->kenc_maxc);
+        if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->descw[s], B * N * D);
+        if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->mdesc[s], B * N * D);
+        if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->nkp[s], B * N * 2);
+        if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->mass[s], N + 4);
+    }
+    const size_t ld = (N + 1 + 3) & ~(size_t)3;
+    if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->dist, B * N * N);
+    if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->ot.P, B * (N + 1) * ld);
+    if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->ot.PT, B * (N + 1) * ld);
+    if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->ot.u, B * ld);
+    if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->ot.v, B * ld);
+    if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->max0, B * N);
+    if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->max1, B * N);
+    if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->arg0, B * N);
+    if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->arg1, B * N);
+    const size_t chunks = score_maxima_chunks((int)N);
+    if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->colpart_v, B * chunks * N);
+    if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->colpart_i, B * chunks * N);
+    for (int k = 0; k < 4 && !rc; ++k) {
+        rc = dev_alloc(c, c->allocs_ws, &c->colsum[k], B * IMP_NUM_HEADS * N);
+        if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->amass[k], B * N);
+    }
+    if (rc) { free_pool(c->allocs_ws); return rc; }
+    c->cap_b = batch;
+    c->cap_n = n;
+    return IMP_OK;
+}
+
+inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
+
+int check_ready(imp_ctx* c, int batch, int n0, int n1) {
+    if (!c) return fail(IMP_E_ARG, "null context");
+    if (!c->finalized) return fail(IMP_E_STATE, "weights not finalised (imp_finalize_weights)");
+    if (batch < 1 || n0 < 1 || n1 < 1) return fail(IMP_E_ARG, "batch, n0, n1 must be >= 1");
+    HIP_TRY(hipSetDevice(c->device));
+    return ensure_workspace(c, batch, n0 > n1 ? n0 : n1);
+}
+
+GemmParams gemm_defaults(int K) {
+    GemmParams p;
+    memset(&p, 0, sizeof p);
+    p.K = K; p.ksplit = K; p.nside = 2; p.nsub = 1; p.div = 1.f; p.norm_eps = 1e-3f;
+    return p;
+}
+
+// y_s = x_s @ W^T + b for both image sides (the plain 1x1 conv)
+int linear_both(imp_ctx* c, const Linear& L, int batch, const int n[2], const float* const x[2], int ldx, float* const y[2],
+                int ldy, hipStream_t st) {
+    GemmParams p = gemm_defaults(L.in);
+    for (int s = 0; s < 2; ++s) {
+        GemmSide& g = p.side[s];
+        g.A = x[s]; g.W = L.W; g.C = y[s]; g.M = n[s]; g.N = L.out;
+        g.sA_b = (long)n[s] * ldx; g.sC_b = (long)n[s] * ldy;
+    }
+    p.bias = L.b; p.lda = ldx; p.ldw = L.in; p.ldc = ldy;
+    HIP_TRY(launch_gemm_f32(p, batch, st));
+    return IMP_OK;
+}
+
+// keypoint encoder: first conv on the VALU, then the MLP chain as GEMMs with InstanceNorm/BatchNorm + activation
+// applied while staging the A operand and the statistics produced by the previous GEMM's epilogue.
+int run_kenc(imp_ctx* c, int batch, const int n[2], const float* const kpts[2], const float* const scores[2],
+             float width, float height, const float* const desc[2], float* const out[2], hipStream_t st) {
+    const imp_config& cfg = c->cfg;
+    const int nk = n_kenc(cfg);
+    const int D = c->D;
+    const bool in_norm = cfg.norm_fn == IMP_NORM_IN;
+    // two statistics slots per side behind the GNN-layer statistics: a launch reads the previous layer's slot in its
+    // prologue while other workgroups already write this layer's slot in their epilogue
+    const size_t tiles_cap = ((size_t)c->cap_n + 63) / 64;
+    const size_t slot = (size_t)c->cap_b * tiles_cap * c->kenc_maxc * 2;
+    float* kstats[2] = {c->stats[0] + (size_t)c->cap_b * tiles_cap * 2 * D * 2,
+                        c->stats[1] + (size_t)c->cap_b * tiles_cap * 2 * D * 2};
+    Kenc0Side ks[2];
+    for (int s = 0; s < 2; ++s) ks[s] = Kenc0Side{kpts[s], scores[s], c->kbuf[s][0], in_norm ? kstats[s] : nullptr, n[s]};
+    HIP_TRY(launch_kenc_first(ks, batch, c->kenc[0].out, c->kenc[0].W, c->kenc[0].b, width, height, st));
+    int in_tiles[2] = {(n[0] + 127) / 128, (n[1] + 127) / 128};   // kenc_first: 128-token statistics tiles
+    const int maxn = n[0] > n[1] ? n[0] : n[1];
+    int cur = 0;
+    for (int i = 1; i <= nk; ++i) {
+        const Linear& L = c->kenc[i];
+        const bool last = i == nk;
+        GemmParams p = gemm_defaults(L.in);
+        p.flags = GEMM_PRO_NORM;
+        p.act = cfg.ac_fn;
+        if (!in_norm) {
+            const NormC& nc = c->kenc_bn[i - 1];
+            p.flags |= GEMM_PRO_AFFINE;
+            p.nm_mean = nc.mean; p.nm_rstd = nc.rstd; p.nm_gamma = nc.gamma; p.nm_beta = nc.beta;
+        }
+        if (!last && in_norm) p.flags |= GEMM_EPI_STATS;
+        const int bm = gemm_tile_m(maxn, L.out, 2 * batch);
+        for (int s = 0; s < 2; ++s) {
+            GemmSide& g = p.side[s];
+            g.A = c->kbuf[s][cur]; g.W = L.W; g.M = n[s]; g.N = L.out;
+            g.sA_b = (long)n[s] * L.in;
+            g.in_stats = in_norm ? kstats[s] + ((i - 1) & 1) * slot : nullptr;
+            g.in_tiles = in_tiles[s];
+            if (last) {
+                g.C = out[s]; g.sC_b = (long)n[s] * D;
+                if (desc[s]) { g.R = desc[s]; g.sR_b = (long)n[s] * D; }
+            } else {
+                g.C = c->kbuf[s][cur ^ 1]; g.sC_b = (long)n[s] * L.out;
+                g.out_stats = in_norm ? kstats[s] + (i & 1) * slot : nullptr;
+            }
+        }
+        p.bias = L.b; p.lda = L.in; p.ldw = L.in; p.ldc = last ? D : L.out; p.ldr = D;
+        HIP_TRY(launch_gemm_f32(p, batch, st));
+        for (int s = 0; s < 2; ++s) in_tiles[s] = (n[s] + bm - 1) / bm;
+        cur ^= 1;
+    }
+    return IMP_OK;
+}
+
+int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const desc[2], float* const out[2],
+              const uint8_t* const kmask[2], hipStream_t st) {
+    const imp_config& cfg = c->cfg;
+    const GnnLayer& L = c->layers[li];
+    const int D = c->D, kind = L.cross ? 1 : 0;
+    AttnCache& cache = c->cache[kind];
+    float* const* qkv = c->qkv[kind];
+    if (L.shared) {
+        if (!cache.valid || cache.batch != batch || cache.n[0] != n[0] || cache.n[1] != n[1])
+            return fail(IMP_E_STATE, "attention-sharing layer " + std::to_string(li) +
+                                         " called without a matching cached attention of the same kind/shape");
+    }
+    // 1. projections: q|k|v of both images in one GEMM (the layer's weights are shared by the two images);
+    //    a sharing layer only refreshes the value slot and keeps last iteration's q,k (== its probabilities)
+    {
+        GemmParams p = gemm_defaults(D);
+        for (int s = 0; s < 2; ++s) {
+            GemmSide& g = p.side[s];
+            g.A = desc[s]; g.W = L.proj.W; g.M = n[s]; g.N = L.proj.out;
+            g.C = L.shared ? qkv[s] + 2 * D : qkv[s];
+            g.sA_b = (long)n[s] * D; g.sC_b = (long)n[s] * 3 * D;
+        }
+        p.bias = L.proj.b; p.lda = D; p.ldw = D; p.ldc = 3 * D;
+        HIP_TRY(launch_gemm_f32(p, batch, st));
+    }
+    if (!L.shared) {
+        for (int img = 0; img < 2; ++img) {
+            cache.masked[img] = kmask[img] != nullptr;
+            if (kmask[img])
+                HIP_TRY(hipMemcpyAsync(c->cmask[kind][img], kmask[img], (size_t)batch * n[img], hipMemcpyDeviceToDevice, st));
+        }
+        cache.valid = true; cache.batch = batch; cache.n[0] = n[0]; cache.n[1] = n[1];
+    }
+    // 2. attention (nets/layers.py:121-131), sources: self -> same image, cross -> the other image
+    {
+        AttnParams a;
+        memset(&a, 0, sizeof a);
+        a.nside = 2; a.ldq = a.ldk = 3 * D; a.ldo = D; a.dh = c->dh;
+        for (int s = 0; s < 2; ++s) {
+            const int src = L.cross ? 1 - s : s;
+            AttnSide& g = a.side[s];
+            g.q = qkv[s]; g.k = qkv[src] + D; g.v = qkv[src] + 2 * D;
+            g.out = c->attn_out[s];
+            g.lse = L.shared ? nullptr : c->lse[kind][s];
+            g.kmask = cache.masked[src] ? c->cmask[kind][src] : nullptr;
+            g.sq_b = (long)n[s] * 3 * D; g.sk_b = (long)n[src] * 3 * D; g.so_b = (long)n[s] * D;
+            g.nq = n[s]; g.nk = n[src];
+        }
+        HIP_TRY(launch_attention_f32(a, batch, st));
+    }
+    // 3. merge conv
+    {
+        const float* x[2] = {c->attn_out[0], c->attn_out[1]};
+        int rc = linear_both(c, L.merge, batch, n, x, D, c->msg, D, st);
+        if (rc) return rc;
+    }
+    // 4. MLP conv 0 on cat([x, message]) (the concat is a K-split over two sources) + InstanceNorm statistics
+    const bool in_norm = cfg.norm_fn == IMP_NORM_IN;
+    const int maxn = n[0] > n[1] ? n[0] : n[1];
+    const int bm0 = gemm_tile_m(maxn, 2 * D, 2 * batch);
+    {
+        GemmParams p = gemm_defaults(2 * D);
+        p.ksplit = D;
+        for (int s = 0; s < 2; ++s) {
+            GemmSide& g = p.side[s];
+            g.A = desc[s]; g.A2 = c->msg[s]; g.W = L.mlp0.W; g.C = c->hid[s]; g.M = n[s]; g.N = 2 * D;
+            g.sA_b = (long)n[s] * D; g.sC_b = (long)n[s] * 2 * D;
+            g.out_stats = in_norm ? c->stats[s] : nullptr;
+        }
+        if (in_norm) p.flags |= GEMM_EPI_STATS;
+        p.bias = L.mlp0.b; p.lda = D; p.lda2 = D; p.ldw = 2 * D; p.ldc = 2 * D;
+        HIP_TRY(launch_gemm_f32(p, batch, st));
+    }
+    // 5. norm + activation while staging, conv 3, bias, residual add -> new descriptors
+    {
+        GemmParams p = gemm_defaults(2 * D);
+        p.flags = GEMM_PRO_NORM;
+        p.act = cfg.ac_fn;
+        if (!in_norm) {
+            p.flags |= GEMM_PRO_AFFINE;
+            p.nm_mean = L.bn.mean; p.nm_rstd = L.bn.rstd; p.nm_gamma = L.bn.gamma; p.nm_beta = L.bn.beta;
+        }
+        for (int s = 0; s < 2; ++s) {
+            GemmSide& g = p.side[s];
+            g.A = c->hid[s]; g.W = L.mlp3.W; g.C = out[s]; g.R = desc[s]; g.M = n[s]; g.N = D;
+            g.sA_b = (long)n[s] * 2 * D; g.sC_b = (long)n[s] * D; g.sR_b = (long)n[s] * D;
+            g.in_stats = in_norm ? c->stats[s] : nullptr;
+            g.in_tiles = (n[s] + bm0 - 1) / bm0;
+        }
+        p.bias = L.mlp3.b; p.lda = 2 * D; p.ldw = 2 * D; p.ldc = D; p.ldr = D;
+        HIP_TRY(launch_gemm_f32(p, batch, st));
+    }
+    return IMP_OK;
+}
+
+int run_distance(imp_ctx* c, int layer_id, int batch, const int n[2], const float* const desc[2], float* dist,
+                 hipStream_t st) {
+    const int D = c->D;
+    int idx = layer_id < 0 ? c->cfg.n_layers + layer_id : layer_id;
+    if (idx < 0 || idx >= c->cfg.n_layers) return fail(IMP_E_ARG, "compute_distance: layer_id out of range");
+    int rc = linear_both(c, c->final_proj[idx], batch, n, desc, D, c->mdesc, D, st);
+    if (rc) return rc;
+    GemmParams p = gemm_defaults(D);
+    p.nside = 1;
+    GemmSide& g = p.side[0];
+    g.A = c->mdesc[0]; g.W = c->mdesc[1]; g.C = dist; g.M = n[0]; g.N = n[1];
+    g.sA_b = (long)n[0] * D; g.sW_b = (long)n[1] * D; g.sC_b = (long)n[0] * n[1];
+    p.lda = D; p.ldw = D; p.ldc = n[1];
+    p.flags = GEMM_EPI_DIV;
+    p.div = (float)std::sqrt((double)D);      // dist / descriptor_dim ** .5   nets/gm.py:294
+    HIP_TRY(launch_gemm_f32(p, batch, st));
+    return IMP_OK;
+}
+
+void ot_layout(imp_ctx* c, int n0, int n1, OtBuffers* o) {
+    *o = c->ot;
+    o->ldp = (n1 + 1 + 3) & ~3;
+    o->ldpt = (n0 + 1 + 3) & ~3;
+}
+
+int run_score(imp_ctx* c, int batch, int n0, int n1, const float* dist, float bin, int iterations, int with_sinkhorn,
+              float* scores, OtBuffers* ot_out, hipStream_t st) {
+    OtBuffers o;
+    ot_layout(c, n0, n1, &o);
+    const int dual = with_sinkhorn ? 0 : 1;
+    HIP_TRY(launch_ot_init(dist, batch, n0, n1, bin, dual, o, st));
+    if (dual) HIP_TRY(launch_ot_dual_lse(batch, n0, n1, o, st));
+    else HIP_TRY(launch_ot_iterations(batch, n0, n1, iterations, o, st));
+    if (scores) HIP_TRY(launch_ot_scores(batch, n0, n1, dual, o, scores, st));
+    if (ot_out) *ot_out = o;
+    return IMP_OK;
+}
+
+struct ProbSpec { int kind, qside, kside; };
+// which: 0 self img0, 1 self img1, 2 cross img0<-img1 (reference cross_prob1), 3 cross img1<-img0 (cross_prob0)
+const ProbSpec kProb[4] = {{0, 0, 0}, {0, 1, 1}, {1, 0, 1}, {1, 1, 0}};
+
+__global__ void zero_masked_columns_kernel(float* prob, const uint8_t* mask, int nq, int nk, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int key = (int)(i % nk);
+    const long b = i / ((long)IMP_NUM_HEADS * nq * nk);
+    if (!mask[b * nk + key]) prob[i] = 0.f;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char* imp_last_error(void) { return g_err.c_str(); }
+const char* imp_version(void) { return "imp_hip 0.1 gfx950 f32-mfma"; }
+
+int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
+    if (!out || !cfg) return fail(IMP_E_ARG, "imp_create: null argument");
+    if (cfg->descriptor_dim != 256 && cfg->descriptor_dim != 128)
+        return fail(IMP_E_ARG, "descriptor_dim must be 256 or 128 (4 heads x 64 / 32)");
+    if (cfg->n_gnn_layers < 0 || cfg->n_gnn_layers > 128 || cfg->n_layers < 1)
+        return fail(IMP_E_ARG, "bad layer counts");
+    const int nk = n_kenc(*cfg);
+    if (nk < 1 || cfg->kenc_channels[0] > 64) return fail(IMP_E_ARG, "keypoint_encoder needs >= 1 layer, first <= 64 channels");
+    for (int i = 0; i < nk; ++i)
+        if (cfg->kenc_channels[i] % 32) return fail(IMP_E_ARG, "keypoint_encoder channels must be multiples of 32");
+    HIP_TRY(hipSetDevice(device));
+    imp_ctx* c = new imp_ctx();
+    c->cfg = *cfg;
+    c->device = device;
+    c->D = cfg->descriptor_dim;
+    c->dh = c->D / IMP_NUM_HEADS;
+    c->kenc_maxc = c->D;
+    for (int i = 0; i < nk; ++i) if (cfg->kenc_channels[i] > c->kenc_maxc) c->kenc_maxc = cfg->kenc_channels[i];
+    build_schema(c);
+    *out = c;
+    return IMP_OK;
+}
+
+int imp_destroy(imp_ctx* c) {
+    if (!c) return IMP_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    free_pool(c->allocs_w);
+    free_pool(c->allocs_ws);
+    delete c;
+    return IMP_OK;
+}
+
+int imp_num_keys(imp_ctx* c) { return c ? (int)c->schema.size() : 0; }
+const char* imp_key_name(imp_ctx* c, int i) {
+    if (!c || i < 0 || i >= (int)c->schema.size()) return nullptr;
+    return c->schema[i].c_str();
+}
+
+int imp_load_tensor(imp_ctx* c, const char* key, const float* data, const int64_t* shape, int ndim) {
+    if (!c || !key || !data || ndim < 0 || ndim > 8) return fail(IMP_E_ARG, "imp_load_tensor: bad argument");
+    bool known = false;
+    for (const std::string& s : c->schema) if (s == key) { known = true; break; }
+    if (!known) return fail(IMP_E_KEY, std::string("unexpected state_dict key: ") + key);
+    int64_t numel = 1;
+    HostTensor t;
+    for (int i = 0; i < ndim; ++i) { numel *= shape[i]; t.shape.push_back(shape[i]); }
+    t.data.assign(data, data + numel);
+    c->raw[key] = std::move(t);
+    c->finalized = false;
+    return IMP_OK;
+}
+
+int imp_finalize_weights(imp_ctx* c) {
+    if (!c) return fail(IMP_E_ARG, "null context");
+    for (const std::string& s : c->schema)
+        if (!c->raw.count(s)) return fail(IMP_E_KEY, "missing state_dict key: " + s);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    free_pool(c->allocs_w);
+    const imp_config& cfg = c->cfg;
+    const int D = c->D, dh = c->dh, nk = n_kenc(cfg);
+    c->bin_score = c->raw["bin_score"].data[0];
+    int rc;
+    // keypoint encoder: [3, c1, ..., ck, D]
+    c->kenc.assign(nk + 1, Linear());
+    c->kenc_bn.assign(nk, NormC());
+    int cin = 3;
+    for (int i = 0; i <= nk; ++i) {
+        const int cout = i < nk ? cfg.kenc_channels[i] : D;
+        if ((rc = pack_linear(c, kname("kenc.encoder.%d", 3 * i), cout, cin, &c->kenc[i]))) return rc;
+        if (i < nk && cfg.norm_fn == IMP_NORM_BN)
+            if ((rc = pack_norm(c, kname("kenc.encoder.%d", 3 * i + 1), cout, &c->kenc_bn[i]))) return rc;
+        cin = cout;
+    }
+    c->layers.assign(cfg.n_gnn_layers, GnnLayer());
+    for (int li = 0; li < cfg.n_gnn_layers; ++li) {
+        GnnLayer& L = c->layers[li];
+        L.cross = cfg.layer_is_cross[li] != 0;
+        L.shared = layer_shared(cfg, li);
+        const std::string p = kname("gnn.layers.%d", li);
+        const std::string pa = L.shared ? p : p + ".attn";
+        // projections, output rows permuted to head-major
+        const int nproj = L.shared ? 1 : 3;
+        std::vector<float> W((size_t)nproj * D * D), b((size_t)nproj * D);
+        for (int j = 0; j < nproj; ++j) {
+            const std::string key = L.shared ? p + ".proj" : pa + kname(".proj.%d", j);
+            const HostTensor* w = get(c, key + ".weight", (int64_t)D * D);
+            const HostTensor* bb = get(c, key + ".bias", D);
+            if (!w || !bb) return IMP_E_KEY;
+            for (int r = 0; r < D; ++r) {
+                const int src = ref_channel(r, dh);
+                memcpy(&W[((size_t)j * D + r) * D], &w->data[(size_t)src * D], D * sizeof(float));
+                b[(size_t)j * D + r] = bb->data[src];
+            }
+        }
+        L.proj.out = nproj * D; L.proj.in = D;
+        if ((rc = upload(c, &L.proj.W, W))) return rc;
+        if ((rc = upload(c, &L.proj.b, b))) return rc;
+        // merge, input columns permuted to head-major
+        {
+            const HostTensor* w = get(c, pa + ".merge.weight", (int64_t)D * D);
+            const HostTensor* bb = get(c, pa + ".merge.bias", D);
+            if (!w || !bb) return IMP_E_KEY;
+            std::vector<float> Wm((size_t)D * D);
+            for (int o = 0; o < D; ++o)
+                for (int k = 0; k < D; ++k) Wm[(size_t)o * D + k] = w->data[(size_t)o * D + ref_channel(k, dh)];
+            L.merge.out = D; L.merge.in = D;
+            if ((rc = upload(c, &L.merge.W, Wm))) return rc;
+            if ((rc = upload(c, &L.merge.b, bb->data))) return rc;
+        }
+        if ((rc = pack_linear(c, p + ".mlp.0", 2 * D, 2 * D, &L.mlp0))) return rc;
+        if (cfg.norm_fn == IMP_NORM_BN)
+            if ((rc = pack_norm(c, p + ".mlp.1", 2 * D, &L.bn))) return rc;
+        if ((rc = pack_linear(c, p + ".mlp.3", D, 2 * D, &L.mlp3))) return rc;
+    }
+    c->final_proj.assign(cfg.n_layers, Linear());
+    for (int i = 0; i < cfg.n_layers; ++i)
+        if ((rc = pack_linear(c, kname("final_proj.%d", i), D, D, &c->final_proj[i]))) return rc;
+    c->finalized = true;
+    c->cache[0].valid = c->cache[1].valid = false;
+    if (cfg.max_batch > 0 && cfg.max_keypoints > 0) return ensure_workspace(c, cfg.max_batch, cfg.max_keypoints);
+    return IMP_OK;
+}
+
+int imp_normalize_keypoints(imp_ctx* c, const float* kpts, int batch, int n, float width, float height, float* out,
+                            void* stream) {
+    if (!c || !kpts || !out) return fail(IMP_E_ARG, "imp_normalize_keypoints: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_normalize_kpts(kpts, (long)batch * n, width, height, out, S(stream)));
+    return IMP_OK;
+}
+
+int imp_encode_keypoints(imp_ctx* c, int batch, int n0, int n1, const float* nkpts0, const float* scores0,
+                         const float* desc0, float* out0, const float* nkpts1, const float* scores1,
+                         const float* desc1, float* out1, void* stream) {
+    int rc = check_ready(c, batch, n0, n1);
+    if (rc) return rc;
+    if (!nkpts0 || !nkpts1 || !scores0 || !scores1 || !out0 || !out1) return fail(IMP_E_ARG, "imp_encode_keypoints: null argument");
+    const int n[2] = {n0, n1};
+    const float* kp[2] = {nkpts0, nkpts1};
+    const float* sc[2] = {scores0, scores1};
+    const float* de[2] = {desc0, desc1};
+    float* out[2] = {out0, out1};
+    return run_kenc(c, batch, n, kp, sc, 0.f, 0.f, de, out, S(stream));
+}
+
+int imp_forward_layer(imp_ctx* c, int layer_i, int batch, int n0, int n1, const float* desc0, const float* desc1,
+                      float* out0, float* out1, const uint8_t* key_mask0, const uint8_t* key_mask1, void* stream) {
+    int rc = check_ready(c, batch, n0, n1);
+    if (rc) return rc;
+    if (layer_i < 0 || layer_i >= c->cfg.n_gnn_layers) return fail(IMP_E_ARG, "layer index out of range");
+    if (!desc0 || !desc1 || !out0 || !out1) return fail(IMP_E_ARG, "imp_forward_layer: null argument");
+    const int n[2] = {n0, n1};
+    const float* de[2] = {desc0, desc1};
+    float* out[2] = {out0, out1};
+    const uint8_t* km[2] = {key_mask0, key_mask1};
+    return run_layer(c, layer_i, batch, n, de, out, km, S(stream));
+}
+
+int imp_attention_prob(imp_ctx* c, int which, float* prob, void* stream) {
+    if (!c || !prob || which < 0 || which > 3) return fail(IMP_E_ARG, "imp_attention_prob: bad argument");
+    const ProbSpec ps = kProb[which];
+    const AttnCache& cache = c->cache[ps.kind];
+    if (!cache.valid) return fail(IMP_E_STATE, "no cached attention of that kind");
+    HIP_TRY(hipSetDevice(c->device));
+    const int D = c->D, dh = c->dh, nq = cache.n[ps.qside], nk = cache.n[ps.kside];
+    GemmParams p = gemm_defaults(dh);
+    p.nside = 1; p.nsub = IMP_NUM_HEADS;
+    GemmSide& g = p.side[0];
+    g.A = c->qkv[ps.kind][ps.qside]; g.W = c->qkv[ps.kind][ps.kside] + D; g.C = prob;
+    g.rowvec = c->lse[ps.kind][ps.qside];
+    g.M = nq; g.N = nk;
+    g.sA_b = (long)nq * 3 * D; g.sA_s = dh; g.sW_b = (long)nk * 3 * D; g.sW_s = dh;
+    g.sC_b = (long)IMP_NUM_HEADS * nq * nk; g.sC_s = (long)nq * nk;
+    g.sRV_b = (long)IMP_NUM_HEADS * nq; g.sRV_s = nq;
+    p.lda = 3 * D; p.ldw = 3 * D; p.ldc = nk;
+    p.flags = GEMM_EPI_DIV | GEMM_EPI_EXPROW;
+    p.div = (float)std::sqrt((double)dh);
+    HIP_TRY(launch_gemm_f32(p, cache.batch, S(stream)));
+    if (cache.masked[ps.kside]) {
+        const long total = (long)cache.batch * IMP_NUM_HEADS * nq * nk;
+        hipLaunchKernelGGL(zero_masked_columns_kernel, dim3((total + 255) / 256), dim3(256), 0, S(stream), prob,
+                           c->cmask[ps.kind][ps.kside], nq, nk, total);
+        HIP_TRY(hipGetLastError());
+    }
+    return IMP_OK;
+}
+
+int imp_attention_received(imp_ctx* c, int which, float* out, void* stream) {
+    if (!c || !out || which < 0 || which > 3) return fail(IMP_E_ARG, "imp_attention_received: bad argument");
+    const ProbSpec ps = kProb[which];
+    const AttnCache& cache = c->cache[ps.kind];
+    if (!cache.valid) return fail(IMP_E_STATE, "no cached attention of that kind");
+    HIP_TRY(hipSetDevice(c->device));
+    const int D = c->D, nq = cache.n[ps.qside], nk = cache.n[ps.kside];
+    ColsumParams p;
+    memset(&p, 0, sizeof p);
+    p.nside = 1; p.ldq = p.ldk = 3 * D; p.dh = c->dh;
+    ColsumSide& g = p.side[0];
+    g.q = c->qkv[ps.kind][ps.qside]; g.k = c->qkv[ps.kind][ps.kside] + D; g.lse = c->lse[ps.kind][ps.qside];
+    g.out = c->colsum[which];
+    g.kmask = cache.masked[ps.kside] ? c->cmask[ps.kind][ps.kside] : nullptr;
+    g.nq = nq; g.nk = nk; g.sq_b = (long)nq * 3 * D; g.sk_b = (long)nk * 3 * D;
+    HIP_TRY(launch_attn_colsum_f32(p, cache.batch, S(stream)));
+    for (int b = 0; b < cache.batch; ++b)
+        HIP_TRY(launch_attn_mass_normalize(c->colsum[which] + (size_t)b * IMP_NUM_HEADS * nk, nk, out + (size_t)b * nk,
+                                           S(stream)));
+    return IMP_OK;
+}
+
+int imp_score_mass(imp_ctx* c, int n0, int n1, const float* scores, float* mass0, float* mass1, void* stream) {
+    int rc = check_ready(c, 1, n0, n1);
+    if (rc) return rc;
+    if (!scores || !mass0 || !mass1) return fail(IMP_E_ARG, "imp_score_mass: null argument");
+    HIP_TRY(launch_score_mass(scores, n0, n1, mass0, mass1, c->colpart_v, S(stream)));
+    return IMP_OK;
+}
+
+int imp_pool_select(imp_ctx* c, int n, const float* mass, const float* a_self, const float* a_cross, float thr,
+                    int64_t* ids, int32_t* counts, void* stream) {
+    if (!c || !mass || !a_self || !a_cross || !ids || !counts || n < 1) return fail(IMP_E_ARG, "imp_pool_select: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    PoolSide ps[2];
+    ps[0] = PoolSide{mass, a_self, a_cross, ids, n, 0};
+    ps[1] = ps[0];
+    HIP_TRY(launch_pool_select(ps, 1, thr, counts, S(stream)));
+    return IMP_OK;
+}
+
+int imp_compute_distance(imp_ctx* c, int layer_id, int batch, int n0, int n1, const float* desc0, const float* desc1,
+                         float* dist, void* stream) {
+    int rc = check_ready(c, batch, n0, n1);
+    if (rc) return rc;
+    if (!desc0 || !desc1 || !dist) return fail(IMP_E_ARG, "imp_compute_distance: null argument");
+    const int n[2] = {n0, n1};
+    const float* de[2] = {desc0, desc1};
+    return run_distance(c, layer_id, batch, n, de, dist, S(stream));
+}
+
+int imp_compute_score(imp_ctx* c, int batch, int n0, int n1, const float* dist, float bin_score, int iterations,
+                      int with_sinkhorn, float* scores, void* stream) {
+    int rc = check_ready(c, batch, n0, n1);
+    if (rc) return rc;
+    if (!dist) return fail(IMP_E_ARG, "imp_compute_score: null dist");
+    return run_score(c, batch, n0, n1, dist, bin_score, iterations, with_sinkhorn, scores, nullptr, S(stream));
+}
+
+int imp_compute_matches(imp_ctx* c, int batch, int n0, int n1, const float* scores, float p, int64_t* indices0,
+                        int64_t* indices1, float* mscores0, float* mscores1, void* stream) {
+    int rc = check_ready(c, batch, n0, n1);
+    if (rc) return rc;
+    if (!scores) return fail(IMP_E_ARG, "imp_compute_matches: null scores");
+    HIP_TRY(launch_score_maxima(scores, batch, n0, n1, c->max0, c->arg0, c->max1, c->arg1, c->colpart_v, c->colpart_i,
+                                S(stream)));
+    HIP_TRY(launch_mutual_matches(batch, n0, n1, c->max0, c->arg0, c->max1, c->arg1, p, indices0, indices1, mscores0,
+                                  mscores1, S(stream)));
+    return IMP_OK;
+}
+
+int imp_pool(imp_ctx* c, int n0, int n1, const float* scores, float mscore_th, float uncertainty_ratio, int n_min_tokens,
+             int64_t* ids0, int64_t* ids1, int32_t* counts, void* stream) {
+    int rc = check_ready(c, 1, n0, n1);
+    if (rc) return rc;
+    if (!scores || !ids0 || !ids1 || !counts) return fail(IMP_E_ARG, "imp_pool: null argument");
+    for (int k = 0; k < 2; ++k)
+        if (!c->cache[k].valid || c->cache[k].n[0] != n0 || c->cache[k].n[1] != n1)
+            return fail(IMP_E_STATE, "imp_pool: cached self/cross attention does not match (n0, n1)");
+    hipStream_t st = S(stream);
+    const int D = c->D;
+    // attention mass received per key: a00, a11 (self) and a01 (img1 queries -> img0 keys), a10 (nets/adgm.py:557-565)
+    for (int kind = 0; kind < 2; ++kind) {
+        ColsumParams p;
+        memset(&p, 0, sizeof p);
+        p.nside = 2; p.ldq = p.ldk = 3 * D; p.dh = c->dh;
+        for (int keyside = 0; keyside < 2; ++keyside) {
+            const int qside = kind == 0 ? keyside : 1 - keyside;
+            ColsumSide& g = p.side[keyside];
+            g.q = c->qkv[kind][qside]; g.k = c->qkv[kind][keyside] + D; g.lse = c->lse[kind][qside];
+            g.out = c->colsum[kind * 2 + keyside];
+            g.nq = kind == 0 ? (keyside ? n1 : n0) : (qside ? n1 : n0);
+            g.nk = keyside ? n1 : n0;
+            g.sq_b = (long)g.nq * 3 * D; g.sk_b = (long)g.nk * 3 * D;
+        }
+        HIP_TRY(launch_attn_colsum_f32(p, 1, st));
+        for (int keyside = 0; keyside < 2; ++keyside)
+            HIP_TRY(launch_attn_mass_normalize(c->colsum[kind * 2 + keyside], keyside ? n1 : n0, c->amass[kind * 2 + keyside], st));
+    }
+    HIP_TRY(launch_score_mass(scores, n0, n1, c->mass[0], c->mass[1], c->colpart_v, st));
+    PoolSide ps[2];
+    // image 0: a_self = a00 (colsum[0]), a_cross = a01 (colsum[2]); image 1: a_self = a11 (colsum[1]), a_cross = a10 (colsum[3])
+    ps[0] = PoolSide{c->mass[0], c->amass[0], c->amass[2], ids0, n0, (n_min_tokens > 0 && n0 + 1 <= n_min_tokens) ? 1 : 0};
+    ps[1] = PoolSide{c->mass[1], c->amass[1], c->amass[3], ids1, n1, (n_min_tokens > 0 && n1 + 1 <= n_min_tokens) ? 1 : 0};
+    HIP_TRY(launch_pool_select(ps, 2, mscore_th * uncertainty_ratio, counts, st));
+    return IMP_OK;
+}
+
+int imp_gather_rows(imp_ctx* c, int batch, int n_in, int n_out, int dim, const float* in, const int64_t* ids, float* out,
+                    void* stream) {
+    if (!c || !in || !ids || !out || dim % 4) return fail(IMP_E_ARG, "imp_gather_rows: bad argument (dim % 4 == 0)");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_gather_rows(in, ids, out, batch, n_in, n_out, dim, S(stream)));
+    return IMP_OK;
+}
+
+int imp_match_pair(imp_ctx* c, int batch, int n0, int n1, const float* kpts0, const float* scores0, const float* desc0,
+                   const float* kpts1, const float* scores1, const float* desc1, float width, float height,
+                   float bin_score, int sinkhorn_iterations, int with_sinkhorn, float p, int64_t* indices0,
+                   float* mscores0, int64_t* indices1, float* mscores1, float* scores, void* stream) {
+    int rc = check_ready(c, batch, n0, n1);
+    if (rc) return rc;
+    if (!kpts0 || !kpts1 || !scores0 || !scores1 || !desc0 || !desc1) return fail(IMP_E_ARG, "imp_match_pair: null input");
+    hipStream_t st = S(stream);
+    const int n[2] = {n0, n1};
+    const float* kp[2] = {kpts0, kpts1};
+    const float* sc[2] = {scores0, scores1};
+    const float* de[2] = {desc0, desc1};
+    float* dw[2] = {c->descw[0], c->descw[1]};
+    if ((rc = run_kenc(c, batch, n, kp, sc, width, height, de, dw, st))) return rc;   // desc + enc (nets/gm.py:177-178)
+    const uint8_t* nomask[2] = {nullptr, nullptr};
+    const float* dr[2] = {c->descw[0], c->descw[1]};
+    for (int li = 0; li < c->cfg.n_gnn_layers; ++li)
+        if ((rc = run_layer(c, li, batch, n, dr, dw, nomask, st))) return rc;
+    if ((rc = run_distance(c, c->cfg.n_layers - 1, batch, n, dr, c->dist, st))) return rc;
+    OtBuffers o;
+    if ((rc = run_score(c, batch, n0, n1, c->dist, bin_score, sinkhorn_iterations, with_sinkhorn, scores, &o, st))) return rc;
+    HIP_TRY(launch_ot_maxima(batch, n0, n1, with_sinkhorn ? 0 : 1, o, c->max0, c->arg0, c->max1, c->arg1, st));
+    HIP_TRY(launch_mutual_matches(batch, n0, n1, c->max0, c->arg0, c->max1, c->arg1, p, indices0, indices1, mscores0,
+                                  mscores1, st));
+    return IMP_OK;
+}
+
+int imp_op_linear(imp_ctx* c, int M, int N, int K, const float* x, const float* W, const float* bias, float* y,
+                  void* stream) {
+    if (!c || !x || !W || !y || K % 32) return fail(IMP_E_ARG, "imp_op_linear: bad argument (K % 32 == 0)");
+    HIP_TRY(hipSetDevice(c->device));
+    GemmParams p = gemm_defaults(K);
+    p.nside = 1;
+    GemmSide& g = p.side[0];
+    g.A = x; g.W = W; g.C = y; g.M = M; g.N = N;
+    p.bias = bias; p.lda = K; p.ldw = K; p.ldc = N;
+    HIP_TRY(launch_gemm_f32(p, 1, S(stream)));
+    return IMP_OK;
+}
+
+int imp_op_attention(imp_ctx* c, int batch, int nq, int nk, int dim, const float* qkv_q, const float* qkv_kv,
+                     const uint8_t* key_mask, float* out, float* lse, void* stream) {
+    if (!c || !qkv_q || !qkv_kv || !out || (dim != 256 && dim != 128)) return fail(IMP_E_ARG, "imp_op_attention: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    AttnParams a;
+    memset(&a, 0, sizeof a);
+    a.nside = 1; a.ldq = a.ldk = 3 * dim; a.ldo = dim; a.dh = dim / IMP_NUM_HEADS;
+    AttnSide& g = a.side[0];
+    g.q = qkv_q; g.k = qkv_kv + dim; g.v = qkv_kv + 2 * dim; g.out = out; g.lse = lse; g.kmask = key_mask;
+    g.sq_b = (long)nq * 3 * dim; g.sk_b = (long)nk * 3 * dim; g.so_b = (long)nq * dim;
+    g.nq = nq; g.nk = nk;
+    HIP_TRY(launch_attention_f32(a, batch, S(stream)));
+    return IMP_OK;
+}
+
+int imp_time_attention(imp_ctx* c, int batch, int n, int reps, float* ms, void* stream) {
+    int rc = check_ready(c, batch, n, n);
+    if (rc) return rc;
+    if (!ms || reps < 1) return fail(IMP_E_ARG, "imp_time_attention: bad argument");
+    hipStream_t st = S(stream);
+    const int D = c->D;
+    AttnParams a;
+    memset(&a, 0, sizeof a);
+    a.nside = 2; a.ldq = a.ldk = 3 * D; a.ldo = D; a.dh = c->dh;
+    for (int s = 0; s < 2; ++s) {
+        AttnSide& g = a.side[s];
+        g.q = c->qkv[0][s]; g.k = c->qkv[0][s] + D; g.v = c->qkv[0][s] + 2 * D; g.out = c->attn_out[s];
+        g.sq_b = g.sk_b = (long)n * 3 * D; g.so_b = (long)n * D; g.nq = g.nk = n;
+    }
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(launch_attention_f32(a, batch, st));   // warm
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; ++r) HIP_TRY(launch_attention_f32(a, batch, st));
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms = t / reps;
+    return IMP_OK;
+}
+
+int imp_time_sinkhorn(imp_ctx* c, int batch, int n, int iterations, float* ms, void* stream) {
+    int rc = check_ready(c, batch, n, n);
+    if (rc) return rc;
+    if (!ms || iterations < 1) return fail(IMP_E_ARG, "imp_time_sinkhorn: bad argument");
+    hipStream_t st = S(stream);
+    OtBuffers o;
+    ot_layout(c, n, n, &o);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(launch_ot_iterations(batch, n, n, 2, o, st));   // warm
+    HIP_TRY(hipEventRecord(e0, st));
+    HIP_TRY(launch_ot_iterations(batch, n, n, iterations, o, st));
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms = t / (2.f * iterations);
+    return IMP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,135 @@
+// Internal kernel interface of libimp_hip.so (gfx950 only).  Host launchers live next to their
+// kernels in the .hip files; context.hip orchestrates them.  Nothing here is part of the C-ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define IMP_NUM_HEADS 4          // hard-coded in nets/layers.py:157,230
+
+// ------------------------------------------------------------------------------------------------
+// fp32 MFMA GEMM:  C[z] = epilogue( prologue(A[z]) [M x K] * W[z]^T [K x N] )
+// z = (b * nsub + sub) * nside + side ; each side has its own operand set (image 0 / image 1).
+// ------------------------------------------------------------------------------------------------
+enum {
+    GEMM_PRO_NORM = 1 << 0,       // A' = act(norm(A)) per K-channel (InstanceNorm from in_stats, or fixed BN)
+    GEMM_PRO_AFFINE = 1 << 1,     // norm has gamma/beta (BatchNorm)
+    GEMM_EPI_EXPROW = 1 << 2,     // v = exp(v - rowvec[row])   (probability re-materialisation)
+    GEMM_EPI_STATS = 1 << 3,      // per-column partial (sum, sumsq) over the tile's rows -> out_stats
+    GEMM_EPI_NOSTORE = 1 << 4,    // do not write C (column statistics only)
+    GEMM_EPI_DIV = 1 << 5,        // v = acc / div  (before bias)
+};
+
+struct GemmSide {
+    const float* A;        // [b][sub][M][lda]
+    const float* A2;       // optional second K-range source (k >= ksplit), same strides as A
+    const float* W;        // [b][sub][N][ldw]   (weights: strides 0)
+    float* C;              // [b][sub][M][ldc]
+    const float* R;        // residual, [b][M][ldr] or null
+    const float* rowvec;   // [b][sub][M] or null
+    const float* in_stats; // [b][in_tiles][K][2] partial sums of the producer, or null
+    float* out_stats;      // [b][row_tiles][N][2]
+    long sA_b, sA_s, sW_b, sW_s, sC_b, sC_s, sR_b, sRV_b, sRV_s;
+    int M, N;
+    int in_tiles;          // number of partial-sum tiles behind in_stats
+};
+
+struct GemmParams {
+    GemmSide side[2];
+    const float* bias;     // [N] or null
+    const float* nm_mean;  // fixed per-channel normalisation (BatchNorm eval) or null
+    const float* nm_rstd;
+    const float* nm_gamma;
+    const float* nm_beta;
+    int K, ksplit;         // ksplit: first k served by A2 (== K when unused)
+    int lda, lda2, ldw, ldc, ldr;
+    int nside, nsub;
+    int flags, act;
+    float div, norm_eps;
+};
+
+hipError_t launch_gemm_f32(const GemmParams& p, int batch, hipStream_t stream);
+// rows of out_stats produced per launch for M rows (the tile height the launcher will choose)
+int gemm_stats_tiles(int M, int N, int total_z);
+int gemm_tile_m(int M, int N, int total_z);
+
+// ------------------------------------------------------------------------------------------------
+// attention (flash-style, fp32 MFMA, softmax in registers)
+// ------------------------------------------------------------------------------------------------
+struct AttnSide {
+    const float* q;        // [b][nq][ldq]   head h at columns h*DH
+    const float* k;        // [b][nk][ldk]
+    const float* v;        // [b][nk][ldk]
+    float* out;            // [b][nq][ldo]
+    float* lse;            // [b][H][nq] or null
+    const uint8_t* kmask;  // [b][nk] or null (1 = key kept)
+    long sq_b, sk_b, so_b;
+    int nq, nk;
+};
+struct AttnParams {
+    AttnSide side[2];
+    int nside, ldq, ldk, ldo, dh;
+};
+hipError_t launch_attention_f32(const AttnParams& p, int batch, hipStream_t stream);
+
+// column sums of the probability matrix: colsum[b][side][h][key] = sum_q exp(q.k*scale - lse[q])
+struct ColsumSide {
+    const float* q; const float* k; const float* lse; float* out;   // out [b][H][nk]
+    const uint8_t* kmask;                                            // [b][nk] or null: masked keys receive 0
+    long sq_b, sk_b;
+    int nq, nk;
+};
+struct ColsumParams { ColsumSide side[2]; int nside, ldq, ldk, dh; };
+hipError_t launch_attn_colsum_f32(const ColsumParams& p, int batch, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// keypoint encoder first layer + normalisation
+// ------------------------------------------------------------------------------------------------
+hipError_t launch_normalize_kpts(const float* kpts, long count, float width, float height, float* out,
+                                 hipStream_t stream);
+// y[b][n][C0] = W0[C0][3] . (x, y, score) + b0 ; optional fused normalisation (width > 0)
+// plus per-channel partial statistics (tiles of 128 tokens) for the following InstanceNorm
+struct Kenc0Side { const float* kpts; const float* scores; float* y; float* stats; int n; };
+hipError_t launch_kenc_first(const Kenc0Side sides[2], int batch, int c0, const float* W0, const float* b0,
+                             float width, float height, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// optimal transport (probability-domain Sinkhorn, nets/layers.py:27-46) + matches
+// ------------------------------------------------------------------------------------------------
+struct OtBuffers {
+    float* P;      // [B][n0+1][ldp]      row softmax of the dustbin-augmented matrix (or logits for dual softmax)
+    float* PT;     // [B][n1+1][ldpt]     transpose of P
+    float* u;      // [B][n0+1]
+    float* v;      // [B][n1+1]
+    int ldp, ldpt;
+};
+hipError_t launch_ot_init(const float* dist, int batch, int n0, int n1, float bin_score, int dual,
+                          const OtBuffers& ot, hipStream_t stream);
+hipError_t launch_ot_iterations(int batch, int n0, int n1, int iterations, const OtBuffers& ot, hipStream_t stream);
+// dual softmax: row / column log-sum-exp into u / v
+hipError_t launch_ot_dual_lse(int batch, int n0, int n1, const OtBuffers& ot, hipStream_t stream);
+// scores[b][i][j] = (P*u)*v  (or exp(lsr + lsc) for dual)   [B][n0+1][n1+1] contiguous
+hipError_t launch_ot_scores(int batch, int n0, int n1, int dual, const OtBuffers& ot, float* scores, hipStream_t stream);
+// row / column maxima of the inner block straight from P / PT (fused path, no score tensor)
+hipError_t launch_ot_maxima(int batch, int n0, int n1, int dual, const OtBuffers& ot, float* max0, int* arg0,
+                            float* max1, int* arg1, hipStream_t stream);
+// maxima of an arbitrary score tensor [B][n0+1][n1+1]
+hipError_t launch_score_maxima(const float* scores, int batch, int n0, int n1, float* max0, int* arg0,
+                               float* max1, int* arg1, float* colpart_val, int* colpart_arg, hipStream_t stream);
+int score_maxima_chunks(int n0);
+hipError_t launch_mutual_matches(int batch, int n0, int n1, const float* max0, const int* arg0, const float* max1,
+                                 const int* arg1, float p, int64_t* indices0, int64_t* indices1, float* ms0,
+                                 float* ms1, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// adaptive pooling (nets/adgm.py:552-605) + ragged compaction
+// ------------------------------------------------------------------------------------------------
+// inner-block row sums / column sums of a score tensor [n0+1][n1+1] (batch element 0)
+hipError_t launch_score_mass(const float* scores, int n0, int n1, float* mass0, float* mass1, float* colpart,
+                             hipStream_t stream);
+// one workgroup per side: threshold, lower medians, union, compaction
+struct PoolSide { const float* mass; const float* a_self; const float* a_cross; int64_t* ids; int n; int skip; };
+hipError_t launch_pool_select(const PoolSide sides[2], int nsides, float thr, int32_t* counts, hipStream_t stream);
+// a[key] = sum_h colsum[h][key] / total   (attention mass received, L1-normalised)
+hipError_t launch_attn_mass_normalize(const float* colsum, int n, float* out, hipStream_t stream);
+hipError_t launch_gather_rows(const float* in, const int64_t* ids, float* out, int batch, int n_in, int n_out, int dim,
+                              hipStream_t stream);

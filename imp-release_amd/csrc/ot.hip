@@ -1,0 +1,405 @@
+// Optimal-transport scoring and match extraction for gfx950.
+//   sink_algorithm / sinkhorn   nets/layers.py:27-46   (probability domain, NOT log domain)
+//   dual_softmax                nets/layers.py:20-24
+//   GM.compute_matches          nets/gm.py:305-320
+//
+// HBM/LLC-bound byte work: the (N+1)x(M+1) fp32 matrix (16.8 MB at N=M=2048) is read twice per
+// Sinkhorn iteration.  Both mat-vec products of an iteration are turned into ROW passes by keeping the
+// row-softmax P and its transpose P^T resident (33.6 MB/pair: Infinity-Cache resident), so every pass
+// is a fully coalesced float4 stream with a wavefront shuffle reduction per row, no atomics, and a
+// fixed summation order (bit-reproducible run to run).  Each of the 2T passes is one launch over all
+// B pairs (a kernel boundary, ~1.5 us, is the cheapest chip-wide dependency on this part).
+#include "imp_kernels.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr float OT_EPS = 1e-8f;   // nets/layers.py:13
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// (value, index) max with "first index wins" on ties (torch.max semantics, nets/gm.py:306-307)
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o);
+        const int oi = __shfl_xor(i, o);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+
+// ---- init: dustbin augmentation (nets/layers.py:39-40) + row softmax (nets/layers.py:28) -------------
+// one wave per augmented row; dual != 0 keeps the augmented logits instead (dual_softmax needs them)
+__global__ __launch_bounds__(256) void ot_init_kernel(const float* __restrict__ dist, int n0, int n1, float bin,
+                                                      int dual, float* __restrict__ P, int ldp,
+                                                      float* __restrict__ u, float* __restrict__ v, int ldpt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    const int b = blockIdx.y;
+    if (row > n0) return;
+    const float* drow = dist + ((long)b * n0 + row) * n1;
+    float* prow = P + ((long)b * (n0 + 1) + row) * ldp;
+    const bool last = row == n0;
+    if (row == 0) {   // Sinkhorn start vectors (nets/layers.py:29-30); padded tails are zero
+        for (int j = lane; j < ldp; j += 64) v[(long)b * ldp + j] = j <= n1 ? 1.f : 0.f;
+        for (int i = lane; i < ldpt; i += 64) u[(long)b * ldpt + i] = i <= n0 ? 1.f : 0.f;
+    }
+    if (dual) {
+        for (int j = lane; j < ldp; j += 64) prow[j] = j > n1 ? 0.f : ((last || j == n1) ? bin : drow[j]);
+        return;
+    }
+    float mx = bin;
+    if (!last) for (int j = lane; j < n1; j += 64) mx = fmaxf(mx, drow[j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j <= n1; j += 64) sum += expf(((last || j == n1) ? bin : drow[j]) - mx);
+    sum = wave_sum(sum);
+    for (int j = lane; j < ldp; j += 64)
+        prow[j] = j > n1 ? 0.f : expf(((last || j == n1) ? bin : drow[j]) - mx) / sum;
+}
+
+// ---- 32x32 LDS tile transpose: PT[j][i] = P[i][j]; padded tail of PT rows zeroed ----------------------
+__global__ __launch_bounds__(256) void ot_transpose_kernel(const float* __restrict__ P, int rows, int cols, int ldp,
+                                                           float* __restrict__ PT, int ldpt) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const float* src = P + (long)b * rows * ldp;
+    float* dst = PT + (long)b * cols * ldpt;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (r < rows && c < cols) ? src[(long)r * ldp + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;   // dst row = c (source column), dst col = r
+        if (c < cols && r < ldpt) dst[(long)c * ldpt + r] = tile[tx][ty + 8 * k];
+    }
+}
+
+// ---- one Sinkhorn half-iteration (nets/layers.py:32 or :33) as a row pass --------------------------------
+//   out[i] = marg_i / (sum_j Mx[i][j] * in[j] + eps),  marg = 1 except the last (dustbin) row = rows
+// RPW rows per wave share the loaded `in` vector chunk.
+template <int RPW>
+__global__ __launch_bounds__(256) void ot_rowpass_kernel(const float* __restrict__ Mx, int rows, int ld,
+                                                         const float* __restrict__ in, float* __restrict__ out,
+                                                         int ld_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int r0 = (blockIdx.x * 4 + wave) * RPW;
+    if (r0 >= rows) return;
+    const float* base = Mx + (long)b * rows * ld;
+    const f32x4* vin = reinterpret_cast<const f32x4*>(in + (long)b * ld);
+    const f32x4* rp[RPW];
+    float acc[RPW];
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+        const int r = r0 + k < rows ? r0 + k : rows - 1;
+        rp[k] = reinterpret_cast<const f32x4*>(base + (long)r * ld);
+        acc[k] = 0.f;
+    }
+    const int n4 = ld >> 2;
+    for (int c = lane; c < n4; c += 64) {
+        const f32x4 x = vin[c];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const f32x4 m = rp[k][c];
+            acc[k] = fmaf(m[0], x[0], acc[k]);
+            acc[k] = fmaf(m[1], x[1], acc[k]);
+            acc[k] = fmaf(m[2], x[2], acc[k]);
+            acc[k] = fmaf(m[3], x[3], acc[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+        const float s = wave_sum(acc[k]);
+        const int r = r0 + k;
+        if (lane == 0 && r < rows) {
+            const float marg = r == rows - 1 ? (float)rows : 1.f;
+            out[(long)b * ld_out + r] = marg / (s + OT_EPS);
+        }
+    }
+}
+
+// ---- dual softmax: per-row log-sum-exp of the logits (rows of P -> u, rows of PT -> v) -----------------
+__global__ __launch_bounds__(256) void ot_rowlse_kernel(const float* __restrict__ Mx, int rows, int cols, int ld,
+                                                        float* __restrict__ out, int ld_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= rows) return;
+    const float* row = Mx + ((long)b * rows + r) * ld;
+    float mx = -INFINITY;
+    for (int j = lane; j < cols; j += 64) mx = fmaxf(mx, row[j]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int j = lane; j < cols; j += 64) s += expf(row[j] - mx);
+    s = wave_sum(s);
+    if (lane == 0) out[(long)b * ld_out + r] = mx + logf(s);
+}
+
+__device__ __forceinline__ float ot_value(float m, float ui, float vj, int dual) {
+    // Sinkhorn: (p * u) * v as nets/layers.py:34 ; dual: exp(log_softmax_row + log_softmax_col) nets/layers.py:23-24
+    return dual ? expf((m - ui) + (m - vj)) : (m * ui) * vj;
+}
+
+__global__ __launch_bounds__(256) void ot_scores_kernel(const float* __restrict__ P, int n0, int n1, int ldp,
+                                                        const float* __restrict__ u, int ldu,
+                                                        const float* __restrict__ v, int dual,
+                                                        float* __restrict__ scores) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 4 + wave;
+    if (i > n0) return;
+    const float* prow = P + ((long)b * (n0 + 1) + i) * ldp;
+    const float ui = u[(long)b * ldu + i];
+    const float* vb = v + (long)b * ldp;
+    float* srow = scores + ((long)b * (n0 + 1) + i) * (n1 + 1);
+    for (int j = lane; j <= n1; j += 64) srow[j] = ot_value(prow[j], ui, vb[j], dual);
+}
+
+// row maxima of the inner block straight from P (TRANSPOSED = 0) or PT (TRANSPOSED = 1); both evaluate
+// the identical expression (p*u_i)*v_j so the two sides see bit-identical values for the mutual check.
+template <int TRANSPOSED>
+__global__ __launch_bounds__(256) void ot_maxima_kernel(const float* __restrict__ Mx, int rows, int cols, int ld,
+                                                        const float* __restrict__ rowvec, int ldr,
+                                                        const float* __restrict__ colvec, int ldc, int dual,
+                                                        float* __restrict__ maxv, int* __restrict__ argv) {
+    // rows/cols = inner sizes (n0,n1) or (n1,n0); Mx has rows+1 rows
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= rows) return;
+    const float* row = Mx + ((long)b * (rows + 1) + r) * ld;
+    const float rvv = rowvec[(long)b * ldr + r];
+    const float* cv = colvec + (long)b * ldc;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < cols; c += 64) {
+        const float val = TRANSPOSED ? ot_value(row[c], cv[c], rvv, dual) : ot_value(row[c], rvv, cv[c], dual);
+        if (val > best) { best = val; bi = c; }
+    }
+    wave_argmax(best, bi);
+    if (lane == 0) { maxv[(long)b * rows + r] = best; argv[(long)b * rows + r] = bi; }
+}
+
+// ---- maxima of an arbitrary score tensor [B][n0+1][n1+1] --------------------------------------------------
+__global__ __launch_bounds__(256) void score_rowmax_kernel(const float* __restrict__ scores, int n0, int n1,
+                                                           float* __restrict__ maxv, int* __restrict__ argv) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= n0) return;
+    const float* row = scores + ((long)b * (n0 + 1) + r) * (n1 + 1);
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < n1; c += 64) {
+        const float val = row[c];
+        if (val > best) { best = val; bi = c; }
+    }
+    wave_argmax(best, bi);
+    if (lane == 0) { maxv[(long)b * n0 + r] = best; argv[(long)b * n0 + r] = bi; }
+}
+
+constexpr int COL_CHUNK = 64;   // rows per column-maximum / column-sum partial
+// partial column maxima over a chunk of 64 rows: block = 64 columns x 4 row lanes
+__global__ __launch_bounds__(256) void score_colmax_part_kernel(const float* __restrict__ scores, int n0, int n1,
+                                                                int chunks, float* __restrict__ pv,
+                                                                int* __restrict__ pi) {
+    __shared__ float sv[4][64];
+    __shared__ int si[4][64];
+    const int cx = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int b = blockIdx.z, chunk = blockIdx.y;
+    const int c = blockIdx.x * 64 + cx;
+    const float* base = scores + (long)b * (n0 + 1) * (n1 + 1);
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    if (c < n1) {
+        const int rend = min(n0, (chunk + 1) * COL_CHUNK);
+        for (int r = chunk * COL_CHUNK + rg; r < rend; r += 4) {
+            const float val = base[(long)r * (n1 + 1) + c];
+            if (val > best) { best = val; bi = r; }
+        }
+    }
+    sv[rg][cx] = best; si[rg][cx] = bi;
+    __syncthreads();
+    if (rg == 0 && c < n1) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            const float ov = sv[k][cx]; const int oi = si[k][cx];
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        pv[((long)b * chunks + chunk) * n1 + c] = best;
+        pi[((long)b * chunks + chunk) * n1 + c] = bi;
+    }
+}
+__global__ __launch_bounds__(256) void colmax_combine_kernel(const float* __restrict__ pv, const int* __restrict__ pi,
+                                                             int n1, int chunks, float* __restrict__ maxv,
+                                                             int* __restrict__ argv) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n1) return;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int k = 0; k < chunks; ++k) {   // ascending row chunks: strict > keeps the first maximal row
+        const float ov = pv[((long)b * chunks + k) * n1 + c];
+        const int oi = pi[((long)b * chunks + k) * n1 + c];
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    maxv[(long)b * n1 + c] = best; argv[(long)b * n1 + c] = bi;
+}
+
+// ---- mutual nearest neighbours + threshold (nets/gm.py:308-318) ---------------------------------------------
+__global__ __launch_bounds__(256) void mutual_kernel(int n0, int n1, const float* __restrict__ max0,
+                                                     const int* __restrict__ arg0, const float* __restrict__ max1,
+                                                     const int* __restrict__ arg1, float p,
+                                                     int64_t* __restrict__ ind0, int64_t* __restrict__ ind1,
+                                                     float* __restrict__ ms0, float* __restrict__ ms1) {
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const float* m0 = max0 + (long)b * n0;
+    const int* a0 = arg0 + (long)b * n0;
+    const int* a1 = arg1 + (long)b * n1;
+    if (t < n0) {
+        const int j = a0[t];
+        const bool mutual = a1[j] == t;
+        const float s = mutual ? m0[t] : 0.f;
+        if (ms0) ms0[(long)b * n0 + t] = s;
+        if (ind0) ind0[(long)b * n0 + t] = (mutual && s > p) ? (int64_t)j : (int64_t)-1;
+    }
+    if (t < n1) {
+        const int i = a1[t];
+        const bool mutual1 = a0[i] == t;
+        const bool mutual0_i = a1[a0[i]] == i;
+        const float s0_i = mutual0_i ? m0[i] : 0.f;
+        const bool valid0_i = mutual0_i && s0_i > p;
+        if (ms1) ms1[(long)b * n1 + t] = mutual1 ? s0_i : 0.f;
+        if (ind1) ind1[(long)b * n1 + t] = (mutual1 && valid0_i) ? (int64_t)i : (int64_t)-1;
+    }
+}
+
+// ---- inner-block row sums / column sums of a score tensor (pooling confidence, nets/adgm.py:577-579,592-593)
+__global__ __launch_bounds__(256) void score_rowsum_kernel(const float* __restrict__ scores, int n0, int n1,
+                                                           float* __restrict__ mass0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= n0) return;
+    const float* row = scores + (long)r * (n1 + 1);
+    float s = 0.f;
+    for (int c = lane; c < n1; c += 64) s += row[c];
+    s = wave_sum(s);
+    if (lane == 0) mass0[r] = s;
+}
+__global__ __launch_bounds__(256) void score_colsum_part_kernel(const float* __restrict__ scores, int n0, int n1,
+                                                                float* __restrict__ part) {
+    __shared__ float sv[4][64];
+    const int cx = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int chunk = blockIdx.y;
+    const int c = blockIdx.x * 64 + cx;
+    float s = 0.f;
+    if (c < n1) {
+        const int rend = min(n0, (chunk + 1) * COL_CHUNK);
+        for (int r = chunk * COL_CHUNK + rg; r < rend; r += 4) s += scores[(long)r * (n1 + 1) + c];
+    }
+    sv[rg][cx] = s;
+    __syncthreads();
+    if (rg == 0 && c < n1) part[(long)chunk * n1 + c] = (sv[0][cx] + sv[1][cx]) + (sv[2][cx] + sv[3][cx]);
+}
+__global__ __launch_bounds__(256) void colsum_combine_kernel(const float* __restrict__ part, int n1, int chunks,
+                                                             float* __restrict__ mass1) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n1) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += part[(long)k * n1 + c];
+    mass1[c] = s;
+}
+
+}  // namespace
+
+hipError_t launch_ot_init(const float* dist, int batch, int n0, int n1, float bin_score, int dual,
+                          const OtBuffers& ot, hipStream_t stream) {
+    hipLaunchKernelGGL(ot_init_kernel, dim3((n0 + 1 + 3) / 4, batch), dim3(256), 0, stream, dist, n0, n1, bin_score,
+                       dual, ot.P, ot.ldp, ot.u, ot.v, ot.ldpt);
+    hipLaunchKernelGGL(ot_transpose_kernel, dim3((n1 + 1 + 31) / 32, (ot.ldpt + 31) / 32, batch), dim3(256), 0, stream,
+                       ot.P, n0 + 1, n1 + 1, ot.ldp, ot.PT, ot.ldpt);
+    return hipGetLastError();
+}
+
+hipError_t launch_ot_iterations(int batch, int n0, int n1, int iterations, const OtBuffers& ot, hipStream_t stream) {
+    constexpr int RPW = 2;
+    const dim3 g0((n0 + 1 + 4 * RPW - 1) / (4 * RPW), batch), g1((n1 + 1 + 4 * RPW - 1) / (4 * RPW), batch);
+    for (int it = 0; it < iterations; ++it) {
+        // u = r / (P v + eps)        nets/layers.py:32   (u lives with ld = ldpt: it multiplies PT's columns)
+        hipLaunchKernelGGL(ot_rowpass_kernel<RPW>, g0, dim3(256), 0, stream, ot.P, n0 + 1, ot.ldp, ot.v, ot.u, ot.ldpt);
+        // v = c / (P^T u + eps)      nets/layers.py:33
+        hipLaunchKernelGGL(ot_rowpass_kernel<RPW>, g1, dim3(256), 0, stream, ot.PT, n1 + 1, ot.ldpt, ot.u, ot.v, ot.ldp);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_ot_dual_lse(int batch, int n0, int n1, const OtBuffers& ot, hipStream_t stream) {
+    hipLaunchKernelGGL(ot_rowlse_kernel, dim3((n0 + 1 + 3) / 4, batch), dim3(256), 0, stream, ot.P, n0 + 1, n1 + 1, ot.ldp,
+                       ot.u, ot.ldpt);
+    hipLaunchKernelGGL(ot_rowlse_kernel, dim3((n1 + 1 + 3) / 4, batch), dim3(256), 0, stream, ot.PT, n1 + 1, n0 + 1,
+                       ot.ldpt, ot.v, ot.ldp);
+    return hipGetLastError();
+}
+
+hipError_t launch_ot_scores(int batch, int n0, int n1, int dual, const OtBuffers& ot, float* scores, hipStream_t stream) {
+    hipLaunchKernelGGL(ot_scores_kernel, dim3((n0 + 1 + 3) / 4, batch), dim3(256), 0, stream, ot.P, n0, n1, ot.ldp, ot.u,
+                       ot.ldpt, ot.v, dual, scores);
+    return hipGetLastError();
+}
+
+hipError_t launch_ot_maxima(int batch, int n0, int n1, int dual, const OtBuffers& ot, float* max0, int* arg0,
+                            float* max1, int* arg1, hipStream_t stream) {
+    hipLaunchKernelGGL(ot_maxima_kernel<0>, dim3((n0 + 3) / 4, batch), dim3(256), 0, stream, ot.P, n0, n1, ot.ldp, ot.u,
+                       ot.ldpt, ot.v, ot.ldp, dual, max0, arg0);
+    hipLaunchKernelGGL(ot_maxima_kernel<1>, dim3((n1 + 3) / 4, batch), dim3(256), 0, stream, ot.PT, n1, n0, ot.ldpt, ot.v,
+                       ot.ldp, ot.u, ot.ldpt, dual, max1, arg1);
+    return hipGetLastError();
+}
+
+int score_maxima_chunks(int n0) { return (n0 + COL_CHUNK - 1) / COL_CHUNK; }
+
+hipError_t launch_score_maxima(const float* scores, int batch, int n0, int n1, float* max0, int* arg0, float* max1,
+                               int* arg1, float* colpart_val, int* colpart_arg, hipStream_t stream) {
+    const int chunks = score_maxima_chunks(n0);
+    hipLaunchKernelGGL(score_rowmax_kernel, dim3((n0 + 3) / 4, batch), dim3(256), 0, stream, scores, n0, n1, max0, arg0);
+    hipLaunchKernelGGL(score_colmax_part_kernel, dim3((n1 + 63) / 64, chunks, batch), dim3(256), 0, stream, scores, n0,
+                       n1, chunks, colpart_val, colpart_arg);
+    hipLaunchKernelGGL(colmax_combine_kernel, dim3((n1 + 255) / 256, batch), dim3(256), 0, stream, colpart_val,
+                       colpart_arg, n1, chunks, max1, arg1);
+    return hipGetLastError();
+}
+
+hipError_t launch_mutual_matches(int batch, int n0, int n1, const float* max0, const int* arg0, const float* max1,
+                                 const int* arg1, float p, int64_t* indices0, int64_t* indices1, float* ms0,
+                                 float* ms1, hipStream_t stream) {
+    const int n = n0 > n1 ? n0 : n1;
+    hipLaunchKernelGGL(mutual_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, stream, n0, n1, max0, arg0, max1, arg1,
+                       p, indices0, indices1, ms0, ms1);
+    return hipGetLastError();
+}
+
+hipError_t launch_score_mass(const float* scores, int n0, int n1, float* mass0, float* mass1, float* colpart,
+                             hipStream_t stream) {
+    const int chunks = score_maxima_chunks(n0);
+    hipLaunchKernelGGL(score_rowsum_kernel, dim3((n0 + 3) / 4), dim3(256), 0, stream, scores, n0, n1, mass0);
+    hipLaunchKernelGGL(score_colsum_part_kernel, dim3((n1 + 63) / 64, chunks), dim3(256), 0, stream, scores, n0, n1,
+                       colpart);
+    hipLaunchKernelGGL(colsum_combine_kernel, dim3((n1 + 255) / 256), dim3(256), 0, stream, colpart, n1, chunks, mass1);
+    return hipGetLastError();
+}

@@ -1,0 +1,349 @@
+// Small kernels around the GEMM / attention / OT cores (gfx950):
+//   normalize_keypoints                nets/layers.py:49-56
+//   KeypointEncoder first 3->C0 conv   nets/layers.py:85,88-90   (K = 3 is not an MFMA shape: VALU)
+//   attention column sums for pooling  nets/adgm.py:557-565      (MFMA, roles of Q and K swapped)
+//   AdaGMN.pool selection              nets/adgm.py:567-605      (threshold, LOWER medians by radix select,
+//                                                                 union, wave-ballot stream compaction)
+//   ragged gather                      eval/matching.py:166-174
+#include "imp_kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ kpts, long count, float cx, float cy,
+                                                        float scaling, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const float x = kpts[2 * i], y = kpts[2 * i + 1];
+    out[2 * i] = (x - cx) / scaling;
+    out[2 * i + 1] = (y - cy) / scaling;
+}
+
+// one thread per keypoint, 128 keypoints per block (= one statistics tile for the following InstanceNorm)
+__global__ __launch_bounds__(128) void kenc_first_kernel(Kenc0Side s0, Kenc0Side s1, int c0,
+                                                         const float* __restrict__ W0, const float* __restrict__ b0,
+                                                         float cx, float cy, float scaling) {
+    __shared__ float red[2][2][64];   // [wave][sum|sq][channel]   (c0 <= 64)
+    const Kenc0Side& S = blockIdx.y == 0 ? s0 : s1;
+    const int b = blockIdx.z, n = S.n;
+    const int tiles = (n + 127) / 128;
+    if ((int)blockIdx.x >= tiles) return;
+    const int tok = blockIdx.x * 128 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool ok = tok < n;
+    float x = 0.f, y = 0.f, sc = 0.f;
+    if (ok) {
+        x = S.kpts[((long)b * n + tok) * 2];
+        y = S.kpts[((long)b * n + tok) * 2 + 1];
+        sc = S.scores[(long)b * n + tok];
+        if (scaling > 0.f) { x = (x - cx) / scaling; y = (y - cy) / scaling; }
+    }
+    for (int c = 0; c < c0; ++c) {
+        float v = fmaf(W0[c * 3 + 2], sc, fmaf(W0[c * 3 + 1], y, W0[c * 3] * x)) + b0[c];
+        if (ok) S.y[((long)b * n + tok) * c0 + c] = v; else v = 0.f;
+        const float s = wave_sum(v), q = wave_sum(v * v);
+        if (lane == 0) { red[wave][0][c] = s; red[wave][1][c] = q; }
+    }
+    __syncthreads();
+    if (S.stats && (int)threadIdx.x < c0) {
+        float* st = S.stats + (((long)b * tiles + blockIdx.x) * c0 + threadIdx.x) * 2;
+        st[0] = red[0][0][threadIdx.x] + red[1][0][threadIdx.x];
+        st[1] = red[0][1][threadIdx.x] + red[1][1][threadIdx.x];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// colsum[b][h][key] = sum_q exp(q.k / sqrt(dh) - lse[b][h][q])   : attention mass a key receives.
+// S = Q.K^T with A = Q rows streamed through LDS (i = query) and B = K held in registers (j = key = lane),
+// so the sum over queries is an in-lane sum over the 16 accumulator registers (+ one cross-half add).
+constexpr int QT = 64;
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_colsum_kernel(const ColsumParams p, int ktiles) {
+    constexpr int LDQ = DH + 4, QS = DH / 2, F4 = QT * DH / 4, LPT = F4 / 256;
+    __shared__ __attribute__((aligned(16))) float Qs[2][QT][LDQ];
+    __shared__ __attribute__((aligned(16))) float Ls[2][QT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    int id = blockIdx.x;
+    const int kt = id % ktiles; id /= ktiles;
+    const int h = id % IMP_NUM_HEADS; id /= IMP_NUM_HEADS;
+    const int sidx = id % p.nside;
+    const int b = id / p.nside;
+    const ColsumSide& S = p.side[sidx];
+    const int nq = S.nq, nk = S.nk;
+    const int k0 = kt * 128;
+    if (k0 >= nk) return;
+    const float* Qg = S.q + b * S.sq_b + h * DH;
+    const float* Kg = S.k + b * S.sk_b + h * DH;
+    const float* Lg = S.lse + ((long)b * IMP_NUM_HEADS + h) * nq;
+
+    float kreg[QS];
+    {
+        const int krow = k0 + wave * 32 + l31;
+        const float* src = Kg + (long)(krow < nk ? krow : nk - 1) * p.ldk + half * QS;
+#pragma unroll
+        for (int c = 0; c < QS / 4; ++c) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * c);
+            kreg[4 * c] = v[0]; kreg[4 * c + 1] = v[1]; kreg[4 * c + 2] = v[2]; kreg[4 * c + 3] = v[3];
+        }
+    }
+    f32x4 rq[LPT];
+    float rl = 0.f;
+    auto load_tile = [&](int t) {
+        const int q0 = t * QT;
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            const int f = tid + j * 256;
+            const int row = f / (DH / 4), c4 = (f % (DH / 4)) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (q0 + row < nq) v = *reinterpret_cast<const f32x4*>(Qg + (long)(q0 + row) * p.ldq + c4);
+            rq[j] = v;
+        }
+        if (tid < QT) rl = (q0 + tid < nq) ? Lg[q0 + tid] : INFINITY;   // exp(s - inf) = 0 for padded queries
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            const int f = tid + j * 256;
+            const int row = f / (DH / 4), c4 = (f % (DH / 4)) * 4;
+            *reinterpret_cast<f32x4*>(&Qs[buf][row][c4]) = rq[j];
+        }
+        if (tid < QT) Ls[buf][tid] = rl;
+    };
+    float colacc = 0.f;
+    const int nt = (nq + QT - 1) / QT;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) load_tile(t + 1);
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            const float* qrow = &Qs[buf][jb * 32 + l31][half * QS];
+#pragma unroll
+            for (int c = 0; c < QS / 4; ++c) {
+                const f32x4 qf = *reinterpret_cast<const f32x4*>(qrow + 4 * c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[e], kreg[4 * c + e], sacc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 ls = *reinterpret_cast<const f32x4*>(&Ls[buf][jb * 32 + 8 * g + 4 * half]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float s = DH == 64 ? sacc[4 * g + e] * 0.125f : sacc[4 * g + e] / 5.656854249492381f;
+                    colacc += __builtin_amdgcn_exp2f((s - ls[e]) * LOG2E);
+                }
+            }
+        }
+        if (t + 1 < nt) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    colacc += __shfl_xor(colacc, 32);
+    const int key = k0 + wave * 32 + l31;
+    if (half == 0 && key < nk) {
+        if (S.kmask && !S.kmask[(long)b * nk + key]) colacc = 0.f;   // masked keys had probability exactly 0
+        S.out[((long)b * IMP_NUM_HEADS + h) * nk + key] = colacc;
+    }
+}
+
+// a[key] = (sum_h colsum[h][key]) / sum_key(...)   (nets/adgm.py:557-565), single workgroup, fixed order
+__global__ __launch_bounds__(1024) void mass_normalize_kernel(const float* __restrict__ colsum, int n,
+                                                              float* __restrict__ out) {
+    __shared__ float part[16];
+    __shared__ float total;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float loc = 0.f;
+    for (int i = tid; i < n; i += 1024) {
+        float a = 0.f;
+#pragma unroll
+        for (int h = 0; h < IMP_NUM_HEADS; ++h) a += colsum[(long)h * n + i];
+        out[i] = a;
+        loc += a;
+    }
+    loc = wave_sum(loc);
+    if (lane == 0) part[wave] = loc;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        total = t;
+    }
+    __syncthreads();
+    const float t = total;
+    for (int i = tid; i < n; i += 1024) out[i] = out[i] / t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// AdaGMN.pool selection, one 1024-thread workgroup per image side.
+__device__ __forceinline__ unsigned f2key(float f) {      // order-preserving float -> uint
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+// k-th smallest (0-based) of vals[i] over i with flag[i] != 0 : 4-pass MSB radix select, LDS histogram
+__device__ float radix_select(const float* __restrict__ vals, const unsigned char* flag, int n, int k,
+                              unsigned* hist, unsigned* sh) {
+    const int tid = threadIdx.x;
+    unsigned prefix = 0, mask = 0;
+    int kk = k;
+    for (int pass = 3; pass >= 0; --pass) {
+        const int shift = pass * 8;
+        for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += blockDim.x) {
+            if (flag[i]) {
+                const unsigned key = f2key(vals[i]);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned acc = 0;
+            int bin = 0;
+            for (; bin < 256; ++bin) {
+                if (acc + hist[bin] > (unsigned)kk) break;
+                acc += hist[bin];
+            }
+            sh[0] = (unsigned)bin;
+            sh[1] = acc;
+        }
+        __syncthreads();
+        prefix |= sh[0] << shift;
+        mask |= 255u << shift;
+        kk -= (int)sh[1];
+        __syncthreads();
+    }
+    return key2f(prefix);
+}
+
+__global__ __launch_bounds__(1024) void pool_select_kernel(PoolSide s0, PoolSide s1, float thr, int32_t* counts) {
+    extern __shared__ unsigned char dyn[];          // flag[n]
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sh[2];
+    __shared__ int wcount[16];
+    __shared__ int base_s, npid_s;
+    const PoolSide& S = blockIdx.x == 0 ? s0 : s1;
+    const int n = S.n, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t* cnt = counts + 2 * blockIdx.x;
+    if (S.skip) { if (tid == 0) { cnt[0] = -1; cnt[1] = 0; } return; }
+    unsigned char* flag = dyn;
+    if (tid == 0) npid_s = 0;
+    __syncthreads();
+    int loc = 0;
+    for (int i = tid; i < n; i += 1024) {
+        const unsigned char f = S.mass[i] >= thr ? 1 : 0;      // nets/adgm.py:578-579
+        flag[i] = f;
+        loc += f;
+    }
+    if (loc) atomicAdd(&npid_s, loc);
+    __syncthreads();
+    const int npid = npid_s;
+    if (npid == 0) { if (tid == 0) { cnt[0] = -1; cnt[1] = 0; } return; }    // nets/adgm.py:580,586-587
+    const int k = (npid - 1) / 2;                                           // torch.median = lower median
+    const float md_self = radix_select(S.a_self, flag, n, k, hist, sh);
+    const float md_cross = radix_select(S.a_cross, flag, n, k, hist, sh);
+    // keep = pids | {a_self >= md_self} | {a_cross >= md_cross}; ascending ids (torch.unique sorts)
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int start = 0; start < n; start += 1024) {
+        const int i = start + tid;
+        const bool keep = i < n && (flag[i] || S.a_self[i] >= md_self || S.a_cross[i] >= md_cross);
+        const unsigned long long bal = __ballot(keep);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wcount[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wcount[w];
+        const int base = base_s;
+        if (keep) S.ids[base + woff + before] = (int64_t)i;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += wcount[w];
+            base_s = base + t;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { cnt[0] = base_s; cnt[1] = npid; }
+}
+
+__global__ __launch_bounds__(64) void gather_rows_kernel(const float* __restrict__ in, const int64_t* __restrict__ ids,
+                                                         float* __restrict__ out, int n_in, int n_out, int dim) {
+    const int b = blockIdx.y, i = blockIdx.x;
+    const long src = ids[i];
+    const f32x4* s = reinterpret_cast<const f32x4*>(in + ((long)b * n_in + src) * dim);
+    f32x4* d = reinterpret_cast<f32x4*>(out + ((long)b * n_out + i) * dim);
+    for (int c = threadIdx.x; c < dim / 4; c += 64) d[c] = s[c];
+}
+
+}  // namespace
+
+hipError_t launch_normalize_kpts(const float* kpts, long count, float width, float height, float* out,
+                                 hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    const float mx = width > height ? width : height;
+    const float scaling = mx * 0.7f;                 // size.max() * 0.7 in fp32 (nets/layers.py:55)
+    hipLaunchKernelGGL(normalize_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, kpts, count, width / 2.f,
+                       height / 2.f, scaling, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_kenc_first(const Kenc0Side sides[2], int batch, int c0, const float* W0, const float* b0,
+                             float width, float height, hipStream_t stream) {
+    const int nmax = sides[0].n > sides[1].n ? sides[0].n : sides[1].n;
+    if (nmax <= 0 || c0 > 64) return c0 > 64 ? hipErrorInvalidValue : hipSuccess;
+    float scaling = 0.f;
+    if (width > 0.f) scaling = (width > height ? width : height) * 0.7f;
+    hipLaunchKernelGGL(kenc_first_kernel, dim3((nmax + 127) / 128, 2, batch), dim3(128), 0, stream, sides[0], sides[1], c0,
+                       W0, b0, width / 2.f, height / 2.f, scaling);
+    return hipGetLastError();
+}
+
+hipError_t launch_attn_colsum_f32(const ColsumParams& p, int batch, hipStream_t stream) {
+    int maxk = p.side[0].nk;
+    if (p.nside == 2 && p.side[1].nk > maxk) maxk = p.side[1].nk;
+    if (maxk <= 0) return hipSuccess;
+    const int ktiles = (maxk + 127) / 128;
+    const int total = ktiles * IMP_NUM_HEADS * p.nside * batch;
+    if (p.dh == 64) hipLaunchKernelGGL(attn_colsum_kernel<64>, dim3(total), dim3(256), 0, stream, p, ktiles);
+    else if (p.dh == 32) hipLaunchKernelGGL(attn_colsum_kernel<32>, dim3(total), dim3(256), 0, stream, p, ktiles);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_attn_mass_normalize(const float* colsum, int n, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(mass_normalize_kernel, dim3(1), dim3(1024), 0, stream, colsum, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_pool_select(const PoolSide sides[2], int nsides, float thr, int32_t* counts, hipStream_t stream) {
+    const int nmax = (nsides == 2 && sides[1].n > sides[0].n) ? sides[1].n : sides[0].n;
+    hipLaunchKernelGGL(pool_select_kernel, dim3(nsides), dim3(1024), (size_t)((nmax + 15) & ~15), stream, sides[0],
+                       sides[nsides - 1], thr, counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_rows(const float* in, const int64_t* ids, float* out, int batch, int n_in, int n_out, int dim,
+                              hipStream_t stream) {
+    if (n_out <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(n_out, batch), dim3(64), 0, stream, in, ids, out, n_in, n_out, dim);
+    return hipGetLastError();
+}

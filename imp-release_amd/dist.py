@@ -1,0 +1,54 @@
+"""Multi-GPU partitioning of image pairs.
+
+Image pairs are independent (every op is per-sample, InstanceNorm is per-sample, the model caches are
+per-instance), so the batch / pair list is sharded over ranks with NO data-path collective; weights are
+replicated.  The only exchange is one all-gather of the per-pair results (indices0 int64 + mscores0 f32 =
+12 bytes per keypoint), issued through ``torch.distributed`` (backend "nccl" = RCCL over xGMI on the GPU
+box, "gloo" in the CPU tests).  One process per GPU.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    """contiguous balanced block [start, stop) of ``n_items`` for ``rank`` (first n % world ranks get one more)"""
+    q, r = divmod(n_items, world)
+    start = rank * q + min(rank, r)
+    return start, start + q + (1 if rank < r else 0)
+
+
+def pack_matches(indices0: torch.Tensor, mscores0: torch.Tensor) -> torch.Tensor:
+    """[b, N] int64 + [b, N] float32 -> [b, N*12] uint8 (one buffer = one collective)"""
+    b, n = indices0.shape
+    a = indices0.contiguous().view(torch.uint8).reshape(b, n * 8)
+    m = mscores0.contiguous().view(torch.uint8).reshape(b, n * 4)
+    return torch.cat([a, m], dim=1)
+
+
+def unpack_matches(buf: torch.Tensor, n: int):
+    b = buf.shape[0]
+    idx = buf[:, :n * 8].contiguous().view(torch.int64).reshape(b, n)
+    ms = buf[:, n * 8:].contiguous().view(torch.float32).reshape(b, n)
+    return idx, ms
+
+
+def all_gather_matches(indices0: torch.Tensor, mscores0: torch.Tensor, n_total: int, group=None):
+    """Every rank contributes the results of its shard_range() block; returns the full [n_total, N] tensors on
+    every rank.  Blocks are padded to ceil(n_total / world) rows so that ONE equal-size all-gather suffices."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return indices0, mscores0
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = indices0.shape[1]
+    per = -(-n_total // world)
+    local = pack_matches(indices0, mscores0)
+    pad = torch.zeros(per, n * 12, dtype=torch.uint8, device=local.device)
+    pad[:local.shape[0]] = local
+    out = torch.empty(world * per, n * 12, dtype=torch.uint8, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    rows = []
+    for r in range(world):
+        s, e = shard_range(n_total, r, world)
+        rows.append(out[r * per: r * per + (e - s)])
+    return unpack_matches(torch.cat(rows, dim=0), n)

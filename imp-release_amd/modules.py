@@ -1,0 +1,469 @@
+"""Host-side mirror of the reference's matcher modules over libimp_hip.
+
+Same constructor, ``state_dict`` key schema, method names, argument meaning and error behaviour as
+``nets/gm.py`` (GM), ``nets/gms.py`` (DGNNS = "IMP") and ``nets/adgm.py`` (AdaGMN = "EIMP") so the
+objects drop into ``eval/matching.py`` / ``eval/eval_imp.py`` style callers unchanged.
+The ``nn.Module`` tree below only *holds parameters* under the reference's names; all arithmetic
+happens in hand-written HIP kernels behind the C-ABI.  There is no torch / CPU fallback.
+
+Layout note: the reference keeps descriptors channel-major ``[B, D, N]``; the kernels are
+token-major ``[B, N, D]``.  The step API accepts and returns ``[B, D, N]``-shaped tensors whose
+*storage* is token-major (``x.transpose(1, 2)`` views) - zero-copy for the tensors the reference's
+own loops produce, one transposing copy otherwise.
+"""
+from __future__ import annotations
+
+from copy import deepcopy
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+VALID_ITS = (3, 5, 7, 9, 11, 13, 14)       # eval/matching.py:43,154
+
+
+def _sharing_pattern(n, model):
+    if model == 'GM':
+        return [False] * n
+    return ([False, False] * 2 + [False, False, True, True] * 21)[:n]     # nets/gms.py:17, nets/adgm.py:18
+
+
+def _param_mlp(channels, ac_fn, norm_fn):
+    """Parameter container with the index layout of nets/layers.py:59-77 (conv j at 3j, norm at 3j+1)."""
+    layers = []
+    n = len(channels)
+    for i in range(1, n):
+        layers.append(nn.Conv1d(channels[i - 1], channels[i], kernel_size=1, bias=True))
+        if i < n - 1:
+            if norm_fn == 'in':
+                layers.append(nn.InstanceNorm1d(channels[i], eps=1e-3))
+            elif norm_fn == 'bn':
+                layers.append(nn.BatchNorm1d(channels[i], eps=1e-3))
+            if ac_fn == 'relu':
+                layers.append(nn.ReLU())
+            elif ac_fn == 'gelu':
+                layers.append(nn.GELU())
+            elif ac_fn == 'lrelu':
+                layers.append(nn.LeakyReLU(negative_slope=0.1))
+    return nn.Sequential(*layers)
+
+
+class _Holder(nn.Module):
+    """parameter holder: computing through it is a bug (the product path is the HIP library)"""
+
+    def forward(self, *a, **k):
+        raise RuntimeError('parameter container only: compute goes through libimp_hip')
+
+
+class _KeypointEncoder(_Holder):            # nets/layers.py:80-86
+    def __init__(self, feature_dim, layers, ac_fn, norm_fn):
+        super().__init__()
+        self.encoder = _param_mlp([3] + list(layers) + [feature_dim], ac_fn, norm_fn)
+        nn.init.constant_(self.encoder[-1].bias, 0.0)
+
+
+class _MultiHeadedAttention(_Holder):       # nets/layers.py:100-107
+    def __init__(self, d_model):
+        super().__init__()
+        self.merge = nn.Conv1d(d_model, d_model, kernel_size=1)
+        self.proj = nn.ModuleList([deepcopy(self.merge) for _ in range(3)])
+
+
+class _Propagation(_Holder):                # nets/layers.py:139-145 and :182-198
+    def __init__(self, feature_dim, sharing, ac_fn, norm_fn):
+        super().__init__()
+        if not sharing:
+            self.attn = _MultiHeadedAttention(feature_dim)
+        else:
+            self.proj = nn.Conv1d(feature_dim, feature_dim, kernel_size=1)
+            self.merge = nn.Conv1d(feature_dim, feature_dim, kernel_size=1)
+        self.mlp = _param_mlp([feature_dim * 2, feature_dim * 2, feature_dim], ac_fn, norm_fn)
+        nn.init.constant_(self.mlp[-1].bias, 0.0)
+
+
+class _GNN(_Holder):                        # nets/layers.py:152-159 / :221-234
+    def __init__(self, feature_dim, layer_names, sharing, ac_fn, norm_fn):
+        super().__init__()
+        self.layers = nn.ModuleList([_Propagation(feature_dim, sharing[i], ac_fn, norm_fn)
+                                     for i in range(len(layer_names))])
+        self.names = list(layer_names)
+
+
+class AttentionHandle:
+    """Stands in for the ``[B, 4, N, M]`` probability tensor the reference caches in
+    ``model.self_prob0/1`` / ``model.cross_prob0/1`` (nets/gm.py:272-283).  The kernels keep (Q, K,
+    log-sum-exp) instead; ``materialize()`` re-creates the tensor on demand."""
+
+    def __init__(self, model, which, generation, shape):
+        self._model, self.which, self.generation, self.shape = model, which, generation, shape
+
+    def is_current(self):
+        return self._model._attn_generation[self.which] == self.generation
+
+    def materialize(self) -> torch.Tensor:
+        if not self.is_current():
+            raise RuntimeError('stale attention handle: a later layer of the same kind overwrote the cached attention')
+        B, _, nq, nk = self.shape
+        return self._model._ctx.attention_prob(self.which, B, nq, nk, self._model._device())
+
+    def __repr__(self):
+        return f'AttentionHandle(which={self.which}, shape={tuple(self.shape)}, current={self.is_current()})'
+
+
+def _token_major(x: torch.Tensor) -> torch.Tensor:
+    """[B, D, N] (any strides) -> contiguous [B, N, D]; zero-copy when the storage already is token-major."""
+    t = x.transpose(1, 2)
+    return t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float()
+
+
+class GM(nn.Module):
+    """Drop-in for nets/gm.py:16 ``GM`` (inference surface)."""
+
+    MODEL = 'GM'
+    default_config = {                      # nets/gm.py:30-44
+        'descriptor_dim': 256, 'weights': 'indoor', 'keypoint_encoder': [32, 64, 128, 256],
+        'GNN_layers': ['self', 'cross'] * 9, 'sinkhorn_iterations': 20, 'match_threshold': 0.2,
+        'with_pose': False, 'n_layers': 9, 'n_min_tokens': 256, 'with_sinkhorn': True,
+        'ac_fn': 'relu', 'norm_fn': 'bn',
+    }
+
+    def __init__(self, config={}):
+        super().__init__()
+        self.config = {**self.default_config, **config}
+        self.n_layers = self.config['n_layers']
+        self.with_sinkhorn = self.config['with_sinkhorn']
+        self.match_threshold = self.config['match_threshold']
+        self.sinkhorn_iterations = self.config['sinkhorn_iterations']
+        self.n_min_tokens = self.config['n_min_tokens']
+        D = self.config['descriptor_dim']
+        names = self.config['GNN_layers']
+        self.sharing_layers = _sharing_pattern(len(names), self.MODEL)
+        self.kenc = _KeypointEncoder(D, self.config['keypoint_encoder'], self.config['ac_fn'], self.config['norm_fn'])
+        self.gnn = _GNN(D, names, self.sharing_layers, self.config['ac_fn'], self.config['norm_fn'])
+        self.final_proj = nn.ModuleList([nn.Conv1d(D, D, kernel_size=1, bias=True) for _ in range(self.n_layers)])
+        self.register_parameter('bin_score', torch.nn.Parameter(torch.tensor(1.)))
+        self._ctx: Optional[_lib.Context] = None
+        self._ctx_key = None
+        self._bin_value = 1.0
+        self._attn_generation = [0, 0, 0, 0]
+        self._attn_shape = [None] * 4
+
+    # ------------------------------------------------------------------ context management
+    def _device(self):
+        return self.bin_score.device
+
+    def _weights_version(self):
+        return (str(self._device()), tuple(p._version for p in self.parameters()),
+                tuple(b._version for b in self.buffers()))
+
+    def _ensure_ctx(self) -> _lib.Context:
+        dev = self._device()
+        if dev.type != 'cuda':
+            raise RuntimeError('imp_release_amd has no CPU path: move the module to the GPU first (.cuda())')
+        key = self._weights_version()
+        if self._ctx is None or self._ctx_key != key:
+            if self._ctx is None or self._ctx.device != dev:
+                if self._ctx is not None:
+                    self._ctx.close()
+                self._ctx = _lib.Context(self.config, self.MODEL, dev)
+            self._ctx.load_state_dict(self.state_dict())        # strict: every schema key must be present
+            self._bin_value = float(self.bin_score.detach().cpu())
+            self._ctx_key = key
+            self._attn_generation = [g + 1 for g in self._attn_generation]
+        return self._ctx
+
+    def _bin(self, dustbin):
+        if dustbin is None or dustbin is self.bin_score:
+            self._ensure_ctx()
+            return self._bin_value
+        return float(dustbin)
+
+    # ------------------------------------------------------------------ cached attention (reference attributes)
+    def _handle(self, which):
+        shp = self._attn_shape[which]
+        return None if shp is None else AttentionHandle(self, which, self._attn_generation[which], shp)
+
+    self_prob0 = property(lambda self: self._handle(0), lambda self, v: None)
+    self_prob1 = property(lambda self: self._handle(1), lambda self, v: None)
+    cross_prob1 = property(lambda self: self._handle(2), lambda self, v: None)   # image0 queries over image1 keys
+    cross_prob0 = property(lambda self: self._handle(3), lambda self, v: None)   # image1 queries over image0 keys
+
+    def _note_layer(self, layer_i, B, n0, n1):
+        if self.sharing_layers[layer_i]:
+            return
+        if self.gnn.names[layer_i] == 'cross':
+            for w, shp in ((2, (B, 4, n0, n1)), (3, (B, 4, n1, n0))):
+                self._attn_generation[w] += 1
+                self._attn_shape[w] = shp
+        else:
+            for w, shp in ((0, (B, 4, n0, n0)), (1, (B, 4, n1, n1))):
+                self._attn_generation[w] += 1
+                self._attn_shape[w] = shp
+
+    # ------------------------------------------------------------------ step API (eval/matching.py)
+    def encode_keypoint(self, norm_kpts0, norm_kpts1, scores0, scores1):
+        """nets/gm.py:287-288 -> (enc0, enc1) shaped [B, D, N]"""
+        ctx = self._ensure_ctx()
+        e0, e1 = ctx.encode_keypoints(norm_kpts0, scores0, norm_kpts1, scores1)
+        return e0.transpose(1, 2), e1.transpose(1, 2)
+
+    def forward_one_layer(self, desc0, desc1, M0, M1, layer_i):
+        """nets/gm.py:263-285 / nets/gms.py:260-282 / nets/adgm.py:528-550 (M0, M1 are ignored there too)."""
+        ctx = self._ensure_ctx()
+        d0, d1 = _token_major(desc0), _token_major(desc1)
+        o0, o1 = ctx.forward_layer(layer_i, d0, d1)
+        self._note_layer(layer_i, d0.shape[0], d0.shape[1], d1.shape[1])
+        return o0.transpose(1, 2), o1.transpose(1, 2)
+
+    def compute_distance(self, desc0, desc1, layer_id=-1):
+        """nets/gm.py:290-295"""
+        ctx = self._ensure_ctx()
+        return ctx.compute_distance(layer_id, _token_major(desc0), _token_major(desc1))
+
+    def compute_score(self, dist, dustbin, iteration):
+        """nets/gm.py:297-303"""
+        ctx = self._ensure_ctx()
+        return ctx.compute_score(dist, self._bin(dustbin), iteration, self.with_sinkhorn)
+
+    def compute_matches(self, scores, p=0.2):
+        """nets/gm.py:305-320"""
+        return self._ensure_ctx().compute_matches(scores, p)
+
+    def pool(self, **kwargs):
+        return None, None
+
+    # ------------------------------------------------------------------ whole-pair drivers
+    @staticmethod
+    def _empty_result(kpts0, kpts1):
+        shape0, shape1 = kpts0.shape[:-1], kpts1.shape[:-1]      # nets/gm.py:154-162
+        return {'matches0': kpts0.new_full(shape0, -1, dtype=torch.int)[0],
+                'matches1': kpts1.new_full(shape1, -1, dtype=torch.int)[0],
+                'matching_scores0': kpts0.new_zeros(shape0)[0],
+                'matching_scores1': kpts1.new_zeros(shape1)[0],
+                'skip_train': True}
+
+    def _inputs(self, data, need_kpts=True):
+        """-> (kpts0, kpts1, width, height): width == 0 means 'already normalised' (nets/gm.py:164-172)."""
+        if 'norm_keypoints0' in data.keys() and 'norm_keypoints1' in data.keys():
+            return data['norm_keypoints0'], data['norm_keypoints1'], 0.0, 0.0
+        if 'image0' in data.keys() and 'image1' in data.keys():
+            _, _, h0, w0 = data['image0'].shape
+            _, _, h1, w1 = data['image1'].shape
+            if (h0, w0) != (h1, w1):
+                ctx = self._ensure_ctx()
+                return (ctx.normalize_keypoints(data['keypoints0'], w0, h0),
+                        ctx.normalize_keypoints(data['keypoints1'], w1, h1), 0.0, 0.0)
+            return data['keypoints0'], data['keypoints1'], float(w0), float(h0)
+        raise ValueError('Require image shape for keypoint coordinate normalization')
+
+    def _acc_stats(self, data, indices0, nB, nI, dev):
+        """nets/gm.py:206-219 (ground-truth bookkeeping; plain tensor ops on the result indices)."""
+        if 'matching_mask' in data.keys():
+            gt_mask = data['matching_mask'].repeat(nI, 1, 1)
+            gt = torch.max(gt_mask[:, :-1, :], dim=-1, keepdim=False)[1]
+            last = gt_mask.shape[-1] - 1
+            return (torch.sum(((indices0 - gt) == 0) * (indices0 != -1) * (gt < last)) / (nB * nI),
+                    torch.sum((indices0 == -1) * (gt == last)) / (nB * nI),
+                    torch.sum(gt < last) / (nB * nI), torch.sum(gt == last) / (nB * nI))
+        z = torch.zeros(size=[], device=dev)
+        return z + 0, z + 0, z + 1, z + 1
+
+    def _run_iterations(self, data, p, only_last, want_scores):
+        """shared body of GM / DGNNS produce_matches: returns per-emitted-iteration lists"""
+        ctx = self._ensure_ctx()
+        k0, k1, w, h = self._inputs(data)
+        nI = self.n_layers
+        out = {'scores': [], 'indices0': [], 'indices1': [], 'mscores0': [], 'mscores1': []}
+        B, n0, n1 = k0.shape[0], k0.shape[1], k1.shape[1]
+        if only_last and len(self.gnn.names) == 2 * nI:
+            r = ctx.match_pair(k0, data['scores0'], data['descriptors0'], k1, data['scores1'], data['descriptors1'],
+                               w, h, self._bin(None), self.sinkhorn_iterations, self.with_sinkhorn, p,
+                               want_scores=want_scores, want_side1=True)
+            for li in range(len(self.gnn.names)):
+                self._note_layer(li, B, n0, n1)
+            for k in out:
+                if k in r:
+                    out[k].append(r[k])
+            return out
+        if w > 0:
+            k0, k1 = ctx.normalize_keypoints(k0, w, h), ctx.normalize_keypoints(k1, w, h)
+        d0, d1 = ctx.encode_keypoints(k0, data['scores0'], k1, data['scores1'], data['descriptors0'],
+                                      data['descriptors1'])
+        for it in range(nI):
+            for li in (2 * it, 2 * it + 1):
+                d0, d1 = ctx.forward_layer(li, d0, d1, inplace=True)
+                self._note_layer(li, B, n0, n1)
+            if only_last and it != nI - 1:
+                continue
+            dist = ctx.compute_distance(it, d0, d1)
+            score = ctx.compute_score(dist, self._bin(None), self.sinkhorn_iterations, self.with_sinkhorn)
+            i0, i1, m0, m1 = ctx.compute_matches(score, p)
+            out['scores'].append(score); out['indices0'].append(i0); out['indices1'].append(i1)
+            out['mscores0'].append(m0); out['mscores1'].append(m1)
+        return out
+
+    def produce_matches(self, data, p=0.2, only_last=False, **kwargs):
+        """nets/gm.py:145-247"""
+        kpts0, kpts1 = data['keypoints0'], data['keypoints1']
+        if kpts0.shape[1] == 0 or kpts1.shape[1] == 0:
+            return self._empty_result(kpts0, kpts1)
+        r = self._run_iterations(data, p, only_last, want_scores=True)
+        nB = kpts0.shape[0]
+        nI = len(r['indices0'])
+        acc = self._acc_stats(data, torch.cat(r['indices0'], 0), nB, nI, kpts0.device)
+        return {'scores': r['scores'], 'indices0': r['indices0'], 'mscores0': r['mscores0'],
+                'acc_corr': [acc[0]], 'acc_incorr': [acc[1]], 'total_acc_corr': [acc[2]],
+                'total_acc_incorr': [acc[3]]}
+
+    def produce_matches_test(self, data, p=0.2, only_last=False, **kwargs):
+        return self.produce_matches(data=data, p=p, only_last=only_last, kwargs=kwargs)
+
+    def forward(self, data, mode=0):
+        """nets/gm.py:252-258 (training is out of scope for this build: SURVEY.md §2 #6,#13)"""
+        if not self.training:
+            if mode == 0:
+                return self.produce_matches(data=data)
+            return self.run(data=data)
+        raise NotImplementedError('forward_train is outside the inference hot path this library implements; '
+                                  'call .eval() first')
+
+    def _run_data(self, data):
+        return {'descriptors0': data['desc1'], 'descriptors1': data['desc2'],
+                'norm_keypoints0': data['x1'][:, :, :2], 'norm_keypoints1': data['x2'][:, :, :2],
+                'scores0': data['x1'][:, :, -1], 'scores1': data['x2'][:, :, -1],
+                'keypoints0': data['x1'][:, :, :2], 'keypoints1': data['x2'][:, :, :2]}
+
+    def run(self, data):
+        """nets/gm.py:322-364 -> {'p': scores[B, N+1, M+1]}"""
+        r = self._run_iterations(self._run_data(data), self.match_threshold, True, want_scores=True)
+        return {'p': r['scores'][-1]}
+
+
+class DGNNS(GM):
+    """Drop-in for nets/gms.py:15 ``DGNNS`` ("IMP"): attention-sharing GNN."""
+    MODEL = 'DGNNS'
+
+    def produce_matches(self, data, p=0.2, only_last=False, **kwargs):
+        """nets/gms.py:139-258.  'prob00/01/11/10' hold AttentionHandle objects (the reference retains up to
+        60 x 67 MB tensors here); only the last iteration's handles stay current."""
+        kpts0, kpts1 = data['keypoints0'], data['keypoints1']
+        if kpts0.shape[1] == 0 or kpts1.shape[1] == 0:
+            return self._empty_result(kpts0, kpts1)
+        r = self._run_iterations(data, p, only_last, want_scores=False)
+        nI = self.n_layers
+        return {'indices0': r['indices0'], 'mscores0': r['mscores0'],
+                'prob00': [self.self_prob0] * nI, 'prob01': [self.cross_prob0] * nI,
+                'prob11': [self.self_prob1] * nI, 'prob10': [self.cross_prob1] * nI}
+
+    def run(self, data):
+        """nets/gms.py:284-314 -> {'index0', 'index1'}.  (The reference version raises KeyError('keypoints0')
+        because it forwards a dict without keypoints to produce_matches; this one works as evidently intended.)"""
+        out = self.produce_matches(self._run_data(data), p=self.config['match_threshold'], only_last=True)
+        indices0 = out['indices0'][-1][0]
+        index0 = torch.where(indices0 >= 0)[0]
+        return {'index0': index0, 'index1': indices0[index0]}
+
+
+class AdaGMN(GM):
+    """Drop-in for nets/adgm.py:15 ``AdaGMN`` ("EIMP"): attention sharing + adaptive pooling."""
+    MODEL = 'AdaGMN'
+
+    def __init__(self, config={}):
+        self.pool_sizes = [0, 0] * 2 + [0, 0, 0, 0] * 21
+        super().__init__(config={**config, **{'pool_sizes': self.pool_sizes}})
+        self.with_ada = True
+        self.first_it_to_update = 2
+
+    def pool(self, pred_score, prob00=None, prob01=None, prob11=None, prob10=None, mscore_th=0.1,
+             uncertainty_ratio=1.0, n_min_tokens=256):
+        """nets/adgm.py:552-605.  The prob arguments must be this model's current cached attention
+        (``model.self_prob0`` ... as eval/matching.py:185-188,254 passes them); the column sums are computed
+        from the cached (Q, K, lse) by an MFMA kernel, never from a materialised [1,4,N,M] tensor."""
+        for name, h in (('prob00', prob00), ('prob01', prob01), ('prob11', prob11), ('prob10', prob10)):
+            if h is not None and not (isinstance(h, AttentionHandle) and h._model is self and h.is_current()):
+                raise TypeError(f'{name}: expected the current model.self_prob*/cross_prob* handle of this model')
+        return self._ensure_ctx().pool(pred_score, mscore_th, uncertainty_ratio, n_min_tokens)
+
+    def produce_matches(self, data, p=0.2, mscore_th=0.1, uncertainty_ratio=1., **kwargs):
+        """nets/adgm.py:327-526: *masked* adaptive pooling (tensors keep their size; pruned keypoints are
+        masked out as attention keys and excluded from scoring)."""
+        ctx = self._ensure_ctx()
+        k0, k1, w, h = self._inputs(data)
+        if w > 0:
+            k0, k1 = ctx.normalize_keypoints(k0, w, h), ctx.normalize_keypoints(k1, w, h)
+        d0, d1 = ctx.encode_keypoints(k0, data['scores0'], k1, data['scores1'], data['descriptors0'],
+                                      data['descriptors1'])
+        nB, nK0, nK1 = d0.shape[0], d0.shape[1], d1.shape[1]
+        dev = d0.device
+        nI = self.config['n_layers']
+        n_min = self.n_min_tokens
+        binv = self._bin(None)
+        gids0 = [torch.arange(nK0, device=dev) for _ in range(nB)]
+        gids1 = [torch.arange(nK1, device=dev) for _ in range(nB)]
+        mask0 = mask1 = None                  # uint8 [B, n]: "keypoint is still a valid attention key"
+        all_i0, all_m0, pred_score = [], [], None
+        for ni in range(nI):
+            d0, d1 = ctx.forward_layer(2 * ni, d0, d1, mask0, mask1, inplace=True)
+            self._note_layer(2 * ni, nB, nK0, nK1)
+            cm0, cm1 = (None, None) if ni == 3 else (mask0, mask1)          # nets/adgm.py:392,396
+            d0, d1 = ctx.forward_layer(2 * ni + 1, d0, d1, cm0, cm1, inplace=True)
+            self._note_layer(2 * ni + 1, nB, nK0, nK1)
+            if ni < self.first_it_to_update:
+                score = ctx.compute_score(ctx.compute_distance(ni, d0, d1), binv, self.sinkhorn_iterations,
+                                          self.with_sinkhorn)
+                i0, _, m0, _ = ctx.compute_matches(score, p)
+                pred_score = score
+                all_i0.append(i0); all_m0.append(m0)
+                continue
+            b_i0 = torch.full((nB, nK0), -1, device=dev, dtype=torch.long)
+            b_m0 = torch.zeros(nB, nK0, device=dev)
+            updating = self.sharing_layers[2 * ni]
+            if updating:
+                a00 = ctx.attention_received(0, nB, nK0, dev); a11 = ctx.attention_received(1, nB, nK1, dev)
+                a10 = ctx.attention_received(2, nB, nK1, dev); a01 = ctx.attention_received(3, nB, nK0, dev)
+                mask0 = torch.zeros(nB, nK0, device=dev, dtype=torch.uint8)
+                mask1 = torch.zeros(nB, nK1, device=dev, dtype=torch.uint8)
+            for bi in range(nB):
+                g0, g1 = gids0[bi], gids1[bi]
+                full = g0.numel() == nK0 and g1.numel() == nK1
+                s0 = d0[bi:bi + 1] if full else ctx.gather_rows(d0[bi:bi + 1], g0)
+                s1 = d1[bi:bi + 1] if full else ctx.gather_rows(d1[bi:bi + 1], g1)
+                # final_proj is per token, so projecting the gathered tokens == gathering the projection
+                score = ctx.compute_score(ctx.compute_distance(ni, s0, s1), binv, self.sinkhorn_iterations,
+                                          self.with_sinkhorn)
+                i0, _, m0, _ = ctx.compute_matches(score, p)
+                i0, m0 = i0[0], m0[0]
+                v0 = i0 >= 0
+                b_i0[bi, g0[v0]] = g1[i0[v0]]
+                b_m0[bi, g0] = m0
+                pred_score = score
+                if updating:
+                    thr = mscore_th * uncertainty_ratio
+                    mass0, mass1 = ctx.score_mass(score[0])
+                    if not (n_min > 0 and g0.numel() <= n_min):               # nets/adgm.py:465 (N, not N+1)
+                        f0 = ctx.pool_select(mass0, a00[bi][g0], a01[bi][g0], thr)
+                        if f0 is not None:
+                            g0 = g0[f0]
+                    if not (n_min > 0 and g1.numel() <= n_min):
+                        f1 = ctx.pool_select(mass1, a11[bi][g1], a10[bi][g1], thr)
+                        if f1 is not None:
+                            g1 = g1[f1]
+                    gids0[bi], gids1[bi] = g0, g1
+                    mask0[bi, g0] = 1
+                    mask1[bi, g1] = 1
+            all_i0.append(b_i0); all_m0.append(b_m0)
+        z = torch.zeros(size=[], device=dev)
+        return {'scores': [pred_score], 'indices0': all_i0, 'mscores0': all_m0, 'acc_corr': [z + 0],
+                'acc_incorr': [z + 0], 'total_acc_corr': [z + 1], 'total_acc_incorr': [z + 1]}
+
+    def run(self, data):
+        """nets/adgm.py:607-635"""
+        out = self.produce_matches_test(self._run_data(data), p=self.config['match_threshold'])
+        indices0 = out['indices0'][-1][0]
+        index0 = torch.where(indices0 >= 0)[0]
+        return {'index0': index0, 'index1': indices0[index0]}
+
+    def produce_matches_test(self, data, p=0.2, only_last=False, **kwargs):
+        return self.produce_matches(data=data, p=p)

@@ -1,0 +1,192 @@
+/*
+ * imp_hip.h -- C-ABI of the MI355X (gfx950) implementation of the IMP / EIMP matching hot path.
+ *
+ * The reference (feixue94/imp-release) has no FFI layer: its boundary is the Python nn.Module
+ * surface of GM / DGNNS / AdaGMN.  This library sits directly below that
+ * surface; each entry point replaces one reference method (cited per function, paths relative to
+ * the reference root) and is what a ctypes / cffi / pybind stub in the reference would bind
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch / C++ types.  `stream` is a hipStream_t passed
+ *    as void* (NULL = default stream).  All launches are asynchronous on that stream; no entry
+ *    point synchronises the host unless its comment says so.
+ *  - All tensors are DEVICE pointers to float32 unless stated, TOKEN-MAJOR and contiguous:
+ *      descriptors / encodings  [B][N][D]      (the reference keeps [B][D][N]; the host mirror
+ *                                               hands out transposed views)
+ *      keypoints                [B][N][2]       scores [B][N]
+ *      dist                     [B][N0][N1]     score matrix [B][N0+1][N1+1]
+ *      indices                  int64 [B][N]    (-1 = unmatched, as nets/gm.py:317-318)
+ *    "side 0" has n0 keypoints per image, "side 1" has n1; both are uniform over the batch B
+ *    (exactly as the reference's rectangular [B,N,*] tensors).
+ *  - Return value: 0 = ok, <0 = error (IMP_E_*); message via imp_last_error().  No exceptions,
+ *    no caller-visible allocation.  A context is bound to one device, is NOT thread-safe, and -
+ *    like the reference modules (nets/gm.py:79-82, nets/layers.py:132,209,216) - is stateful:
+ *    it caches the last self / cross attention operands for the attention-sharing layers and
+ *    for pooling.  One in-flight pair batch per context.
+ *  - Arithmetic: float32 end-to-end (fp32-input MFMA for every GEMM-shaped op), int64 indices.
+ */
+#ifndef IMP_HIP_H
+#define IMP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMP_OK 0
+#define IMP_E_ARG (-1)      /* bad argument / shape */
+#define IMP_E_STATE (-2)    /* call order (weights not finalised, no cached attention, ...) */
+#define IMP_E_HIP (-3)      /* HIP runtime error */
+#define IMP_E_NOMEM (-4)
+#define IMP_E_KEY (-5)      /* unknown / missing state_dict key */
+
+/* model flavours: which GNN layers re-use the previous iteration's attention
+ * (nets/gm.py:62 GM = none; nets/gms.py:17 DGNNS and nets/adgm.py:18 AdaGMN = [F,F]*2+[F,F,T,T]*21) */
+#define IMP_MODEL_GM 0
+#define IMP_MODEL_DGNNS 1
+#define IMP_MODEL_ADAGMN 2
+
+#define IMP_NORM_IN 0       /* nn.InstanceNorm1d(eps=1e-3)  nets/layers.py:67-68 */
+#define IMP_NORM_BN 1       /* nn.BatchNorm1d(eps=1e-3), eval mode  nets/layers.py:69-70 */
+#define IMP_ACT_RELU 0      /* nets/layers.py:71-76 */
+#define IMP_ACT_GELU 1
+#define IMP_ACT_LRELU 2
+
+typedef struct imp_ctx imp_ctx;
+
+typedef struct imp_config {
+    int32_t model;            /* IMP_MODEL_* */
+    int32_t descriptor_dim;   /* 256 (SuperPoint) or 128 (SIFT); nets/gm.py:31, eval/eval_imp.py:260 */
+    int32_t n_gnn_layers;     /* len(config['GNN_layers']); layer i is 'self' if i even else 'cross' */
+    int32_t n_layers;         /* number of final_proj heads (config['n_layers']) */
+    int32_t kenc_channels[8]; /* config['keypoint_encoder'], zero-terminated, e.g. {32,64,128,256,0} */
+    int32_t norm_fn;          /* IMP_NORM_* */
+    int32_t ac_fn;            /* IMP_ACT_* */
+    int32_t max_batch;        /* workspace sizing: pairs per call */
+    int32_t max_keypoints;    /* workspace sizing: max(n0, n1) */
+    int32_t layer_is_cross[128]; /* per GNN layer: 0 = 'self', 1 = 'cross' (config['GNN_layers']) */
+} imp_config;
+
+const char* imp_last_error(void);
+/* library / build identification, e.g. "imp_hip 0.1 gfx950 f32-mfma" */
+const char* imp_version(void);
+
+/* GM.__init__ (nets/gm.py:46-82) + .cuda(): allocates packed-weight storage and workspace on `device`. */
+int imp_create(imp_ctx** out, const imp_config* cfg, int device);
+int imp_destroy(imp_ctx* ctx);
+
+/* load_state_dict(strict=True) (eval/eval_imp.py:333): one call per tensor, `key` is the reference
+ * state_dict key ("kenc.encoder.0.weight", "gnn.layers.3.attn.proj.1.bias", "bin_score", ...),
+ * `data` is a HOST pointer to float32 in the reference's own layout ([out][in][1] for conv weights).
+ * imp_finalize_weights() checks that every key of the schema was supplied (IMP_E_KEY otherwise),
+ * and packs: attention projections are concatenated to one [3D][D] matrix with rows permuted from the
+ * reference's interleaved head layout (channel = d*4 + h, nets/layers.py:119-120) to head-major. */
+int imp_load_tensor(imp_ctx* ctx, const char* key, const float* data, const int64_t* shape, int ndim);
+int imp_finalize_weights(imp_ctx* ctx);
+/* number of schema keys / i-th key (so a host can enumerate what strict loading expects) */
+int imp_num_keys(imp_ctx* ctx);
+const char* imp_key_name(imp_ctx* ctx, int i);
+
+/* normalize_keypoints (nets/layers.py:49-56): (kpts - [w,h]/2) / (0.7*max(w,h)); kpts,out [B][n][2] */
+int imp_normalize_keypoints(imp_ctx* ctx, const float* kpts, int batch, int n, float width, float height,
+                            float* out, void* stream);
+
+/* GM.encode_keypoint / KeypointEncoder.forward (nets/gm.py:287-288, nets/layers.py:80-90).
+ * enc = MLP(cat(norm_kpts, scores)); if `desc*` is non-NULL the residual add of nets/gm.py:177-178 is
+ * fused: out = desc + enc.  out* [B][n*][D]. */
+int imp_encode_keypoints(imp_ctx* ctx, int batch, int n0, int n1,
+                         const float* nkpts0, const float* scores0, const float* desc0, float* out0,
+                         const float* nkpts1, const float* scores1, const float* desc1, float* out1,
+                         void* stream);
+
+/* GM/DGNNS/AdaGMN.forward_one_layer (nets/gm.py:263-285, nets/gms.py:260-282, nets/adgm.py:528-550):
+ * one (Shared)AttentionalPropagation layer on both images, both deltas from the pre-update
+ * descriptors, out = desc + delta (out may alias desc).  Shared layers (DGNNS/AdaGMN) re-use the
+ * attention of the previous layer of the same kind, which this context caches as (Q, K, row
+ * log-sum-exp) rather than as the [B][4][N][M] probability tensor of nets/layers.py:132.
+ * key_mask0/1: optional uint8 [B][n] "key is kept" masks for the masked attention of
+ * AdaGMN.produce_matches (nets/adgm.py:377-396, nets/layers.py:124-127): key_mask0 masks the
+ * image-0 keypoints wherever they act as keys, key_mask1 the image-1 keypoints. */
+int imp_forward_layer(imp_ctx* ctx, int layer_i, int batch, int n0, int n1,
+                      const float* desc0, const float* desc1, float* out0, float* out1,
+                      const uint8_t* key_mask0, const uint8_t* key_mask1, void* stream);
+
+/* Materialise a cached attention probability tensor (what the reference keeps in
+ * model.self_prob0/1, model.cross_prob0/1, nets/gm.py:272-283): which = 0 self image0 [B][4][n0][n0],
+ * 1 self image1 [B][4][n1][n1], 2 cross image0<-image1 [B][4][n0][n1] (reference "cross_prob1"),
+ * 3 cross image1<-image0 [B][4][n1][n0] (reference "cross_prob0"). */
+int imp_attention_prob(imp_ctx* ctx, int which, float* prob, void* stream);
+
+/* Attention mass received per key, summed over heads and queries and L1-normalised per batch element
+ * (nets/adgm.py:424-432 / 557-565) for one cached probability matrix (`which` as above); out [B][nk]. */
+int imp_attention_received(imp_ctx* ctx, int which, float* out, void* stream);
+
+/* GM.compute_distance (nets/gm.py:290-295): final_proj[layer_id] on both sides, dot / sqrt(D). */
+int imp_compute_distance(imp_ctx* ctx, int layer_id, int batch, int n0, int n1,
+                         const float* desc0, const float* desc1, float* dist, void* stream);
+
+/* GM.compute_score (nets/gm.py:297-303) -> sink_algorithm (nets/layers.py:38-46, 27-35) or
+ * dual_softmax (nets/layers.py:20-24).  dist [B][n0][n1]; scores [B][n0+1][n1+1] (may be NULL when
+ * only the fused match extraction below is wanted).  `bin_score` < 0 is NOT special: pass the value. */
+int imp_compute_score(imp_ctx* ctx, int batch, int n0, int n1, const float* dist, float bin_score,
+                      int iterations, int with_sinkhorn, float* scores, void* stream);
+
+/* GM.compute_matches (nets/gm.py:305-320) on an arbitrary score tensor [B][n0+1][n1+1]. */
+int imp_compute_matches(imp_ctx* ctx, int batch, int n0, int n1, const float* scores, float p,
+                        int64_t* indices0, int64_t* indices1, float* mscores0, float* mscores1, void* stream);
+
+/* AdaGMN.pool (nets/adgm.py:552-605) for batch element 0 using the cached attention of the last
+ * self and cross layers.  ids0/ids1: int64 [n0]/[n1] output buffers (ascending kept ids);
+ * counts: int32[4] DEVICE buffer = {n_keep0, n_confident0, n_keep1, n_confident1}; a side whose
+ * n_confident is 0 or that is skipped by n_min_tokens reports n_keep = -1 (reference: None). */
+int imp_pool(imp_ctx* ctx, int n0, int n1, const float* scores, float mscore_th, float uncertainty_ratio,
+             int n_min_tokens, int64_t* ids0, int64_t* ids1, int32_t* counts, void* stream);
+
+/* Matching confidence per keypoint used by the pooling (nets/adgm.py:476-477,488-489): row sums and column
+ * sums of the inner n0 x n1 block of one score matrix [n0+1][n1+1]; mass0 [n0], mass1 [n1]. */
+int imp_score_mass(imp_ctx* ctx, int n0, int n1, const float* scores, float* mass0, float* mass1, void* stream);
+
+/* One side of the pooling selection on caller-supplied vectors of length n (the masked variant of
+ * AdaGMN.produce_matches, nets/adgm.py:475-497, works on gathered subsets): confident = mass >= thr;
+ * keep = confident | a_self >= lower_median(a_self[confident]) | a_cross >= lower_median(a_cross[confident]).
+ * ids int64 [n]; counts int32[2] DEVICE = {n_keep or -1 when nothing is confident, n_confident}. */
+int imp_pool_select(imp_ctx* ctx, int n, const float* mass, const float* a_self, const float* a_cross, float thr,
+                    int64_t* ids, int32_t* counts, void* stream);
+
+/* desc[:, :, sel_ids] of eval/matching.py:166-174 on token-major data: out[b][i][:] = in[b][ids[i]][:] */
+int imp_gather_rows(imp_ctx* ctx, int batch, int n_in, int n_out, int dim, const float* in,
+                    const int64_t* ids, float* out, void* stream);
+
+/* Fused one-shot matcher = GM/DGNNS.produce_matches(data, p, only_last=True)
+ * (nets/gm.py:145-247, nets/gms.py:139-258): normalise (if width>0, else kpts are already
+ * normalised), encode, all GNN layers, final_proj[n_layers-1], Sinkhorn / dual-softmax, mutual matches.
+ * Nothing is synchronised; outputs: indices0 int64 [B][n0], mscores0 [B][n0] (+ optional indices1,
+ * mscores1, scores [B][n0+1][n1+1], any of which may be NULL). */
+int imp_match_pair(imp_ctx* ctx, int batch, int n0, int n1,
+                   const float* kpts0, const float* scores0, const float* desc0,
+                   const float* kpts1, const float* scores1, const float* desc1,
+                   float width, float height, float bin_score, int sinkhorn_iterations, int with_sinkhorn,
+                   float p, int64_t* indices0, float* mscores0, int64_t* indices1, float* mscores1,
+                   float* scores, void* stream);
+
+/* ---- op-level entry points (used by the parity tests and by bench.py's roofline leg) ---------- */
+
+/* y[M][N] = x[M][K] @ W[N][K]^T + bias   (fp32 MFMA GEMM that every 1x1 conv maps to) */
+int imp_op_linear(imp_ctx* ctx, int M, int N, int K, const float* x, const float* W, const float* bias,
+                  float* y, void* stream);
+/* multi-head attention core on packed projections: qkv_q [B][nq][3D], qkv_kv [B][nk][3D]
+ * (q | k | v, head-major), out [B][nq][D], lse [B][4][nq] (optional).  nets/layers.py:121-131 */
+int imp_op_attention(imp_ctx* ctx, int batch, int nq, int nk, int dim, const float* qkv_q,
+                     const float* qkv_kv, const uint8_t* key_mask, float* out, float* lse, void* stream);
+/* timing hooks for bench.py: hipEvent-bracketed repetition of one attention / one Sinkhorn pass on
+ * the context's own stream-ordered workspace; returns average milliseconds per launch in *ms. */
+int imp_time_attention(imp_ctx* ctx, int batch, int n, int reps, float* ms, void* stream);
+/* same for the Sinkhorn row pass: 2*iterations launches over [batch][n+1][n+1]; *ms = average per launch */
+int imp_time_sinkhorn(imp_ctx* ctx, int batch, int n, int iterations, float* ms, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMP_HIP_H */

@@ -1,0 +1,212 @@
+"""GPU: every kernel behind the C-ABI against the oracle / an fp64 torch reference on seeded inputs.
+Tolerances are written per test; indices are compared exactly."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import eval_config, make_hip_model
+from imp_release_amd import synthetic
+from oracle import imp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _model(model='GM', **over):
+    cfg = eval_config(**{'n_layers': 2, **over})
+    sd = synthetic.make_state_dict(cfg, model=model, seed=5)
+    return cfg, sd, make_hip_model(model, cfg, sd), orc.MatcherOracle(cfg, sd, model=model)
+
+
+@pytest.fixture(scope='module')
+def gm():
+    return _model()
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 256, 256), (2048, 768, 256), (64, 32, 32), (1, 512, 512), (257, 129, 64),
+                                   (130, 256, 512), (1000, 1000, 256)])
+def test_linear_fp32_mfma(gm, M, N, K):
+    ctx = gm[2]._ensure_ctx()
+    x, W, b = _rand(M, K, seed=1), _rand(N, K, seed=2) / K ** .5, _rand(N, seed=3)
+    y = ctx.op_linear(x.to(DEV), W.to(DEV), b.to(DEV)).cpu()
+    ref = (x.double() @ W.double().t() + b.double())
+    err = (y.double() - ref).abs().max().item()
+    assert err < 2e-6 * max(1.0, ref.abs().max().item()) * (K / 32) ** .5, f'linear {M}x{N}x{K}: max err {err:.3e}'
+    # transposition check (asymmetric operands): compare against the transposed product explicitly
+    if M == N:
+        assert (y.double() - ref.t()).abs().max().item() > 1e-2
+
+
+def _ref_attention(qkv_q, qkv_kv, D, mask=None):
+    """fp64 reference of nets/layers.py:121-131 on packed head-major projections"""
+    B, nq, _ = qkv_q.shape
+    nk = qkv_kv.shape[1]
+    dh = D // 4
+    q = qkv_q[..., :D].double().view(B, nq, 4, dh).transpose(1, 2)
+    k = qkv_kv[..., D:2 * D].double().view(B, nk, 4, dh).transpose(1, 2)
+    v = qkv_kv[..., 2 * D:].double().view(B, nk, 4, dh).transpose(1, 2)
+    s = q @ k.transpose(-1, -2) / dh ** .5
+    if mask is not None:
+        s = s.masked_fill(~mask[:, None, None, :].bool(), -torch.finfo(torch.float32).max)
+    prob = torch.softmax(s, -1)
+    out = (prob @ v).transpose(1, 2).reshape(B, nq, D)
+    return out, torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize('B,nq,nk,D,masked', [(1, 128, 128, 256, False), (2, 300, 307, 256, False),
+                                              (1, 64, 2048, 256, False), (4, 1024, 1024, 256, False),
+                                              (1, 200, 190, 128, False), (2, 257, 131, 256, True),
+                                              (1, 33, 65, 128, True)])
+def test_attention_fp32_mfma(gm, B, nq, nk, D, masked):
+    ctx = gm[2]._ensure_ctx()
+    qq, kv = _rand(B, nq, 3 * D, seed=4), _rand(B, nk, 3 * D, seed=5)
+    mask = None
+    if masked:
+        mask = (torch.rand(B, nk, generator=torch.Generator().manual_seed(6)) > 0.4).to(torch.uint8)
+        mask[:, :70] = 0                      # a whole first key tile masked out
+        mask[:, -1] = 1
+    out, lse = ctx.op_attention(qq.to(DEV), kv.to(DEV), None if mask is None else mask.to(DEV))
+    ref, ref_lse = _ref_attention(qq, kv, D, mask)
+    e_out = (out.cpu().double() - ref).abs().max().item()
+    e_lse = (lse.cpu().double() - ref_lse).abs().max().item()
+    assert e_out < 2e-5, f'attention out err {e_out:.3e} (lse err {e_lse:.3e})'
+    assert e_lse < 2e-5, f'attention lse err {e_lse:.3e}'
+
+
+def test_attention_online_softmax_rescale_branch(gm):
+    """a key that dominates late in the stream forces the running-max rescale (rare data-dependent branch)"""
+    ctx = gm[2]._ensure_ctx()
+    B, n, D = 1, 256, 256
+    qq, kv = _rand(B, n, 3 * D, seed=7), _rand(B, n, 3 * D, seed=8)
+    kv[0, 200, D:2 * D] = qq[0, 5, :D] * 4.0          # spike: key 200 (4th tile) against query 5, all heads
+    out, lse = ctx.op_attention(qq.to(DEV), kv.to(DEV))
+    ref, ref_lse = _ref_attention(qq, kv, D)
+    assert (out.cpu().double() - ref).abs().max().item() < 5e-5
+    assert (lse.cpu().double() - ref_lse).abs().max().item() < 5e-4
+
+
+@pytest.mark.parametrize('n0,n1,T,sink', [(64, 64, 20, True), (300, 307, 100, True), (1, 5, 3, True),
+                                          (255, 256, 20, True), (130, 97, 0, False), (1024, 1000, 100, True)])
+def test_compute_score_and_matches(gm, n0, n1, T, sink):
+    cfg, sd, m, o = gm
+    ctx = m._ensure_ctx()
+    B = 2
+    dist = _rand(B, n0, n1, seed=9, scale=2.0)
+    k = min(n0, n1) // 2
+    for b in range(B):
+        ids = torch.randperm(min(n0, n1), generator=torch.Generator().manual_seed(b))[:k]
+        dist[b, ids, ids] += 6.0
+    bin_score = 1.3
+    got = ctx.compute_score(dist.to(DEV), bin_score, T, sink)
+    aug = orc.dustbin_augment(dist, torch.tensor(bin_score))
+    ref = orc.sinkhorn(aug, T) if sink else orc.dual_softmax(aug)
+    err = (got.cpu() - ref).abs().max().item()
+    assert err < 2e-5, f'compute_score err {err:.3e}'
+    if sink and T > 0:       # property: after the last step every column sums to its marginal
+        cs = got.cpu().double().sum(1)
+        assert (cs[:, :-1] - 1).abs().max().item() < 1e-4 and (cs[:, -1] - (n1 + 1)).abs().max().item() < 1e-3
+    # matches on the SAME score tensor must be identical (integer work)
+    i0, i1, m0, m1 = ctx.compute_matches(got, 0.2)
+    r0, r1, rm0, rm1 = orc.compute_matches(got.cpu(), 0.2)
+    assert torch.equal(i0.cpu(), r0) and torch.equal(i1.cpu(), r1)
+    assert torch.equal(m0.cpu(), rm0) and torch.equal(m1.cpu(), rm1)
+
+
+def test_compute_matches_tie_break_first_index(gm):
+    ctx = gm[2]._ensure_ctx()
+    s = torch.rand(1, 41, 38, generator=torch.Generator().manual_seed(3)) * 0.1
+    s[0, 3, 7] = s[0, 3, 20] = 0.9          # row tie -> first column
+    s[0, 10, 5] = s[0, 30, 5] = 0.8         # column tie -> first row
+    s[0, :, -1] = 5.0                        # dustbin column / row must be ignored
+    s[0, -1, :] = 5.0
+    got = ctx.compute_matches(s.to(DEV), 0.2)
+    ref = orc.compute_matches(s, 0.2)
+    for g, r in zip(got, ref):
+        assert torch.equal(g.cpu(), r)
+
+
+@pytest.mark.parametrize('norm,act,D', [('in', 'relu', 256), ('bn', 'lrelu', 256), ('in', 'gelu', 128)])
+def test_encode_keypoints(norm, act, D):
+    cfg, sd, m, o = _model(norm_fn=norm, ac_fn=act, descriptor_dim=D)
+    ctx = m._ensure_ctx()
+    pair = synthetic.make_pair(300, 129, desc_dim=D, seed=3, batch=2)
+    t = {k: torch.from_numpy(v) for k, v in pair.items() if k != 'image_shape'}
+    nk0 = orc.normalize_keypoints(t['keypoints0'], pair['image_shape'])
+    nk1 = orc.normalize_keypoints(t['keypoints1'], pair['image_shape'])
+    g0 = ctx.normalize_keypoints(t['keypoints0'].to(DEV), 640, 480)
+    assert (g0.cpu() - nk0).abs().max().item() < 1e-6
+    e0, e1 = ctx.encode_keypoints(nk0.to(DEV), t['scores0'].to(DEV), nk1.to(DEV), t['scores1'].to(DEV))
+    r0, r1 = o.encode_keypoint(nk0, nk1, t['scores0'], t['scores1'])
+    err = max((e0.cpu() - r0).abs().max().item(), (e1.cpu() - r1).abs().max().item())
+    assert err < 5e-5, f'kenc err {err:.3e}'
+    # fused residual
+    f0, f1 = ctx.encode_keypoints(nk0.to(DEV), t['scores0'].to(DEV), nk1.to(DEV), t['scores1'].to(DEV),
+                                  t['descriptors0'].to(DEV), t['descriptors1'].to(DEV))
+    assert (f0.cpu() - (t['descriptors0'] + r0)).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize('model,norm,D,n0,n1', [('GM', 'in', 256, 300, 307), ('GM', 'bn', 256, 128, 64),
+                                                ('DGNNS', 'in', 256, 200, 260), ('GM', 'in', 128, 150, 140)])
+def test_forward_layers_and_cached_attention(model, norm, D, n0, n1):
+    nl = 4 if model == 'DGNNS' else 2
+    cfg, sd, m, o = _model(model, norm_fn=norm, descriptor_dim=D, n_layers=nl)
+    ctx = m._ensure_ctx()
+    B = 2
+    x0, x1 = _rand(B, n0, D, seed=11, scale=0.5), _rand(B, n1, D, seed=12, scale=0.5)
+    g0, g1 = x0.to(DEV), x1.to(DEV)
+    r0, r1 = x0, x1
+    for li in range(2 * nl):
+        g0, g1 = ctx.forward_layer(li, g0, g1)
+        r0, r1 = o.forward_one_layer(r0, r1, li)
+        err = max((g0.cpu() - r0).abs().max().item(), (g1.cpu() - r1).abs().max().item())
+        assert err < 1e-4 * (li + 1), f'{model} layer {li} (shared={o.shared[li]}): err {err:.3e}'
+    # re-materialised probabilities == what the reference caches (nets/layers.py:132)
+    for which, ref in ((0, o.self_prob0), (1, o.self_prob1), (2, o.cross_prob1), (3, o.cross_prob0)):
+        got = ctx.attention_prob(which, B, ref.shape[2], ref.shape[3], DEV)
+        assert (got.cpu() - ref).abs().max().item() < 2e-5, f'prob {which}'
+        recv = ctx.attention_received(which, B, ref.shape[3], DEV)
+        assert (recv.cpu() - orc.attention_received(ref)).abs().max().item() < 1e-6, f'received {which}'
+    # compute_distance
+    d = ctx.compute_distance(nl - 1, g0, g1)
+    rd = o.compute_distance(r0, r1, nl - 1)
+    assert (d.cpu() - rd).abs().max().item() < 2e-4
+
+
+def test_pool_and_gather():
+    cfg, sd, m, o = _model('AdaGMN', n_layers=2)
+    ctx = m._ensure_ctx()
+    n0, n1, D = 333, 300, 256
+    x0, x1 = _rand(1, n0, D, seed=21, scale=0.5), _rand(1, n1, D, seed=22, scale=0.5)
+    g0, g1 = x0.to(DEV), x1.to(DEV)
+    r0, r1 = x0, x1
+    for li in range(2):
+        g0, g1 = ctx.forward_layer(li, g0, g1)
+        r0, r1 = o.forward_one_layer(r0, r1, li)
+    gen = torch.Generator().manual_seed(5)
+    score = torch.rand(1, n0 + 1, n1 + 1, generator=gen) * (0.5 / n1)
+    ids = torch.randperm(min(n0, n1), generator=gen)[:120]
+    score[0, ids, ids] += 0.4
+    for th, nmin in ((0.2, 256), (0.05, 0), (50.0, 256), (0.2, 400)):
+        got = ctx.pool(score.to(DEV), th, 1.0, nmin)
+        ref = orc.pool(score, o.self_prob0, o.cross_prob0, o.self_prob1, o.cross_prob1, th, 1.0, nmin)
+        for side in range(2):
+            if ref[side] is None:
+                assert got[side] is None, f'th={th} nmin={nmin} side {side}'
+            else:
+                assert got[side] is not None and torch.equal(got[side].cpu(), ref[side]), f'th={th} side {side}'
+    keep = torch.tensor([5, 0, 7, 300, 332])
+    assert torch.equal(ctx.gather_rows(g0, keep.to(DEV)).cpu(), g0.cpu()[:, keep])
+    # selection on caller vectors incl. an even-count lower median
+    mass = torch.tensor([0.5, 0.0, 0.9, 0.3, 0.0, 0.7])
+    a_s = torch.tensor([0.10, 0.30, 0.20, 0.40, 0.25, 0.05])
+    a_c = torch.tensor([0.60, 0.10, 0.20, 0.30, 0.90, 0.40])
+    got = ctx.pool_select(mass.to(DEV), a_s.to(DEV), a_c.to(DEV), 0.25)
+    assert torch.equal(got.cpu(), orc._pool_side(mass, a_s, a_c, 0.25))
+    m0, m1 = ctx.score_mass(score[0].to(DEV))
+    assert (m0.cpu() - score[0, :-1, :-1].sum(-1)).abs().max().item() < 1e-5
+    assert (m1.cpu() - score[0, :-1, :-1].sum(0)).abs().max().item() < 1e-5

@@ -1,0 +1,214 @@
+"""GPU: the whole hot path through the reference-shaped boundary (GM / DGNNS / AdaGMN over the C-ABI)
+against (a) the golden vectors captured from the imported reference, (b) the oracle on the same seeded
+inputs, and (c) size-independent properties at the BASELINE sizes (N = 2048) where the oracle is slow.
+
+Parity bar (BASELINE.json north_star): match indices identical, scores within 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_case, compare_matches, eval_config, golden_names, load_golden, make_hip_model
+from imp_release_amd import matching as hip_matching, synthetic
+from oracle import imp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+TOL = 1e-4
+
+
+def _cpu(x):
+    return x.detach().cpu()
+
+
+@pytest.mark.parametrize('name', golden_names(['gm_l', 'dgnns_l', 'adagmn_masked']))
+def test_produce_matches_vs_golden(name):
+    spec, z = load_golden(name)
+    cfg, sd, data = build_case(spec, DEV)
+    m = make_hip_model(spec, cfg, sd)
+    call = spec.get('call', {})
+    with torch.no_grad():
+        out = m.produce_matches(data, **call)
+    n = int(z['n_emitted'])
+    assert len(out['indices0']) == n
+    msgs = []
+    for i in range(n):
+        assert out['indices0'][i].dtype == torch.int64
+        msgs.append(compare_matches(_cpu(out['indices0'][i]), _cpu(out['mscores0'][i]), z[f'indices0_{i}'],
+                                    z[f'mscores0_{i}'], call.get('p', 0.2), TOL, f'{name}[{i}]'))
+    if 'score_rowsum' in z.files and out.get('scores'):
+        s = _cpu(out['scores'][-1])[0].double()
+        assert np.abs(s.sum(-1).numpy() - z['score_rowsum']).max() < 5e-4
+        assert np.abs(s[:8, :8].numpy() - z['score_corner']).max() < TOL
+    print('\n'.join(msgs))
+
+
+@pytest.mark.parametrize('name', golden_names(['gm_run', 'adagmn_run']))
+def test_run_vs_golden(name):
+    spec, z = load_golden(name)
+    cfg, sd, data = build_case(spec, DEV)
+    m = make_hip_model(spec, cfg, sd)
+    ctx = m._ensure_ctx()
+    nk0 = ctx.normalize_keypoints(data['keypoints0'], 640, 480)
+    nk1 = ctx.normalize_keypoints(data['keypoints1'], 640, 480)
+    rd = {'desc1': data['descriptors0'], 'desc2': data['descriptors1'],
+          'x1': torch.cat([nk0, data['scores0'][..., None]], -1), 'x2': torch.cat([nk1, data['scores1'][..., None]], -1)}
+    with torch.no_grad():
+        out = m(rd, mode=1)
+    if 'p' in out:
+        s = _cpu(out['p'])[0].double()
+        assert np.abs(s.sum(-1).numpy() - z['score_rowsum']).max() < 5e-4
+        assert np.abs(s[:8, :8].numpy() - z['score_corner']).max() < TOL
+    else:
+        assert np.array_equal(_cpu(out['index0']).numpy(), z['index0'])
+        assert np.array_equal(_cpu(out['index1']).numpy(), z['index1'])
+
+
+def _loop_data(data):
+    d = dict(data)
+    d['pts0_cpu'] = data['keypoints0'][0].cpu().numpy()
+    d['pts1_cpu'] = data['keypoints1'][0].cpu().numpy()
+    d['K0'] = d['K1'] = np.eye(3)
+    d['T_0to1'] = np.eye(4)
+    return d
+
+
+def test_imp_iterative_loop_vs_golden():
+    spec, z = load_golden('imp_loop_n400')
+    cfg, sd, data = build_case(spec, DEV)
+    m = make_hip_model(spec, cfg, sd)
+    with torch.no_grad():
+        i0, ms0, R, t, nit = hip_matching.matching_iterative(_loop_data(data), m, 15, 0.1, 25, 1.0, {'pose': 1.5})
+    assert nit == int(z['n_iter']) and R is None
+    compare_matches(i0, ms0, z['indices0'], z['mscores0'], 0.2, TOL, 'imp loop final')
+
+
+def test_eimp_sliced_loop_vs_golden():
+    """BASELINE config 4 analogue: real ragged slicing (pool -> compaction -> gather), pinned to the
+    reference's pruning trajectory 1024/1000 -> 751/725 -> ... (tests/golden/eimp_loop_sliced_n1024)."""
+    spec, z = load_golden('eimp_loop_sliced_n1024')
+    cfg, sd, data = build_case(spec, DEV)
+    m = make_hip_model(spec, cfg, sd)
+    with torch.no_grad():
+        p0, p1, nk0, nk1, i0, ms0, R, t, nit = hip_matching.matching_iterative_uncertainty(
+            _loop_data(data), m, 15, 0.1, 25, 1.0, {'pose': 1.5}, with_uncertainty=False)
+    assert nit == int(z['n_iter'])
+    assert p0.shape == z['pts0_final'].shape and p1.shape == z['pts1_final'].shape, \
+        f'pruned sizes {p0.shape[0]}/{p1.shape[0]} vs reference {z["pts0_final"].shape[0]}/{z["pts1_final"].shape[0]}'
+    assert np.array_equal(p0, z['pts0_final']) and np.array_equal(p1, z['pts1_final'])
+    compare_matches(i0, ms0, z['indices0'], z['mscores0'], 0.2, TOL, 'eimp loop final')
+
+
+def test_reference_style_step_api_loop_matches_fused_path():
+    """eval/matching.py drives the model through [B, D, N] tensors (encode_keypoint, forward_one_layer,
+    compute_distance, compute_score, compute_matches): same result as the fused produce_matches."""
+    cfg = eval_config(n_layers=3)
+    sd = synthetic.make_state_dict(cfg, 'DGNNS', seed=2)
+    m = make_hip_model('DGNNS', cfg, sd)
+    pair = synthetic.make_correlated_pair(210, 190, seed=4)
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+    with torch.no_grad():
+        fused = m.produce_matches(data, p=0.2, only_last=True)
+        ctx = m._ensure_ctx()
+        nk0 = ctx.normalize_keypoints(data['keypoints0'], 640, 480)
+        nk1 = ctx.normalize_keypoints(data['keypoints1'], 640, 480)
+        desc0, desc1 = data['descriptors0'].transpose(1, 2), data['descriptors1'].transpose(1, 2)
+        enc0, enc1 = m.encode_keypoint(norm_kpts0=nk0, norm_kpts1=nk1, scores0=data['scores0'], scores1=data['scores1'])
+        assert enc0.shape == (1, 256, 210)
+        desc0, desc1 = desc0 + enc0, desc1 + enc1
+        for it in range(3):
+            desc0, desc1 = m.forward_one_layer(desc0=desc0, desc1=desc1, M0=None, M1=None, layer_i=it * 2)
+            desc0, desc1 = m.forward_one_layer(desc0=desc0, desc1=desc1, M0=None, M1=None, layer_i=it * 2 + 1)
+        dist = m.compute_distance(desc0=desc0, desc1=desc1, layer_id=2)
+        score = m.compute_score(dist=dist, dustbin=m.bin_score, iteration=m.sinkhorn_iterations)
+        i0, i1, ms0, ms1 = m.compute_matches(scores=score, p=0.2)
+    assert m.self_prob0.materialize().shape == (1, 4, 210, 210) and m.cross_prob0.shape == (1, 4, 190, 210)
+    assert torch.equal(i0, fused['indices0'][-1]) and torch.equal(ms0, fused['mscores0'][-1])
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE sizes (N = 2048, L = 9, T = 100): oracle comparison once + size-independent properties
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def big():
+    cfg = eval_config(n_layers=9, sinkhorn_iterations=100)
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=1)
+    m = make_hip_model('GM', cfg, sd)
+    pair = synthetic.make_correlated_pair(2048, 2048, seed=31, batch=2)
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+    with torch.no_grad():
+        out = m.produce_matches(data, p=0.2, only_last=True)
+    return cfg, sd, m, pair, data, out
+
+
+def test_full_size_vs_oracle(big):
+    cfg, sd, m, pair, data, out = big
+    o = orc.MatcherOracle(cfg, sd, 'GM')
+    cdata = {k: v[:1].cpu() for k, v in data.items()}
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = o.produce_matches(cdata, p=0.2, only_last=True)
+    print(compare_matches(_cpu(out['indices0'][-1][:1]), _cpu(out['mscores0'][-1][:1]), ref['indices0'][-1].numpy(),
+                          ref['mscores0'][-1].numpy(), 0.2, TOL, 'N=2048 L=9 T=100'))
+
+
+def test_full_size_properties(big):
+    cfg, sd, m, pair, data, out = big
+    i0, ms0, score = out['indices0'][-1], out['mscores0'][-1], out['scores'][-1]
+    B, N = i0.shape
+    assert int((i0 >= 0).sum()) > 0.2 * N * B
+    # Sinkhorn: columns meet their marginals exactly after the last step; everything finite and non-negative
+    cs = score.double().sum(1)
+    assert (cs[:, :-1] - 1).abs().max().item() < 1e-4 and (cs[:, -1] - (N + 1)).abs().max().item() < 2e-3
+    assert torch.isfinite(score).all() and (score >= 0).all()
+    # mutual consistency recomputed from the score tensor (integer work: exact)
+    r0, r1, rm0, rm1 = m.compute_matches(score, 0.2)
+    assert torch.equal(r0, i0) and torch.equal(rm0, ms0)
+    for b in range(B):
+        v = torch.where(r0[b] >= 0)[0]
+        assert torch.equal(r1[b][r0[b][v]], v)
+    # batch invariance: pair 1 alone == pair 1 inside the batch (per-sample ops only)
+    solo = {k: (v[1:2] if v.shape[0] == B else v) for k, v in data.items()}
+    with torch.no_grad():
+        o1 = m.produce_matches(solo, p=0.2, only_last=True)
+    print(compare_matches(_cpu(o1['indices0'][-1]), _cpu(o1['mscores0'][-1]), _cpu(i0[1:2]).numpy(), _cpu(ms0[1:2]).numpy(),
+                          0.2, TOL, 'batch invariance'))
+    # permutation equivariance: shuffling image 1's keypoints permutes the matches accordingly
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(1)).to(DEV)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(N, device=DEV)
+    shuf = dict(solo)
+    for k in ('keypoints1', 'scores1', 'descriptors1'):
+        shuf[k] = solo[k][:, perm]
+    with torch.no_grad():
+        o2 = m.produce_matches(shuf, p=0.2, only_last=True)
+    j = o2['indices0'][-1][0]
+    mapped = torch.where(j >= 0, perm[j.clamp(min=0)], j)
+    print(compare_matches(_cpu(mapped)[None], _cpu(o2['mscores0'][-1]), _cpu(o1['indices0'][-1]).numpy(),
+                          _cpu(o1['mscores0'][-1]).numpy(), 0.2, TOL, 'permutation equivariance'))
+    # determinism: identical bits run to run (fixed reduction orders, no float atomics)
+    with torch.no_grad():
+        o3 = m.produce_matches(solo, p=0.2, only_last=True)
+    assert torch.equal(o3['indices0'][-1], o1['indices0'][-1]) and torch.equal(o3['mscores0'][-1], o1['mscores0'][-1])
+    assert torch.equal(o3['scores'][-1], o1['scores'][-1])
+
+
+def test_eimp_pruning_path_at_4096():
+    """BASELINE config 4 size: N = 4096 start, sliced EIMP loop, pruning must happen and stay consistent."""
+    cfg = eval_config()
+    sd = synthetic.make_state_dict(cfg, 'AdaGMN', seed=9, bin_score=5.0)
+    m = make_hip_model('AdaGMN', cfg, sd)
+    pair = synthetic.make_correlated_pair(4096, 4000, seed=41)
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+    with torch.no_grad():
+        p0, p1, nk0, nk1, i0, ms0, R, t, nit = hip_matching.matching_iterative_uncertainty(
+            _loop_data(data), m, 15, 0.1, 25, 1.0, {'pose': 1.5})
+    assert nit == 15 and p0.shape[0] < 4096 and p1.shape[0] < 4000 and p0.shape[0] == i0.shape[0]
+    # survivors are a subsequence of the original keypoints (compaction keeps ascending order)
+    k0 = pair['keypoints0'][0]
+    pos = [np.nonzero((k0 == r).all(1))[0][0] for r in p0[:50]]
+    assert pos == sorted(pos)
+    assert ((i0 >= -1) & (i0 < p1.shape[0])).all()
+    print(f'N trajectory end: {p0.shape[0]}/{p1.shape[0]}, matches {(i0 >= 0).sum()}')

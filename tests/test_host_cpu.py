@@ -1,0 +1,136 @@
+"""CPU: host logic, C-ABI surface (load + symbols only, no compute without a GPU), multi-rank sharding."""
+import ctypes
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import imp_release_amd as P
+from imp_release_amd import _lib, dist as pdist, synthetic
+from helpers import ROOT, eval_config
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = _lib.lib()
+    header = open(os.path.join(ROOT, 'include', 'imp_hip.h')).read()
+    declared = set(re.findall(r'\b(imp_[a-z_0-9]+)\s*\(', header)) - {'imp_hip'}
+    assert declared, 'no declarations parsed'
+    for sym in sorted(declared):
+        assert hasattr(L, sym), f'libimp_hip.so does not export {sym}'
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    assert b'gfx950' in L.imp_version()
+
+
+def test_library_is_built_for_gfx950_only():
+    out = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-readelf', '-S', _lib.LIB_PATH], capture_output=True, text=True)
+    if out.returncode != 0:
+        pytest.skip('llvm-readelf unavailable')
+    assert '.hip_fatbin' in out.stdout
+    raw = open(_lib.LIB_PATH, 'rb').read()
+    assert b'gfx950' in raw and b'gfx942' not in raw and b'sm_' not in raw
+
+
+@pytest.mark.parametrize('model,cfg', [('GM', dict(n_layers=9, norm_fn='in')), ('GM', dict(n_layers=2, norm_fn='bn')),
+                                       ('DGNNS', dict()), ('AdaGMN', dict()),
+                                       ('GM', dict(n_layers=3, descriptor_dim=128))])
+def test_state_dict_schema_is_the_reference_schema(model, cfg):
+    cfg = eval_config(**cfg)
+    m = getattr(P, model)(cfg)
+    want = synthetic.make_state_dict(cfg, model)
+    got = m.state_dict()
+    assert list(got.keys()) == list(want.keys()) or set(got.keys()) == set(want.keys())
+    for k, v in want.items():
+        assert tuple(got[k].shape) == tuple(np.asarray(v).shape), k
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in want.items()}, strict=True)
+    if model != 'GM':
+        assert sum(p.numel() for p in m.parameters()) == 19231809     # SURVEY.md §8b [probed]
+
+
+def test_sharing_pattern_and_defaults():
+    assert P.GM.default_config['norm_fn'] == 'bn' and P.GM.default_config['sinkhorn_iterations'] == 20
+    d = P.DGNNS(eval_config())
+    assert d.sharing_layers[:8] == [False] * 6 + [True, True] and d.sharing_layers[8:12] == [False, False, True, True]
+    assert P.GM(eval_config(n_layers=2)).sharing_layers == [False] * 4
+    assert P.AdaGMN(eval_config()).pool_sizes[:4] == [0, 0, 0, 0]
+
+
+def test_no_cpu_fallback_and_error_behaviour():
+    m = P.GM(eval_config(n_layers=1)).eval()
+    d = {'descriptors0': torch.zeros(1, 4, 256), 'descriptors1': torch.zeros(1, 4, 256),
+         'keypoints0': torch.zeros(1, 4, 2), 'keypoints1': torch.zeros(1, 4, 2),
+         'scores0': torch.zeros(1, 4), 'scores1': torch.zeros(1, 4),
+         'image0': torch.zeros(1, 3, 8, 8), 'image1': torch.zeros(1, 3, 8, 8)}
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        m.produce_matches(d)
+    e = dict(d, keypoints0=torch.zeros(1, 0, 2))
+    out = m.produce_matches(e)                       # nets/gm.py:154-162: empty keypoints short-circuit
+    assert out['skip_train'] and out['matches0'].shape == (0,) and out['matches1'].dtype == torch.int32
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(d)
+    with pytest.raises(RuntimeError):
+        m.kenc(torch.zeros(1))                       # parameter containers never compute
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libimp_hip.so')
+    with pytest.raises(_lib.HipLibraryMissing):
+        _lib.lib()
+
+
+def test_shard_range_partitions_everything():
+    for n in (0, 1, 7, 32, 4000):
+        for w in (1, 2, 3, 8):
+            blocks = [pdist.shard_range(n, r, w) for r in range(w)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
+            sizes = [e - s for s, e in blocks]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_pack_roundtrip():
+    i = torch.randint(-1, 2048, (3, 17), dtype=torch.int64)
+    m = torch.rand(3, 17)
+    a, b = pdist.unpack_matches(pdist.pack_matches(i, m), 17)
+    assert torch.equal(a, i) and torch.equal(b, m)
+
+
+_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from imp_release_amd import dist as pdist
+dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
+rank, world = dist.get_rank(), dist.get_world_size()
+n_total, N = 5, 33
+g = torch.Generator().manual_seed(0)
+full_i = torch.randint(-1, N, (n_total, N), generator=g, dtype=torch.int64)
+full_m = torch.rand(n_total, N, generator=g)
+s, e = pdist.shard_range(n_total, rank, world)
+gi, gm = pdist.all_gather_matches(full_i[s:e], full_m[s:e], n_total)
+assert torch.equal(gi, full_i) and torch.equal(gm, full_m), rank
+dist.barrier()
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_world_size_2_all_gather_over_gloo(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, out

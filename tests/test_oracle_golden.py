@@ -1,0 +1,103 @@
+"""CPU: the oracle (oracle/imp_oracle.py) against the golden vectors captured from the imported reference
+(tools/make_golden.py).  This is the oracle's parity pin, re-checked on every run."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_case, golden_names, load_golden
+from oracle import imp_oracle as orc
+
+torch.set_num_threads(max(1, min(8, torch.get_num_threads())))
+
+PRODUCE = golden_names(['gm_l', 'dgnns_l', 'adagmn_masked'])
+
+
+@pytest.mark.parametrize('name', PRODUCE)
+def test_produce_matches_vs_reference(name):
+    spec, z = load_golden(name)
+    cfg, sd, data = build_case(spec)
+    o = orc.MatcherOracle(cfg, sd, model=spec['model'])
+    with torch.no_grad():
+        out = o.produce_matches(data, **spec.get('call', {}))
+    n = int(z['n_emitted'])
+    assert len(out['indices0']) == n
+    for i in range(n):
+        assert np.array_equal(out['indices0'][i].numpy(), z[f'indices0_{i}']), f'{name}: indices0[{i}]'
+        np.testing.assert_allclose(out['mscores0'][i].numpy(), z[f'mscores0_{i}'], atol=2e-5, rtol=0)
+    if 'score_rowsum' in z.files and out.get('scores'):
+        s = out['scores'][-1][0]
+        np.testing.assert_allclose(s.sum(-1).numpy(), z['score_rowsum'], atol=5e-5, rtol=0)
+        np.testing.assert_allclose(s.sum(-2).numpy(), z['score_colsum'], atol=5e-5, rtol=0)
+        np.testing.assert_allclose(s[:8, :8].numpy(), z['score_corner'], atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize('name', golden_names(['gm_run', 'adagmn_run']))
+def test_run_vs_reference(name):
+    spec, z = load_golden(name)
+    cfg, sd, data = build_case(spec)
+    o = orc.MatcherOracle(cfg, sd, model=spec['model'])
+    nk0 = orc.normalize_keypoints(data['keypoints0'], data['image0'].shape)
+    nk1 = orc.normalize_keypoints(data['keypoints1'], data['image1'].shape)
+    rd = {'desc1': data['descriptors0'], 'desc2': data['descriptors1'],
+          'x1': torch.cat([nk0, data['scores0'][..., None]], -1), 'x2': torch.cat([nk1, data['scores1'][..., None]], -1)}
+    with torch.no_grad():
+        out = o.run(rd)
+    if 'p' in out:
+        np.testing.assert_allclose(out['p'][0].sum(-1).numpy(), z['score_rowsum'], atol=5e-5, rtol=0)
+        np.testing.assert_allclose(out['p'][0][:8, :8].numpy(), z['score_corner'], atol=2e-5, rtol=0)
+    else:
+        assert np.array_equal(out['index0'].numpy(), z['index0'])
+        assert np.array_equal(out['index1'].numpy(), z['index1'])
+
+
+@pytest.mark.parametrize('name,unc', [('imp_loop_n400', False), ('eimp_loop_sliced_n1024', True)])
+def test_iterative_loops_vs_reference(name, unc):
+    spec, z = load_golden(name)
+    cfg, sd, data = build_case(spec)
+    o = orc.MatcherOracle(cfg, sd, model=spec['model'])
+    trace = []
+    with torch.no_grad():
+        out = orc.matching_iterative(data, o, nI=15, match_ratio=0.1, min_kpts=25, estimate_pose=None,
+                                     uncertainty=unc, trace=trace)
+    assert out['n_iter'] == int(z['n_iter'])
+    traj = z['trajectory']
+    assert [(t['n0'], t['n1']) for t in trace] == [tuple(r) for r in traj.tolist()]
+    for k, t in enumerate(trace):
+        assert np.array_equal(t['indices0'].numpy(), z[f'it{k}_indices0']), f'{name}: it {k}'
+        np.testing.assert_allclose(t['mscores0'].numpy(), z[f'it{k}_mscores0'], atol=2e-5, rtol=0)
+    assert np.array_equal(out['indices0'].numpy(), z['indices0'])
+    assert np.array_equal(data['keypoints0'][0].numpy()[out['keep0'].numpy()], z['pts0_final'])
+    assert np.array_equal(data['keypoints1'][0].numpy()[out['keep1'].numpy()], z['pts1_final'])
+
+
+def test_pool_edge_cases_vs_reference():
+    spec, z = load_golden('pool_edges')
+    g = torch.Generator().manual_seed(spec['seed'])
+    for tag in ('small0', 'both', 'empty', 'even', 'nmin0'):
+        n0, n1, nmin = [int(v) for v in z[f'{tag}_dims']]
+        th = float(z[f'{tag}_th'])
+        score = torch.rand(1, n0 + 1, n1 + 1, generator=g) * (2.0 / max(n0, n1))
+        idx = torch.randperm(min(n0, n1), generator=g)[:n0 // 3]
+        score[0, idx, idx] += 0.5
+        p00 = torch.softmax(torch.randn(1, 4, n0, n0, generator=g) * 2, -1)
+        p01 = torch.softmax(torch.randn(1, 4, n1, n0, generator=g) * 2, -1)
+        p11 = torch.softmax(torch.randn(1, 4, n1, n1, generator=g) * 2, -1)
+        p10 = torch.softmax(torch.randn(1, 4, n0, n1, generator=g) * 2, -1)
+        o0, o1 = orc.pool(score, p00, p01, p11, p10, mscore_th=th, uncertainty_ratio=1.0, n_min_tokens=nmin)
+        for side, o in ((0, o0), (1, o1)):
+            ref = z[f'{tag}_ids{side}']
+            if ref.shape == (1,) and ref[0] == -1:
+                assert o is None, f'{tag} side {side}'
+            else:
+                assert o is not None and np.array_equal(o.numpy(), ref), f'{tag} side {side}'
+
+
+def test_empty_and_error_behaviour():
+    cfg = {'n_layers': 1, 'GNN_layers': ['self', 'cross'], 'norm_fn': 'in'}
+    from imp_release_amd import synthetic
+    o = orc.MatcherOracle(cfg, synthetic.make_state_dict(cfg, 'GM'), 'GM')
+    d = {'descriptors0': torch.zeros(1, 4, 256), 'descriptors1': torch.zeros(1, 4, 256),
+         'keypoints0': torch.zeros(1, 4, 2), 'keypoints1': torch.zeros(1, 4, 2),
+         'scores0': torch.zeros(1, 4), 'scores1': torch.zeros(1, 4)}
+    with pytest.raises(ValueError):        # nets/gm.py:172
+        o.produce_matches(d)
