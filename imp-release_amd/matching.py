@@ -45,7 +45,7 @@ def _normalize(model, data):
 
 
 def _loop(data, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method, estimate_pose, uncertainty,
-          with_uncertainty):
+          with_uncertainty, trace=None):
     ctx = model._ensure_ctx()
     norm_kpts0, norm_kpts1 = _normalize(model, data)
     pts0_cpu, pts1_cpu = data['pts0_cpu'], data['pts1_cpu']
@@ -78,6 +78,9 @@ def _loop(data, model, nI, match_ratio, min_kpts, error_th, stop_criteria, metho
         indices0, indices1, mscores0, mscores1 = ctx.compute_matches(pred_score, match_ratio)
         indices0_cpu = indices0[0].cpu().numpy()            # the one sync of this iteration
         mscores0_cpu = mscores0[0].cpu().numpy()
+        if trace is not None:
+            trace.append({'it': it, 'n0': n0, 'n1': n1, 'indices0': indices0_cpu.copy(), 'mscores0': mscores0_cpu.copy(),
+                          'pts0': pts0_cpu.copy(), 'pts1': pts1_cpu.copy()})
         matched_ids0 = np.nonzero(indices0_cpu > -1)[0]
         if matched_ids0.shape[0] < min_kpts:                                      # eval/matching.py:63-66
             last_best_R = last_best_t = None
@@ -119,15 +122,16 @@ def _loop(data, model, nI, match_ratio, min_kpts, error_th, stop_criteria, metho
 
 
 def matching_iterative(data, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method=None,
-                       estimate_pose=None):
+                       estimate_pose=None, trace=None):
     """eval/matching.py:16-123 -> (indices0, mscores0, R, t, n_iterations)"""
-    r = _loop(data, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method, estimate_pose, False, False)
+    r = _loop(data, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method, estimate_pose, False, False,
+              trace)
     return r[4], r[5], r[6], r[7], r[8]
 
 
 def matching_iterative_uncertainty(data, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method=None,
-                                   with_uncertainty=False, estimate_pose=None):
+                                   with_uncertainty=False, estimate_pose=None, trace=None):
     """eval/matching.py:126-276 -> (pts0, pts1, norm_kpts0, norm_kpts1, indices0, mscores0, R, t, n_iterations)"""
     r = _loop(data, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method, estimate_pose, True,
-              with_uncertainty)
+              with_uncertainty, trace)
     return (r[0], r[1], r[2][0].cpu().numpy(), r[3][0].cpu().numpy(), r[4], r[5], r[6], r[7], r[8])

@@ -105,7 +105,8 @@ def test_compute_score_and_matches(gm, n0, n1, T, sink):
     got = ctx.compute_score(dist.to(DEV), bin_score, T, sink)
     aug = orc.dustbin_augment(dist, torch.tensor(bin_score))
     ref = orc.sinkhorn(aug, T) if sink else orc.dual_softmax(aug)
-    err = (got.cpu() - ref).abs().max().item()
+    # the dustbin corner holds O(N) mass: tolerance = 2e-5 absolute + 4 ulp relative
+    err = ((got.cpu() - ref).abs() - 5e-7 * ref.abs()).max().item()
     assert err < 2e-5, f'compute_score err {err:.3e}'
     if sink and T > 0:       # property: after the last step every column sums to its marginal
         cs = got.cpu().double().sum(1)

@@ -76,9 +76,14 @@ def test_imp_iterative_loop_vs_golden():
     spec, z = load_golden('imp_loop_n400')
     cfg, sd, data = build_case(spec, DEV)
     m = make_hip_model(spec, cfg, sd)
+    trace = []
     with torch.no_grad():
-        i0, ms0, R, t, nit = hip_matching.matching_iterative(_loop_data(data), m, 15, 0.1, 25, 1.0, {'pose': 1.5})
+        i0, ms0, R, t, nit = hip_matching.matching_iterative(_loop_data(data), m, 15, 0.1, 25, 1.0, {'pose': 1.5},
+                                                             trace=trace)
     assert nit == int(z['n_iter']) and R is None
+    assert [t['it'] for t in trace] == [3, 5, 7, 9, 11, 13, 14]
+    for k, t in enumerate(trace):
+        compare_matches(t['indices0'], t['mscores0'], z[f'it{k}_indices0'], z[f'it{k}_mscores0'], 0.1, TOL, f'imp it{t["it"]}')
     compare_matches(i0, ms0, z['indices0'], z['mscores0'], 0.2, TOL, 'imp loop final')
 
 
@@ -88,10 +93,17 @@ def test_eimp_sliced_loop_vs_golden():
     spec, z = load_golden('eimp_loop_sliced_n1024')
     cfg, sd, data = build_case(spec, DEV)
     m = make_hip_model(spec, cfg, sd)
+    trace = []
     with torch.no_grad():
         p0, p1, nk0, nk1, i0, ms0, R, t, nit = hip_matching.matching_iterative_uncertainty(
-            _loop_data(data), m, 15, 0.1, 25, 1.0, {'pose': 1.5}, with_uncertainty=False)
+            _loop_data(data), m, 15, 0.1, 25, 1.0, {'pose': 1.5}, with_uncertainty=False, trace=trace)
     assert nit == int(z['n_iter'])
+    traj = [(t['n0'], t['n1']) for t in trace]
+    assert traj == [tuple(r) for r in z['trajectory'].tolist()], f'pruning trajectory {traj}'
+    k0, k1 = data['keypoints0'][0].cpu().numpy(), data['keypoints1'][0].cpu().numpy()
+    for k, t in enumerate(trace):
+        assert np.array_equal(t['pts0'], k0[z[f'it{k}_keep0']]) and np.array_equal(t['pts1'], k1[z[f'it{k}_keep1']]), f'keep set it{k}'
+        compare_matches(t['indices0'], t['mscores0'], z[f'it{k}_indices0'], z[f'it{k}_mscores0'], 0.1, TOL, f'eimp it{t["it"]}')
     assert p0.shape == z['pts0_final'].shape and p1.shape == z['pts1_final'].shape, \
         f'pruned sizes {p0.shape[0]}/{p1.shape[0]} vs reference {z["pts0_final"].shape[0]}/{z["pts1_final"].shape[0]}'
     assert np.array_equal(p0, z['pts0_final']) and np.array_equal(p1, z['pts1_final'])

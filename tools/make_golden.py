@@ -184,6 +184,8 @@ def case_loop(name, spec, uncertainty):
         arrays[f'it{k}_mscores0'] = tm.numpy()
         traj.append((n0, n1))
         ok &= bool(torch.equal(ti, otrace[k]['indices0']))
+        arrays[f'it{k}_keep0'] = otrace[k]['keep0'].numpy()      # oracle keep sets (== reference: pts checked below)
+        arrays[f'it{k}_keep1'] = otrace[k]['keep1'].numpy()
     arrays['trajectory'] = np.array(traj)
     ok &= bool(np.array_equal(i0, o['indices0'].numpy()))
     kp0 = data['keypoints0'][0].numpy()[o['keep0'].numpy()]
@@ -259,7 +261,9 @@ def main():
     case_run('adagmn_run_l5', dict(model='AdaGMN', config=dict(n_layers=5), wseed=8, dseed=22, n0=150, n1=140))
     # (6) iterative loops, pose stubbed
     case_loop('imp_loop_n400', dict(model='DGNNS', config=dict(), wseed=9, dseed=23, n0=400, n1=380), False)
-    case_loop('eimp_loop_sliced_n1024', dict(model='AdaGMN', config=dict(), wseed=9, dseed=24, n0=1024, n1=1000,
+    # dseed chosen so that the pruning decisions are well-conditioned: the fp32 and fp64 oracles take the same
+    # trajectory (dseed=24 sits on a knife edge at it=5: fp64 keeps 750 keypoints where fp32 keeps 751)
+    case_loop('eimp_loop_sliced_n1024', dict(model='AdaGMN', config=dict(), wseed=9, dseed=25, n0=1024, n1=1000,
                                              bin_score=5.0), True)
     # (7) pool edge cases
     case_pool_edges('pool_edges')
