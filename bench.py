@@ -81,13 +81,13 @@ def cpu_baseline(args):
 
     probes = {}
     for t in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
-        r = run(t, 512, 1.0, 40)
+        r = run(t, 512, 1.0, 25)
         if r:
             probes[t] = r['pairs'] / r['seconds']
     if not probes:
         return None
     best = max(probes, key=probes.get)
-    r = run(best, args.kpts, 15.0, 90)
+    r = run(best, args.kpts, 15.0, 60)
     if not r:
         return None
     return {'value': r['pairs'] / r['seconds'], 'unit': 'image-pairs/s', 'cores': r['threads'], 'kind': 'port',

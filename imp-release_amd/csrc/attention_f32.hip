@@ -84,12 +84,10 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES == 4 ? 2 : 1)) void attn_f32_k
         for (int j = 0; j < LPT; ++j) {
             const int f = tid + j * NT;
             const int row = f / (DH / 4), c4 = (f % (DH / 4)) * 4;
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (k0 + row < nk) {
-                kv = *reinterpret_cast<const f32x4*>(Kg + (long)(k0 + row) * p.ldk + c4);
-                vv = *reinterpret_cast<const f32x4*>(Vg + (long)(k0 + row) * p.ldk + c4);
-            }
-            rk[j] = kv; rv[j] = vv;
+            // tail keys are clamped to the last valid row (finite data) and neutralised by the -inf key bias
+            const long krow = (long)min(k0 + row, nk - 1) * p.ldk + c4;
+            rk[j] = *reinterpret_cast<const f32x4*>(Kg + krow);
+            rv[j] = *reinterpret_cast<const f32x4*>(Vg + krow);
         }
         if (tid < KT) {
             const int key = k0 + tid;
@@ -131,19 +129,30 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES == 4 ? 2 : 1)) void attn_f32_k
         const float* vs = Vs + buf * KT * DH;
         const float* bs = Bs + buf * KT;
 
-        // ---- S^T = K . Q^T for the two 32-key blocks of the tile --------------------------------------
+        // ---- S^T = K . Q^T for the two 32-key blocks of the tile: the two accumulation chains are interleaved
+        //      and the K fragments of step c+1 are read while step c is multiplied (no LDS wait inside a chain)
         f32x16 sacc[2];
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb) {
+        for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[jb][r] = 0.f;
-            const float* krow = ks + (jb * 32 + l31) * LDK + half * QS;
+        {
+            const float* krow0 = ks + l31 * LDK + half * QS;
+            const float* krow1 = krow0 + 32 * LDK;
+            f32x4 kf[2][2];
+            kf[0][0] = *reinterpret_cast<const f32x4*>(krow0);
+            kf[0][1] = *reinterpret_cast<const f32x4*>(krow1);
 #pragma unroll
             for (int c = 0; c < QS / 4; ++c) {
-                const f32x4 kf = *reinterpret_cast<const f32x4*>(krow + 4 * c);
+                if (c + 1 < QS / 4) {
+                    kf[(c + 1) & 1][0] = *reinterpret_cast<const f32x4*>(krow0 + 4 * (c + 1));
+                    kf[(c + 1) & 1][1] = *reinterpret_cast<const f32x4*>(krow1 + 4 * (c + 1));
+                }
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qreg[4 * c + e], sacc[jb], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) {
+                    sacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c & 1][0][e], qreg[4 * c + e], sacc[0], 0, 0, 0);
+                    sacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[c & 1][1][e], qreg[4 * c + e], sacc[1], 0, 0, 0);
+                }
             }
         }
         // ---- scale, key bias (tail / mask), online softmax ---------------------------------------------
@@ -179,10 +188,12 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES == 4 ? 2 : 1)) void attn_f32_k
             }
         l_run = l_run * alpha + lsum;
         m_run = m_new;
+        if (__any(alpha != 1.f)) {          // wave-uniform: the running max rarely moves after the first tiles
 #pragma unroll
-        for (int d = 0; d < DT; ++d)
+            for (int d = 0; d < DT; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+        }
         // ---- O^T += V^T . P^T ---------------------------------------------------------------------------
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb) {

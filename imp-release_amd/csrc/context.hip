@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -30,6 +31,7 @@ struct GnnLayer {
     Linear proj;     // non-shared: packed [3D][D] (q|k|v, head-major rows); shared: value projection [D][D]
     Linear merge;    // [D][D], input columns head-major
     Linear mlp0;     // [2D][2D]
+    Linear mlp0f;    // [2D][2D] with the merge conv folded in: [W1a | W1b.Wm], bias b1 + W1b.bm (fuse_merge)
     NormC bn;        // only norm_fn == 'bn'
     Linear mlp3;     // [D][2D]
 };
@@ -47,6 +49,7 @@ struct imp_ctx {
     std::vector<std::string> schema;
     std::map<std::string, HostTensor> raw;
     bool finalized = false;
+    bool fuse_merge = true;   // fold attn.merge into mlp.0 (one GEMM and one launch less per layer); IMP_NO_FUSE_MERGE=1 disables
     float bin_score = 1.f;
     std::vector<void*> allocs_w, allocs_ws;
     // packed weights
@@ -58,7 +61,7 @@ struct imp_ctx {
     int cap_b = 0, cap_n = 0, kenc_maxc = 0;
     float *qkv[2][2] = {}, *lse[2][2] = {};         // [kind: 0 self, 1 cross][side]
     uint8_t* cmask[2][2] = {};                       // [kind][image] cached key masks
-    float *attn_out[2] = {}, *msg[2] = {}, *hid[2] = {}, *stats[2] = {};
+    float *attn_out[2] = {}, *msg[2] = {}, *hid[2] = {}, *stats[2] = {}, *nstat[2] = {};
     float *kbuf[2][2] = {};                          // keypoint-encoder ping-pong per side
     float *descw[2] = {}, *mdesc[2] = {}, *nkp[2] = {};
     float* dist = nullptr;
@@ -203,6 +206,7 @@ int ensure_workspace(imp_ctx* c, int batch, int n) {
         if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->msg[s], B * N * D);
         if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->hid[s], B * N * 2 * D);
         if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->stats[s], B * tiles * 2 * D * 2 + 2 * B * tiles * (size_t)c->kenc_maxc * 2);
+        if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->nstat[s], B * (size_t)(2 * D > (size_t)c->kenc_maxc ? 2 * D : c->kenc_maxc) * 2);
         if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->kbuf[s][0], B * N * (size_t)c->kenc_maxc);
         if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->kbuf[s][1], B * N * (size_t)c->kenc_maxc);
         if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->descw[s], B * N * D);
@@ -297,12 +301,16 @@ int run_kenc(imp_ctx* c, int batch, const int n[2], const float* const kpts[2], 
         }
         if (!last && in_norm) p.flags |= GEMM_EPI_STATS;
         const int bm = gemm_tile_m(maxn, L.out, 2 * batch);
+        if (in_norm) {
+            StatsSide ss[2];
+            for (int s = 0; s < 2; ++s) ss[s] = StatsSide{kstats[s] + ((i - 1) & 1) * slot, c->nstat[s], in_tiles[s], n[s]};
+            HIP_TRY(launch_stats_finalize(ss, 2, batch, L.in, 1e-3f, st));
+        }
         for (int s = 0; s < 2; ++s) {
             GemmSide& g = p.side[s];
             g.A = c->kbuf[s][cur]; g.W = L.W; g.M = n[s]; g.N = L.out;
             g.sA_b = (long)n[s] * L.in;
-            g.in_stats = in_norm ? kstats[s] + ((i - 1) & 1) * slot : nullptr;
-            g.in_tiles = in_tiles[s];
+            g.in_stats = in_norm ? c->nstat[s] : nullptr;
             if (last) {
                 g.C = out[s]; g.sC_b = (long)n[s] * D;
                 if (desc[s]) { g.R = desc[s]; g.sR_b = (long)n[s] * D; }
@@ -369,12 +377,13 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
         }
         HIP_TRY(launch_attention_f32(a, batch, st));
     }
-    // 3. merge conv
-    {
+    // 3. merge conv (skipped when it is folded into mlp.0's weights)
+    if (!c->fuse_merge) {
         const float* x[2] = {c->attn_out[0], c->attn_out[1]};
         int rc = linear_both(c, L.merge, batch, n, x, D, c->msg, D, st);
         if (rc) return rc;
     }
+    const Linear& M0 = c->fuse_merge ? L.mlp0f : L.mlp0;
     // 4. MLP conv 0 on cat([x, message]) (the concat is a K-split over two sources) + InstanceNorm statistics
     const bool in_norm = cfg.norm_fn == IMP_NORM_IN;
     const int maxn = n[0] > n[1] ? n[0] : n[1];
@@ -384,15 +393,20 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
         p.ksplit = D;
         for (int s = 0; s < 2; ++s) {
             GemmSide& g = p.side[s];
-            g.A = desc[s]; g.A2 = c->msg[s]; g.W = L.mlp0.W; g.C = c->hid[s]; g.M = n[s]; g.N = 2 * D;
+            g.A = desc[s]; g.A2 = c->fuse_merge ? c->attn_out[s] : c->msg[s]; g.W = M0.W; g.C = c->hid[s]; g.M = n[s]; g.N = 2 * D;
             g.sA_b = (long)n[s] * D; g.sC_b = (long)n[s] * 2 * D;
             g.out_stats = in_norm ? c->stats[s] : nullptr;
         }
         if (in_norm) p.flags |= GEMM_EPI_STATS;
-        p.bias = L.mlp0.b; p.lda = D; p.lda2 = D; p.ldw = 2 * D; p.ldc = 2 * D;
+        p.bias = M0.b; p.lda = D; p.lda2 = D; p.ldw = 2 * D; p.ldc = 2 * D;
         HIP_TRY(launch_gemm_f32(p, batch, st));
     }
     // 5. norm + activation while staging, conv 3, bias, residual add -> new descriptors
+    if (in_norm) {
+        StatsSide ss[2];
+        for (int s = 0; s < 2; ++s) ss[s] = StatsSide{c->stats[s], c->nstat[s], (n[s] + bm0 - 1) / bm0, n[s]};
+        HIP_TRY(launch_stats_finalize(ss, 2, batch, 2 * D, 1e-3f, st));
+    }
     {
         GemmParams p = gemm_defaults(2 * D);
         p.flags = GEMM_PRO_NORM;
@@ -405,8 +419,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
             GemmSide& g = p.side[s];
             g.A = c->hid[s]; g.W = L.mlp3.W; g.C = out[s]; g.R = desc[s]; g.M = n[s]; g.N = D;
             g.sA_b = (long)n[s] * 2 * D; g.sC_b = (long)n[s] * D; g.sR_b = (long)n[s] * D;
-            g.in_stats = in_norm ? c->stats[s] : nullptr;
-            g.in_tiles = (n[s] + bm0 - 1) / bm0;
+            g.in_stats = in_norm ? c->nstat[s] : nullptr;
         }
         p.bias = L.mlp3.b; p.lda = 2 * D; p.ldw = 2 * D; p.ldc = D; p.ldr = D;
         HIP_TRY(launch_gemm_f32(p, batch, st));
@@ -488,6 +501,7 @@ int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     c->device = device;
     c->D = cfg->descriptor_dim;
     c->dh = c->D / IMP_NUM_HEADS;
+    { const char* e = getenv("IMP_NO_FUSE_MERGE"); c->fuse_merge = !(e && e[0] == '1'); }
     c->kenc_maxc = c->D;
     for (int i = 0; i < nk; ++i) if (cfg->kenc_channels[i] > c->kenc_maxc) c->kenc_maxc = cfg->kenc_channels[i];
     build_schema(c);
@@ -584,6 +598,33 @@ int imp_finalize_weights(imp_ctx* c) {
             if ((rc = upload(c, &L.merge.b, bb->data))) return rc;
         }
         if ((rc = pack_linear(c, p + ".mlp.0", 2 * D, 2 * D, &L.mlp0))) return rc;
+        if (c->fuse_merge) {
+            // mlp.0(cat[x, merge(o)]) = W1a x + (W1b Wm) o + (b1 + W1b bm): precomposed in fp64, rounded once to fp32
+            const HostTensor* w1 = get(c, p + ".mlp.0.weight", (int64_t)4 * D * D);
+            const HostTensor* b1 = get(c, p + ".mlp.0.bias", 2 * D);
+            const HostTensor* wm = get(c, pa + ".merge.weight", (int64_t)D * D);
+            const HostTensor* bm = get(c, pa + ".merge.bias", D);
+            if (!w1 || !b1 || !wm || !bm) return IMP_E_KEY;
+            std::vector<float> Wf((size_t)4 * D * D), bf(2 * D);
+            std::vector<double> row(D);
+            for (int o = 0; o < 2 * D; ++o) {
+                const float* w1row = &w1->data[(size_t)o * 2 * D];
+                memcpy(&Wf[(size_t)o * 2 * D], w1row, D * sizeof(float));
+                for (int k = 0; k < D; ++k) row[k] = 0.0;
+                double bacc = b1->data[o];
+                for (int j = 0; j < D; ++j) {
+                    const double a = w1row[D + j];
+                    const float* wmrow = &wm->data[(size_t)j * D];
+                    for (int k = 0; k < D; ++k) row[k] += a * (double)wmrow[k];
+                    bacc += a * (double)bm->data[j];
+                }
+                for (int k = 0; k < D; ++k) Wf[(size_t)o * 2 * D + D + k] = (float)row[ref_channel(k, dh)];
+                bf[o] = (float)bacc;
+            }
+            L.mlp0f.out = 2 * D; L.mlp0f.in = 2 * D;
+            if ((rc = upload(c, &L.mlp0f.W, Wf))) return rc;
+            if ((rc = upload(c, &L.mlp0f.b, bf))) return rc;
+        }
         if (cfg.norm_fn == IMP_NORM_BN)
             if ((rc = pack_norm(c, p + ".mlp.1", 2 * D, &L.bn))) return rc;
         if ((rc = pack_linear(c, p + ".mlp.3", D, 2 * D, &L.mlp3))) return rc;

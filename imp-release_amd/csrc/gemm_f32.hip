@@ -8,9 +8,17 @@
 // re-materialised attention probabilities are the same kernel with per-batch "weights".
 //
 // Workgroup = 4 wave64 as 2(M) x 2(N); wave tile (BM/2) x (BN/2) built from 32x32 MFMA tiles; BK = 32.
-// Operands are staged global -> registers -> (normalise + activation) -> LDS, double-buffered, one
-// barrier per K-tile.  LDS rows are padded to 36 floats so that the ds_read_b128 fragment reads of 16
-// consecutive rows hit 16 distinct 16-byte slots (conflict-free).
+// Operands are staged global -> registers -> (normalise + activation) -> LDS.  ONE LDS buffer (37 KB for
+// 128x128) + register prefetch of the next K-tile: the loads of tile k+1 are in flight while tile k is
+// multiplied, and 3 workgroups fit a CU, which is what hides the two barriers per K-tile (fp32 MFMA is
+// 64 cycles per instruction, so one wave per SIMD already saturates the pipe when it never stalls; the
+// co-resident workgroups cover the stalls).  LDS rows are padded to 36 floats so that the ds_read_b128
+// fragment reads of 16 consecutive rows hit 16 distinct 16-byte slots (conflict-free).
+//
+// The K-loop is branch-free: out-of-range rows of A / W are CLAMPED to the last valid row instead of being
+// predicated (a garbage A row only feeds an output row >= M and a garbage W row an output column >= N,
+// neither of which is ever stored or counted), row pointers are computed once, and the prologue mode is a
+// template parameter (PRO 0: none, 1: InstanceNorm/fixed norm + ReLU, 2: generic affine norm + any activation).
 //
 // MFMA k-pairing: step s of a 32-deep K-tile multiplies k = s (lanes 0-31) and k = 16 + s (lanes 32-63);
 // A and W fragments use the same pairing so each lane reads 16 contiguous floats of its row.
@@ -30,110 +38,117 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); // exact gelu
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmParams p) {
+// bijective XCD-aware remap of a linear block id (hardware places block b on XCD b % 8): each XCD gets a
+// contiguous chunk of the logical tile order, in which the column tiles sharing an A row-tile are adjacent.
+__device__ __forceinline__ int xcd_remap(int lin, int total) {
+    const int q = total / 8, r = total % 8;
+    const int xcd = lin % 8, idx = lin / 8;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+template <int BM, int BN, int PRO>
+__global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const GemmParams p, int col_tiles, int row_tiles, int total) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int LA = BM / 32, LW = BN / 32;   // float4 loads per thread per K-tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                       // [2][BM][LDT]
-    float* Ws = smem + 2 * BM * LDT;        // [2][BN][LDT]
-    float* tr = Ws + 2 * BN * LDT;          // [mu K][rs K]([gamma K][beta K])
+    float* As = smem;                       // [BM][LDT]
+    float* Ws = smem + BM * LDT;            // [BN][LDT]
+    float* tr = Ws + BN * LDT;              // [mu K][rs K]([gamma K][beta K])
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    int z = blockIdx.z;
+    int z = xcd_remap(blockIdx.x, total);
+    const int ctile = z % col_tiles; z /= col_tiles;
+    const int rtile = z % row_tiles; z /= row_tiles;
     const int sidx = z % p.nside; z /= p.nside;
     const int sub = z % p.nsub;
     const int b = z / p.nsub;
     const GemmSide& S = p.side[sidx];
     const int M = S.M, N = S.N, K = p.K;
-    const int row0 = blockIdx.y * BM, col0 = blockIdx.x * BN;
+    const int row0 = rtile * BM, col0 = ctile * BN;
     if (row0 >= M || col0 >= N) return;     // uniform per workgroup, before any barrier
 
     const float* A = S.A + b * S.sA_b + sub * S.sA_s;
-    const float* A2 = S.A2 ? S.A2 + b * S.sA_b + sub * S.sA_s : nullptr;
+    const float* A2 = S.A2 ? S.A2 + b * S.sA_b + sub * S.sA_s : A;
     const float* W = S.W + b * S.sW_b + sub * S.sW_s;
     const int flags = p.flags;
 
     // ---- prologue: per-channel normalisation constants -------------------------------------------
-    if (flags & GEMM_PRO_NORM) {
+    if (PRO != 0) {
         for (int k = tid; k < K; k += 256) {
             float mu, rs;
             if (S.in_stats) {
-                const float* st = S.in_stats + (long)b * S.in_tiles * K * 2;
-                double s = 0.0, q = 0.0;
-                for (int t = 0; t < S.in_tiles; ++t) {
-                    s += (double)st[((long)t * K + k) * 2];
-                    q += (double)st[((long)t * K + k) * 2 + 1];
-                }
-                const double mean = s / (double)M;
-                double var = q / (double)M - mean * mean;
-                var = var < 0.0 ? 0.0 : var;
-                mu = (float)mean;
-                rs = (float)(1.0 / sqrt(var + (double)p.norm_eps));
+                const float* st = S.in_stats + ((long)b * K + k) * 2;
+                mu = st[0];
+                rs = st[1];
             } else {
                 mu = p.nm_mean[k];
                 rs = p.nm_rstd[k];
             }
             tr[k] = mu;
             tr[K + k] = rs;
-            if (flags & GEMM_PRO_AFFINE) {
-                tr[2 * K + k] = p.nm_gamma[k];
-                tr[3 * K + k] = p.nm_beta[k];
+            if (PRO == 2) {
+                tr[2 * K + k] = (flags & GEMM_PRO_AFFINE) ? p.nm_gamma[k] : 1.f;
+                tr[3 * K + k] = (flags & GEMM_PRO_AFFINE) ? p.nm_beta[k] : 0.f;
             }
         }
         __syncthreads();
     }
 
-    const int lr = tid >> 3, lc = (tid & 7) << 2;   // staging: row within 32-row group, float offset in K-tile
+    // ---- per-thread staging geometry (loop invariant) ----------------------------------------------
+    const int lr = tid >> 3, lc = (tid & 7) << 2;   // row within a 32-row group, float offset in the K-tile
+    const float* pa[LA];
+    const float* pa2[LA];
+    const float* pw[LW];
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+        const int r = min(row0 + lr + 32 * j, M - 1);
+        pa[j] = A + (long)r * p.lda + lc;
+        pa2[j] = A2 + (long)r * p.lda2 + lc - p.ksplit;
+    }
+#pragma unroll
+    for (int j = 0; j < LW; ++j) {
+        const int r = min(col0 + lr + 32 * j, N - 1);
+        pw[j] = W + (long)r * p.ldw + lc;
+    }
     f32x4 ra[LA], rw[LW];
-
     auto load_tile = [&](int kt) {
         const int k0 = kt * BK;
-        const float* src;
-        int ld;
-        if (k0 < p.ksplit) { src = A + k0; ld = p.lda; } else { src = A2 + (k0 - p.ksplit); ld = p.lda2; }
+        const bool second = k0 >= p.ksplit;          // uniform
 #pragma unroll
-        for (int j = 0; j < LA; ++j) {
-            const int r = row0 + lr + 32 * j;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < M) v = *reinterpret_cast<const f32x4*>(src + (long)r * ld + lc);
-            ra[j] = v;
-        }
+        for (int j = 0; j < LA; ++j) ra[j] = *reinterpret_cast<const f32x4*>((second ? pa2[j] : pa[j]) + k0);
 #pragma unroll
-        for (int j = 0; j < LW; ++j) {
-            const int r = col0 + lr + 32 * j;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < N) v = *reinterpret_cast<const f32x4*>(W + (long)r * p.ldw + k0 + lc);
-            rw[j] = v;
-        }
+        for (int j = 0; j < LW; ++j) rw[j] = *reinterpret_cast<const f32x4*>(pw[j] + k0);
     };
-    auto store_tile = [&](int kt, int buf) {
-        float* as = As + buf * BM * LDT;
-        float* ws = Ws + buf * BN * LDT;
-        if (flags & GEMM_PRO_NORM) {
+    auto store_tile = [&](int kt) {
+        if (PRO != 0) {
             const int k0 = kt * BK + lc;
             const f32x4 mu = *reinterpret_cast<const f32x4*>(tr + k0);
             const f32x4 rs = *reinterpret_cast<const f32x4*>(tr + K + k0);
-            f32x4 ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
-            if (flags & GEMM_PRO_AFFINE) {
-                ga = *reinterpret_cast<const f32x4*>(tr + 2 * K + k0);
-                be = *reinterpret_cast<const f32x4*>(tr + 3 * K + k0);
-            }
+            if (PRO == 1) {
 #pragma unroll
-            for (int j = 0; j < LA; ++j) {
+                for (int j = 0; j < LA; ++j)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float v = (ra[j][e] - mu[e]) * rs[e];
-                    if (flags & GEMM_PRO_AFFINE) v = v * ga[e] + be[e];
-                    ra[j][e] = apply_act(v, p.act);
-                }
+                    for (int e = 0; e < 4; ++e) ra[j][e] = fmaxf((ra[j][e] - mu[e]) * rs[e], 0.f);
+            } else {
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(tr + 2 * K + k0);
+                const f32x4 be = *reinterpret_cast<const f32x4*>(tr + 3 * K + k0);
+                const int act = p.act;
+#pragma unroll
+                for (int j = 0; j < LA; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = (ra[j][e] - mu[e]) * rs[e];
+                        if (flags & GEMM_PRO_AFFINE) v = v * ga[e] + be[e];
+                        ra[j][e] = apply_act(v, act);
+                    }
             }
         }
 #pragma unroll
-        for (int j = 0; j < LA; ++j) *reinterpret_cast<f32x4*>(as + (lr + 32 * j) * LDT + lc) = ra[j];
+        for (int j = 0; j < LA; ++j) *reinterpret_cast<f32x4*>(As + (lr + 32 * j) * LDT + lc) = ra[j];
 #pragma unroll
-        for (int j = 0; j < LW; ++j) *reinterpret_cast<f32x4*>(ws + (lr + 32 * j) * LDT + lc) = rw[j];
+        for (int j = 0; j < LW; ++j) *reinterpret_cast<f32x4*>(Ws + (lr + 32 * j) * LDT + lc) = rw[j];
     };
 
     f32x16 acc[TM][TN];
@@ -146,74 +161,131 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmParams p) {
 
     const int nkt = K / BK;
     load_tile(0);
-    store_tile(0, 0);
-    __syncthreads();
-
     const int frow = lane & 31, fk = (lane >> 5) * 16;
+    const float* as = As + (wm * WM + frow) * LDT + fk;
+    const float* ws = Ws + (wn * WN + frow) * LDT + fk;
     for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1);
-        const float* as = As + buf * BM * LDT + (wm * WM + frow) * LDT + fk;
-        const float* ws = Ws + buf * BN * LDT + (wn * WN + frow) * LDT + fk;
+        store_tile(kt);
+        __syncthreads();
+        load_tile(kt + 1 < nkt ? kt + 1 : kt);   // in flight during the MFMAs below (last one: harmless re-load)
+        f32x4 af[2][TM], wf[2][TN];              // fragment double buffer: c+1 is read while c is multiplied
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDT);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf[0][j] = *reinterpret_cast<const f32x4*>(ws + j * 32 * LDT);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            f32x4 af[TM], wf[TN];
+            if (c < 3) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDT + c * 4);
+                for (int i = 0; i < TM; ++i)
+                    af[(c + 1) & 1][i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDT + (c + 1) * 4);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) wf[j] = *reinterpret_cast<const f32x4*>(ws + j * 32 * LDT + c * 4);
+                for (int j = 0; j < TN; ++j)
+                    wf[(c + 1) & 1][j] = *reinterpret_cast<const f32x4*>(ws + j * 32 * LDT + (c + 1) * 4);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], wf[j][e], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c & 1][i][e], wf[c & 1][j][e], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nkt) store_tile(kt + 1, buf ^ 1);
-        __syncthreads();
+        __syncthreads();                          // every wave is done reading before the next store_tile
     }
 
-    // ---- epilogue -----------------------------------------------------------------------------------
-    float* C = S.C ? S.C + b * S.sC_b + sub * S.sC_s : nullptr;
-    const float* R = S.R ? S.R + b * S.sR_b : nullptr;
-    const float* rv = S.rowvec ? S.rowvec + b * S.sRV_b + sub * S.sRV_s : nullptr;
-    const bool do_store = !(flags & GEMM_EPI_NOSTORE);
+    // ---- epilogue: value transforms with the (uniform) flags hoisted out of the element loops -------------
     const int half = lane >> 5;
-    float ssum[TN], ssq[TN];
+    const int rbase = row0 + wm * WM + 4 * half;            // + i*32 + (r&3) + 8*(r>>2)
+    const int cbase = col0 + wn * WN + (lane & 31);         // + j*32
+    if (flags & GEMM_EPI_DIV) {
+        const float dv = p.div;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = col0 + wn * WN + j * 32 + (lane & 31);
-        const bool colok = col < N;
-        const float bv = (p.bias && colok) ? p.bias[col] : 0.f;
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] / dv;
+    }
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float bv = p.bias[min(cbase + j * 32, N - 1)];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
+        }
+    }
+    if (flags & GEMM_EPI_EXPROW) {
+        const float* rv = S.rowvec + b * S.sRV_b + sub * S.sRV_s;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = row0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < M && colok) {
-                    float v = acc[i][j][r];
-                    if (flags & GEMM_EPI_DIV) v = v / p.div;
-                    v += bv;
-                    if (flags & GEMM_EPI_EXPROW) v = expf(v - rv[row]);
-                    if (R) v += R[(long)row * p.ldr + col];
-                    if (do_store) C[(long)row * p.ldc + col] = v;
-                    ssum[j] += v;
-                    ssq[j] += v * v;
-                }
+                const float lv = rv[min(rbase + i * 32 + (r & 3) + 8 * (r >> 2), M - 1)];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j][r] = expf(acc[i][j][r] - lv);
             }
+    }
+    if (S.R) {
+        const float* R = S.R + b * S.sR_b;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long ro = (long)min(rbase + i * 32 + (r & 3) + 8 * (r >> 2), M - 1) * p.ldr;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j][r] += R[ro + min(cbase + j * 32, N - 1)];
+            }
+    }
+    const bool interior = row0 + BM <= M && col0 + BN <= N;     // uniform
+    if (!(flags & GEMM_EPI_NOSTORE)) {
+        float* C = S.C + b * S.sC_b + sub * S.sC_s;
+        if (interior) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float* crow = C + (long)(rbase + i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldc + cbase;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) crow[j * 32] = acc[i][j][r];
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + i * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        if (row < M && cbase + j * 32 < N) C[(long)row * p.ldc + cbase + j * 32] = acc[i][j][r];
+                }
         }
     }
     if (flags & GEMM_EPI_STATS) {
-        // per-column sums over the BM rows of this tile: lane pair (l, l^32), then the two M-waves via LDS
-        float* sc = As;   // main loop finished with a barrier: the staging buffers are free
+        // per-column (sum, sumsq) over the valid rows of this tile: in-lane over the 16 x TM registers, lane
+        // pair (l, l^32), then the two M-waves through LDS (the staging buffers are free after the last barrier)
+        float ssum[TN], ssq[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            ssum[j] += __shfl_xor(ssum[j], 32);
-            ssq[j] += __shfl_xor(ssq[j], 32);
-            if (wm == 1 && lane < 32) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = interior || (rbase + i * 32 + (r & 3) + 8 * (r >> 2) < M);
+                    const float v = ok ? acc[i][j][r] : 0.f;
+                    s += v;
+                    q += v * v;
+                }
+            ssum[j] = s + __shfl_xor(s, 32);
+            ssq[j] = q + __shfl_xor(q, 32);
+        }
+        float* sc = As;
+        if (wm == 1 && lane < 32) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
                 sc[(wn * WN + j * 32 + lane) * 2] = ssum[j];
                 sc[(wn * WN + j * 32 + lane) * 2 + 1] = ssq[j];
             }
@@ -221,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmParams p) {
         __syncthreads();
         if (wm == 0 && lane < 32) {
             const int tiles_side = (M + BM - 1) / BM;   // dense per side: [b][tile][N][2]
-            float* os = S.out_stats + ((long)b * tiles_side + blockIdx.y) * N * 2;
+            float* os = S.out_stats + ((long)b * tiles_side + rtile) * N * 2;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int cl = wn * WN + j * 32 + lane;
@@ -235,19 +307,75 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmParams p) {
     }
 }
 
-size_t gemm_lds_bytes(int BM, int BN, const GemmParams& p) {
-    size_t f = 2 * (size_t)(BM + BN) * LDT;
-    if (p.flags & GEMM_PRO_NORM) f += (size_t)p.K * ((p.flags & GEMM_PRO_AFFINE) ? 4 : 2);
+__global__ __launch_bounds__(256) void stats_finalize_kernel(StatsSide s0, StatsSide s1, int K, float eps) {
+    const StatsSide& S = blockIdx.y == 0 ? s0 : s1;
+    const int b = blockIdx.z;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const float2* st = reinterpret_cast<const float2*>(S.part) + (long)b * S.tiles * K + k;
+    double s = 0.0, q = 0.0;
+    int t = 0;
+    for (; t + 8 <= S.tiles; t += 8) {          // 8 independent loads in flight, then a fixed-order fp64 sum
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = st[(long)(t + u) * K];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s += (double)v[u].x; q += (double)v[u].y; }
+    }
+    for (; t < S.tiles; ++t) { const float2 v = st[(long)t * K]; s += (double)v.x; q += (double)v.y; }
+    const double mean = s / (double)S.M;
+    double var = q / (double)S.M - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    float2 o;
+    o.x = (float)mean;
+    o.y = (float)(1.0 / sqrt(var + (double)eps));
+    reinterpret_cast<float2*>(S.out)[(long)b * K + k] = o;
+}
+
+size_t gemm_lds_bytes(int BM, int BN, int pro, int K) {
+    size_t f = (size_t)(BM + BN) * LDT;
+    if (f < 4 * (size_t)BN) f = 4 * (size_t)BN;     // statistics scratch
+    if (pro) f += (size_t)K * (pro == 2 ? 4 : 2);
     return f * sizeof(float);
+}
+
+// tile choice: the largest tile that still gives >= 2 workgroups per CU (512); all three keep 4 waves
+void gemm_pick_tile(int M, int N, int total_z, int* bm, int* bn) {
+    auto wgs = [&](int tm, int tn) { return (long)((M + tm - 1) / tm) * ((N + tn - 1) / tn) * total_z; };
+    if (wgs(128, 128) >= 512) { *bm = 128; *bn = 128; }
+    else if (wgs(128, 64) >= 512) { *bm = 128; *bn = 64; }
+    else { *bm = 64; *bn = 64; }
+}
+
+template <int BM, int BN, int PRO>
+hipError_t gemm_launch_one(const GemmParams& p, dim3 grid, hipStream_t stream) {
+    const size_t lds = gemm_lds_bytes(BM, BN, PRO, p.K);
+    static size_t lds_set = 0;           // largest dynamic-LDS size already granted to this instantiation
+    if (lds > lds_set && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, PRO>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_set = lds;
+    }
+    const int total = (int)(grid.x * grid.y * grid.z);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, PRO>), dim3(total), dim3(256), lds, stream, p, (int)grid.x, (int)grid.y,
+                       total);
+    return hipGetLastError();
+}
+
+template <int BM, int BN>
+hipError_t gemm_launch_pro(const GemmParams& p, int pro, dim3 grid, hipStream_t stream) {
+    if (pro == 0) return gemm_launch_one<BM, BN, 0>(p, grid, stream);
+    if (pro == 1) return gemm_launch_one<BM, BN, 1>(p, grid, stream);
+    return gemm_launch_one<BM, BN, 2>(p, grid, stream);
 }
 
 }  // namespace
 
 int gemm_tile_m(int M, int N, int total_z) {
-    // 128x128 tiles when that still yields about a full wave of workgroups (2 per CU x 256 CUs would be
-    // ideal, one per CU is the floor); otherwise 64x64 to fill more CUs.
-    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128) * total_z;
-    return t128 >= 192 ? 128 : 64;
+    int bm, bn;
+    gemm_pick_tile(M, N, total_z, &bm, &bn);
+    return bm;
 }
 
 int gemm_stats_tiles(int M, int N, int total_z) {
@@ -260,28 +388,19 @@ hipError_t launch_gemm_f32(const GemmParams& p, int batch, hipStream_t stream) {
     const int maxN = p.nside == 2 ? (p.side[0].N > p.side[1].N ? p.side[0].N : p.side[1].N) : p.side[0].N;
     const int total_z = batch * p.nsub * p.nside;
     if (maxM <= 0 || maxN <= 0 || total_z <= 0) return hipSuccess;
-    // the tile choice must be reproducible by gemm_stats_tiles(): decide on the LARGER side's M
-    const int bm = gemm_tile_m(maxM, maxN, total_z);
-    dim3 grid((maxN + bm - 1) / bm, (maxM + bm - 1) / bm, total_z);
-    static size_t lds_set[2] = {0, 0};   // largest dynamic-LDS size already granted per instantiation
-    if (bm == 128) {
-        const size_t lds = gemm_lds_bytes(128, 128, p);
-        if (lds > lds_set[0]) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<128, 128>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            lds_set[0] = lds;
-        }
-        hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), grid, dim3(256), lds, stream, p);
-    } else {
-        const size_t lds = gemm_lds_bytes(64, 64, p);
-        if (lds > lds_set[1]) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<64, 64>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            lds_set[1] = lds;
-        }
-        hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), grid, dim3(256), lds, stream, p);
-    }
+    // the tile choice must be reproducible by gemm_tile_m(): it is decided on the LARGER side's M
+    int bm, bn;
+    gemm_pick_tile(maxM, maxN, total_z, &bm, &bn);
+    dim3 grid((maxN + bn - 1) / bn, (maxM + bm - 1) / bm, total_z);
+    int pro = 0;
+    if (p.flags & GEMM_PRO_NORM) pro = (!(p.flags & GEMM_PRO_AFFINE) && p.act == 0) ? 1 : 2;
+    if (bm == 128 && bn == 128) return gemm_launch_pro<128, 128>(p, pro, grid, stream);
+    if (bm == 128 && bn == 64) return gemm_launch_pro<128, 64>(p, pro, grid, stream);
+    return gemm_launch_pro<64, 64>(p, pro, grid, stream);
+}
+
+hipError_t launch_stats_finalize(const StatsSide sides[2], int nside, int batch, int K, float eps, hipStream_t stream) {
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((K + 255) / 256, nside, batch), dim3(256), 0, stream, sides[0],
+                       sides[nside - 1], K, eps);
     return hipGetLastError();
 }

@@ -26,11 +26,10 @@ struct GemmSide {
     float* C;              // [b][sub][M][ldc]
     const float* R;        // residual, [b][M][ldr] or null
     const float* rowvec;   // [b][sub][M] or null
-    const float* in_stats; // [b][in_tiles][K][2] partial sums of the producer, or null
+    const float* in_stats; // [b][K][2] finalised (mean, rstd) of the producer (launch_stats_finalize), or null
     float* out_stats;      // [b][row_tiles][N][2]
     long sA_b, sA_s, sW_b, sW_s, sC_b, sC_s, sR_b, sRV_b, sRV_s;
     int M, N;
-    int in_tiles;          // number of partial-sum tiles behind in_stats
 };
 
 struct GemmParams {
@@ -48,6 +47,10 @@ struct GemmParams {
 };
 
 hipError_t launch_gemm_f32(const GemmParams& p, int batch, hipStream_t stream);
+// InstanceNorm statistics: partial (sum, sumsq) tiles [b][tiles][K][2] of a producer -> (mean, rstd) [b][K][2],
+// accumulated in fp64 in a fixed order, once per (batch, side) instead of once per consumer workgroup
+struct StatsSide { const float* part; float* out; int tiles; int M; };
+hipError_t launch_stats_finalize(const StatsSide sides[2], int nside, int batch, int K, float eps, hipStream_t stream);
 // rows of out_stats produced per launch for M rows (the tile height the launcher will choose)
 int gemm_stats_tiles(int M, int N, int total_z);
 int gemm_tile_m(int M, int N, int total_z);

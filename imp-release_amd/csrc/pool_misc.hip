@@ -105,9 +105,7 @@ __global__ __launch_bounds__(256, 2) void attn_colsum_kernel(const ColsumParams 
         for (int j = 0; j < LPT; ++j) {
             const int f = tid + j * 256;
             const int row = f / (DH / 4), c4 = (f % (DH / 4)) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (q0 + row < nq) v = *reinterpret_cast<const f32x4*>(Qg + (long)(q0 + row) * p.ldq + c4);
-            rq[j] = v;
+            rq[j] = *reinterpret_cast<const f32x4*>(Qg + (long)min(q0 + row, nq - 1) * p.ldq + c4);   // lse = +inf masks the tail
         }
         if (tid < QT) rl = (q0 + tid < nq) ? Lg[q0 + tid] : INFINITY;   // exp(s - inf) = 0 for padded queries
     };
