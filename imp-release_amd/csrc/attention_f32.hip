@@ -116,6 +116,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES == 4 ? 2 : 1)) void attn_f32_k
         for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const float scale = DH == 64 ? 0.125f : 0.17677669529663687f;   // 1/sqrt(DH) (exact for DH = 64)
+    const float SL2E = scale * LOG2E;
 
     const int nt = (nk + KT - 1) / KT;
     load_tile(0);
@@ -155,58 +156,75 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES == 4 ? 2 : 1)) void attn_f32_k
                 }
             }
         }
-        // ---- scale, key bias (tail / mask), online softmax ---------------------------------------------
+        // ---- online softmax on the RAW dot products: s = raw * scale; scale (> 0) is folded into the exp2 constant and
+        //      into the running max.  Only a tile with invalid keys (tail of the key range, or a key mask) pays for the
+        //      additive -inf key bias (uniform branch) ---------------------------------------------------------------
+        if (mk != nullptr || (t + 1) * KT > nk) {
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bias = *reinterpret_cast<const f32x4*>(bs + jb * 32 + 8 * g + 4 * half);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sacc[jb][4 * g + e] += bias[e];
+                }
+        }
         float tmax = -INFINITY;
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb) {
+        for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 bias = *reinterpret_cast<const f32x4*>(bs + jb * 32 + 8 * g + 4 * half);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float s;
-                    if (DH == 64) s = sacc[jb][4 * g + e] * scale + bias[e];
-                    else s = sacc[jb][4 * g + e] / 5.656854249492381f + bias[e];   // x / dim**.5 as the reference
-                    sacc[jb][4 * g + e] = s;
-                    tmax = fmaxf(tmax, s);
-                }
-            }
-        }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[jb][r]);
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * scale;
         const float m_new = fmaxf(m_run, tmax);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = fast_exp2((m_run - m_use) * LOG2E);
         const float mneg = -m_use * LOG2E;
-        float lsum = 0.f;
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = fast_exp2(fmaf(sacc[jb][r], LOG2E, mneg));
-                sacc[jb][r] = pv;
-                lsum += pv;
-            }
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
         if (__any(alpha != 1.f)) {          // wave-uniform: the running max rarely moves after the first tiles
 #pragma unroll
             for (int d = 0; d < DT; ++d)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
         }
-        // ---- O^T += V^T . P^T ---------------------------------------------------------------------------
+        // ---- P = exp(S - m) and O^T += V^T . P^T, software-pipelined over 8 groups of 4 keys:
+        //      iteration g issues the LDS reads of group g+1's V operands, exponentiates group g+1's scores (VALU)
+        //      and multiplies group g (MFMA).  sched_barrier pins "reads first" so no MFMA waits on an LDS round trip.
+        float lsum = 0.f;
+        {
+            float vv[2][4][DT];
+            const float* vbase = vs + (4 * half) * DH + l31;
+            auto loadv = [&](int buf2, int idx) {          // idx = jb*4 + g ; keys jb*32 + 8g + rr (+4 for the upper half)
+                const float* vp = vbase + ((idx >> 2) * 32 + (idx & 3) * 8) * DH;
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb) {
+                for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    for (int d = 0; d < DT; ++d) vv[buf2][rr][d] = vp[rr * DH + d * 32];
+            };
+            auto expg = [&](int idx) {
 #pragma unroll
-                for (int d = 0; d < DT; ++d) {
-                    const float vv = vs[key * DH + d * 32 + l31];
-                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, sacc[jb][r], oacc[d], 0, 0, 0);
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float pv = fast_exp2(fmaf(sacc[idx >> 2][(idx & 3) * 4 + rr], SL2E, mneg));
+                    sacc[idx >> 2][(idx & 3) * 4 + rr] = pv;
+                    lsum += pv;
                 }
+            };
+            loadv(0, 0);
+            expg(0);
+#pragma unroll
+            for (int idx = 0; idx < 8; ++idx) {
+                if (idx + 1 < 8) loadv((idx + 1) & 1, idx + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (idx + 1 < 8) expg(idx + 1);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int d = 0; d < DT; ++d)
+                        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[idx & 1][rr][d], sacc[idx >> 2][(idx & 3) * 4 + rr],
+                                                                       oacc[d], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
         if (t + 1 < nt) store_tile(buf ^ 1);
         __syncthreads();
     }
