@@ -23,7 +23,7 @@ ACT_IDS = {'relu': 0, 'gelu': 1, 'lrelu': 2}
 # every symbol include/imp_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     'imp_last_error', 'imp_version', 'imp_create', 'imp_destroy', 'imp_load_tensor', 'imp_finalize_weights',
-    'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
+    'imp_set_precision', 'imp_get_precision', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
     'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear',
     'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn',
@@ -75,6 +75,8 @@ def lib():
     L.imp_destroy.argtypes = [C.c_void_p]
     L.imp_load_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]
     L.imp_finalize_weights.argtypes = [C.c_void_p]
+    L.imp_set_precision.argtypes = [C.c_void_p, C.c_int]
+    L.imp_get_precision.argtypes = [C.c_void_p]
     P, I, F = C.c_void_p, C.c_int, C.c_float
     L.imp_normalize_keypoints.argtypes = [P, P, I, I, F, F, P, P]
     L.imp_encode_keypoints.argtypes = [P, I, I, I, P, P, P, P, P, P, P, P, P]
@@ -146,6 +148,15 @@ class Context:
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self._check(self.L.imp_create(C.byref(self.handle), C.byref(cfg), idx))
         self.D = cfg.descriptor_dim
+        prec = config.get('precision')          # extra (non-reference) config key: 'f16x3' (default) | 'f32'
+        if prec is not None:
+            if prec not in ('f32', 'f16x3'):
+                raise ValueError("precision must be 'f32' or 'f16x3'")
+            self._check(self.L.imp_set_precision(self.handle, 1 if prec == 'f16x3' else 0))
+
+    @property
+    def precision(self):
+        return 'f16x3' if self.L.imp_get_precision(self.handle) == 1 else 'f32'
 
     def _check(self, rc):
         if rc != 0:

@@ -49,6 +49,7 @@ struct imp_ctx {
     std::vector<std::string> schema;
     std::map<std::string, HostTensor> raw;
     bool finalized = false;
+    int prec = 1;             // matrix arithmetic: 1 = f16x3 split (default), 0 = native fp32 MFMA (imp_set_precision / IMP_PRECISION=f32)
     bool fuse_merge = true;   // fold attn.merge into mlp.0 (one GEMM and one launch less per layer); IMP_NO_FUSE_MERGE=1 disables
     float bin_score = 1.f;
     std::vector<void*> allocs_w, allocs_ws;
@@ -247,9 +248,13 @@ int check_ready(imp_ctx* c, int batch, int n0, int n1) {
     return ensure_workspace(c, batch, n0 > n1 ? n0 : n1);
 }
 
-GemmParams gemm_defaults(int K) {
+hipError_t launch_attention(const imp_ctx* c, const AttnParams& a, int batch, hipStream_t st) {
+    return c->prec == 1 ? launch_attention_f16x3(a, batch, st) : launch_attention_f32(a, batch, st);
+}
+GemmParams gemm_defaults(const imp_ctx* c, int K) {
     GemmParams p;
     memset(&p, 0, sizeof p);
+    p.prec = c->prec;
     p.K = K; p.ksplit = K; p.nside = 2; p.nsub = 1; p.div = 1.f; p.norm_eps = 1e-3f;
     return p;
 }
@@ -257,7 +262,7 @@ GemmParams gemm_defaults(int K) {
 // y_s = x_s @ W^T + b for both image sides (the plain 1x1 conv)
 int linear_both(imp_ctx* c, const Linear& L, int batch, const int n[2], const float* const x[2], int ldx, float* const y[2],
                 int ldy, hipStream_t st) {
-    GemmParams p = gemm_defaults(L.in);
+    GemmParams p = gemm_defaults(c, L.in);
     for (int s = 0; s < 2; ++s) {
         GemmSide& g = p.side[s];
         g.A = x[s]; g.W = L.W; g.C = y[s]; g.M = n[s]; g.N = L.out;
@@ -291,7 +296,7 @@ int run_kenc(imp_ctx* c, int batch, const int n[2], const float* const kpts[2], 
     for (int i = 1; i <= nk; ++i) {
         const Linear& L = c->kenc[i];
         const bool last = i == nk;
-        GemmParams p = gemm_defaults(L.in);
+        GemmParams p = gemm_defaults(c, L.in);
         p.flags = GEMM_PRO_NORM;
         p.act = cfg.ac_fn;
         if (!in_norm) {
@@ -342,7 +347,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
     // 1. projections: q|k|v of both images in one GEMM (the layer's weights are shared by the two images);
     //    a sharing layer only refreshes the value slot and keeps last iteration's q,k (== its probabilities)
     {
-        GemmParams p = gemm_defaults(D);
+        GemmParams p = gemm_defaults(c, D);
         for (int s = 0; s < 2; ++s) {
             GemmSide& g = p.side[s];
             g.A = desc[s]; g.W = L.proj.W; g.M = n[s]; g.N = L.proj.out;
@@ -375,7 +380,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
             g.sq_b = (long)n[s] * 3 * D; g.sk_b = (long)n[src] * 3 * D; g.so_b = (long)n[s] * D;
             g.nq = n[s]; g.nk = n[src];
         }
-        HIP_TRY(launch_attention_f32(a, batch, st));
+        HIP_TRY(launch_attention(c, a, batch, st));
     }
     // 3. merge conv (skipped when it is folded into mlp.0's weights)
     if (!c->fuse_merge) {
@@ -389,7 +394,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
     const int maxn = n[0] > n[1] ? n[0] : n[1];
     const int bm0 = gemm_tile_m(maxn, 2 * D, 2 * batch);
     {
-        GemmParams p = gemm_defaults(2 * D);
+        GemmParams p = gemm_defaults(c, 2 * D);
         p.ksplit = D;
         for (int s = 0; s < 2; ++s) {
             GemmSide& g = p.side[s];
@@ -408,7 +413,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
         HIP_TRY(launch_stats_finalize(ss, 2, batch, 2 * D, 1e-3f, st));
     }
     {
-        GemmParams p = gemm_defaults(2 * D);
+        GemmParams p = gemm_defaults(c, 2 * D);
         p.flags = GEMM_PRO_NORM;
         p.act = cfg.ac_fn;
         if (!in_norm) {
@@ -434,7 +439,7 @@ int run_distance(imp_ctx* c, int layer_id, int batch, const int n[2], const floa
     if (idx < 0 || idx >= c->cfg.n_layers) return fail(IMP_E_ARG, "compute_distance: layer_id out of range");
     int rc = linear_both(c, c->final_proj[idx], batch, n, desc, D, c->mdesc, D, st);
     if (rc) return rc;
-    GemmParams p = gemm_defaults(D);
+    GemmParams p = gemm_defaults(c, D);
     p.nside = 1;
     GemmSide& g = p.side[0];
     g.A = c->mdesc[0]; g.W = c->mdesc[1]; g.C = dist; g.M = n[0]; g.N = n[1];
@@ -483,7 +488,7 @@ __global__ void zero_masked_columns_kernel(float* prob, const uint8_t* mask, int
 extern "C" {
 
 const char* imp_last_error(void) { return g_err.c_str(); }
-const char* imp_version(void) { return "imp_hip 0.1 gfx950 f32-mfma"; }
+const char* imp_version(void) { return "imp_hip 0.2 gfx950 f16x3-mfma|f32-mfma"; }
 
 int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     if (!out || !cfg) return fail(IMP_E_ARG, "imp_create: null argument");
@@ -502,6 +507,7 @@ int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     c->D = cfg->descriptor_dim;
     c->dh = c->D / IMP_NUM_HEADS;
     { const char* e = getenv("IMP_NO_FUSE_MERGE"); c->fuse_merge = !(e && e[0] == '1'); }
+    { const char* e = getenv("IMP_PRECISION"); c->prec = (e && !strcmp(e, "f32")) ? 0 : 1; }
     c->kenc_maxc = c->D;
     for (int i = 0; i < nk; ++i) if (cfg->kenc_channels[i] > c->kenc_maxc) c->kenc_maxc = cfg->kenc_channels[i];
     build_schema(c);
@@ -518,6 +524,13 @@ int imp_destroy(imp_ctx* c) {
     delete c;
     return IMP_OK;
 }
+
+int imp_set_precision(imp_ctx* c, int precision) {
+    if (!c || (precision != 0 && precision != 1)) return fail(IMP_E_ARG, "imp_set_precision: 0 (f32) or 1 (f16x3)");
+    c->prec = precision;
+    return IMP_OK;
+}
+int imp_get_precision(imp_ctx* c) { return c ? c->prec : -1; }
 
 int imp_num_keys(imp_ctx* c) { return c ? (int)c->schema.size() : 0; }
 const char* imp_key_name(imp_ctx* c, int i) {
@@ -680,7 +693,7 @@ int imp_attention_prob(imp_ctx* c, int which, float* prob, void* stream) {
     if (!cache.valid) return fail(IMP_E_STATE, "no cached attention of that kind");
     HIP_TRY(hipSetDevice(c->device));
     const int D = c->D, dh = c->dh, nq = cache.n[ps.qside], nk = cache.n[ps.kside];
-    GemmParams p = gemm_defaults(dh);
+    GemmParams p = gemm_defaults(c, dh);
     p.nside = 1; p.nsub = IMP_NUM_HEADS;
     GemmSide& g = p.side[0];
     g.A = c->qkv[ps.kind][ps.qside]; g.W = c->qkv[ps.kind][ps.kside] + D; g.C = prob;
@@ -849,7 +862,7 @@ int imp_op_linear(imp_ctx* c, int M, int N, int K, const float* x, const float* 
                   void* stream) {
     if (!c || !x || !W || !y || K % 32) return fail(IMP_E_ARG, "imp_op_linear: bad argument (K % 32 == 0)");
     HIP_TRY(hipSetDevice(c->device));
-    GemmParams p = gemm_defaults(K);
+    GemmParams p = gemm_defaults(c, K);
     p.nside = 1;
     GemmSide& g = p.side[0];
     g.A = x; g.W = W; g.C = y; g.M = M; g.N = N;
@@ -869,7 +882,7 @@ int imp_op_attention(imp_ctx* c, int batch, int nq, int nk, int dim, const float
     g.q = qkv_q; g.k = qkv_kv + dim; g.v = qkv_kv + 2 * dim; g.out = out; g.lse = lse; g.kmask = key_mask;
     g.sq_b = (long)nq * 3 * dim; g.sk_b = (long)nk * 3 * dim; g.so_b = (long)nq * dim;
     g.nq = nq; g.nk = nk;
-    HIP_TRY(launch_attention_f32(a, batch, S(stream)));
+    HIP_TRY(launch_attention(c, a, batch, S(stream)));
     return IMP_OK;
 }
 
@@ -890,9 +903,9 @@ int imp_time_attention(imp_ctx* c, int batch, int n, int reps, float* ms, void* 
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(launch_attention_f32(a, batch, st));   // warm
+    HIP_TRY(launch_attention(c, a, batch, st));   // warm
     HIP_TRY(hipEventRecord(e0, st));
-    for (int r = 0; r < reps; ++r) HIP_TRY(launch_attention_f32(a, batch, st));
+    for (int r = 0; r < reps; ++r) HIP_TRY(launch_attention(c, a, batch, st));
     HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(hipEventSynchronize(e1));
     float t = 0.f;

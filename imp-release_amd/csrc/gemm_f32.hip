@@ -20,12 +20,19 @@
 // neither of which is ever stored or counted), row pointers are computed once, and the prologue mode is a
 // template parameter (PRO 0: none, 1: InstanceNorm/fixed norm + ReLU, 2: generic affine norm + any activation).
 //
-// MFMA k-pairing: step s of a 32-deep K-tile multiplies k = s (lanes 0-31) and k = 16 + s (lanes 32-63);
+// PREC = 1 ("f16x3"): every fp32 operand x is split on the fly into two halves, hi = f16(x) and lo = f16(x - hi)
+// (22 significant bits together), and each fp32 product becomes three f16 MFMAs (hi.hi + hi.lo + lo.hi, fp32
+// accumulate, v_mfma_f32_32x32x16_f16): fp32-level results (validated end to end against the reference fixtures)
+// at 3/16 of the fp32-MFMA pipe time.  The LDS tile keeps its size: a row holds [32 hi halves | 32 lo halves].
+//
+// MFMA k-pairing (fp32 path): step s of a 32-deep K-tile multiplies k = s (lanes 0-31) and k = 16 + s (lanes 32-63);
 // A and W fragments use the same pairing so each lane reads 16 contiguous floats of its row.
 #include "imp_kernels.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -47,7 +54,16 @@ __device__ __forceinline__ int xcd_remap(int lin, int total) {
     return base + idx;
 }
 
-template <int BM, int BN, int PRO>
+// x -> (hi, lo) halves, round-to-nearest both times; x - float(hi) is exact in fp32
+__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = (_Float16)v[e];
+        lo[e] = (_Float16)(v[e] - (float)hi[e]);
+    }
+}
+
+template <int BM, int BN, int PRO, int PREC>
 __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const GemmParams p, int col_tiles, int row_tiles, int total) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int LA = BM / 32, LW = BN / 32;   // float4 loads per thread per K-tile
@@ -145,10 +161,30 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const GemmParams p, in
                     }
             }
         }
+        if (PREC == 0) {
 #pragma unroll
-        for (int j = 0; j < LA; ++j) *reinterpret_cast<f32x4*>(As + (lr + 32 * j) * LDT + lc) = ra[j];
+            for (int j = 0; j < LA; ++j) *reinterpret_cast<f32x4*>(As + (lr + 32 * j) * LDT + lc) = ra[j];
 #pragma unroll
-        for (int j = 0; j < LW; ++j) *reinterpret_cast<f32x4*>(Ws + (lr + 32 * j) * LDT + lc) = rw[j];
+            for (int j = 0; j < LW; ++j) *reinterpret_cast<f32x4*>(Ws + (lr + 32 * j) * LDT + lc) = rw[j];
+        } else {
+            // row = [hi: 32 halves = 16 dwords | lo: 32 halves | 4 dwords pad]; this thread owns k = lc..lc+3
+#pragma unroll
+            for (int j = 0; j < LA; ++j) {
+                f16x4 hi, lo;
+                split4(ra[j], hi, lo);
+                float* row = As + (lr + 32 * j) * LDT;
+                *reinterpret_cast<f16x4*>(row + (lc >> 1)) = hi;
+                *reinterpret_cast<f16x4*>(row + 16 + (lc >> 1)) = lo;
+            }
+#pragma unroll
+            for (int j = 0; j < LW; ++j) {
+                f16x4 hi, lo;
+                split4(rw[j], hi, lo);
+                float* row = Ws + (lr + 32 * j) * LDT;
+                *reinterpret_cast<f16x4*>(row + (lc >> 1)) = hi;
+                *reinterpret_cast<f16x4*>(row + 16 + (lc >> 1)) = lo;
+            }
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -161,37 +197,74 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const GemmParams p, in
 
     const int nkt = K / BK;
     load_tile(0);
-    const int frow = lane & 31, fk = (lane >> 5) * 16;
-    const float* as = As + (wm * WM + frow) * LDT + fk;
-    const float* ws = Ws + (wn * WN + frow) * LDT + fk;
-    for (int kt = 0; kt < nkt; ++kt) {
-        store_tile(kt);
-        __syncthreads();
-        load_tile(kt + 1 < nkt ? kt + 1 : kt);   // in flight during the MFMAs below (last one: harmless re-load)
-        f32x4 af[2][TM], wf[2][TN];              // fragment double buffer: c+1 is read while c is multiplied
+    const int frow = lane & 31;
+    if (PREC == 0) {
+        const int fk = (lane >> 5) * 16;
+        const float* as = As + (wm * WM + frow) * LDT + fk;
+        const float* ws = Ws + (wn * WN + frow) * LDT + fk;
+        for (int kt = 0; kt < nkt; ++kt) {
+            store_tile(kt);
+            __syncthreads();
+            load_tile(kt + 1 < nkt ? kt + 1 : kt);   // in flight during the MFMAs below (last one: harmless re-load)
+            f32x4 af[2][TM], wf[2][TN];              // fragment double buffer: c+1 is read while c is multiplied
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDT);
+            for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDT);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) wf[0][j] = *reinterpret_cast<const f32x4*>(ws + j * 32 * LDT);
+            for (int j = 0; j < TN; ++j) wf[0][j] = *reinterpret_cast<const f32x4*>(ws + j * 32 * LDT);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c < 3) {
+            for (int c = 0; c < 4; ++c) {
+                if (c < 3) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    af[(c + 1) & 1][i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDT + (c + 1) * 4);
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    wf[(c + 1) & 1][j] = *reinterpret_cast<const f32x4*>(ws + j * 32 * LDT + (c + 1) * 4);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
+                        af[(c + 1) & 1][i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDT + (c + 1) * 4);
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c & 1][i][e], wf[c & 1][j][e], acc[i][j], 0, 0, 0);
+                        wf[(c + 1) & 1][j] = *reinterpret_cast<const f32x4*>(ws + j * 32 * LDT + (c + 1) * 4);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c & 1][i][e], wf[c & 1][j][e], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();                          // every wave is done reading before the next store_tile
         }
-        __syncthreads();                          // every wave is done reading before the next store_tile
+    } else {
+        // f16x3: k-step s (16 deep) of the tile; lane (row, half) reads 8 consecutive halves k = 16 s + 8 half ...
+        const float* as = As + (wm * WM + frow) * LDT + (lane >> 5) * 4;
+        const float* ws = Ws + (wn * WN + frow) * LDT + (lane >> 5) * 4;
+        for (int kt = 0; kt < nkt; ++kt) {
+            store_tile(kt);
+            __syncthreads();
+            load_tile(kt + 1 < nkt ? kt + 1 : kt);
+            f16x8 ah[2][TM], al[2][TM], wh[2][TN], wl[2][TN];
+#pragma unroll
+            for (int sK = 0; sK < 2; ++sK) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[sK][i] = *reinterpret_cast<const f16x8*>(as + i * 32 * LDT + sK * 8);
+                    al[sK][i] = *reinterpret_cast<const f16x8*>(as + i * 32 * LDT + 16 + sK * 8);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    wh[sK][j] = *reinterpret_cast<const f16x8*>(ws + j * 32 * LDT + sK * 8);
+                    wl[sK][j] = *reinterpret_cast<const f16x8*>(ws + j * 32 * LDT + 16 + sK * 8);
+                }
+            }
+#pragma unroll
+            for (int sK = 0; sK < 2; ++sK)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sK][i], wh[sK][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sK][i], wl[sK][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sK][i], wh[sK][j], acc[i][j], 0, 0, 0);
+                    }
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: value transforms with the (uniform) flags hoisted out of the element loops -------------
@@ -347,27 +420,32 @@ void gemm_pick_tile(int M, int N, int total_z, int* bm, int* bn) {
     else { *bm = 64; *bn = 64; }
 }
 
-template <int BM, int BN, int PRO>
+template <int BM, int BN, int PRO, int PREC>
 hipError_t gemm_launch_one(const GemmParams& p, dim3 grid, hipStream_t stream) {
     const size_t lds = gemm_lds_bytes(BM, BN, PRO, p.K);
     static size_t lds_set = 0;           // largest dynamic-LDS size already granted to this instantiation
     if (lds > lds_set && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, PRO>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, PRO, PREC>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         lds_set = lds;
     }
     const int total = (int)(grid.x * grid.y * grid.z);
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, PRO>), dim3(total), dim3(256), lds, stream, p, (int)grid.x, (int)grid.y,
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, PRO, PREC>), dim3(total), dim3(256), lds, stream, p, (int)grid.x, (int)grid.y,
                        total);
     return hipGetLastError();
 }
 
 template <int BM, int BN>
 hipError_t gemm_launch_pro(const GemmParams& p, int pro, dim3 grid, hipStream_t stream) {
-    if (pro == 0) return gemm_launch_one<BM, BN, 0>(p, grid, stream);
-    if (pro == 1) return gemm_launch_one<BM, BN, 1>(p, grid, stream);
-    return gemm_launch_one<BM, BN, 2>(p, grid, stream);
+    if (p.prec == 1) {
+        if (pro == 0) return gemm_launch_one<BM, BN, 0, 1>(p, grid, stream);
+        if (pro == 1) return gemm_launch_one<BM, BN, 1, 1>(p, grid, stream);
+        return gemm_launch_one<BM, BN, 2, 1>(p, grid, stream);
+    }
+    if (pro == 0) return gemm_launch_one<BM, BN, 0, 0>(p, grid, stream);
+    if (pro == 1) return gemm_launch_one<BM, BN, 1, 0>(p, grid, stream);
+    return gemm_launch_one<BM, BN, 2, 0>(p, grid, stream);
 }
 
 }  // namespace

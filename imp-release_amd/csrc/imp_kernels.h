@@ -43,6 +43,7 @@ struct GemmParams {
     int lda, lda2, ldw, ldc, ldr;
     int nside, nsub;
     int flags, act;
+    int prec;              // 0: fp32 MFMA, 1: f16x3 split (hi/lo halves, 3 f16 MFMAs per fp32 product)
     float div, norm_eps;
 };
 
@@ -73,6 +74,8 @@ struct AttnParams {
     int nside, ldq, ldk, ldo, dh;
 };
 hipError_t launch_attention_f32(const AttnParams& p, int batch, hipStream_t stream);
+// split-precision variant (hi/lo halves, 3 f16 MFMAs per fp32 product): attention_f16x3.hip
+hipError_t launch_attention_f16x3(const AttnParams& p, int batch, hipStream_t stream);
 
 // column sums of the probability matrix: colsum[b][side][h][key] = sum_q exp(q.k*scale - lse[q])
 struct ColsumSide {

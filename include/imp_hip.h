@@ -24,7 +24,8 @@
  *    like the reference modules (nets/gm.py:79-82, nets/layers.py:132,209,216) - is stateful:
  *    it caches the last self / cross attention operands for the attention-sharing layers and
  *    for pooling.  One in-flight pair batch per context.
- *  - Arithmetic: float32 end-to-end (fp32-input MFMA for every GEMM-shaped op), int64 indices.
+ *  - Arithmetic: float32 storage and accumulation end-to-end; GEMM-shaped products on the matrix pipe either as
+ *    split-half f16x3 MFMAs (default, fp32-level accuracy) or native fp32 MFMAs (imp_set_precision); int64 indices.
  */
 #ifndef IMP_HIP_H
 #define IMP_HIP_H
@@ -85,6 +86,15 @@ int imp_destroy(imp_ctx* ctx);
  * reference's interleaved head layout (channel = d*4 + h, nets/layers.py:119-120) to head-major. */
 int imp_load_tensor(imp_ctx* ctx, const char* key, const float* data, const int64_t* shape, int ndim);
 int imp_finalize_weights(imp_ctx* ctx);
+/* Matrix arithmetic of every GEMM-shaped op (projections, attention, score matrix):
+ *   1 (default) "f16x3": each fp32 operand is split into two halves hi = f16(x), lo = f16(x - hi) and each fp32
+ *       product is three f16 MFMAs with fp32 accumulation - fp32-level results (parity suite green) at 3/16 of
+ *       the fp32-MFMA pipe time;
+ *   0 "f32": native fp32-input MFMA (v_mfma_f32_32x32x2_f32).
+ * Environment override at imp_create: IMP_PRECISION=f32|f16x3. */
+int imp_set_precision(imp_ctx* ctx, int precision);
+int imp_get_precision(imp_ctx* ctx);
+
 /* number of schema keys / i-th key (so a host can enumerate what strict loading expects) */
 int imp_num_keys(imp_ctx* ctx);
 const char* imp_key_name(imp_ctx* ctx, int i);

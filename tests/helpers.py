@@ -46,9 +46,12 @@ def build_case(spec, device='cpu'):
     return cfg, sd, data
 
 
-def make_hip_model(spec_or_model, cfg, sd, device='cuda'):
+def make_hip_model(spec_or_model, cfg, sd, device='cuda', precision=None):
+    """precision: None = library default (f16x3 split-half MFMA), 'f32' = native fp32 MFMA"""
     import imp_release_amd as P
     name = spec_or_model if isinstance(spec_or_model, str) else spec_or_model['model']
+    if precision is not None:
+        cfg = dict(cfg, precision=precision)
     m = getattr(P, name)(cfg).eval()
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     return m.to(device)

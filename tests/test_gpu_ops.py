@@ -12,15 +12,15 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
 
-def _model(model='GM', **over):
+def _model(model='GM', precision=None, **over):
     cfg = eval_config(**{'n_layers': 2, **over})
     sd = synthetic.make_state_dict(cfg, model=model, seed=5)
-    return cfg, sd, make_hip_model(model, cfg, sd), orc.MatcherOracle(cfg, sd, model=model)
+    return cfg, sd, make_hip_model(model, cfg, sd, precision=precision), orc.MatcherOracle(cfg, sd, model=model)
 
 
-@pytest.fixture(scope='module')
-def gm():
-    return _model()
+@pytest.fixture(scope='module', params=['f16x3', 'f32'])
+def gm(request):
+    return _model(precision=request.param)
 
 
 def _rand(*shape, seed=0, scale=1.0):
@@ -36,7 +36,8 @@ def test_linear_fp32_mfma(gm, M, N, K):
     y = ctx.op_linear(x.to(DEV), W.to(DEV), b.to(DEV)).cpu()
     ref = (x.double() @ W.double().t() + b.double())
     err = (y.double() - ref).abs().max().item()
-    assert err < 2e-6 * max(1.0, ref.abs().max().item()) * (K / 32) ** .5, f'linear {M}x{N}x{K}: max err {err:.3e}'
+    # fp32 MFMA: fp32 summation-order noise; f16x3: 2^-22 relative per product on top (still fp32-class)
+    assert err < 3e-6 * max(1.0, ref.abs().max().item()) * (K / 32) ** .5, f'linear {M}x{N}x{K}: max err {err:.3e}'
     # transposition check (asymmetric operands): compare against the transposed product explicitly
     if M == N:
         assert (y.double() - ref.t()).abs().max().item() > 1e-2
@@ -151,11 +152,12 @@ def test_encode_keypoints(norm, act, D):
     assert (f0.cpu() - (t['descriptors0'] + r0)).abs().max().item() < 5e-5
 
 
+@pytest.mark.parametrize('precision', ['f16x3', 'f32'])
 @pytest.mark.parametrize('model,norm,D,n0,n1', [('GM', 'in', 256, 300, 307), ('GM', 'bn', 256, 128, 64),
                                                 ('DGNNS', 'in', 256, 200, 260), ('GM', 'in', 128, 150, 140)])
-def test_forward_layers_and_cached_attention(model, norm, D, n0, n1):
+def test_forward_layers_and_cached_attention(model, norm, D, n0, n1, precision):
     nl = 4 if model == 'DGNNS' else 2
-    cfg, sd, m, o = _model(model, norm_fn=norm, descriptor_dim=D, n_layers=nl)
+    cfg, sd, m, o = _model(model, precision=precision, norm_fn=norm, descriptor_dim=D, n_layers=nl)
     ctx = m._ensure_ctx()
     B = 2
     x0, x1 = _rand(B, n0, D, seed=11, scale=0.5), _rand(B, n1, D, seed=12, scale=0.5)

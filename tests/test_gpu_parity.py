@@ -20,11 +20,13 @@ def _cpu(x):
     return x.detach().cpu()
 
 
+@pytest.mark.parametrize('precision', ['f16x3', 'f32'])
 @pytest.mark.parametrize('name', golden_names(['gm_l', 'dgnns_l', 'adagmn_masked']))
-def test_produce_matches_vs_golden(name):
+def test_produce_matches_vs_golden(name, precision):
     spec, z = load_golden(name)
     cfg, sd, data = build_case(spec, DEV)
-    m = make_hip_model(spec, cfg, sd)
+    m = make_hip_model(spec, cfg, sd, precision=precision)
+    assert m._ensure_ctx().precision == precision
     call = spec.get('call', {})
     with torch.no_grad():
         out = m.produce_matches(data, **call)
@@ -87,12 +89,13 @@ def test_imp_iterative_loop_vs_golden():
     compare_matches(i0, ms0, z['indices0'], z['mscores0'], 0.2, TOL, 'imp loop final')
 
 
-def test_eimp_sliced_loop_vs_golden():
+@pytest.mark.parametrize('precision', ['f16x3', 'f32'])
+def test_eimp_sliced_loop_vs_golden(precision):
     """BASELINE config 4 analogue: real ragged slicing (pool -> compaction -> gather), pinned to the
     reference's pruning trajectory 1024/1000 -> 751/725 -> ... (tests/golden/eimp_loop_sliced_n1024)."""
     spec, z = load_golden('eimp_loop_sliced_n1024')
     cfg, sd, data = build_case(spec, DEV)
-    m = make_hip_model(spec, cfg, sd)
+    m = make_hip_model(spec, cfg, sd, precision=precision)
     trace = []
     with torch.no_grad():
         p0, p1, nk0, nk1, i0, ms0, R, t, nit = hip_matching.matching_iterative_uncertainty(
@@ -141,11 +144,11 @@ def test_reference_style_step_api_loop_matches_fused_path():
 # ---------------------------------------------------------------------------------------------------
 # BASELINE sizes (N = 2048, L = 9, T = 100): oracle comparison once + size-independent properties
 # ---------------------------------------------------------------------------------------------------
-@pytest.fixture(scope='module')
-def big():
+@pytest.fixture(scope='module', params=['f16x3', 'f32'])
+def big(request):
     cfg = eval_config(n_layers=9, sinkhorn_iterations=100)
     sd = synthetic.make_state_dict(cfg, 'GM', seed=1)
-    m = make_hip_model('GM', cfg, sd)
+    m = make_hip_model('GM', cfg, sd, precision=request.param)
     pair = synthetic.make_correlated_pair(2048, 2048, seed=31, batch=2)
     data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
     data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
