@@ -105,12 +105,14 @@ struct OtBuffers {
     float* P;      // [B][n0+1][ldp]      row softmax of the dustbin-augmented matrix (or logits for dual softmax)
     float* PT;     // [B][n1+1][ldpt]     transpose of P
     float* u;      // [B][n0+1]
-    float* v;      // [B][n1+1]
+    float* v;      // [B][n1+1]   (always the newest v: the fused Sinkhorn path ping-pongs v <-> v2)
+    float* v2;     // second v buffer
+    float* partials; // [B][ceil((n0+1)/16)][ldp] column partial sums of the fused Sinkhorn pass (null: two-pass path)
     int ldp, ldpt;
 };
 hipError_t launch_ot_init(const float* dist, int batch, int n0, int n1, float bin_score, int dual,
                           const OtBuffers& ot, hipStream_t stream);
-hipError_t launch_ot_iterations(int batch, int n0, int n1, int iterations, const OtBuffers& ot, hipStream_t stream);
+hipError_t launch_ot_iterations(int batch, int n0, int n1, int iterations, OtBuffers& ot, hipStream_t stream);
 // dual softmax: row / column log-sum-exp into u / v
 hipError_t launch_ot_dual_lse(int batch, int n0, int n1, const OtBuffers& ot, hipStream_t stream);
 // scores[b][i][j] = (P*u)*v  (or exp(lsr + lsc) for dual)   [B][n0+1][n1+1] contiguous

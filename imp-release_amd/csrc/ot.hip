@@ -41,7 +41,8 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 // one wave per augmented row; dual != 0 keeps the augmented logits instead (dual_softmax needs them)
 __global__ __launch_bounds__(256) void ot_init_kernel(const float* __restrict__ dist, int n0, int n1, float bin,
                                                       int dual, float* __restrict__ P, int ldp,
-                                                      float* __restrict__ u, float* __restrict__ v, int ldpt) {
+                                                      float* __restrict__ u, float* __restrict__ v, int ldpt,
+                                                      float* __restrict__ v2) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     const int b = blockIdx.y;
@@ -50,7 +51,10 @@ __global__ __launch_bounds__(256) void ot_init_kernel(const float* __restrict__ 
     float* prow = P + ((long)b * (n0 + 1) + row) * ldp;
     const bool last = row == n0;
     if (row == 0) {   // Sinkhorn start vectors (nets/layers.py:29-30); padded tails are zero
-        for (int j = lane; j < ldp; j += 64) v[(long)b * ldp + j] = j <= n1 ? 1.f : 0.f;
+        for (int j = lane; j < ldp; j += 64) {
+            v[(long)b * ldp + j] = j <= n1 ? 1.f : 0.f;
+            if (v2) v2[(long)b * ldp + j] = 0.f;      // pads of the ping-pong buffer stay zero
+        }
         for (int i = lane; i < ldpt; i += 64) u[(long)b * ldpt + i] = i <= n0 ? 1.f : 0.f;
     }
     if (dual) {
@@ -130,6 +134,138 @@ __global__ __launch_bounds__(256) void ot_rowpass_kernel(const float* __restrict
             const float marg = r == rows - 1 ? (float)rows : 1.f;
             out[(long)b * ld_out + r] = marg / (s + OT_EPS);
         }
+    }
+}
+
+// ---- fused Sinkhorn iteration: ONE read of P per iteration ------------------------------------------------
+// A wave keeps a whole row of P in registers (NCH float4 per lane): dot with v -> u_i (nets/layers.py:32), then the
+// SAME registers times u_i are accumulated into per-lane column partials for nets/layers.py:33, so the transposed
+// pass disappears.  4 rows per wave (next row prefetched while the current one is reduced), 4 waves per workgroup
+// combine their partials in LDS and write one partial vector per workgroup; ot_colreduce_kernel turns the partial
+// vectors into v.  Fixed summation order everywhere (no atomics).
+constexpr int FP_WAVES = 8, FP_RPW = 2, FP_ROWS = FP_WAVES * FP_RPW;   // 512 threads, 16 rows per workgroup
+template <int NCH>
+__global__ __launch_bounds__(512, 2) void ot_fused_pass_kernel(const float* __restrict__ P, int rows, int prows, int ld,
+                                                               const float* __restrict__ v, float* __restrict__ u,
+                                                               int ld_u, float* __restrict__ partials, int nwg) {
+    // rows = n0 REAL rows handled here (the constant dustbin row n0 is folded into ot_colreduce_kernel so that the
+    // grid is ceil(n0/16) x B workgroups - exactly 2 per CU at n0 = 2048, B = 4); prows = n0 + 1 rows per pair in P
+    extern __shared__ __attribute__((aligned(16))) float lds[];     // [ld] v  |  [FP_WAVES][ld] partial vectors
+    float* vs = lds;
+    float* red = lds + ld;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * FP_ROWS + wave * FP_RPW;
+    const float* base = P + (long)b * prows * ld;
+    const int n4 = ld >> 2;
+    f32x4 part[NCH], row[2][NCH];
+    auto load_row = [&](int slot, int r) {
+        const f32x4* rp = reinterpret_cast<const f32x4*>(base + (long)min(r, rows - 1) * ld);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int c4 = min(lane + 64 * c, n4 - 1);     // clamped: the duplicate is zeroed by the v image below
+            row[slot][c] = rp[c4];
+        }
+    };
+    load_row(0, r0);
+    load_row(1, r0 + 1);
+    {   // v -> LDS once per workgroup; chunk slots past the row end read an explicit zero
+        const f32x4* vin = reinterpret_cast<const f32x4*>(v + (long)b * ld);
+        for (int c4 = threadIdx.x; c4 < n4; c4 += 512) *reinterpret_cast<f32x4*>(vs + 4 * c4) = vin[c4];
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) part[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < FP_RPW; ++k) {
+        const int r = r0 + k;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int c4 = lane + 64 * c;
+            if (c4 < n4) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(vs + 4 * c4);
+                const f32x4 m = row[k][c];
+                acc = fmaf(m[0], x[0], acc);
+                acc = fmaf(m[1], x[1], acc);
+                acc = fmaf(m[2], x[2], acc);
+                acc = fmaf(m[3], x[3], acc);
+            }
+        }
+        const float sdot = wave_sum(acc);
+        const float ui = r < rows ? 1.f / (sdot + OT_EPS) : 0.f;      // real rows: marginal 1; rows past the end: nothing
+        if (lane == 0 && r < rows) u[(long)b * ld_u + r] = ui;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[c][e] = fmaf(row[k][c][e], ui, part[c][e]);
+    }
+    // workgroup combine: FP_WAVES partial vectors -> 1 (fixed order)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int c4 = lane + 64 * c;
+        if (c4 < n4) *reinterpret_cast<f32x4*>(red + wave * ld + 4 * c4) = part[c];
+    }
+    __syncthreads();
+    float* out = partials + ((long)b * nwg + blockIdx.x) * ld;
+    for (int j = threadIdx.x; j < ld; j += 512) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < FP_WAVES; ++w) s += red[w * ld + j];
+        out[j] = s;
+    }
+}
+
+// v_new[j] = c_j / (sum over workgroup partials + P[n0][j] * u[n0] + eps), c = 1 except the dustbin column = cols
+// (nets/layers.py:33,43-44).  The dustbin ROW n0 of P is handled here: u[n0] = (n0+1) / (P[n0][:] . v_old + eps)
+// (nets/layers.py:32,41-42), computed redundantly per workgroup in a fixed order; v is ping-ponged (v_old -> v_new).
+// block = 64 columns x 16 partial groups (1024 threads): group g sums partials g, g+16, ... ; LDS combine in order
+__global__ __launch_bounds__(1024) void ot_colreduce_kernel(const float* __restrict__ partials, int nwg, int ld, int cols,
+                                                            const float* __restrict__ P, int n0,
+                                                            const float* __restrict__ v_old, float* __restrict__ v_new,
+                                                            float* __restrict__ u, int ld_u) {
+    __shared__ float sm[16][64];
+    __shared__ float dpart[16];
+    __shared__ float ulast_s;
+    const int cx = threadIdx.x & 63, g = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 64 + cx;
+    const float* plast = P + ((long)b * (n0 + 1) + n0) * ld;
+    const float* vo = v_old + (long)b * ld;
+    // dustbin-row dot product: thread t takes columns t, t+1024, ... (pads of P and v are zero)
+    float d = 0.f;
+    for (int c = threadIdx.x; c < ld; c += 1024) d = fmaf(plast[c], vo[c], d);
+    float s = 0.f;
+    if (j < cols) {
+        const float* pp = partials + (long)b * nwg * ld + j;
+        int w = g;
+        for (; w + 48 < nwg; w += 64) {          // 4 independent loads in flight
+            const float t0 = pp[(long)w * ld], t1 = pp[(long)(w + 16) * ld], t2 = pp[(long)(w + 32) * ld],
+                        t3 = pp[(long)(w + 48) * ld];
+            s += (t0 + t1) + (t2 + t3);
+        }
+        for (; w < nwg; w += 16) s += pp[(long)w * ld];
+    }
+    d = wave_sum(d);
+    sm[g][cx] = s;
+    if (lane == 0) dpart[g] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += dpart[k];
+        const float ul = (float)(n0 + 1) / (t + OT_EPS);
+        ulast_s = ul;
+        if (blockIdx.x == 0) u[(long)b * ld_u + n0] = ul;
+    }
+    __syncthreads();
+    if (g == 0 && j < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][cx];
+        t = fmaf(plast[j], ulast_s, t);
+        const float marg = j == cols - 1 ? (float)cols : 1.f;
+        v_new[(long)b * ld + j] = marg / (t + OT_EPS);
     }
 }
 
@@ -331,13 +467,39 @@ __global__ __launch_bounds__(256) void colsum_combine_kernel(const float* __rest
 hipError_t launch_ot_init(const float* dist, int batch, int n0, int n1, float bin_score, int dual,
                           const OtBuffers& ot, hipStream_t stream) {
     hipLaunchKernelGGL(ot_init_kernel, dim3((n0 + 1 + 3) / 4, batch), dim3(256), 0, stream, dist, n0, n1, bin_score,
-                       dual, ot.P, ot.ldp, ot.u, ot.v, ot.ldpt);
+                       dual, ot.P, ot.ldp, ot.u, ot.v, ot.ldpt, ot.v2);
     hipLaunchKernelGGL(ot_transpose_kernel, dim3((n1 + 1 + 31) / 32, (ot.ldpt + 31) / 32, batch), dim3(256), 0, stream,
                        ot.P, n0 + 1, n1 + 1, ot.ldp, ot.PT, ot.ldpt);
     return hipGetLastError();
 }
 
-hipError_t launch_ot_iterations(int batch, int n0, int n1, int iterations, const OtBuffers& ot, hipStream_t stream) {
+template <int NCH>
+static void launch_fused_iteration(int batch, int n0, int n1, OtBuffers& ot, hipStream_t stream) {
+    const int nwg = (n0 + FP_ROWS - 1) / FP_ROWS;
+    const size_t lds = (size_t)(1 + FP_WAVES) * ot.ldp * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)ot_fused_pass_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)((1 + FP_WAVES) * 2304 * sizeof(float)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ot_fused_pass_kernel<NCH>, dim3(nwg, batch), dim3(512), lds, stream, ot.P, n0, n0 + 1, ot.ldp, ot.v,
+                       ot.u, ot.ldpt, ot.partials, nwg);
+    hipLaunchKernelGGL(ot_colreduce_kernel, dim3((n1 + 1 + 63) / 64, batch), dim3(1024), 0, stream, ot.partials, nwg,
+                       ot.ldp, n1 + 1, ot.P, n0, ot.v, ot.v2, ot.u, ot.ldpt);
+    float* t = ot.v; ot.v = ot.v2; ot.v2 = t;      // ping-pong: ot.v is always the newest v
+}
+
+hipError_t launch_ot_iterations(int batch, int n0, int n1, int iterations, OtBuffers& ot, hipStream_t stream) {
+    if (ot.partials && ot.v2 && ot.ldp <= 2304) {
+        // fused path: P is read once per iteration (row held in registers), column partials reduced by a tiny kernel
+        for (int it = 0; it < iterations; ++it) {
+            if (ot.ldp <= 512) launch_fused_iteration<2>(batch, n0, n1, ot, stream);
+            else if (ot.ldp <= 1280) launch_fused_iteration<5>(batch, n0, n1, ot, stream);
+            else launch_fused_iteration<9>(batch, n0, n1, ot, stream);
+        }
+        return hipGetLastError();
+    }
     constexpr int RPW = 2;
     const dim3 g0((n0 + 1 + 4 * RPW - 1) / (4 * RPW), batch), g1((n1 + 1 + 4 * RPW - 1) / (4 * RPW), batch);
     for (int it = 0; it < iterations; ++it) {

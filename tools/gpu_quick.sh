@@ -14,6 +14,6 @@ import json
 for l in open('gpurun_out/bench_$TAG.log'):
     if l.startswith('{'):
         d=json.loads(l); r=d['roofline']
-        print('pairs/s %.1f  ms/step %.2f  attn %.1f TF (%.3f ms)  whole %.1f TF  sinkhorn pass %.1f us' % (d['value'], d['ms_per_step'], r['achieved'], r['launch_ms'], r['whole_path_tflops'], r['sinkhorn_rowpass']['launch_ms']*1e3))
+        print('pairs/s %.1f  ms/step %.2f  attn %.1f TF (%.3f ms)  whole %.1f TF  sinkhorn iter %.1f us' % (d['value'], d['ms_per_step'], r['achieved'], r['launch_ms'], r['whole_path_tflops'], r['sinkhorn_iteration']['iteration_ms']*1e3))
 PY
 head -7 gpurun_out/prof_$TAG/bench_kernel_stats.csv | cut -c1-160
