@@ -19,6 +19,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -88,21 +89,39 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_f16x3_kernel(const AttnPa
     f32x4 rk[KLPT];
     float rv[VGPT][16];
     float rb = 0.f;
+    // Staging loads go through raw buffer loads: SGPR descriptor (wave-uniform K / V base of this batch/head),
+    // 32-bit per-lane byte offset (loop invariant), scalar byte offset for the tile / key row: no 64-bit VALU address
+    // arithmetic in the loop, and rows past nk read as ZERO by the hardware bounds check (they are neutralised by the
+    // -inf key bias anyway), so there is no clamped tail path.
+    const unsigned kv_bytes = (unsigned)(((long)(nk - 1) * p.ldk + DH) * 4);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kg, 0, kv_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vg, 0, kv_bytes, 0x00020000);
+    int koff[KLPT], voff[VGPT];
+#pragma unroll
+    for (int j = 0; j < KLPT; ++j) {
+        const int f = tid + j * NT;
+        koff[j] = ((f / (DH / 4)) * p.ldk + (f % (DH / 4)) * 4) * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < VGPT; ++i) {
+        const int g = tid + i * NT;
+        voff[i] = (((g / DH) * 16) * p.ldk + (g % DH)) * 4;
+    }
+    const int row_bytes = p.ldk * 4;
     auto load_tile = [&](int t) {
         const int k0 = t * KT;
+        const int soff = k0 * row_bytes;                    // uniform
 #pragma unroll
         for (int j = 0; j < KLPT; ++j) {
-            const int f = tid + j * NT;
-            const int row = f / (DH / 4), c4 = (f % (DH / 4)) * 4;
-            rk[j] = *reinterpret_cast<const f32x4*>(Kg + (long)min(k0 + row, nk - 1) * p.ldk + c4);
+            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsK, koff[j], soff, 0);
+            rk[j] = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
         }
 #pragma unroll
         for (int i = 0; i < VGPT; ++i) {
-            const int g = tid + i * NT;
-            if (VG % NT == 0 || g < VG) {
-                const int d = g % DH, kg = g / DH;
+            if (VG % NT == 0 || tid + i * NT < VG) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) rv[i][e] = Vg[(long)min(k0 + kg * 16 + e, nk - 1) * p.ldk + d];
+                for (int e = 0; e < 16; ++e)
+                    rv[i][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsV, voff[i], soff + e * row_bytes, 0));
             }
         }
         if (tid < KT) {
