@@ -190,6 +190,16 @@ def main():
     pair_flops = (4 * args.iters * (20 * 256 ** 2 * N + 4 * N * N * 256) + 2 * 2 * N * 108640 + 4 * 256 ** 2 * N
                   + 2 * N * N * 256 + args.sinkhorn * 4 * (N + 1) ** 2)
 
+    # HBM traffic of the dominant kernel: measured offline with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in their own
+    # passes (tools/gpu_pmc.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction) and committed under
+    # profiles/; reported only when the profiled kernel and launch geometry are the ones timed here
+    traffic = None
+    kname = 'attn_f16x3_kernel<64, 4>' if f16x3 else 'attn_f32_kernel<64, 4>'
+    tpath = os.path.join(ROOT, 'profiles', 'r01', 'traffic_v3.json')
+    if os.path.exists(tpath):
+        for k, v in json.load(open(tpath)).items():
+            if k.startswith(kname) and k.endswith(f'grid={-(-N // 128) * 4 * 2 * B * 256}'):
+                traffic = v['fetch_bytes_corrected'] + v['write_bytes']
     if rank == 0:
         line = {
             'metric': 'image-pairs/s (N=2048 kpts, 9 self+cross iters, 100 Sinkhorn)',
@@ -205,7 +215,9 @@ def main():
                        'matched_keypoints': n_matched},
             'roofline': {'bound': 'mfma', 'kernel': 'attn_f16x3_kernel<64,4>' if f16x3 else 'attn_f32_kernel<64,4>',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': None, 'launch_ms': attn_ms, 'flops_per_launch': attn_flops,
+                         'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/r01/traffic_v3.json)',
+                         'algorithmic_bytes_per_launch': (3 * 256 + 256) * 4.0 * N * 2 * B,
+                         'launch_ms': attn_ms, 'flops_per_launch': attn_flops,
                          'peak_note': ('algorithmic fp32-equivalent flops; peak = 2500 TF dense f16 MFMA / 3 products per '
                                        'flop (executed MFMA rate = 3 x achieved); native fp32-MFMA roof would be 157.3')
                          if f16x3 else 'native fp32-input MFMA, dense',
