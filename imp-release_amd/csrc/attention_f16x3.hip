@@ -203,14 +203,16 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_f16x3_kernel(const AttnPa
                     kh[jb][s] = *reinterpret_cast<const f16x8*>(ks + jb * 32 * KROW + 8 * s);
                     kl[jb][s] = *reinterpret_cast<const f16x8*>(ks + jb * 32 * KROW + DH / 2 + 8 * s);
                 }
+            // product-major order: consecutive MFMAs alternate between the two accumulators (no dependent pairs)
 #pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int jb = 0; jb < 2; ++jb) {
-                    sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[jb][s], qh[s], sacc[jb], 0, 0, 0);
-                    sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[jb][s], ql[s], sacc[jb], 0, 0, 0);
-                    sacc[jb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[jb][s], qh[s], sacc[jb], 0, 0, 0);
-                }
+            for (int s = 0; s < KS; ++s) {
+                sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[0][s], qh[s], sacc[0], 0, 0, 0);
+                sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[1][s], qh[s], sacc[1], 0, 0, 0);
+                sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[0][s], ql[s], sacc[0], 0, 0, 0);
+                sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[1][s], ql[s], sacc[1], 0, 0, 0);
+                sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[0][s], qh[s], sacc[0], 0, 0, 0);
+                sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[1][s], qh[s], sacc[1], 0, 0, 0);
+            }
         }
         // ---- online softmax on the raw dot products (scale folded into the exp2 constant) ---------------------
         if (mk != nullptr || (t + 1) * KT > nk) {
@@ -261,11 +263,11 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_f16x3_kernel(const AttnPa
                     ph[e] = hh; pl[e] = ll;
                 }
 #pragma unroll
-                for (int d = 0; d < DT; ++d) {
-                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[d], ph, oacc[d], 0, 0, 0);
-                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[d], pl, oacc[d], 0, 0, 0);
-                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[d], ph, oacc[d], 0, 0, 0);
-                }
+                for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[d], ph, oacc[d], 0, 0, 0);
+#pragma unroll
+                for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[d], pl, oacc[d], 0, 0, 0);
+#pragma unroll
+                for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[d], ph, oacc[d], 0, 0, 0);
             }
         }
         l_run = l_run * alpha + lsum;

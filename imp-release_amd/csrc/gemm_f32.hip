@@ -253,16 +253,25 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const GemmParams p, in
                     wl[sK][j] = *reinterpret_cast<const f16x8*>(ws + j * 32 * LDT + 16 + sK * 8);
                 }
             }
+            // product-major issue order: consecutive MFMAs write DIFFERENT accumulators (no dependent back-to-back pairs)
 #pragma unroll
-            for (int sK = 0; sK < 2; ++sK)
+            for (int sK = 0; sK < 2; ++sK) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) {
+                    for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[sK][i], wh[sK][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sK][i], wl[sK][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sK][i], wh[sK][j], acc[i][j], 0, 0, 0);
-                    }
+            }
             __syncthreads();
         }
     }
