@@ -222,7 +222,7 @@ int ensure_workspace(imp_ctx* c, int batch, int n) {
     if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->ot.u, B * ld);
     if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->ot.v, B * ld);
     if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->ot.v2, B * ld);
-    if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->ot.partials, B * ((N + 1 + 15) / 16) * ld);
+    if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->ot.partials, B * ((N + 1 + 15) / 16) * ld);   // >= ceil(n0 / FP_ROWS) partial vectors
     if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->max0, B * N);
     if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->max1, B * N);
     if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->arg0, B * N);

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void ot_rowpass_kernel(const float* __restrict
 // pass disappears.  4 rows per wave (next row prefetched while the current one is reduced), 4 waves per workgroup
 // combine their partials in LDS and write one partial vector per workgroup; ot_colreduce_kernel turns the partial
 // vectors into v.  Fixed summation order everywhere (no atomics).
-constexpr int FP_WAVES = 8, FP_RPW = 2, FP_ROWS = FP_WAVES * FP_RPW;   // 512 threads, 16 rows per workgroup
+constexpr int FP_WAVES = 8, FP_RPW = 4, FP_ROWS = FP_WAVES * FP_RPW;   // 512 threads, 32 rows per workgroup
 template <int NCH>
 __global__ __launch_bounds__(512, 2) void ot_fused_pass_kernel(const float* __restrict__ P, int rows, int prows, int ld,
                                                                const float* __restrict__ v, float* __restrict__ u,
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(512, 2) void ot_fused_pass_kernel(const float* __re
             const int c4 = lane + 64 * c;
             if (c4 < n4) {
                 const f32x4 x = *reinterpret_cast<const f32x4*>(vs + 4 * c4);
-                const f32x4 m = row[k][c];
+                const f32x4 m = row[k & 1][c];
                 acc = fmaf(m[0], x[0], acc);
                 acc = fmaf(m[1], x[1], acc);
                 acc = fmaf(m[2], x[2], acc);
@@ -198,7 +198,8 @@ __global__ __launch_bounds__(512, 2) void ot_fused_pass_kernel(const float* __re
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) part[c][e] = fmaf(row[k][c][e], ui, part[c][e]);
+            for (int e = 0; e < 4; ++e) part[c][e] = fmaf(row[k & 1][c][e], ui, part[c][e]);
+        if (k + 2 < FP_RPW) load_row(k & 1, r0 + k + 2);      // rotate the two register slots: row k+2 streams in
     }
     // workgroup combine: FP_WAVES partial vectors -> 1 (fixed order)
 #pragma unroll

@@ -227,3 +227,29 @@ def test_eimp_pruning_path_at_4096():
     assert pos == sorted(pos)
     assert ((i0 >= -1) & (i0 < p1.shape[0])).all()
     print(f'N trajectory end: {p0.shape[0]}/{p1.shape[0]}, matches {(i0 >= 0).sum()}')
+
+
+def test_fused_call_is_hip_graph_capturable():
+    """imp_match_pair enqueues ~300 kernels and never synchronises or allocates once the workspace is sized: the
+    whole pair can be captured in a HIP graph and replayed (bitwise the same result as the eager call)."""
+    cfg = eval_config(n_layers=3)
+    sd = synthetic.make_state_dict(cfg, 'DGNNS', seed=2)
+    m = make_hip_model('DGNNS', cfg, sd)
+    pair = synthetic.make_correlated_pair(300, 280, seed=9, batch=2)
+    d = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+    ctx = m._ensure_ctx()
+    args = (d['keypoints0'], d['scores0'], d['descriptors0'], d['keypoints1'], d['scores1'], d['descriptors1'],
+            640., 480., 1.0, 20, True, 0.2)
+    eager = ctx.match_pair(*args, want_side1=True)
+    out = {k: torch.zeros_like(v) for k, v in eager.items()}
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ctx.match_pair(*args, out=out)
+    for _ in range(2):
+        for v in out.values():
+            v.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for k in eager:
+            assert torch.equal(out[k], eager[k]), k
