@@ -808,6 +808,7 @@ int imp_pool(imp_ctx* c, int n0, int n1, const float* scores, float mscore_th, f
             ColsumSide& g = p.side[keyside];
             g.q = c->qkv[kind][qside]; g.k = c->qkv[kind][keyside] + D; g.lse = c->lse[kind][qside];
             g.out = c->colsum[kind * 2 + keyside];
+            g.kmask = c->cache[kind].masked[keyside] ? c->cmask[kind][keyside] : nullptr;   // masked keys received exactly 0
             g.nq = kind == 0 ? (keyside ? n1 : n0) : (qside ? n1 : n0);
             g.nk = keyside ? n1 : n0;
             g.sq_b = (long)g.nq * 3 * D; g.sk_b = (long)g.nk * 3 * D;

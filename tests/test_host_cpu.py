@@ -101,6 +101,15 @@ def test_pack_roundtrip():
     assert torch.equal(a, i) and torch.equal(b, m)
 
 
+def test_eval_loop_summary_rows():
+    from imp_release_amd import eval_loop
+    i0 = np.array([3, -1, 0, -1]); ms = np.array([0.5, 0.0, 0.3, 0.0], dtype=np.float32)
+    r = eval_loop.summarize((i0, ms, None, None, 15), eimp=False)
+    assert r.tolist()[:2] == [15, 2] and abs(r[2] - 0.4) < 1e-6 and r[3] == -1
+    r = eval_loop.summarize((np.zeros((7, 2)), np.zeros((9, 2)), None, None, i0, ms, None, None, 12), eimp=True)
+    assert r.tolist() == [12, 2, r[2], 7, 9]
+
+
 _WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
@@ -114,6 +123,13 @@ full_m = torch.rand(n_total, N, generator=g)
 s, e = pdist.shard_range(n_total, rank, world)
 gi, gm = pdist.all_gather_matches(full_i[s:e], full_m[s:e], n_total)
 assert torch.equal(gi, full_i) and torch.equal(gm, full_m), rank
+# per-pair summary rows of the sharded evaluation loop
+import numpy as np
+from imp_release_amd import eval_loop
+table = np.arange(7 * 5, dtype=np.float64).reshape(7, 5)
+s2, e2 = pdist.shard_range(7, rank, world)
+got = eval_loop.gather_rows_across_ranks(table[s2:e2], 7)
+assert np.array_equal(got, table), rank
 dist.barrier()
 dist.destroy_process_group()
 print('rank', rank, 'ok')

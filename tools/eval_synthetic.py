@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Synthetic analogue of `python -m eval.eval_imp --matching_method IMP|EIMP --use_iterative` (BASELINE config 5):
+N independent synthetic pairs through the iterative loop, sharded over the ranks of one node.
+
+    python tools/eval_synthetic.py --pairs 16 --model EIMP --kpts 2048
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/eval_synthetic.py --pairs 4000 --model EIMP
+
+The OpenCV pose step of the reference is out of scope (no cv2 here): the loops run without early exit."""
+import argparse, json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import imp_release_amd as P
+from imp_release_amd import synthetic, eval_loop
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--pairs', type=int, default=16)
+    ap.add_argument('--model', choices=['IMP', 'EIMP'], default='EIMP')
+    ap.add_argument('--kpts', type=int, default=2048)
+    ap.add_argument('--bin-score', type=float, default=5.0)
+    a = ap.parse_args()
+    rank, world, lr = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(lr)
+    dev = torch.device('cuda', lr)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    cfg = {'descriptor_dim': 256, 'sinkhorn_iterations': 20, 'match_threshold': 0.2, 'with_sinkhorn': True, 'n_layers': 15,
+           'GNN_layers': ['self', 'cross'] * 15, 'ac_fn': 'relu', 'norm_fn': 'in', 'n_min_tokens': 256}
+    name = 'AdaGMN' if a.model == 'EIMP' else 'DGNNS'
+    sd = synthetic.make_state_dict(cfg, name, seed=0, bin_score=a.bin_score)
+    m = getattr(P, name)(cfg).eval()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m = m.to(dev)
+
+    def provider(pid):
+        pair = synthetic.make_correlated_pair(a.kpts, a.kpts - 37, seed=1000 + pid)
+        d = {k: torch.from_numpy(v).to(dev) for k, v in pair.items() if k != 'image_shape'}
+        d['image0'] = d['image1'] = torch.zeros(pair['image_shape'], device=dev)
+        d['pts0_cpu'] = pair['keypoints0'][0]; d['pts1_cpu'] = pair['keypoints1'][0]
+        return d
+
+    eval_loop.run_pairs_sharded(m, provider, min(a.pairs, 2 * world), eimp=a.model == 'EIMP')      # warm-up
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    table = eval_loop.run_pairs_sharded(m, provider, a.pairs, eimp=a.model == 'EIMP')
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({'model': a.model, 'pairs': a.pairs, 'n_gpus': world, 'kpts': a.kpts, 'pairs_per_s': a.pairs / dt,
+                          'includes': 'synthetic pair generation + H2D on the host path of each rank',
+                          'mean': dict(zip(eval_loop.SUMMARY_COLUMNS, table.mean(0).round(3).tolist()))}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
