@@ -273,3 +273,25 @@ def test_sharded_eval_loop_single_rank():
     assert (table[:, 1] > 25).all() and (table[:, 3] < 640).all() and (table[:, 3] > 0).all()
     again = eval_loop.run_pairs_sharded(m, provider, 3, eimp=True)
     assert np.array_equal(table, again)          # deterministic
+
+
+@pytest.mark.parametrize('precision', ['f16x3', 'f32'])
+@pytest.mark.parametrize('model', ['GM', 'DGNNS'])
+def test_odd_and_tiny_shapes_vs_oracle(model, precision):
+    """ragged / tiny keypoint counts straddling every tile boundary (1, 2, 31..33, 63..65, 127..129, 255..257)"""
+    nl = 4 if model == 'DGNNS' else 2
+    cfg = eval_config(n_layers=nl, sinkhorn_iterations=10)
+    sd = synthetic.make_state_dict(cfg, model, seed=3)
+    m = make_hip_model(model, cfg, sd, precision=precision)
+    o = orc.MatcherOracle(cfg, sd, model)
+    shapes = [(1, 1), (2, 3), (5, 1), (31, 33), (32, 64), (63, 65), (64, 127), (129, 128), (255, 257), (300, 17)]
+    for k, (n0, n1) in enumerate(shapes):
+        pair = synthetic.make_correlated_pair(n0, n1, seed=70 + k, batch=2 if k % 3 == 0 else 1)
+        data = {kk: torch.from_numpy(v).to(DEV) for kk, v in pair.items() if kk != 'image_shape'}
+        data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+        with torch.no_grad():
+            got = m.produce_matches(data, p=0.2, only_last=True)
+            ref = o.produce_matches({kk: v.cpu() for kk, v in data.items()}, p=0.2, only_last=True)
+        compare_matches(_cpu(got['indices0'][-1]), _cpu(got['mscores0'][-1]), ref['indices0'][-1].numpy(),
+                        ref['mscores0'][-1].numpy(), 0.2, TOL, f'{model} {precision} n0={n0} n1={n1}')
+        assert torch.isfinite(got['mscores0'][-1]).all()
