@@ -101,6 +101,18 @@ def test_pack_roundtrip():
     assert torch.equal(a, i) and torch.equal(b, m)
 
 
+def test_metrics_tail_vs_reference_golden():
+    from imp_release_amd import metrics
+    from helpers import load_golden
+    _, z = load_golden('metrics')
+    assert np.allclose(metrics.pose_auc(z['errs'], z['ths'].tolist()), z['auc'], atol=1e-12)
+    et, eR = metrics.compute_pose_error(z['T'], z['R'], z['t'])
+    assert abs(et - float(z['err_t'])) < 1e-10 and abs(eR - float(z['err_R'])) < 1e-10
+    mask, dis = metrics.compute_epi_inlier(z['x1'], z['x2'], z['E'], 0.3, return_error=True)
+    assert np.array_equal(mask, z['mask']) and np.allclose(dis, z['dis'], atol=1e-12)
+    assert metrics.pose_auc([1., 2., 30.], [5])[0] > 0.4
+
+
 def test_eval_loop_summary_rows():
     from imp_release_amd import eval_loop
     i0 = np.array([3, -1, 0, -1]); ms = np.array([0.5, 0.0, 0.3, 0.0], dtype=np.float32)

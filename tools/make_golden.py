@@ -224,6 +224,37 @@ def case_pool_edges(name):
     assert ok
 
 
+def case_metrics(name):
+    """metrics tail (tools/utils.py:425-457, components/utils/metrics.py:51-64) on seeded random inputs"""
+    import tools.utils as ref_utils                       # needs the cv2 stub installed above
+    # components/__init__.py pulls in h5py (not installed): register bare package shells so that only
+    # components/utils/metrics.py (+ its sibling transformations.py) is executed
+    for modname, sub in (('components', 'components'), ('components.utils', 'components/utils')):
+        shell = types.ModuleType(modname)
+        shell.__path__ = [os.path.join(REF, sub)]
+        sys.modules.setdefault(modname, shell)
+    from components.utils import metrics as ref_metrics
+    from imp_release_amd import metrics as mine
+    g = np.random.default_rng(11)
+    errs = np.abs(g.normal(0, 12, size=257))
+    ths = [5, 10, 20]
+    auc = ref_utils.pose_auc(errs, ths)
+    def rot(a, ax):
+        ax = ax / np.linalg.norm(ax); K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+    T = np.eye(4); T[:3, :3] = rot(0.3, g.normal(size=3)); T[:3, 3] = g.normal(size=3)
+    R = rot(0.34, g.normal(size=3)); t = -T[:3, 3] + 0.1 * g.normal(size=3)
+    et, eR = ref_utils.compute_pose_error(T, R, t)
+    x1, x2 = g.normal(size=(64, 2)), g.normal(size=(64, 2)); E = g.normal(size=(3, 3))
+    mask, dis = ref_metrics.compute_epi_inlier(x1, x2, E, 0.3, return_error=True)
+    ok = np.allclose(mine.pose_auc(errs, ths), auc, atol=1e-12) and np.allclose(mine.compute_pose_error(T, R, t), (et, eR), atol=1e-12)
+    m2, d2 = mine.compute_epi_inlier(x1, x2, E, 0.3, return_error=True)
+    ok &= bool(np.array_equal(m2, mask) and np.allclose(d2, dis, atol=1e-12))
+    save(name, {'kind': 'metrics'}, dict(errs=errs, ths=np.array(ths), auc=np.array(auc), T=T, R=R, t=t, err_t=et, err_R=eR, x1=x1, x2=x2,
+                                         E=E, mask=mask, dis=dis), f'mine_equal={ok}')
+    assert ok
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -267,6 +298,7 @@ def main():
                                              bin_score=5.0), True)
     # (7) pool edge cases
     case_pool_edges('pool_edges')
+    case_metrics('metrics')
 
 
 if __name__ == '__main__':
