@@ -7,7 +7,8 @@
 #define IMP_NUM_HEADS 4          // hard-coded in nets/layers.py:157,230
 
 // ------------------------------------------------------------------------------------------------
-// fp32 MFMA GEMM:  C[z] = epilogue( prologue(A[z]) [M x K] * W[z]^T [K x N] )
+// MFMA GEMM (fp32 operands; products as f16x3 split MFMAs or native fp32 MFMAs, see GemmParams::prec):
+//   C[z] = epilogue( prologue(A[z]) [M x K] * W[z]^T [K x N] )
 // z = (b * nsub + sub) * nside + side ; each side has its own operand set (image 0 / image 1).
 // ------------------------------------------------------------------------------------------------
 enum {
@@ -57,7 +58,7 @@ int gemm_stats_tiles(int M, int N, int total_z);
 int gemm_tile_m(int M, int N, int total_z);
 
 // ------------------------------------------------------------------------------------------------
-// attention (flash-style, fp32 MFMA, softmax in registers)
+// attention (flash-style, softmax in registers; launch_attention_f16x3 = split-half MFMA, launch_attention_f32 = fp32 MFMA)
 // ------------------------------------------------------------------------------------------------
 struct AttnSide {
     const float* q;        // [b][nq][ldq]   head h at columns h*DH

@@ -3,12 +3,17 @@
 //   dual_softmax                nets/layers.py:20-24
 //   GM.compute_matches          nets/gm.py:305-320
 //
-// HBM/LLC-bound byte work: the (N+1)x(M+1) fp32 matrix (16.8 MB at N=M=2048) is read twice per
-// Sinkhorn iteration.  Both mat-vec products of an iteration are turned into ROW passes by keeping the
-// row-softmax P and its transpose P^T resident (33.6 MB/pair: Infinity-Cache resident), so every pass
-// is a fully coalesced float4 stream with a wavefront shuffle reduction per row, no atomics, and a
-// fixed summation order (bit-reproducible run to run).  Each of the 2T passes is one launch over all
-// B pairs (a kernel boundary, ~1.5 us, is the cheapest chip-wide dependency on this part).
+// HBM/LLC-bound byte work: the (N+1)x(M+1) fp32 matrix (16.8 MB at N=M=2048, 67 MB for 4 pairs: Infinity-Cache
+// resident) is the only large operand of the T Sinkhorn iterations.
+//
+// Main path (rows up to 2304 floats): ONE read of P per iteration.  ot_fused_pass_kernel holds a row in registers,
+// computes u_i = r_i / (P_i . v + eps) and immediately accumulates P_ij * u_i into per-lane column partials, so the
+// transposed mat-vec needs no second pass; ot_colreduce_kernel sums the per-workgroup partial vectors (plus the
+// constant dustbin row) into v.  Two launches per iteration over all B pairs: a kernel boundary (~1.5 us) is the
+// cheapest chip-wide dependency on this part (a grid barrier costs 4-6 us).
+// Fallback (longer rows): P and its transpose P^T are both kept and every half-iteration is a coalesced float4 row
+// pass with a wavefront shuffle reduction (ot_rowpass_kernel).
+// No atomics and fixed summation orders everywhere: results are bit-reproducible run to run.
 #include "imp_kernels.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
