@@ -194,7 +194,7 @@ def main():
     # passes (tools/gpu_pmc.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction) and committed under
     # profiles/; reported only when the profiled kernel and launch geometry are the ones timed here
     traffic = None
-    kname = 'attn_f16x3_kernel<64, 4>' if f16x3 else 'attn_f32_kernel<64, 4>'
+    kname = 'attn_f16x3_kernel<64, 8>' if f16x3 else 'attn_f32_kernel<64, 4>'
     tpath = os.path.join(ROOT, 'profiles', 'r01', 'traffic_v3.json')
     if os.path.exists(tpath):
         for k, v in json.load(open(tpath)).items():
@@ -213,7 +213,7 @@ def main():
                                    f'seeded random weights',
                        'pairs_per_gpu': B, 'keypoints': N, 'parallelism': f'pair-sharded x{world}',
                        'matched_keypoints': n_matched},
-            'roofline': {'bound': 'mfma', 'kernel': 'attn_f16x3_kernel<64,4>' if f16x3 else 'attn_f32_kernel<64,4>',
+            'roofline': {'bound': 'mfma', 'kernel': 'attn_f16x3_kernel<64,8>' if f16x3 else 'attn_f32_kernel<64,4>',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                          'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/r01/traffic_v3.json)',
                          'algorithmic_bytes_per_launch': (3 * 256 + 256) * 4.0 * N * 2 * B,
