@@ -195,7 +195,7 @@ def main():
     # profiles/; reported only when the profiled kernel and launch geometry are the ones timed here
     traffic = None
     kname = 'attn_f16x3_kernel<64, 8>' if f16x3 else 'attn_f32_kernel<64, 4>'
-    tpath = os.path.join(ROOT, 'profiles', 'r01', 'traffic_v3.json')
+    tpath = os.path.join(ROOT, 'profiles', 'r01', 'traffic_v4.json')
     if os.path.exists(tpath):
         for k, v in json.load(open(tpath)).items():
             if k.startswith(kname) and k.endswith(f'grid={-(-N // 128) * 4 * 2 * B * 256}'):
@@ -215,7 +215,7 @@ def main():
                        'matched_keypoints': n_matched},
             'roofline': {'bound': 'mfma', 'kernel': 'attn_f16x3_kernel<64,8>' if f16x3 else 'attn_f32_kernel<64,4>',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/r01/traffic_v3.json)',
+                         'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/r01/traffic_v4.json)',
                          'algorithmic_bytes_per_launch': (3 * 256 + 256) * 4.0 * N * 2 * B,
                          'launch_ms': attn_ms, 'flops_per_launch': attn_flops,
                          'peak_note': ('algorithmic fp32-equivalent flops; peak = 2500 TF dense f16 MFMA / 3 products per '
