@@ -14,6 +14,7 @@
 // keys {4h + 8g + e}, so after the swap the 8 keys a lane needs for one 16-deep k-step are contiguous = ONE
 // ds_read_b128 per operand, and the probabilities are used straight from the accumulator registers.
 #include "imp_kernels.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -33,9 +34,20 @@ __device__ __forceinline__ int xcd_remap(int lin, int total) {
     const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
 }
-__device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)v;
-    lo = (_Float16)(v - (float)hi);
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
+// 8 consecutive operand values -> one MFMA fragment of hi halves and one of lo halves
+__device__ __forceinline__ void split8(const float (&x)[8], f16x8& hi, f16x8& lo) {
+    u32x4 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { unsigned a, b; imp_split2(x[2 * i], x[2 * i + 1], a, b); h[i] = a; l[i] = b; }
+    hi = __builtin_bit_cast(f16x8, h);
+    lo = __builtin_bit_cast(f16x8, l);
+}
+__device__ __forceinline__ void split4(const f32x4 x, u32x2& hi, u32x2& lo) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { unsigned a, b; imp_split2(x[2 * i], x[2 * i + 1], a, b); hi[i] = a; lo[i] = b; }
 }
 __device__ __forceinline__ int swap23(int k) { return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1); }
 
@@ -77,12 +89,8 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_f16x3_kernel(const AttnPa
         for (int s = 0; s < KS; ++s) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(src + 16 * s);
             const f32x4 c = *reinterpret_cast<const f32x4*>(src + 16 * s + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                _Float16 hh, ll;
-                split1(a[e], hh, ll); qh[s][e] = hh; ql[s][e] = ll;
-                split1(c[e], hh, ll); qh[s][4 + e] = hh; ql[s][4 + e] = ll;
-            }
+            const float x[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+            split8(x, qh[s], ql[s]);
         }
     }
 
@@ -138,11 +146,10 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_f16x3_kernel(const AttnPa
         for (int j = 0; j < KLPT; ++j) {
             const int f = tid + j * NT;
             const int row = f / (DH / 4), c4 = (f % (DH / 4)) * 4;
-            f16x4 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { _Float16 hh, ll; split1(rk[j][e], hh, ll); hi[e] = hh; lo[e] = ll; }
-            *reinterpret_cast<f16x4*>(ks + row * KROW + (c4 >> 1)) = hi;
-            *reinterpret_cast<f16x4*>(ks + row * KROW + DH / 2 + (c4 >> 1)) = lo;
+            u32x2 hi, lo;
+            split4(rk[j], hi, lo);
+            *reinterpret_cast<u32x2*>(ks + row * KROW + (c4 >> 1)) = hi;
+            *reinterpret_cast<u32x2*>(ks + row * KROW + DH / 2 + (c4 >> 1)) = lo;
         }
 #pragma unroll
         for (int i = 0; i < VGPT; ++i) {
@@ -151,11 +158,11 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_f16x3_kernel(const AttnPa
                 const int d = g % DH, kg = g / DH;
                 f16x8 hi[2], lo[2];
 #pragma unroll
-                for (int pos = 0; pos < 16; ++pos) {          // position pos holds key swap23(pos) of this 16-key group
-                    _Float16 hh, ll;
-                    split1(rv[i][swap23(pos)], hh, ll);
-                    hi[pos >> 3][pos & 7] = hh;
-                    lo[pos >> 3][pos & 7] = ll;
+                for (int g8 = 0; g8 < 2; ++g8) {              // position pos holds key swap23(pos) of this 16-key group
+                    float x[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = rv[i][swap23(8 * g8 + e)];
+                    split8(x, hi[g8], lo[g8]);
                 }
                 float* row = vs + d * VROW + kg * 8;          // 16 halves = 8 floats per group
                 *reinterpret_cast<f16x8*>(row) = hi[0];
@@ -254,14 +261,13 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_f16x3_kernel(const AttnPa
                     vl[d] = *reinterpret_cast<const f16x8*>(vs + d * 32 * VROW + KT / 2 + jb * 16 + 8 * s2);
                 }
                 f16x8 ph, pl;
+                float pv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float pv = fast_exp2(fmaf(sacc[jb][8 * s2 + e], SL2E, mneg));
-                    lsum += pv;
-                    _Float16 hh, ll;
-                    split1(pv, hh, ll);
-                    ph[e] = hh; pl[e] = ll;
+                    pv[e] = fast_exp2(fmaf(sacc[jb][8 * s2 + e], SL2E, mneg));
+                    lsum += pv[e];
                 }
+                split8(pv, ph, pl);
 #pragma unroll
                 for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[d], ph, oacc[d], 0, 0, 0);
 #pragma unroll
@@ -307,6 +313,366 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_f16x3_kernel(const AttnPa
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Ping-pong variant (DH = 64, 8 waves = 256 queries per workgroup, one workgroup per CU).
+//
+// In the kernel above the two waves that share a SIMD run in lock step (one barrier per key tile), so the matrix
+// pipe idles while both do their softmax / split VALU work and the VALU idles while both issue MFMAs - and with
+// the split-precision scheme the vector work is the larger half (measured on gfx950: a VALU instruction of a wave
+// whose SIMD partner streams MFMAs costs ~6 cycles, v_exp_f32 / v_fma_mix ~10; 48 MFMAs = 1536 pipe cycles).
+// Here every key tile is cut into a matrix phase X and a vector phase Y,
+//     X(t): O^T += V(t-1)^T . P(t-1)^T   then   S(t)^T = K(t) . Q^T      (48 MFMAs, LDS fragment reads; it also
+//           issues the global loads of tile t+3 - VMEM issue is slow and the matrix phase has the issue slots)
+//     Y(t): softmax numerators of S(t) -> P(t) as hi/lo halves in registers, conversion of tile t+2 into LDS,
+// with a workgroup barrier after every phase, and waves 4-7 pass ONE extra barrier before their loop: they run
+// exactly one phase behind waves 0-3 for the whole kernel, so on every SIMD one wave is in X while its partner is
+// in Y.  Barrier-phase index of a phase: waves 0-3 X(t) = 2t, Y(t) = 2t+1; waves 4-7 X(t) = 2t+1, Y(t) = 2t+2.
+// LDS ring of 4 tiles (slot = t & 3; K rows [hi | lo] halves, V rows the same, key-major): tile t is written in phases 2t-3 / 2t-2 (each group stages the half of the
+// tile its threads own), K(t) is read in phases 2t / 2t+1, V(t) in 2t+2 / 2t+3, and the slot is next written for
+// tile t+4 in phase 2t+5 - every write is separated from every read of the previous occupant by a barrier.
+// Two staged tiles are in flight in registers: a tile is loaded three phases before it is converted.
+//
+// Softmax with a lazily updated reference (removes the per-tile max, scale and rescale work from the common path):
+// Q is pre-multiplied by scale * log2(e), the S accumulators are INITIALISED to -m_ref (the query's reference
+// exponent, per lane), so the MFMAs deliver log2-domain logits relative to m_ref and P = exp2(acc) directly.
+// m_ref is only raised when a tile's probabilities get large: the row sums are computed anyway, and a wave
+// whose partial sums stay below 2^14 has every P < 2^14 (no f16 overflow, hi/lo relative precision unchanged);
+// otherwise - and for the first tile(s), until every query of the wave has seen an unmasked key - the tile takes the
+// slow path: exact tile maximum, m_ref += delta, O and l rescaled by 2^-delta, P recomputed from the same registers.
+// ------------------------------------------------------------------------------------------------------------------
+#define PP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifdef PP_PROFILE     // tools/probe/attn_probe.hip: per-wave cycle counts of the phases of workgroup 0
+__device__ unsigned long long pp_prof[8][8];
+#define PP_CLK(i) { const unsigned long long c_ = __builtin_readcyclecounter(); prof[i] += c_ - tlast; tlast = c_; }
+#else
+#define PP_CLK(i)
+#endif
+#ifndef PP_LOADS_IN_X
+#define PP_LOADS_IN_X 1
+#endif
+
+template <int DH>
+__global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams p, int qtiles, int total_blocks) {
+    static_assert(DH == 64, "ping-pong attention is instantiated for 64-channel heads");
+    constexpr int NT = 512;
+    constexpr int KROW = DH + 4;                 // K row: 32 floats of hi halves, 32 of lo halves, 4 pad
+    constexpr int VROW = DH + 16;                // V row: same split, padded to 320 B (conflict-free transpose reads)
+    constexpr int DT = DH / 32, KS = DH / 16;
+    constexpr float SL2E = 0.125f * LOG2E;       // 1/sqrt(64) * log2(e)
+    constexpr float P_SUM_LIMIT = 16384.f;       // per-lane partial row sum that forces a reference update
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                           // [4][KT][KROW]
+    float* Vs = Ks + 4 * KT * KROW;             // [4][KT][VROW]   V stays key-major: the PV operand is read transposed
+    float* Bs = Vs + 4 * KT * VROW;             // [4][KT]
+
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = wave >> 2;                // 0: waves 0-3, 1: waves 4-7 (one phase behind)
+    int id = xcd_remap(blockIdx.x, total_blocks);
+    const int qt = id % qtiles; id /= qtiles;
+    const int h = id % IMP_NUM_HEADS; id /= IMP_NUM_HEADS;
+    const int sidx = id % p.nside;
+    const int b = id / p.nside;
+    const AttnSide& S = p.side[sidx];
+    const int nq = S.nq, nk = S.nk;
+    const int q0 = qt * 256;
+    if (q0 >= nq) return;
+
+    const float* Qg = S.q + b * S.sq_b + h * DH;
+    const float* Kg = S.k + b * S.sk_b + h * DH;
+    const float* Vg = S.v + b * S.sk_b + h * DH;
+    const uint8_t* mk = S.kmask ? S.kmask + (long)b * nk : nullptr;
+
+    f16x8 qh[KS], ql[KS];
+    {
+        const int qrow = q0 + wave * 32 + l31;
+        const float* src = Qg + (long)(qrow < nq ? qrow : nq - 1) * p.ldq + 8 * half;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src + 16 * s);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(src + 16 * s + 4);
+            const float x[8] = {a[0] * SL2E, a[1] * SL2E, a[2] * SL2E, a[3] * SL2E,
+                                c[0] * SL2E, c[1] * SL2E, c[2] * SL2E, c[3] * SL2E};
+            split8(x, qh[s], ql[s]);
+        }
+    }
+
+    // ---- staging: thread = 2 float4 of K and 2 of V (row f/16, channels 4(f%16)..) ---------------------------------
+    const unsigned kv_bytes = (unsigned)(((long)(nk - 1) * p.ldk + DH) * 4);
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kg, 0, kv_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vg, 0, kv_bytes, 0x00020000);
+    const int row_bytes = p.ldk * 4;
+    int koff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int f = tid + j * NT;
+        koff[j] = (f / (DH / 4)) * row_bytes + (f % (DH / 4)) * 16;
+    }
+    f32x4 rkA[2], rkB[2];                          // two staged tiles in flight (even / odd tile index)
+    f32x4 rvA[2], rvB[2];
+    unsigned char rbA = 1, rbB = 1;
+    auto load_tile = [&](int t, f32x4 (&rk)[2], f32x4 (&rv)[2], unsigned char& rb) {
+        const int k0 = t * KT;
+        const int soff = k0 * row_bytes;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsK, koff[j], soff, 0);
+            rk[j] = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsV, koff[j], soff, 0);
+            rv[j] = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
+        }
+        if (tid < KT) {                       // key-validity byte, turned into the 0 / -inf bias when the tile is stored
+            const int key = k0 + tid;
+            unsigned char keep = key < nk;
+            if (keep && mk) keep = mk[key];
+            rb = keep;
+        }
+    };
+    auto store_tile = [&](int slot, const f32x4 (&rk)[2], const f32x4 (&rv)[2], const unsigned char rb) {
+        float* ks = Ks + slot * KT * KROW;
+        float* vs = Vs + slot * KT * VROW;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int f = tid + j * NT;
+            const int row = f / (DH / 4), c4 = (f % (DH / 4)) * 4;
+            u32x2 hi, lo;
+            split4(rk[j], hi, lo);
+            *reinterpret_cast<u32x2*>(ks + row * KROW + (c4 >> 1)) = hi;
+            *reinterpret_cast<u32x2*>(ks + row * KROW + DH / 2 + (c4 >> 1)) = lo;
+            split4(rv[j], hi, lo);
+            *reinterpret_cast<u32x2*>(vs + row * VROW + (c4 >> 1)) = hi;
+            *reinterpret_cast<u32x2*>(vs + row * VROW + DH / 2 + (c4 >> 1)) = lo;
+        }
+        if (tid < KT) Bs[slot * KT + tid] = rb ? 0.f : -INFINITY;
+    };
+
+    f32x16 oacc[DT], sacc[2];
+    f16x8 ph[2][2], pl[2][2];
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+    float m_ref = 0.f;            // log2-domain reference exponent of this lane's query (identical in both lane halves)
+    float l_run = 0.f;            // this lane's partial row sum, relative to m_ref
+    bool need_slow = true;        // wave-uniform: some query of the wave has not seen an unmasked key yet
+    const int nt = (nk + KT - 1) / KT;
+
+    load_tile(0, rkA, rvA, rbA);
+    if (nt > 1) load_tile(1, rkB, rvB, rbB);
+    store_tile(0, rkA, rvA, rbA);
+    if (nt > 2) load_tile(2, rkA, rvA, rbA);
+    if (nt > 1) store_tile(1, rkB, rvB, rbB);
+#if !PP_LOADS_IN_X
+    if (nt > 3) load_tile(3, rkB, rvB, rbB);
+#endif
+    PP_BARRIER();
+    if (group == 1) PP_BARRIER();
+
+    // A operand of O^T += V^T . P^T through the LDS transpose read (ds_read_b64_tr_b16): every 16-lane group hands in
+    // the addresses of a [4 keys][16 channels] block (lane i: key i/4, channels 4(i%4)..+3) and lane i receives channel
+    // i of the 4 keys.  K-slot e of lane-half h is key 32 jb + 16 s2 + 4 h + 8 (e >> 2) + (e & 3) - the key order the
+    // S^T accumulator registers (= the B operand P^T) already have - so two reads (keys +0..3 and +8..11) per fragment.
+    const int vlane = ((4 * half + ((lane & 15) >> 2)) * VROW) * 4 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    // Fragment reads are software-pipelined by hand (the compiler otherwise issues the reads of a k-step only after
+    // the previous step's MFMAs and waits for them in front of the next MFMA: ~150 idle pipe cycles per step): the
+    // operands of step i+1 are read into the other half of a register double buffer before the MFMAs of step i are
+    // issued; sched_barrier(0) pins that order.
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    auto read_v = [&](int slot, int g, f16x8 (&f)[4]) {            // f = {vh[0], vh[1], vl[0], vl[1]} of k-step g
+        const char* vs = reinterpret_cast<const char*>(Vs + slot * KT * VROW) + vlane + (16 * g) * (VROW * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char* a = vs + (i & 1) * 64 + (i >> 1) * (DH * 2);
+            const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+            const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 8 * VROW * 4));
+            f[i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    };
+    auto read_k = [&](int slot, int s, f16x8 (&f)[4]) {            // f = {kh[0], kh[1], kl[0], kl[1]} of k-step s
+        const float* ks = Ks + slot * KT * KROW + l31 * KROW + 4 * half + 8 * s;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            f[i] = *reinterpret_cast<const f16x8*>(ks + (i & 1) * 32 * KROW + (i >> 1) * (DH / 2));
+    };
+    auto mfma_v = [&](int g, const f16x8 (&f)[4]) {
+        const int jb = g >> 1, s2 = g & 1;
+#pragma unroll
+        for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[2 + d], ph[jb][s2], oacc[d], 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[d], pl[jb][s2], oacc[d], 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[d], ph[jb][s2], oacc[d], 0, 0, 0);
+    };
+    auto mfma_k = [&](int s, const f16x8 (&f)[4]) {
+        sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[2], qh[s], sacc[0], 0, 0, 0);
+        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[3], qh[s], sacc[1], 0, 0, 0);
+        sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], ql[s], sacc[0], 0, 0, 0);
+        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[1], ql[s], sacc[1], 0, 0, 0);
+        sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], qh[s], sacc[0], 0, 0, 0);
+        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[1], qh[s], sacc[1], 0, 0, 0);
+    };
+    f16x8 fr[2][4];                                                 // fragment double buffer
+    // O^T += V(slot)^T . P^T ; when kslot >= 0 the first K fragments of the following S^T are prefetched at the end
+    auto pv_mfmas = [&](int slot, int kslot) {
+        read_v(slot, 0, fr[0]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) read_v(slot, g + 1, fr[(g + 1) & 1]);
+            else if (kslot >= 0) read_k(kslot, 0, fr[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_v(g, fr[g & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto qk_mfmas = [&](int kslot, bool prefetched) {
+        if (!prefetched) read_k(kslot, 0, fr[0]);
+        const float c0 = -m_ref;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[jb][r] = c0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s + 1 < KS) read_k(kslot, s + 1, fr[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_k(s, fr[s & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // P = exp2(acc - delta) for the 32 logits of this lane, split into the B-operand fragments; returns their sum
+    auto probabilities = [&](float delta) {
+        float lsum = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float pv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    pv[e] = fast_exp2(sacc[jb][8 * s2 + e] - delta);
+                    lsum += pv[e];
+                }
+                split8(pv, ph[jb][s2], pl[jb][s2]);
+            }
+        return lsum;
+    };
+
+#ifdef PP_PROFILE
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_readcyclecounter();
+#endif
+    auto tile_step = [&](int t, f32x4 (&rk)[2], f32x4 (&rv)[2], unsigned char& rb, f32x4 (&rk2)[2], f32x4 (&rv2)[2], unsigned char& rb2) {
+        PP_CLK(7);
+        // =============================== X(t): matrix phase ===============================================
+        __builtin_amdgcn_s_setprio(1);
+#if PP_LOADS_IN_X
+        if (t + 3 < nt) load_tile(t + 3, rk2, rv2, rb2);          // the other register set was converted in Y(t-1)
+#endif
+        if (t > 0) pv_mfmas((t - 1) & 3, t & 3);
+        qk_mfmas(t & 3, t > 0);
+        __builtin_amdgcn_s_setprio(0);
+        PP_CLK(0);
+        PP_BARRIER();
+        PP_CLK(1);
+        // =============================== Y(t): vector phase ===============================================
+        if (mk != nullptr || (t + 1) * KT > nk) {
+            const float* bs = Bs + (t & 3) * KT;
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 bias = *reinterpret_cast<const f32x4*>(bs + jb * 32 + 8 * g + 4 * half);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sacc[jb][4 * g + e] += bias[e];
+                }
+        }
+        float lsum = 0.f;
+        bool slow = need_slow;
+        if (!slow) {
+            lsum = probabilities(0.f);
+            slow = __any(!(lsum < P_SUM_LIMIT));                  // also catches inf / nan
+        }
+        if (slow) {
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[jb][r]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float lq = l_run + __shfl_xor(l_run, 32);       // > 0 once the query has an anchored reference
+            // anchored queries only ever raise their reference; an empty one takes the tile maximum as it is
+            const float delta = (tmax == -INFINITY) ? 0.f : (lq > 0.f ? fmaxf(tmax, 0.f) : tmax);
+            const float alpha = lq > 0.f ? fast_exp2(-delta) : 0.f;
+            m_ref += delta;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+            lsum = probabilities(delta);
+            need_slow = __any(tmax == -INFINITY && !(lq > 0.f));
+        }
+        l_run += lsum;
+        PP_CLK(2);
+        if (t + 2 < nt) store_tile((t + 2) & 3, rk, rv, rb);      // this set holds tile t+2 (same parity as t)
+#if !PP_LOADS_IN_X
+        if (t + 4 < nt) load_tile(t + 4, rk, rv, rb);
+#endif
+        PP_CLK(3);
+        PP_BARRIER();
+        PP_CLK(4);
+    };
+    for (int t = 0; t < nt; t += 2) {
+        tile_step(t, rkA, rvA, rbA, rkB, rvB, rbB);
+        if (t + 1 < nt) tile_step(t + 1, rkB, rvB, rbB, rkA, rvA, rbA);
+    }
+    pv_mfmas((nt - 1) & 3, -1);
+#ifdef PP_PROFILE
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) pp_prof[wave][i] = prof[i];
+#endif
+    if (group == 0) PP_BARRIER();               // balance the extra barrier of waves 4-7
+    PP_BARRIER();                               // everyone is done with the ring: reuse it for the transposition
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    constexpr int LDO = DH + 1;
+    float* ot = smem + wave * 32 * LDO;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            ot[l31 * LDO + d * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = oacc[d][r] / l_tot;
+    if (S.lse && half == 0) {
+        const int qrow = q0 + wave * 32 + l31;
+        if (qrow < nq) S.lse[((long)b * IMP_NUM_HEADS + h) * nq + qrow] = m_ref * (1.0f / LOG2E) + logf(l_tot);
+    }
+    __syncthreads();
+    float* Og = S.out + b * S.so_b + h * DH;
+#pragma unroll 4
+    for (int i = 0; i < 32; ++i) {
+        const int qrow = q0 + wave * 32 + i;
+        if (qrow < nq) Og[(long)qrow * p.ldo + lane] = ot[i * LDO + lane];
+    }
+}
+
+hipError_t launch_pp(const AttnParams& p, int batch, int maxq, hipStream_t stream) {
+    const int qtiles = (maxq + 255) / 256;
+    const int total = qtiles * IMP_NUM_HEADS * p.nside * batch;
+    const size_t lds = (size_t)(4 * KT * (64 + 4) + 4 * KT * (64 + 16) + 4 * KT) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_f16x3_pp_kernel<64>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attn_f16x3_pp_kernel<64>), dim3(total), dim3(512), lds, stream, p, qtiles, total);
+    return hipGetLastError();
+}
+
 template <int DH, int NWAVES>
 hipError_t launch_one(const AttnParams& p, int batch, int maxq, hipStream_t stream) {
     const int qtiles = (maxq + NWAVES * 32 - 1) / (NWAVES * 32);
@@ -333,8 +699,11 @@ hipError_t launch_attention_f16x3(const AttnParams& p, int batch, hipStream_t st
     const bool big = wg4 >= 256;
     // 8-wave workgroups (256 queries) when that still gives >= 1 workgroup per CU: every K/V tile is staged and split
     // once per 256 queries instead of once per 128 (measured 127 -> 114 us at N=2048, B=4)
-    if (p.dh == 64 && (long)((maxq + 255) / 256) * IMP_NUM_HEADS * p.nside * batch >= 256)
-        return launch_one<64, 8>(p, batch, maxq, stream);
+    if (p.dh == 64 && (long)((maxq + 255) / 256) * IMP_NUM_HEADS * p.nside * batch >= 256) {
+        static const int variant = [] { const char* e = getenv("IMP_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
+        if (variant == 1) return launch_one<64, 8>(p, batch, maxq, stream);     // lock-step 8-wave kernel (A/B runs)
+        return launch_pp(p, batch, maxq, stream);
+    }
     if (p.dh == 64) return big ? launch_one<64, 4>(p, batch, maxq, stream) : launch_one<64, 2>(p, batch, maxq, stream);
     if (p.dh == 32) return big ? launch_one<32, 4>(p, batch, maxq, stream) : launch_one<32, 2>(p, batch, maxq, stream);
     return hipErrorInvalidValue;

@@ -54,13 +54,11 @@ __device__ __forceinline__ int xcd_remap(int lin, int total) {
     return base + idx;
 }
 
-// x -> (hi, lo) halves, round-to-nearest both times; x - float(hi) is exact in fp32
-__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
+// x -> (hi, lo) halves, round-to-nearest both times; x - float(hi) is exact in fp32 (imp_split2, imp_kernels.h)
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        hi[e] = (_Float16)v[e];
-        lo[e] = (_Float16)(v[e] - (float)hi[e]);
-    }
+    for (int i = 0; i < 2; ++i) { unsigned a, b; imp_split2(v[2 * i], v[2 * i + 1], a, b); hi[i] = a; lo[i] = b; }
 }
 
 template <int BM, int BN, int PRO, int PREC>
@@ -170,19 +168,19 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const GemmParams p, in
             // row = [hi: 32 halves = 16 dwords | lo: 32 halves | 4 dwords pad]; this thread owns k = lc..lc+3
 #pragma unroll
             for (int j = 0; j < LA; ++j) {
-                f16x4 hi, lo;
+                u32x2 hi, lo;
                 split4(ra[j], hi, lo);
                 float* row = As + (lr + 32 * j) * LDT;
-                *reinterpret_cast<f16x4*>(row + (lc >> 1)) = hi;
-                *reinterpret_cast<f16x4*>(row + 16 + (lc >> 1)) = lo;
+                *reinterpret_cast<u32x2*>(row + (lc >> 1)) = hi;
+                *reinterpret_cast<u32x2*>(row + 16 + (lc >> 1)) = lo;
             }
 #pragma unroll
             for (int j = 0; j < LW; ++j) {
-                f16x4 hi, lo;
+                u32x2 hi, lo;
                 split4(rw[j], hi, lo);
                 float* row = Ws + (lr + 32 * j) * LDT;
-                *reinterpret_cast<f16x4*>(row + (lc >> 1)) = hi;
-                *reinterpret_cast<f16x4*>(row + 16 + (lc >> 1)) = lo;
+                *reinterpret_cast<u32x2*>(row + (lc >> 1)) = hi;
+                *reinterpret_cast<u32x2*>(row + 16 + (lc >> 1)) = lo;
             }
         }
     };

@@ -6,6 +6,24 @@
 
 #define IMP_NUM_HEADS 4          // hard-coded in nets/layers.py:157,230
 
+#ifdef __HIPCC__
+// Split-precision operands: x = hi + lo with hi = f16(x) (round to nearest even) and lo = f16(x - hi); x - hi is exact
+// in fp32, so lo carries the next 11 significant bits.  Two values at a time: one packed convert for the hi halves and
+// one mixed-precision FMA per lo half (v_fma_mix{lo,hi}_f16 reads the f16 hi half and the fp32 x directly and rounds
+// x - hi once into the low / high half of the destination) - 3 VALU instructions per pair of values.
+typedef _Float16 imp_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void imp_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    imp_f16x2 h;
+    h[0] = (_Float16)a;
+    h[1] = (_Float16)b;
+    hi = __builtin_bit_cast(unsigned, h);
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(a));
+    asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(b));
+    lo = l;
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // MFMA GEMM (fp32 operands; products as f16x3 split MFMAs or native fp32 MFMAs, see GemmParams::prec):
 //   C[z] = epilogue( prologue(A[z]) [M x K] * W[z]^T [K x N] )

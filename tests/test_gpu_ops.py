@@ -79,6 +79,31 @@ def test_attention_fp32_mfma(gm, B, nq, nk, D, masked):
     assert e_lse < 2e-5, f'attention lse err {e_lse:.3e}'
 
 
+@pytest.mark.parametrize('B,nq,nk,masked', [(8, 2048, 2048, False), (8, 2048, 64, False), (8, 2048, 100, True),
+                                           (8, 2048, 130, False), (8, 2001, 1999, True), (16, 1000, 333, False),
+                                           (8, 1793, 257, False)])
+def test_attention_large_grid_pingpong_path(gm, B, nq, nk, masked):
+    """>= 256 workgroups of 256 queries: the f16x3 build takes the phase-staggered (ping-pong) kernel with its
+    4-slot LDS ring; key counts cover 1, 2, 3, 5 and 32 tiles, ragged tails, masks and a spike that forces the
+    running-max rescale late in the stream"""
+    ctx = gm[2]._ensure_ctx()
+    D = 256
+    qq, kv = _rand(B, nq, 3 * D, seed=14), _rand(B, nk, 3 * D, seed=15)
+    if nk > 200:
+        kv[0, nk - 60, D:2 * D] = qq[0, 5, :D] * 4.0
+    mask = None
+    if masked:
+        mask = (torch.rand(B, nk, generator=torch.Generator().manual_seed(16)) > 0.4).to(torch.uint8)
+        mask[:, :70] = 0
+        mask[:, -1] = 1
+    out, lse = ctx.op_attention(qq.to(DEV), kv.to(DEV), None if mask is None else mask.to(DEV))
+    ref, ref_lse = _ref_attention(qq, kv, D, mask)
+    e_out = (out.cpu().double() - ref).abs().max().item()
+    e_lse = (lse.cpu().double() - ref_lse).abs().max().item()
+    assert e_out < 5e-5, f'attention out err {e_out:.3e} (lse err {e_lse:.3e})'
+    assert e_lse < 5e-4, f'attention lse err {e_lse:.3e}'
+
+
 def test_attention_online_softmax_rescale_branch(gm):
     """a key that dominates late in the stream forces the running-max rescale (rare data-dependent branch)"""
     ctx = gm[2]._ensure_ctx()
