@@ -194,12 +194,15 @@ def main():
     # passes (tools/gpu_pmc.sh; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 correction) and committed under
     # profiles/; reported only when the profiled kernel and launch geometry are the ones timed here
     traffic = None
-    kname = 'attn_f16x3_kernel<64, 8>' if f16x3 else 'attn_f32_kernel<64, 4>'
-    tpath = os.path.join(ROOT, 'profiles', 'r01', 'traffic_v4.json')
+    # the f16x3 build takes the phase-staggered 8-wave kernel (256 queries per workgroup) at this size
+    kname = 'attn_f16x3_pp_kernel<64>' if f16x3 else 'attn_f32_kernel<64, 4>'
+    kgrid = -(-N // 256) * 4 * 2 * B * 512 if f16x3 else -(-N // 128) * 4 * 2 * B * 256
+    tfile = 'traffic_v5.json' if f16x3 else 'traffic_v4.json'
+    tpath = os.path.join(ROOT, 'profiles', 'r01', tfile)
     if os.path.exists(tpath):
         for k, v in json.load(open(tpath)).items():
-            if k.startswith(kname) and k.endswith(f'grid={-(-N // 128) * 4 * 2 * B * 256}'):
-                traffic = v['fetch_bytes_corrected'] + v['write_bytes']
+            if k.startswith(kname) and k.endswith(f'grid={kgrid}'):
+                traffic = v.get('fetch_bytes', v.get('fetch_bytes_corrected')) + v['write_bytes']
     if rank == 0:
         line = {
             'metric': 'image-pairs/s (N=2048 kpts, 9 self+cross iters, 100 Sinkhorn)',
@@ -213,9 +216,9 @@ def main():
                                    f'seeded random weights',
                        'pairs_per_gpu': B, 'keypoints': N, 'parallelism': f'pair-sharded x{world}',
                        'matched_keypoints': n_matched},
-            'roofline': {'bound': 'mfma', 'kernel': 'attn_f16x3_kernel<64,8>' if f16x3 else 'attn_f32_kernel<64,4>',
+            'roofline': {'bound': 'mfma', 'kernel': kname,
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': traffic, 'traffic_unit': 'bytes/launch (PMC, profiles/r01/traffic_v4.json)',
+                         'traffic': traffic, 'traffic_unit': f'bytes/launch (PMC, profiles/r01/{tfile})',
                          'algorithmic_bytes_per_launch': (3 * 256 + 256) * 4.0 * N * 2 * B,
                          'launch_ms': attn_ms, 'flops_per_launch': attn_flops,
                          'peak_note': ('algorithmic fp32-equivalent flops; peak = 2500 TF dense f16 MFMA / 3 products per '

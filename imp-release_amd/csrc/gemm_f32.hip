@@ -57,8 +57,12 @@ __device__ __forceinline__ int xcd_remap(int lin, int total) {
 // x -> (hi, lo) halves, round-to-nearest both times; x - float(hi) is exact in fp32 (imp_split2, imp_kernels.h)
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
+#ifdef GEMM_X_NOSPLIT
+    hi[0] = __float_as_uint(v[0]); hi[1] = __float_as_uint(v[1]); lo[0] = __float_as_uint(v[2]); lo[1] = __float_as_uint(v[3]);
+#else
 #pragma unroll
     for (int i = 0; i < 2; ++i) { unsigned a, b; imp_split2(v[2 * i], v[2 * i + 1], a, b); hi[i] = a; lo[i] = b; }
+#endif
 }
 
 template <int BM, int BN, int PRO, int PREC>
@@ -243,15 +247,34 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const GemmParams p, in
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     ah[sK][i] = *reinterpret_cast<const f16x8*>(as + i * 32 * LDT + sK * 8);
+#ifdef GEMM_X_HALFREAD
+                    al[sK][i] = ah[sK][i];
+#else
                     al[sK][i] = *reinterpret_cast<const f16x8*>(as + i * 32 * LDT + 16 + sK * 8);
+#endif
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     wh[sK][j] = *reinterpret_cast<const f16x8*>(ws + j * 32 * LDT + sK * 8);
+#ifdef GEMM_X_HALFREAD
+                    wl[sK][j] = wh[sK][j];
+#else
                     wl[sK][j] = *reinterpret_cast<const f16x8*>(ws + j * 32 * LDT + 16 + sK * 8);
+#endif
                 }
             }
             // product-major issue order: consecutive MFMAs write DIFFERENT accumulators (no dependent back-to-back pairs)
+#ifdef GEMM_X_THIRD
+#pragma unroll
+            for (int sK = 0; sK < 2; ++sK)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sK][i], wh[sK][j], acc[i][j], 0, 0, 0);
+                        acc[i][j][0] += (float)al[sK][i][0] + (float)wl[sK][j][0];
+                    }
+#else
 #pragma unroll
             for (int sK = 0; sK < 2; ++sK) {
 #pragma unroll
@@ -270,6 +293,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const GemmParams p, in
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sK][i], wh[sK][j], acc[i][j], 0, 0, 0);
             }
+#endif
             __syncthreads();
         }
     }
