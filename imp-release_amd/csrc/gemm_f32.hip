@@ -28,6 +28,7 @@
 // MFMA k-pairing (fp32 path): step s of a 32-deep K-tile multiplies k = s (lanes 0-31) and k = 16 + s (lanes 32-63);
 // A and W fragments use the same pairing so each lane reads 16 contiguous floats of its row.
 #include "imp_kernels.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -35,6 +36,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+
+#ifdef GEMM_PROFILE   // tools/probe/gemm_probe.hip: cycle stamps of the K-loop phases of workgroup 0 (f16x3 path)
+__device__ unsigned long long gemm_prof[4][8];
+#define GP_CLK(i) { const unsigned long long c_ = __builtin_readcyclecounter(); prof[i] += c_ - tlast; tlast = c_; }
+#else
+#define GP_CLK(i)
+#endif
 
 constexpr int BK = 32;
 constexpr int LDT = BK + 4;   // padded LDS row (floats)
@@ -57,16 +65,12 @@ __device__ __forceinline__ int xcd_remap(int lin, int total) {
 // x -> (hi, lo) halves, round-to-nearest both times; x - float(hi) is exact in fp32 (imp_split2, imp_kernels.h)
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(const f32x4 v, u32x2& hi, u32x2& lo) {
-#ifdef GEMM_X_NOSPLIT
-    hi[0] = __float_as_uint(v[0]); hi[1] = __float_as_uint(v[1]); lo[0] = __float_as_uint(v[2]); lo[1] = __float_as_uint(v[3]);
-#else
 #pragma unroll
     for (int i = 0; i < 2; ++i) { unsigned a, b; imp_split2(v[2 * i], v[2 * i + 1], a, b); hi[i] = a; lo[i] = b; }
-#endif
 }
 
-template <int BM, int BN, int PRO, int PREC>
-__global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const GemmParams p, int col_tiles, int row_tiles, int total) {
+template <int BM, int BN, int PRO, int PREC, int DEEP>
+__global__ __launch_bounds__(256, DEEP ? 2 : 3) void gemm_f32_kernel(const GemmParams p, int col_tiles, int row_tiles, int total) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int LA = BM / 32, LW = BN / 32;   // float4 loads per thread per K-tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -130,8 +134,10 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const GemmParams p, in
         const int r = min(col0 + lr + 32 * j, N - 1);
         pw[j] = W + (long)r * p.ldw + lc;
     }
-    f32x4 ra[LA], rw[LW];
-    auto load_tile = [&](int kt) {
+    // staged tile(s) in registers: one set (prefetch distance 1, 3 workgroups per CU) or, DEEP, two sets that alternate
+    // (a tile is requested two K-steps before it is converted; 2 workgroups per CU - for launches that have no more)
+    f32x4 ra0[LA], rw0[LW], ra1[DEEP ? LA : 1], rw1[DEEP ? LW : 1];
+    auto load_tile = [&](int kt, f32x4 (&ra)[LA], f32x4 (&rw)[LW]) {
         const int k0 = kt * BK;
         const bool second = k0 >= p.ksplit;          // uniform
 #pragma unroll
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const GemmParams p, in
 #pragma unroll
         for (int j = 0; j < LW; ++j) rw[j] = *reinterpret_cast<const f32x4*>(pw[j] + k0);
     };
-    auto store_tile = [&](int kt) {
+    auto store_tile = [&](int kt, f32x4 (&ra)[LA], f32x4 (&rw)[LW]) {
         if (PRO != 0) {
             const int k0 = kt * BK + lc;
             const f32x4 mu = *reinterpret_cast<const f32x4*>(tr + k0);
@@ -198,16 +204,16 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const GemmParams p, in
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nkt = K / BK;
-    load_tile(0);
+    load_tile(0, ra0, rw0);
     const int frow = lane & 31;
     if (PREC == 0) {
         const int fk = (lane >> 5) * 16;
         const float* as = As + (wm * WM + frow) * LDT + fk;
         const float* ws = Ws + (wn * WN + frow) * LDT + fk;
         for (int kt = 0; kt < nkt; ++kt) {
-            store_tile(kt);
+            store_tile(kt, ra0, rw0);
             __syncthreads();
-            load_tile(kt + 1 < nkt ? kt + 1 : kt);   // in flight during the MFMAs below (last one: harmless re-load)
+            load_tile(kt + 1 < nkt ? kt + 1 : kt, ra0, rw0);   // in flight during the MFMAs below (last one: harmless re-load)
             f32x4 af[2][TM], wf[2][TN];              // fragment double buffer: c+1 is read while c is multiplied
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LDT);
@@ -237,44 +243,34 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const GemmParams p, in
         // f16x3: k-step s (16 deep) of the tile; lane (row, half) reads 8 consecutive halves k = 16 s + 8 half ...
         const float* as = As + (wm * WM + frow) * LDT + (lane >> 5) * 4;
         const float* ws = Ws + (wn * WN + frow) * LDT + (lane >> 5) * 4;
-        for (int kt = 0; kt < nkt; ++kt) {
-            store_tile(kt);
+        constexpr int DIST = DEEP ? 2 : 1;
+#ifdef GEMM_PROFILE
+        unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long tlast = __builtin_readcyclecounter();
+#endif
+        auto k_step = [&](int kt, f32x4 (&ra)[LA], f32x4 (&rw)[LW]) {
+            GP_CLK(5);
+            store_tile(kt, ra, rw);
+            GP_CLK(0);
             __syncthreads();
-            load_tile(kt + 1 < nkt ? kt + 1 : kt);
+            GP_CLK(1);
+            load_tile(kt + DIST < nkt ? kt + DIST : nkt - 1, ra, rw);   // (past the end: harmless re-load)
+            GP_CLK(2);
             f16x8 ah[2][TM], al[2][TM], wh[2][TN], wl[2][TN];
 #pragma unroll
             for (int sK = 0; sK < 2; ++sK) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     ah[sK][i] = *reinterpret_cast<const f16x8*>(as + i * 32 * LDT + sK * 8);
-#ifdef GEMM_X_HALFREAD
-                    al[sK][i] = ah[sK][i];
-#else
                     al[sK][i] = *reinterpret_cast<const f16x8*>(as + i * 32 * LDT + 16 + sK * 8);
-#endif
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     wh[sK][j] = *reinterpret_cast<const f16x8*>(ws + j * 32 * LDT + sK * 8);
-#ifdef GEMM_X_HALFREAD
-                    wl[sK][j] = wh[sK][j];
-#else
                     wl[sK][j] = *reinterpret_cast<const f16x8*>(ws + j * 32 * LDT + 16 + sK * 8);
-#endif
                 }
             }
             // product-major issue order: consecutive MFMAs write DIFFERENT accumulators (no dependent back-to-back pairs)
-#ifdef GEMM_X_THIRD
-#pragma unroll
-            for (int sK = 0; sK < 2; ++sK)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sK][i], wh[sK][j], acc[i][j], 0, 0, 0);
-                        acc[i][j][0] += (float)al[sK][i][0] + (float)wl[sK][j][0];
-                    }
-#else
 #pragma unroll
             for (int sK = 0; sK < 2; ++sK) {
 #pragma unroll
@@ -293,9 +289,25 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const GemmParams p, in
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[sK][i], wh[sK][j], acc[i][j], 0, 0, 0);
             }
-#endif
+            GP_CLK(3);
             __syncthreads();
+            GP_CLK(4);
+        };
+        if (DEEP) {
+            if constexpr (DEEP != 0) {
+                load_tile(nkt > 1 ? 1 : 0, ra1, rw1);
+                for (int kt = 0; kt < nkt; kt += 2) {
+                    k_step(kt, ra0, rw0);
+                    if (kt + 1 < nkt) k_step(kt + 1, ra1, rw1);
+                }
+            }
+        } else {
+            for (int kt = 0; kt < nkt; ++kt) k_step(kt, ra0, rw0);
         }
+#ifdef GEMM_PROFILE
+        if (blockIdx.x == 0 && lane == 0)
+            for (int i = 0; i < 8; ++i) gemm_prof[wave][i] = prof[i];
+#endif
     }
 
     // ---- epilogue: value transforms with the (uniform) flags hoisted out of the element loops -------------
@@ -451,18 +463,18 @@ void gemm_pick_tile(int M, int N, int total_z, int* bm, int* bn) {
     else { *bm = 64; *bn = 64; }
 }
 
-template <int BM, int BN, int PRO, int PREC>
+template <int BM, int BN, int PRO, int PREC, int DEEP>
 hipError_t gemm_launch_one(const GemmParams& p, dim3 grid, hipStream_t stream) {
     const size_t lds = gemm_lds_bytes(BM, BN, PRO, p.K);
     static size_t lds_set = 0;           // largest dynamic-LDS size already granted to this instantiation
     if (lds > lds_set && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, PRO, PREC>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, PRO, PREC, DEEP>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         lds_set = lds;
     }
     const int total = (int)(grid.x * grid.y * grid.z);
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, PRO, PREC>), dim3(total), dim3(256), lds, stream, p, (int)grid.x, (int)grid.y,
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, PRO, PREC, DEEP>), dim3(total), dim3(256), lds, stream, p, (int)grid.x, (int)grid.y,
                        total);
     return hipGetLastError();
 }
@@ -470,13 +482,22 @@ hipError_t gemm_launch_one(const GemmParams& p, dim3 grid, hipStream_t stream) {
 template <int BM, int BN>
 hipError_t gemm_launch_pro(const GemmParams& p, int pro, dim3 grid, hipStream_t stream) {
     if (p.prec == 1) {
-        if (pro == 0) return gemm_launch_one<BM, BN, 0, 1>(p, grid, stream);
-        if (pro == 1) return gemm_launch_one<BM, BN, 1, 1>(p, grid, stream);
-        return gemm_launch_one<BM, BN, 2, 1>(p, grid, stream);
+        // two register sets (prefetch distance 2) where they are free: the 128x64 and 64x64 tiles stay under 168 VGPRs
+        // with them (still 3 waves per SIMD); measured 31.0 -> 28.7 us on the MLP3 GEMM, no gain on 128x128 tiles
+        static const int deep_mode = [] { const char* e = getenv("IMP_GEMM_DEEP"); return e ? atoi(e) : -1; }();
+        const bool deep = deep_mode >= 0 ? deep_mode != 0 : (BM * BN <= 128 * 64);
+        if (deep) {
+            if (pro == 0) return gemm_launch_one<BM, BN, 0, 1, 1>(p, grid, stream);
+            if (pro == 1) return gemm_launch_one<BM, BN, 1, 1, 1>(p, grid, stream);
+            return gemm_launch_one<BM, BN, 2, 1, 1>(p, grid, stream);
+        }
+        if (pro == 0) return gemm_launch_one<BM, BN, 0, 1, 0>(p, grid, stream);
+        if (pro == 1) return gemm_launch_one<BM, BN, 1, 1, 0>(p, grid, stream);
+        return gemm_launch_one<BM, BN, 2, 1, 0>(p, grid, stream);
     }
-    if (pro == 0) return gemm_launch_one<BM, BN, 0, 0>(p, grid, stream);
-    if (pro == 1) return gemm_launch_one<BM, BN, 1, 0>(p, grid, stream);
-    return gemm_launch_one<BM, BN, 2, 0>(p, grid, stream);
+    if (pro == 0) return gemm_launch_one<BM, BN, 0, 0, 0>(p, grid, stream);
+    if (pro == 1) return gemm_launch_one<BM, BN, 1, 0, 0>(p, grid, stream);
+    return gemm_launch_one<BM, BN, 2, 0, 0>(p, grid, stream);
 }
 
 }  // namespace

@@ -163,18 +163,17 @@ __global__ __launch_bounds__(512, 2) void ot_fused_pass_kernel(const float* __re
     const int r0 = blockIdx.x * FP_ROWS + wave * FP_RPW;
     const float* base = P + (long)b * prows * ld;
     const int n4 = ld >> 2;
-    // all FP_RPW rows of the wave are requested up front (one memory latency per workgroup instead of one per pair of
-    // rows: 4 x 36 + 36 accumulator registers at NCH = 9), v goes to LDS meanwhile
-    f32x4 part[NCH], row[FP_RPW][NCH];
-#pragma unroll
-    for (int k = 0; k < FP_RPW; ++k) {
-        const f32x4* rp = reinterpret_cast<const f32x4*>(base + (long)min(r0 + k, rows - 1) * ld);
+    f32x4 part[NCH], row[2][NCH];
+    auto load_row = [&](int slot, int r) {
+        const f32x4* rp = reinterpret_cast<const f32x4*>(base + (long)min(r, rows - 1) * ld);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int c4 = min(lane + 64 * c, n4 - 1);     // clamped: the duplicate is zeroed by the v image below
-            row[k][c] = rp[c4];
+            row[slot][c] = rp[c4];
         }
-    }
+    };
+    load_row(0, r0);
+    load_row(1, r0 + 1);
     {   // v -> LDS once per workgroup; chunk slots past the row end read an explicit zero
         const f32x4* vin = reinterpret_cast<const f32x4*>(v + (long)b * ld);
         for (int c4 = threadIdx.x; c4 < n4; c4 += 512) *reinterpret_cast<f32x4*>(vs + 4 * c4) = vin[c4];
@@ -191,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void ot_fused_pass_kernel(const float* __re
             const int c4 = lane + 64 * c;
             if (c4 < n4) {
                 const f32x4 x = *reinterpret_cast<const f32x4*>(vs + 4 * c4);
-                const f32x4 m = row[k][c];
+                const f32x4 m = row[k & 1][c];
                 acc = fmaf(m[0], x[0], acc);
                 acc = fmaf(m[1], x[1], acc);
                 acc = fmaf(m[2], x[2], acc);
@@ -204,7 +203,8 @@ __global__ __launch_bounds__(512, 2) void ot_fused_pass_kernel(const float* __re
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) part[c][e] = fmaf(row[k][c][e], ui, part[c][e]);
+            for (int e = 0; e < 4; ++e) part[c][e] = fmaf(row[k & 1][c][e], ui, part[c][e]);
+        if (k + 2 < FP_RPW) load_row(k & 1, r0 + k + 2);      // rotate the two register slots: row k+2 streams in
     }
     // workgroup combine: FP_WAVES partial vectors -> 1 (fixed order)
 #pragma unroll
@@ -238,7 +238,6 @@ __global__ __launch_bounds__(1024) void ot_colreduce_kernel(const float* __restr
     const int j = blockIdx.x * 64 + cx;
     const float* plast = P + ((long)b * (n0 + 1) + n0) * ld;
     const float* vo = v_old + (long)b * ld;
-    const float pl_j = j < cols ? plast[j] : 0.f;          // requested with everything else: one memory latency in total
     // dustbin-row dot product: thread t takes columns t, t+1024, ... (pads of P and v are zero)
     float d = 0.f;
     for (int c = threadIdx.x; c < ld; c += 1024) d = fmaf(plast[c], vo[c], d);
@@ -270,7 +269,7 @@ __global__ __launch_bounds__(1024) void ot_colreduce_kernel(const float* __restr
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += sm[k][cx];
-        t = fmaf(pl_j, ulast_s, t);
+        t = fmaf(plast[j], ulast_s, t);
         const float marg = j == cols - 1 ? (float)cols : 1.f;
         v_new[(long)b * ld + j] = marg / (t + OT_EPS);
     }

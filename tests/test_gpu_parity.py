@@ -209,6 +209,36 @@ def test_full_size_properties(big):
     assert torch.equal(o3['scores'][-1], o1['scores'][-1])
 
 
+def test_bench_batch_of_four_takes_the_pingpong_attention_path():
+    """bench.py's launch geometry (4 pairs x 2048 keypoints) is the one that selects the phase-staggered attention
+    kernel (>= 256 workgroups of 256 queries); a batch of 1 or 2 runs the lock-step kernels.  Same pairs, two different
+    kernel families: indices must agree exactly and scores within the parity tolerance; pair 0 is also checked against
+    the oracle at the full BASELINE size."""
+    cfg = eval_config(n_layers=9, sinkhorn_iterations=100)
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=1)
+    m = make_hip_model('GM', cfg, sd)
+    pair = synthetic.make_correlated_pair(2048, 2048, seed=77, batch=4)
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+    with torch.no_grad():
+        out4 = m.produce_matches(data, p=0.2, only_last=True)
+        again = m.produce_matches(data, p=0.2, only_last=True)
+    assert torch.equal(out4['indices0'][-1], again['indices0'][-1]) and torch.equal(out4['mscores0'][-1], again['mscores0'][-1])
+    for b in (1, 3):
+        solo = {k: (v[b:b + 1] if v.shape[0] == 4 else v) for k, v in data.items()}
+        with torch.no_grad():
+            o1 = m.produce_matches(solo, p=0.2, only_last=True)
+        print(compare_matches(_cpu(out4['indices0'][-1][b:b + 1]), _cpu(out4['mscores0'][-1][b:b + 1]),
+                              _cpu(o1['indices0'][-1]).numpy(), _cpu(o1['mscores0'][-1]).numpy(), 0.2, TOL,
+                              f'batch-of-4 (ping-pong kernel) vs solo (lock-step kernel), pair {b}'))
+    o = orc.MatcherOracle(cfg, sd, 'GM')
+    cdata = {k: v[:1].cpu() for k, v in data.items()}
+    with torch.no_grad():
+        ref = o.produce_matches(cdata, p=0.2, only_last=True)
+    print(compare_matches(_cpu(out4['indices0'][-1][:1]), _cpu(out4['mscores0'][-1][:1]), ref['indices0'][-1].numpy(),
+                          ref['mscores0'][-1].numpy(), 0.2, TOL, 'N=2048 L=9 T=100 B=4 pair 0 vs oracle'))
+
+
 def test_eimp_pruning_path_at_4096():
     """BASELINE config 4 size: N = 4096 start, sliced EIMP loop, pruning must happen and stay consistent."""
     cfg = eval_config()

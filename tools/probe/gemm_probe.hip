@@ -35,6 +35,14 @@ int main(int argc, char** argv) {
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (rep == 2) printf("%-6s %.1f us   %.2f TB/s algorithmic   %.0f TF(fp32-equivalent)\n", name, ms / 50 * 1e3, bytes / (ms / 50 * 1e-3) / 1e12, flops / (ms / 50 * 1e-3) / 1e12);
         }
+#ifdef GEMM_PROFILE
+        unsigned long long prof[4][8];
+        hipMemcpyFromSymbol(prof, HIP_SYMBOL(gemm_prof), sizeof prof);
+        const int nkt = p.K / 32;
+        for (int w = 0; w < 4; ++w)
+            printf("   wave %d per K-tile: store(wait+split+ds_write) %5.0f  barrier %5.0f  load-issue %5.0f  frags+mfma %5.0f  barrier %5.0f  loop %4.0f\n", w,
+                   (double)prof[w][0] / nkt, (double)prof[w][1] / nkt, (double)prof[w][2] / nkt, (double)prof[w][3] / nkt, (double)prof[w][4] / nkt, (double)prof[w][5] / nkt);
+#endif
     };
     const double M = 2.0 * B * n;
     {   // qkv
