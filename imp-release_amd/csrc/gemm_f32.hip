@@ -29,6 +29,7 @@
 // A and W fragments use the same pairing so each lane reads 16 contiguous floats of its row.
 #include "imp_kernels.h"
 #include <stdlib.h>
+#include <mutex>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -466,12 +467,17 @@ void gemm_pick_tile(int M, int N, int total_z, int* bm, int* bn) {
 template <int BM, int BN, int PRO, int PREC, int DEEP>
 hipError_t gemm_launch_one(const GemmParams& p, dim3 grid, hipStream_t stream) {
     const size_t lds = gemm_lds_bytes(BM, BN, PRO, p.K);
-    static size_t lds_set = 0;           // largest dynamic-LDS size already granted to this instantiation
-    if (lds > lds_set && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, PRO, PREC, DEEP>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_set = lds;
+    // largest dynamic-LDS size already granted to this instantiation (several host threads may launch: eval_loop workers)
+    static std::mutex mu;
+    static size_t lds_set = 0;
+    if (lds > 48 * 1024) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (lds > lds_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, PRO, PREC, DEEP>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            lds_set = lds;
+        }
     }
     const int total = (int)(grid.x * grid.y * grid.z);
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, PRO, PREC, DEEP>), dim3(total), dim3(256), lds, stream, p, (int)grid.x, (int)grid.y,

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from helpers import build_case, compare_matches, eval_config, golden_names, load_golden, make_hip_model
-from imp_release_amd import matching as hip_matching, synthetic
+from imp_release_amd import eval_loop, matching as hip_matching, synthetic
 from oracle import imp_oracle as orc
 
 pytestmark = pytest.mark.gpu
@@ -303,6 +303,35 @@ def test_sharded_eval_loop_single_rank():
     assert (table[:, 1] > 25).all() and (table[:, 3] < 640).all() and (table[:, 3] > 0).all()
     again = eval_loop.run_pairs_sharded(m, provider, 3, eimp=True)
     assert np.array_equal(table, again)          # deterministic
+
+
+def test_eval_loop_pairs_in_flight_give_identical_rows():
+    """workers=K (K model replicas, K streams, K host threads) must reproduce the sequential table bit for bit; the
+    injected pose step sleeps like a host-side solver so that the overlap is observable"""
+    import time
+    cfg = eval_config()
+    sd = synthetic.make_state_dict(cfg, 'AdaGMN', seed=9, bin_score=5.0)
+    m = make_hip_model('AdaGMN', cfg, sd)
+
+    def provider(pid):
+        pair = synthetic.make_correlated_pair(700, 650, seed=500 + pid)
+        d = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+        d['image0'] = d['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+        return _loop_data(d)
+
+    def slow_pose(*a, **k):
+        time.sleep(0.01)
+        return None
+
+    reps = eval_loop.replicate(m, 3)
+    eval_loop.run_pairs_sharded(m, provider, 3, eimp=True, workers=3, replicas=reps)             # warm-up (workspaces)
+    t0 = time.perf_counter()
+    seq = eval_loop.run_pairs_sharded(m, provider, 6, eimp=True, estimate_pose=slow_pose)
+    t1 = time.perf_counter()
+    par = eval_loop.run_pairs_sharded(m, provider, 6, eimp=True, estimate_pose=slow_pose, workers=3, replicas=reps)
+    t2 = time.perf_counter()
+    assert np.array_equal(seq, par), (seq, par)
+    print(f'6 pairs: sequential {t1 - t0:.3f} s, 3 in flight {t2 - t1:.3f} s')
 
 
 @pytest.mark.parametrize('precision', ['f16x3', 'f32'])

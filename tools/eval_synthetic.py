@@ -19,6 +19,7 @@ def main():
     ap.add_argument('--model', choices=['IMP', 'EIMP'], default='EIMP')
     ap.add_argument('--kpts', type=int, default=2048)
     ap.add_argument('--bin-score', type=float, default=5.0)
+    ap.add_argument('--workers', type=int, default=1, help='pairs in flight per GPU (model replicas + streams)')
     a = ap.parse_args()
     rank, world, lr = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(lr)
@@ -42,12 +43,14 @@ def main():
         d['pts0_cpu'] = pair['keypoints0'][0]; d['pts1_cpu'] = pair['keypoints1'][0]
         return d
 
-    eval_loop.run_pairs_sharded(m, provider, min(a.pairs, 2 * world), eimp=a.model == 'EIMP')      # warm-up
+    reps = eval_loop.replicate(m, a.workers)
+    kw = dict(eimp=a.model == 'EIMP', workers=a.workers, replicas=reps)
+    eval_loop.run_pairs_sharded(m, provider, min(a.pairs, 2 * world * a.workers), **kw)      # warm-up
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    table = eval_loop.run_pairs_sharded(m, provider, a.pairs, eimp=a.model == 'EIMP')
+    table = eval_loop.run_pairs_sharded(m, provider, a.pairs, **kw)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     if rank == 0:
-        print(json.dumps({'model': a.model, 'pairs': a.pairs, 'n_gpus': world, 'kpts': a.kpts, 'pairs_per_s': a.pairs / dt,
+        print(json.dumps({'model': a.model, 'pairs': a.pairs, 'n_gpus': world, 'kpts': a.kpts, 'workers_per_gpu': a.workers, 'pairs_per_s': a.pairs / dt,
                           'includes': 'synthetic pair generation + H2D on the host path of each rank',
                           'mean': dict(zip(eval_loop.SUMMARY_COLUMNS, table.mean(0).round(3).tolist()))}))
     if world > 1:
