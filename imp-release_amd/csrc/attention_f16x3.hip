@@ -347,8 +347,11 @@ __device__ unsigned long long pp_prof[8][8];
 #else
 #define PP_CLK(i)
 #endif
+#ifndef PP_INIT_IN_ACC
+#define PP_INIT_IN_ACC 1    // S accumulators start at -m_ref (1) or at 0 with the reference subtracted in the vector phase (0)
+#endif
 #ifndef PP_LOADS_IN_X
-#define PP_LOADS_IN_X 1
+#define PP_LOADS_IN_X 0    // where the global loads of the staged tile are issued: matrix phase (1) or vector phase (0); measured equal
 #endif
 
 template <int DH>
@@ -529,7 +532,11 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     };
     auto qk_mfmas = [&](int kslot, bool prefetched) {
         if (!prefetched) read_k(kslot, 0, fr[0]);
+#if PP_INIT_IN_ACC
         const float c0 = -m_ref;
+#else
+        const float c0 = 0.f;                   // (the compiler feeds the first MFMA of each chain an inline zero)
+#endif
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
@@ -542,7 +549,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // P = exp2(acc - delta) for the 32 logits of this lane, split into the B-operand fragments; returns their sum
+    // P = exp2(acc - ref) for the 32 logits of this lane, split into the B-operand fragments; returns their sum
     auto probabilities = [&](float delta) {
         float lsum = 0.f;
 #pragma unroll
@@ -591,8 +598,13 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
         }
         float lsum = 0.f;
         bool slow = need_slow;
+#if PP_INIT_IN_ACC
+        const float base = 0.f;                 // the accumulators already hold S - m_ref
+#else
+        const float base = m_ref;               // subtracted here: 32 v_sub in the vector phase instead of 32 v_mov in the matrix phase
+#endif
         if (!slow) {
-            lsum = probabilities(0.f);
+            lsum = probabilities(base);
             slow = __any(!(lsum < P_SUM_LIMIT));                  // also catches inf / nan
         }
         if (slow) {
@@ -601,7 +613,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
             for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[jb][r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) - base;
             const float lq = l_run + __shfl_xor(l_run, 32);       // > 0 once the query has an anchored reference
             // anchored queries only ever raise their reference; an empty one takes the tile maximum as it is
             const float delta = (tmax == -INFINITY) ? 0.f : (lq > 0.f ? fmaxf(tmax, 0.f) : tmax);
@@ -612,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
             for (int d = 0; d < DT; ++d)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
-            lsum = probabilities(delta);
+            lsum = probabilities(base + delta);
             need_slow = __any(tmax == -INFINITY && !(lq > 0.f));
         }
         l_run += lsum;
