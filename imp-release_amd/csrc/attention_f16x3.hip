@@ -711,9 +711,11 @@ hipError_t launch_attention_f16x3(const AttnParams& p, int batch, hipStream_t st
     const bool big = wg4 >= 256;
     // 8-wave workgroups (256 queries) when that still gives >= 1 workgroup per CU: every K/V tile is staged and split
     // once per 256 queries instead of once per 128 (measured 127 -> 114 us at N=2048, B=4)
+    // IMP_ATTN_VARIANT (A/B runs): 1 = lock-step 8-wave kernel instead of the ping-pong one, 2 = ping-pong at any grid size
+    static const int variant = [] { const char* e = getenv("IMP_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
+    if (p.dh == 64 && variant == 2) return launch_pp(p, batch, maxq, stream);
     if (p.dh == 64 && (long)((maxq + 255) / 256) * IMP_NUM_HEADS * p.nside * batch >= 256) {
-        static const int variant = [] { const char* e = getenv("IMP_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
-        if (variant == 1) return launch_one<64, 8>(p, batch, maxq, stream);     // lock-step 8-wave kernel (A/B runs)
+        if (variant == 1) return launch_one<64, 8>(p, batch, maxq, stream);
         return launch_pp(p, batch, maxq, stream);
     }
     if (p.dh == 64) return big ? launch_one<64, 4>(p, batch, maxq, stream) : launch_one<64, 2>(p, batch, maxq, stream);
