@@ -1,0 +1,97 @@
+"""Several batch-steps in flight on one GPU.
+
+One pass of the matcher over a batch is a chain of ~310 dependent kernels; a third of its time (the 200 Sinkhorn
+launches, the small GEMMs) is latency- rather than throughput-bound and leaves most of the chip idle, while the
+attention kernel is power-limited at the full-chip launch.  Independent batches therefore overlap
+well: K replicas of the model (each owns its workspace and attention cache), one host thread and one stream each, run
+steps s = i, i+K, i+2K, ... concurrently.  The result exchange between ranks stays ONE ordered lane: a single thread
+issues the all-gather of step 0, 1, 2, ... in step order on its own stream (after waiting for that step's event), so
+every rank issues the same sequence of collectives on one communicator whatever the interleaving of its workers.
+
+Per-step results are bit-identical to the sequential loop (fixed reduction orders; replicas share nothing).
+"""
+from __future__ import annotations
+
+import queue
+import threading
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+from . import dist as pdist
+
+
+class StepPipeline:
+    """``step_fns[i]()`` runs one batch-step on replica i (enqueues on the CURRENT stream) and returns
+    ``(indices0 [B, N] int64, mscores0 [B, N] float32)``; ``exchange(indices0, mscores0)`` is the per-step result
+    exchange (default: :func:`imp_release_amd.dist.all_gather_matches` over ``group``)."""
+
+    def __init__(self, step_fns: Sequence[Callable], n_total: int, group=None, device=None,
+                 exchange: Optional[Callable] = None):
+        if not step_fns:
+            raise ValueError('StepPipeline needs at least one step function')
+        self.step_fns = list(step_fns)
+        self.n_total = n_total
+        self.device = torch.device(device) if device is not None else None
+        self.cuda = self.device is not None and self.device.type == 'cuda'
+        self.exchange = exchange or (lambda i0, m0: pdist.all_gather_matches(i0, m0, n_total, group=group))
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in self.step_fns] if self.cuda else None
+        self.lane = torch.cuda.Stream(device=self.device) if self.cuda else None
+
+    def run(self, steps: int, keep: bool = False) -> List:
+        """runs ``steps`` batch-steps; returns the exchanged result of the last step (or of every step with ``keep``)"""
+        K = len(self.step_fns)
+        done: "queue.Queue" = queue.Queue()
+        errors: list = []
+
+        def worker(i):
+            try:
+                with torch.no_grad():
+                    for s in range(i, steps, K):
+                        if errors:
+                            return
+                        if self.cuda:
+                            with torch.cuda.stream(self.streams[i]):
+                                i0, m0 = self.step_fns[i]()
+                                ev = torch.cuda.Event()
+                                ev.record(self.streams[i])
+                        else:
+                            i0, m0 = self.step_fns[i]()
+                            ev = None
+                        done.put((s, i0, m0, ev))
+            except BaseException as ex:
+                errors.append(ex)
+                done.put((-1, None, None, None))
+
+        threads = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(min(K, steps))]
+        for t in threads:
+            t.start()
+        pending, results, last = {}, [], None
+        for s in range(steps):                      # the ordered exchange lane
+            while s not in pending:
+                item = done.get()
+                if item[0] < 0:
+                    for t in threads:
+                        t.join()
+                    raise errors[0]
+                pending[item[0]] = item
+            _, i0, m0, ev = pending.pop(s)
+            if self.cuda:
+                with torch.cuda.stream(self.lane):
+                    self.lane.wait_event(ev)
+                    i0.record_stream(self.lane)        # allocated on the worker's stream, read on this one
+                    m0.record_stream(self.lane)
+                    last = self.exchange(i0, m0)
+            else:
+                last = self.exchange(i0, m0)
+            if keep:
+                results.append(last)
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        if self.cuda:
+            self.lane.synchronize()
+            for st in self.streams:
+                st.synchronize()
+        return results if keep else last

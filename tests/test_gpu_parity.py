@@ -305,6 +305,37 @@ def test_sharded_eval_loop_single_rank():
     assert np.array_equal(table, again)          # deterministic
 
 
+def test_batch_steps_in_flight_reproduce_the_sequential_results():
+    """bench.py's default mode: 3 batch-steps in flight (3 replicas, 3 streams) - every step's result must equal the
+    one-after-the-other result bit for bit"""
+    from imp_release_amd import pipeline
+    cfg = eval_config(n_layers=3, sinkhorn_iterations=20)
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=1)
+    m = make_hip_model('GM', cfg, sd)
+    datas = []
+    for k in range(4):
+        pair = synthetic.make_correlated_pair(1024, 1000, seed=60 + k, batch=2)
+        d = {kk: torch.from_numpy(v).to(DEV) for kk, v in pair.items() if kk != 'image_shape'}
+        d['image0'] = d['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+        datas.append(d)
+
+    def make_fn(model, start, stride):
+        state = {'s': start}
+
+        def fn():
+            d = datas[state['s'] % len(datas)]; state['s'] += stride
+            out = model.produce_matches(d, p=0.2, only_last=True)
+            return out['indices0'][-1], out['mscores0'][-1]
+        return fn
+
+    seq = pipeline.StepPipeline([make_fn(m, 0, 1)], 2, device=DEV).run(8, keep=True)
+    reps = eval_loop.replicate(m, 3)
+    par = pipeline.StepPipeline([make_fn(r, i, 3) for i, r in enumerate(reps)], 2, device=DEV).run(8, keep=True)
+    for s_, (a, b) in enumerate(zip(seq, par)):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), s_
+    assert not torch.equal(seq[0][0], seq[1][0])          # the steps really see different batches
+
+
 def test_eval_loop_pairs_in_flight_give_identical_rows():
     """workers=K (K model replicas, K streams, K host threads) must reproduce the sequential table bit for bit; the
     injected pose step sleeps like a host-side solver so that the overlap is observable"""

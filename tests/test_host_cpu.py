@@ -142,6 +142,29 @@ table = np.arange(7 * 5, dtype=np.float64).reshape(7, 5)
 s2, e2 = pdist.shard_range(7, rank, world)
 got = eval_loop.gather_rows_across_ranks(table[s2:e2], 7)
 assert np.array_equal(got, table), rank
+# several batch-steps in flight (pipeline.StepPipeline): 3 workers with skewed speeds, ONE ordered exchange lane
+import time
+from imp_release_amd import pipeline
+n_tot, Nk = 4, 17
+def make_fn(i):
+    state = {'s': i}
+    def fn():
+        s_ = state['s']; state['s'] += 3
+        time.sleep(0.002 * ((i + rank) % 3))           # workers finish out of order, differently on each rank
+        gen = torch.Generator().manual_seed(1000 + s_)
+        fi = torch.randint(-1, Nk, (n_tot, Nk), generator=gen, dtype=torch.int64)
+        fm = torch.rand(n_tot, Nk, generator=gen)
+        a, b = pdist.shard_range(n_tot, rank, world)
+        return fi[a:b], fm[a:b]
+    return fn
+pipe = pipeline.StepPipeline([make_fn(i) for i in range(3)], n_tot)
+outs = pipe.run(10, keep=True)
+assert len(outs) == 10
+for s_, (gi_, gm_) in enumerate(outs):
+    gen = torch.Generator().manual_seed(1000 + s_)
+    fi = torch.randint(-1, Nk, (n_tot, Nk), generator=gen, dtype=torch.int64)
+    fm = torch.rand(n_tot, Nk, generator=gen)
+    assert torch.equal(gi_, fi) and torch.equal(gm_, fm), (rank, s_)
 dist.barrier()
 dist.destroy_process_group()
 print('rank', rank, 'ok')
@@ -162,3 +185,27 @@ def test_world_size_2_all_gather_over_gloo(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=120)
         assert p.returncode == 0, out
+
+
+def test_step_pipeline_orders_results_and_surfaces_errors():
+    from imp_release_amd import pipeline
+    import time
+
+    def make_fn(i):
+        state = {'s': i}
+
+        def fn():
+            s_ = state['s']; state['s'] += 2
+            time.sleep(0.003 * (1 - i))
+            return torch.full((2, 3), s_, dtype=torch.int64), torch.full((2, 3), float(s_))
+        return fn
+
+    pipe = pipeline.StepPipeline([make_fn(0), make_fn(1)], 2)
+    outs = pipe.run(7, keep=True)
+    assert [int(o[0][0, 0]) for o in outs] == list(range(7))
+    assert int(pipeline.StepPipeline([make_fn(0)], 2).run(4)[0][0, 0]) == 6        # one worker: its 4th call
+
+    def boom():
+        raise RuntimeError('step failed')
+    with pytest.raises(RuntimeError, match='step failed'):
+        pipeline.StepPipeline([boom, boom], 2).run(4)
