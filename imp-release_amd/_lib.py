@@ -103,8 +103,10 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    """the calling thread's current stream ON `device` (not on the thread's current device: worker threads of a
+    multi-GPU rank start with device 0 current)"""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
@@ -146,6 +148,7 @@ class Context:
             raise ValueError('imp_release_amd needs a GPU device; there is no CPU path')
         self.handle = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device('cuda', idx)
         self._check(self.L.imp_create(C.byref(self.handle), C.byref(cfg), idx))
         self.D = cfg.descriptor_dim
         prec = config.get('precision')          # extra (non-reference) config key: 'f16x3' (default) | 'f32'
@@ -195,7 +198,7 @@ class Context:
         out = torch.empty_like(kpts)
         B, n = kpts.shape[0], kpts.shape[1]
         self._check(self.L.imp_normalize_keypoints(self.handle, _ptr(kpts), B, n, float(width), float(height),
-                                                   _ptr(out), _stream()))
+                                                   _ptr(out), _stream(self.device)))
         return out
 
     def encode_keypoints(self, nk0, sc0, nk1, sc1, desc0=None, desc1=None):
@@ -206,7 +209,7 @@ class Context:
         o0 = torch.empty(B, n0, self.D, device=nk0.device, dtype=torch.float32)
         o1 = torch.empty(B, n1, self.D, device=nk0.device, dtype=torch.float32)
         self._check(self.L.imp_encode_keypoints(self.handle, B, n0, n1, _ptr(nk0), _ptr(sc0), _ptr(d0), _ptr(o0),
-                                                _ptr(nk1), _ptr(sc1), _ptr(d1), _ptr(o1), _stream()))
+                                                _ptr(nk1), _ptr(sc1), _ptr(d1), _ptr(o1), _stream(self.device)))
         return o0, o1
 
     def forward_layer(self, layer_i, desc0, desc1, mask0=None, mask1=None, inplace=False):
@@ -219,17 +222,17 @@ class Context:
         if mask1 is not None:
             mask1 = mask1.to(torch.uint8).contiguous()
         self._check(self.L.imp_forward_layer(self.handle, layer_i, B, n0, n1, _ptr(desc0), _ptr(desc1), _ptr(o0),
-                                             _ptr(o1), _ptr(mask0), _ptr(mask1), _stream()))
+                                             _ptr(o1), _ptr(mask0), _ptr(mask1), _stream(self.device)))
         return o0, o1
 
     def attention_prob(self, which, B, nq, nk, device):
         out = torch.empty(B, 4, nq, nk, device=device, dtype=torch.float32)
-        self._check(self.L.imp_attention_prob(self.handle, which, _ptr(out), _stream()))
+        self._check(self.L.imp_attention_prob(self.handle, which, _ptr(out), _stream(self.device)))
         return out
 
     def attention_received(self, which, B, nk, device):
         out = torch.empty(B, nk, device=device, dtype=torch.float32)
-        self._check(self.L.imp_attention_received(self.handle, which, _ptr(out), _stream()))
+        self._check(self.L.imp_attention_received(self.handle, which, _ptr(out), _stream(self.device)))
         return out
 
     def compute_distance(self, layer_id, desc0, desc1):
@@ -237,7 +240,7 @@ class Context:
         B, n0, n1 = desc0.shape[0], desc0.shape[1], desc1.shape[1]
         dist = torch.empty(B, n0, n1, device=desc0.device, dtype=torch.float32)
         self._check(self.L.imp_compute_distance(self.handle, layer_id, B, n0, n1, _ptr(desc0), _ptr(desc1),
-                                                _ptr(dist), _stream()))
+                                                _ptr(dist), _stream(self.device)))
         return dist
 
     def compute_score(self, dist, bin_score, iterations, with_sinkhorn=True):
@@ -245,7 +248,7 @@ class Context:
         B, n0, n1 = dist.shape
         scores = torch.empty(B, n0 + 1, n1 + 1, device=dist.device, dtype=torch.float32)
         self._check(self.L.imp_compute_score(self.handle, B, n0, n1, _ptr(dist), float(bin_score), int(iterations),
-                                             1 if with_sinkhorn else 0, _ptr(scores), _stream()))
+                                             1 if with_sinkhorn else 0, _ptr(scores), _stream(self.device)))
         return scores
 
     def compute_matches(self, scores, p):
@@ -257,7 +260,7 @@ class Context:
         m0 = torch.empty(B, n0, device=dev, dtype=torch.float32)
         m1 = torch.empty(B, n1, device=dev, dtype=torch.float32)
         self._check(self.L.imp_compute_matches(self.handle, B, n0, n1, _ptr(scores), float(p), _ptr(i0), _ptr(i1),
-                                               _ptr(m0), _ptr(m1), _stream()))
+                                               _ptr(m0), _ptr(m1), _stream(self.device)))
         return i0, i1, m0, m1
 
     def pool(self, scores, mscore_th, uncertainty_ratio, n_min_tokens):
@@ -269,7 +272,7 @@ class Context:
         ids1 = torch.empty(n1, device=dev, dtype=torch.int64)
         counts = torch.empty(4, device=dev, dtype=torch.int32)
         self._check(self.L.imp_pool(self.handle, n0, n1, _ptr(scores), float(mscore_th), float(uncertainty_ratio),
-                                    int(n_min_tokens), _ptr(ids0), _ptr(ids1), _ptr(counts), _stream()))
+                                    int(n_min_tokens), _ptr(ids0), _ptr(ids1), _ptr(counts), _stream(self.device)))
         c = counts.tolist()
         return (ids0[:c[0]] if c[0] >= 0 else None), (ids1[:c[2]] if c[2] >= 0 else None)
 
@@ -278,7 +281,7 @@ class Context:
         n0, n1 = scores.shape[-2] - 1, scores.shape[-1] - 1
         m0 = torch.empty(n0, device=scores.device, dtype=torch.float32)
         m1 = torch.empty(n1, device=scores.device, dtype=torch.float32)
-        self._check(self.L.imp_score_mass(self.handle, n0, n1, _ptr(scores), _ptr(m0), _ptr(m1), _stream()))
+        self._check(self.L.imp_score_mass(self.handle, n0, n1, _ptr(scores), _ptr(m0), _ptr(m1), _stream(self.device)))
         return m0, m1
 
     def pool_select(self, mass, a_self, a_cross, thr):
@@ -287,7 +290,7 @@ class Context:
         ids = torch.empty(n, device=mass.device, dtype=torch.int64)
         counts = torch.empty(2, device=mass.device, dtype=torch.int32)
         self._check(self.L.imp_pool_select(self.handle, n, _ptr(mass), _ptr(a_self), _ptr(a_cross), float(thr),
-                                           _ptr(ids), _ptr(counts), _stream()))
+                                           _ptr(ids), _ptr(counts), _stream(self.device)))
         c = counts.tolist()
         return ids[:c[0]] if c[0] >= 0 else None
 
@@ -297,7 +300,7 @@ class Context:
         B, n_in, dim = x.shape
         out = torch.empty(B, ids.numel(), dim, device=x.device, dtype=torch.float32)
         self._check(self.L.imp_gather_rows(self.handle, B, n_in, ids.numel(), dim, _ptr(x), _ptr(ids), _ptr(out),
-                                           _stream()))
+                                           _stream(self.device)))
         return out
 
     def match_pair(self, kpts0, sc0, desc0, kpts1, sc1, desc1, width, height, bin_score, iterations, with_sinkhorn,
@@ -318,7 +321,7 @@ class Context:
             self.handle, B, n0, n1, _ptr(kpts0), _ptr(sc0), _ptr(desc0), _ptr(kpts1), _ptr(sc1), _ptr(desc1),
             float(width), float(height), float(bin_score), int(iterations), 1 if with_sinkhorn else 0, float(p),
             _ptr(out['indices0']), _ptr(out['mscores0']), _ptr(out.get('indices1')), _ptr(out.get('mscores1')),
-            _ptr(out.get('scores')), _stream()))
+            _ptr(out.get('scores')), _stream(self.device)))
         return out
 
     def op_linear(self, x, W, bias=None):
@@ -327,7 +330,7 @@ class Context:
         N = W.shape[0]
         y = torch.empty(M, N, device=x.device, dtype=torch.float32)
         b = None if bias is None else _f32(bias, 'bias')
-        self._check(self.L.imp_op_linear(self.handle, M, N, K, _ptr(x), _ptr(W), _ptr(b), _ptr(y), _stream()))
+        self._check(self.L.imp_op_linear(self.handle, M, N, K, _ptr(x), _ptr(W), _ptr(b), _ptr(y), _stream(self.device)))
         return y
 
     def op_attention(self, qkv_q, qkv_kv, key_mask=None, want_lse=True):
@@ -338,15 +341,15 @@ class Context:
         lse = torch.empty(B, 4, nq, device=qkv_q.device, dtype=torch.float32) if want_lse else None
         km = None if key_mask is None else key_mask.to(torch.uint8).contiguous()
         self._check(self.L.imp_op_attention(self.handle, B, nq, nk, D, _ptr(qkv_q), _ptr(qkv_kv), _ptr(km), _ptr(out),
-                                            _ptr(lse), _stream()))
+                                            _ptr(lse), _stream(self.device)))
         return out, lse
 
     def time_attention(self, batch, n, reps):
         ms = C.c_float()
-        self._check(self.L.imp_time_attention(self.handle, batch, n, reps, C.byref(ms), _stream()))
+        self._check(self.L.imp_time_attention(self.handle, batch, n, reps, C.byref(ms), _stream(self.device)))
         return ms.value
 
     def time_sinkhorn(self, batch, n, iterations):
         ms = C.c_float()
-        self._check(self.L.imp_time_sinkhorn(self.handle, batch, n, iterations, C.byref(ms), _stream()))
+        self._check(self.L.imp_time_sinkhorn(self.handle, batch, n, iterations, C.byref(ms), _stream(self.device)))
         return ms.value

@@ -88,6 +88,8 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
         def worker(m):
             stream = torch.cuda.Stream(device=device) if device.type == 'cuda' else None
             try:
+                if stream is not None:
+                    torch.cuda.set_device(device)            # a new thread starts with device 0 current
                 with torch.no_grad():
                     while not errors:
                         with lock:

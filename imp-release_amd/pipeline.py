@@ -46,6 +46,8 @@ class StepPipeline:
 
         def worker(i):
             try:
+                if self.cuda:
+                    torch.cuda.set_device(self.device)       # a new thread starts with device 0 current
                 with torch.no_grad():
                     for s in range(i, steps, K):
                         if errors:
