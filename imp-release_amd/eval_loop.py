@@ -81,6 +81,8 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
         if len(models) < workers:
             raise ValueError(f'workers={workers} needs {workers} model replicas, got {len(models)}')
         device = model._device()
+        if device.type == 'cuda' and device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
         todo = iter(range(s, e))
         lock = threading.Lock()
         errors = []

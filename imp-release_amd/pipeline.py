@@ -34,6 +34,8 @@ class StepPipeline:
         self.n_total = n_total
         self.device = torch.device(device) if device is not None else None
         self.cuda = self.device is not None and self.device.type == 'cuda'
+        if self.cuda and self.device.index is None:
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.exchange = exchange or (lambda i0, m0: pdist.all_gather_matches(i0, m0, n_total, group=group))
         self.streams = [torch.cuda.Stream(device=self.device) for _ in self.step_fns] if self.cuda else None
         self.lane = torch.cuda.Stream(device=self.device) if self.cuda else None
