@@ -238,3 +238,30 @@ def test_pool_and_gather():
     m0, m1 = ctx.score_mass(score[0].to(DEV))
     assert (m0.cpu() - score[0, :-1, :-1].sum(-1)).abs().max().item() < 1e-5
     assert (m1.cpu() - score[0, :-1, :-1].sum(0)).abs().max().item() < 1e-5
+
+
+def test_pool_select_fuzz_with_ties_and_duplicates():
+    """integer work must be exact: 200 random selection problems with heavy ties (quantised values), exact zeros,
+    subnormals, sizes 1..5000 and thresholds that keep none / few / all candidates - kept id lists must equal the oracle's
+    (torch.median = LOWER median; union; ascending)"""
+    ctx = _model('AdaGMN', n_layers=2)[2]._ensure_ctx()
+    g = torch.Generator().manual_seed(123)
+    for trial in range(200):
+        n = int(torch.randint(1, 5001, (1,), generator=g)) if trial % 4 else int(torch.randint(1, 70, (1,), generator=g))
+        levels = int(torch.randint(1, 40, (1,), generator=g))
+        def vec():
+            v = torch.randint(0, levels + 1, (n,), generator=g).float() / levels
+            kind = int(torch.randint(0, 4, (1,), generator=g))
+            if kind == 1:
+                v = v * 1e-41                      # subnormal range
+            elif kind == 2:
+                v = v + torch.rand(n, generator=g) * 1e-7
+            return v
+        mass, a_s, a_c = vec(), vec(), vec()
+        thr = [0.0, 0.5, 2.0, float(mass.median())][trial % 4]
+        ref = orc._pool_side(mass, a_s, a_c, thr)
+        got = ctx.pool_select(mass.to(DEV), a_s.to(DEV), a_c.to(DEV), thr)
+        if ref is None:
+            assert got is None, (trial, n, thr)
+        else:
+            assert got is not None and torch.equal(got.cpu(), ref), (trial, n, thr, levels)
