@@ -113,6 +113,8 @@ def main():
     ap.add_argument('--in-flight', type=int, default=3,
                     help='batch-steps in flight per GPU (model replicas, one stream + host thread each; the result '
                          'exchange stays one ordered lane). 1 = strictly one step after the other')
+    ap.add_argument('--sinkhorn-storage', type=int, choices=[3, 4], default=4,
+                    help='bytes per matrix element the Sinkhorn iterations stream (4 = fp32, default; 3 = opt-in 3-byte copy)')
     ap.add_argument('--precision', choices=['f16x3', 'f32'], default='f16x3',
                     help='matrix arithmetic: split-half f16 x3 MFMA (fp32-level results, default) or native fp32 MFMA')
     args = ap.parse_args()
@@ -138,7 +140,7 @@ def main():
 
     cfg = eval_config(args.iters, args.sinkhorn)
     sd = synthetic.make_state_dict(cfg, 'GM', seed=0)
-    model = P.GM(dict(cfg, precision=args.precision)).eval()
+    model = P.GM(dict(cfg, precision=args.precision, sinkhorn_storage=args.sinkhorn_storage)).eval()
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     model = model.to(dev)
 
@@ -239,7 +241,7 @@ def main():
                                    f'{B} pairs per GPU (BASELINE configs[2]: batch 32 over 8 GPUs), norm_fn=in, '
                                    f'seeded random weights',
                        'pairs_per_gpu': B, 'keypoints': N, 'parallelism': f'pair-sharded x{world}',
-                       'steps_in_flight_per_gpu': inflight,
+                       'steps_in_flight_per_gpu': inflight, 'sinkhorn_storage_bytes': args.sinkhorn_storage,
                        'matched_keypoints': n_matched},
             'roofline': {'bound': 'mfma', 'kernel': kname,
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,

@@ -23,7 +23,7 @@ ACT_IDS = {'relu': 0, 'gelu': 1, 'lrelu': 2}
 # every symbol include/imp_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     'imp_last_error', 'imp_version', 'imp_create', 'imp_destroy', 'imp_load_tensor', 'imp_finalize_weights',
-    'imp_set_precision', 'imp_get_precision', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
+    'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
     'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear',
     'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn',
@@ -77,6 +77,7 @@ def lib():
     L.imp_finalize_weights.argtypes = [C.c_void_p]
     L.imp_set_precision.argtypes = [C.c_void_p, C.c_int]
     L.imp_get_precision.argtypes = [C.c_void_p]
+    L.imp_set_sinkhorn_storage.argtypes = [C.c_void_p, C.c_int]
     P, I, F = C.c_void_p, C.c_int, C.c_float
     L.imp_normalize_keypoints.argtypes = [P, P, I, I, F, F, P, P]
     L.imp_encode_keypoints.argtypes = [P, I, I, I, P, P, P, P, P, P, P, P, P]
@@ -156,6 +157,13 @@ class Context:
             if prec not in ('f32', 'f16x3'):
                 raise ValueError("precision must be 'f32' or 'f16x3'")
             self._check(self.L.imp_set_precision(self.handle, 1 if prec == 'f16x3' else 0))
+        stor = config.get('sinkhorn_storage')   # extra config key: 4 (default, fp32) | 3 (3-byte copy for the iterations)
+        if stor is not None:
+            self._check(self.L.imp_set_sinkhorn_storage(self.handle, int(stor)))
+
+    def set_sinkhorn_storage(self, bytes_per_element: int):
+        """4 = the Sinkhorn iterations stream the fp32 matrix (default), 3 = the 3-byte copy (include/imp_hip.h)"""
+        self._check(self.L.imp_set_sinkhorn_storage(self.handle, int(bytes_per_element)))
 
     @property
     def precision(self):

@@ -50,6 +50,7 @@ struct imp_ctx {
     std::map<std::string, HostTensor> raw;
     bool finalized = false;
     int prec = 1;             // matrix arithmetic: 1 = f16x3 split (default), 0 = native fp32 MFMA (imp_set_precision / IMP_PRECISION=f32)
+    int ot_compact = 0;       // Sinkhorn iterations stream the 3-byte copy of P (imp_set_sinkhorn_storage / IMP_OT_COMPACT=1)
     bool fuse_merge = true;   // fold attn.merge into mlp.0 (one GEMM and one launch less per layer); IMP_NO_FUSE_MERGE=1 disables
     float bin_score = 1.f;
     std::vector<void*> allocs_w, allocs_ws;
@@ -223,6 +224,7 @@ int ensure_workspace(imp_ctx* c, int batch, int n) {
     if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->ot.v, B * ld);
     if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->ot.v2, B * ld);
     if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->ot.partials, B * ((N + 1 + 15) / 16) * ld);   // >= ceil(n0 / FP_ROWS) partial vectors
+    if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->ot.P24, B * (N + 1) * (ld / 4) * 3);          // 3 bytes per matrix element
     if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->max0, B * N);
     if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->max1, B * N);
     if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->arg0, B * N);
@@ -455,6 +457,7 @@ int run_distance(imp_ctx* c, int layer_id, int batch, const int n[2], const floa
 
 void ot_layout(imp_ctx* c, int n0, int n1, OtBuffers* o) {
     *o = c->ot;
+    o->compact = c->ot_compact;
     o->ldp = (n1 + 1 + 3) & ~3;
     o->ldpt = (n0 + 1 + 3) & ~3;
 }
@@ -510,6 +513,7 @@ int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     c->dh = c->D / IMP_NUM_HEADS;
     { const char* e = getenv("IMP_NO_FUSE_MERGE"); c->fuse_merge = !(e && e[0] == '1'); }
     { const char* e = getenv("IMP_PRECISION"); c->prec = (e && !strcmp(e, "f32")) ? 0 : 1; }
+    { const char* e = getenv("IMP_OT_COMPACT"); c->ot_compact = (e && atoi(e) != 0) ? 1 : 0; }
     c->kenc_maxc = c->D;
     for (int i = 0; i < nk; ++i) if (cfg->kenc_channels[i] > c->kenc_maxc) c->kenc_maxc = cfg->kenc_channels[i];
     build_schema(c);
@@ -533,6 +537,11 @@ int imp_set_precision(imp_ctx* c, int precision) {
     return IMP_OK;
 }
 int imp_get_precision(imp_ctx* c) { return c ? c->prec : -1; }
+int imp_set_sinkhorn_storage(imp_ctx* c, int bytes) {
+    if (!c || (bytes != 3 && bytes != 4)) return fail(IMP_E_ARG, "imp_set_sinkhorn_storage: 3 or 4 bytes per element");
+    c->ot_compact = bytes == 3;
+    return IMP_OK;
+}
 
 int imp_num_keys(imp_ctx* c) { return c ? (int)c->schema.size() : 0; }
 const char* imp_key_name(imp_ctx* c, int i) {

@@ -127,6 +127,9 @@ struct OtBuffers {
     float* v;      // [B][n1+1]   (always the newest v: the fused Sinkhorn path ping-pongs v <-> v2)
     float* v2;     // second v buffer
     float* partials; // [B][ceil((n0+1)/16)][ldp] column partial sums of the fused Sinkhorn pass (null: two-pass path)
+    unsigned* P24;   // [B][n0+1][3*ldp/4 dwords] 3-byte copy of P (sign, exponent, 15 mantissa bits, round to nearest even)
+                     // read by the fused Sinkhorn iterations instead of P when `compact`; scores / maxima always use P
+    int compact;
     int ldp, ldpt;
 };
 hipError_t launch_ot_init(const float* dist, int batch, int n0, int n1, float bin_score, int dual,

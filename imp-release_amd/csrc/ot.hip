@@ -17,8 +17,33 @@
 #include "imp_kernels.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// 12-byte record of the 3-byte matrix copy (a 3-element ext_vector would be padded to 16 bytes)
+struct __attribute__((packed, aligned(4))) u32x3 { unsigned w0, w1, w2; };
 
 namespace {
+
+// ---- 3-byte storage of P for the Sinkhorn iterations ---------------------------------------------------------
+// The iterations only need the scaling vectors u, v; they stream the matrix T times, so its bytes are the cost.  A copy
+// that keeps sign, exponent and 15 mantissa bits (round to nearest even: relative 2^-17) moves 3/4 of the bytes; the
+// scores p.u.v and the maxima are still formed from the fp32 matrix.  Chosen by experiment like the f16x3 products:
+// emulated in the oracle on 11 pairs (N = 512 / 1024 / 2048, L = 9, T = 100) it gives 0 index mismatches and
+// |dmscore| <= 1.0e-5 (tolerance 1e-4), whereas 11 mantissa bits (a 2-byte copy) drifts to 1.8e-4.
+// Four consecutive values a, b, c, d are packed into three dwords: [a0 a1 a2 b0 | b1 b2 c0 c1 | c2 d0 d1 d2] (x2 = top byte).
+__device__ __forceinline__ unsigned q24(float x) {          // rounded fp32 bit pattern with the low byte cleared
+    unsigned u = __float_as_uint(x);
+    u += 0x7Fu + ((u >> 8) & 1u);
+    return u & 0xFFFFFF00u;
+}
+__device__ __forceinline__ u32x3 pack24(const f32x4 x) {
+    const unsigned a = q24(x[0]) >> 8, b = q24(x[1]) >> 8, c = q24(x[2]) >> 8, d = q24(x[3]) >> 8;
+    return u32x3{a | (b << 24), (b >> 8) | (c << 16), (c >> 16) | (d << 8)};   // aggregate init of the 12-byte record
+}
+__device__ __forceinline__ f32x4 unpack24(const u32x3 w) {
+    return f32x4{__uint_as_float(w.w0 << 8),
+                 __uint_as_float(__builtin_amdgcn_perm(w.w1, w.w0, 0x0504030cu)),     // v_perm_b32: 0-3 = 2nd source, 0x0c = 0
+                 __uint_as_float(__builtin_amdgcn_perm(w.w2, w.w1, 0x0403020cu)),
+                 __uint_as_float(w.w2 & 0xFFFFFF00u)};
+}
 
 constexpr float OT_EPS = 1e-8f;   // nets/layers.py:13
 
@@ -47,7 +72,7 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 __global__ __launch_bounds__(256) void ot_init_kernel(const float* __restrict__ dist, int n0, int n1, float bin,
                                                       int dual, float* __restrict__ P, int ldp,
                                                       float* __restrict__ u, float* __restrict__ v, int ldpt,
-                                                      float* __restrict__ v2) {
+                                                      float* __restrict__ v2, unsigned* __restrict__ P24) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     const int b = blockIdx.y;
@@ -72,8 +97,23 @@ __global__ __launch_bounds__(256) void ot_init_kernel(const float* __restrict__ 
     float sum = 0.f;
     for (int j = lane; j <= n1; j += 64) sum += expf(((last || j == n1) ? bin : drow[j]) - mx);
     sum = wave_sum(sum);
-    for (int j = lane; j < ldp; j += 64)
-        prow[j] = j > n1 ? 0.f : expf(((last || j == n1) ? bin : drow[j]) - mx) / sum;
+    if (P24 == nullptr) {
+        for (int j = lane; j < ldp; j += 64)
+            prow[j] = j > n1 ? 0.f : expf(((last || j == n1) ? bin : drow[j]) - mx) / sum;
+        return;
+    }
+    // 4 consecutive columns per lane: one float4 of P and the 12-byte packed copy (same values, same expressions)
+    u32x3* qrow = reinterpret_cast<u32x3*>(P24 + ((long)b * (n0 + 1) + row) * (3 * (ldp >> 2)));
+    for (int j4 = lane; j4 < (ldp >> 2); j4 += 64) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = 4 * j4 + e;
+            o[e] = j > n1 ? 0.f : expf(((last || j == n1) ? bin : drow[min(j, n1 - 1)]) - mx) / sum;
+        }
+        *reinterpret_cast<f32x4*>(prow + 4 * j4) = o;
+        qrow[j4] = pack24(o);
+    }
 }
 
 // ---- 32x32 LDS tile transpose: PT[j][i] = P[i][j]; padded tail of PT rows zeroed ----------------------
@@ -149,7 +189,7 @@ __global__ __launch_bounds__(256) void ot_rowpass_kernel(const float* __restrict
 // combine their partials in LDS and write one partial vector per workgroup; ot_colreduce_kernel turns the partial
 // vectors into v.  Fixed summation order everywhere (no atomics).
 constexpr int FP_WAVES = 8, FP_RPW = 4, FP_ROWS = FP_WAVES * FP_RPW;   // 512 threads, 32 rows per workgroup
-template <int NCH>
+template <int NCH, int COMPACT>
 __global__ __launch_bounds__(512, 2) void ot_fused_pass_kernel(const float* __restrict__ P, int rows, int prows, int ld,
                                                                const float* __restrict__ v, float* __restrict__ u,
                                                                int ld_u, float* __restrict__ partials, int nwg) {
@@ -165,6 +205,13 @@ __global__ __launch_bounds__(512, 2) void ot_fused_pass_kernel(const float* __re
     const int n4 = ld >> 2;
     f32x4 part[NCH], row[2][NCH];
     auto load_row = [&](int slot, int r) {
+        if (COMPACT) {      // P points at the 3-byte copy: 3 dwords per 4 values
+            const u32x3* rp = reinterpret_cast<const u32x3*>(reinterpret_cast<const unsigned*>(P) +
+                                                             ((long)b * prows + min(r, rows - 1)) * (3 * n4));
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) row[slot][c] = unpack24(rp[min(lane + 64 * c, n4 - 1)]);
+            return;
+        }
         const f32x4* rp = reinterpret_cast<const f32x4*>(base + (long)min(r, rows - 1) * ld);
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -229,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void ot_fused_pass_kernel(const float* __re
 __global__ __launch_bounds__(1024) void ot_colreduce_kernel(const float* __restrict__ partials, int nwg, int ld, int cols,
                                                             const float* __restrict__ P, int n0,
                                                             const float* __restrict__ v_old, float* __restrict__ v_new,
-                                                            float* __restrict__ u, int ld_u) {
+                                                            float* __restrict__ u, int ld_u, int compact) {
     __shared__ float sm[16][64];
     __shared__ float dpart[16];
     __shared__ float ulast_s;
@@ -240,7 +287,8 @@ __global__ __launch_bounds__(1024) void ot_colreduce_kernel(const float* __restr
     const float* vo = v_old + (long)b * ld;
     // dustbin-row dot product: thread t takes columns t, t+1024, ... (pads of P and v are zero)
     float d = 0.f;
-    for (int c = threadIdx.x; c < ld; c += 1024) d = fmaf(plast[c], vo[c], d);
+    // (compact: the iterations see the 3-byte values of the whole matrix, so the dustbin row is rounded the same way)
+    for (int c = threadIdx.x; c < ld; c += 1024) d = fmaf(compact ? __uint_as_float(q24(plast[c])) : plast[c], vo[c], d);
     float s = 0.f;
     if (j < cols) {
         const float* pp = partials + (long)b * nwg * ld + j;
@@ -269,7 +317,7 @@ __global__ __launch_bounds__(1024) void ot_colreduce_kernel(const float* __restr
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += sm[k][cx];
-        t = fmaf(plast[j], ulast_s, t);
+        t = fmaf(compact ? __uint_as_float(q24(plast[j])) : plast[j], ulast_s, t);
         const float marg = j == cols - 1 ? (float)cols : 1.f;
         v_new[(long)b * ld + j] = marg / (t + OT_EPS);
     }
@@ -472,37 +520,46 @@ __global__ __launch_bounds__(256) void colsum_combine_kernel(const float* __rest
 
 hipError_t launch_ot_init(const float* dist, int batch, int n0, int n1, float bin_score, int dual,
                           const OtBuffers& ot, hipStream_t stream) {
+    const bool compact = ot.compact && ot.P24 && !dual && ot.partials && ot.v2 && ot.ldp <= 2304;   // fused-path launches only
     hipLaunchKernelGGL(ot_init_kernel, dim3((n0 + 1 + 3) / 4, batch), dim3(256), 0, stream, dist, n0, n1, bin_score,
-                       dual, ot.P, ot.ldp, ot.u, ot.v, ot.ldpt, ot.v2);
+                       dual, ot.P, ot.ldp, ot.u, ot.v, ot.ldpt, ot.v2, compact ? ot.P24 : (unsigned*)nullptr);
     hipLaunchKernelGGL(ot_transpose_kernel, dim3((n1 + 1 + 31) / 32, (ot.ldpt + 31) / 32, batch), dim3(256), 0, stream,
                        ot.P, n0 + 1, n1 + 1, ot.ldp, ot.PT, ot.ldpt);
     return hipGetLastError();
 }
 
-template <int NCH>
+template <int NCH, int COMPACT>
 static void launch_fused_iteration(int batch, int n0, int n1, OtBuffers& ot, hipStream_t stream) {
     const int nwg = (n0 + FP_ROWS - 1) / FP_ROWS;
     const size_t lds = (size_t)(1 + FP_WAVES) * ot.ldp * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)ot_fused_pass_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)ot_fused_pass_kernel<NCH, COMPACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)((1 + FP_WAVES) * 2304 * sizeof(float)));
         attr_set = true;
     }
-    hipLaunchKernelGGL(ot_fused_pass_kernel<NCH>, dim3(nwg, batch), dim3(512), lds, stream, ot.P, n0, n0 + 1, ot.ldp, ot.v,
-                       ot.u, ot.ldpt, ot.partials, nwg);
+    hipLaunchKernelGGL((ot_fused_pass_kernel<NCH, COMPACT>), dim3(nwg, batch), dim3(512), lds, stream,
+                       COMPACT ? reinterpret_cast<const float*>(ot.P24) : ot.P, n0, n0 + 1, ot.ldp, ot.v, ot.u, ot.ldpt,
+                       ot.partials, nwg);
     hipLaunchKernelGGL(ot_colreduce_kernel, dim3((n1 + 1 + 63) / 64, batch), dim3(1024), 0, stream, ot.partials, nwg,
-                       ot.ldp, n1 + 1, ot.P, n0, ot.v, ot.v2, ot.u, ot.ldpt);
-    float* t = ot.v; ot.v = ot.v2; ot.v2 = t;      // ping-pong: ot.v is always the newest v
+                       ot.ldp, n1 + 1, ot.P, n0, ot.v, ot.v2, ot.u, ot.ldpt, COMPACT);
+    float* t = ot.v; ot.v = ot.v2; ot.v2 = t;
 }
 
 hipError_t launch_ot_iterations(int batch, int n0, int n1, int iterations, OtBuffers& ot, hipStream_t stream) {
     if (ot.partials && ot.v2 && ot.ldp <= 2304) {
         // fused path: P is read once per iteration (row held in registers), column partials reduced by a tiny kernel
+        const bool compact = ot.compact && ot.P24;
         for (int it = 0; it < iterations; ++it) {
-            if (ot.ldp <= 512) launch_fused_iteration<2>(batch, n0, n1, ot, stream);
-            else if (ot.ldp <= 1280) launch_fused_iteration<5>(batch, n0, n1, ot, stream);
-            else launch_fused_iteration<9>(batch, n0, n1, ot, stream);
+            if (compact) {
+                if (ot.ldp <= 512) launch_fused_iteration<2, 1>(batch, n0, n1, ot, stream);
+                else if (ot.ldp <= 1280) launch_fused_iteration<5, 1>(batch, n0, n1, ot, stream);
+                else launch_fused_iteration<9, 1>(batch, n0, n1, ot, stream);
+            } else {
+                if (ot.ldp <= 512) launch_fused_iteration<2, 0>(batch, n0, n1, ot, stream);
+                else if (ot.ldp <= 1280) launch_fused_iteration<5, 0>(batch, n0, n1, ot, stream);
+                else launch_fused_iteration<9, 0>(batch, n0, n1, ot, stream);
+            }
         }
         return hipGetLastError();
     }

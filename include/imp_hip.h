@@ -94,6 +94,12 @@ int imp_finalize_weights(imp_ctx* ctx);
  * Environment override at imp_create: IMP_PRECISION=f32|f16x3. */
 int imp_set_precision(imp_ctx* ctx, int precision);
 int imp_get_precision(imp_ctx* ctx);
+/* Storage the T Sinkhorn iterations (nets/layers.py:31-33) stream: 4 (default) = the fp32 matrix; 3 = a 3-byte copy
+ * (sign, exponent, 15 mantissa bits, round to nearest even) - 3/4 of the bytes of the HBM-bound loop.  The returned
+ * scores p.u.v and the match maxima are formed from the fp32 matrix either way; with 3, u and v (and so every score)
+ * move by ~1e-5 RELATIVE (measured: match scores <= 1.2e-5 from the reference, indices identical), i.e. O(N)-sized
+ * dustbin entries move by ~1e-5 N.  Environment default at imp_create: IMP_OT_COMPACT=1 selects 3. */
+int imp_set_sinkhorn_storage(imp_ctx* ctx, int bytes_per_element);
 
 /* number of schema keys / i-th key (so a host can enumerate what strict loading expects) */
 int imp_num_keys(imp_ctx* ctx);

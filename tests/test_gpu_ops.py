@@ -265,3 +265,35 @@ def test_pool_select_fuzz_with_ties_and_duplicates():
             assert got is None, (trial, n, thr)
         else:
             assert got is not None and torch.equal(got.cpu(), ref), (trial, n, thr, levels)
+
+
+@pytest.mark.parametrize('n0,n1,T', [(64, 64, 20), (300, 307, 100), (1, 5, 3), (1024, 1000, 100), (2048, 2048, 100)])
+def test_sinkhorn_on_the_three_byte_copy(n0, n1, T):
+    """opt-in storage mode (imp_set_sinkhorn_storage(3)): the iterations stream a 3-byte copy of P, the scores are still
+    formed from the fp32 matrix.  u, v move by ~1e-5 relative: inner scores (<= 1) stay within 2e-5 of the oracle, the
+    O(N) dustbin entries within 3e-5 relative; column marginals hold to the same relative accuracy; matches taken from the
+    score tensor are exact integer work as always"""
+    cfg = eval_config(n_layers=2, sinkhorn_storage=3)
+    sd = synthetic.make_state_dict(cfg, model='GM', seed=5)
+    ctx = make_hip_model('GM', cfg, sd)._ensure_ctx()
+    B = 2
+    dist = _rand(B, n0, n1, seed=9, scale=2.0)
+    k = min(n0, n1) // 2
+    for b in range(B):
+        ids = torch.randperm(min(n0, n1), generator=torch.Generator().manual_seed(b))[:k]
+        dist[b, ids, ids] += 6.0
+    got = ctx.compute_score(dist.to(DEV), 1.3, T, True)
+    ref = orc.sinkhorn(orc.dustbin_augment(dist, torch.tensor(1.3)), T)
+    d = (got.cpu() - ref).abs()
+    assert (d - 3e-5 * ref.abs()).max().item() < 2e-5, f'max abs {d.max().item():.3e}'
+    assert d[:, :-1, :-1].max().item() < 2e-5                      # everything a match score can be
+    cs = got.cpu().double().sum(1)
+    assert (cs[:, :-1] - 1).abs().max().item() < 1e-4 and ((cs[:, -1] - (n1 + 1)).abs() / (n1 + 1)).max().item() < 3e-5
+    i0, i1, m0, m1 = ctx.compute_matches(got, 0.2)
+    r0, r1, rm0, rm1 = orc.compute_matches(got.cpu(), 0.2)
+    assert torch.equal(i0.cpu(), r0) and torch.equal(i1.cpu(), r1) and torch.equal(m0.cpu(), rm0)
+    # and against the fp32-streaming mode: identical match indices
+    ctx4 = make_hip_model('GM', eval_config(n_layers=2), sd)._ensure_ctx()
+    got4 = ctx4.compute_score(dist.to(DEV), 1.3, T, True)
+    j0 = ctx4.compute_matches(got4, 0.2)[0]
+    assert torch.equal(j0, i0)
