@@ -131,8 +131,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
-    if world > 1:
+    use_pg = world > 1 or bool(os.environ.get('IMP_FORCE_COLLECTIVES'))     # the latter: one-rank check of the RCCL path
+    if use_pg:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     import imp_release_amd as P
@@ -168,7 +170,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -265,7 +267,7 @@ def main():
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

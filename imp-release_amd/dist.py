@@ -8,6 +8,8 @@ box, "gloo" in the CPU tests).  One process per GPU.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -37,7 +39,9 @@ def unpack_matches(buf: torch.Tensor, n: int):
 def all_gather_matches(indices0: torch.Tensor, mscores0: torch.Tensor, n_total: int, group=None):
     """Every rank contributes the results of its shard_range() block; returns the full [n_total, N] tensors on
     every rank.  Blocks are padded to ceil(n_total / world) rows so that ONE equal-size all-gather suffices."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    # IMP_FORCE_COLLECTIVES=1: go through the collective even on one rank (single-GPU check of the exchange lane)
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and
+                                                               not os.environ.get('IMP_FORCE_COLLECTIVES')):
         return indices0, mscores0
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     n = indices0.shape[1]
