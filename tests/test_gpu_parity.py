@@ -210,10 +210,9 @@ def test_full_size_properties(big):
 
 
 def test_bench_batch_of_four_takes_the_pingpong_attention_path():
-    """bench.py's launch geometry (4 pairs x 2048 keypoints) is the one that selects the phase-staggered attention
-    kernel (>= 256 workgroups of 256 queries); a batch of 1 or 2 runs the lock-step kernels.  Same pairs, two different
-    kernel families: indices must agree exactly and scores within the parity tolerance; pair 0 is also checked against
-    the oracle at the full BASELINE size."""
+    """bench.py's launch geometry (4 pairs x 2048 keypoints = one 256-query workgroup per CU): repeatable bit for bit,
+    batch-invariant (a pair inside the batch == the pair alone, where the same kernels run on a quarter of the chip),
+    and pair 0 checked against the oracle at the full BASELINE size."""
     cfg = eval_config(n_layers=9, sinkhorn_iterations=100)
     sd = synthetic.make_state_dict(cfg, 'GM', seed=1)
     m = make_hip_model('GM', cfg, sd)
@@ -230,7 +229,7 @@ def test_bench_batch_of_four_takes_the_pingpong_attention_path():
             o1 = m.produce_matches(solo, p=0.2, only_last=True)
         print(compare_matches(_cpu(out4['indices0'][-1][b:b + 1]), _cpu(out4['mscores0'][-1][b:b + 1]),
                               _cpu(o1['indices0'][-1]).numpy(), _cpu(o1['mscores0'][-1]).numpy(), 0.2, TOL,
-                              f'batch-of-4 (ping-pong kernel) vs solo (lock-step kernel), pair {b}'))
+                              f'batch of 4 vs solo, pair {b}'))
     o = orc.MatcherOracle(cfg, sd, 'GM')
     cdata = {k: v[:1].cpu() for k, v in data.items()}
     with torch.no_grad():
