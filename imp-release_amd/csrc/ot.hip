@@ -273,10 +273,11 @@ __global__ __launch_bounds__(512, 2) void ot_fused_pass_kernel(const float* __re
 // (nets/layers.py:33,43-44).  The dustbin ROW n0 of P is handled here: u[n0] = (n0+1) / (P[n0][:] . v_old + eps)
 // (nets/layers.py:32,41-42), computed redundantly per workgroup in a fixed order; v is ping-ponged (v_old -> v_new).
 // block = 64 columns x 16 partial groups (1024 threads): group g sums partials g, g+16, ... ; LDS combine in order
+template <int COMPACT>
 __global__ __launch_bounds__(1024) void ot_colreduce_kernel(const float* __restrict__ partials, int nwg, int ld, int cols,
                                                             const float* __restrict__ P, int n0,
                                                             const float* __restrict__ v_old, float* __restrict__ v_new,
-                                                            float* __restrict__ u, int ld_u, int compact) {
+                                                            float* __restrict__ u, int ld_u) {
     __shared__ float sm[16][64];
     __shared__ float dpart[16];
     __shared__ float ulast_s;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(1024) void ot_colreduce_kernel(const float* __restr
     // dustbin-row dot product: thread t takes columns t, t+1024, ... (pads of P and v are zero)
     float d = 0.f;
     // (compact: the iterations see the 3-byte values of the whole matrix, so the dustbin row is rounded the same way)
-    for (int c = threadIdx.x; c < ld; c += 1024) d = fmaf(compact ? __uint_as_float(q24(plast[c])) : plast[c], vo[c], d);
+    for (int c = threadIdx.x; c < ld; c += 1024) d = fmaf(COMPACT ? __uint_as_float(q24(plast[c])) : plast[c], vo[c], d);
     float s = 0.f;
     if (j < cols) {
         const float* pp = partials + (long)b * nwg * ld + j;
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(1024) void ot_colreduce_kernel(const float* __restr
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += sm[k][cx];
-        t = fmaf(compact ? __uint_as_float(q24(plast[j])) : plast[j], ulast_s, t);
+        t = fmaf(COMPACT ? __uint_as_float(q24(plast[j])) : plast[j], ulast_s, t);
         const float marg = j == cols - 1 ? (float)cols : 1.f;
         v_new[(long)b * ld + j] = marg / (t + OT_EPS);
     }
@@ -541,8 +542,8 @@ static void launch_fused_iteration(int batch, int n0, int n1, OtBuffers& ot, hip
     hipLaunchKernelGGL((ot_fused_pass_kernel<NCH, COMPACT>), dim3(nwg, batch), dim3(512), lds, stream,
                        COMPACT ? reinterpret_cast<const float*>(ot.P24) : ot.P, n0, n0 + 1, ot.ldp, ot.v, ot.u, ot.ldpt,
                        ot.partials, nwg);
-    hipLaunchKernelGGL(ot_colreduce_kernel, dim3((n1 + 1 + 63) / 64, batch), dim3(1024), 0, stream, ot.partials, nwg,
-                       ot.ldp, n1 + 1, ot.P, n0, ot.v, ot.v2, ot.u, ot.ldpt, COMPACT);
+    hipLaunchKernelGGL(ot_colreduce_kernel<COMPACT>, dim3((n1 + 1 + 63) / 64, batch), dim3(1024), 0, stream, ot.partials, nwg,
+                       ot.ldp, n1 + 1, ot.P, n0, ot.v, ot.v2, ot.u, ot.ldpt);
     float* t = ot.v; ot.v = ot.v2; ot.v2 = t;
 }
 
