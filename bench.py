@@ -113,6 +113,9 @@ def main():
     ap.add_argument('--in-flight', type=int, default=3,
                     help='batch-steps in flight per GPU (model replicas, one stream + host thread each; the result '
                          'exchange stays one ordered lane). 1 = strictly one step after the other')
+    ap.add_argument('--h2d', action='store_true',
+                    help='additionally time the same steps with every batch uploaded from pinned host memory inside the '
+                         'step (PCIe-inclusive rate, reported as value_with_h2d; never the headline value)')
     ap.add_argument('--sinkhorn-storage', type=int, choices=[3, 4], default=4,
                     help='bytes per matrix element the Sinkhorn iterations stream (4 = fp32, default; 3 = opt-in 3-byte copy)')
     ap.add_argument('--precision', choices=['f16x3', 'f32'], default='f16x3',
@@ -194,6 +197,24 @@ def main():
         if world > 1:
             dist.all_reduce(serial_s, op=dist.ReduceOp.MAX)
         serial_s = float(serial_s.item())
+    h2d_s = None
+    if args.h2d:
+        host = {k: v.cpu().pin_memory() for k, v in data.items() if k not in ('image0', 'image1')}
+
+        def make_h2d_step(m):
+            dbuf = {k: torch.empty_like(v, device=dev) for k, v in host.items()}
+            dbuf['image0'] = dbuf['image1'] = data['image0']
+
+            def step_fn():
+                for k, v in host.items():
+                    dbuf[k].copy_(v, non_blocking=True)         # on the worker's stream, ahead of the kernels that read it
+                out = m.produce_matches(dbuf, p=0.2, only_last=True)
+                return out['indices0'][-1], out['mscores0'][-1]
+            return step_fn
+
+        pipe_h = pipeline.StepPipeline([make_h2d_step(m) for m in replicas], n_total, device=dev)
+        pipe_h.run(inflight)
+        _, h2d_s = timed(pipe_h, args.steps)
     elapsed = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -262,6 +283,11 @@ def main():
         line['one_step_in_flight'] = None if serial_s is None else {
             'value': n_total * args.steps / serial_s, 'ms_per_step': serial_s / args.steps * 1e3,
             'note': 'same K steps strictly sequential on one model instance (no overlap between batch-steps)'}
+        if h2d_s is not None:
+            line['value_with_h2d'] = {'value': n_total * args.steps / h2d_s,
+                                      'ms_per_step': h2d_s / args.steps * 1e3,
+                                      'note': 'every step uploads its batch (keypoints, scores, descriptors of '
+                                              'both images) from pinned host memory on the step stream'}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args)
         else:
