@@ -6,7 +6,7 @@
 // HBM/LLC-bound byte work: the (N+1)x(M+1) fp32 matrix (16.8 MB at N=M=2048, 67 MB for 4 pairs: Infinity-Cache
 // resident) is the only large operand of the T Sinkhorn iterations.
 //
-// Main path (rows up to 2304 floats): ONE read of P per iteration.  ot_fused_pass_kernel holds a row in registers,
+// Main path (rows up to 3328 floats): ONE read of P per iteration.  ot_fused_pass_kernel holds a row in registers,
 // computes u_i = r_i / (P_i . v + eps) and immediately accumulates P_ij * u_i into per-lane column partials, so the
 // transposed mat-vec needs no second pass; ot_colreduce_kernel sums the per-workgroup partial vectors (plus the
 // constant dustbin row) into v.  Two launches per iteration over all B pairs: a kernel boundary (~1.5 us) is the
@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256) void ot_rowpass_kernel(const float* __restrict
 // combine their partials in LDS and write one partial vector per workgroup; ot_colreduce_kernel turns the partial
 // vectors into v.  Fixed summation order everywhere (no atomics).
 constexpr int FP_WAVES = 8, FP_RPW = 4, FP_ROWS = FP_WAVES * FP_RPW;   // 512 threads, 32 rows per workgroup
+constexpr int FP_MAX_LD = 3328;   // 13 float4 per lane: 2 row slots + accumulators fill the 256-VGPR budget (17 spills), (1 + 8) x ld floats = 117 KB of LDS
 template <int NCH, int COMPACT>
 __global__ __launch_bounds__(512, 2) void ot_fused_pass_kernel(const float* __restrict__ P, int rows, int prows, int ld,
                                                                const float* __restrict__ v, float* __restrict__ u,
@@ -203,7 +204,8 @@ __global__ __launch_bounds__(512, 2) void ot_fused_pass_kernel(const float* __re
     const int r0 = blockIdx.x * FP_ROWS + wave * FP_RPW;
     const float* base = P + (long)b * prows * ld;
     const int n4 = ld >> 2;
-    f32x4 part[NCH], row[2][NCH];
+    constexpr int NSLOT = 2;
+    f32x4 part[NCH], row[NSLOT][NCH];
     auto load_row = [&](int slot, int r) {
         if (COMPACT) {      // P points at the 3-byte copy: 3 dwords per 4 values
             const u32x3* rp = reinterpret_cast<const u32x3*>(reinterpret_cast<const unsigned*>(P) +
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void ot_fused_pass_kernel(const float* __re
         }
     };
     load_row(0, r0);
-    load_row(1, r0 + 1);
+    if (NSLOT == 2) load_row(1, r0 + 1);
     {   // v -> LDS once per workgroup; chunk slots past the row end read an explicit zero
         const f32x4* vin = reinterpret_cast<const f32x4*>(v + (long)b * ld);
         for (int c4 = threadIdx.x; c4 < n4; c4 += 512) *reinterpret_cast<f32x4*>(vs + 4 * c4) = vin[c4];
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void ot_fused_pass_kernel(const float* __re
             const int c4 = lane + 64 * c;
             if (c4 < n4) {
                 const f32x4 x = *reinterpret_cast<const f32x4*>(vs + 4 * c4);
-                const f32x4 m = row[k & 1][c];
+                const f32x4 m = row[k % NSLOT][c];
                 acc = fmaf(m[0], x[0], acc);
                 acc = fmaf(m[1], x[1], acc);
                 acc = fmaf(m[2], x[2], acc);
@@ -250,8 +252,8 @@ __global__ __launch_bounds__(512, 2) void ot_fused_pass_kernel(const float* __re
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) part[c][e] = fmaf(row[k & 1][c][e], ui, part[c][e]);
-        if (k + 2 < FP_RPW) load_row(k & 1, r0 + k + 2);      // rotate the two register slots: row k+2 streams in
+            for (int e = 0; e < 4; ++e) part[c][e] = fmaf(row[k % NSLOT][c][e], ui, part[c][e]);
+        if (k + NSLOT < FP_RPW) load_row(k % NSLOT, r0 + k + NSLOT);      // rotate the register slots: the next row streams in
     }
     // workgroup combine: FP_WAVES partial vectors -> 1 (fixed order)
 #pragma unroll
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(256) void colsum_combine_kernel(const float* __rest
 
 hipError_t launch_ot_init(const float* dist, int batch, int n0, int n1, float bin_score, int dual,
                           const OtBuffers& ot, hipStream_t stream) {
-    const bool compact = ot.compact && ot.P24 && !dual && ot.partials && ot.v2 && ot.ldp <= 2304;   // fused-path launches only
+    const bool compact = ot.compact && ot.P24 && !dual && ot.partials && ot.v2 && ot.ldp <= FP_MAX_LD;   // fused-path launches only
     hipLaunchKernelGGL(ot_init_kernel, dim3((n0 + 1 + 3) / 4, batch), dim3(256), 0, stream, dist, n0, n1, bin_score,
                        dual, ot.P, ot.ldp, ot.u, ot.v, ot.ldpt, ot.v2, compact ? ot.P24 : (unsigned*)nullptr);
     hipLaunchKernelGGL(ot_transpose_kernel, dim3((n1 + 1 + 31) / 32, (ot.ldpt + 31) / 32, batch), dim3(256), 0, stream,
@@ -536,7 +538,7 @@ static void launch_fused_iteration(int batch, int n0, int n1, OtBuffers& ot, hip
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)ot_fused_pass_kernel<NCH, COMPACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)((1 + FP_WAVES) * 2304 * sizeof(float)));
+                                  (int)((1 + FP_WAVES) * (NCH * 256) * sizeof(float)));
         attr_set = true;
     }
     hipLaunchKernelGGL((ot_fused_pass_kernel<NCH, COMPACT>), dim3(nwg, batch), dim3(512), lds, stream,
@@ -548,18 +550,20 @@ static void launch_fused_iteration(int batch, int n0, int n1, OtBuffers& ot, hip
 }
 
 hipError_t launch_ot_iterations(int batch, int n0, int n1, int iterations, OtBuffers& ot, hipStream_t stream) {
-    if (ot.partials && ot.v2 && ot.ldp <= 2304) {
+    if (ot.partials && ot.v2 && ot.ldp <= FP_MAX_LD) {
         // fused path: P is read once per iteration (row held in registers), column partials reduced by a tiny kernel
         const bool compact = ot.compact && ot.P24;
         for (int it = 0; it < iterations; ++it) {
             if (compact) {
                 if (ot.ldp <= 512) launch_fused_iteration<2, 1>(batch, n0, n1, ot, stream);
                 else if (ot.ldp <= 1280) launch_fused_iteration<5, 1>(batch, n0, n1, ot, stream);
-                else launch_fused_iteration<9, 1>(batch, n0, n1, ot, stream);
+                else if (ot.ldp <= 2304) launch_fused_iteration<9, 1>(batch, n0, n1, ot, stream);
+                else launch_fused_iteration<13, 1>(batch, n0, n1, ot, stream);
             } else {
                 if (ot.ldp <= 512) launch_fused_iteration<2, 0>(batch, n0, n1, ot, stream);
                 else if (ot.ldp <= 1280) launch_fused_iteration<5, 0>(batch, n0, n1, ot, stream);
-                else launch_fused_iteration<9, 0>(batch, n0, n1, ot, stream);
+                else if (ot.ldp <= 2304) launch_fused_iteration<9, 0>(batch, n0, n1, ot, stream);
+                else launch_fused_iteration<13, 0>(batch, n0, n1, ot, stream);
             }
         }
         return hipGetLastError();

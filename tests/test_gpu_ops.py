@@ -117,7 +117,8 @@ def test_attention_online_softmax_rescale_branch(gm):
 
 
 @pytest.mark.parametrize('n0,n1,T,sink', [(64, 64, 20, True), (300, 307, 100, True), (1, 5, 3, True),
-                                          (255, 256, 20, True), (130, 97, 0, False), (1024, 1000, 100, True)])
+                                          (255, 256, 20, True), (130, 97, 0, False), (1024, 1000, 100, True),
+                                          (2400, 2600, 20, True), (3400, 3500, 6, True)])   # 13-chunk fused rows / two-pass fallback
 def test_compute_score_and_matches(gm, n0, n1, T, sink):
     cfg, sd, m, o = gm
     ctx = m._ensure_ctx()
