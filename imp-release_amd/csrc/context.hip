@@ -741,7 +741,7 @@ int imp_attention_received(imp_ctx* c, int which, float* out, void* stream) {
     g.out = c->colsum[which];
     g.kmask = cache.masked[ps.kside] ? c->cmask[ps.kind][ps.kside] : nullptr;
     g.nq = nq; g.nk = nk; g.sq_b = (long)nq * 3 * D; g.sk_b = (long)nk * 3 * D;
-    HIP_TRY(launch_attn_colsum_f32(p, cache.batch, S(stream)));
+    HIP_TRY(launch_attn_colsum(p, cache.batch, c->prec, S(stream)));
     for (int b = 0; b < cache.batch; ++b)
         HIP_TRY(launch_attn_mass_normalize(c->colsum[which] + (size_t)b * IMP_NUM_HEADS * nk, nk, out + (size_t)b * nk,
                                            S(stream)));
@@ -822,7 +822,7 @@ int imp_pool(imp_ctx* c, int n0, int n1, const float* scores, float mscore_th, f
             g.nk = keyside ? n1 : n0;
             g.sq_b = (long)g.nq * 3 * D; g.sk_b = (long)g.nk * 3 * D;
         }
-        HIP_TRY(launch_attn_colsum_f32(p, 1, st));
+        HIP_TRY(launch_attn_colsum(p, 1, c->prec, st));
         for (int keyside = 0; keyside < 2; ++keyside)
             HIP_TRY(launch_attn_mass_normalize(c->colsum[kind * 2 + keyside], keyside ? n1 : n0, c->amass[kind * 2 + keyside], st));
     }

@@ -104,7 +104,7 @@ struct ColsumSide {
     int nq, nk;
 };
 struct ColsumParams { ColsumSide side[2]; int nside, ldq, ldk, dh; };
-hipError_t launch_attn_colsum_f32(const ColsumParams& p, int batch, hipStream_t stream);
+hipError_t launch_attn_colsum(const ColsumParams& p, int batch, int prec, hipStream_t stream);   // prec: GemmParams::prec
 
 // ------------------------------------------------------------------------------------------------
 // keypoint encoder first layer + normalisation

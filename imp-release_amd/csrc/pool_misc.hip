@@ -160,6 +160,127 @@ __global__ __launch_bounds__(256, 2) void attn_colsum_kernel(const ColsumParams 
     }
 }
 
+// Split-precision variant (hi/lo f16 halves, 3 f16 MFMAs per fp32 product - the arithmetic the attention kernels that
+// produced `lse` use): K of the workgroup's 128 keys stays in registers as B-operand fragments, the 64-query tiles are
+// staged through LDS as [hi | lo] rows (A operand, one ds_read_b128 per fragment).  5.3x less matrix-pipe time than the
+// fp32 kernel above; same reduction order (in-lane over the accumulator registers, tiles in ascending order).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_colsum_f16x3_kernel(const ColsumParams p, int ktiles) {
+    constexpr int KROW = DH + 4, KS = DH / 16, F4 = QT * DH / 4, LPT = F4 / 256;
+    __shared__ __attribute__((aligned(16))) float Qs[2][QT][KROW];      // row = [DH hi halves | DH lo halves | pad]
+    __shared__ __attribute__((aligned(16))) float Ls[2][QT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    int id = blockIdx.x;
+    const int kt = id % ktiles; id /= ktiles;
+    const int h = id % IMP_NUM_HEADS; id /= IMP_NUM_HEADS;
+    const int sidx = id % p.nside;
+    const int b = id / p.nside;
+    const ColsumSide& S = p.side[sidx];
+    const int nq = S.nq, nk = S.nk;
+    const int k0 = kt * 128;
+    if (k0 >= nk) return;
+    const float* Qg = S.q + b * S.sq_b + h * DH;
+    const float* Kg = S.k + b * S.sk_b + h * DH;
+    const float* Lg = S.lse + ((long)b * IMP_NUM_HEADS + h) * nq;
+
+    f16x8 kh[KS], kl[KS];                       // lane (key l31, half) holds d = 16 s + 8 half .. + 7 of k-step s
+    {
+        const int krow = k0 + wave * 32 + l31;
+        const float* src = Kg + (long)(krow < nk ? krow : nk - 1) * p.ldk + 8 * half;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(src + 16 * s);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(src + 16 * s + 4);
+            const float x[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+            u32x4 hh, ll;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { unsigned u0, u1; imp_split2(x[2 * i], x[2 * i + 1], u0, u1); hh[i] = u0; ll[i] = u1; }
+            kh[s] = __builtin_bit_cast(f16x8, hh);
+            kl[s] = __builtin_bit_cast(f16x8, ll);
+        }
+    }
+    f32x4 rq[LPT];
+    float rl = 0.f;
+    auto load_tile = [&](int t) {
+        const int q0 = t * QT;
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            const int f = tid + j * 256;
+            const int row = f / (DH / 4), c4 = (f % (DH / 4)) * 4;
+            rq[j] = *reinterpret_cast<const f32x4*>(Qg + (long)min(q0 + row, nq - 1) * p.ldq + c4);   // lse = +inf masks the tail
+        }
+        if (tid < QT) rl = (q0 + tid < nq) ? Lg[q0 + tid] : INFINITY;
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            const int f = tid + j * 256;
+            const int row = f / (DH / 4), c4 = (f % (DH / 4)) * 4;
+            u32x2 hi, lo;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { unsigned u0, u1; imp_split2(rq[j][2 * i], rq[j][2 * i + 1], u0, u1); hi[i] = u0; lo[i] = u1; }
+            *reinterpret_cast<u32x2*>(&Qs[buf][row][c4 >> 1]) = hi;
+            *reinterpret_cast<u32x2*>(&Qs[buf][row][DH / 2 + (c4 >> 1)]) = lo;
+        }
+        if (tid < QT) Ls[buf][tid] = rl;
+    };
+    float colacc = 0.f;
+    const int nt = (nq + QT - 1) / QT;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) load_tile(t + 1);
+        f32x16 sacc[2];
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[jb][r] = 0.f;
+        f16x8 qh[2][KS], ql[2][KS];
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const float* qrow = &Qs[buf][jb * 32 + l31][4 * half + 8 * s];
+                qh[jb][s] = *reinterpret_cast<const f16x8*>(qrow);
+                ql[jb][s] = *reinterpret_cast<const f16x8*>(qrow + DH / 2);
+            }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {          // rows (i) = queries, columns (j = lane) = keys
+            sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[0][s], kh[s], sacc[0], 0, 0, 0);
+            sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ql[1][s], kh[s], sacc[1], 0, 0, 0);
+            sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[0][s], kl[s], sacc[0], 0, 0, 0);
+            sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[1][s], kl[s], sacc[1], 0, 0, 0);
+            sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[0][s], kh[s], sacc[0], 0, 0, 0);
+            sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qh[1][s], kh[s], sacc[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 ls = *reinterpret_cast<const f32x4*>(&Ls[buf][jb * 32 + 8 * g + 4 * half]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float s = DH == 64 ? sacc[jb][4 * g + e] * 0.125f : sacc[jb][4 * g + e] / 5.656854249492381f;
+                    colacc += __builtin_amdgcn_exp2f((s - ls[e]) * LOG2E);
+                }
+            }
+        if (t + 1 < nt) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    colacc += __shfl_xor(colacc, 32);
+    const int key = k0 + wave * 32 + l31;
+    if (half == 0 && key < nk) {
+        if (S.kmask && !S.kmask[(long)b * nk + key]) colacc = 0.f;
+        S.out[((long)b * IMP_NUM_HEADS + h) * nk + key] = colacc;
+    }
+}
+
 // a[key] = (sum_h colsum[h][key]) / sum_key(...)   (nets/adgm.py:557-565), single workgroup, fixed order
 __global__ __launch_bounds__(1024) void mass_normalize_kernel(const float* __restrict__ colsum, int n,
                                                               float* __restrict__ out) {
@@ -315,12 +436,18 @@ hipError_t launch_kenc_first(const Kenc0Side sides[2], int batch, int c0, const 
     return hipGetLastError();
 }
 
-hipError_t launch_attn_colsum_f32(const ColsumParams& p, int batch, hipStream_t stream) {
+hipError_t launch_attn_colsum(const ColsumParams& p, int batch, int prec, hipStream_t stream) {
     int maxk = p.side[0].nk;
     if (p.nside == 2 && p.side[1].nk > maxk) maxk = p.side[1].nk;
     if (maxk <= 0) return hipSuccess;
     const int ktiles = (maxk + 127) / 128;
     const int total = ktiles * IMP_NUM_HEADS * p.nside * batch;
+    if (prec == 1) {        // split-half f16x3 products, like the attention that produced lse
+        if (p.dh == 64) hipLaunchKernelGGL(attn_colsum_f16x3_kernel<64>, dim3(total), dim3(256), 0, stream, p, ktiles);
+        else if (p.dh == 32) hipLaunchKernelGGL(attn_colsum_f16x3_kernel<32>, dim3(total), dim3(256), 0, stream, p, ktiles);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     if (p.dh == 64) hipLaunchKernelGGL(attn_colsum_kernel<64>, dim3(total), dim3(256), 0, stream, p, ktiles);
     else if (p.dh == 32) hipLaunchKernelGGL(attn_colsum_kernel<32>, dim3(total), dim3(256), 0, stream, p, ktiles);
     else return hipErrorInvalidValue;
