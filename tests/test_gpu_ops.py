@@ -298,3 +298,22 @@ def test_sinkhorn_on_the_three_byte_copy(n0, n1, T):
     got4 = ctx4.compute_score(dist.to(DEV), 1.3, T, True)
     j0 = ctx4.compute_matches(got4, 0.2)[0]
     assert torch.equal(j0, i0)
+
+
+@pytest.mark.parametrize('scale,B,nq,nk', [(4.0, 8, 2048, 1024), (6.0, 2, 700, 900), (0.01, 2, 512, 512)])
+def test_attention_extreme_logits(gm, scale, B, nq, nk):
+    """logits with a standard deviation of ~16 / ~36 (every tile moves the softmax reference by far more than the 2^14 lazy
+    window, so the exact-maximum path runs constantly) and nearly flat logits (the reference never moves after tile 0)"""
+    ctx = gm[2]._ensure_ctx()
+    D = 256
+    qq, kv = _rand(B, nq, 3 * D, seed=24), _rand(B, nk, 3 * D, seed=25)
+    qq[..., :D] *= scale
+    kv[..., D:2 * D] *= scale
+    out, lse = ctx.op_attention(qq.to(DEV), kv.to(DEV))
+    ref, ref_lse = _ref_attention(qq, kv, D)
+    e_out = (out.cpu().double() - ref).abs().max().item()
+    e_lse = ((lse.cpu().double() - ref_lse).abs() / ref_lse.abs().clamp(min=1.0)).max().item()
+    assert torch.isfinite(out).all() and torch.isfinite(lse).all()
+    # the logits themselves carry an absolute fp32 error ~ |S| * 1e-6, which the exponential turns into a relative one
+    assert e_out < 3e-5 * max(1.0, scale * scale), f'attention out err {e_out:.3e}'
+    assert e_lse < 2e-5, f'attention lse rel err {e_lse:.3e}'
