@@ -335,6 +335,32 @@ def test_batch_steps_in_flight_reproduce_the_sequential_results():
     assert not torch.equal(seq[0][0], seq[1][0])          # the steps really see different batches
 
 
+def test_prefetched_dataset_feeds_the_loop_identically(tmp_path):
+    """pairs read from the npz mirror of the reference's dump layout, staged in pinned memory and uploaded on the
+    prefetcher's stream, must give the loop the same results as tensors placed on the device directly"""
+    from imp_release_amd import data as pdata
+    recs = []
+    for i in range(4):
+        p = synthetic.make_correlated_pair(640 + 16 * i, 600, seed=90 + i)
+        recs.append({'K1': np.eye(3), 'K2': np.eye(3), 'R': np.eye(3), 'T': np.array([1., 2., 2.]), 'e': np.zeros((3, 3)),
+                     'f': np.zeros((3, 3)), 'kpt1': np.concatenate([p['keypoints0'][0], p['scores0'][0][:, None]], 1),
+                     'kpt2': np.concatenate([p['keypoints1'][0], p['scores1'][0][:, None]], 1),
+                     'desc1': p['descriptors0'][0], 'desc2': p['descriptors1'][0], 'size1': (480, 640), 'size2': (480, 640)})
+    pdata.write_npz_store(recs, str(tmp_path))
+    store = pdata.NpzPairStore(str(tmp_path))
+    cfg = eval_config()
+    sd = synthetic.make_state_dict(cfg, 'AdaGMN', seed=9, bin_score=5.0)
+    m = make_hip_model('AdaGMN', cfg, sd)
+    direct = []
+    with torch.no_grad():
+        for i in range(4):
+            d = pdata.feed_data(store.record(i), DEV)
+            direct.append(hip_matching.matching_iterative_uncertainty(d, m, 15, 0.1, 25, 1.0, {'pose': 1.5}))
+        for i, d in enumerate(pdata.PinnedPrefetcher(store, range(4), DEV, depth=2)):
+            out = hip_matching.matching_iterative_uncertainty(d, m, 15, 0.1, 25, 1.0, {'pose': 1.5})
+            assert np.array_equal(out[4], direct[i][4]) and np.array_equal(out[5], direct[i][5]) and out[0].shape == direct[i][0].shape
+
+
 def test_eval_loop_pairs_in_flight_give_identical_rows():
     """workers=K (K model replicas, K streams, K host threads) must reproduce the sequential table bit for bit; the
     injected pose step sleeps like a host-side solver so that the overlap is observable"""

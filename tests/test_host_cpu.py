@@ -209,3 +209,42 @@ def test_step_pipeline_orders_results_and_surfaces_errors():
         raise RuntimeError('step failed')
     with pytest.raises(RuntimeError, match='step failed'):
         pipeline.StepPipeline([boom, boom], 2).run(4)
+
+
+def _toy_records(n, seed=0):
+    from imp_release_amd import synthetic
+    recs = []
+    for i in range(n):
+        p = synthetic.make_correlated_pair(60 + 7 * i, 50 + 3 * i, seed=seed + i)
+        recs.append({'K1': np.eye(3) * (1 + i), 'K2': np.eye(3) * 2, 'R': np.eye(3), 'T': np.array([3., 0., 4.]) * (i + 1),
+                     'e': np.full((3, 3), float(i)), 'f': np.zeros((3, 3)),
+                     'kpt1': np.concatenate([p['keypoints0'][0], p['scores0'][0][:, None]], 1),
+                     'kpt2': np.concatenate([p['keypoints1'][0], p['scores1'][0][:, None]], 1),
+                     'desc1': p['descriptors0'][0], 'desc2': p['descriptors1'][0], 'size1': (480, 640), 'size2': (360, 500)})
+    return recs
+
+
+def test_pair_store_roundtrip_and_feed_dict(tmp_path):
+    """reference dump layout (components/readers.py:8-33) through the npz mirror: fields, num_kpt cut, t normalised, and
+    the feed dict of eval/eval_imp.py:50-80 (HWC image shape kept: the loops read shape[2:4] = (W, 3))"""
+    from imp_release_amd import data
+    recs = _toy_records(4)
+    assert data.write_npz_store(recs, str(tmp_path)) == 4
+    store = data.NpzPairStore(str(tmp_path), num_kpt=55)
+    assert len(store) == 4
+    r = store.record(2)
+    assert r['x1'].shape == (55, 3) and r['desc1'].shape == (55, 256) and r['x2'].shape == (55, 3)
+    assert np.allclose(r['t'], [0.6, 0.0, 0.8]) and np.array_equal(r['K1'], np.eye(3) * 3) and r['index'] == 2
+    assert np.array_equal(r['x1'], recs[2]['kpt1'][:55]) and np.array_equal(r['desc2'], recs[2]['desc2'][:55])
+    d = data.feed_data(r, 'cpu')
+    assert tuple(d['keypoints0'].shape) == (1, 55, 2) and tuple(d['scores1'].shape) == (1, 55)
+    assert torch.equal(d['scores0'][0], torch.from_numpy(recs[2]['kpt1'][:55, 2].astype(np.float32)))
+    assert tuple(d['image0'].shape) == (1, 480, 640, 3) and tuple(d['image1'].shape) == (1, 360, 500, 3)
+    assert d['T_0to1'].shape == (3, 4) and np.array_equal(d['pts1_cpu'], recs[2]['kpt2'][:55, :2])
+    got = [x['index'] for x in data.PinnedPrefetcher(store, [3, 0, 2], 'cpu', depth=2)]
+    assert got == [3, 0, 2]
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match='h5py'):
+            data.H5PairStore(str(tmp_path / 'x.hdf5'))
