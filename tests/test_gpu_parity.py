@@ -238,6 +238,23 @@ def test_bench_batch_of_four_takes_the_pingpong_attention_path():
                           ref['mscores0'][-1].numpy(), 0.2, TOL, 'N=2048 L=9 T=100 B=4 pair 0 vs oracle'))
 
 
+@pytest.mark.parametrize('seed', [101, 102, 103, 104])
+def test_full_size_more_pairs_vs_oracle(seed):
+    """the BASELINE workload (N=2048, L=9, T=100) on further seeded pairs, ragged second image: indices identical,
+    scores within 1e-4 of the oracle"""
+    cfg = eval_config(n_layers=9, sinkhorn_iterations=100)
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=seed)
+    m = make_hip_model('GM', cfg, sd)
+    pair = synthetic.make_correlated_pair(2048, 2048 - 3 * (seed % 7), seed=seed)
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+    with torch.no_grad():
+        out = m.produce_matches(data, p=0.2, only_last=True)
+        ref = orc.MatcherOracle(cfg, sd, 'GM').produce_matches({k: v.cpu() for k, v in data.items()}, p=0.2, only_last=True)
+    print(compare_matches(_cpu(out['indices0'][-1]), _cpu(out['mscores0'][-1]), ref['indices0'][-1].numpy(),
+                          ref['mscores0'][-1].numpy(), 0.2, TOL, f'N=2048 seed {seed}'))
+
+
 def test_eimp_pruning_path_at_4096():
     """BASELINE config 4 size: N = 4096 start, sliced EIMP loop, pruning must happen and stay consistent."""
     cfg = eval_config()
