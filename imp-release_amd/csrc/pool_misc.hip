@@ -334,15 +334,28 @@ __device__ float radix_select(const float* __restrict__ vals, const unsigned cha
             }
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned acc = 0;
-            int bin = 0;
-            for (; bin < 256; ++bin) {
-                if (acc + hist[bin] > (unsigned)kk) break;
-                acc += hist[bin];
+        if (tid < 64) {
+            // first bin whose cumulative count exceeds kk, found by one wave: lane l owns bins 4l..4l+3, a shuffle scan
+            // gives the counts before each lane (a single thread walking 256 LDS words cost ~10 us per pass)
+            const unsigned c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+            unsigned incl = c0 + c1 + c2 + c3;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned up = __shfl_up(incl, o);
+                if (tid >= o) incl += up;
             }
-            sh[0] = (unsigned)bin;
-            sh[1] = acc;
+            const unsigned long long over = __ballot(incl > (unsigned)kk);      // non-empty: the total exceeds kk
+            const int owner = __ffsll((long long)over) - 1;
+            if (tid == owner) {
+                unsigned acc = incl - (c0 + c1 + c2 + c3);
+                int bin = 4 * tid;
+                if (acc + c0 > (unsigned)kk) { }
+                else if (acc + c0 + c1 > (unsigned)kk) { acc += c0; bin += 1; }
+                else if (acc + c0 + c1 + c2 > (unsigned)kk) { acc += c0 + c1; bin += 2; }
+                else { acc += c0 + c1 + c2; bin += 3; }
+                sh[0] = (unsigned)bin;
+                sh[1] = acc;
+            }
         }
         __syncthreads();
         prefix |= sh[0] << shift;
