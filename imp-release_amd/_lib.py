@@ -271,18 +271,27 @@ class Context:
                                                _ptr(m0), _ptr(m1), _stream(self.device)))
         return i0, i1, m0, m1
 
-    def pool(self, scores, mscore_th, uncertainty_ratio, n_min_tokens):
-        """-> (ids0 | None, ids1 | None); ONE host sync to read the two kept counts (shapes change)."""
+    def pool(self, scores, mscore_th, uncertainty_ratio, n_min_tokens, return_host=False):
+        """-> (ids0 | None, ids1 | None); ONE host sync: the kept counts AND the id lists come back in a single copy
+        (shapes change, and the loop needs the ids on the host anyway to slice its CPU keypoints).
+        ``return_host``: additionally return the two id lists as numpy arrays."""
         scores = _f32(scores, 'scores')
         n0, n1 = scores.shape[1] - 1, scores.shape[2] - 1
         dev = scores.device
-        ids0 = torch.empty(n0, device=dev, dtype=torch.int64)
-        ids1 = torch.empty(n1, device=dev, dtype=torch.int64)
-        counts = torch.empty(4, device=dev, dtype=torch.int32)
+        buf = torch.empty(n0 + n1 + 2, device=dev, dtype=torch.int64)          # ids0 | ids1 | 4 int32 counts
+        ids0, ids1 = buf[:n0], buf[n0:n0 + n1]
+        counts = buf[n0 + n1:].view(torch.int32)
         self._check(self.L.imp_pool(self.handle, n0, n1, _ptr(scores), float(mscore_th), float(uncertainty_ratio),
                                     int(n_min_tokens), _ptr(ids0), _ptr(ids1), _ptr(counts), _stream(self.device)))
-        c = counts.tolist()
-        return (ids0[:c[0]] if c[0] >= 0 else None), (ids1[:c[2]] if c[2] >= 0 else None)
+        host = buf.cpu()
+        c = host[n0 + n1:].view(torch.int32).tolist()
+        r0 = ids0[:c[0]] if c[0] >= 0 else None
+        r1 = ids1[:c[2]] if c[2] >= 0 else None
+        if not return_host:
+            return r0, r1
+        h0 = host[:c[0]].numpy() if c[0] >= 0 else None
+        h1 = host[n0:n0 + c[2]].numpy() if c[2] >= 0 else None
+        return r0, r1, h0, h1
 
     def score_mass(self, scores):
         scores = _f32(scores, 'scores')

@@ -31,9 +31,10 @@ def pack_matches(indices0: torch.Tensor, mscores0: torch.Tensor) -> torch.Tensor
 
 def unpack_matches(buf: torch.Tensor, n: int):
     b = buf.shape[0]
-    idx = buf[:, :n * 8].contiguous().view(torch.int64).reshape(b, n)
-    ms = buf[:, n * 8:].contiguous().view(torch.float32).reshape(b, n)
-    return idx, ms
+    # fresh buffers with row pitches n*8 / n*4 (a one-row slice keeps the 12n pitch of `buf`, which need not be 8-aligned)
+    a = torch.empty((b, n * 8), dtype=torch.uint8, device=buf.device).copy_(buf[:, :n * 8])
+    m = torch.empty((b, n * 4), dtype=torch.uint8, device=buf.device).copy_(buf[:, n * 8:])
+    return a.view(torch.int64).reshape(b, n), m.view(torch.float32).reshape(b, n)
 
 
 def all_gather_matches(indices0: torch.Tensor, mscores0: torch.Tensor, n_total: int, group=None):

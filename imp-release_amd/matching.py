@@ -20,6 +20,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from .dist import pack_matches, unpack_matches
 from .modules import VALID_ITS, _token_major
 
 
@@ -55,18 +56,19 @@ def _loop(data, model, nI, match_ratio, min_kpts, error_th, stop_criteria, metho
                                         data['descriptors0'], data['descriptors1'])
     last_best_R = last_best_t = None
     sel_ids0 = sel_ids1 = None
+    sel_host0 = sel_host1 = None
     pred_score = None
     for it in range(nI):
         if uncertainty:
             if sel_ids0 is not None:                                              # eval/matching.py:166-169
                 desc0 = ctx.gather_rows(desc0, sel_ids0)
-                pts0_cpu = pts0_cpu[sel_ids0.cpu().numpy()]
+                pts0_cpu = pts0_cpu[sel_host0 if sel_host0 is not None else sel_ids0.cpu().numpy()]
                 norm_kpts0 = norm_kpts0[:, sel_ids0, :]
             if sel_ids1 is not None:                                              # eval/matching.py:171-174
                 desc1 = ctx.gather_rows(desc1, sel_ids1)
-                pts1_cpu = pts1_cpu[sel_ids1.cpu().numpy()]
+                pts1_cpu = pts1_cpu[sel_host1 if sel_host1 is not None else sel_ids1.cpu().numpy()]
                 norm_kpts1 = norm_kpts1[:, sel_ids1, :]
-            sel_ids0 = sel_ids1 = None
+            sel_ids0 = sel_ids1 = sel_host0 = sel_host1 = None
         B, n0, n1 = desc0.shape[0], desc0.shape[1], desc1.shape[1]
         for li in (2 * it, 2 * it + 1):
             desc0, desc1 = ctx.forward_layer(li, desc0, desc1, inplace=True)
@@ -76,8 +78,10 @@ def _loop(data, model, nI, match_ratio, min_kpts, error_th, stop_criteria, metho
         dist = ctx.compute_distance(it, desc0, desc1)
         pred_score = ctx.compute_score(dist, model._bin(None), model.sinkhorn_iterations, model.with_sinkhorn)
         indices0, indices1, mscores0, mscores1 = ctx.compute_matches(pred_score, match_ratio)
-        indices0_cpu = indices0[0].cpu().numpy()            # the one sync of this iteration
-        mscores0_cpu = mscores0[0].cpu().numpy()
+        # the one sync of this iteration: indices and scores of image 0 in a single device->host copy
+        packed = pack_matches(indices0[:1], mscores0[:1]).cpu()
+        idx_h, ms_h = unpack_matches(packed, n0)
+        indices0_cpu, mscores0_cpu = idx_h[0].numpy(), ms_h[0].numpy()
         if trace is not None:
             trace.append({'it': it, 'n0': n0, 'n1': n1, 'indices0': indices0_cpu.copy(), 'mscores0': mscores0_cpu.copy(),
                           'pts0': pts0_cpu.copy(), 'pts1': pts1_cpu.copy()})
@@ -109,9 +113,13 @@ def _loop(data, model, nI, match_ratio, min_kpts, error_th, stop_criteria, metho
         last_best_R, last_best_t = R, t
         if uncertainty:                                                           # eval/matching.py:243-257
             mscore_th = 0.2 * inlier_ratio if (with_uncertainty and inlier_ratio != 0) else 0.2
-            sel_ids0, sel_ids1 = model.pool(pred_score=pred_score, prob00=model.self_prob0, prob01=model.cross_prob0,
-                                            prob11=model.self_prob1, prob10=model.cross_prob1, mscore_th=mscore_th,
-                                            uncertainty_ratio=1.0)
+            if hasattr(model, 'pool_host'):      # ids on the host from the same copy as the counts (no extra syncs)
+                sel_ids0, sel_ids1, sel_host0, sel_host1 = model.pool_host(pred_score, mscore_th=mscore_th,
+                                                                           uncertainty_ratio=1.0)
+            else:
+                sel_ids0, sel_ids1 = model.pool(pred_score=pred_score, prob00=model.self_prob0, prob01=model.cross_prob0,
+                                                prob11=model.self_prob1, prob10=model.cross_prob1, mscore_th=mscore_th,
+                                                uncertainty_ratio=1.0)
         if 'pose' in stop_criteria.keys() and pose_diff <= stop_criteria['pose']:  # eval/matching.py:110-117
             output_indice0 = np.zeros_like(indices0_cpu) - 1
             output_indice0[pred_matches[pose_inliers, 0]] = pred_matches[pose_inliers, 1]

@@ -386,6 +386,11 @@ class AdaGMN(GM):
                 raise TypeError(f'{name}: expected the current model.self_prob*/cross_prob* handle of this model')
         return self._ensure_ctx().pool(pred_score, mscore_th, uncertainty_ratio, n_min_tokens)
 
+    def pool_host(self, pred_score, mscore_th=0.1, uncertainty_ratio=1.0, n_min_tokens=256):
+        """pool() of the current cached attention + the kept id lists as numpy arrays from the same device->host copy
+        (imp_release_amd.matching uses them to slice its CPU keypoints without further synchronisations)"""
+        return self._ensure_ctx().pool(pred_score, mscore_th, uncertainty_ratio, n_min_tokens, return_host=True)
+
     def produce_matches(self, data, p=0.2, mscore_th=0.1, uncertainty_ratio=1., **kwargs):
         """nets/adgm.py:327-526: *masked* adaptive pooling (tensors keep their size; pruned keypoints are
         masked out as attention keys and excluded from scoring)."""
