@@ -99,6 +99,14 @@ def test_pack_roundtrip():
     m = torch.rand(3, 17)
     a, b = pdist.unpack_matches(pdist.pack_matches(i, m), 17)
     assert torch.equal(a, i) and torch.equal(b, m)
+    # one-row slices and odd keypoint counts (a [1, 12n] row keeps the 12n pitch, which is not 8-byte aligned for odd n)
+    for n in (1, 33, 775):
+        i = torch.randint(-1, 4096, (3, n), dtype=torch.int64)
+        m = torch.rand(3, n)
+        p = pdist.pack_matches(i, m)
+        for r in range(3):
+            a, b = pdist.unpack_matches(p[r:r + 1], n)
+            assert torch.equal(a, i[r:r + 1]) and torch.equal(b, m[r:r + 1])
 
 
 def test_metrics_tail_vs_reference_golden():
