@@ -69,6 +69,7 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 
 // ---- init: dustbin augmentation (nets/layers.py:39-40) + row softmax (nets/layers.py:28) -------------
 // one wave per augmented row; dual != 0 keeps the augmented logits instead (dual_softmax needs them)
+template <int NV>     // NV > 0: ceil(ldp / 64) columns per lane held in registers; 0: streaming form (any row length)
 __global__ __launch_bounds__(256) void ot_init_kernel(const float* __restrict__ dist, int n0, int n1, float bin,
                                                       int dual, float* __restrict__ P, int ldp,
                                                       float* __restrict__ u, float* __restrict__ v, int ldpt,
@@ -89,6 +90,32 @@ __global__ __launch_bounds__(256) void ot_init_kernel(const float* __restrict__ 
     }
     if (dual) {
         for (int j = lane; j < ldp; j += 64) prow[j] = j > n1 ? 0.f : ((last || j == n1) ? bin : drow[j]);
+        return;
+    }
+    if (NV > 0 && P24 == nullptr) {
+        // the row lives in registers (lane owns columns lane, lane + 64, ...): one read of dist, one exp per element;
+        // same values and the same summation order as the streaming form below
+        float x[NV > 0 ? NV : 1];
+        float mx = bin;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int j = lane + 64 * k;
+            x[k] = j > n1 ? -INFINITY : ((last || j == n1) ? bin : drow[j]);
+            if (j < n1 && !last) mx = fmaxf(mx, x[k]);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            x[k] = expf(x[k] - mx);             // exp(-inf) = 0 for the padded tail
+            if (lane + 64 * k <= n1) sum += x[k];
+        }
+        sum = wave_sum(sum);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int j = lane + 64 * k;
+            if (j < ldp) prow[j] = j > n1 ? 0.f : x[k] / sum;
+        }
         return;
     }
     float mx = bin;
@@ -524,8 +551,16 @@ __global__ __launch_bounds__(256) void colsum_combine_kernel(const float* __rest
 hipError_t launch_ot_init(const float* dist, int batch, int n0, int n1, float bin_score, int dual,
                           const OtBuffers& ot, hipStream_t stream) {
     const bool compact = ot.compact && ot.P24 && !dual && ot.partials && ot.v2 && ot.ldp <= FP_MAX_LD;   // fused-path launches only
-    hipLaunchKernelGGL(ot_init_kernel, dim3((n0 + 1 + 3) / 4, batch), dim3(256), 0, stream, dist, n0, n1, bin_score,
-                       dual, ot.P, ot.ldp, ot.u, ot.v, ot.ldpt, ot.v2, compact ? ot.P24 : (unsigned*)nullptr);
+    unsigned* p24 = compact ? ot.P24 : (unsigned*)nullptr;
+    const dim3 grid((n0 + 1 + 3) / 4, batch);
+#define IMP_OT_INIT(NV) hipLaunchKernelGGL(ot_init_kernel<NV>, grid, dim3(256), 0, stream, dist, n0, n1, bin_score, dual, \
+                                           ot.P, ot.ldp, ot.u, ot.v, ot.ldpt, ot.v2, p24)
+    if (dual || compact || ot.ldp > 3328) IMP_OT_INIT(0);
+    else if (ot.ldp <= 512) IMP_OT_INIT(8);
+    else if (ot.ldp <= 1280) IMP_OT_INIT(20);
+    else if (ot.ldp <= 2304) IMP_OT_INIT(36);
+    else IMP_OT_INIT(52);
+#undef IMP_OT_INIT
     hipLaunchKernelGGL(ot_transpose_kernel, dim3((n1 + 1 + 31) / 32, (ot.ldpt + 31) / 32, batch), dim3(256), 0, stream,
                        ot.P, n0 + 1, n1 + 1, ot.ldp, ot.PT, ot.ldpt);
     return hipGetLastError();
