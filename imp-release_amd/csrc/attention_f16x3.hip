@@ -356,12 +356,13 @@ __device__ unsigned long long pp_prof[8][8];
 
 template <int DH>
 __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams p, int qtiles, int total_blocks) {
-    static_assert(DH == 64, "ping-pong attention is instantiated for 64-channel heads");
+    static_assert(DH == 64 || DH == 32, "head widths of the reference: 256 / 4 and 128 / 4 channels");
     constexpr int NT = 512;
     constexpr int KROW = DH + 4;                 // K row: 32 floats of hi halves, 32 of lo halves, 4 pad
     constexpr int VROW = DH + 16;                // V row: same split, padded to 320 B (conflict-free transpose reads)
     constexpr int DT = DH / 32, KS = DH / 16;
-    constexpr float SL2E = 0.125f * LOG2E;       // 1/sqrt(64) * log2(e)
+    constexpr float SL2E = (DH == 64 ? 0.125f : 0.17677669529663687f) * LOG2E;       // 1/sqrt(DH) * log2(e)
+    constexpr int LK = KT * DH / 4 / NT;         // float4 of K (and of V) per thread and tile: 2 / 1
     constexpr float P_SUM_LIMIT = 16384.f;       // per-lane partial row sum that forces a reference update
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;                           // [4][KT][KROW]
@@ -405,25 +406,25 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kg, 0, kv_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vg, 0, kv_bytes, 0x00020000);
     const int row_bytes = p.ldk * 4;
-    int koff[2];
+    int koff[LK];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < LK; ++j) {
         const int f = tid + j * NT;
         koff[j] = (f / (DH / 4)) * row_bytes + (f % (DH / 4)) * 16;
     }
-    f32x4 rkA[2], rkB[2];                          // two staged tiles in flight (even / odd tile index)
-    f32x4 rvA[2], rvB[2];
+    f32x4 rkA[LK], rkB[LK];                        // two staged tiles in flight (even / odd tile index)
+    f32x4 rvA[LK], rvB[LK];
     unsigned char rbA = 1, rbB = 1;
-    auto load_tile = [&](int t, f32x4 (&rk)[2], f32x4 (&rv)[2], unsigned char& rb) {
+    auto load_tile = [&](int t, f32x4 (&rk)[LK], f32x4 (&rv)[LK], unsigned char& rb) {
         const int k0 = t * KT;
         const int soff = k0 * row_bytes;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < LK; ++j) {
             const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsK, koff[j], soff, 0);
             rk[j] = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < LK; ++j) {
             const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsV, koff[j], soff, 0);
             rv[j] = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
         }
@@ -434,11 +435,11 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
             rb = keep;
         }
     };
-    auto store_tile = [&](int slot, const f32x4 (&rk)[2], const f32x4 (&rv)[2], const unsigned char rb) {
+    auto store_tile = [&](int slot, const f32x4 (&rk)[LK], const f32x4 (&rv)[LK], const unsigned char rb) {
         float* ks = Ks + slot * KT * KROW;
         float* vs = Vs + slot * KT * VROW;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < LK; ++j) {
             const int f = tid + j * NT;
             const int row = f / (DH / 4), c4 = (f % (DH / 4)) * 4;
             u32x2 hi, lo;
@@ -484,11 +485,11 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     // operands of step i+1 are read into the other half of a register double buffer before the MFMAs of step i are
     // issued; sched_barrier(0) pins that order.
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    auto read_v = [&](int slot, int g, f16x8 (&f)[4]) {            // f = {vh[0], vh[1], vl[0], vl[1]} of k-step g
+    auto read_v = [&](int slot, int g, f16x8 (&f)[4]) {            // f = {vh[0..DT), vl[0..DT)} of k-step g
         const char* vs = reinterpret_cast<const char*>(Vs + slot * KT * VROW) + vlane + (16 * g) * (VROW * 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const char* a = vs + (i & 1) * 64 + (i >> 1) * (DH * 2);
+        for (int i = 0; i < 2 * DT; ++i) {
+            const char* a = vs + (i % DT) * 64 + (i / DT) * (DH * 2);
             const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
             const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 8 * VROW * 4));
             f[i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -503,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     auto mfma_v = [&](int g, const f16x8 (&f)[4]) {
         const int jb = g >> 1, s2 = g & 1;
 #pragma unroll
-        for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[2 + d], ph[jb][s2], oacc[d], 0, 0, 0);
+        for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[DT + d], ph[jb][s2], oacc[d], 0, 0, 0);
 #pragma unroll
         for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[d], pl[jb][s2], oacc[d], 0, 0, 0);
 #pragma unroll
@@ -571,7 +572,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_readcyclecounter();
 #endif
-    auto tile_step = [&](int t, f32x4 (&rk)[2], f32x4 (&rv)[2], unsigned char& rb, f32x4 (&rk2)[2], f32x4 (&rv2)[2], unsigned char& rb2) {
+    auto tile_step = [&](int t, f32x4 (&rk)[LK], f32x4 (&rv)[LK], unsigned char& rb, f32x4 (&rk2)[LK], f32x4 (&rv2)[LK], unsigned char& rb2) {
         PP_CLK(7);
         // =============================== X(t): matrix phase ===============================================
         __builtin_amdgcn_s_setprio(1);
@@ -663,25 +664,35 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     }
     __syncthreads();
     float* Og = S.out + b * S.so_b + h * DH;
+    if (DH == 64) {
 #pragma unroll 4
-    for (int i = 0; i < 32; ++i) {
-        const int qrow = q0 + wave * 32 + i;
-        if (qrow < nq) Og[(long)qrow * p.ldo + lane] = ot[i * LDO + lane];
+        for (int i = 0; i < 32; ++i) {
+            const int qrow = q0 + wave * 32 + i;
+            if (qrow < nq) Og[(long)qrow * p.ldo + lane] = ot[i * LDO + lane];
+        }
+    } else {
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {          // two query rows per pass: lanes 0-31 / 32-63
+            const int qi = 2 * i + half;
+            const int qrow = q0 + wave * 32 + qi;
+            if (qrow < nq) Og[(long)qrow * p.ldo + l31] = ot[qi * LDO + l31];
+        }
     }
 }
 
+template <int DH>
 hipError_t launch_pp(const AttnParams& p, int batch, int maxq, hipStream_t stream) {
     const int qtiles = (maxq + 255) / 256;
     const int total = qtiles * IMP_NUM_HEADS * p.nside * batch;
-    const size_t lds = (size_t)(4 * KT * (64 + 4) + 4 * KT * (64 + 16) + 4 * KT) * sizeof(float);
+    const size_t lds = (size_t)(4 * KT * (DH + 4) + 4 * KT * (DH + 16) + 4 * KT) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_f16x3_pp_kernel<64>,
+        hipError_t e = hipFuncSetAttribute((const void*)attn_f16x3_pp_kernel<DH>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((attn_f16x3_pp_kernel<64>), dim3(total), dim3(512), lds, stream, p, qtiles, total);
+    hipLaunchKernelGGL((attn_f16x3_pp_kernel<DH>), dim3(total), dim3(512), lds, stream, p, qtiles, total);
     return hipGetLastError();
 }
 
@@ -707,19 +718,19 @@ hipError_t launch_attention_f16x3(const AttnParams& p, int batch, hipStream_t st
     int maxq = p.side[0].nq;
     if (p.nside == 2 && p.side[1].nq > maxq) maxq = p.side[1].nq;
     if (maxq <= 0 || batch <= 0) return hipSuccess;
+    if (p.dh != 64 && p.dh != 32) return hipErrorInvalidValue;
     const long wg4 = (long)((maxq + 127) / 128) * IMP_NUM_HEADS * p.nside * batch;
     const bool big = wg4 >= 256;
     // 8-wave workgroups (256 queries) when that still gives >= 1 workgroup per CU: every K/V tile is staged and split
     // once per 256 queries instead of once per 128 (measured 127 -> 114 us at N=2048, B=4)
     // IMP_ATTN_VARIANT (A/B runs): 1 = lock-step 8-wave kernel instead of the ping-pong one, 2 = ping-pong at any grid size
     static const int variant = [] { const char* e = getenv("IMP_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
-    if (p.dh == 64 && variant == 2) return launch_pp(p, batch, maxq, stream);
-    // 64-channel heads: the phase-staggered 256-query kernel whenever a workgroup's queries are mostly real (measured equal
-    // or faster than the lock-step kernels at every grid size from 32 to 512 workgroups: 78 vs 101 us at B=3, N=2048)
-    if (p.dh == 64 && maxq > 192) {
-        if (variant == 1) return launch_one<64, 8>(p, batch, maxq, stream);
-        return launch_pp(p, batch, maxq, stream);
-    }
+    if (variant == 2) return p.dh == 64 ? launch_pp<64>(p, batch, maxq, stream) : launch_pp<32>(p, batch, maxq, stream);
+    // the phase-staggered 256-query kernel whenever a workgroup's queries are mostly real (measured equal or faster than the
+    // lock-step kernels at every grid size from 32 to 512 workgroups: 78 vs 101 us at B=3, N=2048)
+    if (maxq > 192 && variant != 1)
+        return p.dh == 64 ? launch_pp<64>(p, batch, maxq, stream) : launch_pp<32>(p, batch, maxq, stream);
+    if (p.dh == 64 && maxq > 192) return launch_one<64, 8>(p, batch, maxq, stream);
     if (p.dh == 64) return big ? launch_one<64, 4>(p, batch, maxq, stream) : launch_one<64, 2>(p, batch, maxq, stream);
     if (p.dh == 32) return big ? launch_one<32, 4>(p, batch, maxq, stream) : launch_one<32, 2>(p, batch, maxq, stream);
     return hipErrorInvalidValue;

@@ -62,7 +62,8 @@ def _ref_attention(qkv_q, qkv_kv, D, mask=None):
 @pytest.mark.parametrize('B,nq,nk,D,masked', [(1, 128, 128, 256, False), (2, 300, 307, 256, False),
                                               (1, 64, 2048, 256, False), (4, 1024, 1024, 256, False),
                                               (1, 200, 190, 128, False), (2, 257, 131, 256, True),
-                                              (1, 33, 65, 128, True)])
+                                              (1, 33, 65, 128, True), (4, 1500, 1300, 128, True),
+                                              (2, 2048, 2048, 128, False)])      # 32-channel heads, ping-pong kernel
 def test_attention_fp32_mfma(gm, B, nq, nk, D, masked):
     ctx = gm[2]._ensure_ctx()
     qq, kv = _rand(B, nq, 3 * D, seed=4), _rand(B, nk, 3 * D, seed=5)
