@@ -721,9 +721,8 @@ hipError_t launch_attention_f16x3(const AttnParams& p, int batch, hipStream_t st
     if (p.dh != 64 && p.dh != 32) return hipErrorInvalidValue;
     const long wg4 = (long)((maxq + 127) / 128) * IMP_NUM_HEADS * p.nside * batch;
     const bool big = wg4 >= 256;
-    // 8-wave workgroups (256 queries) when that still gives >= 1 workgroup per CU: every K/V tile is staged and split
-    // once per 256 queries instead of once per 128 (measured 127 -> 114 us at N=2048, B=4)
-    // IMP_ATTN_VARIANT (A/B runs): 1 = lock-step 8-wave kernel instead of the ping-pong one, 2 = ping-pong at any grid size
+    // IMP_ATTN_VARIANT (A/B runs): 1 = lock-step kernels only (the 8-wave, 256-query one for 64-channel heads: each K/V tile
+    // staged and split once per 256 queries, 127 -> 114 us over the 4-wave kernel), 2 = ping-pong at any size
     static const int variant = [] { const char* e = getenv("IMP_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
     if (variant == 2) return p.dh == 64 ? launch_pp<64>(p, batch, maxq, stream) : launch_pp<32>(p, batch, maxq, stream);
     // the phase-staggered 256-query kernel whenever a workgroup's queries are mostly real (measured equal or faster than the
