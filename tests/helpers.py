@@ -57,7 +57,7 @@ def make_hip_model(spec_or_model, cfg, sd, device='cuda', precision=None):
     return m.to(device)
 
 
-def compare_matches(i_got, ms_got, i_ref, ms_ref, p, tol=1e-4, what=''):
+def compare_matches(i_got, ms_got, i_ref, ms_ref, p, tol=1e-4, what='', low_score_flips=0):
     """The parity bar: match indices identical, scores within `tol` (north star: 1e-4).
     A differing index is tolerated ONLY when the reference decision itself is within `tol` of flipping
     (|mscore - p| < tol at that keypoint, i.e. an fp32 summation-order tie), and is reported."""
@@ -76,6 +76,11 @@ def compare_matches(i_got, ms_got, i_ref, ms_ref, p, tol=1e-4, what=''):
     assert n_bad == 0, msg
     # score tolerance applies where both agree on mutuality (a mutual flip changes mscore to/from 0)
     agree = (ms_got > 0) == (ms_ref > 0)
-    assert (~agree).sum() <= excused + 0, msg + f' mutual-disagreements={(~agree).sum()}'
+    # `low_score_flips` (soak only): a mutual-nearest-neighbour flip on a keypoint that is UNMATCHED on both sides (its score
+    # is below p either way; the argmax among near-equal tiny scores is fp32 summation-order noise) changes mscore between 0
+    # and that small score - tolerated up to the given count, reported in the message
+    low = (~agree) & (np.maximum(ms_got, ms_ref) < p) & (i_got == i_ref)
+    msg += f' mutual-disagreements={(~agree).sum()} (unmatched low-score flips {low.sum()})'
+    assert (~agree).sum() <= excused + min(int(low.sum()), low_score_flips), msg
     assert dms[agree].max(initial=0.0) <= tol, msg
     return msg
