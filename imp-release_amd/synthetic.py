@@ -146,3 +146,33 @@ def make_correlated_pair(n0: int, n1: int, desc_dim: int = 256, seed: int = 0, b
         out['keypoints1'][b, dst] = sh
         out['scores1'][b, dst] = np.clip(out['scores0'][b, src] + 0.05 * g.standard_normal(size=k), 0.01, 0.99).astype(np.float32)
     return out
+
+
+class PoseStub:
+    """Deterministic stand-in for ``eval/pose_estimation.py:92-115 estimate_pose`` (cv2 MAGSAC is absent here) with the
+    reference's keyword signature, so that the SAME object can drive the imported reference loop, the oracle loop and
+    the HIP loop through ``eval/matching.py:84-117`` (pose-change test, early exit with inlier-filtered indices) and
+    ``:243-252`` (``with_uncertainty``: ``mscore_th = 0.2 * inlier_ratio``).
+
+    Call k returns ``None`` when ``schedule[k] is None``; otherwise ``(E, R, t, inliers)`` with R = rotation by
+    ``schedule[k]`` degrees about z, t = R @ [1, 0, 0] and an inlier mask that is a pure function of the matched
+    coordinates (so it is identical for any implementation that passes the same matches).  After the schedule is
+    exhausted the last entry repeats."""
+
+    def __init__(self, schedule, keep_mod=10, keep_below=8):
+        self.schedule, self.keep_mod, self.keep_below = list(schedule), keep_mod, keep_below
+        self.calls = []
+
+    def __call__(self, kpts0, kpts1, K0=None, K1=None, norm_thresh=1.0, method=None, **kw):
+        k = len(self.calls)
+        ang = self.schedule[min(k, len(self.schedule) - 1)]
+        kpts0, kpts1 = np.asarray(kpts0), np.asarray(kpts1)
+        self.calls.append((kpts0.shape[0], ang))
+        if ang is None:
+            return None
+        a = np.deg2rad(float(ang))
+        R = np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]])
+        t = R @ np.array([1.0, 0.0, 0.0])
+        h = (np.floor(kpts0[:, 0]).astype(np.int64) * 31 + np.floor(kpts1[:, 1]).astype(np.int64) * 17
+             + np.floor(kpts0[:, 1]).astype(np.int64) * 7) % self.keep_mod
+        return np.eye(3), R, t, h < self.keep_below

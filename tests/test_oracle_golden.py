@@ -50,15 +50,25 @@ def test_run_vs_reference(name):
         assert np.array_equal(out['index1'].numpy(), z['index1'])
 
 
-@pytest.mark.parametrize('name,unc', [('imp_loop_n400', False), ('eimp_loop_sliced_n1024', True)])
+LOOPS = [('imp_loop_n400', False), ('eimp_loop_sliced_n1024', True), ('imp_loop_exit_n400', False),
+         ('eimp_loop_uncert_exit_n1024', True), ('eimp_loop_uncert_full_n700', True)]
+
+
+@pytest.mark.parametrize('name,unc', LOOPS)
 def test_iterative_loops_vs_reference(name, unc):
+    """incl. the pose-driven branches (eval/matching.py:84-117 early exit with inlier-filtered indices, :243-252
+    with_uncertainty thresholds): the fixtures were captured from the reference driven by synthetic.PoseStub"""
+    from imp_release_amd import synthetic
     spec, z = load_golden(name)
     cfg, sd, data = build_case(spec)
     o = orc.MatcherOracle(cfg, sd, model=spec['model'])
+    sched = spec.get('pose_schedule')
+    stub = synthetic.PoseStub(sched) if sched is not None else None
     trace = []
     with torch.no_grad():
-        out = orc.matching_iterative(data, o, nI=15, match_ratio=0.1, min_kpts=25, estimate_pose=None,
-                                     uncertainty=unc, trace=trace)
+        out = orc.matching_iterative({**data, 'K0': np.eye(3), 'K1': np.eye(3)}, o, nI=15, match_ratio=0.1, min_kpts=25,
+                                     estimate_pose=stub, uncertainty=unc,
+                                     with_uncertainty=bool(spec.get('with_uncertainty', False)), trace=trace, method=38)
     assert out['n_iter'] == int(z['n_iter'])
     traj = z['trajectory']
     assert [(t['n0'], t['n1']) for t in trace] == [tuple(r) for r in traj.tolist()]
@@ -66,8 +76,14 @@ def test_iterative_loops_vs_reference(name, unc):
         assert np.array_equal(t['indices0'].numpy(), z[f'it{k}_indices0']), f'{name}: it {k}'
         np.testing.assert_allclose(t['mscores0'].numpy(), z[f'it{k}_mscores0'], atol=2e-5, rtol=0)
     assert np.array_equal(out['indices0'].numpy(), z['indices0'])
+    np.testing.assert_allclose(out['mscores0'].numpy(), z['mscores0'], atol=2e-5, rtol=0)
     assert np.array_equal(data['keypoints0'][0].numpy()[out['keep0'].numpy()], z['pts0_final'])
     assert np.array_equal(data['keypoints1'][0].numpy()[out['keep1'].numpy()], z['pts1_final'])
+    if 'R' in z.files:
+        assert out['R'] is not None and np.allclose(out['R'], z['R']) and np.allclose(out['t'], z['t'])
+        assert [c[0] for c in stub.calls] == z['pose_calls'].tolist()
+    else:
+        assert out['R'] is None
 
 
 def test_pool_edge_cases_vs_reference():

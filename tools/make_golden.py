@@ -147,8 +147,13 @@ def case_run(name, spec):
 
 
 def case_loop(name, spec, uncertainty):
-    """eval/matching.py loops with the pose step stubbed out (estimate_pose -> None)."""
+    """eval/matching.py loops.  spec['pose_schedule'] is None -> the pose step is stubbed out (estimate_pose -> None:
+    no early exit, all 15 iterations); otherwise a fresh synthetic.PoseStub(schedule) per implementation makes the
+    REFERENCE take eval/matching.py:84-117 (pose-change test, early exit returning inlier-filtered indices) and, with
+    spec['with_uncertainty'], :243-252 (mscore_th = 0.2 * inlier_ratio)."""
     cfg, ref, oracle, data = build(spec)
+    sched = spec.get('pose_schedule')
+    wu = bool(spec.get('with_uncertainty', False))
     d = dict(data)
     d['pts0_cpu'] = data['keypoints0'][0].numpy()
     d['pts1_cpu'] = data['keypoints1'][0].numpy()
@@ -164,22 +169,31 @@ def case_loop(name, spec, uncertainty):
         return out
 
     ref.compute_matches = rec_cm
+    ref_stub = synthetic.PoseStub(sched) if sched is not None else (lambda **k: None)
+    ref_matching.estimate_pose = ref_stub
+    orc_stub = synthetic.PoseStub(sched) if sched is not None else None
     with torch.no_grad():
         if uncertainty:
             ret = ref_matching.matching_iterative_uncertainty(d, ref, 15, 0.1, 25, 1.0, {'pose': 1.5}, method=38,
-                                                              with_uncertainty=False)
+                                                              with_uncertainty=wu)
             p0, p1, _, _, i0, m0, R, t, nit = ret
         else:
             i0, m0, R, t, nit = ref_matching.matching_iterative(d, ref, 15, 0.1, 25, 1.0, {'pose': 1.5}, method=38)
             p0, p1 = d['pts0_cpu'], d['pts1_cpu']
         otrace = []
-        o = orc.matching_iterative(data, oracle, nI=15, match_ratio=0.1, min_kpts=25, estimate_pose=None,
-                                   uncertainty=uncertainty, trace=otrace)
+        o = orc.matching_iterative({**data, 'K0': d['K0'], 'K1': d['K1']}, oracle, nI=15, match_ratio=0.1, min_kpts=25,
+                                   estimate_pose=orc_stub, uncertainty=uncertainty, with_uncertainty=wu, trace=otrace,
+                                   method=38)
+    ref_matching.estimate_pose = lambda **k: None
     arrays = {'indices0': i0, 'mscores0': m0, 'n_iter': np.array(nit),
               'pts0_final': p0, 'pts1_final': p1}
+    exited = R is not None
+    if exited:
+        arrays['R'] = np.asarray(R); arrays['t'] = np.asarray(t)
     traj = []
-    ok = True
-    for k, (n0, n1, ti, tm) in enumerate(trace[:-1]):        # last entry = final p=0.2 call
+    ok = nit == o['n_iter'] and (exited == (o['R'] is not None))
+    scored = trace if exited else trace[:-1]                   # without an early exit the last entry = final p=0.2 call
+    for k, (n0, n1, ti, tm) in enumerate(scored):
         arrays[f'it{k}_indices0'] = ti.numpy()
         arrays[f'it{k}_mscores0'] = tm.numpy()
         traj.append((n0, n1))
@@ -187,11 +201,18 @@ def case_loop(name, spec, uncertainty):
         arrays[f'it{k}_keep0'] = otrace[k]['keep0'].numpy()      # oracle keep sets (== reference: pts checked below)
         arrays[f'it{k}_keep1'] = otrace[k]['keep1'].numpy()
     arrays['trajectory'] = np.array(traj)
+    ok &= len(otrace) == len(scored)
     ok &= bool(np.array_equal(i0, o['indices0'].numpy()))
     kp0 = data['keypoints0'][0].numpy()[o['keep0'].numpy()]
     ok &= bool(np.array_equal(kp0, p0))
-    save(name, spec, arrays, f'n_iter={nit} traj={traj} matches={int((i0 >= 0).sum())} oracle_equal={ok} '
-                             f'max|dms|={np.abs(m0 - o["mscores0"].numpy()).max():.2e}')
+    kp1 = data['keypoints1'][0].numpy()[o['keep1'].numpy()]
+    ok &= bool(np.array_equal(kp1, p1))
+    if sched is not None:
+        ok &= ref_stub.calls == orc_stub.calls
+        arrays['pose_calls'] = np.array([c[0] for c in ref_stub.calls])
+    save(name, spec, arrays, f'n_iter={nit} exit={exited} traj={traj} matches={int((i0 >= 0).sum())} oracle_equal={ok} '
+                             f'max|dms|={np.abs(m0 - o["mscores0"].numpy()).max():.2e}'
+                             + (f' pose_calls={ref_stub.calls}' if sched is not None else ''))
     assert ok, name
 
 
@@ -263,6 +284,9 @@ def main():
                                          wseed=1, dseed=11, n0=256, n1=256, call=dict(p=0.2, only_last=True)))
     case_produce('gm_l9_t100_ragged', dict(model='GM', config=dict(n_layers=9, sinkhorn_iterations=100),
                                            wseed=1, dseed=12, n0=300, n1=307, call=dict(p=0.2, only_last=True)))
+    # BASELINE configs[1] exactly: GM, N = M = 1024, 9 iterations, 100 Sinkhorn, batch 1
+    case_produce('gm_l9_t100_n1024', dict(model='GM', config=dict(n_layers=9, sinkhorn_iterations=100),
+                                          wseed=1, dseed=27, n0=1024, n1=1024, call=dict(p=0.2, only_last=True)))
     # all iterations emitted, batch 2, uncorrelated inputs
     case_produce('gm_l3_alliters_b2', dict(model='GM', config=dict(n_layers=3), wseed=2, dseed=13, n0=130, n1=97,
                                            batch=2, correlated=False, call=dict(p=0.2, only_last=False)))
@@ -296,6 +320,19 @@ def main():
     # trajectory (dseed=24 sits on a knife edge at it=5: fp64 keeps 750 keypoints where fp32 keeps 751)
     case_loop('eimp_loop_sliced_n1024', dict(model='AdaGMN', config=dict(), wseed=9, dseed=25, n0=1024, n1=1000,
                                              bin_score=5.0), True)
+    # the pose-driven half of the loops: a deterministic pose stub (synthetic.PoseStub) makes the reference itself take the
+    # early exit (eval/matching.py:109-117: diff 0.5 deg <= 1.5 at the 3rd pose -> it = 7, n_iter = 8, inlier-filtered indices)
+    case_loop('imp_loop_exit_n400', dict(model='DGNNS', config=dict(), wseed=9, dseed=23, n0=400, n1=380,
+                                         pose_schedule=[0.0, 10.0, 10.5]), False)
+    # ... and, for EIMP, with_uncertainty=True (eval/matching.py:243-252): no pose at it=3 (th 0.2), then th = 0.2 * inlier
+    # ratio for the pools at it = 5, 7, 9; pose change 20 -> 20.3 deg exits at it = 9 (n_iter = 10) on the sliced sets
+    case_loop('eimp_loop_uncert_exit_n1024', dict(model='AdaGMN', config=dict(), wseed=9, dseed=25, n0=1024, n1=1000,
+                                                  bin_score=5.0, pose_schedule=[None, 0.0, 20.0, 20.3],
+                                                  with_uncertainty=True), True)
+    # with_uncertainty=True and a pose that keeps changing: all 15 iterations with the lowered pool thresholds
+    case_loop('eimp_loop_uncert_full_n700', dict(model='AdaGMN', config=dict(), wseed=9, dseed=26, n0=700, n1=730,
+                                                 bin_score=5.0, pose_schedule=[0.0, 5.0, 10.0, 15.0, 20.0, 25.0, 30.0],
+                                                 with_uncertainty=True), True)
     # (7) pool edge cases
     case_pool_edges('pool_edges')
     case_metrics('metrics')
