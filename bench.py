@@ -125,12 +125,24 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run --nproc-per-node {args.gpus}')
-        args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the matching hot path has no CPU fallback')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N` (how the driver's scaling sweep may call it): launch ourselves as one process
+        # per GPU under torch.distributed.run and hand the ranks the same command line
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f'--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible')
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(('127.0.0.1', 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+    if world != args.gpus:
+        args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
@@ -219,6 +231,12 @@ def main():
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
+    ranks_seen = [0]
+    if use_pg:               # which ranks really took part (from an all-gather, not from the environment)
+        mine = torch.tensor([rank], dtype=torch.int64, device=dev)
+        seen = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(seen, mine)
+        ranks_seen = seen.tolist()
     assert res[0].shape[0] == n_total
     n_matched = int((res[0] >= 0).sum())
 
@@ -255,7 +273,7 @@ def main():
     if rank == 0:
         line = {
             'metric': 'image-pairs/s (N=2048 kpts, 9 self+cross iters, 100 Sinkhorn)',
-            'value': n_total * args.steps / elapsed, 'unit': 'image-pairs/s', 'n_gpus': world, 'steps': args.steps,
+            'value': n_total * args.steps / elapsed, 'unit': 'image-pairs/s', 'n_gpus': world, 'ranks_seen': ranks_seen, 'steps': args.steps,
             'warmup': n_warm, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 (products as split-half f16x3 MFMA, fp32 accumulate)' if f16x3 else 'f32', 'data': 'synthetic',

@@ -14,7 +14,7 @@ from . import synthetic  # noqa: F401,E402  (numpy only)
 
 def __getattr__(name):
     # torch-dependent modules are imported lazily so that `synthetic` stays usable without them
-    if name in ('GM', 'DGNNS', 'AdaGMN', 'AttentionHandle'):
+    if name in ('GM', 'DGNNS', 'AdaGMN', 'AttentionHandle', 'normalize_keypoints'):
         from . import modules
         return getattr(modules, name)
     if name in ('matching_iterative', 'matching_iterative_uncertainty'):

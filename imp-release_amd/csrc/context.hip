@@ -664,8 +664,14 @@ int imp_finalize_weights(imp_ctx* c) {
 
 int imp_normalize_keypoints(imp_ctx* c, const float* kpts, int batch, int n, float width, float height, float* out,
                             void* stream) {
-    if (!c || !kpts || !out) return fail(IMP_E_ARG, "imp_normalize_keypoints: null argument");
-    HIP_TRY(hipSetDevice(c->device));
+    if (!kpts || !out) return fail(IMP_E_ARG, "imp_normalize_keypoints: null argument");
+    if (c) {
+        HIP_TRY(hipSetDevice(c->device));
+    } else {   // context-free use (the free function nets/layers.py:49-56): launch on the device that owns the buffer
+        hipPointerAttribute_t at;
+        HIP_TRY(hipPointerGetAttributes(&at, kpts));
+        HIP_TRY(hipSetDevice(at.device));
+    }
     HIP_TRY(launch_normalize_kpts(kpts, (long)batch * n, width, height, out, S(stream)));
     return IMP_OK;
 }

@@ -47,7 +47,7 @@ def _normalize(model, data):
 
 def _loop(data, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method, estimate_pose, uncertainty,
           with_uncertainty, trace=None):
-    ctx = model._ensure_ctx()
+    ctx = model._ensure_ctx(check=True)
     norm_kpts0, norm_kpts1 = _normalize(model, data)
     pts0_cpu, pts1_cpu = data['pts0_cpu'], data['pts1_cpu']
     K0, K1 = data.get('K0'), data.get('K1')

@@ -118,6 +118,21 @@ def _token_major(x: torch.Tensor) -> torch.Tensor:
     return t if (t.is_contiguous() and t.dtype == torch.float32) else t.contiguous().float()
 
 
+def normalize_keypoints(kpts: torch.Tensor, image_shape):
+    """Drop-in for the free function ``nets.gm.normalize_keypoints`` (nets/layers.py:49-56) that eval/matching.py:11,24
+    imports: centre on [w, h] / 2, divide by 0.7 * max(w, h), (h, w) = image_shape[2:4].  HIP kernel, no context."""
+    from ._lib import _f32, _ptr, _stream, lib
+    _, _, height, width = image_shape
+    k = _f32(kpts, 'kpts')
+    out = torch.empty_like(k)
+    L = lib()
+    rc = L.imp_normalize_keypoints(None, _ptr(k), k.shape[0], k.shape[1], float(width), float(height), _ptr(out),
+                                   _stream(k.device))
+    if rc != 0:
+        raise _lib.ImpError(rc, L.imp_last_error().decode())
+    return out
+
+
 class GM(nn.Module):
     """Drop-in for nets/gm.py:16 ``GM`` (inference surface)."""
 
@@ -155,13 +170,31 @@ class GM(nn.Module):
         return self.bin_score.device
 
     def _weights_version(self):
-        return (str(self._device()), tuple(p._version for p in self.parameters()),
-                tuple(b._version for b in self.buffers()))
+        # _version catches in-place updates (load_state_dict, optimiser steps), data_ptr catches `p.data = new_tensor`
+        ps = list(self.parameters()) + list(self.buffers())
+        return (str(self._device()), tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
 
-    def _ensure_ctx(self) -> _lib.Context:
+    def refresh_weights(self):
+        """force the HIP context to re-pack the module's parameters at the next call (it is done automatically after
+        load_state_dict / .to() / in-place parameter updates seen at the entry of produce_matches, run and encode_keypoint)"""
+        self._ctx_key = None
+
+    def _apply(self, fn, *a, **k):
+        self._ctx_key = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._ctx_key = None
+        return super().load_state_dict(*a, **k)
+
+    def _ensure_ctx(self, check: bool = False) -> _lib.Context:
+        """check=True (entry points of a pair: produce_matches / run / encode_keypoint / the loops) walks the ~350
+        tensors for changes; the per-layer step calls in between only look at the invalidation flag."""
         dev = self._device()
         if dev.type != 'cuda':
             raise RuntimeError('imp_release_amd has no CPU path: move the module to the GPU first (.cuda())')
+        if self._ctx is not None and self._ctx_key is not None and not check:
+            return self._ctx
         key = self._weights_version()
         if self._ctx is None or self._ctx_key != key:
             if self._ctx is None or self._ctx.device != dev:
@@ -205,7 +238,7 @@ class GM(nn.Module):
     # ------------------------------------------------------------------ step API (eval/matching.py)
     def encode_keypoint(self, norm_kpts0, norm_kpts1, scores0, scores1):
         """nets/gm.py:287-288 -> (enc0, enc1) shaped [B, D, N]"""
-        ctx = self._ensure_ctx()
+        ctx = self._ensure_ctx(check=True)
         e0, e1 = ctx.encode_keypoints(norm_kpts0, scores0, norm_kpts1, scores1)
         return e0.transpose(1, 2), e1.transpose(1, 2)
 
@@ -272,7 +305,7 @@ class GM(nn.Module):
 
     def _run_iterations(self, data, p, only_last, want_scores):
         """shared body of GM / DGNNS produce_matches: returns per-emitted-iteration lists"""
-        ctx = self._ensure_ctx()
+        ctx = self._ensure_ctx(check=True)
         k0, k1, w, h = self._inputs(data)
         nI = self.n_layers
         out = {'scores': [], 'indices0': [], 'indices1': [], 'mscores0': [], 'mscores1': []}
@@ -394,7 +427,7 @@ class AdaGMN(GM):
     def produce_matches(self, data, p=0.2, mscore_th=0.1, uncertainty_ratio=1., **kwargs):
         """nets/adgm.py:327-526: *masked* adaptive pooling (tensors keep their size; pruned keypoints are
         masked out as attention keys and excluded from scoring)."""
-        ctx = self._ensure_ctx()
+        ctx = self._ensure_ctx(check=True)
         k0, k1, w, h = self._inputs(data)
         if w > 0:
             k0, k1 = ctx.normalize_keypoints(k0, w, h), ctx.normalize_keypoints(k1, w, h)

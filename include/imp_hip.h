@@ -105,7 +105,8 @@ int imp_set_sinkhorn_storage(imp_ctx* ctx, int bytes_per_element);
 int imp_num_keys(imp_ctx* ctx);
 const char* imp_key_name(imp_ctx* ctx, int i);
 
-/* normalize_keypoints (nets/layers.py:49-56): (kpts - [w,h]/2) / (0.7*max(w,h)); kpts,out [B][n][2] */
+/* normalize_keypoints (nets/layers.py:49-56): (kpts - [w,h]/2) / (0.7*max(w,h)); kpts,out [B][n][2].
+   ctx may be NULL (the reference's free function has no model): the launch then goes to the device owning kpts */
 int imp_normalize_keypoints(imp_ctx* ctx, const float* kpts, int batch, int n, float width, float height,
                             float* out, void* stream);
 

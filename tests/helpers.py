@@ -57,21 +57,31 @@ def make_hip_model(spec_or_model, cfg, sd, device='cuda', precision=None):
     return m.to(device)
 
 
-def compare_matches(i_got, ms_got, i_ref, ms_ref, p, tol=1e-4, what='', low_score_flips=0):
+EXCUSED = []          # (what, count) of every non-strict comparison that used the threshold-tie excuse: conftest prints the total
+
+
+def compare_matches(i_got, ms_got, i_ref, ms_ref, p, tol=1e-4, what='', low_score_flips=0, strict=True):
     """The parity bar: match indices identical, scores within `tol` (north star: 1e-4).
-    A differing index is tolerated ONLY when the reference decision itself is within `tol` of flipping
-    (|mscore - p| < tol at that keypoint, i.e. an fp32 summation-order tie), and is reported."""
+
+    strict=True (default; EVERY golden-fixture comparison): bit-exact indices, no excuse of any kind.
+    strict=False (only the oracle-at-N=2048 runs and the opt-in soak, where the comparison partner is itself an
+    fp32 computation with another summation order): a differing index is tolerated ONLY when the decision is within
+    `tol` of flipping (|mscore - p| < tol at that keypoint); the excused count is recorded in EXCUSED, printed by
+    the terminal summary (visible with -q) and returned in the message."""
     i_got, i_ref = np.asarray(i_got), np.asarray(i_ref)
     ms_got, ms_ref = np.asarray(ms_got, dtype=np.float64), np.asarray(ms_ref, dtype=np.float64)
     assert i_got.shape == i_ref.shape, f'{what}: shape {i_got.shape} vs {i_ref.shape}'
     dms = np.abs(ms_got - ms_ref)
     bad = np.nonzero(i_got != i_ref)
     excused = 0
-    for pos in zip(*bad):
-        if abs(ms_ref[pos] - p) < tol or abs(ms_got[pos] - p) < tol:
-            excused += 1
+    if not strict:
+        for pos in zip(*bad):
+            if abs(ms_ref[pos] - p) < tol or abs(ms_got[pos] - p) < tol:
+                excused += 1
+        if excused:
+            EXCUSED.append((what, excused))
     n_bad = len(bad[0]) - excused
-    msg = (f'{what}: {len(bad[0])} index mismatches ({excused} threshold ties) of {i_ref.size}, '
+    msg = (f'{what}: {len(bad[0])} index mismatches ({excused} threshold ties excused) of {i_ref.size}, '
            f'max|dmscore|={dms.max() if dms.size else 0:.3e}, matched_ref={(i_ref >= 0).sum()}')
     assert n_bad == 0, msg
     # score tolerance applies where both agree on mutuality (a mutual flip changes mscore to/from 0)

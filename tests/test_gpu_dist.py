@@ -1,0 +1,56 @@
+"""GPU: the exchange lane on real RCCL, and bench.py's launch contract.  The box has ONE GPU, so the
+process group has one rank; IMP_FORCE_COLLECTIVES=1 makes the lane issue the collective anyway."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(**kw):
+    e = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    e.update(kw)
+    return e
+
+
+def _last_json(out):
+    for ln in reversed(out.strip().splitlines()):
+        if ln.startswith('{'):
+            return json.loads(ln)
+    raise AssertionError('no JSON line in:\n' + out[-2000:])
+
+
+def test_rccl_lane_single_rank_three_replicas_in_flight():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'nccl_lane_worker.py')],
+                       env=_env(MASTER_PORT='29641'), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    assert j['same'] and j['distinct_batches'] and j['steps'] == 7 and j['matched'] > 0, j
+
+
+def test_bench_under_torch_distributed_run_with_the_collective_lane():
+    """the driver's N>1 command line (python -m torch.distributed.run ... bench.py --gpus N) at N = 1, RCCL lane forced"""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29643', os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1',
+           '--kpts', '512', '--pairs-per-gpu', '2', '--no-cpu-baseline']
+    r = subprocess.run(cmd, env=_env(IMP_FORCE_COLLECTIVES='1'), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    assert j['n_gpus'] == 1 and j['ranks_seen'] == [0] and j['value'] > 0 and j['config']['matched_keypoints'] > 0
+
+
+def test_bench_self_launch_refuses_more_gpus_than_visible():
+    """plain `python bench.py --gpus N` re-launches itself under torch.distributed.run; with fewer GPUs than N it must say
+    so instead of hanging in a rendezvous"""
+    import torch
+    n = torch.cuda.device_count() + 1
+    e = _env()
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '1', '--warmup', '0',
+                        '--no-cpu-baseline'], env=e, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and 'visible' in (r.stderr + r.stdout)
