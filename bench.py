@@ -249,9 +249,11 @@ def main():
     # f16x3 executes 3 f16 MFMA flops per algorithmic (fp32-equivalent) flop: the roof for ALGORITHMIC flops is the
     # dense f16 peak / 3; the native fp32-MFMA roof (157.3) is what the same math costs without the split
     peak = PEAK_F16_MFMA_TFLOPS / 3.0 if f16x3 else PEAK_F32_MFMA_TFLOPS
-    sk_ms = ctx.time_sinkhorn(B, N, 20) * 2.0       # per Sinkhorn ITERATION (2 launches: fused P pass + column reduce)
+    sk_ms = ctx.time_sinkhorn(B, N, 50)             # per Sinkhorn ITERATION, on the path the product takes for this shape
+    sk_resident = ctx.resident_status()[1]
     ld = (N + 1 + 3) // 4 * 4
-    # algorithmic bytes per iteration: P read once + the column partial vectors written and read back once
+    # bytes ONE pass over the matrix moves (what an iteration costs when P is streamed: the streaming path reads P once per
+    # iteration + the column partial vectors; the chip-resident kernel keeps P in registers and moves only vectors)
     sk_bytes = B * (N + 1) * ld * 4.0 + 2.0 * B * ((N + 1 + 15) // 16) * ld * 4.0
     layer_sides = 4 * args.iters
     pair_flops = (4 * args.iters * (20 * 256 ** 2 * N + 4 * N * N * 256) + 2 * 2 * N * 108640 + 4 * 256 ** 2 * N
@@ -295,8 +297,15 @@ def main():
                          'vs_native_f32_mfma_roof': achieved / PEAK_F32_MFMA_TFLOPS,
                          'launches_per_step': layer_sides // 2,
                          'whole_path_tflops': pair_flops * n_total * args.steps / elapsed / 1e12 / world,
-                         'sinkhorn_iteration': {'bound': 'hbm', 'iteration_ms': sk_ms, 'bytes_per_iteration': sk_bytes,
-                                                'achieved_GBs': sk_bytes / (sk_ms * 1e-3) / 1e9, 'peak_GBs': PEAK_HBM_GBS}},
+                         'sinkhorn_iteration': {
+                             'path': 'chip-resident (P in VGPRs for all T iterations, 2 group barriers per iteration)'
+                             if sk_resident else 'streaming (P read once per iteration, 2 launches)',
+                             'bound': 'latency (group barriers + vector exchange)' if sk_resident else 'hbm',
+                             'iteration_ms': sk_ms, 'matrix_bytes': sk_bytes,
+                             'matrix_bytes_per_iteration_time_GBs': sk_bytes / (sk_ms * 1e-3) / 1e9,
+                             'peak_GBs': PEAK_HBM_GBS,
+                             'note': 'resident: no HBM traffic per iteration; the GB/s figure is what a streaming '
+                                     'implementation would need to match it' if sk_resident else ''}},
         }
         line['one_step_in_flight'] = None if serial_s is None else {
             'value': n_total * args.steps / serial_s, 'ms_per_step': serial_s / args.steps * 1e3,

@@ -26,7 +26,7 @@ SYMBOLS = [
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
     'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear',
-    'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn',
+    'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status',
 ]
 
 
@@ -96,6 +96,7 @@ def lib():
     L.imp_op_attention.argtypes = [P, I, I, I, I, P, P, P, P, P, P]
     L.imp_time_attention.argtypes = [P, I, I, I, C.POINTER(C.c_float), P]
     L.imp_time_sinkhorn.argtypes = [P, I, I, I, C.POINTER(C.c_float), P]
+    L.imp_resident_status.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -370,3 +371,9 @@ class Context:
         ms = C.c_float()
         self._check(self.L.imp_time_sinkhorn(self.handle, batch, n, iterations, C.byref(ms), _stream(self.device)))
         return ms.value
+
+    def resident_status(self):
+        """(timed_out, used) of the chip-resident Sinkhorn kernel on this context (synchronises)"""
+        st, used = C.c_int(), C.c_int()
+        self._check(self.L.imp_resident_status(self.handle, C.byref(st), C.byref(used)))
+        return bool(st.value), bool(used.value)

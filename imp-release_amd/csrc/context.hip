@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -53,7 +54,7 @@ struct imp_ctx {
     int ot_compact = 0;       // Sinkhorn iterations stream the 3-byte copy of P (imp_set_sinkhorn_storage / IMP_OT_COMPACT=1)
     bool fuse_merge = true;   // fold attn.merge into mlp.0 (one GEMM and one launch less per layer); IMP_NO_FUSE_MERGE=1 disables
     float bin_score = 1.f;
-    std::vector<void*> allocs_w, allocs_ws;
+    std::vector<void*> allocs_w, allocs_ws, allocs_x;   // weights / workspace (regrown) / resident-Sinkhorn exchange
     // packed weights
     std::vector<Linear> kenc;
     std::vector<NormC> kenc_bn;
@@ -68,6 +69,14 @@ struct imp_ctx {
     float *descw[2] = {}, *mdesc[2] = {}, *nkp[2] = {};
     float* dist = nullptr;
     OtBuffers ot{};
+    // chip-resident Sinkhorn (ot_resident.hip): exchange buffers sized for one workgroup per CU, independent of N
+    int ot_resident = 1;      // IMP_OT_RESIDENT=0 forces the streaming path
+    int num_cus = 0;
+    float *xpart = nullptr, *xv = nullptr, *xmax = nullptr;
+    unsigned* xcounters = nullptr;
+    int* xstatus = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    int xcap_b = 0;
     float *max0 = nullptr, *max1 = nullptr, *colpart_v = nullptr;
     int *arg0 = nullptr, *arg1 = nullptr, *colpart_i = nullptr;
     float *colsum[4] = {}, *amass[4] = {}, *mass[2] = {};
@@ -462,11 +471,92 @@ void ot_layout(imp_ctx* c, int n0, int n1, OtBuffers* o) {
     o->ldpt = (n0 + 1 + 3) & ~3;
 }
 
+// All resident launches of a device go through ONE stream: a resident kernel spins on group barriers, so two of them
+// dispatched concurrently (pairs in flight on replicas, eval_loop workers) could each hold CUs the other is waiting for.
+// Stream order on the lane rules that out; the caller's stream is joined in and out with events.
+struct ResidentLane { std::mutex mu; hipStream_t stream = nullptr; };
+ResidentLane* resident_lane(int device) {
+    static std::mutex mu;
+    static std::map<int, ResidentLane*> lanes;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = lanes.find(device);
+    if (it != lanes.end()) return it->second;
+    ResidentLane* l = new ResidentLane();
+    if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess) { delete l; return nullptr; }
+    lanes[device] = l;
+    return l;
+}
+
+constexpr size_t kResidentMaxLdx = 256 * 16 + 4;
+int ensure_resident_buffers(imp_ctx* c, int batch) {
+    if (c->xpart && batch <= c->xcap_b) return IMP_OK;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    c->num_cus = prop.multiProcessorCount;
+    const size_t wgs = (size_t)c->num_cus;
+    int rc = 0;
+    const int cap = batch < 8 ? 8 : batch;
+    if (!c->xpart) {
+        rc = dev_alloc(c, c->allocs_x, &c->xpart, wgs * kResidentMaxLdx);
+        if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xmax, 2 * wgs * kResidentMaxLdx);
+        if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xstatus, 4);
+        if (!rc) HIP_TRY(hipMemset(c->xstatus, 0, 16));
+        if (!rc) HIP_TRY(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+        if (!rc) HIP_TRY(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
+    }
+    if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xv, (size_t)cap * kResidentMaxLdx);
+    if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xcounters, (size_t)cap * 32);
+    if (!rc) HIP_TRY(hipMemset(c->xcounters, 0, (size_t)cap * 32 * sizeof(unsigned)));
+    if (rc) return rc;
+    c->xcap_b = cap;
+    return IMP_OK;
+}
+
+// the resident launch on the device's lane, joined to `st` on both sides; returns IMP_OK, or >0 when not applicable
+int run_score_resident(imp_ctx* c, int batch, int n0, int n1, const float* dist, float bin, int iterations, float* scores,
+                       bool want_max, bool want_uv, hipStream_t st) {
+    if (!c->ot_resident) return 1;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 1;   // graphs: streaming path
+    int rc = ensure_resident_buffers(c, batch);
+    if (rc) return rc;
+    int nch, rpw, G;
+    if (!ot_resident_plan(batch, n0, n1, c->num_cus, &nch, &rpw, &G)) return 1;
+    ResidentLane* lane = resident_lane(c->device);
+    if (!lane) return 1;
+    OtResidentParams p;
+    memset(&p, 0, sizeof p);
+    p.dist = dist; p.B = batch; p.n0 = n0; p.n1 = n1; p.T = iterations; p.G = G; p.bin = bin;
+    p.xpart = c->xpart; p.xv = c->xv; p.xmax = c->xmax; p.counters = c->xcounters; p.status = c->xstatus;
+    if (want_uv) { p.u = c->ot.u; p.ldu = (n0 + 1 + 3) & ~3; p.v = c->ot.v; p.ldv = (n1 + 1 + 3) & ~3; }
+    p.scores = scores;
+    if (want_max) { p.max0 = c->max0; p.arg0 = c->arg0; p.max1 = c->max1; p.arg1 = c->arg1; }
+    std::lock_guard<std::mutex> lock(lane->mu);
+    HIP_TRY(hipEventRecord(c->ev_in, st));
+    HIP_TRY(hipStreamWaitEvent(lane->stream, c->ev_in, 0));
+    HIP_TRY(launch_ot_resident(p, nch, rpw, lane->stream));
+    HIP_TRY(hipEventRecord(c->ev_out, lane->stream));
+    HIP_TRY(hipStreamWaitEvent(st, c->ev_out, 0));
+    return IMP_OK;
+}
+
+// scores (optional) and, with max_done, the row / column maxima of the inner block in c->max0/arg0/max1/arg1.
+// *max_done is set when the maxima were produced here (resident path); otherwise the caller takes them from ot_out.
 int run_score(imp_ctx* c, int batch, int n0, int n1, const float* dist, float bin, int iterations, int with_sinkhorn,
-              float* scores, OtBuffers* ot_out, hipStream_t st) {
+              float* scores, OtBuffers* ot_out, hipStream_t st, bool* max_done = nullptr) {
     OtBuffers o;
     ot_layout(c, n0, n1, &o);
     const int dual = with_sinkhorn ? 0 : 1;
+    if (max_done) *max_done = false;
+    if (!dual && (scores || max_done)) {
+        const int rr = run_score_resident(c, batch, n0, n1, dist, bin, iterations, scores, max_done != nullptr, true, st);
+        if (rr < 0) return rr;
+        if (rr == 0) {
+            if (max_done) *max_done = true;
+            if (ot_out) *ot_out = o;
+            return IMP_OK;
+        }
+    }
     HIP_TRY(launch_ot_init(dist, batch, n0, n1, bin, dual, o, st));
     if (dual) HIP_TRY(launch_ot_dual_lse(batch, n0, n1, o, st));
     else HIP_TRY(launch_ot_iterations(batch, n0, n1, iterations, o, st));
@@ -514,6 +604,7 @@ int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     { const char* e = getenv("IMP_NO_FUSE_MERGE"); c->fuse_merge = !(e && e[0] == '1'); }
     { const char* e = getenv("IMP_PRECISION"); c->prec = (e && !strcmp(e, "f32")) ? 0 : 1; }
     { const char* e = getenv("IMP_OT_COMPACT"); c->ot_compact = (e && atoi(e) != 0) ? 1 : 0; }
+    { const char* e = getenv("IMP_OT_RESIDENT"); c->ot_resident = (e && atoi(e) == 0) ? 0 : 1; }
     c->kenc_maxc = c->D;
     for (int i = 0; i < nk; ++i) if (cfg->kenc_channels[i] > c->kenc_maxc) c->kenc_maxc = cfg->kenc_channels[i];
     build_schema(c);
@@ -527,6 +618,9 @@ int imp_destroy(imp_ctx* c) {
     (void)hipDeviceSynchronize();
     free_pool(c->allocs_w);
     free_pool(c->allocs_ws);
+    free_pool(c->allocs_x);
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    if (c->ev_out) (void)hipEventDestroy(c->ev_out);
     delete c;
     return IMP_OK;
 }
@@ -869,8 +963,9 @@ int imp_match_pair(imp_ctx* c, int batch, int n0, int n1, const float* kpts0, co
         if ((rc = run_layer(c, li, batch, n, dr, dw, nomask, st))) return rc;
     if ((rc = run_distance(c, c->cfg.n_layers - 1, batch, n, dr, c->dist, st))) return rc;
     OtBuffers o;
-    if ((rc = run_score(c, batch, n0, n1, c->dist, bin_score, sinkhorn_iterations, with_sinkhorn, scores, &o, st))) return rc;
-    HIP_TRY(launch_ot_maxima(batch, n0, n1, with_sinkhorn ? 0 : 1, o, c->max0, c->arg0, c->max1, c->arg1, st));
+    bool max_done = false;
+    if ((rc = run_score(c, batch, n0, n1, c->dist, bin_score, sinkhorn_iterations, with_sinkhorn, scores, &o, st, &max_done))) return rc;
+    if (!max_done) HIP_TRY(launch_ot_maxima(batch, n0, n1, with_sinkhorn ? 0 : 1, o, c->max0, c->arg0, c->max1, c->arg1, st));
     HIP_TRY(launch_mutual_matches(batch, n0, n1, c->max0, c->arg0, c->max1, c->arg1, p, indices0, indices1, mscores0,
                                   mscores1, st));
     return IMP_OK;
@@ -939,21 +1034,54 @@ int imp_time_sinkhorn(imp_ctx* c, int batch, int n, int iterations, float* ms, v
     if (rc) return rc;
     if (!ms || iterations < 1) return fail(IMP_E_ARG, "imp_time_sinkhorn: bad argument");
     hipStream_t st = S(stream);
-    OtBuffers o;
-    ot_layout(c, n, n, &o);
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(launch_ot_iterations(batch, n, n, 2, o, st));   // warm
-    HIP_TRY(hipEventRecord(e0, st));
-    HIP_TRY(launch_ot_iterations(batch, n, n, iterations, o, st));
-    HIP_TRY(hipEventRecord(e1, st));
-    HIP_TRY(hipEventSynchronize(e1));
     float t = 0.f;
-    HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+    int nch, rpw, G;
+    rc = c->ot_resident ? ensure_resident_buffers(c, batch) : 1;
+    if (rc < 0) return rc;
+    if (rc == 0 && ot_resident_plan(batch, n, n, c->num_cus, &nch, &rpw, &G)) {
+        // resident path: per-iteration time = (launch with T iterations - launch with 0 iterations) / T, both on `st`
+        // (nothing else runs during a timing call), events on the stream the kernel is launched on
+        OtResidentParams p;
+        memset(&p, 0, sizeof p);
+        p.dist = c->dist; p.B = batch; p.n0 = n; p.n1 = n; p.G = G; p.bin = 1.f;
+        p.xpart = c->xpart; p.xv = c->xv; p.xmax = c->xmax; p.counters = c->xcounters; p.status = c->xstatus;
+        float tt[2];
+        for (int k = 0; k < 2; ++k) {
+            p.T = k ? iterations : 0;
+            HIP_TRY(launch_ot_resident(p, nch, rpw, st));   // warm
+            HIP_TRY(hipEventRecord(e0, st));
+            for (int r = 0; r < 3; ++r) HIP_TRY(launch_ot_resident(p, nch, rpw, st));
+            HIP_TRY(hipEventRecord(e1, st));
+            HIP_TRY(hipEventSynchronize(e1));
+            HIP_TRY(hipEventElapsedTime(&tt[k], e0, e1));
+        }
+        t = (tt[1] - tt[0]) / 3.f / iterations;
+    } else {
+        OtBuffers o;
+        ot_layout(c, n, n, &o);
+        HIP_TRY(launch_ot_iterations(batch, n, n, 2, o, st));   // warm
+        HIP_TRY(hipEventRecord(e0, st));
+        HIP_TRY(launch_ot_iterations(batch, n, n, iterations, o, st));
+        HIP_TRY(hipEventRecord(e1, st));
+        HIP_TRY(hipEventSynchronize(e1));
+        HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+        t /= iterations;
+    }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    *ms = t / (2.f * iterations);
+    *ms = t;          // milliseconds per Sinkhorn ITERATION
+    return IMP_OK;
+}
+
+int imp_resident_status(imp_ctx* c, int* status, int* used) {
+    if (!c || !status) return fail(IMP_E_ARG, "imp_resident_status: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    *status = 0;
+    if (used) *used = c->xstatus != nullptr;
+    if (c->xstatus) HIP_TRY(hipMemcpy(status, c->xstatus, sizeof(int), hipMemcpyDeviceToHost));
     return IMP_OK;
 }
 

@@ -163,3 +163,25 @@ hipError_t launch_pool_select(const PoolSide sides[2], int nsides, float thr, in
 hipError_t launch_attn_mass_normalize(const float* colsum, int n, float* out, hipStream_t stream);
 hipError_t launch_gather_rows(const float* in, const int64_t* ids, float* out, int batch, int n_in, int n_out, int dim,
                               hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// chip-resident Sinkhorn: row softmax + T iterations + scores + maxima in ONE launch (ot_resident.hip)
+// ------------------------------------------------------------------------------------------------
+struct OtResidentParams {
+    const float* dist;        // [B][n0][n1]
+    int B, n0, n1, T, G;      // G workgroups per pair
+    float bin;
+    float* xpart;             // [B][G][ldx]     exchanged column partial sums
+    float* xv;                // [B][ldx]        exchanged v (inner columns | dustbin column)
+    float* xmax;              // [B][G][2][ldx]  exchanged column maxima (values | row indices); used only with max0
+    unsigned* counters;       // [B][32]         [0] barrier arrivals, [1] exits; zero before the first launch, self re-arming
+    int* status;              // device flag, set to 1 when a barrier timed out
+    float* u; int ldu;        // optional outputs in the layout of OtBuffers (u [B][ldu], v [B][ldv]); v is required with u
+    float* v; int ldv;
+    float* scores;            // optional [B][n0+1][n1+1]
+    float* max0; int* arg0;   // optional row / column maxima of the inner block (all four or none)
+    float* max1; int* arg1;
+};
+int ot_resident_plan(int batch, int n0, int n1, int max_wgs, int* nch, int* rpw, int* G);
+size_t ot_resident_ldx(int nch);
+hipError_t launch_ot_resident(const OtResidentParams& p, int nch, int rpw, hipStream_t stream);

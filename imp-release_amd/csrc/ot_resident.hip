@@ -1,0 +1,442 @@
+// Chip-resident Sinkhorn (nets/layers.py:27-46 + nets/gm.py:305-307), gfx950.
+//
+// The streaming path (ot.hip) reads the (N+1)x(M+1) matrix from HBM/LLC once per iteration through two dependent
+// launches: 19 us per iteration at B = 4, N = 2048, 200 launches per pair batch.  But the matrix FITS ON THE CHIP: 4 pairs
+// x 2048 x 2048 fp32 = 64 MiB = 128 VGPRs of every lane of a 512-thread workgroup on each of the 256 CUs.  This kernel
+// keeps it there for all T iterations: ONE launch computes the row softmax of the dustbin-augmented matrix straight from
+// the distance matrix into registers, runs the T iterations exchanging only vectors between workgroups, and finishes with
+// the scores and the row / column maxima - P never exists in memory.
+//
+// Decomposition: a pair's real rows are split over G workgroups (8 waves x RPW rows each); a lane owns NCH float4 chunks
+// of each of its rows (columns 4 (lane + 64 c) .. +3).  The dustbin COLUMN is one scalar per row; the dustbin ROW is the
+// constant 1 / (n1 + 1) (softmax of a constant row) and is never stored.  One iteration:
+//   A  u_i = 1 / (P_i . v + eps) for the own rows, column partials += P_i u_i          (registers + v from LDS)
+//   B  8 waves' partials summed in LDS -> the workgroup's partial vector -> memory      (write-through stores)
+//   -- group barrier --
+//   C  every workgroup sums ITS SLICE of columns over the G partial vectors (fixed order), adds the dustbin row,
+//      v_j = c_j / (. + eps) -> memory
+//   -- group barrier --
+//   D  every workgroup reads v
+// Group barrier (tools/probe/barrier2_probe.hip, measured on MI355X: 1.0 - 1.3 us across the 8 XCDs against ~8 us with
+// __threadfence): the exchanged vectors move with sc1 (agent-scope, write-through / cache-bypassing) buffer accesses, a
+// thread's stores are acknowledged by s_waitcnt vmcnt(0) before the workgroup barrier, and the counter is a relaxed
+// agent-scope atomic - no L2 write-back anywhere.  Spins are bounded: a timed-out barrier raises *status and goes on
+// (garbage results, never a hang).  All workgroups of a launch must be co-resident: the host launches at most one workgroup per CU and serialises
+// resident launches of a device on one lane stream (context.hip), so two of them can never hold each other's CUs.
+//
+// Fixed summation orders, no float atomics: bit-reproducible run to run.  Values differ from the streaming path in the last
+// bits (another summation order); both paths are checked against the same fixtures.
+#include "imp_kernels.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr float OT_EPS = 1e-8f;      // nets/layers.py:13
+constexpr int AUX_SC1 = 16;          // gfx940+ cache policy bit: agent-scope coherent access (what a relaxed agent atomic uses)
+constexpr int SPIN_LIMIT = 1 << 22;   // ~2-4 s of polling; after the first time-out every later barrier of the launch falls through
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {     // first index wins on ties (torch.max)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o);
+        const int oi = __shfl_xor(i, o);
+        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+    }
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 ld4_sc1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, AUX_SC1);
+    return f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
+}
+__device__ __forceinline__ void st4_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, const f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
+                                           r, byte_off, 0, AUX_SC1);
+}
+__device__ __forceinline__ void st1_sc1(__amdgpu_buffer_rsrc_t r, int byte_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, byte_off, 0, AUX_SC1);
+}
+
+// all workgroups of a group arrive; `target` = arrivals expected so far in this launch
+__device__ __forceinline__ void group_barrier(unsigned* counter, unsigned target, int* status) {
+    __builtin_amdgcn_s_waitcnt(0);            // this thread's write-through stores are acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? SPIN_LIMIT : 0;
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spins > SPIN_LIMIT) { __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __syncthreads();
+}
+
+template <int NCH, int RPW>
+__global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentParams p) {
+    constexpr int DCOL = 256 * NCH;            // exchange vectors: inner columns | dustbin column | 3 pads
+    constexpr int LDX = DCOL + 4;
+    constexpr int NQ = LDX / 4;                // float4 chunks of an exchange vector
+    constexpr int ROWS = 8 * RPW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* vs = lds;                           // [LDX]      current v
+    float* red = lds + LDX;                    // [8][LDX]   wave partials / staging (sized by the launcher)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = p.G;
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int n0 = p.n0, n1 = p.n1;
+    const int r0 = g * ROWS + wave * RPW;
+    unsigned* counter = p.counters + b * 32;
+    unsigned nbar = 0;
+
+    const __amdgpu_buffer_rsrc_t rs_part = make_rsrc(p.xpart + (size_t)b * G * LDX, (unsigned)((size_t)G * LDX * 4));
+    const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(p.xv + (size_t)b * LDX, (unsigned)(LDX * 4));
+
+    // ---- row softmax of the dustbin-augmented matrix (nets/layers.py:39-40,28) straight into registers -----------
+    f32x4 P[RPW][NCH];
+    float Pd[RPW];
+    const float bin = p.bin;
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+        const int r = r0 + k;
+        const bool rv = r < n0;
+        const float* drow = p.dist + ((size_t)b * n0 + (rv ? r : 0)) * n1;
+        float mx = bin;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int j = 4 * (lane + 64 * c);
+            f32x4 x;
+            if (rv && j + 3 < n1 && (n1 & 3) == 0) {
+                x = *reinterpret_cast<const f32x4*>(drow + j);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[e] = (rv && j + e < n1) ? drow[j + e] : -INFINITY;
+            }
+            P[k][c] = x;
+            mx = fmaxf(mx, fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ev = expf(P[k][c][e] - mx);        // exp(-inf) = 0 for columns past n1 / rows past n0
+                P[k][c][e] = ev;
+                sum += ev;
+            }
+        const float ed = expf(bin - mx);
+        sum = wave_sum(sum) + ed;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) P[k][c][e] = rv ? P[k][c][e] / sum : 0.f;
+        Pd[k] = rv ? ed / sum : 0.f;
+    }
+    const float c0 = 1.0f / (float)(n1 + 1);   // every entry of the dustbin row: softmax of n1 + 1 equal logits
+
+    // start vectors (nets/layers.py:29-30): u = 1, v = 1
+    for (int j = tid; j < LDX; j += 512) vs[j] = (j < n1 || j == DCOL) ? 1.f : 0.f;
+    float vsum = (float)(n1 + 1);              // sum of v over the n1 + 1 real columns
+    float u[RPW];
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) u[k] = (r0 + k < n0) ? 1.f : 0.f;
+    float u_last = 1.f;
+    __syncthreads();
+
+    const int cq = (NQ + G - 1) / G;           // float4 chunks of the exchange vector owned by one workgroup
+    for (int it = 0; it < p.T; ++it) {
+        // ---- A: u for the own rows, column partials ---------------------------------------------------------------
+        float acc[RPW];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(vs + 4 * (lane + 64 * c));
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) {
+                acc[k] = fmaf(P[k][c][0], x[0], acc[k]);
+                acc[k] = fmaf(P[k][c][1], x[1], acc[k]);
+                acc[k] = fmaf(P[k][c][2], x[2], acc[k]);
+                acc[k] = fmaf(P[k][c][3], x[3], acc[k]);
+            }
+        }
+        const float vd = vs[DCOL];
+        float pdpart = 0.f;
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const float s = fmaf(Pd[k], vd, wave_sum(acc[k]));
+            u[k] = (r0 + k < n0) ? 1.f / (s + OT_EPS) : 0.f;          // real rows have marginal 1 (nets/layers.py:32,41)
+            pdpart = fmaf(Pd[k], u[k], pdpart);
+        }
+        u_last = (float)(n0 + 1) / (c0 * vsum + OT_EPS);              // dustbin row: marginal n0 + 1 (nets/layers.py:42)
+        // ---- B: workgroup partial vector ---------------------------------------------------------------------------
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            f32x4 part = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < RPW; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part[e] = fmaf(P[k][c][e], u[k], part[e]);
+            *reinterpret_cast<f32x4*>(red + wave * LDX + 4 * (lane + 64 * c)) = part;
+        }
+        if (lane == 0) *reinterpret_cast<f32x4*>(red + wave * LDX + DCOL) = f32x4{pdpart, 0.f, 0.f, 0.f};
+        __syncthreads();
+        for (int q = tid; q < NQ; q += 512) {
+            f32x4 s = *reinterpret_cast<const f32x4*>(red + 4 * q);
+#pragma unroll
+            for (int w = 1; w < 8; ++w) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(red + w * LDX + 4 * q);
+                s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+            }
+            st4_sc1(rs_part, (g * LDX + 4 * q) * 4, s);
+        }
+        nbar += G;
+        group_barrier(counter, nbar, p.status);
+        // ---- C: this workgroup's slice of columns over the G partial vectors -------------------------------------
+        {
+            f32x4* stage = reinterpret_cast<f32x4*>(red);             // [G][cq]
+            for (int idx = tid; idx < cq * G; idx += 512) {
+                const int w = idx / cq, qq = idx - w * cq;
+                const int q = g * cq + qq;
+                stage[idx] = q < NQ ? ld4_sc1(rs_part, (w * LDX + 4 * q) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            __syncthreads();
+            // 8 threads per column, each over a contiguous eighth of the workgroups; then combined in order
+            float* sub = red + (size_t)cq * G * 4;                    // [8][4 cq]
+            const int ncol = 4 * cq;
+            const int seg = (G + 7) / 8;
+            for (int t = tid; t < 8 * ncol; t += 512) {
+                const int h = t / ncol, cl = t - h * ncol;
+                const int qq = cl >> 2, e = cl & 3;
+                float s = 0.f;
+                const int w1 = min(G, (h + 1) * seg);
+                for (int w = h * seg; w < w1; ++w) s += red[(size_t)(w * cq + qq) * 4 + e];
+                sub[h * ncol + cl] = s;
+            }
+            __syncthreads();
+            for (int cl = tid; cl < ncol; cl += 512) {
+                float s = sub[cl];
+#pragma unroll
+                for (int h = 1; h < 8; ++h) s += sub[h * ncol + cl];
+                const int xi = 4 * (g * cq) + cl;                     // index in the exchange layout
+                if (xi < LDX) {
+                    const bool dust = xi == DCOL;
+                    const bool real = xi < n1 || dust;
+                    const float t = fmaf(c0, u_last, s);              // + dustbin row entry * its u
+                    const float marg = dust ? (float)(n1 + 1) : 1.f;  // nets/layers.py:43-44
+                    st1_sc1(rs_v, xi * 4, real ? marg / (t + OT_EPS) : 0.f);
+                }
+            }
+        }
+        nbar += G;
+        group_barrier(counter, nbar, p.status);
+        // ---- D: everybody reads v -----------------------------------------------------------------------------------
+        for (int q = tid; q < NQ; q += 512) *reinterpret_cast<f32x4*>(vs + 4 * q) = ld4_sc1(rs_v, 16 * q);
+        __syncthreads();
+        {   // sum of v (every wave computes the same value in the same order: no further barrier)
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(vs + 4 * (lane + 64 * c));
+                s += (x[0] + x[1]) + (x[2] + x[3]);
+            }
+            vsum = wave_sum(s) + vs[DCOL];
+        }
+    }
+
+    // ---- outputs ----------------------------------------------------------------------------------------------------
+    const float vd = vs[DCOL];
+    if (p.u) {
+        if (lane == 0)
+#pragma unroll
+            for (int k = 0; k < RPW; ++k)
+                if (r0 + k < n0) p.u[(size_t)b * p.ldu + r0 + k] = u[k];
+        if (g == 0) {
+            if (tid == 0) p.u[(size_t)b * p.ldu + n0] = u_last;
+            for (int j = tid; j < n1; j += 512) p.v[(size_t)b * p.ldv + j] = vs[j];
+            if (tid == 0) p.v[(size_t)b * p.ldv + n1] = vd;
+        }
+    }
+    const bool want_max = p.max0 != nullptr;
+    float* rowbuf = red + wave * LDX;                  // per-wave staging of one score row
+    __syncthreads();                                   // `red` is free again
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+        const int r = r0 + k;
+        if (r >= n0) continue;                         // wave-uniform
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(vs + 4 * (lane + 64 * c));
+            f32x4 s;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s[e] = (P[k][c][e] * u[k]) * x[e];     // (p * u) * v as nets/layers.py:34
+                const int j = 4 * (lane + 64 * c) + e;
+                if (j < n1 && s[e] > best) { best = s[e]; bi = j; }      // ascending j inside the lane: first wins
+            }
+            if (p.scores) *reinterpret_cast<f32x4*>(rowbuf + 4 * (lane + 64 * c)) = s;
+        }
+        if (want_max) {
+            wave_argmax(best, bi);
+            if (lane == 0) { p.max0[(size_t)b * n0 + r] = best; p.arg0[(size_t)b * n0 + r] = bi; }
+        }
+        if (p.scores) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float* srow = p.scores + ((size_t)b * (n0 + 1) + r) * (n1 + 1);
+            for (int j = lane; j < n1; j += 64) srow[j] = rowbuf[j];       // lane-linear dword stores
+            if (lane == 0) srow[n1] = (Pd[k] * u[k]) * vd;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (p.scores && g == 0) {                          // dustbin row of the score tensor
+        float* srow = p.scores + ((size_t)b * (n0 + 1) + n0) * (n1 + 1);
+        for (int j = tid; j < n1; j += 512) srow[j] = (c0 * u_last) * vs[j];
+        if (tid == 0) srow[n1] = (c0 * u_last) * vd;
+    }
+    if (want_max) {
+        // column maxima of the SAME expression (bit-identical values on both sides of the mutual check).  The waves take
+        // turns in ascending order (= ascending rows; strict > keeps the first row on ties) on one LDS vector, then the
+        // workgroup vectors are combined across the group like the column sums.
+        __syncthreads();
+        float* mv = red;                               // [LDX] values
+        int* mi = reinterpret_cast<int*>(red + LDX);   // [LDX] row indices
+        for (int w = 0; w < 8; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(vs + 4 * (lane + 64 * c));
+                    f32x4 cb;
+                    int ci[4];
+                    if (w == 0) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { cb[e] = -INFINITY; ci[e] = 0x7fffffff; }
+                    } else {
+                        cb = *reinterpret_cast<const f32x4*>(mv + 4 * (lane + 64 * c));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ci[e] = mi[4 * (lane + 64 * c) + e];
+                    }
+#pragma unroll
+                    for (int k = 0; k < RPW; ++k)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float sv = (P[k][c][e] * u[k]) * x[e];
+                            if (r0 + k < n0 && sv > cb[e]) { cb[e] = sv; ci[e] = r0 + k; }
+                        }
+                    *reinterpret_cast<f32x4*>(mv + 4 * (lane + 64 * c)) = cb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mi[4 * (lane + 64 * c) + e] = ci[e];
+                }
+            }
+            __syncthreads();
+        }
+        const __amdgpu_buffer_rsrc_t rs_mx = make_rsrc(p.xmax + (size_t)b * G * 2 * LDX, (unsigned)((size_t)G * 2 * LDX * 4));
+        for (int q = tid; q < DCOL / 4; q += 512) {
+            st4_sc1(rs_mx, (g * 2 * LDX + 4 * q) * 4, *reinterpret_cast<const f32x4*>(mv + 4 * q));
+            st4_sc1(rs_mx, (g * 2 * LDX + LDX + 4 * q) * 4, *reinterpret_cast<const f32x4*>(red + LDX + 4 * q));
+        }
+        nbar += G;
+        group_barrier(counter, nbar, p.status);
+        const int ncq = (DCOL / 4 + G - 1) / G;        // float4 column chunks per workgroup
+        f32x4* stage = reinterpret_cast<f32x4*>(red);  // [2][G][ncq]
+        for (int idx = tid; idx < 2 * ncq * G; idx += 512) {
+            const int which = idx / (ncq * G), rem = idx - which * ncq * G;
+            const int w = rem / ncq, qq = rem - w * ncq;
+            const int q = g * ncq + qq;
+            stage[idx] = q < DCOL / 4 ? ld4_sc1(rs_mx, (w * 2 * LDX + which * LDX + 4 * q) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+        for (int cl = tid; cl < 4 * ncq; cl += 512) {
+            const int j = 4 * (g * ncq) + cl;
+            if (j < n1) {
+                const int qq = cl >> 2, e = cl & 3;
+                float best = -INFINITY;
+                int bi = 0x7fffffff;
+                for (int w = 0; w < G; ++w) {          // ascending workgroups = ascending rows
+                    const float ov = red[(size_t)(w * ncq + qq) * 4 + e];
+                    const int oi = __float_as_int(red[(size_t)((G + w) * ncq + qq) * 4 + e]);
+                    if (ov > best) { best = ov; bi = oi; }
+                }
+                p.max1[(size_t)b * n1 + j] = best;
+                p.arg1[(size_t)b * n1 + j] = bi;
+            }
+        }
+    }
+    // ---- leave: the last workgroup of the group to get here re-arms the counters for the next launch ------------------
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(counter + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)G - 1) {
+            __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+template <int NCH, int RPW>
+hipError_t launch_one(const OtResidentParams& p, hipStream_t stream) {
+    constexpr int LDX = 256 * NCH + 4;
+    const int cq = (LDX / 4 + p.G - 1) / p.G;
+    // vs + max(8 wave vectors, slice staging [G][cq] float4 + [8][4 cq])
+    size_t red = (size_t)8 * LDX;
+    const size_t stage = (size_t)cq * p.G * 4 + (size_t)8 * 4 * cq;
+    if (stage > red) red = stage;
+    const size_t stage2 = (size_t)2 * p.G * ((256 * NCH / 4 + p.G - 1) / p.G) * 4;     // column-maxima staging
+    if (stage2 > red) red = stage2;
+    const size_t lds = (LDX + red) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute((const void*)ot_resident_kernel<NCH, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ot_resident_kernel<NCH, RPW>), dim3(p.B * p.G), dim3(512), lds, stream, p);
+    return hipGetLastError();
+}
+
+struct Shape { int nch, rpw; };
+// (NCH, RPW) instantiations; NCH * RPW <= 32 float4 = 128 VGPRs of matrix per lane
+constexpr Shape kShapes[] = {{2, 2}, {2, 4}, {2, 8}, {4, 2}, {4, 4}, {4, 8}, {6, 2}, {6, 4}, {8, 2}, {8, 4}, {12, 2}, {16, 1}};
+// ((2, 16) and (16, 2) would also hold 128 matrix registers but spill at the 256-VGPR budget of 2 waves per SIMD)
+
+}  // namespace
+
+// Picks the decomposition: the narrowest column class that holds n1, then the FEWEST rows per wave that still fits the
+// launch on `max_wgs` workgroups (more workgroups = more CUs streaming the distance matrix in and the scores out).
+// Returns 0 when the problem does not fit on the chip (the caller falls back to the streaming path).
+int ot_resident_plan(int batch, int n0, int n1, int max_wgs, int* nch, int* rpw, int* G) {
+    if (batch <= 0 || n0 <= 0 || n1 <= 0) return 0;
+    int cls = 0;
+    for (const Shape& s : kShapes)
+        if (256 * s.nch >= n1) { cls = s.nch; break; }            // kShapes ascends in nch, then in rpw
+    if (!cls) return 0;
+    for (const Shape& s : kShapes) {
+        if (s.nch != cls) continue;
+        const int g = (n0 + 8 * s.rpw - 1) / (8 * s.rpw);
+        if ((long)g * batch <= max_wgs) { *nch = s.nch; *rpw = s.rpw; *G = g; return 1; }
+    }
+    return 0;        // the widest row count of the class still needs more workgroups than there are CUs
+}
+
+size_t ot_resident_ldx(int nch) { return (size_t)256 * nch + 4; }
+
+hipError_t launch_ot_resident(const OtResidentParams& p, int nch, int rpw, hipStream_t stream) {
+#define IMP_OTR(N, R) if (nch == N && rpw == R) return launch_one<N, R>(p, stream)
+    IMP_OTR(2, 2); IMP_OTR(2, 4); IMP_OTR(2, 8); IMP_OTR(4, 2); IMP_OTR(4, 4); IMP_OTR(4, 8);
+    IMP_OTR(6, 2); IMP_OTR(6, 4); IMP_OTR(8, 2); IMP_OTR(8, 4); IMP_OTR(12, 2); IMP_OTR(16, 1);
+#undef IMP_OTR
+    return hipErrorInvalidValue;
+}

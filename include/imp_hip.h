@@ -200,8 +200,14 @@ int imp_op_attention(imp_ctx* ctx, int batch, int nq, int nk, int dim, const flo
 /* timing hooks for bench.py: hipEvent-bracketed repetition of one attention / one Sinkhorn pass on
  * the context's own stream-ordered workspace; returns average milliseconds per launch in *ms. */
 int imp_time_attention(imp_ctx* ctx, int batch, int n, int reps, float* ms, void* stream);
-/* same for the Sinkhorn row pass: 2*iterations launches over [batch][n+1][n+1]; *ms = average per launch */
+/* same for the Sinkhorn iterations (nets/layers.py:31-33) over [batch][n+1][n+1] on the path the product takes for that
+ * shape (chip-resident kernel: time(T iterations) - time(0 iterations); streaming path: 2 launches per iteration);
+ * *ms = average milliseconds per ITERATION */
 int imp_time_sinkhorn(imp_ctx* ctx, int batch, int n, int iterations, float* ms, void* stream);
+/* chip-resident Sinkhorn health (ot_resident.hip): *status != 0 when a group barrier ever timed out on this context
+ * (results of that call are then garbage - never observed; the spin is bounded so that it cannot hang); *used = whether
+ * the resident path has been taken at all.  Synchronises. */
+int imp_resident_status(imp_ctx* ctx, int* status, int* used);
 
 #ifdef __cplusplus
 }

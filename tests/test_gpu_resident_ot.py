@@ -1,0 +1,160 @@
+"""GPU: the chip-resident Sinkhorn kernel (csrc/ot_resident.hip; nets/layers.py:27-46 + nets/gm.py:305-307) - every
+register-shape class, ragged shapes, T = 0, batches, the fused maxima, and agreement with the streaming path."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import compare_matches, eval_config, make_hip_model
+from imp_release_amd import synthetic
+from oracle import imp_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _ctx_pair():
+    """two contexts on the same weights: chip-resident Sinkhorn (default) and the streaming path (IMP_OT_RESIDENT=0)"""
+    cfg = eval_config(n_layers=2)
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=5)
+    res = make_hip_model('GM', cfg, sd)
+    res._ensure_ctx()
+    os.environ['IMP_OT_RESIDENT'] = '0'
+    try:
+        stream = make_hip_model('GM', cfg, sd)
+        stream._ensure_ctx()
+    finally:
+        del os.environ['IMP_OT_RESIDENT']
+    return cfg, sd, res, stream
+
+
+@pytest.fixture(scope='module')
+def ctxs():
+    return _ctx_pair()
+
+
+def _dist(B, n0, n1, seed):
+    g = torch.Generator().manual_seed(seed)
+    d = torch.randn(B, n0, n1, generator=g) * 2.0
+    k = min(n0, n1) // 2
+    for b in range(B):
+        ids = torch.randperm(min(n0, n1), generator=torch.Generator().manual_seed(seed + b))[:k]
+        d[b, ids, ids] += 6.0
+    return d
+
+
+# (n0, n1, T, B): every column class (n1 <= 512, 1024, 1536, 2048, 3072, 4096), rows that do / do not fill the last wave,
+# a single row / column, T = 0, and shapes beyond the chip (fallback to the streaming path inside the same entry point)
+SHAPES = [(64, 64, 20, 2), (1, 5, 3, 1), (5, 1, 3, 2), (300, 307, 100, 2), (255, 256, 20, 3), (513, 511, 20, 1),
+          (1024, 1000, 100, 1), (1030, 1025, 50, 2), (1500, 1536, 20, 1), (2048, 2048, 100, 1), (2047, 2049, 20, 2),
+          (2600, 2563, 20, 1), (1000, 3072, 20, 1), (1900, 4000, 10, 1), (130, 97, 0, 2), (2048, 2048, 7, 4),
+          (3400, 3500, 6, 2), (700, 4100, 4, 1)]
+
+
+@pytest.mark.parametrize('n0,n1,T,B', SHAPES)
+def test_scores_vs_oracle_and_streaming_path(ctxs, n0, n1, T, B):
+    cfg, sd, res, stream = ctxs
+    dist = _dist(B, n0, n1, seed=n0 + n1)
+    bin_score = 1.3
+    got = res._ensure_ctx().compute_score(dist.to(DEV), bin_score, T, True)
+    old = stream._ensure_ctx().compute_score(dist.to(DEV), bin_score, T, True)
+    assert not res._ensure_ctx().resident_status()[0], 'a group barrier timed out'
+    aug = orc.dustbin_augment(dist, torch.tensor(bin_score))
+    ref = orc.sinkhorn(aug, T)
+    for name, x in (('resident', got), ('streaming', old)):
+        err = ((x.cpu() - ref).abs() - 5e-7 * ref.abs()).max().item()     # dustbin corner holds O(N) mass
+        assert err < 2e-5, f'{name} compute_score err {err:.3e}'
+    assert ((got - old).abs() - 5e-7 * old.abs()).max().item() < 2e-5
+    # after the last step every column meets its marginal - for near-balanced shapes: with n1 >> n0 the
+    # marginals are infeasible, u collapses to the eps scale and c * t / (t + eps) < c in the reference as well
+    if T > 0 and max(n0, n1) <= 1.3 * min(n0, n1) and min(n0, n1) > 8:
+        cs = got.double().sum(1).cpu()
+        assert (cs[:, :-1] - 1).abs().max().item() < 1e-4 and (cs[:, -1] - (n1 + 1)).abs().max().item() < 2e-3
+    # bit-reproducible
+    again = res._ensure_ctx().compute_score(dist.to(DEV), bin_score, T, True)
+    assert torch.equal(got, again)
+
+
+def test_resident_path_is_the_one_taken(ctxs):
+    cfg, sd, res, stream = ctxs
+    d = _dist(1, 300, 300, 1).to(DEV)
+    res._ensure_ctx().compute_score(d, 1.0, 5, True)
+    stream._ensure_ctx().compute_score(d, 1.0, 5, True)
+    assert res._ensure_ctx().resident_status() == (False, True)
+    assert stream._ensure_ctx().resident_status() == (False, False)
+
+
+@pytest.mark.parametrize('n0,n1,B,T', [(320, 300, 2, 20), (1024, 1024, 1, 100), (2048, 2048, 4, 100), (2047, 1999, 3, 20),
+                                       (700, 1300, 2, 0)])
+def test_fused_maxima_equal_the_maxima_of_the_score_tensor(n0, n1, B, T):
+    """imp_match_pair takes row AND column maxima inside the resident kernel: they must be exactly the matches
+    compute_matches derives from the score tensor of the same call (same expression (p*u)*v, first index on ties)"""
+    cfg = eval_config(n_layers=1, sinkhorn_iterations=T)
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=3)
+    m = make_hip_model('GM', cfg, sd)
+    pair = synthetic.make_correlated_pair(n0, n1, seed=n0 + B, batch=B)
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+    with torch.no_grad():
+        out = m.produce_matches(data, p=0.2, only_last=True)          # fused call: maxima from the resident kernel
+    score = out['scores'][-1]
+    r0, r1, rm0, rm1 = orc.compute_matches(score.cpu(), 0.2)
+    assert torch.equal(out['indices0'][-1].cpu(), r0) and torch.equal(out['mscores0'][-1].cpu(), rm0)
+    i0, i1, m0, m1 = m.compute_matches(score, 0.2)
+    assert torch.equal(i0.cpu(), r0) and torch.equal(i1.cpu(), r1)
+    assert m._ensure_ctx().resident_status() == (False, True)
+
+
+def test_column_maximum_ties_keep_the_first_row(ctxs):
+    """two bit-identical rows: torch.max over dim 1 returns the first row for every column"""
+    cfg, sd, res, stream = ctxs
+    cfg1 = eval_config(n_layers=1, sinkhorn_iterations=10)
+    sd1 = synthetic.make_state_dict(cfg1, 'GM', seed=3)
+    m = make_hip_model('GM', cfg1, sd1)
+    pair = synthetic.make_correlated_pair(300, 280, seed=5)
+    for k in ('keypoints0', 'scores0', 'descriptors0'):
+        pair[k][0, 77] = pair[k][0, 13]            # keypoint 77 duplicates keypoint 13 (different waves / workgroups)
+        pair[k][0, 299] = pair[k][0, 13]
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+    with torch.no_grad():
+        out = m.produce_matches(data, p=0.0, only_last=True)
+    score = out['scores'][-1]
+    r0, r1, rm0, rm1 = orc.compute_matches(score.cpu(), 0.0)
+    assert torch.equal(out['indices0'][-1].cpu(), r0) and torch.equal(out['mscores0'][-1].cpu(), rm0)
+    i0 = out['indices0'][-1][0].cpu()
+    assert i0[77] == -1 and i0[299] == -1 or i0[13] == -1     # at most the FIRST of the identical rows can be mutual
+
+
+def test_pairs_in_flight_share_the_resident_lane():
+    """3 replicas on 3 streams and host threads all launch resident kernels: the device-wide lane serialises them (two
+    resident kernels dispatched concurrently could hold each other's CUs); results equal the sequential ones"""
+    from imp_release_amd import eval_loop, pipeline
+    cfg = eval_config(n_layers=1, sinkhorn_iterations=30)
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=1)
+    m = make_hip_model('GM', cfg, sd)
+    datas = []
+    for k in range(3):
+        pair = synthetic.make_correlated_pair(2048, 2000, seed=260 + k, batch=4)
+        d = {kk: torch.from_numpy(v).to(DEV) for kk, v in pair.items() if kk != 'image_shape'}
+        d['image0'] = d['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+        datas.append(d)
+
+    def make_fn(model, start, stride):
+        st = {'s': start}
+
+        def fn():
+            d = datas[st['s'] % len(datas)]
+            st['s'] += stride
+            out = model.produce_matches(d, p=0.2, only_last=True)
+            return out['indices0'][-1], out['mscores0'][-1]
+        return fn
+
+    seq = pipeline.StepPipeline([make_fn(m, 0, 1)], 4, device=DEV).run(9, keep=True)
+    reps = eval_loop.replicate(m, 3)
+    par = pipeline.StepPipeline([make_fn(r, i, 3) for i, r in enumerate(reps)], 4, device=DEV).run(9, keep=True)
+    for a, b in zip(seq, par):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for r in reps:
+        assert r._ensure_ctx().resident_status() == (False, True)
