@@ -73,7 +73,7 @@ struct imp_ctx {
     int ot_resident = 1;      // IMP_OT_RESIDENT=0 forces the streaming path
     int num_cus = 0;
     float *xpart = nullptr, *xv = nullptr, *xmax = nullptr;
-    unsigned* xcounters = nullptr;
+    unsigned xtag = 0;       // tag base of the next resident launch (tags must never repeat on the exchange buffers)
     int* xstatus = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     int xcap_b = 0;
@@ -497,19 +497,37 @@ int ensure_resident_buffers(imp_ctx* c, int batch) {
     int rc = 0;
     const int cap = batch < 8 ? 8 : batch;
     if (!c->xpart) {
-        rc = dev_alloc(c, c->allocs_x, &c->xpart, wgs * kResidentMaxLdx);
-        if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xmax, 2 * wgs * kResidentMaxLdx);
+        rc = dev_alloc(c, c->allocs_x, &c->xpart, 2 * wgs * kResidentMaxLdx);
+        if (!rc) HIP_TRY(hipMemset(c->xpart, 0, 2 * wgs * kResidentMaxLdx * sizeof(float)));     // tag 0 = never written
+        if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xmax, 4 * wgs * kResidentMaxLdx);
+        if (!rc) HIP_TRY(hipMemset(c->xmax, 0, 4 * wgs * kResidentMaxLdx * sizeof(float)));
         if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xstatus, 4);
         if (!rc) HIP_TRY(hipMemset(c->xstatus, 0, 16));
         if (!rc) HIP_TRY(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
         if (!rc) HIP_TRY(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
     }
-    if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xv, (size_t)cap * kResidentMaxLdx);
-    if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xcounters, (size_t)cap * 32);
-    if (!rc) HIP_TRY(hipMemset(c->xcounters, 0, (size_t)cap * 32 * sizeof(unsigned)));
+    if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xv, 2 * (size_t)cap * kResidentMaxLdx);
+    if (!rc) HIP_TRY(hipMemset(c->xv, 0, 2 * (size_t)cap * kResidentMaxLdx * sizeof(float)));
     if (rc) return rc;
     c->xcap_b = cap;
     return IMP_OK;
+}
+
+// reserves the tags of one launch.  Tags must never repeat on the exchange buffers; when the 32-bit counter is about to
+// wrap (after ~20 million launches) the buffers are cleared and the count restarts.
+unsigned resident_tags(imp_ctx* c, int iterations) {
+    const unsigned need = 2u * (unsigned)iterations + 4u;
+    if (c->xtag > 0xFFFFFFFFu - need - 8u) {
+        (void)hipDeviceSynchronize();
+        const size_t wgs = (size_t)c->num_cus;
+        (void)hipMemset(c->xpart, 0, 2 * wgs * kResidentMaxLdx * sizeof(float));
+        (void)hipMemset(c->xmax, 0, 4 * wgs * kResidentMaxLdx * sizeof(float));
+        (void)hipMemset(c->xv, 0, 2 * (size_t)c->xcap_b * kResidentMaxLdx * sizeof(float));
+        c->xtag = 0;
+    }
+    const unsigned base = c->xtag;
+    c->xtag += need;
+    return base;
 }
 
 // the resident launch on the device's lane, joined to `st` on both sides; returns IMP_OK, or >0 when not applicable
@@ -527,7 +545,8 @@ int run_score_resident(imp_ctx* c, int batch, int n0, int n1, const float* dist,
     OtResidentParams p;
     memset(&p, 0, sizeof p);
     p.dist = dist; p.B = batch; p.n0 = n0; p.n1 = n1; p.T = iterations; p.G = G; p.bin = bin;
-    p.xpart = c->xpart; p.xv = c->xv; p.xmax = c->xmax; p.counters = c->xcounters; p.status = c->xstatus;
+    p.xpart = c->xpart; p.xv = c->xv; p.xmax = c->xmax; p.status = c->xstatus;
+    p.tag_base = resident_tags(c, iterations);
     if (want_uv) { p.u = c->ot.u; p.ldu = (n0 + 1 + 3) & ~3; p.v = c->ot.v; p.ldv = (n1 + 1 + 3) & ~3; }
     p.scores = scores;
     if (want_max) { p.max0 = c->max0; p.arg0 = c->arg0; p.max1 = c->max1; p.arg1 = c->arg1; }
@@ -1047,13 +1066,17 @@ int imp_time_sinkhorn(imp_ctx* c, int batch, int n, int iterations, float* ms, v
         OtResidentParams p;
         memset(&p, 0, sizeof p);
         p.dist = c->dist; p.B = batch; p.n0 = n; p.n1 = n; p.G = G; p.bin = 1.f;
-        p.xpart = c->xpart; p.xv = c->xv; p.xmax = c->xmax; p.counters = c->xcounters; p.status = c->xstatus;
+        p.xpart = c->xpart; p.xv = c->xv; p.xmax = c->xmax; p.status = c->xstatus;
         float tt[2];
         for (int k = 0; k < 2; ++k) {
             p.T = k ? iterations : 0;
+            p.tag_base = resident_tags(c, p.T);
             HIP_TRY(launch_ot_resident(p, nch, rpw, st));   // warm
             HIP_TRY(hipEventRecord(e0, st));
-            for (int r = 0; r < 3; ++r) HIP_TRY(launch_ot_resident(p, nch, rpw, st));
+            for (int r = 0; r < 3; ++r) {
+                p.tag_base = resident_tags(c, p.T);
+                HIP_TRY(launch_ot_resident(p, nch, rpw, st));
+            }
             HIP_TRY(hipEventRecord(e1, st));
             HIP_TRY(hipEventSynchronize(e1));
             HIP_TRY(hipEventElapsedTime(&tt[k], e0, e1));

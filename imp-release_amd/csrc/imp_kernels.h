@@ -171,11 +171,12 @@ struct OtResidentParams {
     const float* dist;        // [B][n0][n1]
     int B, n0, n1, T, G;      // G workgroups per pair
     float bin;
-    float* xpart;             // [B][G][ldx]     exchanged column partial sums
-    float* xv;                // [B][ldx]        exchanged v (inner columns | dustbin column)
-    float* xmax;              // [B][G][2][ldx]  exchanged column maxima (values | row indices); used only with max0
-    unsigned* counters;       // [B][32]         [0] barrier arrivals, [1] exits; zero before the first launch, self re-arming
-    int* status;              // device flag, set to 1 when a barrier timed out
+    // exchange buffers of 8-byte granules {value, tag}: 2 floats per exchanged float
+    float* xpart;             // [B][G][ldx][2]     column partial sums
+    float* xv;                // [B][ldx][2]        v (inner columns | dustbin column)
+    float* xmax;              // [B][G][2][ldx][2]  column maxima (values | row indices); used only with max0
+    unsigned tag_base;        // tags of this launch are tag_base + 1 .. tag_base + 2 T + 1: never reused on these buffers
+    int* status;              // device flag, set to 1 when a wait timed out
     float* u; int ldu;        // optional outputs in the layout of OtBuffers (u [B][ldu], v [B][ldv]); v is required with u
     float* v; int ldv;
     float* scores;            // optional [B][n0+1][n1+1]
