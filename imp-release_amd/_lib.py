@@ -26,7 +26,7 @@ SYMBOLS = [
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
     'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear',
-    'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status',
+    'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_op_linear_planes', 'imp_trust_descriptor_planes',
 ]
 
 
@@ -97,6 +97,8 @@ def lib():
     L.imp_time_attention.argtypes = [P, I, I, I, C.POINTER(C.c_float), P]
     L.imp_time_sinkhorn.argtypes = [P, I, I, I, C.POINTER(C.c_float), P]
     L.imp_resident_status.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.imp_op_linear_planes.argtypes = [P, I, I, I, P, P, P, P, P, P, P]
+    L.imp_trust_descriptor_planes.argtypes = [P, I]
     _lib = L
     return L
 
@@ -377,3 +379,19 @@ class Context:
         st, used = C.c_int(), C.c_int()
         self._check(self.L.imp_resident_status(self.handle, C.byref(st), C.byref(used)))
         return bool(st.value), bool(used.value)
+
+    def trust_descriptor_planes(self, on: bool):
+        """promise (or withdraw the promise) that descriptors handed to consecutive forward_layer calls are the unmodified
+        outputs of the previous call when the tensors are the same (include/imp_hip.h imp_trust_descriptor_planes)"""
+        self._check(self.L.imp_trust_descriptor_planes(self.handle, 1 if on else 0))
+
+    def op_linear_planes(self, x, W, bias=None, residual=None, roundtrip=False):
+        x, W = _f32(x, 'x'), _f32(W, 'W')
+        M, K = x.shape
+        N = W.shape[0]
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        yp = torch.empty_like(y) if roundtrip else None
+        self._check(self.L.imp_op_linear_planes(self.handle, M, N, K, _ptr(x), _ptr(W), _ptr(None if bias is None else _f32(bias, 'bias')),
+                                                _ptr(None if residual is None else _f32(residual, 'residual')), _ptr(y), _ptr(yp),
+                                                _stream(self.device)))
+        return (y, yp) if roundtrip else y

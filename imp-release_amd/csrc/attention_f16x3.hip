@@ -51,6 +51,38 @@ __device__ __forceinline__ void split4(const f32x4 x, u32x2& hi, u32x2& lo) {
 }
 __device__ __forceinline__ int swap23(int k) { return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1); }
 
+// a wave's 32 output rows (staged in LDS as ot[row][DH]) -> memory: fp32 rows, or - out_planes - the rows as planes
+// [D hi halves | D lo halves] for the split-half GEMM that consumes them (gemm_planes.hip)
+template <int DH>
+__device__ __forceinline__ void store_attention_rows(const AttnParams& p, const AttnSide& S, int b, int h, int qbase, int nq,
+                                                     const float* ot, int ldot, int lane) {
+    const int half = lane >> 5, l31 = lane & 31;
+    constexpr int RPP = 64 / DH;                 // rows per pass: DH = 64 -> 1 (lane = channel), DH = 32 -> 2
+    if (p.out_planes) {
+        _Float16* Op = reinterpret_cast<_Float16*>(S.out) + b * S.so_b + h * DH;
+        constexpr int D = IMP_NUM_HEADS * DH;
+#pragma unroll 4
+        for (int i = 0; i < 32 / RPP; ++i) {
+            const int qi = RPP == 1 ? i : 2 * i + half, ch = RPP == 1 ? lane : l31;
+            const int qrow = qbase + qi;
+            if (qrow < nq) {
+                const float x = ot[qi * ldot + ch];
+                const _Float16 hi = (_Float16)x;
+                Op[(long)qrow * p.ldo + ch] = hi;
+                Op[(long)qrow * p.ldo + D + ch] = (_Float16)(x - (float)hi);
+            }
+        }
+        return;
+    }
+    float* Og = S.out + b * S.so_b + h * DH;
+#pragma unroll 4
+    for (int i = 0; i < 32 / RPP; ++i) {
+        const int qi = RPP == 1 ? i : 2 * i + half, ch = RPP == 1 ? lane : l31;
+        const int qrow = qbase + qi;
+        if (qrow < nq) Og[(long)qrow * p.ldo + ch] = ot[qi * ldot + ch];
+    }
+}
+
 template <int DH, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64, 2) void attn_f16x3_kernel(const AttnParams p, int qtiles, int total_blocks) {
     constexpr int NT = NWAVES * 64;
@@ -296,21 +328,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_f16x3_kernel(const AttnPa
         if (qrow < nq) S.lse[((long)b * IMP_NUM_HEADS + h) * nq + qrow] = m_run + logf(l_tot);
     }
     __syncthreads();
-    float* Og = S.out + b * S.so_b + h * DH;
-    if (DH == 64) {
-#pragma unroll 4
-        for (int i = 0; i < 32; ++i) {
-            const int qrow = q0 + wave * 32 + i;
-            if (qrow < nq) Og[(long)qrow * p.ldo + lane] = ot[i * LDO + lane];
-        }
-    } else {
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int qi = 2 * i + half;
-            const int qrow = q0 + wave * 32 + qi;
-            if (qrow < nq) Og[(long)qrow * p.ldo + l31] = ot[qi * LDO + l31];
-        }
-    }
+    store_attention_rows<DH>(p, S, b, h, q0 + wave * 32, nq, ot, LDO, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -663,21 +681,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
         if (qrow < nq) S.lse[((long)b * IMP_NUM_HEADS + h) * nq + qrow] = m_ref * (1.0f / LOG2E) + logf(l_tot);
     }
     __syncthreads();
-    float* Og = S.out + b * S.so_b + h * DH;
-    if (DH == 64) {
-#pragma unroll 4
-        for (int i = 0; i < 32; ++i) {
-            const int qrow = q0 + wave * 32 + i;
-            if (qrow < nq) Og[(long)qrow * p.ldo + lane] = ot[i * LDO + lane];
-        }
-    } else {
-#pragma unroll 4
-        for (int i = 0; i < 16; ++i) {          // two query rows per pass: lanes 0-31 / 32-63
-            const int qi = 2 * i + half;
-            const int qrow = q0 + wave * 32 + qi;
-            if (qrow < nq) Og[(long)qrow * p.ldo + l31] = ot[qi * LDO + l31];
-        }
-    }
+    store_attention_rows<DH>(p, S, b, h, q0 + wave * 32, nq, ot, LDO, lane);
 }
 
 template <int DH>

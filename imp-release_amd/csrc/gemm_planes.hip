@@ -1,0 +1,465 @@
+// Split-half ("f16x3") MFMA GEMM on PRE-SPLIT operands, gfx950.
+//
+//   C[M x N] = epilogue( A[M x K] * W[N x K]^T )          (every 1x1 Conv1d of a GNN layer: nets/layers.py:119,134,145-149,210-218)
+//
+// gemm_f32.hip splits every fp32 operand into (hi, lo) halves while staging it - every workgroup re-converts the same
+// weights and the same activations N / BN times, and the conversion (3 VALU per pair of values + ds_write) sits between
+// the global load and the MFMAs.  Here the operands live in memory as "planes": a row of a C-channel matrix is
+// [C hi halves | C lo halves] (hi = f16(x), lo = f16(x - hi); same 4 bytes per element as fp32), written once by the
+// producer (weights: at pack time; activations: by the producing kernel's epilogue).  Staging is then a pure copy, done by
+// the LDS-DMA path (global_load_lds_dwordx4: no staging registers, no ds_write pass), double buffered, ONE workgroup
+// barrier per 32-deep K-tile, and the K-loop contains nothing but ds_read_b128 + MFMA:
+//     per k16-step and wave: 8 ds_read_b128 (2 A tiles + 2 W tiles, hi and lo) feed 12 MFMAs (lo.hi + hi.lo + hi.hi).
+//
+// LDS image of one operand tile (R rows x 32 k, two planes): pieces of 16 rows x 64 B = 1 KiB, written lane-linearly by
+// one DMA instruction.  Lane l of the DMA fetches row l / 4, 16-byte k-chunk (l % 4) ^ ((row / 4) % 4) - four lanes
+// read one contiguous 64-byte row segment - so the chunk c of row i sits in slot 4 i + (c ^ (i / 4 % 4)): the ds_read_b128
+// fragment reads (16 rows x one chunk per lane group) hit 16 distinct 16-byte slots of the 256-byte bank row
+// (conflict-free), and the two k16-steps of a tile differ by XOR 32 in the byte address.
+//
+// ASRC = 1 (the MLP's second conv): A is the fp32 hidden activation; InstanceNorm / BatchNorm + activation are applied
+// while it is staged through registers (next K-tile prefetched) and split into the same LDS image; W still comes by DMA.
+//
+// Epilogue through LDS (the two stages are free by then): + bias, per-column-range scale (the softmax scale of the query
+// section), exp(. - rowvec), + fp32 residual, per-tile column statistics (sum, M2 about the tile mean: merged with
+// Chan's formula, so a channel whose |mean| >> std loses no digits), fp32 output rows as float4, and / or the result
+// as planes for the next consumer.
+#include "imp_kernels.h"
+#include <mutex>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int BM = 128, BK = 32;
+
+__device__ __forceinline__ int xcd_remap(int lin, int total) {
+    const int q = total / 8, r = total % 8;
+    const int xcd = lin % 8, idx = lin / 8;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == 0) return fmaxf(v, 0.0f);
+    if (act == 2) return v > 0.0f ? v : 0.1f * v;
+    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+}
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+// slot (in 16-byte units) of k-chunk c of row i inside a 16-row piece
+__device__ __forceinline__ int slot_of(int i, int c) { return 4 * i + (c ^ ((i >> 2) & 3)); }
+
+template <int BN, int ASRC, int PRO>     // PRO (ASRC = 1 only): 1 = InstanceNorm/fixed norm + ReLU, 2 = generic affine norm + any activation
+__global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PGemmParams p, int col_tiles, int row_tiles, int total) {
+    constexpr int TN = BN / 64;                       // 32-column MFMA tiles per wave (wave tile 64 x BN/2)
+    constexpr int A_BYTES = BM * 64 * 2;              // one stage of A: BM rows x 64 B x 2 planes
+    constexpr int W_BYTES = BN * 64 * 2;
+    constexpr int STAGE = A_BYTES + W_BYTES;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    float* tr = reinterpret_cast<float*>(smem + 2 * STAGE);        // ASRC = 1: [mu K][rs K]([gamma K][beta K])
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int z = xcd_remap(blockIdx.x, total);
+    const int ctile = z % col_tiles; z /= col_tiles;
+    const int rtile = z % row_tiles; z /= row_tiles;
+    const int sidx = z % p.nside; z /= p.nside;
+    const int sub = z % p.nsub;
+    const int b = z / p.nsub;
+    const PGemmSide& S = p.side[sidx];
+    const int M = S.M, N = S.N, K = p.K;
+    const int row0 = rtile * BM, col0 = ctile * BN;
+    if (row0 >= M || col0 >= N) return;               // uniform, before any barrier
+
+    // ---- operand bases ------------------------------------------------------------------------------------------------
+    // planes rows: [K hi | K lo] halves per source (A, A2: k >= ksplit, its own row pitch); W rows: [K hi | K lo]
+    const _Float16* Ap = S.Ap + b * S.sA_b + sub * S.sA_s;
+    const _Float16* Ap2 = S.Ap2 ? S.Ap2 + b * S.sA2_b : Ap;
+    const float* Af = S.Af ? S.Af + b * S.sAf_b : nullptr;
+    const _Float16* Wp = S.Wp + b * S.sW_b + sub * S.sW_s;
+    const int flags = p.flags;
+
+    if (ASRC == 1) {
+        for (int k = tid; k < K; k += 256) {
+            float mu, rs;
+            if (S.in_stats) {
+                const float* st = S.in_stats + ((long)b * K + k) * 2;
+                mu = st[0]; rs = st[1];
+            } else { mu = p.nm_mean[k]; rs = p.nm_rstd[k]; }
+            tr[k] = mu; tr[K + k] = rs;
+            if (PRO == 2) {
+                tr[2 * K + k] = (flags & PG_PRO_AFFINE) ? p.nm_gamma[k] : 1.f;
+                tr[3 * K + k] = (flags & PG_PRO_AFFINE) ? p.nm_beta[k] : 0.f;
+            }
+        }
+    }
+
+    // ---- DMA geometry: this wave issues pieces wave, wave + 4, ... of each operand ----------------------------------------
+    // piece q of A: plane q & 1, 16-row block q >> 1 (BM / 16 blocks); lane: row l / 4, chunk (l % 4) ^ (row / 4 % 4)
+    const int li = lane >> 2, lc = (lane & 3) ^ ((li >> 2) & 3);
+    constexpr int APW = (ASRC == 0) ? (BM / 16) * 2 / 4 : 0;      // A pieces per wave and stage
+    constexpr int WPW = (BN / 16) * 2 / 4;
+    const char* asrc[APW > 0 ? APW : 1];
+    const char* asrc2[APW > 0 ? APW : 1];
+    const char* wsrc[WPW];
+    if (ASRC == 0) {
+#pragma unroll
+        for (int j = 0; j < APW; ++j) {
+            const int q = wave + 4 * j, plane = q & 1, blk = q >> 1;
+            const int r = min(row0 + blk * 16 + li, M - 1);
+            asrc[j] = reinterpret_cast<const char*>(Ap + (long)r * p.lda + plane * p.apw) + lc * 16;
+            asrc2[j] = reinterpret_cast<const char*>(Ap2 + (long)r * p.lda2 + plane * p.apw2) + lc * 16 - (long)p.ksplit * 2;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) {
+        const int q = wave + 4 * j, plane = q & 1, blk = q >> 1;
+        const int r = min(col0 + blk * 16 + li, N - 1);
+        wsrc[j] = reinterpret_cast<const char*>(Wp + (long)r * p.ldw + plane * K) + lc * 16;
+    }
+    auto dma_stage = [&](int kt, int stage) {
+        char* sbase = smem + stage * STAGE;
+        const long koff = (long)kt * (BK * 2);
+        if (ASRC == 0) {
+            const bool second = kt * BK >= p.ksplit;       // uniform
+#pragma unroll
+            for (int j = 0; j < APW; ++j) {
+                const int q = wave + 4 * j;
+                __builtin_amdgcn_global_load_lds((gbl_void*)((second ? asrc2[j] : asrc[j]) + koff),
+                                                 (lds_void*)(sbase + (q & 1) * (BM * 64) + (q >> 1) * 1024), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WPW; ++j) {
+            const int q = wave + 4 * j;
+            __builtin_amdgcn_global_load_lds((gbl_void*)(wsrc[j] + koff),
+                                             (lds_void*)(sbase + A_BYTES + (q & 1) * (BN * 64) + (q >> 1) * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- ASRC = 1: fp32 A through registers (norm + activation + split), same LDS image -----------------------------------
+    constexpr int LA = BM / 32;
+    const int sr = tid >> 3, sk = (tid & 7) << 2;        // row within a 32-row group, k offset (4 consecutive k) in the tile
+    const float* pa[LA];
+    f32x4 ra[LA];
+    if (ASRC == 1) {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) pa[j] = Af + (long)min(row0 + sr + 32 * j, M - 1) * p.ldaf + sk;
+    }
+    auto load_a = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < LA; ++j) ra[j] = *reinterpret_cast<const f32x4*>(pa[j] + kt * BK);
+    };
+    auto store_a = [&](int kt, int stage) {
+        const int k0 = kt * BK + sk;
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(tr + k0);
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(tr + K + k0);
+        f32x4 ga, be;
+        if (PRO == 2) { ga = *reinterpret_cast<const f32x4*>(tr + 2 * K + k0); be = *reinterpret_cast<const f32x4*>(tr + 3 * K + k0); }
+        char* sbase = smem + stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < LA; ++j) {
+            f32x4 v = ra[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = (v[e] - mu[e]) * rs[e];
+                if (PRO == 1) t = fmaxf(t, 0.f);
+                else { if (flags & PG_PRO_AFFINE) t = t * ga[e] + be[e]; t = apply_act(t, p.act); }
+                v[e] = t;
+            }
+            u32x2 hi, lo;
+            { unsigned a, c; imp_split2(v[0], v[1], a, c); hi[0] = a; lo[0] = c; imp_split2(v[2], v[3], a, c); hi[1] = a; lo[1] = c; }
+            const int row = sr + 32 * j, i = row & 15, blk = row >> 4;
+            const int byte = blk * 1024 + slot_of(i, sk >> 3) * 16 + ((sk >> 2) & 1) * 8;
+            *reinterpret_cast<u32x2*>(sbase + byte) = hi;
+            *reinterpret_cast<u32x2*>(sbase + BM * 64 + byte) = lo;
+        }
+    };
+
+    // ---- fragment addresses (bytes inside a stage) --------------------------------------------------------------------
+    const int fr = lane & 31, fh = lane >> 5;
+    int aoff[2], woff[TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = wm * 64 + i * 32 + fr;
+        aoff[i] = (row >> 4) * 1024 + slot_of(row & 15, fh) * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = wn * (BN / 2) + j * 32 + fr;
+        woff[j] = A_BYTES + (col >> 4) * 1024 + slot_of(col & 15, fh) * 16;
+    }
+
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nkt = K / BK;
+    if (ASRC == 1) { load_a(0); __syncthreads(); store_a(0, 0); if (nkt > 1) load_a(1); }
+    dma_stage(0, 0);
+    __syncthreads();                                   // (drains the DMA: vmcnt(0) inside the barrier's release)
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int st = kt & 1;
+        if (kt + 1 < nkt) dma_stage(kt + 1, st ^ 1);   // the other stage was released by the barrier that ended step kt - 1
+        const char* sb = smem + st * STAGE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {                  // two k16-steps: byte address ^ 32
+            f16x8 ah[2], al[2], wh[TN], wl[TN];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const f16x8*>(sb + (aoff[i] ^ (s * 32)));
+                al[i] = *reinterpret_cast<const f16x8*>(sb + BM * 64 + (aoff[i] ^ (s * 32)));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                wh[j] = *reinterpret_cast<const f16x8*>(sb + (woff[j] ^ (s * 32)));
+                wl[j] = *reinterpret_cast<const f16x8*>(sb + BN * 64 + (woff[j] ^ (s * 32)));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh[j], acc[i][j], 0, 0, 0);
+        }
+        if (ASRC == 1 && kt + 1 < nkt) {               // convert the prefetched A tile into the other stage, fetch the one after
+            store_a(kt + 1, st ^ 1);
+            if (kt + 2 < nkt) load_a(kt + 2);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------
+    // value transforms in registers (lane = one column, 16 rows per accumulator), then through an XOR-swizzled fp32 LDS tile
+    // T[BM][BN] (float4 index ^ (row & 7)) so that rows leave as 16-byte segments whatever the output format
+    const int half = lane >> 5;
+    const int rloc = wm * 64 + 4 * half;                 // + i*32 + (r&3) + 8*(r>>2)
+    const int cloc = wn * (BN / 2) + (lane & 31);        // + j*32
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float bv = p.bias[min(col0 + cloc + j * 32, N - 1)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
+        }
+    }
+    if (p.scale_cols > 0) {                               // e.g. the query section carries the softmax scale (uniform per tile)
+        if (col0 < p.scale_cols) {
+            const float sc = p.scale;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] *= sc;
+        }
+    }
+    if (flags & PG_EPI_EXPROW) {
+        const float* rv = S.rowvec + b * S.sRV_b + sub * S.sRV_s;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float lv = rv[min(row0 + rloc + i * 32 + (r & 3) + 8 * (r >> 2), M - 1)] * p.rowvec_scale;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j][r] = (flags & PG_EPI_EXP2) ? __builtin_amdgcn_exp2f(acc[i][j][r] - lv) : expf(acc[i][j][r] - lv);
+            }
+    }
+    float* T = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rloc + i * 32 + (r & 3) + 8 * (r >> 2), col = cloc + j * 32;
+                T[row * BN + (((col >> 2) ^ (row & 7)) << 2) + (col & 3)] = acc[i][j][r];
+            }
+    __syncthreads();
+    const int rows_here = min(BM, M - row0);
+    // rows out: thread handles float4 column chunk cq of rows rr, rr + 256 / (BN / 4), ...
+    constexpr int CQ = BN / 4;
+    const int cq = tid % CQ;
+    const int col = col0 + 4 * cq;
+    const float* R = S.R ? S.R + b * S.sR_b : nullptr;
+    float* C = S.C ? S.C + b * S.sC_b + sub * S.sC_s : nullptr;
+    _Float16* Cp = S.Cp ? S.Cp + b * S.sCp_b : nullptr;
+    // planes address of output column `col`: plane groups of p.cpw channels, [hi cpw | lo cpw] each
+    const int pgrp = p.cpw > 0 ? col / p.cpw : 0, pcol = p.cpw > 0 ? col - pgrp * p.cpw : 0;
+    for (int rr = tid / CQ; rr < rows_here; rr += 256 / CQ) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(T + rr * BN + ((cq ^ (rr & 7)) << 2));
+        const long grow = row0 + rr;
+        if (R) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(R + grow * p.ldr + col);
+            v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
+        }
+        if (col < N) {
+            if (C) *reinterpret_cast<f32x4*>(C + grow * p.ldc + col) = v;
+            if (Cp) {
+                u32x2 hi, lo;
+                { unsigned a, c; imp_split2(v[0], v[1], a, c); hi[0] = a; lo[0] = c; imp_split2(v[2], v[3], a, c); hi[1] = a; lo[1] = c; }
+                _Float16* dst = Cp + grow * p.ldcp + pgrp * 2 * p.cpw + pcol;
+                *reinterpret_cast<u32x2*>(dst) = hi;
+                *reinterpret_cast<u32x2*>(dst + p.cpw) = lo;
+            }
+        }
+    }
+    if (flags & PG_EPI_STATS) {
+        // per column: (sum, M2 about the tile mean) over the valid rows; two threads per column (row halves), merged
+        // with Chan's formula (exact counts), written per tile; launch_stats_finalize merges the tiles the same way in fp64
+        const int c = tid % BN, hsel = tid / BN;                 // BN = 128: 2 halves; BN = 64: 4 quarters
+        constexpr int NH = 256 / BN;
+        const int r_begin = hsel * (BM / NH), r_end = min(rows_here, (hsel + 1) * (BM / NH));
+        float s = 0.f;
+        for (int rr = r_begin; rr < r_end; ++rr) s += T[rr * BN + (((c >> 2) ^ (rr & 7)) << 2) + (c & 3)];
+        const int cnt = max(r_end - r_begin, 0);
+        const float mean = cnt > 0 ? s / (float)cnt : 0.f;
+        float m2 = 0.f;
+        for (int rr = r_begin; rr < r_end; ++rr) {
+            const float d = T[rr * BN + (((c >> 2) ^ (rr & 7)) << 2) + (c & 3)] - mean;
+            m2 = fmaf(d, d, m2);
+        }
+        __syncthreads();                                           // everyone is done reading T
+        float* sc = reinterpret_cast<float*>(smem);                // [NH][BN][2]
+        sc[(hsel * BN + c) * 2] = s;
+        sc[(hsel * BN + c) * 2 + 1] = m2;
+        __syncthreads();
+        if (hsel == 0 && col0 + c < N) {
+            float ts = 0.f, tm2 = 0.f;
+            int tn = 0;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const int hn = max(min(rows_here, (h + 1) * (BM / NH)) - h * (BM / NH), 0);
+                if (hn == 0) continue;
+                const float hs = sc[(h * BN + c) * 2], hm2 = sc[(h * BN + c) * 2 + 1];
+                if (tn == 0) { ts = hs; tm2 = hm2; tn = hn; }
+                else {
+                    const float delta = hs / (float)hn - ts / (float)tn;
+                    tm2 = tm2 + hm2 + delta * delta * ((float)tn * (float)hn / (float)(tn + hn));
+                    ts += hs; tn += hn;
+                }
+            }
+            const int tiles_side = (M + BM - 1) / BM;
+            float* os = S.out_stats + (((long)b * tiles_side + rtile) * N + col0 + c) * 2;
+            os[0] = ts;
+            os[1] = tm2;
+        }
+    }
+}
+
+// ---- fp32 -> planes (rows [C hi | C lo] halves); 8 channels per thread ----------------------------------------------------
+__global__ __launch_bounds__(256) void make_planes_kernel(const float* __restrict__ x, _Float16* __restrict__ out, long rows,
+                                                          int C, long ldx, long ldo) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int cpr = C / 8;
+    if (t >= rows * cpr) return;
+    const long r = t / cpr;
+    const int c = (int)(t - r * cpr) * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(x + r * ldx + c + 4);
+    u32x4 hi, lo;
+    { unsigned h, l; imp_split2(a[0], a[1], h, l); hi[0] = h; lo[0] = l; imp_split2(a[2], a[3], h, l); hi[1] = h; lo[1] = l;
+      imp_split2(d[0], d[1], h, l); hi[2] = h; lo[2] = l; imp_split2(d[2], d[3], h, l); hi[3] = h; lo[3] = l; }
+    *reinterpret_cast<u32x4*>(out + r * ldo + c) = hi;
+    *reinterpret_cast<u32x4*>(out + r * ldo + C + c) = lo;
+}
+
+// ---- InstanceNorm statistics: per-tile (sum, M2 about the tile mean) -> (mean, rstd), Chan's parallel merge in fp64 ----------
+__global__ __launch_bounds__(256) void stats_finalize_chan_kernel(StatsSide s0, StatsSide s1, int K, float eps) {
+    const StatsSide& S = blockIdx.y == 0 ? s0 : s1;
+    const int b = blockIdx.z;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const float2* st = reinterpret_cast<const float2*>(S.part) + (long)b * S.tiles * K + k;
+    // first the grand mean (fixed order), then M2 = sum_t [ M2_t + n_t (mean_t - mean)^2 ]
+    double tot = 0.0;
+    for (int t = 0; t < S.tiles; ++t) tot += (double)st[(long)t * K].x;
+    const double mean = tot / (double)S.M;
+    double m2 = 0.0;
+    for (int t = 0; t < S.tiles; ++t) {
+        const float2 v = st[(long)t * K];
+        const int nt = min(S.tile_rows, S.M - t * S.tile_rows);
+        const double d = (double)v.x / (double)nt - mean;
+        m2 += (double)v.y + (double)nt * d * d;
+    }
+    float2 o;
+    o.x = (float)mean;
+    o.y = (float)(1.0 / sqrt(m2 / (double)S.M + (double)eps));       // biased variance (nets/layers.py:67-68)
+    reinterpret_cast<float2*>(S.out)[(long)b * K + k] = o;
+}
+
+template <int BN, int ASRC, int PRO>
+hipError_t launch_one(const PGemmParams& p, dim3 grid, hipStream_t stream) {
+    size_t lds = (size_t)2 * (BM * 64 * 2 + BN * 64 * 2);
+    if (ASRC == 1) lds += (size_t)p.K * (PRO == 2 ? 4 : 2) * sizeof(float);
+    static std::mutex mu;
+    static size_t lds_set = 0;
+    if (lds > 48 * 1024) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (lds > lds_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_planes_kernel<BN, ASRC, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            lds_set = lds;
+        }
+    }
+    const int total = (int)(grid.x * grid.y * grid.z);
+    hipLaunchKernelGGL((gemm_planes_kernel<BN, ASRC, PRO>), dim3(total), dim3(256), lds, stream, p, (int)grid.x, (int)grid.y, total);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+int pgemm_tile_rows() { return BM; }
+
+// BN: 128 when that still fills the chip twice over or N needs it, else 64 (N must be a multiple of 64)
+hipError_t launch_gemm_planes(const PGemmParams& p, int batch, hipStream_t stream) {
+    const int maxM = p.nside == 2 ? (p.side[0].M > p.side[1].M ? p.side[0].M : p.side[1].M) : p.side[0].M;
+    const int N = p.side[0].N;
+    const int total_z = batch * p.nsub * p.nside;
+    if (maxM <= 0 || N <= 0 || total_z <= 0) return hipSuccess;
+    if (p.K % BK || N % 4) return hipErrorInvalidValue;
+    const long wg128 = (long)((maxM + BM - 1) / BM) * ((N + 127) / 128) * total_z;
+    const bool bn128 = wg128 >= 512 && p.bn_hint != 64;
+    const int bn = bn128 ? 128 : 64;
+    dim3 grid((N + bn - 1) / bn, (maxM + BM - 1) / BM, total_z);
+    const bool a_f32 = p.side[0].Af != nullptr;
+    int pro = 0;
+    if (a_f32) pro = (!(p.flags & PG_PRO_AFFINE) && p.act == 0) ? 1 : 2;
+    if (bn128) {
+        if (!a_f32) return launch_one<128, 0, 0>(p, grid, stream);
+        return pro == 1 ? launch_one<128, 1, 1>(p, grid, stream) : launch_one<128, 1, 2>(p, grid, stream);
+    }
+    if (!a_f32) return launch_one<64, 0, 0>(p, grid, stream);
+    return pro == 1 ? launch_one<64, 1, 1>(p, grid, stream) : launch_one<64, 1, 2>(p, grid, stream);
+}
+
+hipError_t launch_make_planes(const float* x, _Float16* out, long rows, int C, long ldx, long ldo, hipStream_t stream) {
+    if (rows <= 0) return hipSuccess;
+    if (C % 8) return hipErrorInvalidValue;
+    const long n = rows * (C / 8);
+    hipLaunchKernelGGL(make_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, out, rows, C, ldx, ldo);
+    return hipGetLastError();
+}
+
+hipError_t launch_stats_finalize_chan(const StatsSide sides[2], int nside, int batch, int K, float eps, hipStream_t stream) {
+    hipLaunchKernelGGL(stats_finalize_chan_kernel, dim3((K + 255) / 256, nside, batch), dim3(256), 0, stream, sides[0],
+                       sides[nside - 1], K, eps);
+    return hipGetLastError();
+}

@@ -204,6 +204,16 @@ int imp_time_attention(imp_ctx* ctx, int batch, int n, int reps, float* ms, void
  * shape (chip-resident kernel: time(T iterations) - time(0 iterations); streaming path: 2 launches per iteration);
  * *ms = average milliseconds per ITERATION */
 int imp_time_sinkhorn(imp_ctx* ctx, int batch, int n, int iterations, float* ms, void* stream);
+/* test entry of the pre-split ("planes") split-half GEMM (gemm_planes.hip): y = x W^T + bias (+ residual), x [M][K], W [N][K]
+ * fp32 in memory, converted to planes and multiplied by the kernel the GNN layers use; y_planes_roundtrip (optional, [M][N])
+ * receives the result as written by the planes epilogue (hi + lo).  K % 32 == 0, N % 64 == 0.  Synchronises. */
+int imp_op_linear_planes(imp_ctx* ctx, int M, int N, int K, const float* x, const float* W, const float* bias,
+                         const float* residual, float* y, float* y_planes_roundtrip, void* stream);
+/* The planes of the descriptors (the split-half operands of the layer GEMMs, nets/layers.py:145-149,210-218) are written by
+ * every layer's last GEMM next to its fp32 output.  With on != 0 the caller promises that a descriptor tensor passed to
+ * imp_forward_layer is the UNMODIFIED output of the previous imp_forward_layer call whenever the pointers and shapes match,
+ * so the layer reuses those planes instead of re-splitting its input.  Default off; imp_match_pair always chains its own. */
+int imp_trust_descriptor_planes(imp_ctx* ctx, int on);
 /* chip-resident Sinkhorn health (ot_resident.hip): *status != 0 when a group barrier ever timed out on this context
  * (results of that call are then garbage - never observed; the spin is bounded so that it cannot hang); *used = whether
  * the resident path has been taken at all.  Synchronises. */
