@@ -26,7 +26,7 @@ SYMBOLS = [
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
     'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear',
-    'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_op_linear_planes', 'imp_trust_descriptor_planes',
+    'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_op_linear_planes', 'imp_trust_descriptor_planes', 'imp_time_layer_gemm',
 ]
 
 
@@ -99,6 +99,7 @@ def lib():
     L.imp_resident_status.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.imp_op_linear_planes.argtypes = [P, I, I, I, P, P, P, P, P, P, P]
     L.imp_trust_descriptor_planes.argtypes = [P, I]
+    L.imp_time_layer_gemm.argtypes = [P, I, I, I, I, I, C.POINTER(C.c_float), P]
     _lib = L
     return L
 
@@ -395,3 +396,8 @@ class Context:
                                                 _ptr(None if residual is None else _f32(residual, 'residual')), _ptr(y), _ptr(yp),
                                                 _stream(self.device)))
         return (y, yp) if roundtrip else y
+
+    def time_layer_gemm(self, batch, n, which, dbg=0, reps=20):
+        ms = C.c_float()
+        self._check(self.L.imp_time_layer_gemm(self.handle, batch, n, which, dbg, reps, C.byref(ms), _stream(self.device)))
+        return ms.value

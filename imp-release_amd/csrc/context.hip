@@ -84,7 +84,7 @@ struct imp_ctx {
     float *colsum[4] = {}, *amass[4] = {}, *mass[2] = {};
     AttnCache cache[2];
     // planes path (gemm_planes.hip): f16x3 arithmetic with the merge conv folded; IMP_GEMM_PLANES=0 keeps gemm_f32.hip
-    int use_planes = 1;
+    int use_planes = 0;
     _Float16* xpl[2] = {};                 // planes of the current descriptors of image 0 / 1  [B][n][2D halves]
     const float* xpl_src[2] = {};          // fp32 tensor they were made from / written next to (trusted only inside one call chain)
     int xpl_b = 0, xpl_n[2] = {0, 0};
@@ -98,6 +98,10 @@ int dev_alloc(imp_ctx* c, std::vector<void*>& pool, T** out, size_t count) {
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, count * sizeof(T) + 64);
     if (e != hipSuccess) return fail(IMP_E_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    // debugging aid (IMP_POISON_WORKSPACE=1): fresh allocations are filled with NaN bit patterns, so that a read of
+    // never-written workspace shows up in the results instead of depending on what the allocator handed out
+    static const bool poison = [] { const char* v = getenv("IMP_POISON_WORKSPACE"); return v && atoi(v) != 0; }();
+    if (poison) { (void)hipMemset(p, 0xFF, count * sizeof(T) + 64); (void)hipDeviceSynchronize(); }
     pool.push_back(p);
     *out = static_cast<T*>(p);
     return IMP_OK;
@@ -227,7 +231,7 @@ int ensure_workspace(imp_ctx* c, int batch, int n) {
     c->cap_b = c->cap_n = 0;
     c->cache[0].valid = c->cache[1].valid = false;
     const size_t B = batch, N = n, D = c->D;
-    const size_t tiles = (N + 63) / 64;
+    const size_t tiles = (N + 31) / 32;            // statistics blocks: one per 32 rows at the smallest GEMM tile
     int rc = 0;
     for (int k = 0; k < 2 && !rc; ++k)
         for (int s = 0; s < 2 && !rc; ++s) {
@@ -321,14 +325,14 @@ int run_kenc(imp_ctx* c, int batch, const int n[2], const float* const kpts[2], 
     const bool in_norm = cfg.norm_fn == IMP_NORM_IN;
     // two statistics slots per side behind the GNN-layer statistics: a launch reads the previous layer's slot in its
     // prologue while other workgroups already write this layer's slot in their epilogue
-    const size_t tiles_cap = ((size_t)c->cap_n + 63) / 64;
+    const size_t tiles_cap = ((size_t)c->cap_n + 31) / 32;
     const size_t slot = (size_t)c->cap_b * tiles_cap * c->kenc_maxc * 2;
     float* kstats[2] = {c->stats[0] + (size_t)c->cap_b * tiles_cap * 2 * D * 2,
                         c->stats[1] + (size_t)c->cap_b * tiles_cap * 2 * D * 2};
     Kenc0Side ks[2];
     for (int s = 0; s < 2; ++s) ks[s] = Kenc0Side{kpts[s], scores[s], c->kbuf[s][0], in_norm ? kstats[s] : nullptr, n[s]};
     HIP_TRY(launch_kenc_first(ks, batch, c->kenc[0].out, c->kenc[0].W, c->kenc[0].b, width, height, st));
-    int in_tiles[2] = {(n[0] + 127) / 128, (n[1] + 127) / 128};   // kenc_first: 128-token statistics tiles
+    int in_rows = 64;                                            // kenc_first: 64-token statistics blocks
     const int maxn = n[0] > n[1] ? n[0] : n[1];
     int cur = 0;
     for (int i = 1; i <= nk; ++i) {
@@ -343,10 +347,10 @@ int run_kenc(imp_ctx* c, int batch, const int n[2], const float* const kpts[2], 
             p.nm_mean = nc.mean; p.nm_rstd = nc.rstd; p.nm_gamma = nc.gamma; p.nm_beta = nc.beta;
         }
         if (!last && in_norm) p.flags |= GEMM_EPI_STATS;
-        const int bm = gemm_tile_m(maxn, L.out, 2 * batch);
+        const int srows = gemm_stats_rows(maxn, L.out, 2 * batch);
         if (in_norm) {
             StatsSide ss[2];
-            for (int s = 0; s < 2; ++s) ss[s] = StatsSide{kstats[s] + ((i - 1) & 1) * slot, c->nstat[s], in_tiles[s], n[s]};
+            for (int s = 0; s < 2; ++s) ss[s] = StatsSide{kstats[s] + ((i - 1) & 1) * slot, c->nstat[s], (n[s] + in_rows - 1) / in_rows, n[s], in_rows};
             HIP_TRY(launch_stats_finalize(ss, 2, batch, L.in, 1e-3f, st));
         }
         for (int s = 0; s < 2; ++s) {
@@ -364,7 +368,7 @@ int run_kenc(imp_ctx* c, int batch, const int n[2], const float* const kpts[2], 
         }
         p.bias = L.b; p.lda = L.in; p.ldw = L.in; p.ldc = last ? D : L.out; p.ldr = D;
         HIP_TRY(launch_gemm_f32(p, batch, st));
-        for (int s = 0; s < 2; ++s) in_tiles[s] = (n[s] + bm - 1) / bm;
+        in_rows = srows;
         cur ^= 1;
     }
     return IMP_OK;
@@ -384,7 +388,9 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
     }
     // planes path: split-half GEMMs on pre-split operands (gemm_planes.hip).  The descriptors' planes come from the previous
     // layer's last GEMM when this call continues a trusted chain, otherwise they are made here.
-    const bool planes = c->prec == 1 && c->fuse_merge && c->use_planes;
+    // (worth it only when the panels fill the chip: one 64-row panel per workgroup, gemm_planes.hip)
+    const long panels = (long)(((n[0] > n[1] ? n[0] : n[1]) + 63) / 64) * 2 * batch;
+    const bool planes = c->prec == 1 && c->fuse_merge && c->use_planes && panels >= 96 && D % 128 == 0;
     if (planes) {
         for (int s = 0; s < 2; ++s) {
             const bool have = c->trust_planes && c->xpl_src[s] == desc[s] && c->xpl_b == batch && c->xpl_n[s] == n[s];
@@ -455,7 +461,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
     // 4. MLP conv 0 on cat([x, message]) (the concat is a K-split over two sources) + InstanceNorm statistics
     const bool in_norm = cfg.norm_fn == IMP_NORM_IN;
     const int maxn = n[0] > n[1] ? n[0] : n[1];
-    const int bm0 = planes ? pgemm_tile_rows() : gemm_tile_m(maxn, 2 * D, 2 * batch);
+    int bm0 = gemm_stats_rows(maxn, 2 * D, 2 * batch);      // rows per statistics block of the MLP0 launch
     if (planes) {
         PGemmParams p;
         memset(&p, 0, sizeof p);
@@ -469,6 +475,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
         }
         if (in_norm) p.flags |= PG_EPI_STATS;
         p.bias = M0.b; p.lda = 2 * D; p.apw = D; p.lda2 = 2 * D; p.apw2 = D; p.ldw = 4 * D; p.ldc = 2 * D;
+        bm0 = pgemm_stats_rows(p, batch);
         HIP_TRY(launch_gemm_planes(p, batch, st));
     } else {
         GemmParams p = gemm_defaults(c, 2 * D);
@@ -487,8 +494,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
     if (in_norm) {
         StatsSide ss[2];
         for (int s = 0; s < 2; ++s) ss[s] = StatsSide{c->stats[s], c->nstat[s], (n[s] + bm0 - 1) / bm0, n[s], bm0};
-        if (planes) HIP_TRY(launch_stats_finalize_chan(ss, 2, batch, 2 * D, 1e-3f, st));
-        else HIP_TRY(launch_stats_finalize(ss, 2, batch, 2 * D, 1e-3f, st));
+        HIP_TRY(launch_stats_finalize(ss, 2, batch, 2 * D, 1e-3f, st));
     }
     if (planes) {
         PGemmParams p;
@@ -593,6 +599,9 @@ int ensure_resident_buffers(imp_ctx* c, int batch) {
     if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xv, 2 * (size_t)cap * kResidentMaxLdx);
     if (!rc) HIP_TRY(hipMemset(c->xv, 0, 2 * (size_t)cap * kResidentMaxLdx * sizeof(float)));
     if (rc) return rc;
+    // the clears above run on the NULL stream, which the callers' (non-blocking) streams and the lane do not wait for:
+    // they must have landed before the first resident kernel writes its tags into these buffers
+    HIP_TRY(hipDeviceSynchronize());
     c->xcap_b = cap;
     return IMP_OK;
 }
@@ -708,7 +717,9 @@ int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     { const char* e = getenv("IMP_PRECISION"); c->prec = (e && !strcmp(e, "f32")) ? 0 : 1; }
     { const char* e = getenv("IMP_OT_COMPACT"); c->ot_compact = (e && atoi(e) != 0) ? 1 : 0; }
     { const char* e = getenv("IMP_OT_RESIDENT"); c->ot_resident = (e && atoi(e) == 0) ? 0 : 1; }
-    { const char* e = getenv("IMP_GEMM_PLANES"); c->use_planes = (e && atoi(e) == 0) ? 0 : 1; }
+    // pre-split planes GEMMs (gemm_planes.hip) for the layer convs: measured SLOWER than gemm_f32.hip on MI355X,
+    // kept as an opt-in experiment and A/B switch
+    { const char* e = getenv("IMP_GEMM_PLANES"); c->use_planes = (e && atoi(e) != 0) ? 1 : 0; }
     c->kenc_maxc = c->D;
     for (int i = 0; i < nk; ++i) if (cfg->kenc_channels[i] > c->kenc_maxc) c->kenc_maxc = cfg->kenc_channels[i];
     build_schema(c);
@@ -1232,6 +1243,65 @@ int imp_time_sinkhorn(imp_ctx* c, int batch, int n, int iterations, float* ms, v
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     *ms = t;          // milliseconds per Sinkhorn ITERATION
+    return IMP_OK;
+}
+
+// probe: average time of ONE of the three layer GEMMs of layer 0 on the context's workspace (which: 0 QKV, 1 MLP0, 2 MLP3),
+// planes kernel with probe switches `dbg` (gemm_planes.hip) or, dbg < 0, the gemm_f32.hip kernel
+int imp_time_layer_gemm(imp_ctx* c, int batch, int n, int which, int dbg, int reps, float* ms, void* stream) {
+    int rc = check_ready(c, batch, n, n);
+    if (rc) return rc;
+    if (!ms || reps < 1 || which < 0 || which > 2 || c->layers.empty()) return fail(IMP_E_ARG, "imp_time_layer_gemm: bad argument");
+    hipStream_t st = S(stream);
+    const int D = c->D;
+    const GnnLayer& L = c->layers[0];
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    auto launch = [&]() -> hipError_t {
+        if (dbg < 0) {
+            GemmParams p = gemm_defaults(c, which == 0 ? D : 2 * D);
+            if (which == 1) p.ksplit = D;
+            for (int s = 0; s < 2; ++s) {
+                GemmSide& g = p.side[s];
+                g.M = n;
+                if (which == 0) { g.A = c->descw[s]; g.W = L.proj.W; g.C = c->qkv[0][s]; g.N = 3 * D; g.sA_b = (long)n * D; g.sC_b = (long)n * 3 * D; }
+                if (which == 1) { g.A = c->descw[s]; g.A2 = c->attn_out[s]; g.W = L.mlp0f.W; g.C = c->hid[s]; g.N = 2 * D; g.sA_b = (long)n * D; g.sC_b = (long)n * 2 * D; g.out_stats = c->stats[s]; }
+                if (which == 2) { g.A = c->hid[s]; g.W = L.mlp3.W; g.C = c->mdesc[s]; g.R = c->descw[s]; g.N = D; g.sA_b = (long)n * 2 * D; g.sC_b = (long)n * D; g.sR_b = (long)n * D; g.in_stats = c->nstat[s]; }
+            }
+            if (which == 0) { p.bias = L.proj.b; p.lda = D; p.ldw = D; p.ldc = 3 * D; }
+            if (which == 1) { p.flags |= GEMM_EPI_STATS; p.bias = L.mlp0f.b; p.lda = D; p.lda2 = D; p.ldw = 2 * D; p.ldc = 2 * D; }
+            if (which == 2) { p.flags = GEMM_PRO_NORM; p.bias = L.mlp3.b; p.lda = 2 * D; p.ldw = 2 * D; p.ldc = D; p.ldr = D; }
+            return launch_gemm_f32(p, batch, st);
+        }
+        PGemmParams p;
+        memset(&p, 0, sizeof p);
+        p.nside = 2; p.nsub = 1; p.dbg = dbg;
+        p.K = which == 0 ? D : 2 * D; p.ksplit = which == 1 ? D : p.K;
+        for (int s = 0; s < 2; ++s) {
+            PGemmSide& g = p.side[s];
+            g.M = n;
+            if (which == 0) { g.Ap = c->xpl[s]; g.Wp = L.proj_p; g.C = c->qkv[0][s]; g.N = 3 * D; g.sA_b = (long)n * 2 * D; g.sC_b = (long)n * 3 * D; }
+            if (which == 1) { g.Ap = c->xpl[s]; g.Ap2 = reinterpret_cast<const _Float16*>(c->attn_out[s]); g.Wp = L.mlp0f_p; g.C = c->hid[s]; g.N = 2 * D;
+                              g.sA_b = g.sA2_b = (long)n * 2 * D; g.sC_b = (long)n * 2 * D; g.out_stats = c->stats[s]; }
+            if (which == 2) { g.Af = c->hid[s]; g.Wp = L.mlp3_p; g.C = c->mdesc[s]; g.R = c->descw[s]; g.Cp = c->xpl[s]; g.N = D; g.sAf_b = (long)n * 2 * D;
+                              g.sC_b = (long)n * D; g.sR_b = (long)n * D; g.sCp_b = (long)n * 2 * D; g.in_stats = c->nstat[s]; }
+        }
+        if (which == 0) { p.bias = L.proj.b; p.lda = 2 * D; p.apw = D; p.ldw = 2 * D; p.ldc = 3 * D; }
+        if (which == 1) { p.flags |= PG_EPI_STATS; p.bias = L.mlp0f.b; p.lda = p.lda2 = 2 * D; p.apw = p.apw2 = D; p.ldw = 4 * D; p.ldc = 2 * D; }
+        if (which == 2) { p.bias = L.mlp3.b; p.ldaf = 2 * D; p.ldw = 4 * D; p.ldc = D; p.ldr = D; p.ldcp = 2 * D; p.cpw = D; }
+        return launch_gemm_planes(p, batch, st);
+    };
+    HIP_TRY(launch());
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; ++r) HIP_TRY(launch());
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms = t / reps;
     return IMP_OK;
 }
 

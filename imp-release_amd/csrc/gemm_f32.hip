@@ -381,77 +381,81 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 3) void gemm_f32_kernel(const GemmP
         }
     }
     if (flags & GEMM_EPI_STATS) {
-        // per-column (sum, sumsq) over the valid rows of this tile: in-lane over the 16 x TM registers, lane
-        // pair (l, l^32), then the two M-waves through LDS (the staging buffers are free after the last barrier)
-        float ssum[TN], ssq[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float s = 0.f, q = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const bool ok = interior || (rbase + i * 32 + (r & 3) + 8 * (r >> 2) < M);
-                    const float v = ok ? acc[i][j][r] : 0.f;
-                    s += v;
-                    q += v * v;
-                }
-            ssum[j] = s + __shfl_xor(s, 32);
-            ssq[j] = q + __shfl_xor(q, 32);
-        }
-        float* sc = As;
-        if (wm == 1 && lane < 32) {
+        // per column and per WAVE-ROW-BLOCK (WM rows = one statistics tile): (sum, M2 about the block mean) over the valid
+        // rows, two passes over the accumulators: in-lane over the 16 x TM registers, then the lane pair (l, l ^ 32).  No
+        // LDS, no cross-wave step; launch_stats_finalize merges the blocks with Chan's formula in fp64, so a channel
+        // whose |mean| is far above its standard deviation keeps its digits (E[x^2] - mean^2 would cancel them).
+        const int blk_row0 = row0 + wm * WM;
+        const int cnt = min(WM, M - blk_row0);                    // valid rows of this block (<= 0: nothing to report)
+        if (cnt > 0) {
+            const int tiles_side = (M + WM - 1) / WM;             // dense per side: [b][block][N][2]
+            float* os = S.out_stats + ((long)b * tiles_side + (rtile * 2 + wm)) * N * 2;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                sc[(wn * WN + j * 32 + lane) * 2] = ssum[j];
-                sc[(wn * WN + j * 32 + lane) * 2 + 1] = ssq[j];
-            }
-        }
-        __syncthreads();
-        if (wm == 0 && lane < 32) {
-            const int tiles_side = (M + BM - 1) / BM;   // dense per side: [b][tile][N][2]
-            float* os = S.out_stats + ((long)b * tiles_side + rtile) * N * 2;
+                float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int cl = wn * WN + j * 32 + lane;
-                const int col = col0 + cl;
-                if (col < N) {
-                    os[(long)col * 2] = ssum[j] + sc[cl * 2];
-                    os[(long)col * 2 + 1] = ssq[j] + sc[cl * 2 + 1];
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool ok = interior || (rbase + i * 32 + (r & 3) + 8 * (r >> 2) < M);
+                        s += ok ? acc[i][j][r] : 0.f;
+                    }
+                s += __shfl_xor(s, 32);
+                const float mean = s / (float)cnt;
+                float m2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool ok = interior || (rbase + i * 32 + (r & 3) + 8 * (r >> 2) < M);
+                        const float d = acc[i][j][r] - mean;
+                        m2 = fmaf(ok ? d : 0.f, d, m2);
+                    }
+                m2 += __shfl_xor(m2, 32);
+                const int col = cbase + j * 32;
+                if (lane < 32 && col < N) {
+                    os[(long)col * 2] = s;
+                    os[(long)col * 2 + 1] = m2;
                 }
             }
         }
     }
 }
 
+// per-block (sum, M2 about the block mean) -> (mean, rstd): Chan's parallel merge in fp64, fixed order.
+// block t covers rows [t * tile_rows, min(M, (t + 1) * tile_rows)).
 __global__ __launch_bounds__(256) void stats_finalize_kernel(StatsSide s0, StatsSide s1, int K, float eps) {
     const StatsSide& S = blockIdx.y == 0 ? s0 : s1;
     const int b = blockIdx.z;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= K) return;
     const float2* st = reinterpret_cast<const float2*>(S.part) + (long)b * S.tiles * K + k;
-    double s = 0.0, q = 0.0;
+    double tot = 0.0;
     int t = 0;
     for (; t + 8 <= S.tiles; t += 8) {          // 8 independent loads in flight, then a fixed-order fp64 sum
         float2 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = st[(long)(t + u) * K];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { s += (double)v[u].x; q += (double)v[u].y; }
+        for (int u = 0; u < 8; ++u) tot += (double)v[u].x;
     }
-    for (; t < S.tiles; ++t) { const float2 v = st[(long)t * K]; s += (double)v.x; q += (double)v.y; }
-    const double mean = s / (double)S.M;
-    double var = q / (double)S.M - mean * mean;
-    var = var < 0.0 ? 0.0 : var;
+    for (; t < S.tiles; ++t) tot += (double)st[(long)t * K].x;
+    const double mean = tot / (double)S.M;
+    double m2 = 0.0;
+    for (t = 0; t < S.tiles; ++t) {             // (second sweep: the partials are L2-resident)
+        const float2 v = st[(long)t * K];
+        const int nt = min(S.tile_rows, S.M - t * S.tile_rows);
+        const double d = (double)v.x / (double)nt - mean;
+        m2 += (double)v.y + (double)nt * d * d;
+    }
     float2 o;
     o.x = (float)mean;
-    o.y = (float)(1.0 / sqrt(var + (double)eps));
+    o.y = (float)(1.0 / sqrt(m2 / (double)S.M + (double)eps));       // biased variance, eps inside the root (nets/layers.py:67-68)
     reinterpret_cast<float2*>(S.out)[(long)b * K + k] = o;
 }
 
 size_t gemm_lds_bytes(int BM, int BN, int pro, int K) {
     size_t f = (size_t)(BM + BN) * LDT;
-    if (f < 4 * (size_t)BN) f = 4 * (size_t)BN;     // statistics scratch
     if (pro) f += (size_t)K * (pro == 2 ? 4 : 2);
     return f * sizeof(float);
 }
@@ -514,10 +518,8 @@ int gemm_tile_m(int M, int N, int total_z) {
     return bm;
 }
 
-int gemm_stats_tiles(int M, int N, int total_z) {
-    const int bm = gemm_tile_m(M, N, total_z);
-    return (M + bm - 1) / bm;
-}
+// rows per statistics block (= rows of one wave's accumulator tile) of the launch the parameters will get
+int gemm_stats_rows(int M, int N, int total_z) { return gemm_tile_m(M, N, total_z) / 2; }
 
 hipError_t launch_gemm_f32(const GemmParams& p, int batch, hipStream_t stream) {
     const int maxM = p.nside == 2 ? (p.side[0].M > p.side[1].M ? p.side[0].M : p.side[1].M) : p.side[0].M;

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PGemmParams p
     const float* Af = S.Af ? S.Af + b * S.sAf_b : nullptr;
     const _Float16* Wp = S.Wp + b * S.sW_b + sub * S.sW_s;
     const int flags = p.flags;
+    const int dbg = p.dbg;                          // probe switches (tools/probe): 1 no stores, 2 no MFMA, 4 no DMA after tile 0, 8 no epilogue
 
     if (ASRC == 1) {
         for (int k = tid; k < K; k += 256) {
@@ -209,8 +210,9 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PGemmParams p
     __syncthreads();                                   // (drains the DMA: vmcnt(0) inside the barrier's release)
     for (int kt = 0; kt < nkt; ++kt) {
         const int st = kt & 1;
-        if (kt + 1 < nkt) dma_stage(kt + 1, st ^ 1);   // the other stage was released by the barrier that ended step kt - 1
+        if (kt + 1 < nkt && !(dbg & 4)) dma_stage(kt + 1, st ^ 1);   // the other stage was released by the barrier that ended step kt - 1
         const char* sb = smem + st * STAGE;
+        if (!(dbg & 2))
 #pragma unroll
         for (int s = 0; s < 2; ++s) {                  // two k16-steps: byte address ^ 32
             f16x8 ah[2], al[2], wh[TN], wl[TN];
@@ -247,6 +249,7 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PGemmParams p
     // ---- epilogue ---------------------------------------------------------------------------------------------------------
     // value transforms in registers (lane = one column, 16 rows per accumulator), then through an XOR-swizzled fp32 LDS tile
     // T[BM][BN] (float4 index ^ (row & 7)) so that rows leave as 16-byte segments whatever the output format
+    if (dbg & 8) { if (acc[0][0][0] == 123.456f) S.C[0] = 1.f; return; }
     const int half = lane >> 5;
     const int rloc = wm * 64 + 4 * half;                 // + i*32 + (r&3) + 8*(r>>2)
     const int cloc = wn * (BN / 2) + (lane & 31);        // + j*32
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PGemmParams p
             const f32x4 rv = *reinterpret_cast<const f32x4*>(R + grow * p.ldr + col);
             v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
         }
-        if (col < N) {
+        if (col < N && !((dbg & 1) && v[0] != 123.456f)) {
             if (C) *reinterpret_cast<f32x4*>(C + grow * p.ldc + col) = v;
             if (Cp) {
                 u32x2 hi, lo;
@@ -381,30 +384,6 @@ __global__ __launch_bounds__(256) void make_planes_kernel(const float* __restric
     *reinterpret_cast<u32x4*>(out + r * ldo + C + c) = lo;
 }
 
-// ---- InstanceNorm statistics: per-tile (sum, M2 about the tile mean) -> (mean, rstd), Chan's parallel merge in fp64 ----------
-__global__ __launch_bounds__(256) void stats_finalize_chan_kernel(StatsSide s0, StatsSide s1, int K, float eps) {
-    const StatsSide& S = blockIdx.y == 0 ? s0 : s1;
-    const int b = blockIdx.z;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= K) return;
-    const float2* st = reinterpret_cast<const float2*>(S.part) + (long)b * S.tiles * K + k;
-    // first the grand mean (fixed order), then M2 = sum_t [ M2_t + n_t (mean_t - mean)^2 ]
-    double tot = 0.0;
-    for (int t = 0; t < S.tiles; ++t) tot += (double)st[(long)t * K].x;
-    const double mean = tot / (double)S.M;
-    double m2 = 0.0;
-    for (int t = 0; t < S.tiles; ++t) {
-        const float2 v = st[(long)t * K];
-        const int nt = min(S.tile_rows, S.M - t * S.tile_rows);
-        const double d = (double)v.x / (double)nt - mean;
-        m2 += (double)v.y + (double)nt * d * d;
-    }
-    float2 o;
-    o.x = (float)mean;
-    o.y = (float)(1.0 / sqrt(m2 / (double)S.M + (double)eps));       // biased variance (nets/layers.py:67-68)
-    reinterpret_cast<float2*>(S.out)[(long)b * K + k] = o;
-}
-
 template <int BN, int ASRC, int PRO>
 hipError_t launch_one(const PGemmParams& p, dim3 grid, hipStream_t stream) {
     size_t lds = (size_t)2 * (BM * 64 * 2 + BN * 64 * 2);
@@ -426,7 +405,14 @@ hipError_t launch_one(const PGemmParams& p, dim3 grid, hipStream_t stream) {
 
 }  // namespace
 
-int pgemm_tile_rows() { return BM; }
+int pgemm_panel_groups(const PGemmParams& p, int batch, int* ng);
+hipError_t launch_gemm_panel(const PGemmParams& p, int batch, int ng, hipStream_t stream);
+int pgemm_panel_rows();
+// rows per statistics tile of the kernel launch_gemm_planes will pick for these parameters
+int pgemm_stats_rows(const PGemmParams& p, int batch) {
+    int ng;
+    return pgemm_panel_groups(p, batch, &ng) ? pgemm_panel_rows() : BM;
+}
 
 // BN: 128 when that still fills the chip twice over or N needs it, else 64 (N must be a multiple of 64)
 hipError_t launch_gemm_planes(const PGemmParams& p, int batch, hipStream_t stream) {
@@ -435,6 +421,8 @@ hipError_t launch_gemm_planes(const PGemmParams& p, int batch, hipStream_t strea
     const int total_z = batch * p.nsub * p.nside;
     if (maxM <= 0 || N <= 0 || total_z <= 0) return hipSuccess;
     if (p.K % BK || N % 4) return hipErrorInvalidValue;
+    int ng;
+    if (pgemm_panel_groups(p, batch, &ng)) return launch_gemm_panel(p, batch, ng, stream);
     const long wg128 = (long)((maxM + BM - 1) / BM) * ((N + 127) / 128) * total_z;
     const bool bn128 = wg128 >= 512 && p.bn_hint != 64;
     const int bn = bn128 ? 128 : 64;
@@ -458,8 +446,322 @@ hipError_t launch_make_planes(const float* x, _Float16* out, long rows, int C, l
     return hipGetLastError();
 }
 
-hipError_t launch_stats_finalize_chan(const StatsSide sides[2], int nside, int batch, int K, float eps, hipStream_t stream) {
-    hipLaunchKernelGGL(stats_finalize_chan_kernel, dim3((K + 255) / 256, nside, batch), dim3(256), 0, stream, sides[0],
-                       sides[nside - 1], K, eps);
+// =======================================================================================================================
+// Panel kernel: the same GEMM for the shapes of a GNN layer at batch sizes that fill the chip (M >= ~6000 rows).
+//
+// What the probe switches of the tile kernel above showed (tools/probe/gemm_time.py, B = 4, N = 2048, QKV: 31.9 us):
+// the DMA + barrier loop ALONE costs 17.4 us - eight dependent global->LDS round trips per tile with a prefetch distance
+// of one K-tile, every workgroup in the same phase - MFMAs add 6 us, the epilogue 8.5 us.  So the structure is turned
+// around: a workgroup owns a PANEL of 64 rows and keeps its whole A operand (64 rows x 256 k as planes = 64 KB) in LDS,
+// loaded by ONE burst of DMA instructions (one latency); then it walks over all N columns.  Each of the 8 waves (two per
+// SIMD: one computes while the other waits for LDS / DMA) owns all 64 rows x ITS 32 columns of every 256-column tile, so a
+// wave's W operand is private: it runs its own 4-stage DMA ring (2 KB per 16-deep k-step, counted s_waitcnt vmcnt, three
+// steps in flight) and the main loop contains NO workgroup barrier.  A is read from HBM exactly once, W streams from L2,
+// M / 64 workgroups = one per CU at B = 4, N = 2048: one round, no tail.
+//   K > 256 (the MLP convs, K = 512): two K-chunks; the accumulators of ALL N columns stay in registers (NG tiles x 2 MFMA
+//   tiles x 16) while the A chunk in LDS is replaced (N <= 512); N > NG * 256 (q|k|v, N = 768) needs K <= 256 and loops over
+//   groups of NG column tiles, the epilogue of a group overlapping the other waves' MFMAs.
+// Epilogue straight from the accumulators (lane = column, 128-byte row segments): bias, column-range scale, fp32 residual,
+// fp32 rows and / or planes, and the per-panel column statistics (sum, M2 about the panel mean; the whole column of a
+// panel lives in one wave: two passes over registers, no LDS).
+// =======================================================================================================================
+namespace {
+
+constexpr int PM = 64;            // panel rows
+constexpr int KC_MAX = 256;       // K-chunk held in LDS
+constexpr int WST = 4;            // W ring stages per wave
+constexpr int PW = 8;             // waves per workgroup
+constexpr int WSTAGE_BYTES = 2048;            // 32 columns x 16 k x 2 planes x 2 B
+
+template <int NG, int ASRC, int PRO>
+__global__ __launch_bounds__(512, 2) void gemm_panel_kernel(const PGemmParams p, int panels_max) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int K = p.K, KC = K < KC_MAX ? K : KC_MAX, nkt = KC / BK, nchunks = K / KC;
+    char* Abuf = smem;                                   // [nkt][2 planes][4 pieces][1 KiB]
+    char* Wring = smem + nkt * 8192;                     // [8 waves][WST][2 KiB]
+    float* tr = reinterpret_cast<float*>(Wring + PW * WST * WSTAGE_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int z = blockIdx.x;
+    const int panel = z % panels_max; z /= panels_max;
+    const int sidx = z % p.nside;
+    const int b = z / p.nside;
+    const PGemmSide& S = p.side[sidx];
+    const int M = S.M, N = S.N;
+    const int row0 = panel * PM;
+    if (row0 >= M) return;
+    const int flags = p.flags;
+
+    const _Float16* Ap = S.Ap ? S.Ap + b * S.sA_b : nullptr;
+    const _Float16* Ap2 = S.Ap2 ? S.Ap2 + b * S.sA2_b : Ap;
+    const float* Af = S.Af ? S.Af + b * S.sAf_b : nullptr;
+    const char* Wp = reinterpret_cast<const char*>(S.Wp);
+
+    if (ASRC == 1) {
+        for (int k = tid; k < K; k += 512) {
+            float mu, rs;
+            if (S.in_stats) { const float* st = S.in_stats + ((long)b * K + k) * 2; mu = st[0]; rs = st[1]; }
+            else { mu = p.nm_mean[k]; rs = p.nm_rstd[k]; }
+            tr[k] = mu; tr[K + k] = rs;
+            if (PRO == 2) {
+                tr[2 * K + k] = (flags & PG_PRO_AFFINE) ? p.nm_gamma[k] : 1.f;
+                tr[3 * K + k] = (flags & PG_PRO_AFFINE) ? p.nm_beta[k] : 0.f;
+            }
+        }
+    }
+
+    // ---- W ring: this wave's 32 columns of column tile jt, one 16-deep k-step per stage --------------------------------------
+    // stage image [plane][chunk (8 k)][column] of 16-byte slots: DMA lane l fetches column l & 31, chunk l >> 5; the fragment
+    // read of lane (column, half) is slot half * 32 + column: 16 consecutive slots per lane group, conflict-free
+    const unsigned wlane = (unsigned)(((lane & 31) * (long)p.ldw + 8 * (lane >> 5)) * 2);
+    char* wring = Wring + wave * (WST * WSTAGE_BYTES);
+    const int ngroups = N / (NG * 256);
+    const int nks = KC / 16;                                // k-steps per chunk
+    int ic = 0, ig = 0, ij = 0, ik = 0, ipos = 0;           // issue cursor: runs 3 steps ahead, wraps around harmlessly at the end
+    auto issue_w = [&]() {
+        const long col0 = (long)((ig * NG + ij) * 256 + wave * 32);
+        const char* src = Wp + (col0 * p.ldw + ic * KC + ik * 16) * 2 + wlane;
+        char* dst = wring + (ipos & (WST - 1)) * WSTAGE_BYTES;
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(src + (long)K * 2), (lds_void*)(dst + 1024), 16, 0, 0);
+        ++ipos;
+        if (++ik == nks) { ik = 0; if (++ij == NG) { ij = 0; if (++ig == ngroups) { ig = 0; if (++ic == nchunks) ic = 0; } } }
+    };
+
+    // ---- A chunk -> LDS ---------------------------------------------------------------------------------------------------
+    const int li = lane >> 2, lc = (lane & 3) ^ ((li >> 2) & 3);
+    auto load_a_chunk = [&](int c) {
+        if (ASRC == 0) {
+            const bool second = c * KC >= p.ksplit;
+            const _Float16* src = second ? Ap2 : Ap;
+            const int ld = second ? p.lda2 : p.lda, pw = second ? p.apw2 : p.apw;
+            const int kbase = second ? c * KC - p.ksplit : c * KC;
+            for (int q = wave; q < nkt * 8; q += PW) {     // pieces: kt x plane x 16-row block
+                const int kt = q >> 3, plane = (q >> 2) & 1, blk = q & 3;
+                const int r = min(row0 + blk * 16 + li, M - 1);
+                const char* g = reinterpret_cast<const char*>(src + (long)r * ld + plane * pw + kbase + kt * BK) + lc * 16;
+                __builtin_amdgcn_global_load_lds((gbl_void*)g, (lds_void*)(Abuf + kt * 8192 + plane * 4096 + blk * 1024), 16, 0, 0);
+            }
+        } else {
+            // fp32 rows: normalise + activate + split; thread = row tid / 8, 4 consecutive k, 32-k stride
+            const int r = tid >> 3, kq = (tid & 7) * 4;
+            const float* src = Af + (long)min(row0 + r, M - 1) * p.ldaf + c * KC;
+            const int i = r & 15, blk = r >> 4;
+            for (int k0 = 0; k0 < KC; k0 += 128) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = (k0 + 32 * u < KC) ? *reinterpret_cast<const f32x4*>(src + k0 + 32 * u + kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int k = k0 + 32 * u + kq, kg = c * KC + k;
+                    if (k >= KC) break;
+                    const f32x4 mu = *reinterpret_cast<const f32x4*>(tr + kg);
+                    const f32x4 rs = *reinterpret_cast<const f32x4*>(tr + K + kg);
+                    f32x4 x = v[u];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = (x[e] - mu[e]) * rs[e];
+                        if (PRO == 1) t = fmaxf(t, 0.f);
+                        else {
+                            if (flags & PG_PRO_AFFINE) t = t * tr[2 * K + kg + e] + tr[3 * K + kg + e];
+                            t = apply_act(t, p.act);
+                        }
+                        x[e] = t;
+                    }
+                    u32x2 hi, lo;
+                    { unsigned a, d; imp_split2(x[0], x[1], a, d); hi[0] = a; lo[0] = d; imp_split2(x[2], x[3], a, d); hi[1] = a; lo[1] = d; }
+                    const int kt = k >> 5, kk = k & 31;
+                    char* dst = Abuf + kt * 8192 + blk * 1024 + slot_of(i, kk >> 3) * 16 + ((kk >> 2) & 1) * 8;
+                    *reinterpret_cast<u32x2*>(dst) = hi;
+                    *reinterpret_cast<u32x2*>(dst + 4096) = lo;
+                }
+            }
+        }
+    };
+
+    // ---- fragment addresses -------------------------------------------------------------------------------------------------
+    const int fr = lane & 31, fh = lane >> 5;
+    int aoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) aoff[i] = (i * 2 + (fr >> 4)) * 1024 + slot_of(fr & 15, fh) * 16;
+    const int woff = (fh * 32 + fr) * 16;
+
+    f32x16 acc[NG][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int j = 0; j < NG; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+    };
+
+    // ---- epilogue of the NG column tiles of group g ---------------------------------------------------------------------------
+    const int half = lane >> 5, l31 = lane & 31;
+    const int rows_here = min(PM, M - row0);
+    auto epilogue = [&](int g) {
+        const float* R = S.R ? S.R + b * S.sR_b : nullptr;
+        float* C = S.C ? S.C + b * S.sC_b : nullptr;
+        _Float16* Cp = S.Cp ? S.Cp + b * S.sCp_b : nullptr;
+#pragma unroll
+        for (int j = 0; j < NG; ++j) {
+            const int col = (g * NG + j) * 256 + wave * 32 + l31;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+            const float sc = (p.scale_cols > 0 && col < p.scale_cols) ? p.scale : 1.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][i][r] = (acc[j][i][r] + bv) * sc;
+            if (flags & PG_EPI_STATS) {
+                // whole column of the panel in this wave: lanes l, l + 32 hold complementary rows
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = i * 32 + 4 * half + 8 * (r >> 2) + (r & 3);
+                        s += rl < rows_here ? acc[j][i][r] : 0.f;
+                    }
+                s += __shfl_xor(s, 32);
+                const float mean = s / (float)rows_here;
+                float m2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = i * 32 + 4 * half + 8 * (r >> 2) + (r & 3);
+                        const float d = acc[j][i][r] - mean;
+                        m2 = fmaf(rl < rows_here ? d : 0.f, d, m2);
+                    }
+                m2 += __shfl_xor(m2, 32);
+                if (half == 0) {
+                    float* os = S.out_stats + (((long)b * ((M + PM - 1) / PM) + panel) * N + col) * 2;
+                    os[0] = s;
+                    os[1] = m2;
+                }
+            }
+            const int pgrp = p.cpw > 0 ? col / p.cpw : 0, pcol = p.cpw > 0 ? col - pgrp * p.cpw : 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = i * 32 + 4 * half + 8 * (r >> 2) + (r & 3);
+                    if (rl < rows_here) {
+                        const long grow = row0 + rl;
+                        float v = acc[j][i][r];
+                        if (R) v += R[grow * p.ldr + col];
+                        if (C) C[grow * p.ldc + col] = v;
+                        if (Cp) {
+                            const _Float16 hi = (_Float16)v;
+                            _Float16* dst = Cp + grow * p.ldcp + pgrp * 2 * p.cpw + pcol;
+                            dst[0] = hi;
+                            dst[p.cpw] = (_Float16)(v - (float)hi);
+                        }
+                    }
+                }
+        }
+    };
+
+    // ---- main loop ----------------------------------------------------------------------------------------------------------
+    for (int q = 0; q < WST - 1; ++q) issue_w();           // the W ring starts before the A burst: both latencies overlap
+    int pos = 0;
+    zero_acc();
+    for (int c = 0; c < nchunks; ++c) {
+        if (c > 0 || ASRC == 1) __syncthreads();           // every wave is done with the previous A chunk / the norm table is there
+        load_a_chunk(c);
+        __syncthreads();                                   // (drains the A burst and whatever W stages are in flight)
+        for (int g = 0; g < ngroups; ++g) {
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+#pragma unroll 2
+                for (int ks = 0; ks < nks; ++ks) {
+                    issue_w();                             // step pos + 3 into the stage consumed at pos - 1
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // 3 younger steps x 2 loads may still fly
+                    const char* ws = wring + (pos & (WST - 1)) * WSTAGE_BYTES;
+                    const char* as = Abuf + (ks >> 1) * 8192;
+                    const int sx = (ks & 1) * 32;
+                    f16x8 ah[2], al[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        ah[i] = *reinterpret_cast<const f16x8*>(as + (aoff[i] ^ sx));
+                        al[i] = *reinterpret_cast<const f16x8*>(as + 4096 + (aoff[i] ^ sx));
+                    }
+                    const f16x8 wh = *reinterpret_cast<const f16x8*>(ws + woff);
+                    const f16x8 wl = *reinterpret_cast<const f16x8*>(ws + 1024 + woff);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh, acc[j][i], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl, acc[j][i], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh, acc[j][i], 0, 0, 0);
+                    ++pos;
+                }
+            }
+            if (c == nchunks - 1) {
+                epilogue(g);
+                if (g + 1 < ngroups) zero_acc();
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the wrapped-around prefetches must land before the LDS is released
+}
+
+template <int NG, int ASRC, int PRO>
+hipError_t launch_panel(const PGemmParams& p, int batch, int panels_max, hipStream_t stream) {
+    const int KC = p.K < KC_MAX ? p.K : KC_MAX;
+    size_t lds = (size_t)(KC / BK) * 8192 + PW * WST * WSTAGE_BYTES;
+    if (ASRC == 1) lds += (size_t)p.K * (PRO == 2 ? 4 : 2) * sizeof(float);
+    static std::mutex mu;
+    static size_t lds_set = 0;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (lds > lds_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_panel_kernel<NG, ASRC, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            lds_set = lds;
+        }
+    }
+    hipLaunchKernelGGL((gemm_panel_kernel<NG, ASRC, PRO>), dim3(panels_max * p.nside * batch), dim3(512), lds, stream, p, panels_max);
     return hipGetLastError();
 }
+
+}  // namespace
+
+// the panel kernel takes a GEMM when: planes or fp32-normalised A, no sub-batches / row vectors, N a multiple of 256 that is
+// either <= 512 (all N accumulated in registers, any K = chunks of 256 or <= 256) or several 256-column groups with K <= 256,
+// and enough panels to fill the chip
+int pgemm_panel_groups(const PGemmParams& p, int batch, int* ng) {
+    if (p.nsub != 1 || (p.flags & PG_EPI_EXPROW) || p.dbg) return 0;
+    const int N = p.side[0].N, K = p.K;
+    if (N % 256 || (K > KC_MAX && K % KC_MAX) || K % BK) return 0;
+    if (K > KC_MAX && p.ksplit != K && p.ksplit != KC_MAX) return 0;
+    if (K <= KC_MAX && p.ksplit != K) return 0;
+    const int tiles = N / 256;
+    int g = 0;
+    if (tiles <= 2) g = tiles;
+    else if (K <= KC_MAX) g = 1;
+    else return 0;
+    const int maxM = p.nside == 2 ? (p.side[0].M > p.side[1].M ? p.side[0].M : p.side[1].M) : p.side[0].M;
+    const long panels = (long)((maxM + PM - 1) / PM) * p.nside * batch;
+    if (panels < 96) return 0;
+    *ng = g;
+    return 1;
+}
+
+hipError_t launch_gemm_panel(const PGemmParams& p, int batch, int ng, hipStream_t stream) {
+    const int maxM = p.nside == 2 ? (p.side[0].M > p.side[1].M ? p.side[0].M : p.side[1].M) : p.side[0].M;
+    const int panels_max = (maxM + PM - 1) / PM;
+    const bool a_f32 = p.side[0].Af != nullptr;
+    const int pro = a_f32 ? ((!(p.flags & PG_PRO_AFFINE) && p.act == 0) ? 1 : 2) : 0;
+#define IMP_PANEL(NGV)                                                                              \
+    if (ng == NGV) {                                                                                \
+        if (!a_f32) return launch_panel<NGV, 0, 0>(p, batch, panels_max, stream);                   \
+        return pro == 1 ? launch_panel<NGV, 1, 1>(p, batch, panels_max, stream)                     \
+                        : launch_panel<NGV, 1, 2>(p, batch, panels_max, stream);                    \
+    }
+    IMP_PANEL(1) IMP_PANEL(2)
+#undef IMP_PANEL
+    return hipErrorInvalidValue;
+}
+int pgemm_panel_rows() { return PM; }

@@ -67,12 +67,13 @@ struct GemmParams {
 };
 
 hipError_t launch_gemm_f32(const GemmParams& p, int batch, hipStream_t stream);
-// InstanceNorm statistics: partial (sum, sumsq) tiles [b][tiles][K][2] of a producer -> (mean, rstd) [b][K][2],
-// accumulated in fp64 in a fixed order, once per (batch, side) instead of once per consumer workgroup
-struct StatsSide { const float* part; float* out; int tiles; int M; int tile_rows; };   // tile_rows: Chan variant only
+// InstanceNorm statistics: per-block (sum, M2 about the block mean) [b][tiles][K][2] of a producer -> (mean, rstd) [b][K][2];
+// block t = rows [t * tile_rows, min(M, (t + 1) * tile_rows)); merged with Chan's formula in fp64 in a fixed order, once
+// per (batch, side) instead of once per consumer workgroup
+struct StatsSide { const float* part; float* out; int tiles; int M; int tile_rows; };
 hipError_t launch_stats_finalize(const StatsSide sides[2], int nside, int batch, int K, float eps, hipStream_t stream);
-// rows of out_stats produced per launch for M rows (the tile height the launcher will choose)
-int gemm_stats_tiles(int M, int N, int total_z);
+// rows per statistics block of the launch these sizes will get (half the tile height: one wave's rows)
+int gemm_stats_rows(int M, int N, int total_z);
 int gemm_tile_m(int M, int N, int total_z);
 
 // ------------------------------------------------------------------------------------------------
@@ -109,11 +110,11 @@ struct PGemmParams {
     int bn_hint;           // 64 forces 64-column tiles
     int scale_cols;        // output columns < scale_cols are multiplied by `scale` after the bias (multiple of 128)
     float scale, rowvec_scale;
+    int dbg;               // probe switches (gemm_planes.hip), 0 in the product
 };
 hipError_t launch_gemm_planes(const PGemmParams& p, int batch, hipStream_t stream);
-int pgemm_tile_rows();
+int pgemm_stats_rows(const PGemmParams& p, int batch);   // rows per statistics tile of the kernel that will run
 hipError_t launch_make_planes(const float* x, _Float16* out, long rows, int C, long ldx, long ldo, hipStream_t stream);
-hipError_t launch_stats_finalize_chan(const StatsSide sides[2], int nside, int batch, int K, float eps, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // attention (flash-style, softmax in registers; launch_attention_f16x3 = split-half MFMA, launch_attention_f32 = fp32 MFMA)

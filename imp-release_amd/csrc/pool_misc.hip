@@ -28,15 +28,14 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict_
     out[2 * i + 1] = (y - cy) / scaling;
 }
 
-// one thread per keypoint, 128 keypoints per block (= one statistics tile for the following InstanceNorm)
+// one thread per keypoint, 128 keypoints per block; every WAVE (64 keypoints) is one statistics block for the following
+// InstanceNorm: (sum, M2 about the block mean) per channel, merged by launch_stats_finalize (Chan's formula)
 __global__ __launch_bounds__(128) void kenc_first_kernel(Kenc0Side s0, Kenc0Side s1, int c0,
                                                          const float* __restrict__ W0, const float* __restrict__ b0,
                                                          float cx, float cy, float scaling) {
-    __shared__ float red[2][2][64];   // [wave][sum|sq][channel]   (c0 <= 64)
     const Kenc0Side& S = blockIdx.y == 0 ? s0 : s1;
     const int b = blockIdx.z, n = S.n;
-    const int tiles = (n + 127) / 128;
-    if ((int)blockIdx.x >= tiles) return;
+    if ((int)blockIdx.x * 128 >= n) return;
     const int tok = blockIdx.x * 128 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool ok = tok < n;
@@ -47,17 +46,21 @@ __global__ __launch_bounds__(128) void kenc_first_kernel(Kenc0Side s0, Kenc0Side
         sc = S.scores[(long)b * n + tok];
         if (scaling > 0.f) { x = (x - cx) / scaling; y = (y - cy) / scaling; }
     }
+    const int blk = blockIdx.x * 2 + wave, nblk = (n + 63) / 64;
+    const int cnt = min(64, n - blk * 64);                      // valid keypoints of this wave's block
     for (int c = 0; c < c0; ++c) {
         float v = fmaf(W0[c * 3 + 2], sc, fmaf(W0[c * 3 + 1], y, W0[c * 3] * x)) + b0[c];
         if (ok) S.y[((long)b * n + tok) * c0 + c] = v; else v = 0.f;
-        const float s = wave_sum(v), q = wave_sum(v * v);
-        if (lane == 0) { red[wave][0][c] = s; red[wave][1][c] = q; }
-    }
-    __syncthreads();
-    if (S.stats && (int)threadIdx.x < c0) {
-        float* st = S.stats + (((long)b * tiles + blockIdx.x) * c0 + threadIdx.x) * 2;
-        st[0] = red[0][0][threadIdx.x] + red[1][0][threadIdx.x];
-        st[1] = red[0][1][threadIdx.x] + red[1][1][threadIdx.x];
+        if (S.stats && cnt > 0) {                               // wave-uniform
+            const float s = wave_sum(v);
+            const float d = v - s / (float)cnt;
+            const float m2 = wave_sum(ok ? d * d : 0.f);
+            if (lane == 0) {
+                float* st = S.stats + (((long)b * nblk + blk) * c0 + c) * 2;
+                st[0] = s;
+                st[1] = m2;
+            }
+        }
     }
 }
 

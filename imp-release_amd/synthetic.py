@@ -54,12 +54,15 @@ def _rng_for(seed: int, key: str) -> np.random.Generator:
     return np.random.Generator(np.random.PCG64([seed, zlib.crc32(key.encode())]))
 
 
-def _conv(sd, seed, prefix, cout, cin, zero_bias=False, gain=1.0):
+def _conv(sd, seed, prefix, cout, cin, zero_bias=False, gain=1.0, bias_offset=0.0):
     bound = gain / np.sqrt(cin)
     w = _rng_for(seed, prefix + '.weight').uniform(-bound, bound, size=(cout, cin, 1))
     b = _rng_for(seed, prefix + '.bias').uniform(-bound, bound, size=(cout,))
     if zero_bias:
         b[:] = 0.0
+    if bias_offset:
+        # channels whose mean is far above their spread (alternating sign): the stress case for InstanceNorm statistics
+        b = b + bias_offset * np.where(np.arange(cout) % 2 == 0, 1.0, -1.0)
     sd[prefix + '.weight'] = w.astype(np.float32)
     sd[prefix + '.bias'] = b.astype(np.float32)
 
@@ -73,9 +76,10 @@ def _bn(sd, seed, prefix, c):
 
 
 def make_state_dict(config: dict, model: str = 'GM', seed: int = 0, bin_score: float = 1.0,
-                    gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+                    gain: float = 1.0, bias_offset: float = 0.0) -> "OrderedDict[str, np.ndarray]":
     """numpy state_dict with the reference key schema; uniform(+-gain/sqrt(fan_in)) like torch's default
-    Conv1d init, last kenc / MLP biases zero as in nets/layers.py:86,145,191,198."""
+    Conv1d init, last kenc / MLP biases zero as in nets/layers.py:86,145,191,198.  ``bias_offset`` shifts the biases of
+    every conv that feeds an InstanceNorm (keypoint encoder, mlp.0) by +-offset: |channel mean| >> channel std."""
     cfg = {**DEFAULT_CONFIG, **config}
     D = cfg['descriptor_dim']
     names = cfg['GNN_layers']
@@ -85,7 +89,8 @@ def make_state_dict(config: dict, model: str = 'GM', seed: int = 0, bin_score: f
     chans = [3] + list(cfg['keypoint_encoder']) + [D]
     for i in range(1, len(chans)):
         last = i == len(chans) - 1
-        _conv(sd, seed, f'kenc.encoder.{3 * (i - 1)}', chans[i], chans[i - 1], zero_bias=last, gain=gain)
+        _conv(sd, seed, f'kenc.encoder.{3 * (i - 1)}', chans[i], chans[i - 1], zero_bias=last, gain=gain,
+              bias_offset=0.0 if last else bias_offset)
         if not last and norm == 'bn':
             _bn(sd, seed, f'kenc.encoder.{3 * (i - 1) + 1}', chans[i])
     shared = sharing_pattern(len(names), model)
@@ -98,7 +103,7 @@ def make_state_dict(config: dict, model: str = 'GM', seed: int = 0, bin_score: f
             _conv(sd, seed, p + '.attn.merge', D, D, gain=gain)
             for j in range(3):
                 _conv(sd, seed, p + f'.attn.proj.{j}', D, D, gain=gain)
-        _conv(sd, seed, p + '.mlp.0', 2 * D, 2 * D, gain=gain)
+        _conv(sd, seed, p + '.mlp.0', 2 * D, 2 * D, gain=gain, bias_offset=bias_offset)
         if norm == 'bn':
             _bn(sd, seed, p + '.mlp.1', 2 * D)
         _conv(sd, seed, p + '.mlp.3', D, 2 * D, zero_bias=True, gain=gain)

@@ -214,6 +214,10 @@ int imp_op_linear_planes(imp_ctx* ctx, int M, int N, int K, const float* x, cons
  * imp_forward_layer is the UNMODIFIED output of the previous imp_forward_layer call whenever the pointers and shapes match,
  * so the layer reuses those planes instead of re-splitting its input.  Default off; imp_match_pair always chains its own. */
 int imp_trust_descriptor_planes(imp_ctx* ctx, int on);
+/* probe (tools/probe/gemm_time.py): average milliseconds of one of the three GEMMs of GNN layer 0 (which: 0 q|k|v projection,
+ * 1 MLP conv 0, 2 MLP conv 3) at [batch][n] on the context's workspace; dbg >= 0: gemm_planes.hip with its probe switches,
+ * dbg < 0: gemm_f32.hip */
+int imp_time_layer_gemm(imp_ctx* ctx, int batch, int n, int which, int dbg, int reps, float* ms, void* stream);
 /* chip-resident Sinkhorn health (ot_resident.hip): *status != 0 when a group barrier ever timed out on this context
  * (results of that call are then garbage - never observed; the spin is bounded so that it cannot hang); *used = whether
  * the resident path has been taken at all.  Synchronises. */

