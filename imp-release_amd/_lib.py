@@ -14,7 +14,8 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libimp_hip.so')
+# IMP_HIP_LIB: an alternative build of the same library (A/B runs of kernel variants: tools/build_variant.sh)
+LIB_PATH = os.environ.get('IMP_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libimp_hip.so')
 
 MODEL_IDS = {'GM': 0, 'DGNNS': 1, 'AdaGMN': 2}
 NORM_IDS = {'in': 0, 'bn': 1}

@@ -368,6 +368,12 @@ __device__ unsigned long long pp_prof[8][8];
 #ifndef PP_INIT_IN_ACC
 #define PP_INIT_IN_ACC 1    // S accumulators start at -m_ref (1) or at 0 with the reference subtracted in the vector phase (0)
 #endif
+#ifndef PP_CNEG
+#define PP_CNEG 1           // first MFMA of each S chain reads its C operand from a constant -m_ref vector instead of 32 v_mov per tile (A/B on one box: 94.3 vs 95.4 us)
+#endif
+#ifndef PP_PKADD
+#define PP_PKADD 0          // row sums with v_pk_add_f32: measured 118 vs 95 us (the register pairing costs more than the adds save)
+#endif
 #ifndef PP_LOADS_IN_X
 #define PP_LOADS_IN_X 0    // where the global loads of the staged tile are issued: matrix phase (1) or vector phase (0); measured equal
 #endif
@@ -528,9 +534,14 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 #pragma unroll
         for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[d], ph[jb][s2], oacc[d], 0, 0, 0);
     };
+    // cneg = -m_ref in all 16 registers: the C operand of the FIRST MFMA of both S chains of a tile (the MFMA reads C from
+    // cneg and writes D to sacc), so the accumulators need no 32 v_mov per tile; rewritten only when m_ref moves (slow path)
+    f32x16 cneg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cneg[r] = 0.f;
     auto mfma_k = [&](int s, const f16x8 (&f)[4]) {
-        sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[2], qh[s], sacc[0], 0, 0, 0);
-        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[3], qh[s], sacc[1], 0, 0, 0);
+        sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[2], qh[s], (PP_CNEG && PP_INIT_IN_ACC && s == 0) ? cneg : sacc[0], 0, 0, 0);
+        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[3], qh[s], (PP_CNEG && PP_INIT_IN_ACC && s == 0) ? cneg : sacc[1], 0, 0, 0);
         sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], ql[s], sacc[0], 0, 0, 0);
         sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[1], ql[s], sacc[1], 0, 0, 0);
         sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], qh[s], sacc[0], 0, 0, 0);
@@ -551,15 +562,13 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     };
     auto qk_mfmas = [&](int kslot, bool prefetched) {
         if (!prefetched) read_k(kslot, 0, fr[0]);
-#if PP_INIT_IN_ACC
-        const float c0 = -m_ref;
-#else
-        const float c0 = 0.f;                   // (the compiler feeds the first MFMA of each chain an inline zero)
-#endif
+#if !(PP_CNEG && PP_INIT_IN_ACC)
+        const float c0 = PP_INIT_IN_ACC ? -m_ref : 0.f;         // (0: the compiler feeds the first MFMA of each chain an inline zero)
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[jb][r] = c0;
+#endif
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             if (s + 1 < KS) read_k(kslot, s + 1, fr[(s + 1) & 1]);
@@ -570,20 +579,25 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     };
     // P = exp2(acc - ref) for the 32 logits of this lane, split into the B-operand fragments; returns their sum
     auto probabilities = [&](float delta) {
-        float lsum = 0.f;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 ls2 = {0.f, 0.f};                 // two running sums: v_pk_add_f32 (one instruction per pair of probabilities)
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 float pv[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    pv[e] = fast_exp2(sacc[jb][8 * s2 + e] - delta);
-                    lsum += pv[e];
-                }
+                for (int e = 0; e < 8; ++e) pv[e] = fast_exp2(sacc[jb][8 * s2 + e] - delta);
+#if PP_PKADD
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) ls2 += f32x2{pv[e], pv[e + 1]};
+#else
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ls2[0] += pv[e];
+#endif
                 split8(pv, ph[jb][s2], pl[jb][s2]);
             }
-        return lsum;
+        return ls2[0] + ls2[1];
     };
 
 #ifdef PP_PROFILE
@@ -638,6 +652,10 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
             const float delta = (tmax == -INFINITY) ? 0.f : (lq > 0.f ? fmaxf(tmax, 0.f) : tmax);
             const float alpha = lq > 0.f ? fast_exp2(-delta) : 0.f;
             m_ref += delta;
+#if PP_CNEG && PP_INIT_IN_ACC
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cneg[r] = -m_ref;
+#endif
             l_run *= alpha;
 #pragma unroll
             for (int d = 0; d < DT; ++d)
@@ -689,13 +707,7 @@ hipError_t launch_pp(const AttnParams& p, int batch, int maxq, hipStream_t strea
     const int qtiles = (maxq + 255) / 256;
     const int total = qtiles * IMP_NUM_HEADS * p.nside * batch;
     const size_t lds = (size_t)(4 * KT * (DH + 4) + 4 * KT * (DH + 16) + 4 * KT) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_f16x3_pp_kernel<DH>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = imp_grant_dynamic_lds((const void*)attn_f16x3_pp_kernel<DH>, lds)) return e;
     hipLaunchKernelGGL((attn_f16x3_pp_kernel<DH>), dim3(total), dim3(512), lds, stream, p, qtiles, total);
     return hipGetLastError();
 }
@@ -705,13 +717,7 @@ hipError_t launch_one(const AttnParams& p, int batch, int maxq, hipStream_t stre
     const int qtiles = (maxq + NWAVES * 32 - 1) / (NWAVES * 32);
     const int total = qtiles * IMP_NUM_HEADS * p.nside * batch;
     const size_t lds = (size_t)(2 * KT * (DH + 4) + 2 * DH * (KT + 4) + 2 * KT) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_f16x3_kernel<DH, NWAVES>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = imp_grant_dynamic_lds((const void*)attn_f16x3_kernel<DH, NWAVES>, lds)) return e;
     hipLaunchKernelGGL((attn_f16x3_kernel<DH, NWAVES>), dim3(total), dim3(NWAVES * 64), lds, stream, p, qtiles, total);
     return hipGetLastError();
 }

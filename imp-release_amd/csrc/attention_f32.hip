@@ -265,13 +265,7 @@ hipError_t launch_one(const AttnParams& p, int batch, int maxq, hipStream_t stre
     const int qtiles = (maxq + NWAVES * 32 - 1) / (NWAVES * 32);
     const int total = qtiles * IMP_NUM_HEADS * p.nside * batch;
     const size_t lds = (size_t)(2 * KT * (DH + 4) + 2 * KT * DH + 2 * KT) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_f32_kernel<DH, NWAVES>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = imp_grant_dynamic_lds((const void*)attn_f32_kernel<DH, NWAVES>, lds)) return e;
     hipLaunchKernelGGL((attn_f32_kernel<DH, NWAVES>), dim3(total), dim3(NWAVES * 64), lds, stream, p, qtiles, total);
     return hipGetLastError();
 }

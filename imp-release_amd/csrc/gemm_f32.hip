@@ -422,36 +422,52 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 3) void gemm_f32_kernel(const GemmP
     }
 }
 
-// per-block (sum, M2 about the block mean) -> (mean, rstd): Chan's parallel merge in fp64, fixed order.
-// block t covers rows [t * tile_rows, min(M, (t + 1) * tile_rows)).
+// per-block (sum, M2 about the block mean) -> (mean, rstd): Chan's parallel merge, fp64, fixed order.
+// block t covers rows [t * tile_rows, min(M, (t + 1) * tile_rows)).  With n_t rows, sum s_t and M2_t per block:
+//     mean = sum_t s_t / N,   M2 = sum_t M2_t + sum_t s_t^2 / n_t - N mean^2
+// (the last two terms are the between-block part sum_t n_t (mean_t - mean)^2; in fp64 their cancellation costs
+// (mean / std)^2 x 2^-53 relative - nothing for any fp32-representable channel).  Workgroup = 64 channels x 4 block groups
+// (group g takes blocks g, g + 4, ...; 4 independent loads in flight), combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void stats_finalize_kernel(StatsSide s0, StatsSide s1, int K, float eps) {
+    __shared__ double sm[4][3][64];
     const StatsSide& S = blockIdx.y == 0 ? s0 : s1;
     const int b = blockIdx.z;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= K) return;
-    const float2* st = reinterpret_cast<const float2*>(S.part) + (long)b * S.tiles * K + k;
-    double tot = 0.0;
-    int t = 0;
-    for (; t + 8 <= S.tiles; t += 8) {          // 8 independent loads in flight, then a fixed-order fp64 sum
-        float2 v[8];
+    const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + cx;
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (k < K) {
+        const float2* st = reinterpret_cast<const float2*>(S.part) + (long)b * S.tiles * K + k;
+        int t = g;
+        for (; t + 12 < S.tiles; t += 16) {
+            float2 v[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = st[(long)(t + u) * K];
+            for (int u = 0; u < 4; ++u) v[u] = st[(long)(t + 4 * u) * K];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) tot += (double)v[u].x;
+            for (int u = 0; u < 4; ++u) {
+                const int nt = min(S.tile_rows, S.M - (t + 4 * u) * S.tile_rows);
+                a1 += (double)v[u].x; a2 += (double)v[u].y; a3 += (double)v[u].x * (double)v[u].x / (double)nt;
+            }
+        }
+        for (; t < S.tiles; t += 4) {
+            const float2 v = st[(long)t * K];
+            const int nt = min(S.tile_rows, S.M - t * S.tile_rows);
+            a1 += (double)v.x; a2 += (double)v.y; a3 += (double)v.x * (double)v.x / (double)nt;
+        }
     }
-    for (; t < S.tiles; ++t) tot += (double)st[(long)t * K].x;
-    const double mean = tot / (double)S.M;
-    double m2 = 0.0;
-    for (t = 0; t < S.tiles; ++t) {             // (second sweep: the partials are L2-resident)
-        const float2 v = st[(long)t * K];
-        const int nt = min(S.tile_rows, S.M - t * S.tile_rows);
-        const double d = (double)v.x / (double)nt - mean;
-        m2 += (double)v.y + (double)nt * d * d;
+    sm[g][0][cx] = a1; sm[g][1][cx] = a2; sm[g][2][cx] = a3;
+    __syncthreads();
+    if (g == 0 && k < K) {
+        const double s1t = (sm[0][0][cx] + sm[1][0][cx]) + (sm[2][0][cx] + sm[3][0][cx]);
+        const double m2w = (sm[0][1][cx] + sm[1][1][cx]) + (sm[2][1][cx] + sm[3][1][cx]);
+        const double sqn = (sm[0][2][cx] + sm[1][2][cx]) + (sm[2][2][cx] + sm[3][2][cx]);
+        const double mean = s1t / (double)S.M;
+        double m2 = m2w + (sqn - (double)S.M * mean * mean);
+        m2 = m2 < 0.0 ? 0.0 : m2;
+        float2 o;
+        o.x = (float)mean;
+        o.y = (float)(1.0 / sqrt(m2 / (double)S.M + (double)eps));       // biased variance, eps inside the root (nets/layers.py:67-68)
+        reinterpret_cast<float2*>(S.out)[(long)b * K + k] = o;
     }
-    float2 o;
-    o.x = (float)mean;
-    o.y = (float)(1.0 / sqrt(m2 / (double)S.M + (double)eps));       // biased variance, eps inside the root (nets/layers.py:67-68)
-    reinterpret_cast<float2*>(S.out)[(long)b * K + k] = o;
 }
 
 size_t gemm_lds_bytes(int BM, int BN, int pro, int K) {
@@ -471,18 +487,7 @@ void gemm_pick_tile(int M, int N, int total_z, int* bm, int* bn) {
 template <int BM, int BN, int PRO, int PREC, int DEEP>
 hipError_t gemm_launch_one(const GemmParams& p, dim3 grid, hipStream_t stream) {
     const size_t lds = gemm_lds_bytes(BM, BN, PRO, p.K);
-    // largest dynamic-LDS size already granted to this instantiation (several host threads may launch: eval_loop workers)
-    static std::mutex mu;
-    static size_t lds_set = 0;
-    if (lds > 48 * 1024) {
-        std::lock_guard<std::mutex> lock(mu);
-        if (lds > lds_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_f32_kernel<BM, BN, PRO, PREC, DEEP>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            lds_set = lds;
-        }
-    }
+    if (hipError_t e = imp_grant_dynamic_lds((const void*)gemm_f32_kernel<BM, BN, PRO, PREC, DEEP>, lds)) return e;
     const int total = (int)(grid.x * grid.y * grid.z);
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, PRO, PREC, DEEP>), dim3(total), dim3(256), lds, stream, p, (int)grid.x, (int)grid.y,
                        total);
@@ -538,7 +543,7 @@ hipError_t launch_gemm_f32(const GemmParams& p, int batch, hipStream_t stream) {
 }
 
 hipError_t launch_stats_finalize(const StatsSide sides[2], int nside, int batch, int K, float eps, hipStream_t stream) {
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((K + 255) / 256, nside, batch), dim3(256), 0, stream, sides[0],
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((K + 63) / 64, nside, batch), dim3(256), 0, stream, sides[0],
                        sides[nside - 1], K, eps);
     return hipGetLastError();
 }

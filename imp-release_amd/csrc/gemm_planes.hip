@@ -388,16 +388,7 @@ template <int BN, int ASRC, int PRO>
 hipError_t launch_one(const PGemmParams& p, dim3 grid, hipStream_t stream) {
     size_t lds = (size_t)2 * (BM * 64 * 2 + BN * 64 * 2);
     if (ASRC == 1) lds += (size_t)p.K * (PRO == 2 ? 4 : 2) * sizeof(float);
-    static std::mutex mu;
-    static size_t lds_set = 0;
-    if (lds > 48 * 1024) {
-        std::lock_guard<std::mutex> lock(mu);
-        if (lds > lds_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_planes_kernel<BN, ASRC, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            lds_set = lds;
-        }
-    }
+    if (hipError_t e = imp_grant_dynamic_lds((const void*)gemm_planes_kernel<BN, ASRC, PRO>, lds)) return e;
     const int total = (int)(grid.x * grid.y * grid.z);
     hipLaunchKernelGGL((gemm_planes_kernel<BN, ASRC, PRO>), dim3(total), dim3(256), lds, stream, p, (int)grid.x, (int)grid.y, total);
     return hipGetLastError();
@@ -712,16 +703,7 @@ hipError_t launch_panel(const PGemmParams& p, int batch, int panels_max, hipStre
     const int KC = p.K < KC_MAX ? p.K : KC_MAX;
     size_t lds = (size_t)(KC / BK) * 8192 + PW * WST * WSTAGE_BYTES;
     if (ASRC == 1) lds += (size_t)p.K * (PRO == 2 ? 4 : 2) * sizeof(float);
-    static std::mutex mu;
-    static size_t lds_set = 0;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        if (lds > lds_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_panel_kernel<NG, ASRC, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            lds_set = lds;
-        }
-    }
+    if (hipError_t e = imp_grant_dynamic_lds((const void*)gemm_panel_kernel<NG, ASRC, PRO>, lds)) return e;
     hipLaunchKernelGGL((gemm_panel_kernel<NG, ASRC, PRO>), dim3(panels_max * p.nside * batch), dim3(512), lds, stream, p, panels_max);
     return hipGetLastError();
 }

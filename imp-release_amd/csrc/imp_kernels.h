@@ -6,6 +6,10 @@
 
 #define IMP_NUM_HEADS 4          // hard-coded in nets/layers.py:157,230
 
+// opt-in to more than 48 KB of dynamic LDS for `kernel`: the attribute is per device, so the largest size already granted is
+// tracked per (device, kernel) under a mutex (worker threads launch concurrently; a process may drive several GPUs)
+hipError_t imp_grant_dynamic_lds(const void* kernel, size_t bytes);
+
 #ifdef __HIPCC__
 // Split-precision operands: x = hi + lo with hi = f16(x) (round to nearest even) and lo = f16(x - hi); x - hi is exact
 // in fp32, so lo carries the next 11 significant bits.  Two values at a time: one packed convert for the hi halves and

@@ -492,17 +492,21 @@ __global__ __launch_bounds__(256) void mutual_kernel(int n0, int n1, const float
     const float* m0 = max0 + (long)b * n0;
     const int* a0 = arg0 + (long)b * n0;
     const int* a1 = arg1 + (long)b * n1;
+    // an argmax of 0x7fffffff means "no maximum found" (a row of NaNs: |operand| >= 65504 in f16x3 mode, or NaN inputs):
+    // such a keypoint has no match - never an out-of-range read
     if (t < n0) {
         const int j = a0[t];
-        const bool mutual = a1[j] == t;
+        const bool mutual = (unsigned)j < (unsigned)n1 && a1[j] == t;
         const float s = mutual ? m0[t] : 0.f;
         if (ms0) ms0[(long)b * n0 + t] = s;
         if (ind0) ind0[(long)b * n0 + t] = (mutual && s > p) ? (int64_t)j : (int64_t)-1;
     }
     if (t < n1) {
         const int i = a1[t];
-        const bool mutual1 = a0[i] == t;
-        const bool mutual0_i = a1[a0[i]] == i;
+        const bool ok_i = (unsigned)i < (unsigned)n0;
+        const int ji = ok_i ? a0[i] : -1;
+        const bool mutual1 = ok_i && ji == t;
+        const bool mutual0_i = ok_i && (unsigned)ji < (unsigned)n1 && a1[ji] == i;
         const float s0_i = mutual0_i ? m0[i] : 0.f;
         const bool valid0_i = mutual0_i && s0_i > p;
         if (ms1) ms1[(long)b * n1 + t] = mutual1 ? s0_i : 0.f;
@@ -570,12 +574,7 @@ template <int NCH, int COMPACT>
 static void launch_fused_iteration(int batch, int n0, int n1, OtBuffers& ot, hipStream_t stream) {
     const int nwg = (n0 + FP_ROWS - 1) / FP_ROWS;
     const size_t lds = (size_t)(1 + FP_WAVES) * ot.ldp * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)ot_fused_pass_kernel<NCH, COMPACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)((1 + FP_WAVES) * (NCH * 256) * sizeof(float)));
-        attr_set = true;
-    }
+    (void)imp_grant_dynamic_lds((const void*)ot_fused_pass_kernel<NCH, COMPACT>, (size_t)(1 + FP_WAVES) * (NCH * 256) * sizeof(float));
     hipLaunchKernelGGL((ot_fused_pass_kernel<NCH, COMPACT>), dim3(nwg, batch), dim3(512), lds, stream,
                        COMPACT ? reinterpret_cast<const float*>(ot.P24) : ot.P, n0, n0 + 1, ot.ldp, ot.v, ot.u, ot.ldpt,
                        ot.partials, nwg);

@@ -396,8 +396,7 @@ hipError_t launch_one(const OtResidentParams& p, hipStream_t stream) {
     if (stage2 > red) red = stage2;
     const size_t lds = (LDX + red) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute((const void*)ot_resident_kernel<NCH, RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    if (hipError_t e = imp_grant_dynamic_lds((const void*)ot_resident_kernel<NCH, RPW>, lds)) return e;
     hipLaunchKernelGGL((ot_resident_kernel<NCH, RPW>), dim3(p.B * p.G), dim3(512), lds, stream, p);
     return hipGetLastError();
 }

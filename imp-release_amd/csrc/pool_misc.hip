@@ -6,6 +6,27 @@
 //                                                                 union, wave-ballot stream compaction)
 //   ragged gather                      eval/matching.py:166-174
 #include "imp_kernels.h"
+#include <map>
+#include <mutex>
+#include <utility>
+
+hipError_t imp_grant_dynamic_lds(const void* kernel, size_t bytes) {
+    if (bytes <= 48 * 1024) return hipSuccess;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> granted;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& g = granted[std::make_pair(dev, kernel)];
+    if (bytes > g) {
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        g = bytes;
+    }
+    return hipSuccess;
+}
+
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -57,7 +57,7 @@ class H5PairStore:
     """the reference's ``*.hdf5`` dump; ``image_sizes`` = callable index -> ((H1, W1), (H2, W2)) or a fixed pair (the file
     stores image PATHS, not sizes: pass the sizes, or a function that looks them up, instead of decoding the JPEGs)"""
 
-    def __init__(self, path: str, num_kpt: Optional[int] = None, image_sizes=((480, 640), (480, 640))):
+    def __init__(self, path: str, num_kpt: Optional[int] = None, *, image_sizes):
         try:
             import h5py
         except ImportError as ex:                                      # pragma: no cover - h5py is absent in this image
@@ -92,8 +92,8 @@ def write_npz_store(records: Iterable[dict], directory: str) -> int:
     return n
 
 
-def convert_h5_to_npz(h5_path: str, directory: str, image_sizes=((480, 640), (480, 640))) -> int:
-    store = H5PairStore(h5_path, None, image_sizes)
+def convert_h5_to_npz(h5_path: str, directory: str, *, image_sizes) -> int:
+    store = H5PairStore(h5_path, None, image_sizes=image_sizes)
     def gen():
         for i in range(len(store)):
             rec = {k: store.f[k][str(i)][()] for k in FIELDS}

@@ -255,4 +255,4 @@ def test_pair_store_roundtrip_and_feed_dict(tmp_path):
         import h5py  # noqa: F401
     except ImportError:
         with pytest.raises(ImportError, match='h5py'):
-            data.H5PairStore(str(tmp_path / 'x.hdf5'))
+            data.H5PairStore(str(tmp_path / 'x.hdf5'), image_sizes=((480, 640), (480, 640)))

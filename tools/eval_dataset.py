@@ -22,6 +22,8 @@ def main():
     ap.add_argument('--dataset', required=True, help='*.hdf5 dump of the reference or a directory of pair_<i>.npz files')
     ap.add_argument('--num-kpt', type=int, default=2000)
     ap.add_argument('--model', choices=['IMP', 'EIMP'], default='IMP')
+    ap.add_argument('--height', type=int, required=False, default=None, help='image height of an *.hdf5 dump (it stores paths, not sizes)')
+    ap.add_argument('--width', type=int, required=False, default=None)
     ap.add_argument('--weights', default=None, help="checkpoint with a 'model' state dict (eval/eval_imp.py:333); "
                                                     'seeded random weights when omitted')
     ap.add_argument('--workers', type=int, default=3)
@@ -35,7 +37,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-    store = pdata.H5PairStore(a.dataset, a.num_kpt) if a.dataset.endswith(('.hdf5', '.h5')) else pdata.NpzPairStore(a.dataset, a.num_kpt)
+    if a.dataset.endswith(('.hdf5', '.h5')) and (a.height is None or a.width is None):
+        ap.error('--height and --width are required for an hdf5 dump (keypoint normalisation depends on them)')
+    store = pdata.H5PairStore(a.dataset, a.num_kpt, image_sizes=((a.height, a.width), (a.height, a.width))) if a.dataset.endswith(('.hdf5', '.h5')) else pdata.NpzPairStore(a.dataset, a.num_kpt)
     n = len(store) if a.pairs <= 0 else min(a.pairs, len(store))
     cfg = {'descriptor_dim': 256, 'sinkhorn_iterations': 20, 'match_threshold': 0.2, 'with_sinkhorn': True, 'n_layers': 15,
            'GNN_layers': ['self', 'cross'] * 15, 'ac_fn': 'relu', 'norm_fn': 'in', 'n_min_tokens': 256}
