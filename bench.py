@@ -97,6 +97,52 @@ def cpu_baseline(args):
                       f"{ {k: round(v, 2) for k, v in probes.items()} } pairs/s probed at N=512), host exposes {ncpu} CPUs"}
 
 
+def batch1_latencies(dev, args):
+    import imp_release_amd as P
+    from imp_release_amd import matching, synthetic
+
+    def model_of(name, cfg, **kw):
+        sd = synthetic.make_state_dict(cfg, name, seed=0, **kw)
+        m = getattr(P, name)(dict(cfg, precision=args.precision)).eval()
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        return m.to(dev)
+
+    def data_of(n0, n1, seed):
+        pair = synthetic.make_correlated_pair(n0, n1, seed=seed)
+        d = {k: torch.from_numpy(v).to(dev) for k, v in pair.items() if k != 'image_shape'}
+        d['image0'] = d['image1'] = torch.zeros(pair['image_shape'], device=dev)
+        return d
+
+    def timeit(fn, reps, warm):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    out = {}
+    with torch.no_grad():
+        m = model_of('GM', eval_config(9, 100))
+        d = data_of(1024, 1024, 5)
+        out['c2_latency_ms'] = timeit(lambda: m.produce_matches(d, p=0.2, only_last=True), 20, 3)
+        del m
+        cfg = eval_config(15, 20)
+        m = model_of('AdaGMN', cfg, bin_score=5.0)
+        d = data_of(4096, 4000, 41)
+        d['pts0_cpu'] = d['keypoints0'][0].cpu().numpy(); d['pts1_cpu'] = d['keypoints1'][0].cpu().numpy()
+        d['K0'] = d['K1'] = np.eye(3); d['T_0to1'] = np.eye(4)
+        tr = []
+        out['eimp_n4096_ms_per_pair'] = timeit(
+            lambda: matching.matching_iterative_uncertainty(d, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, trace=tr), 4, 1)
+        out['eimp_n4096_trajectory'] = [(t['n0'], t['n1']) for t in tr[-7:]]
+    out['batch1_note'] = ('c2 = BASELINE configs[1] (GM, N=1024, 9 iterations, 100 Sinkhorn, batch 1, one call after the other); '
+                          'eimp = configs[3] (AdaGMN sliced loop from N=4096/4000, 15 iterations, 7 score+pool steps, bin_score 5, pose stubbed)')
+    return out
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == '--cpu-worker':
         _cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]))
@@ -315,6 +361,10 @@ def main():
                                       'ms_per_step': h2d_s / args.steps * 1e3,
                                       'note': 'every step uploads its batch (keypoints, scores, descriptors of '
                                               'both images) from pinned host memory on the step stream'}
+        if world == 1:
+            # the batch-1 configurations of BASELINE.json on the same GPU (not the metric; recorded so that every round
+            # shows them): configs[1] GM N=1024 L=9 T=100 batch 1, and configs[3] the EIMP sliced loop from N=4096
+            line.update(batch1_latencies(dev, args))
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args)
         else:

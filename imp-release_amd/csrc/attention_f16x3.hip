@@ -379,7 +379,7 @@ __device__ unsigned long long pp_prof[8][8];
 #endif
 
 template <int DH>
-__global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams p, int qtiles, int total_blocks) {
+__global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams p, int qtiles, int total_blocks, int nsplit) {
     static_assert(DH == 64 || DH == 32, "head widths of the reference: 256 / 4 and 128 / 4 channels");
     constexpr int NT = 512;
     constexpr int KROW = DH + 4;                 // K row: 32 floats of hi halves, 32 of lo halves, 4 pad
@@ -397,6 +397,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int group = wave >> 2;                // 0: waves 0-3, 1: waves 4-7 (one phase behind)
     int id = xcd_remap(blockIdx.x, total_blocks);
+    const int sp = id % nsplit; id /= nsplit;   // key split: this workgroup walks over tiles [t0, t0 + nt) of the keys
     const int qt = id % qtiles; id /= qtiles;
     const int h = id % IMP_NUM_HEADS; id /= IMP_NUM_HEADS;
     const int sidx = id % p.nside;
@@ -406,6 +407,9 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     const int q0 = qt * 256;
     if (q0 >= nq) return;
 
+    const int nt_all = (nk + KT - 1) / KT, t_per = (nt_all + nsplit - 1) / nsplit;
+    const int t0 = sp * t_per;
+    const int nt = min(nt_all, t0 + t_per) - t0;     // >= 1: the launcher never makes more splits than it has tiles for
     const float* Qg = S.q + b * S.sq_b + h * DH;
     const float* Kg = S.k + b * S.sk_b + h * DH;
     const float* Vg = S.v + b * S.sk_b + h * DH;
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     f32x4 rvA[LK], rvB[LK];
     unsigned char rbA = 1, rbB = 1;
     auto load_tile = [&](int t, f32x4 (&rk)[LK], f32x4 (&rv)[LK], unsigned char& rb) {
-        const int k0 = t * KT;
+        const int k0 = (t0 + t) * KT;
         const int soff = k0 * row_bytes;
 #pragma unroll
         for (int j = 0; j < LK; ++j) {
@@ -486,8 +490,6 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     float m_ref = 0.f;            // log2-domain reference exponent of this lane's query (identical in both lane halves)
     float l_run = 0.f;            // this lane's partial row sum, relative to m_ref
     bool need_slow = true;        // wave-uniform: some query of the wave has not seen an unmasked key yet
-    const int nt = (nk + KT - 1) / KT;
-
     load_tile(0, rkA, rvA, rbA);
     if (nt > 1) load_tile(1, rkB, rvB, rbB);
     store_tile(0, rkA, rvA, rbA);
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
         PP_BARRIER();
         PP_CLK(1);
         // =============================== Y(t): vector phase ===============================================
-        if (mk != nullptr || (t + 1) * KT > nk) {
+        if (mk != nullptr || (t0 + t + 1) * KT > nk) {
             const float* bs = Bs + (t & 3) * KT;
 #pragma unroll
             for (int jb = 0; jb < 2; ++jb)
@@ -689,6 +691,100 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     constexpr int LDO = DH + 1;
     float* ot = smem + wave * 32 * LDO;
+    if (nsplit > 1) {
+        // ---- key split: this workgroup holds a PARTIAL result (O relative to its own m_ref, l, m_ref).  It goes to scratch
+        // with agent-coherent write-through stores; a ticket per (pair, side, head, query tile) tells the LAST of the nsplit
+        // workgroups to arrive, and that one merges: m = max m_s, O = sum_s 2^(m_s - m) O_s, l likewise, out = O / l.
+        // Nobody waits for anybody (no spin): the ticket is a relaxed agent-scope atomic taken after the stores are acknowledged.
+        constexpr int PART = 256 * DH + 512;                  // floats per partial: O [256][DH] | m [256] | l [256]
+        const long unit = (((long)b * p.nside + sidx) * IMP_NUM_HEADS + h) * qtiles + qt;
+        float* wsu = p.split_ws + unit * nsplit * PART;
+        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)wsu, 0, (unsigned)(nsplit * PART * 4), 0x00020000);
+        // rows staged with a 16-byte aligned pitch: 128-bit write-through stores, LPR lanes per row, RPI rows per instruction
+        constexpr int LDP = DH + 4, LPR = DH / 4, RPI = 64 / LPR;
+        float* otp = smem + wave * 32 * LDP;
+        const int prow = lane / LPR, pc4 = (lane % LPR) * 4;
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) otp[l31 * LDP + d * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = oacc[d][r];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 32 / RPI; ++j) {
+            const int qi = j * RPI + prow;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(otp + qi * LDP + pc4);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
+                                                   rsW, ((sp * PART) + (wave * 32 + qi) * DH + pc4) * 4, 0, 16);
+        }
+        if (half == 0) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m_ref), rsW, (sp * PART + 256 * DH + wave * 32 + l31) * 4, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l_tot), rsW, (sp * PART + 256 * DH + 256 + wave * 32 + l31) * 4, 0, 16);
+        }
+        __builtin_amdgcn_s_waitcnt(0);                         // the write-through stores are acknowledged
+        __syncthreads();
+        __shared__ int s_last;
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(p.split_cnt + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == (unsigned)nsplit - 1;
+            if (s_last) __hip_atomic_store(p.split_cnt + unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+        }
+        __syncthreads();
+        if (!s_last) return;
+        // merge (this wave: its 32 queries; lane l31 owns query l31 for the scalars)
+        float* wq = smem + 8 * 32 * LDP + wave * 32 * 8;       // [32 queries][up to 7 split weights | total l], behind the staging rows
+        {
+            const int moff = (256 * DH + wave * 32 + l31) * 4, loff = moff + 256 * 4;
+            float mmax = -INFINITY;
+            for (int s2 = 0; s2 < nsplit; ++s2) {
+                const float ms = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsW, s2 * PART * 4 + moff, 0, 16));
+                const float ls = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsW, s2 * PART * 4 + loff, 0, 16));
+                if (ls > 0.f) mmax = fmaxf(mmax, ms);
+            }
+            float L = 0.f;
+            for (int s2 = 0; s2 < nsplit; ++s2) {
+                const float ms = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsW, s2 * PART * 4 + moff, 0, 16));
+                const float ls = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsW, s2 * PART * 4 + loff, 0, 16));
+                const float w = ls > 0.f ? fast_exp2(ms - mmax) : 0.f;
+                L = fmaf(w, ls, L);
+                if (half == 0) wq[l31 * 8 + s2] = w;
+            }
+            if (half == 0) {
+                wq[l31 * 8 + 7] = L;                          // (nsplit <= 7)
+                const int qrow = q0 + wave * 32 + l31;
+                if (S.lse && qrow < nq) S.lse[((long)b * IMP_NUM_HEADS + h) * nq + qrow] = mmax * (1.0f / LOG2E) + logf(L);
+            }
+        }
+        __syncthreads();
+        // rows: all partial loads of a 16-row pass are issued before any of them is used
+        for (int pass = 0; pass < 2; ++pass) {
+            constexpr int NJ = 16 / RPI;
+            f32x4 acc[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int s2 = 0; s2 < nsplit; ++s2) {
+                u32x4 v[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, ((s2 * PART) + (wave * 32 + pass * 16 + j * RPI + prow) * DH + pc4) * 4, 0, 16);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const float w = wq[(pass * 16 + j * RPI + prow) * 8 + s2];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[j][e] = fmaf(w, __uint_as_float(v[j][e]), acc[j][e]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int qi = pass * 16 + j * RPI + prow;
+                const float inv = 1.0f / wq[qi * 8 + 7];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ot[qi * LDO + pc4 + e] = acc[j][e] * inv;
+            }
+        }
+        __syncthreads();
+        store_attention_rows<DH>(p, S, b, h, q0 + wave * 32, nq, ot, LDO, lane);
+        return;
+    }
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
@@ -703,12 +799,12 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 }
 
 template <int DH>
-hipError_t launch_pp(const AttnParams& p, int batch, int maxq, hipStream_t stream) {
+hipError_t launch_pp(const AttnParams& p, int batch, int maxq, int nsplit, hipStream_t stream) {
     const int qtiles = (maxq + 255) / 256;
-    const int total = qtiles * IMP_NUM_HEADS * p.nside * batch;
+    const int total = qtiles * IMP_NUM_HEADS * p.nside * batch * nsplit;
     const size_t lds = (size_t)(4 * KT * (DH + 4) + 4 * KT * (DH + 16) + 4 * KT) * sizeof(float);
     if (hipError_t e = imp_grant_dynamic_lds((const void*)attn_f16x3_pp_kernel<DH>, lds)) return e;
-    hipLaunchKernelGGL((attn_f16x3_pp_kernel<DH>), dim3(total), dim3(512), lds, stream, p, qtiles, total);
+    hipLaunchKernelGGL((attn_f16x3_pp_kernel<DH>), dim3(total), dim3(512), lds, stream, p, qtiles, total, nsplit);
     return hipGetLastError();
 }
 
@@ -724,23 +820,62 @@ hipError_t launch_one(const AttnParams& p, int batch, int maxq, hipStream_t stre
 
 }  // namespace
 
+// Key split of the ping-pong kernel for launches that leave most of the chip idle (one pair of ~1000-4000 keypoints = 32-128
+// workgroups on 256 CUs, each walking serially over all keys: 37 us at N = 1024 however the queries are tiled,
+// tools/probe/attn_small.py): nsplit workgroups share a query tile's keys and the last one to finish merges the partials.
+// Needs the scratch of AttnParams (split_ws / split_cnt); 1 = no split.
+int attention_f16x3_splits(const AttnParams& p, int batch) {
+    static const int force = [] { const char* e = getenv("IMP_ATTN_SPLIT"); return e ? atoi(e) : 0; }();
+    int maxq = p.side[0].nq, mink = p.side[0].nk;
+    if (p.nside == 2) { if (p.side[1].nq > maxq) maxq = p.side[1].nq; if (p.side[1].nk < mink) mink = p.side[1].nk; }
+    if (!p.split_ws || !p.split_cnt || maxq <= 192 || force == 1) return 1;
+    const long wg = (long)((maxq + 255) / 256) * IMP_NUM_HEADS * p.nside * batch;
+    const int tiles = (mink + KT - 1) / KT;
+    int s = 1;
+    if (force > 1) s = force;
+    else if (wg <= 128) s = wg <= 32 ? 4 : (wg <= 64 ? 3 : 2);
+    while (s > 1 && tiles < 4 * s) --s;            // at least 4 key tiles per split
+    if (s > 7) s = 7;
+    return s;
+}
+size_t attention_f16x3_split_floats(const AttnParams& p, int batch, int nsplit) {
+    int maxq = p.side[0].nq;
+    if (p.nside == 2 && p.side[1].nq > maxq) maxq = p.side[1].nq;
+    return (size_t)((maxq + 255) / 256) * IMP_NUM_HEADS * p.nside * batch * nsplit * (256 * (size_t)p.dh + 512);
+}
+size_t attention_f16x3_split_units(const AttnParams& p, int batch) {
+    int maxq = p.side[0].nq;
+    if (p.nside == 2 && p.side[1].nq > maxq) maxq = p.side[1].nq;
+    return (size_t)((maxq + 255) / 256) * IMP_NUM_HEADS * p.nside * batch;
+}
+
 hipError_t launch_attention_f16x3(const AttnParams& p, int batch, hipStream_t stream) {
     int maxq = p.side[0].nq;
     if (p.nside == 2 && p.side[1].nq > maxq) maxq = p.side[1].nq;
     if (maxq <= 0 || batch <= 0) return hipSuccess;
     if (p.dh != 64 && p.dh != 32) return hipErrorInvalidValue;
-    const long wg4 = (long)((maxq + 127) / 128) * IMP_NUM_HEADS * p.nside * batch;
-    const bool big = wg4 >= 256;
-    // IMP_ATTN_VARIANT (A/B runs): 1 = lock-step kernels only (the 8-wave, 256-query one for 64-channel heads: each K/V tile
-    // staged and split once per 256 queries, 127 -> 114 us over the 4-wave kernel), 2 = ping-pong at any size
+    const long units = (long)IMP_NUM_HEADS * p.nside * batch;        // (head, side, pair) combinations
+    auto wgs = [&](int qpw) { return (long)((maxq + qpw - 1) / qpw) * units; };
+    // A/B switches: IMP_ATTN_VARIANT 1 = lock-step kernels only, 2 = ping-pong at any size; IMP_ATTN_WAVES = waves (x 32
+    // queries) per lock-step workgroup
     static const int variant = [] { const char* e = getenv("IMP_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
-    if (variant == 2) return p.dh == 64 ? launch_pp<64>(p, batch, maxq, stream) : launch_pp<32>(p, batch, maxq, stream);
-    // the phase-staggered 256-query kernel whenever a workgroup's queries are mostly real (measured equal or faster than the
-    // lock-step kernels at every grid size from 32 to 512 workgroups: 78 vs 101 us at B=3, N=2048)
+    static const int force_waves = [] { const char* e = getenv("IMP_ATTN_WAVES"); return e ? atoi(e) : 0; }();
+    auto lockstep = [&](int nw) -> hipError_t {
+        if (p.dh == 64) {
+            if (nw >= 8) return launch_one<64, 8>(p, batch, maxq, stream);
+            return nw >= 4 ? launch_one<64, 4>(p, batch, maxq, stream) : launch_one<64, 2>(p, batch, maxq, stream);
+        }
+        return nw >= 4 ? launch_one<32, 4>(p, batch, maxq, stream) : launch_one<32, 2>(p, batch, maxq, stream);
+    };
+    if (force_waves) return lockstep(force_waves);
+    const int nsplit = attention_f16x3_splits(p, batch);
+    if (variant == 2) return p.dh == 64 ? launch_pp<64>(p, batch, maxq, nsplit, stream) : launch_pp<32>(p, batch, maxq, nsplit, stream);
+    // The phase-staggered 256-query kernel wins whenever its workgroups cover a good part of the chip (measured equal or
+    // faster than the lock-step kernels from 64 workgroups up: 78 vs 101 us at B = 3, N = 2048).  Below that (one pair of
+    // ~1000 keypoints = 32 workgroups on 256 CUs) the launch is latency-bound by the serial walk over the keys of a few
+    // workgroups: smaller query tiles put 2-4x more CUs to work (tools/probe/attn_small.py).
     if (maxq > 192 && variant != 1)
-        return p.dh == 64 ? launch_pp<64>(p, batch, maxq, stream) : launch_pp<32>(p, batch, maxq, stream);
-    if (p.dh == 64 && maxq > 192) return launch_one<64, 8>(p, batch, maxq, stream);
-    if (p.dh == 64) return big ? launch_one<64, 4>(p, batch, maxq, stream) : launch_one<64, 2>(p, batch, maxq, stream);
-    if (p.dh == 32) return big ? launch_one<32, 4>(p, batch, maxq, stream) : launch_one<32, 2>(p, batch, maxq, stream);
-    return hipErrorInvalidValue;
+        return p.dh == 64 ? launch_pp<64>(p, batch, maxq, nsplit, stream) : launch_pp<32>(p, batch, maxq, nsplit, stream);
+    if (variant == 1 && p.dh == 64 && maxq > 192) return launch_one<64, 8>(p, batch, maxq, stream);
+    return lockstep(wgs(128) >= 192 ? 4 : 2);
 }

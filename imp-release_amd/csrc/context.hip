@@ -88,7 +88,10 @@ struct imp_ctx {
     _Float16* xpl[2] = {};                 // planes of the current descriptors of image 0 / 1  [B][n][2D halves]
     const float* xpl_src[2] = {};          // fp32 tensor they were made from / written next to (trusted only inside one call chain)
     int xpl_b = 0, xpl_n[2] = {0, 0};
-    bool trust_planes = false;             // imp_trust_descriptor_planes: consecutive imp_forward_layer calls chain unmodified outputs
+    bool trust_planes = false;
+    float* attn_split_ws = nullptr;        // key-split scratch of the attention kernel (grown on demand, allocs_x)
+    unsigned* attn_split_cnt = nullptr;
+    size_t attn_split_cap = 0, attn_split_units = 0;             // imp_trust_descriptor_planes: consecutive imp_forward_layer calls chain unmodified outputs
 };
 
 namespace {
@@ -290,8 +293,29 @@ int check_ready(imp_ctx* c, int batch, int n0, int n1) {
     return ensure_workspace(c, batch, n0 > n1 ? n0 : n1);
 }
 
-hipError_t launch_attention(const imp_ctx* c, const AttnParams& a, int batch, hipStream_t st) {
-    return c->prec == 1 ? launch_attention_f16x3(a, batch, st) : launch_attention_f32(a, batch, st);
+// attention launch; in f16x3 mode the context lends its key-split scratch (grown on demand) for launches too small to fill the chip
+int launch_attention(imp_ctx* c, AttnParams& a, int batch, hipStream_t st) {
+    if (c->prec != 1) { HIP_TRY(launch_attention_f32(a, batch, st)); return IMP_OK; }
+    // size the scratch for the largest split the launcher may choose (it decides with the pointers set)
+    float dummy_ws; unsigned dummy_cnt;
+    a.split_ws = &dummy_ws; a.split_cnt = &dummy_cnt;
+    const int ns = attention_f16x3_splits(a, batch);
+    a.split_ws = nullptr; a.split_cnt = nullptr;
+    if (ns > 1) {
+        const size_t need = attention_f16x3_split_floats(a, batch, ns), units = attention_f16x3_split_units(a, batch);
+        if (need > c->attn_split_cap || units > c->attn_split_units) {
+            HIP_TRY(hipStreamSynchronize(st));                 // (rare: the scratch grows; earlier launches may still use the old one)
+            int rc = dev_alloc(c, c->allocs_x, &c->attn_split_ws, need);
+            if (!rc) rc = dev_alloc(c, c->allocs_x, &c->attn_split_cnt, units);
+            if (rc) return rc;
+            HIP_TRY(hipMemset(c->attn_split_cnt, 0, units * sizeof(unsigned)));
+            HIP_TRY(hipDeviceSynchronize());                   // the clear runs on the NULL stream
+            c->attn_split_cap = need; c->attn_split_units = units;
+        }
+        a.split_ws = c->attn_split_ws; a.split_cnt = c->attn_split_cnt;
+    }
+    HIP_TRY(launch_attention_f16x3(a, batch, st));
+    return IMP_OK;
 }
 GemmParams gemm_defaults(const imp_ctx* c, int K) {
     GemmParams p;
@@ -449,7 +473,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
             if (planes) g.so_b = (long)n[s] * 2 * D;        // output rows as planes [D hi | D lo] halves
         }
         if (planes) { a.out_planes = 1; a.ldo = 2 * D; }
-        HIP_TRY(launch_attention(c, a, batch, st));
+        if (int arc = launch_attention(c, a, batch, st)) return arc;
     }
     // 3. merge conv (skipped when it is folded into mlp.0's weights)
     if (!c->fuse_merge) {
@@ -1161,7 +1185,7 @@ int imp_op_attention(imp_ctx* c, int batch, int nq, int nk, int dim, const float
     g.q = qkv_q; g.k = qkv_kv + dim; g.v = qkv_kv + 2 * dim; g.out = out; g.lse = lse; g.kmask = key_mask;
     g.sq_b = (long)nq * 3 * dim; g.sk_b = (long)nk * 3 * dim; g.so_b = (long)nq * dim;
     g.nq = nq; g.nk = nk;
-    HIP_TRY(launch_attention(c, a, batch, S(stream)));
+    if (int arc = launch_attention(c, a, batch, S(stream))) return arc;
     return IMP_OK;
 }
 
@@ -1182,9 +1206,10 @@ int imp_time_attention(imp_ctx* c, int batch, int n, int reps, float* ms, void* 
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(launch_attention(c, a, batch, st));   // warm
+    if (int arc = launch_attention(c, a, batch, st)) return arc;   // warm
     HIP_TRY(hipEventRecord(e0, st));
-    for (int r = 0; r < reps; ++r) HIP_TRY(launch_attention(c, a, batch, st));
+    for (int r = 0; r < reps; ++r)
+        if (int arc = launch_attention(c, a, batch, st)) return arc;
     HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(hipEventSynchronize(e1));
     float t = 0.f;

@@ -137,7 +137,14 @@ struct AttnParams {
     AttnSide side[2];
     int nside, ldq, ldk, ldo, dh;
     int out_planes;        // f16x3 kernels only: `out` rows are planes [D hi halves | D lo halves]; ldo / so_b count halves
+    // key-split scratch of the f16x3 ping-pong kernel (optional; null = never split): partial results
+    // [unit][split][256 x dh + 512] and one zero-initialised, self re-arming ticket per unit, unit = (pair, side, head, query tile)
+    float* split_ws;
+    unsigned* split_cnt;
 };
+int attention_f16x3_splits(const AttnParams& p, int batch);                        // splits launch_attention_f16x3 will use
+size_t attention_f16x3_split_floats(const AttnParams& p, int batch, int nsplit);   // floats of split_ws it needs
+size_t attention_f16x3_split_units(const AttnParams& p, int batch);                // tickets it needs
 hipError_t launch_attention_f32(const AttnParams& p, int batch, hipStream_t stream);
 // split-precision variant (hi/lo halves, 3 f16 MFMAs per fp32 product): attention_f16x3.hip
 hipError_t launch_attention_f16x3(const AttnParams& p, int batch, hipStream_t stream);

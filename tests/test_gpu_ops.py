@@ -83,7 +83,11 @@ def _ref_attention(qkv_q, qkv_kv, D, mask=None):
                                               (1, 64, 2048, 256, False), (4, 1024, 1024, 256, False),
                                               (1, 200, 190, 128, False), (2, 257, 131, 256, True),
                                               (1, 33, 65, 128, True), (4, 1500, 1300, 128, True),
-                                              (2, 2048, 2048, 128, False)])      # 32-channel heads, ping-pong kernel
+                                              (2, 2048, 2048, 128, False),       # 32-channel heads, ping-pong kernel
+                                              # launches too small to fill the chip: the keys are split over 2-4 workgroups
+                                              # per query tile and the last one merges the partial (O, m, l)
+                                              (1, 1024, 1024, 256, False), (1, 600, 2100, 256, True), (2, 1000, 3000, 256, False),
+                                              (1, 257, 1030, 128, True), (1, 4096, 4000, 256, False)])
 def test_attention_fp32_mfma(gm, B, nq, nk, D, masked):
     ctx = gm[2]._ensure_ctx()
     qq, kv = _rand(B, nq, 3 * D, seed=4), _rand(B, nk, 3 * D, seed=5)
