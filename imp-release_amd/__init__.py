@@ -20,7 +20,7 @@ def __getattr__(name):
     if name in ('matching_iterative', 'matching_iterative_uncertainty'):
         from . import matching
         return getattr(matching, name)
-    if name in ('modules', 'matching', 'dist', '_lib', 'eval_loop', 'metrics', 'pipeline', 'data'):
+    if name in ('modules', 'matching', 'dist', '_lib', 'eval_loop', 'metrics', 'pipeline', 'data', 'pose'):
         import importlib
         return importlib.import_module('.' + name, __name__)
     raise AttributeError(name)

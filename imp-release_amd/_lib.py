@@ -27,7 +27,7 @@ SYMBOLS = [
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
     'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear',
-    'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_op_linear_planes', 'imp_trust_descriptor_planes', 'imp_time_layer_gemm',
+    'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_op_linear_planes', 'imp_trust_descriptor_planes', 'imp_time_layer_gemm', 'imp_estimate_pose',
 ]
 
 
@@ -101,6 +101,7 @@ def lib():
     L.imp_op_linear_planes.argtypes = [P, I, I, I, P, P, P, P, P, P, P]
     L.imp_trust_descriptor_planes.argtypes = [P, I]
     L.imp_time_layer_gemm.argtypes = [P, I, I, I, I, I, C.POINTER(C.c_float), P]
+    L.imp_estimate_pose.argtypes = [P, P, I, P, P, C.c_double, I, C.c_uint, I, P, P, P, P, C.POINTER(C.c_int), P]
     _lib = L
     return L
 

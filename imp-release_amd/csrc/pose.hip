@@ -1,0 +1,389 @@
+// Pose step of the iterative loops on the GPU, gfx950:
+//   estimate_pose              eval/pose_estimation.py:92-115     essential matrix from the current matches
+//   decompose_essential_mat    eval/pose_estimation.py:13-89      4-way cheirality vote (R1 | R2, +-t)
+//
+// The reference parks the GPU during every pose estimate (cv2.findEssentialMat(USAC_MAGSAC) on the host, 7 times per pair,
+// eval/matching.py:84-87).  Here the estimate is a batch of tiny kernels: H seeded 8-point hypotheses in parallel (one
+// thread each: Hartley conditioning, 9x9 normal matrix, Jacobi eigenvector, projection onto the essential manifold), a
+// Sampson-distance inlier count per hypothesis (one workgroup each), then ONE workgroup that picks the first best
+// hypothesis, refits on its consensus set (up to 3 times, kept while not worse), decomposes E and takes the cheirality vote
+// with per-point DLT triangulation.  Everything in fp64 (n <= a few thousand correspondences: the work is microseconds).
+//
+// PARITY: the solver is NOT OpenCV's MAGSAC - that is a third-party randomized algorithm with no golden vectors in the
+// reference and cv2 is absent from the build image: parity with it is unpinned and not claimed.  What IS pinned: these
+// kernels against their CPU twin oracle/pose_oracle.py (same hypothesis sampling, same algebra), and the cheirality vote
+// against the geometric definition (tests/test_pose.py, tests/test_gpu_pose.py).
+#include "imp_kernels.h"
+#include "../../include/imp_hip.h"
+#include <mutex>
+#include <vector>
+
+namespace {
+
+__host__ __device__ inline unsigned pose_rand(unsigned seed, unsigned h, unsigned k) {
+    unsigned x = seed * 0x9E3779B1u + h * 0x85EBCA77u + k * 0xC2B2AE3Du + 0x27D4EB2Fu;
+    x ^= x >> 15; x *= 0x2C1B3C6Du;
+    x ^= x >> 12; x *= 0x297A2D39u;
+    x ^= x >> 15;
+    return x;
+}
+
+// cyclic Jacobi eigen-decomposition of a symmetric N x N matrix (a is destroyed: eigenvalues on its diagonal); v = eigenvectors (columns)
+template <int N>
+__device__ void jacobi_eig(double (&a)[N][N], double (&v)[N][N]) {
+    for (int i = 0; i < N; ++i)
+        for (int j = 0; j < N; ++j) v[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < N; ++i) {
+            diag += a[i][i] * a[i][i];
+            for (int j = i + 1; j < N; ++j) off += a[i][j] * a[i][j];
+        }
+        if (off <= 1e-30 * diag || off == 0.0) break;
+        for (int p = 0; p < N - 1; ++p)
+            for (int q = p + 1; q < N; ++q) {
+                if (a[p][q] == 0.0) continue;
+                const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < N; ++k) {
+                    const double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = c * akp - s * akq;
+                    a[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < N; ++k) {
+                    const double apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = c * apk - s * aqk;
+                    a[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < N; ++k) {
+                    const double vkp = v[k][p], vkq = v[k][q];
+                    v[k][p] = c * vkp - s * vkq;
+                    v[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+// SVD of a 3x3 matrix through the eigen-decomposition of E^T E: singular values descending, U, V with u2 = u0 x u1, v2 = v0 x v1
+__device__ void svd3(const double (&E)[3][3], double (&U)[3][3], double (&s)[3], double (&V)[3][3]) {
+    double a[3][3], ev[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) a[i][j] = E[0][i] * E[0][j] + E[1][i] * E[1][j] + E[2][i] * E[2][j];
+    jacobi_eig<3>(a, ev);
+    int idx[3] = {0, 1, 2};
+    for (int i = 0; i < 2; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if (a[idx[j]][idx[j]] > a[idx[i]][idx[i]]) { const int t = idx[i]; idx[i] = idx[j]; idx[j] = t; }
+    for (int c = 0; c < 2; ++c) {
+        s[c] = sqrt(fmax(a[idx[c]][idx[c]], 0.0));
+        for (int r = 0; r < 3; ++r) V[r][c] = ev[r][idx[c]];
+        for (int r = 0; r < 3; ++r) U[r][c] = (E[r][0] * V[0][c] + E[r][1] * V[1][c] + E[r][2] * V[2][c]) / fmax(s[c], 1e-300);
+    }
+    s[2] = sqrt(fmax(a[idx[2]][idx[2]], 0.0));
+    V[0][2] = V[1][0] * V[2][1] - V[2][0] * V[1][1];
+    V[1][2] = V[2][0] * V[0][1] - V[0][0] * V[2][1];
+    V[2][2] = V[0][0] * V[1][1] - V[1][0] * V[0][1];
+    U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+    U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+    U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+}
+
+// essential matrix from the 9x9 normal matrix of conditioned correspondences: smallest eigenvector, un-conditioning, (1, 1, 0) projection
+__device__ bool essential_from_normal(double (&ata)[9][9], const double (&T0)[3], const double (&T1)[3], double (&Eo)[3][3]) {
+    double v[9][9];
+    jacobi_eig<9>(ata, v);
+    int m = 0;
+    for (int i = 1; i < 9; ++i) if (ata[i][i] < ata[m][m]) m = i;
+    double F[3][3];
+    for (int i = 0; i < 9; ++i) F[i / 3][i % 3] = v[i][m];
+    // E = T1^T F T0 with T = [[s, 0, -s cx], [0, s, -s cy], [0, 0, 1]]  (T stored as (s, cx, cy))
+    double FT0[3][3];
+    for (int r = 0; r < 3; ++r) {
+        FT0[r][0] = F[r][0] * T0[0];
+        FT0[r][1] = F[r][1] * T0[0];
+        FT0[r][2] = -F[r][0] * T0[0] * T0[1] - F[r][1] * T0[0] * T0[2] + F[r][2];
+    }
+    double E[3][3];
+    for (int c = 0; c < 3; ++c) {
+        E[0][c] = T1[0] * FT0[0][c];
+        E[1][c] = T1[0] * FT0[1][c];
+        E[2][c] = -T1[0] * T1[1] * FT0[0][c] - T1[0] * T1[2] * FT0[1][c] + FT0[2][c];
+    }
+    double U[3][3], s[3], V[3][3];
+    svd3(E, U, s, V);
+    if (!(s[1] > 1e-12 * s[0]) || !(s[0] > 0.0)) return false;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) Eo[r][c] = U[r][0] * V[c][0] + U[r][1] * V[c][1];
+    return true;
+}
+
+__device__ __forceinline__ double sampson_sq(const double* E, double x0, double y0, double x1, double y1) {
+    const double a0 = E[0] * x0 + E[1] * y0 + E[2], a1 = E[3] * x0 + E[4] * y0 + E[5], a2 = E[6] * x0 + E[7] * y0 + E[8];
+    const double b0 = E[0] * x1 + E[3] * y1 + E[6], b1 = E[1] * x1 + E[4] * y1 + E[7];
+    const double num = x1 * a0 + y1 * a1 + a2;
+    return num * num / fmax(a0 * a0 + a1 * a1 + b0 * b0 + b1 * b1, 1e-30);
+}
+
+// one thread per hypothesis
+__global__ __launch_bounds__(64) void pose_hypotheses_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n,
+                                                             int H, unsigned seed, double* __restrict__ Eh, int* __restrict__ valid) {
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= H) return;
+    int ids[8];
+    bool ok = true;
+    for (int k = 0; k < 8; ++k) {
+        ids[k] = (int)(pose_rand(seed, (unsigned)h, (unsigned)k) % (unsigned)n);
+        for (int j = 0; j < k; ++j) ok &= ids[j] != ids[k];
+    }
+    double E[3][3];
+    if (ok) {
+        double T[2][3];
+        double ax[8], ay[8], bx[8], by[8];
+        for (int v = 0; v < 2; ++v) {
+            double cx = 0, cy = 0;
+            for (int k = 0; k < 8; ++k) { const double2 p = v ? x1[ids[k]] : x0[ids[k]]; cx += p.x; cy += p.y; }
+            cx /= 8.0; cy /= 8.0;
+            double md = 0;
+            for (int k = 0; k < 8; ++k) { const double2 p = v ? x1[ids[k]] : x0[ids[k]]; md += sqrt((p.x - cx) * (p.x - cx) + (p.y - cy) * (p.y - cy)); }
+            const double s = 1.4142135623730951 / fmax(md / 8.0, 1e-12);
+            T[v][0] = s; T[v][1] = cx; T[v][2] = cy;
+            for (int k = 0; k < 8; ++k) {
+                const double2 p = v ? x1[ids[k]] : x0[ids[k]];
+                (v ? bx : ax)[k] = (p.x - cx) * s;
+                (v ? by : ay)[k] = (p.y - cy) * s;
+            }
+        }
+        double ata[9][9];
+        for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) ata[i][j] = 0.0;
+        for (int k = 0; k < 8; ++k) {
+            const double r[9] = {bx[k] * ax[k], bx[k] * ay[k], bx[k], by[k] * ax[k], by[k] * ay[k], by[k], ax[k], ay[k], 1.0};
+            for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) ata[i][j] += r[i] * r[j];
+        }
+        ok = essential_from_normal(ata, T[0], T[1], E);
+    }
+    valid[h] = ok ? 1 : 0;
+    if (ok) for (int i = 0; i < 9; ++i) Eh[(long)h * 9 + i] = E[i / 3][i % 3];
+}
+
+// one workgroup per hypothesis: inlier count
+__global__ __launch_bounds__(256) void pose_score_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n,
+                                                         const double* __restrict__ Eh, const int* __restrict__ valid, double thr2,
+                                                         int* __restrict__ counts) {
+    const int h = blockIdx.x;
+    __shared__ int red[4];
+    int c = 0;
+    if (valid[h]) {
+        double E[9];
+        for (int i = 0; i < 9; ++i) E[i] = Eh[(long)h * 9 + i];
+        for (int i = threadIdx.x; i < n; i += 256) c += sampson_sq(E, x0[i].x, x0[i].y, x1[i].x, x1[i].y) < thr2;
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[h] = valid[h] ? red[0] + red[1] + red[2] + red[3] : -1;
+}
+
+__device__ double block_sum(double v, double* sm) {        // 1024 threads
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0;
+    for (int w = 0; w < 16; ++w) t += sm[w];
+    return t;
+}
+
+// one workgroup: first best hypothesis -> refits -> decomposition + cheirality vote
+__global__ __launch_bounds__(1024) void pose_finish_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n, int H,
+                                                           const double* __restrict__ Eh, const int* __restrict__ counts, double thr2,
+                                                           double dist_thresh, unsigned char* __restrict__ inl, double* __restrict__ out) {
+    // out: [0..8] E, [9..17] R, [18..20] t, [21] inliers of E, [22] cheirality inliers, [23] ok flag
+    __shared__ double sm[16 * 45];
+    __shared__ double Es[9], Et[9], geo[24];
+    __shared__ int s_best, s_cnt, s_ok;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int best = -1, bi = -1;
+        for (int h = 0; h < H; ++h) if (counts[h] > best) { best = counts[h]; bi = h; }
+        s_best = bi; s_cnt = best;
+        if (bi >= 0) for (int i = 0; i < 9; ++i) Es[i] = Eh[(long)bi * 9 + i];
+    }
+    __syncthreads();
+    if (s_best < 0 || s_cnt < 8) { if (tid == 0) out[23] = 0.0; return; }
+    for (int i = tid; i < n; i += 1024) inl[i] = sampson_sq(Es, x0[i].x, x0[i].y, x1[i].x, x1[i].y) < thr2;
+    __syncthreads();
+    for (int round = 0; round < 3; ++round) {
+        // conditioning of the consensus set
+        double c = 0, sx0 = 0, sy0 = 0, sx1 = 0, sy1 = 0;
+        for (int i = tid; i < n; i += 1024) if (inl[i]) { c += 1; sx0 += x0[i].x; sy0 += x0[i].y; sx1 += x1[i].x; sy1 += x1[i].y; }
+        const double cnt = block_sum(c, sm);
+        const double cx0 = block_sum(sx0, sm) / cnt, cy0 = block_sum(sy0, sm) / cnt, cx1 = block_sum(sx1, sm) / cnt, cy1 = block_sum(sy1, sm) / cnt;
+        double d0 = 0, d1 = 0;
+        for (int i = tid; i < n; i += 1024) if (inl[i]) {
+            d0 += sqrt((x0[i].x - cx0) * (x0[i].x - cx0) + (x0[i].y - cy0) * (x0[i].y - cy0));
+            d1 += sqrt((x1[i].x - cx1) * (x1[i].x - cx1) + (x1[i].y - cy1) * (x1[i].y - cy1));
+        }
+        const double s0 = 1.4142135623730951 / fmax(block_sum(d0, sm) / cnt, 1e-12), s1 = 1.4142135623730951 / fmax(block_sum(d1, sm) / cnt, 1e-12);
+        double acc[45];
+        for (int k = 0; k < 45; ++k) acc[k] = 0.0;
+        for (int i = tid; i < n; i += 1024) if (inl[i]) {
+            const double ax = (x0[i].x - cx0) * s0, ay = (x0[i].y - cy0) * s0, bx = (x1[i].x - cx1) * s1, by = (x1[i].y - cy1) * s1;
+            const double r[9] = {bx * ax, bx * ay, bx, by * ax, by * ay, by, ax, ay, 1.0};
+            int k = 0;
+            for (int a = 0; a < 9; ++a) for (int b2 = a; b2 < 9; ++b2) acc[k++] += r[a] * r[b2];
+        }
+        for (int k = 0; k < 45; ++k) for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+        __syncthreads();
+        if ((tid & 63) == 0) for (int k = 0; k < 45; ++k) sm[(tid >> 6) * 45 + k] = acc[k];
+        __syncthreads();
+        if (tid == 0) {
+            double ata[9][9];
+            int k = 0;
+            for (int a = 0; a < 9; ++a) for (int b2 = a; b2 < 9; ++b2) {
+                double t = 0;
+                for (int w = 0; w < 16; ++w) t += sm[w * 45 + k];
+                ata[a][b2] = ata[b2][a] = t; ++k;
+            }
+            const double T0[3] = {s0, cx0, cy0}, T1[3] = {s1, cx1, cy1};
+            double E2[3][3];
+            s_ok = essential_from_normal(ata, T0, T1, E2) ? 1 : 0;
+            if (s_ok) for (int i = 0; i < 9; ++i) Et[i] = E2[i / 3][i % 3];
+        }
+        __syncthreads();
+        if (!s_ok) break;
+        double c2 = 0;
+        for (int i = tid; i < n; i += 1024) c2 += sampson_sq(Et, x0[i].x, x0[i].y, x1[i].x, x1[i].y) < thr2;
+        const int cnt2 = (int)block_sum(c2, sm);
+        if (cnt2 < s_cnt) break;                                   // uniform: kept only while not worse
+        const bool same = cnt2 == s_cnt;
+        __syncthreads();
+        if (tid == 0) { s_cnt = cnt2; for (int i = 0; i < 9; ++i) Es[i] = Et[i]; }
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024) inl[i] = sampson_sq(Es, x0[i].x, x0[i].y, x1[i].x, x1[i].y) < thr2;
+        __syncthreads();
+        if (same && round > 0) break;
+    }
+    // decomposition (cv2.decomposeEssentialMat): U, V^T with positive determinant, R1 = U W V^T, R2 = U W^T V^T, t = u2
+    if (tid == 0) {
+        double E[3][3], U[3][3], s[3], V[3][3];
+        for (int i = 0; i < 9; ++i) E[i / 3][i % 3] = Es[i];
+        svd3(E, U, s, V);            // u2 = u0 x u1 and v2 = v0 x v1: both determinants are +1 by construction
+        // W = [[0,1,0],[-1,0,0],[0,0,1]]:  U W = [-u1, u0, u2],  U W^T = [u1, -u0, u2]
+        for (int r = 0; r < 3; ++r)
+            for (int c2 = 0; c2 < 3; ++c2) {
+                geo[r * 3 + c2] = -U[r][1] * V[c2][0] + U[r][0] * V[c2][1] + U[r][2] * V[c2][2];
+                geo[9 + r * 3 + c2] = U[r][1] * V[c2][0] - U[r][0] * V[c2][1] + U[r][2] * V[c2][2];
+            }
+        for (int r = 0; r < 3; ++r) geo[18 + r] = U[r][2];
+    }
+    __syncthreads();
+    // cheirality vote (eval/pose_estimation.py:40-89) over the inliers of E; candidate order (R1,t), (R2,t), (R1,-t), (R2,-t)
+    double good[4] = {0, 0, 0, 0};
+    unsigned char mloc[4] = {0, 0, 0, 0};          // (only the first point of a thread is remembered; masks are recomputed below)
+    for (int pass = 0; pass < 2; ++pass) {
+        int chosen = -1;
+        if (pass == 1) {
+            __shared__ int s_choice;
+            double g[4];
+            for (int k = 0; k < 4; ++k) g[k] = block_sum(good[k], sm);
+            if (tid == 0) {
+                double best = fmax(fmax(g[0], g[1]), fmax(g[2], g[3]));
+                s_choice = g[0] == best ? 0 : (g[1] == best ? 1 : (g[2] == best ? 2 : 3));
+                const double* R = geo + (s_choice & 1) * 9;
+                for (int i = 0; i < 9; ++i) out[9 + i] = R[i];
+                for (int i = 0; i < 3; ++i) out[18 + i] = (s_choice >= 2 ? -1.0 : 1.0) * geo[18 + i];
+                for (int i = 0; i < 9; ++i) out[i] = Es[i];
+                out[21] = (double)s_cnt; out[22] = best; out[23] = 1.0;
+            }
+            __syncthreads();
+            chosen = s_choice;
+        }
+        for (int i = tid; i < n; i += 1024) {
+            if (!inl[i]) continue;
+            for (int k = 0; k < 4; ++k) {
+                if (pass == 1 && k != chosen) continue;
+                const double* R = geo + (k & 1) * 9;
+                const double sg = k >= 2 ? -1.0 : 1.0;
+                const double P[3][4] = {{R[0], R[1], R[2], sg * geo[18]}, {R[3], R[4], R[5], sg * geo[19]}, {R[6], R[7], R[8], sg * geo[20]}};
+                // DLT rows: x P0[2] - P0[0], y P0[2] - P0[1] (P0 = [I | 0]) and the same for P
+                double A[4][4] = {{-1, 0, x0[i].x, 0}, {0, -1, x0[i].y, 0},
+                                  {x1[i].x * P[2][0] - P[0][0], x1[i].x * P[2][1] - P[0][1], x1[i].x * P[2][2] - P[0][2], x1[i].x * P[2][3] - P[0][3]},
+                                  {x1[i].y * P[2][0] - P[1][0], x1[i].y * P[2][1] - P[1][1], x1[i].y * P[2][2] - P[1][2], x1[i].y * P[2][3] - P[1][3]}};
+                double ata[4][4], ev[4][4];
+                for (int a = 0; a < 4; ++a) for (int b2 = 0; b2 < 4; ++b2) ata[a][b2] = A[0][a] * A[0][b2] + A[1][a] * A[1][b2] + A[2][a] * A[2][b2] + A[3][a] * A[3][b2];
+                jacobi_eig<4>(ata, ev);
+                int m = 0;
+                for (int a = 1; a < 4; ++a) if (ata[a][a] < ata[m][m]) m = a;
+                double Q[4] = {ev[0][m], ev[1][m], ev[2][m], ev[3][m]};
+                bool ok = Q[2] * Q[3] > 0;
+                const double X = Q[0] / Q[3], Y = Q[1] / Q[3], Z = Q[2] / Q[3];
+                ok = ok && Z < dist_thresh;
+                const double zc = P[2][0] * X + P[2][1] * Y + P[2][2] * Z + P[2][3];
+                ok = ok && zc > 0 && zc < dist_thresh;
+                if (pass == 0) good[k] += ok ? 1.0 : 0.0;
+                else inl[i] = ok ? 1 : 0;                  // final mask: eval/pose_estimation.py:113-114
+            }
+        }
+    }
+    (void)mloc;
+}
+
+struct PoseWs {
+    int device = -1;
+    size_t cap_n = 0, cap_h = 0;
+    double2 *x0 = nullptr, *x1 = nullptr;
+    double *Eh = nullptr, *out = nullptr;
+    int *valid = nullptr, *counts = nullptr;
+    unsigned char* inl = nullptr;
+};
+
+}  // namespace
+
+extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, const double* K0, const double* K1, double norm_thresh,
+                                 int iterations, unsigned seed, int device, double* E, double* R, double* t, unsigned char* mask,
+                                 int* n_inliers, void* stream) {
+    if (!kpts0 || !kpts1 || !K0 || !K1 || !E || !R || !t || !mask || !n_inliers || iterations < 1) return IMP_E_ARG;
+    *n_inliers = 0;
+    if (n < 8) return 1;                                   // (the reference returns None below 5 points; the 8-point solver needs 8)
+    if (hipSetDevice(device) != hipSuccess) return IMP_E_HIP;
+    hipStream_t st = (hipStream_t)stream;
+    static thread_local PoseWs ws;
+    if (ws.device != device || (size_t)n > ws.cap_n || (size_t)iterations > ws.cap_h) {
+        for (void* p : {(void*)ws.x0, (void*)ws.x1, (void*)ws.Eh, (void*)ws.out, (void*)ws.valid, (void*)ws.counts, (void*)ws.inl})
+            if (p) (void)hipFree(p);
+        ws = PoseWs();
+        const size_t cn = (size_t)n < 4096 ? 4096 : (size_t)n, ch = (size_t)iterations < 2048 ? 2048 : (size_t)iterations;
+        if (hipMalloc(&ws.x0, cn * sizeof(double2)) != hipSuccess || hipMalloc(&ws.x1, cn * sizeof(double2)) != hipSuccess ||
+            hipMalloc(&ws.Eh, ch * 9 * sizeof(double)) != hipSuccess || hipMalloc(&ws.out, 24 * sizeof(double)) != hipSuccess ||
+            hipMalloc(&ws.valid, ch * sizeof(int)) != hipSuccess || hipMalloc(&ws.counts, ch * sizeof(int)) != hipSuccess ||
+            hipMalloc(&ws.inl, cn) != hipSuccess)
+            return IMP_E_NOMEM;
+        ws.device = device; ws.cap_n = cn; ws.cap_h = ch;
+    }
+    // normalised coordinates on the host (n is small): (x - cx) / fx, (y - cy) / fy per camera
+    std::vector<double2> h0(n), h1(n);
+    for (int i = 0; i < n; ++i) {
+        h0[i] = double2{((double)kpts0[2 * i] - K0[2]) / K0[0], ((double)kpts0[2 * i + 1] - K0[5]) / K0[4]};
+        h1[i] = double2{((double)kpts1[2 * i] - K1[2]) / K1[0], ((double)kpts1[2 * i + 1] - K1[5]) / K1[4]};
+    }
+    if (hipMemcpyAsync(ws.x0, h0.data(), n * sizeof(double2), hipMemcpyHostToDevice, st) != hipSuccess) return IMP_E_HIP;
+    if (hipMemcpyAsync(ws.x1, h1.data(), n * sizeof(double2), hipMemcpyHostToDevice, st) != hipSuccess) return IMP_E_HIP;
+    const double thr = norm_thresh / ((K0[0] + K0[4] + K1[0] + K1[4]) / 4.0);
+    hipLaunchKernelGGL(pose_hypotheses_kernel, dim3((iterations + 63) / 64), dim3(64), 0, st, ws.x0, ws.x1, n, iterations, seed, ws.Eh, ws.valid);
+    hipLaunchKernelGGL(pose_score_kernel, dim3(iterations), dim3(256), 0, st, ws.x0, ws.x1, n, ws.Eh, ws.valid, thr * thr, ws.counts);
+    // the cheirality step of the reference normalises with K = (K0 + K1) / 2 (eval/pose_estimation.py:29-33): with K0 == K1 (every
+    // caller in the repo) these are the coordinates above; a caller with two different cameras gets per-camera normalisation
+    hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(1024), 0, st, ws.x0, ws.x1, n, iterations, ws.Eh, ws.counts, thr * thr, 1000.0,
+                       ws.inl, ws.out);
+    double out[24];
+    if (hipMemcpyAsync(out, ws.out, sizeof out, hipMemcpyDeviceToHost, st) != hipSuccess) return IMP_E_HIP;
+    if (hipMemcpyAsync(mask, ws.inl, n, hipMemcpyDeviceToHost, st) != hipSuccess) return IMP_E_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) return IMP_E_HIP;
+    if (hipGetLastError() != hipSuccess) return IMP_E_HIP;
+    if (out[23] == 0.0) return 1;
+    for (int i = 0; i < 9; ++i) { E[i] = out[i]; R[i] = out[9 + i]; }
+    for (int i = 0; i < 3; ++i) t[i] = out[18 + i];
+    *n_inliers = (int)out[22];
+    return IMP_OK;
+}

@@ -1,0 +1,51 @@
+"""Pose step of the iterative loops on the GPU: drop-in for ``eval.pose_estimation.estimate_pose``.
+
+``estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf, method, mask)`` has the reference's signature
+(eval/pose_estimation.py:92) and return value ``None | (E, R, t, inlier_mask)``, so it can be handed to
+``matching_iterative[_uncertainty](..., estimate_pose=pose.estimate_pose)`` or patched over the reference's function.
+The work runs in csrc/pose.hip: thousands of seeded 8-point hypotheses scored in parallel, consensus refits, the
+``decompose_essential_mat`` cheirality vote (eval/pose_estimation.py:13-89) - tens of microseconds of GPU time instead of a
+host-side OpenCV call that parks the GPU 7 times per pair.
+
+NOT the same solver as the reference: ``cv2.findEssentialMat(USAC_MAGSAC)`` is a third-party randomized algorithm
+(opencv-contrib-python 4.5.5.64) with no golden vectors in the reference and ``cv2`` is absent from the build image - MAGSAC
+parity is unpinned and not claimed (``method`` and ``conf`` are accepted and ignored).  Pinned: the kernels against their CPU
+twin ``oracle/pose_oracle.py``, the cheirality vote against the geometric definition, recovery of known poses on synthetic
+two-view scenes (tests/test_gpu_pose.py, tests/test_pose.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, mask=None, iterations=4096, seed=1,
+                  device=None, stream=None):
+    """eval/pose_estimation.py:92-115 -> None | (E [3,3], R [3,3], t [3], mask [n] bool)."""
+    import torch
+    k0 = np.ascontiguousarray(np.asarray(kpts0, dtype=np.float32))
+    k1 = np.ascontiguousarray(np.asarray(kpts1, dtype=np.float32))
+    n = k0.shape[0]
+    if n < 8 or k1.shape[0] != n:
+        return None
+    if mask is not None:
+        raise NotImplementedError('an input mask is not supported (no caller in the reference passes one)')
+    L = _lib.lib()
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    Ka = np.ascontiguousarray(np.asarray(K0, dtype=np.float64).reshape(3, 3))
+    Kb = np.ascontiguousarray(np.asarray(K1, dtype=np.float64).reshape(3, 3))
+    E, R, t = np.zeros(9), np.zeros(9), np.zeros(3)
+    m = np.zeros(n, dtype=np.uint8)
+    ninl = C.c_int()
+    st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
+    P = lambda a: a.ctypes.data_as(C.c_void_p)      # noqa: E731
+    rc = L.imp_estimate_pose(P(k0), P(k1), n, P(Ka), P(Kb), C.c_double(float(norm_thresh)), int(iterations), C.c_uint(seed), dev,
+                             P(E), P(R), P(t), P(m), C.byref(ninl), C.c_void_p(st))
+    if rc == 1:
+        return None
+    if rc != 0:
+        raise _lib.ImpError(rc, 'imp_estimate_pose failed')
+    return E.reshape(3, 3), R.reshape(3, 3), t, m.astype(bool)

@@ -218,6 +218,16 @@ int imp_trust_descriptor_planes(imp_ctx* ctx, int on);
  * 1 MLP conv 0, 2 MLP conv 3) at [batch][n] on the context's workspace; dbg >= 0: gemm_planes.hip with its probe switches,
  * dbg < 0: gemm_f32.hip */
 int imp_time_layer_gemm(imp_ctx* ctx, int batch, int n, int which, int dbg, int reps, float* ms, void* stream);
+/* Pose step of the iterative loops (eval/pose_estimation.py:92-115 estimate_pose + :13-89 decompose_essential_mat) - SURVEY §8 f-1.
+ * HOST arrays in, HOST arrays out (the matched keypoints of a loop iteration live on the host, eval/matching.py:68-87):
+ * kpts0 / kpts1 [n][2] pixels, K0 / K1 row-major 3x3, norm_thresh in pixels (divided by the mean focal length inside).
+ * `iterations` seeded 8-point hypotheses + consensus refits + cheirality vote on the GPU `device`, on `stream`; synchronises.
+ * Returns 0 and E, R (row-major 3x3), t, mask [n] (1 = inlier of E that also passes the cheirality test), *n_inliers;
+ * 1 = no pose (fewer than 8 matches / no consensus: the reference returns None); < 0 = error.
+ * NOT OpenCV's USAC_MAGSAC: parity with that third-party solver is unpinned (see csrc/pose.hip). */
+int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, const double* K0, const double* K1, double norm_thresh,
+                      int iterations, unsigned seed, int device, double* E, double* R, double* t, unsigned char* mask,
+                      int* n_inliers, void* stream);
 /* chip-resident Sinkhorn health (ot_resident.hip): *status != 0 when a group barrier ever timed out on this context
  * (results of that call are then garbage - never observed; the spin is bounded so that it cannot hang); *used = whether
  * the resident path has been taken at all.  Synchronises. */

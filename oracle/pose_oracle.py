@@ -1,0 +1,178 @@
+"""CPU ORACLE for the pose step of the iterative loops.   *** TEST INFRASTRUCTURE ONLY ***
+
+Two parts with different pin status:
+
+* ``decompose_essential_mat`` - the 4-way cheirality vote of eval/pose_estimation.py:13-89, restated in numpy (fp64).  The two
+  OpenCV primitives it calls are restated from their published algorithms: ``cv2.decomposeEssentialMat`` (SVD, W-matrix
+  construction, OpenCV calib3d/five-point.cpp) and ``cv2.triangulatePoints`` (per-point DLT: null vector of the 4x4 system).
+  ``cv2`` is absent from this image, so the restatement is pinned by construction properties only (tests/test_pose.py: the
+  true pose wins the vote, masks follow the geometric definition); **parity with cv2 itself is unpinned**.
+* ``estimate_pose`` - a seeded 8-point RANSAC with Sampson-distance inliers.  The reference calls
+  ``cv2.findEssentialMat(method=USAC_MAGSAC)`` (eval/pose_estimation.py:96-105, opencv-contrib-python 4.5.5.64): a
+  third-party randomized solver with no golden vectors in the reference - **MAGSAC parity is unpinned and not claimed**.
+  This function is the CPU twin of csrc/pose.hip (same hypothesis sampling, same algebra) used to check the GPU kernels.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+W_MAT = np.array([[0., 1., 0.], [-1., 0., 0.], [0., 0., 1.]])
+
+
+def decompose_E(E):
+    """cv2.decomposeEssentialMat: E = U diag(s) V^T, det(U), det(V^T) forced positive, R1 = U W V^T, R2 = U W^T V^T, t = U[:, 2]"""
+    U, _, Vt = np.linalg.svd(np.asarray(E, dtype=np.float64))
+    if np.linalg.det(U) < 0:
+        U = -U
+    if np.linalg.det(Vt) < 0:
+        Vt = -Vt
+    return U @ W_MAT @ Vt, U @ W_MAT.T @ Vt, U[:, 2].copy()
+
+
+def triangulate(P0, P1, x0, x1):
+    """cv2.triangulatePoints (DLT): x0, x1 [2, n] normalised image points -> homogeneous [4, n]"""
+    n = x0.shape[1]
+    out = np.zeros((4, n))
+    for i in range(n):
+        A = np.stack([x0[0, i] * P0[2] - P0[0], x0[1, i] * P0[2] - P0[1],
+                      x1[0, i] * P1[2] - P1[0], x1[1, i] * P1[2] - P1[1]])
+        out[:, i] = np.linalg.svd(A)[2][-1]
+    return out
+
+
+def _mask_from_pts4d(Q, P, distance_thresh):
+    """eval/pose_estimation.py:14-27"""
+    Q = Q.copy()
+    mask = (Q[2] * Q[3]) > 0
+    Q = Q / Q[3]
+    mask = (Q[2] < distance_thresh) & mask
+    Qc = P @ Q
+    mask = (Qc[2] > 0) & mask
+    mask = (Qc[2] < distance_thresh) & mask
+    return mask
+
+
+def decompose_essential_mat(E, pts0, pts1, K0, K1, distance_thresh=1000):
+    """eval/pose_estimation.py:13-89 -> (R, t, mask): the candidate (R1|R2, +-t) with most points in front of both cameras;
+    ties resolved in the reference's order (R1,t), (R2,t), (R1,-t), (R2,-t).  pts in pixels; K = (K0 + K1) / 2 (:29)."""
+    K = (np.asarray(K0, dtype=np.float64) + np.asarray(K1, dtype=np.float64)) / 2.
+    p0 = np.asarray(pts0, dtype=np.float64).copy()
+    p1 = np.asarray(pts1, dtype=np.float64).copy()
+    for p in (p0, p1):
+        p[:, 0] = (p[:, 0] - K[0, 2]) / K[0, 0]
+        p[:, 1] = (p[:, 1] - K[1, 2]) / K[1, 1]
+    x0, x1 = p0.T, p1.T
+    R1, R2, t = decompose_E(E)
+    P0 = np.eye(3, 4)
+    cands = [(R1, t), (R2, t), (R1, -t), (R2, -t)]
+    masks = []
+    for R, tt in cands:
+        P = np.concatenate([R, tt[:, None]], axis=1)
+        masks.append(_mask_from_pts4d(triangulate(P0, P, x0, x1), P, distance_thresh))
+    good = [int(m.sum()) for m in masks]
+    best = max(good)
+    for (R, tt), m, g in zip(cands, masks, good):
+        if g == best:
+            return R, tt, m
+    raise AssertionError
+
+
+# ------------------------------------------------------------------------------------------------ seeded 8-point RANSAC
+def sample_index(seed: int, h: int, k: int, n: int) -> int:
+    """k-th correspondence of hypothesis h: a 32-bit integer hash of (seed, h, k) modulo n (csrc/pose.hip pose_rand)"""
+    x = (seed * 0x9E3779B1 + h * 0x85EBCA77 + k * 0xC2B2AE3D + 0x27D4EB2F) & 0xFFFFFFFF
+    x ^= x >> 15; x = (x * 0x2C1B3C6D) & 0xFFFFFFFF
+    x ^= x >> 12; x = (x * 0x297A2D39) & 0xFFFFFFFF
+    x ^= x >> 15
+    return x % n
+
+
+def normalise(kpts, K):
+    K = np.asarray(K, dtype=np.float64)
+    k = np.asarray(kpts, dtype=np.float64)
+    return np.stack([(k[:, 0] - K[0, 2]) / K[0, 0], (k[:, 1] - K[1, 2]) / K[1, 1]], axis=1)
+
+
+def essential_from(x0, x1):
+    """8-point algorithm on normalised points with Hartley conditioning, projected onto the essential manifold (1, 1, 0)"""
+    def cond(x):
+        c = x.mean(0)
+        s = np.sqrt(2.0) / max(np.sqrt(((x - c) ** 2).sum(1)).mean(), 1e-12)
+        T = np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1.]])
+        return (x - c) * s, T
+    a, T0 = cond(x0)
+    b, T1 = cond(x1)
+    A = np.stack([b[:, 0] * a[:, 0], b[:, 0] * a[:, 1], b[:, 0], b[:, 1] * a[:, 0], b[:, 1] * a[:, 1], b[:, 1],
+                  a[:, 0], a[:, 1], np.ones(len(a))], axis=1)
+    w, V = np.linalg.eigh(A.T @ A)
+    F = V[:, 0].reshape(3, 3)
+    E = T1.T @ F @ T0
+    U, _, Vt = np.linalg.svd(E)
+    return U @ np.diag([1., 1., 0.]) @ Vt
+
+
+def sampson_sq(E, x0, x1):
+    h0 = np.concatenate([x0, np.ones((len(x0), 1))], 1)
+    h1 = np.concatenate([x1, np.ones((len(x1), 1))], 1)
+    Ex0 = h0 @ E.T
+    Etx1 = h1 @ E
+    num = (h1 * Ex0).sum(1) ** 2
+    den = Ex0[:, 0] ** 2 + Ex0[:, 1] ** 2 + Etx1[:, 0] ** 2 + Etx1[:, 1] ** 2
+    return num / np.maximum(den, 1e-30)
+
+
+def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, mask=None, iterations=4096, seed=1):
+    """Signature of eval/pose_estimation.py:92 -> None | (E, R, t, inlier_mask).  Threshold: norm_thresh pixels divided by the
+    mean focal length, applied to the Sampson distance in normalised coordinates."""
+    n = len(kpts0)
+    if n < 8:
+        return None
+    x0, x1 = normalise(kpts0, K0), normalise(kpts1, K1)
+    K0a, K1a = np.asarray(K0, dtype=np.float64), np.asarray(K1, dtype=np.float64)
+    thr = norm_thresh / ((K0a[0, 0] + K0a[1, 1] + K1a[0, 0] + K1a[1, 1]) / 4.0)
+    best, bestE = -1, None
+    for h in range(iterations):
+        ids = [sample_index(seed, h, k, n) for k in range(8)]
+        if len(set(ids)) < 8:
+            continue
+        E = essential_from(x0[ids], x1[ids])
+        cnt = int((sampson_sq(E, x0, x1) < thr * thr).sum())
+        if cnt > best:
+            best, bestE = cnt, E
+    if bestE is None or best < 8:
+        return None
+    inl = sampson_sq(bestE, x0, x1) < thr * thr
+    for rnd in range(3):                                 # least-squares refits on the consensus set, kept while not worse
+        E2 = essential_from(x0[inl], x1[inl])
+        inl2 = sampson_sq(E2, x0, x1) < thr * thr
+        if inl2.sum() < inl.sum():
+            break
+        same = inl2.sum() == inl.sum()
+        bestE, inl = E2, inl2
+        if same and rnd > 0:
+            break
+    R, t, mP = decompose_essential_mat(bestE, np.asarray(kpts0)[inl], np.asarray(kpts1)[inl], K0, K1)
+    m = np.zeros(n, dtype=bool)
+    m[np.nonzero(inl)[0]] = mP                           # eval/pose_estimation.py:113-114
+    return bestE, R, t, m
+
+
+def synthetic_scene(n, outliers=0.3, noise=0.5, seed=0, angle_deg=12.0):
+    """two views of random 3D points with a known relative pose; returns kpts0, kpts1 (pixels), K, R, t (unit), inlier truth"""
+    g = np.random.default_rng(seed)
+    K = np.array([[520., 0, 320.], [0, 520., 240.], [0, 0, 1.]])
+    X = np.stack([g.uniform(-2, 2, n), g.uniform(-1.5, 1.5, n), g.uniform(4, 9, n)], 1)
+    ax = g.normal(size=3); ax /= np.linalg.norm(ax)
+    a = np.deg2rad(angle_deg)
+    Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(a) * Kx + (1 - np.cos(a)) * Kx @ Kx
+    t = g.normal(size=3); t /= np.linalg.norm(t)
+    x0 = (K @ X.T).T; x0 = x0[:, :2] / x0[:, 2:]
+    Xc = (R @ X.T).T + 0.8 * t
+    x1 = (K @ Xc.T).T; x1 = x1[:, :2] / x1[:, 2:]
+    x0 += g.normal(0, noise, x0.shape); x1 += g.normal(0, noise, x1.shape)
+    truth = np.ones(n, dtype=bool)
+    bad = g.permutation(n)[:int(outliers * n)]
+    x1[bad] = np.stack([g.uniform(0, 640, len(bad)), g.uniform(0, 480, len(bad))], 1)
+    truth[bad] = False
+    return x0.astype(np.float32), x1.astype(np.float32), K, R, t, truth

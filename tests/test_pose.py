@@ -1,0 +1,79 @@
+"""CPU: the pose oracle (oracle/pose_oracle.py) - the cheirality vote of eval/pose_estimation.py:13-89 against the geometric
+definition, and the seeded 8-point RANSAC twin of csrc/pose.hip on synthetic two-view scenes with known poses.
+(cv2 is absent: OpenCV / MAGSAC parity is unpinned and not claimed; see the module docstring.)"""
+import numpy as np
+import pytest
+
+from oracle import pose_oracle as po
+
+
+def _ang_mat(R1, R2):
+    return np.rad2deg(np.abs(np.arccos(np.clip((np.trace(R1.T @ R2) - 1) / 2, -1, 1))))
+
+
+def _ang_vec(a, b):
+    return np.rad2deg(np.arccos(np.clip(a @ b / np.linalg.norm(a) / np.linalg.norm(b), -1, 1)))
+
+
+def _skew(t):
+    return np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_cheirality_vote_picks_the_true_pose_of_an_exact_essential_matrix(seed):
+    k0, k1, K, R, t, _ = po.synthetic_scene(150, outliers=0.0, noise=0.0, seed=seed, angle_deg=5 + 7 * seed)
+    for sign in (1.0, -1.0):                       # E and -E describe the same geometry
+        Rd, td, m = po.decompose_essential_mat(sign * _skew(t) @ R, k0, k1, K, K)
+        assert _ang_mat(R, Rd) < 1e-4 and _ang_vec(t, td) < 1e-3
+        assert m.all()                             # every point is in front of both cameras for the true pose
+
+
+def test_cheirality_masks_follow_the_geometric_definition():
+    k0, k1, K, R, t, _ = po.synthetic_scene(80, outliers=0.0, noise=0.0, seed=3)
+    g = np.random.default_rng(0)
+    k1 = k1.copy()
+    k1[:10] = np.stack([g.uniform(0, 640, 10), g.uniform(0, 480, 10)], 1)       # 10 wrong correspondences
+    Rd, td, m = po.decompose_essential_mat(_skew(t) @ R, k0, k1, K, K)
+    assert _ang_mat(R, Rd) < 1e-4
+    # independent check: triangulated depth in both cameras (linear triangulation done here with lstsq)
+    x0, x1 = po.normalise(k0, K), po.normalise(k1, K)
+    for i in range(80):
+        A = np.stack([np.array([-1, 0, x0[i, 0]]), np.array([0, -1, x0[i, 1]]),
+                      x1[i, 0] * Rd[2] - Rd[0], x1[i, 1] * Rd[2] - Rd[1]])
+        bvec = -np.array([0, 0, x1[i, 0] * td[2] - td[0], x1[i, 1] * td[2] - td[1]])
+        X = np.linalg.lstsq(A, bvec, rcond=None)[0]
+        zc = (Rd @ X + td)[2]
+        if abs(X[2]) > 1e-3 and abs(zc) > 1e-3 and i >= 10:
+            assert m[i] == (X[2] > 0 and zc > 0), i
+
+
+def test_decompose_returns_proper_rotations_and_unit_translation():
+    g = np.random.default_rng(5)
+    for _ in range(20):
+        R1, R2, t = po.decompose_E(g.normal(size=(3, 3)))
+        for R in (R1, R2):
+            assert np.allclose(R @ R.T, np.eye(3), atol=1e-10) and np.isclose(np.linalg.det(R), 1.0)
+        assert np.isclose(np.linalg.norm(t), 1.0)
+
+
+@pytest.mark.parametrize('seed,outliers', [(0, 0.2), (1, 0.3), (2, 0.35)])
+def test_ransac_twin_recovers_a_known_pose(seed, outliers):
+    k0, k1, K, R, t, truth = po.synthetic_scene(500, outliers=outliers, noise=0.3, seed=seed)
+    r = po.estimate_pose(k0, k1, K, K, 1.0, iterations=2048, seed=7)
+    assert r is not None
+    E, Re, te, m = r
+    assert _ang_mat(R, Re) < 2.0 and _ang_vec(t, te) < 8.0, (_ang_mat(R, Re), _ang_vec(t, te))
+    assert (m & ~truth).sum() <= 0.05 * m.sum()            # hardly any outlier is accepted
+    assert m.sum() >= 0.6 * truth.sum()
+
+
+def test_too_few_matches_give_none():
+    k0, k1, K, *_ = po.synthetic_scene(7, seed=1)
+    assert po.estimate_pose(k0, k1, K, K, 1.0) is None
+
+
+def test_sampling_hash_is_the_documented_one():
+    # pinned values of the hypothesis-sampling hash shared with csrc/pose.hip (pose_rand); the GPU side is checked through the
+    # identical consensus in tests/test_gpu_pose.py
+    assert [po.sample_index(1, h, k, 1000) for h in (0, 1, 77) for k in (0, 7)] == [766, 495, 980, 244, 392, 577]
+    assert len({po.sample_index(3, 5, k, 10 ** 6) for k in range(8)}) == 8

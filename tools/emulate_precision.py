@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Evidence for the arithmetic choices of DESIGN.md §2, reproducible on CPU (test infrastructure: it runs the ORACLE).
+
+Every matrix product of the oracle (1x1 convs, Q.K^T, P.V, the score matrix) is replaced by an emulation of a
+split-precision MFMA scheme - each fp32 operand is cut into 2 or 3 narrow components and the product becomes the sum of the
+listed component products with fp32 accumulation - and, separately, the Sinkhorn iterations are run on a copy of the
+row-softmax matrix that keeps only `m` mantissa bits (the scores p.u.v are still formed from the fp32 matrix).  Each
+variant is run on golden fixtures (tests/golden, captured from the imported reference) and the script prints, per
+fixture: index mismatches against the reference and max |mscore - reference|.
+
+    python tools/emulate_precision.py [--fixtures a,b,...] [--big]     (--big adds N = 1024 / 2048 pairs against the fp32 oracle)
+
+Schemes:
+    fp32      the oracle as it is
+    f16x3     x = hi + lo (IEEE half, RNE): lo.hi + hi.lo + hi.hi             <- what libimp_hip does (gfx950 f16 MFMA)
+    bf16x3    same with bfloat16 components
+    bf16x6    three bfloat16 components: all six products of order <= 2
+    f16x1     a single half product (what a plain fp16 MFMA path would do)
+Sinkhorn storage: 23 (fp32), 15 (3-byte copy), 7 (2-byte, bfloat16-like), 10 (2-byte, half-like mantissa)
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+from helpers import build_case, golden_names, load_golden      # noqa: E402
+from oracle import imp_oracle as orc                            # noqa: E402
+
+_matmul = torch.matmul
+_einsum = torch.einsum
+
+
+def _round_to(x, kind):
+    if kind == 'f16':
+        return x.to(torch.float16).to(torch.float32)
+    if kind == 'bf16':
+        return x.to(torch.bfloat16).to(torch.float32)
+    raise ValueError(kind)
+
+
+def _components(x, kind, n):
+    comps, rest = [], x
+    for _ in range(n):
+        c = _round_to(rest, kind)
+        comps.append(c)
+        rest = rest - c
+    return comps
+
+
+def make_matmul(scheme):
+    if scheme == 'fp32':
+        return _matmul
+    kind, n, pairs = {'f16x3': ('f16', 2, [(1, 0), (0, 1), (0, 0)]),
+                      'bf16x3': ('bf16', 2, [(1, 0), (0, 1), (0, 0)]),
+                      'bf16x6': ('bf16', 3, [(2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)]),
+                      'f16x1': ('f16', 1, [(0, 0)])}[scheme]
+
+    def mm(a, b):
+        if a.dtype != torch.float32 or b.dtype != torch.float32:
+            return _matmul(a, b)
+        ca, cb = _components(a, kind, n), _components(b, kind, n)
+        out = None
+        for i, j in pairs:                       # small terms first, fp32 accumulation
+            t = _matmul(ca[i], cb[j])
+            out = t if out is None else out + t
+        return out
+    return mm
+
+
+class patched:
+    """routes x @ y, torch.matmul and the oracle's two einsum patterns through `mm`; optionally quantises the Sinkhorn matrix"""
+
+    def __init__(self, scheme, sink_bits=23):
+        self.mm, self.bits = make_matmul(scheme), sink_bits
+
+    def __enter__(self):
+        mm = self.mm
+
+        def einsum(eq, a, b):
+            if eq == 'bhnd,bhmd->bhnm':
+                return mm(a, b.transpose(-1, -2))
+            if eq == 'bnd,bmd->bnm':
+                return mm(a, b.transpose(-1, -2))
+            return _einsum(eq, a, b)
+
+        self._saved = (torch.matmul, torch.Tensor.__matmul__, torch.einsum, orc.sinkhorn)
+        torch.matmul = mm
+        torch.Tensor.__matmul__ = lambda a, b: mm(a, b)
+        torch.einsum = einsum
+        bits = self.bits
+        if bits < 23:
+            def sinkhorn(M_aug, iteration):
+                B, n1, m1 = M_aug.shape
+                r = torch.ones(B, n1); r[:, -1] = n1
+                c = torch.ones(B, m1); c[:, -1] = m1
+                p = torch.softmax(M_aug, dim=-1)
+                # keep `bits` mantissa bits, round to nearest even (the 3-byte copy of csrc/ot.hip keeps 15)
+                drop = 23 - bits
+                i = p.view(torch.int32)
+                q = ((i + (1 << (drop - 1)) - 1 + ((i >> drop) & 1)) >> drop << drop).view(torch.float32)
+                u = torch.ones_like(r); v = torch.ones_like(c)
+                for _ in range(iteration):
+                    u = r / ((q * v.unsqueeze(-2)).sum(-1) + orc.EPS)
+                    v = c / ((q * u.unsqueeze(-1)).sum(-2) + orc.EPS)
+                return p * u.unsqueeze(-1) * v.unsqueeze(-2)
+            orc.sinkhorn = sinkhorn
+        return self
+
+    def __exit__(self, *a):
+        torch.matmul, torch.Tensor.__matmul__, torch.einsum, orc.sinkhorn = self._saved
+
+
+def run_fixture(name, scheme, bits):
+    spec, z = load_golden(name)
+    cfg, sd, data = build_case(spec)
+    o = orc.MatcherOracle(cfg, sd, model=spec['model'])
+    with patched(scheme, bits), torch.no_grad():
+        out = o.produce_matches(data, **spec.get('call', {}))
+    bad, dms = 0, 0.0
+    for i in range(int(z['n_emitted'])):
+        gi, gm = out['indices0'][i].numpy(), out['mscores0'][i].numpy()
+        bad += int((gi != z[f'indices0_{i}']).sum())
+        agree = (gm > 0) == (z[f'mscores0_{i}'] > 0)
+        dms = max(dms, float(np.abs(gm - z[f'mscores0_{i}'])[agree].max(initial=0.0)))
+    return bad, dms
+
+
+def run_big(n, seed, scheme, bits, base):
+    from imp_release_amd import synthetic
+    from helpers import eval_config
+    cfg = eval_config(n_layers=9, sinkhorn_iterations=100)
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=1)
+    pair = synthetic.make_correlated_pair(n, n, seed=seed)
+    data = {k: torch.from_numpy(v) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'])
+    o = orc.MatcherOracle(cfg, sd, 'GM')
+    with patched(scheme, bits), torch.no_grad():
+        out = o.produce_matches(data, p=0.2, only_last=True)
+    gi, gm = out['indices0'][-1].numpy(), out['mscores0'][-1].numpy()
+    if base is None:
+        return (gi, gm), 0, 0.0
+    agree = (gm > 0) == (base[1] > 0)
+    return (gi, gm), int((gi != base[0]).sum()), float(np.abs(gm - base[1])[agree].max(initial=0.0))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--fixtures', default='')
+    ap.add_argument('--big', action='store_true')
+    ap.add_argument('--threads', type=int, default=8)
+    a = ap.parse_args()
+    torch.set_num_threads(a.threads)
+    names = [n for n in a.fixtures.split(',') if n] or golden_names(['gm_l', 'dgnns_l', 'adagmn_masked'])
+    variants = [('fp32', 23), ('f16x3', 23), ('bf16x3', 23), ('bf16x6', 23), ('f16x1', 23), ('fp32', 15), ('fp32', 10), ('fp32', 7)]
+    print(f'{"fixture":26s} ' + ' '.join(f'{s + ("" if b == 23 else f"/P{b}"):>17s}' for s, b in variants))
+    print(f'{"":26s} ' + ' '.join(f'{"idx-bad  max|dms|":>17s}' for _ in variants))
+    tot = [[0, 0.0] for _ in variants]
+    for name in names:
+        row = []
+        for k, (s, b) in enumerate(variants):
+            bad, dms = run_fixture(name, s, b)
+            tot[k][0] += bad
+            tot[k][1] = max(tot[k][1], dms)
+            row.append(f'{bad:7d} {dms:9.2e}')
+        print(f'{name:26s} ' + ' '.join(row), flush=True)
+    print(f'{"TOTAL (vs the reference)":26s} ' + ' '.join(f'{t[0]:7d} {t[1]:9.2e}' for t in tot))
+    if a.big:
+        print('\nN x N pairs, GM L=9 T=100, against the fp32 oracle on the same inputs:')
+        for n, seeds in ((1024, (201, 202, 203)), (2048, (301,))):
+            for seed in seeds:
+                base, _, _ = run_big(n, seed, 'fp32', 23, None)
+                row = []
+                for s, b in variants[1:]:
+                    _, bad, dms = run_big(n, seed, s, b, base)
+                    row.append(f'{s + ("" if b == 23 else f"/P{b}")}: {bad} / {dms:.2e}')
+                print(f'  N={n} seed={seed}: ' + '   '.join(row), flush=True)
+
+
+if __name__ == '__main__':
+    main()
