@@ -4,7 +4,7 @@
 //
 // The reference parks the GPU during every pose estimate (cv2.findEssentialMat(USAC_MAGSAC) on the host, 7 times per pair,
 // eval/matching.py:84-87).  Here the estimate is a batch of tiny kernels: H seeded 8-point hypotheses in parallel (one
-// thread each: Hartley conditioning, 9x9 normal matrix, Jacobi eigenvector, projection onto the essential manifold), a
+// thread each: Hartley conditioning, null vector of the 8x9 system by Gauss-Jordan, projection onto the essential manifold), a
 // Sampson-distance inlier count per hypothesis (one workgroup each), then ONE workgroup that picks the first best
 // hypothesis, refits on its consensus set (up to 3 times, kept while not worse), decomposes E and takes the cheirality vote
 // with per-point DLT triangulation.  Everything in fp64 (n <= a few thousand correspondences: the work is microseconds).
@@ -39,7 +39,7 @@ __device__ void jacobi_eig(double (&a)[N][N], double (&v)[N][N]) {
             diag += a[i][i] * a[i][i];
             for (int j = i + 1; j < N; ++j) off += a[i][j] * a[i][j];
         }
-        if (off <= 1e-30 * diag || off == 0.0) break;
+        if (off <= 1e-26 * diag || off == 0.0) break;     // off-diagonal norm below 1e-13 of the diagonal: converged in fp64
         for (int p = 0; p < N - 1; ++p)
             for (int q = p + 1; q < N; ++q) {
                 if (a[p][q] == 0.0) continue;
@@ -61,6 +61,48 @@ __device__ void jacobi_eig(double (&a)[N][N], double (&v)[N][N]) {
                     v[k][p] = c * vkp - s * vkq;
                     v[k][q] = s * vkp + c * vkq;
                 }
+            }
+    }
+}
+
+// the same cyclic Jacobi for a 9 x 9 matrix held in LDS, executed by ONE wave: lane k owns row / column k of every rotation, the
+// rotation angle is computed redundantly by all lanes (a single thread walking a 9 x 9 array in scratch memory takes ~1 ms)
+__device__ void jacobi9_wave(double* A, double* V, int lane) {
+    auto sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    for (int i = lane; i < 81; i += 64) V[i] = (i / 9 == i % 9) ? 1.0 : 0.0;
+    sync();
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = lane; i < 81; i += 64) {
+            const int r = i / 9, c = i % 9;
+            const double x = A[i];
+            if (r == c) diag += x * x; else if (r < c) off += x * x;
+        }
+        for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o); diag += __shfl_xor(diag, o); }
+        if (off <= 1e-26 * diag || off == 0.0) break;
+        for (int p = 0; p < 8; ++p)
+            for (int q = p + 1; q < 9; ++q) {
+                const double apq = A[p * 9 + q];
+                if (apq == 0.0) continue;                         // uniform
+                const double theta = (A[q * 9 + q] - A[p * 9 + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                sync();
+                if (lane < 9) {
+                    const double akp = A[lane * 9 + p], akq = A[lane * 9 + q];
+                    A[lane * 9 + p] = c * akp - s * akq;
+                    A[lane * 9 + q] = s * akp + c * akq;
+                    const double vkp = V[lane * 9 + p], vkq = V[lane * 9 + q];
+                    V[lane * 9 + p] = c * vkp - s * vkq;
+                    V[lane * 9 + q] = s * vkp + c * vkq;
+                }
+                sync();
+                if (lane < 9) {
+                    const double apk = A[p * 9 + lane], aqk = A[q * 9 + lane];
+                    A[p * 9 + lane] = c * apk - s * aqk;
+                    A[q * 9 + lane] = s * apk + c * aqk;
+                }
+                sync();
             }
     }
 }
@@ -89,15 +131,9 @@ __device__ void svd3(const double (&E)[3][3], double (&U)[3][3], double (&s)[3],
     U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
 }
 
-// essential matrix from the 9x9 normal matrix of conditioned correspondences: smallest eigenvector, un-conditioning, (1, 1, 0) projection
-__device__ bool essential_from_normal(double (&ata)[9][9], const double (&T0)[3], const double (&T1)[3], double (&Eo)[3][3]) {
-    double v[9][9];
-    jacobi_eig<9>(ata, v);
-    int m = 0;
-    for (int i = 1; i < 9; ++i) if (ata[i][i] < ata[m][m]) m = i;
-    double F[3][3];
-    for (int i = 0; i < 9; ++i) F[i / 3][i % 3] = v[i][m];
-    // E = T1^T F T0 with T = [[s, 0, -s cx], [0, s, -s cy], [0, 0, 1]]  (T stored as (s, cx, cy))
+// conditioned fundamental estimate F -> essential matrix: un-conditioning E = T1^T F T0, projection onto singular values (1, 1, 0)
+__device__ bool essential_from_F(const double (&F)[3][3], const double (&T0)[3], const double (&T1)[3], double (&Eo)[3][3]) {
+    // T = [[s, 0, -s cx], [0, s, -s cy], [0, 0, 1]] stored as (s, cx, cy)
     double FT0[3][3];
     for (int r = 0; r < 3; ++r) {
         FT0[r][0] = F[r][0] * T0[0];
@@ -116,6 +152,16 @@ __device__ bool essential_from_normal(double (&ata)[9][9], const double (&T0)[3]
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) Eo[r][c] = U[r][0] * V[c][0] + U[r][1] * V[c][1];
     return true;
+}
+// least-squares form: smallest eigenvector of the 9x9 normal matrix of conditioned correspondences
+__device__ bool essential_from_normal(double (&ata)[9][9], const double (&T0)[3], const double (&T1)[3], double (&Eo)[3][3]) {
+    double v[9][9];
+    jacobi_eig<9>(ata, v);
+    int m = 0;
+    for (int i = 1; i < 9; ++i) if (ata[i][i] < ata[m][m]) m = i;
+    double F[3][3];
+    for (int i = 0; i < 9; ++i) F[i / 3][i % 3] = v[i][m];
+    return essential_from_F(F, T0, T1, Eo);
 }
 
 __device__ __forceinline__ double sampson_sq(const double* E, double x0, double y0, double x1, double y1) {
@@ -154,13 +200,43 @@ __global__ __launch_bounds__(64) void pose_hypotheses_kernel(const double2* __re
                 (v ? by : ay)[k] = (p.y - cy) * s;
             }
         }
-        double ata[9][9];
-        for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) ata[i][j] = 0.0;
+        // minimal sample: the 8 x 9 system has a one-dimensional null space - Gauss-Jordan with full pivoting gives it directly
+        // (the same vector, up to scale, as the smallest eigenvector of A^T A that the least-squares refit uses)
+        double A[8][9];
         for (int k = 0; k < 8; ++k) {
             const double r[9] = {bx[k] * ax[k], bx[k] * ay[k], bx[k], by[k] * ax[k], by[k] * ay[k], by[k], ax[k], ay[k], 1.0};
-            for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) ata[i][j] += r[i] * r[j];
+            for (int j = 0; j < 9; ++j) A[k][j] = r[j];
         }
-        ok = essential_from_normal(ata, T[0], T[1], E);
+        int pcol[8];
+        unsigned used = 0;
+        for (int r = 0; r < 8 && ok; ++r) {
+            int pi = r, pj = -1;
+            double best = 0.0;
+            for (int i = r; i < 8; ++i)
+                for (int j = 0; j < 9; ++j)
+                    if (!((used >> j) & 1u) && fabs(A[i][j]) > best) { best = fabs(A[i][j]); pi = i; pj = j; }
+            if (pj < 0 || best < 1e-12) { ok = false; break; }
+            if (pi != r) for (int j = 0; j < 9; ++j) { const double t = A[r][j]; A[r][j] = A[pi][j]; A[pi][j] = t; }
+            used |= 1u << pj;
+            pcol[r] = pj;
+            const double inv = 1.0 / A[r][pj];
+            for (int j = 0; j < 9; ++j) A[r][j] *= inv;
+            for (int i = 0; i < 8; ++i)
+                if (i != r) {
+                    const double f = A[i][pj];
+                    if (f != 0.0) for (int j = 0; j < 9; ++j) A[i][j] -= f * A[r][j];
+                }
+        }
+        if (ok) {
+            int q = 0;
+            while ((used >> q) & 1u) ++q;                    // the free column
+            double fvec[9];
+            fvec[q] = 1.0;
+            for (int r = 0; r < 8; ++r) fvec[pcol[r]] = -A[r][q];
+            double F[3][3];
+            for (int i = 0; i < 9; ++i) F[i / 3][i % 3] = fvec[i];
+            ok = essential_from_F(F, T[0], T[1], E);
+        }
     }
     valid[h] = ok ? 1 : 0;
     if (ok) for (int i = 0; i < 9; ++i) Eh[(long)h * 9 + i] = E[i / 3][i % 3];
@@ -194,22 +270,33 @@ __device__ double block_sum(double v, double* sm) {        // 1024 threads
     return t;
 }
 
-// one workgroup: first best hypothesis -> refits -> decomposition + cheirality vote
-__global__ __launch_bounds__(1024) void pose_finish_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n, int H,
+// one workgroup: first best hypothesis -> consensus refits -> decomposition of E
+__global__ __launch_bounds__(1024) void pose_consensus_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n, int H,
                                                            const double* __restrict__ Eh, const int* __restrict__ counts, double thr2,
-                                                           double dist_thresh, unsigned char* __restrict__ inl, double* __restrict__ out) {
-    // out: [0..8] E, [9..17] R, [18..20] t, [21] inliers of E, [22] cheirality inliers, [23] ok flag
+                                                           unsigned char* __restrict__ inl, double* __restrict__ out) {
+    // out: [0..8] E, [9..17] R, [18..20] t, [21] inliers of E, [22] cheirality inliers, [23] ok flag, [24..32] R1, [33..41] R2, [42..44] t
     __shared__ double sm[16 * 45];
-    __shared__ double Es[9], Et[9], geo[24];
+    __shared__ double Es[9], Et[9];
     __shared__ int s_best, s_cnt, s_ok;
     const int tid = threadIdx.x;
-    if (tid == 0) {
-        int best = -1, bi = -1;
-        for (int h = 0; h < H; ++h) if (counts[h] > best) { best = counts[h]; bi = h; }
-        s_best = bi; s_cnt = best;
-        if (bi >= 0) for (int i = 0; i < 9; ++i) Es[i] = Eh[(long)bi * 9 + i];
+    {   // first best hypothesis (largest count, lowest index): strided scan + wave / workgroup reduction
+        int best = -1, bi = 0x7fffffff;
+        for (int h = tid; h < H; h += 1024) { const int c = counts[h]; if (c > best) { best = c; bi = h; } }
+        for (int o = 32; o > 0; o >>= 1) {
+            const int ob = __shfl_xor(best, o), oi = __shfl_xor(bi, o);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        int* smi = reinterpret_cast<int*>(sm);
+        if ((tid & 63) == 0) { smi[2 * (tid >> 6)] = best; smi[2 * (tid >> 6) + 1] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 16; ++w)
+                if (smi[2 * w] > best || (smi[2 * w] == best && smi[2 * w + 1] < bi)) { best = smi[2 * w]; bi = smi[2 * w + 1]; }
+            s_best = best >= 0 ? bi : -1; s_cnt = best;
+            if (best >= 0) for (int i = 0; i < 9; ++i) Es[i] = Eh[(long)bi * 9 + i];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (s_best < 0 || s_cnt < 8) { if (tid == 0) out[23] = 0.0; return; }
     for (int i = tid; i < n; i += 1024) inl[i] = sampson_sq(Es, x0[i].x, x0[i].y, x1[i].x, x1[i].y) < thr2;
     __syncthreads();
@@ -237,17 +324,26 @@ __global__ __launch_bounds__(1024) void pose_finish_kernel(const double2* __rest
         __syncthreads();
         if ((tid & 63) == 0) for (int k = 0; k < 45; ++k) sm[(tid >> 6) * 45 + k] = acc[k];
         __syncthreads();
+        __shared__ double JA[81], JV[81];
+        if (tid < 45) {                                            // assemble the symmetric normal matrix (fixed summation order)
+            int a = 0, rem = tid;
+            while (rem >= 9 - a) { rem -= 9 - a; ++a; }
+            const int b2 = a + rem;
+            double t = 0;
+            for (int w = 0; w < 16; ++w) t += sm[w * 45 + tid];
+            JA[a * 9 + b2] = JA[b2 * 9 + a] = t;
+        }
+        __syncthreads();
+        if (tid < 64) jacobi9_wave(JA, JV, tid);
+        __syncthreads();
         if (tid == 0) {
-            double ata[9][9];
-            int k = 0;
-            for (int a = 0; a < 9; ++a) for (int b2 = a; b2 < 9; ++b2) {
-                double t = 0;
-                for (int w = 0; w < 16; ++w) t += sm[w * 45 + k];
-                ata[a][b2] = ata[b2][a] = t; ++k;
-            }
+            int m = 0;
+            for (int i = 1; i < 9; ++i) if (JA[i * 9 + i] < JA[m * 9 + m]) m = i;
+            double F[3][3];
+            for (int i = 0; i < 9; ++i) F[i / 3][i % 3] = JV[i * 9 + m];
             const double T0[3] = {s0, cx0, cy0}, T1[3] = {s1, cx1, cy1};
             double E2[3][3];
-            s_ok = essential_from_normal(ata, T0, T1, E2) ? 1 : 0;
+            s_ok = essential_from_F(F, T0, T1, E2) ? 1 : 0;
             if (s_ok) for (int i = 0; i < 9; ++i) Et[i] = E2[i / 3][i % 3];
         }
         __syncthreads();
@@ -272,61 +368,66 @@ __global__ __launch_bounds__(1024) void pose_finish_kernel(const double2* __rest
         // W = [[0,1,0],[-1,0,0],[0,0,1]]:  U W = [-u1, u0, u2],  U W^T = [u1, -u0, u2]
         for (int r = 0; r < 3; ++r)
             for (int c2 = 0; c2 < 3; ++c2) {
-                geo[r * 3 + c2] = -U[r][1] * V[c2][0] + U[r][0] * V[c2][1] + U[r][2] * V[c2][2];
-                geo[9 + r * 3 + c2] = U[r][1] * V[c2][0] - U[r][0] * V[c2][1] + U[r][2] * V[c2][2];
+                out[24 + r * 3 + c2] = -U[r][1] * V[c2][0] + U[r][0] * V[c2][1] + U[r][2] * V[c2][2];
+                out[33 + r * 3 + c2] = U[r][1] * V[c2][0] - U[r][0] * V[c2][1] + U[r][2] * V[c2][2];
             }
-        for (int r = 0; r < 3; ++r) geo[18 + r] = U[r][2];
+        for (int r = 0; r < 3; ++r) out[42 + r] = U[r][2];
+        for (int i = 0; i < 9; ++i) out[i] = Es[i];
+        out[21] = (double)s_cnt; out[23] = 1.0;
+    }
+}
+
+// cheirality test (eval/pose_estimation.py:14-27,40-68) of every inlier against the four candidates (R1,t), (R2,t), (R1,-t), (R2,-t):
+// bit k of bits[i] = "point i is in front of both cameras of candidate k"; good[k] counts them (integer atomics: order-free)
+__global__ __launch_bounds__(256) void pose_cheirality_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n,
+                                                              const double* __restrict__ out, const unsigned char* __restrict__ inl,
+                                                              double dist_thresh, unsigned char* __restrict__ bits, int* __restrict__ good) {
+    __shared__ int cnt[4];
+    if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (out[23] != 0.0 && i < n && inl[i]) {
+        unsigned char bb = 0;
+        for (int k = 0; k < 4; ++k) {
+            const double* R = out + 24 + (k & 1) * 9;
+            const double sg = k >= 2 ? -1.0 : 1.0;
+            const double P[3][4] = {{R[0], R[1], R[2], sg * out[42]}, {R[3], R[4], R[5], sg * out[43]}, {R[6], R[7], R[8], sg * out[44]}};
+            // DLT rows (cv2.triangulatePoints): x P0[2] - P0[0], y P0[2] - P0[1] with P0 = [I | 0], and the same for P
+            const double A[4][4] = {{-1, 0, x0[i].x, 0}, {0, -1, x0[i].y, 0},
+                                    {x1[i].x * P[2][0] - P[0][0], x1[i].x * P[2][1] - P[0][1], x1[i].x * P[2][2] - P[0][2], x1[i].x * P[2][3] - P[0][3]},
+                                    {x1[i].y * P[2][0] - P[1][0], x1[i].y * P[2][1] - P[1][1], x1[i].y * P[2][2] - P[1][2], x1[i].y * P[2][3] - P[1][3]}};
+            double ata[4][4], ev[4][4];
+            for (int a = 0; a < 4; ++a) for (int b2 = 0; b2 < 4; ++b2) ata[a][b2] = A[0][a] * A[0][b2] + A[1][a] * A[1][b2] + A[2][a] * A[2][b2] + A[3][a] * A[3][b2];
+            jacobi_eig<4>(ata, ev);
+            int m = 0;
+            for (int a = 1; a < 4; ++a) if (ata[a][a] < ata[m][m]) m = a;
+            const double Q[4] = {ev[0][m], ev[1][m], ev[2][m], ev[3][m]};
+            bool ok = Q[2] * Q[3] > 0;
+            const double X = Q[0] / Q[3], Y = Q[1] / Q[3], Z = Q[2] / Q[3];
+            ok = ok && Z < dist_thresh;
+            const double zc = P[2][0] * X + P[2][1] * Y + P[2][2] * Z + P[2][3];
+            ok = ok && zc > 0 && zc < dist_thresh;
+            if (ok) { bb |= 1u << k; atomicAdd(&cnt[k], 1); }
+        }
+        bits[i] = bb;
     }
     __syncthreads();
-    // cheirality vote (eval/pose_estimation.py:40-89) over the inliers of E; candidate order (R1,t), (R2,t), (R1,-t), (R2,-t)
-    double good[4] = {0, 0, 0, 0};
-    unsigned char mloc[4] = {0, 0, 0, 0};          // (only the first point of a thread is remembered; masks are recomputed below)
-    for (int pass = 0; pass < 2; ++pass) {
-        int chosen = -1;
-        if (pass == 1) {
-            __shared__ int s_choice;
-            double g[4];
-            for (int k = 0; k < 4; ++k) g[k] = block_sum(good[k], sm);
-            if (tid == 0) {
-                double best = fmax(fmax(g[0], g[1]), fmax(g[2], g[3]));
-                s_choice = g[0] == best ? 0 : (g[1] == best ? 1 : (g[2] == best ? 2 : 3));
-                const double* R = geo + (s_choice & 1) * 9;
-                for (int i = 0; i < 9; ++i) out[9 + i] = R[i];
-                for (int i = 0; i < 3; ++i) out[18 + i] = (s_choice >= 2 ? -1.0 : 1.0) * geo[18 + i];
-                for (int i = 0; i < 9; ++i) out[i] = Es[i];
-                out[21] = (double)s_cnt; out[22] = best; out[23] = 1.0;
-            }
-            __syncthreads();
-            chosen = s_choice;
-        }
-        for (int i = tid; i < n; i += 1024) {
-            if (!inl[i]) continue;
-            for (int k = 0; k < 4; ++k) {
-                if (pass == 1 && k != chosen) continue;
-                const double* R = geo + (k & 1) * 9;
-                const double sg = k >= 2 ? -1.0 : 1.0;
-                const double P[3][4] = {{R[0], R[1], R[2], sg * geo[18]}, {R[3], R[4], R[5], sg * geo[19]}, {R[6], R[7], R[8], sg * geo[20]}};
-                // DLT rows: x P0[2] - P0[0], y P0[2] - P0[1] (P0 = [I | 0]) and the same for P
-                double A[4][4] = {{-1, 0, x0[i].x, 0}, {0, -1, x0[i].y, 0},
-                                  {x1[i].x * P[2][0] - P[0][0], x1[i].x * P[2][1] - P[0][1], x1[i].x * P[2][2] - P[0][2], x1[i].x * P[2][3] - P[0][3]},
-                                  {x1[i].y * P[2][0] - P[1][0], x1[i].y * P[2][1] - P[1][1], x1[i].y * P[2][2] - P[1][2], x1[i].y * P[2][3] - P[1][3]}};
-                double ata[4][4], ev[4][4];
-                for (int a = 0; a < 4; ++a) for (int b2 = 0; b2 < 4; ++b2) ata[a][b2] = A[0][a] * A[0][b2] + A[1][a] * A[1][b2] + A[2][a] * A[2][b2] + A[3][a] * A[3][b2];
-                jacobi_eig<4>(ata, ev);
-                int m = 0;
-                for (int a = 1; a < 4; ++a) if (ata[a][a] < ata[m][m]) m = a;
-                double Q[4] = {ev[0][m], ev[1][m], ev[2][m], ev[3][m]};
-                bool ok = Q[2] * Q[3] > 0;
-                const double X = Q[0] / Q[3], Y = Q[1] / Q[3], Z = Q[2] / Q[3];
-                ok = ok && Z < dist_thresh;
-                const double zc = P[2][0] * X + P[2][1] * Y + P[2][2] * Z + P[2][3];
-                ok = ok && zc > 0 && zc < dist_thresh;
-                if (pass == 0) good[k] += ok ? 1.0 : 0.0;
-                else inl[i] = ok ? 1 : 0;                  // final mask: eval/pose_estimation.py:113-114
-            }
-        }
+    if (threadIdx.x < 4 && cnt[threadIdx.x]) atomicAdd(&good[threadIdx.x], cnt[threadIdx.x]);
+}
+
+// the vote: most points in front, first candidate on ties (eval/pose_estimation.py:80-89); final mask = inlier of E AND in front (:113-114)
+__global__ __launch_bounds__(256) void pose_vote_kernel(int n, const int* __restrict__ good, const unsigned char* __restrict__ bits,
+                                                        unsigned char* __restrict__ inl, double* __restrict__ out) {
+    if (out[23] == 0.0) return;
+    const int best = max(max(good[0], good[1]), max(good[2], good[3]));
+    const int k = good[0] == best ? 0 : (good[1] == best ? 1 : (good[2] == best ? 2 : 3));
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && inl[i]) inl[i] = (bits[i] >> k) & 1;
+    if (i == 0) {
+        for (int j = 0; j < 9; ++j) out[9 + j] = out[24 + (k & 1) * 9 + j];
+        for (int j = 0; j < 3; ++j) out[18 + j] = (k >= 2 ? -1.0 : 1.0) * out[42 + j];
+        out[22] = (double)best;
     }
-    (void)mloc;
 }
 
 struct PoseWs {
@@ -334,8 +435,8 @@ struct PoseWs {
     size_t cap_n = 0, cap_h = 0;
     double2 *x0 = nullptr, *x1 = nullptr;
     double *Eh = nullptr, *out = nullptr;
-    int *valid = nullptr, *counts = nullptr;
-    unsigned char* inl = nullptr;
+    int *valid = nullptr, *counts = nullptr, *good = nullptr;
+    unsigned char *inl = nullptr, *bits = nullptr;
 };
 
 }  // namespace
@@ -350,12 +451,13 @@ extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, 
     hipStream_t st = (hipStream_t)stream;
     static thread_local PoseWs ws;
     if (ws.device != device || (size_t)n > ws.cap_n || (size_t)iterations > ws.cap_h) {
-        for (void* p : {(void*)ws.x0, (void*)ws.x1, (void*)ws.Eh, (void*)ws.out, (void*)ws.valid, (void*)ws.counts, (void*)ws.inl})
+        for (void* p : {(void*)ws.x0, (void*)ws.x1, (void*)ws.Eh, (void*)ws.out, (void*)ws.valid, (void*)ws.counts, (void*)ws.inl, (void*)ws.good, (void*)ws.bits})
             if (p) (void)hipFree(p);
         ws = PoseWs();
         const size_t cn = (size_t)n < 4096 ? 4096 : (size_t)n, ch = (size_t)iterations < 2048 ? 2048 : (size_t)iterations;
         if (hipMalloc(&ws.x0, cn * sizeof(double2)) != hipSuccess || hipMalloc(&ws.x1, cn * sizeof(double2)) != hipSuccess ||
-            hipMalloc(&ws.Eh, ch * 9 * sizeof(double)) != hipSuccess || hipMalloc(&ws.out, 24 * sizeof(double)) != hipSuccess ||
+            hipMalloc(&ws.Eh, ch * 9 * sizeof(double)) != hipSuccess || hipMalloc(&ws.out, 48 * sizeof(double)) != hipSuccess ||
+            hipMalloc(&ws.good, 4 * sizeof(int)) != hipSuccess || hipMalloc(&ws.bits, cn) != hipSuccess ||
             hipMalloc(&ws.valid, ch * sizeof(int)) != hipSuccess || hipMalloc(&ws.counts, ch * sizeof(int)) != hipSuccess ||
             hipMalloc(&ws.inl, cn) != hipSuccess)
             return IMP_E_NOMEM;
@@ -374,8 +476,10 @@ extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, 
     hipLaunchKernelGGL(pose_score_kernel, dim3(iterations), dim3(256), 0, st, ws.x0, ws.x1, n, ws.Eh, ws.valid, thr * thr, ws.counts);
     // the cheirality step of the reference normalises with K = (K0 + K1) / 2 (eval/pose_estimation.py:29-33): with K0 == K1 (every
     // caller in the repo) these are the coordinates above; a caller with two different cameras gets per-camera normalisation
-    hipLaunchKernelGGL(pose_finish_kernel, dim3(1), dim3(1024), 0, st, ws.x0, ws.x1, n, iterations, ws.Eh, ws.counts, thr * thr, 1000.0,
-                       ws.inl, ws.out);
+    hipLaunchKernelGGL(pose_consensus_kernel, dim3(1), dim3(1024), 0, st, ws.x0, ws.x1, n, iterations, ws.Eh, ws.counts, thr * thr, ws.inl, ws.out);
+    if (hipMemsetAsync(ws.good, 0, 4 * sizeof(int), st) != hipSuccess) return IMP_E_HIP;
+    hipLaunchKernelGGL(pose_cheirality_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws.x0, ws.x1, n, ws.out, ws.inl, 1000.0, ws.bits, ws.good);
+    hipLaunchKernelGGL(pose_vote_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, ws.good, ws.bits, ws.inl, ws.out);
     double out[24];
     if (hipMemcpyAsync(out, ws.out, sizeof out, hipMemcpyDeviceToHost, st) != hipSuccess) return IMP_E_HIP;
     if (hipMemcpyAsync(mask, ws.inl, n, hipMemcpyDeviceToHost, st) != hipSuccess) return IMP_E_HIP;

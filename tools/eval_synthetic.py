@@ -5,7 +5,8 @@ N independent synthetic pairs through the iterative loop, sharded over the ranks
     python tools/eval_synthetic.py --pairs 16 --model EIMP --kpts 2048
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/eval_synthetic.py --pairs 4000 --model EIMP
 
-The OpenCV pose step of the reference is out of scope (no cv2 here): the loops run without early exit."""
+--pose none: no pose is ever found (the loops run all 15 iterations); --pose gpu: the GPU pose step (imp_release_amd.pose, csrc/pose.hip:
+seeded 8-point RANSAC + cheirality vote, NOT OpenCV's MAGSAC) sits in the loop's estimate_pose slot, 7 calls per pair."""
 import argparse, json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,6 +21,7 @@ def main():
     ap.add_argument('--kpts', type=int, default=2048)
     ap.add_argument('--bin-score', type=float, default=5.0)
     ap.add_argument('--workers', type=int, default=1, help='pairs in flight per GPU (model replicas + streams)')
+    ap.add_argument('--pose', choices=['none', 'gpu'], default='none')
     a = ap.parse_args()
     rank, world, lr = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(lr)
@@ -48,6 +50,7 @@ def main():
         d = {k: torch.from_numpy(v).to(dev) for k, v in pair.items() if k != 'image_shape'}
         d['image0'] = d['image1'] = torch.zeros(pair['image_shape'], device=dev)
         d['pts0_cpu'] = pair['keypoints0'][0]; d['pts1_cpu'] = pair['keypoints1'][0]
+        d['K0'] = d['K1'] = np.array([[520., 0, 320.], [0, 520., 240.], [0, 0, 1.]])
         return d
 
     s0, e0 = __import__('imp_release_amd').dist.shard_range(a.pairs, rank, world)
@@ -55,12 +58,15 @@ def main():
         host_pair(pid)
     reps = eval_loop.replicate(m, a.workers)
     kw = dict(eimp=a.model == 'EIMP', workers=a.workers, replicas=reps)
+    if a.pose == 'gpu':
+        from imp_release_amd import pose as gpose
+        kw['estimate_pose'] = lambda **k: gpose.estimate_pose(**{x: v for x, v in k.items() if x != 'method'})
     eval_loop.run_pairs_sharded(m, provider, min(a.pairs, 2 * world * a.workers), **kw)      # warm-up
     torch.cuda.synchronize(); t0 = time.perf_counter()
     table = eval_loop.run_pairs_sharded(m, provider, a.pairs, **kw)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     if rank == 0:
-        print(json.dumps({'model': a.model, 'pairs': a.pairs, 'n_gpus': world, 'kpts': a.kpts, 'workers_per_gpu': a.workers, 'pairs_per_s': a.pairs / dt,
+        print(json.dumps({'model': a.model, 'pairs': a.pairs, 'n_gpus': world, 'kpts': a.kpts, 'workers_per_gpu': a.workers, 'pose': a.pose, 'pairs_per_s': a.pairs / dt,
                           'includes': 'H2D upload of every pair on the host path of each rank (pairs pre-generated)',
                           'mean': dict(zip(eval_loop.SUMMARY_COLUMNS, table.mean(0).round(3).tolist()))}))
     if world > 1:
