@@ -1,12 +1,17 @@
 #!/bin/bash
-# driver-like final check: GPU tests, smoke, default bench (with CPU baseline), rocprof kernel stats
-R=$PWD; mkdir -p gpurun_out
-(timeout 400 python -m pytest tests -m gpu -q --no-header -rfE -p no:cacheprovider 2>&1 | tail -5) > gpurun_out/final_pytest.log 2>&1
-(timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3) > gpurun_out/final_smoke.log 2>&1
-(timeout 600 python bench.py 2>&1 | tail -1) > gpurun_out/final_bench.json 2>&1
+# driver-like final check + the evidence files of a round:  tools/gpu_final.sh <round-tag>   (one gpurun call)
+#   GPU tests, smoke, default bench (with CPU baseline), rocprofv3 kernel stats of the bench workload (one step in flight and
+#   the default), of BASELINE configs[1] (N=1024, batch 1) and of the EIMP loop; everything lands in gpurun_out/final_<tag>_*
+R=$PWD; T=${1:-x}; O=$R/gpurun_out; mkdir -p $O
+(timeout 500 python -m pytest tests -m gpu -q --no-header -rfE -p no:cacheprovider 2>&1 | tail -6) > $O/final_${T}_pytest.log 2>&1
+(timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3) > $O/final_${T}_smoke.log 2>&1
+(timeout 600 python bench.py 2>&1 | tail -1) > $O/final_${T}_bench.json 2>&1
 cd /tmp && export TMPDIR=/tmp
 # per-kernel evidence is taken with ONE step in flight: overlapped kernels share the GPU, their durations are then not those of a full-chip launch
-(timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --in-flight 1 2>&1 | tail -1) > $R/gpurun_out/final_rocprof.log 2>&1
-(timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final3 -o bench -- python $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline 2>&1 | tail -1) > $R/gpurun_out/final_rocprof3.log 2>&1
+(timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/final_${T}_prof1 -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-batch1 --in-flight 1 2>&1 | tail -1) > $O/final_${T}_rocprof1.log 2>&1
+(timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/final_${T}_prof2 -o bench -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-batch1 2>&1 | tail -1) > $O/final_${T}_rocprof2.log 2>&1
+(timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/final_${T}_c2 -o c2 -- python $R/tools/probe/c2_run.py 1024 1 2>&1 | tail -1) > $O/final_${T}_c2.log 2>&1
 cd $R
-tail -3 gpurun_out/final_pytest.log; cat gpurun_out/final_smoke.log | tail -2; cut -c1-1500 gpurun_out/final_bench.json; echo; head -8 gpurun_out/prof_final/bench_kernel_stats.csv | cut -c1-150
+(timeout 200 python tools/gpu_configs.py 2>&1 | tail -7) > $O/final_${T}_configs.log 2>&1
+(timeout 200 python tools/eval_synthetic.py --pairs 24 --model EIMP --kpts 2048 --workers 3 --pose none 2>&1 | tail -1; timeout 200 python tools/eval_synthetic.py --pairs 24 --model EIMP --kpts 2048 --workers 3 --pose gpu 2>&1 | tail -1) > $O/final_${T}_loop.log 2>&1
+tail -4 $O/final_${T}_pytest.log; tail -2 $O/final_${T}_smoke.log; cut -c1-1800 $O/final_${T}_bench.json; echo; head -9 $O/final_${T}_prof1/bench_kernel_stats.csv | cut -c1-150; cat $O/final_${T}_configs.log
