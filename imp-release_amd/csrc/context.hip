@@ -1254,6 +1254,18 @@ int imp_time_sinkhorn(imp_ctx* c, int batch, int n, int iterations, float* ms, v
             HIP_TRY(hipEventElapsedTime(&tt[k], e0, e1));
         }
         t = (tt[1] - tt[0]) / 3.f / iterations;
+        if (getenv("IMP_OTR_PROF")) {              // probe: phase cycles of workgroup 0 over one launch of `iterations`
+            unsigned long long* dprof = nullptr;
+            HIP_TRY(hipMalloc(&dprof, 6 * sizeof(unsigned long long)));
+            p.prof = dprof; p.T = iterations; p.tag_base = resident_tags(c, p.T);
+            HIP_TRY(launch_ot_resident(p, nch, rpw, st));
+            unsigned long long hp[6];
+            HIP_TRY(hipMemcpy(hp, dprof, sizeof hp, hipMemcpyDeviceToHost));
+            (void)hipFree(dprof);
+            fprintf(stderr, "[IMP_OTR_PROF] B=%d n=%d G=%d iterations=%d cycles per iteration (100 MHz-domain counter x?): A %.0f  B %.0f  wait+stage %.0f  reduce+store %.0f  wait+read v %.0f  vsum %.0f\n",
+                    batch, n, G, iterations, (double)hp[0] / iterations, (double)hp[1] / iterations, (double)hp[2] / iterations,
+                    (double)hp[3] / iterations, (double)hp[4] / iterations, (double)hp[5] / iterations);
+        }
     } else {
         OtBuffers o;
         ot_layout(c, n, n, &o);

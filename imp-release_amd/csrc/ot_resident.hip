@@ -43,10 +43,27 @@ constexpr float OT_EPS = 1e-8f;      // nets/layers.py:13
 constexpr int AUX_SC1 = 16;          // gfx940+ cache policy bit: agent-scope coherent access (what a relaxed agent atomic uses)
 constexpr int SPIN_LIMIT = 1 << 21;   // polls of one wait before it is declared dead (seconds)
 
+// sum over the 64 lanes with DPP row operations (6 VALU instructions, no LDS crossbar round trips: the __shfl_xor butterfly costs
+// six dependent ds_bpermute per sum, ~2400 cycles of an iteration's phase A); fixed order, the total is broadcast from lane 63
+#ifndef OTR_DPP_SUM
+#define OTR_DPP_SUM 1
+#endif
 __device__ __forceinline__ float wave_sum(float v) {
+#if OTR_DPP_SUM
+#define OTR_DPP_ADD(ctrl, row_mask) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false))
+    OTR_DPP_ADD(0xB1, 0xf);          // quad_perm [1,0,3,2]
+    OTR_DPP_ADD(0x4E, 0xf);          // quad_perm [2,3,0,1]
+    OTR_DPP_ADD(0x141, 0xf);         // row_half_mirror
+    OTR_DPP_ADD(0x140, 0xf);         // row_mirror: every lane of a 16-lane row holds the row sum
+    OTR_DPP_ADD(0x142, 0xa);         // row_bcast:15 into rows 1 and 3
+    OTR_DPP_ADD(0x143, 0xc);         // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+#undef OTR_DPP_ADD
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#else
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
+#endif
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -64,7 +81,13 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {     // first ind
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
-constexpr int AUX_POLL = AUX_SC1 | (int)0x80000000;   // + volatile: a poll must not be hoisted out of its loop
+#ifndef OTR_POLL_SLEEP
+#define OTR_POLL_SLEEP 0
+#endif
+#ifndef OTR_POLL_AUX
+#define OTR_POLL_AUX (AUX_SC1 | (int)0x80000000)      // + volatile: a poll must not be hoisted out of its loop (the compiler then also sets sc0: system scope)
+#endif
+constexpr int AUX_POLL = OTR_POLL_AUX;
 // four consecutive values of an exchange vector = 4 granules = 32 bytes at granule index 4 q
 __device__ __forceinline__ void stg4(__amdgpu_buffer_rsrc_t r, int q, const f32x4 v, unsigned tag) {
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), tag, __float_as_uint(v[1]), tag}, r, q * 32, 0, AUX_SC1);
@@ -78,9 +101,13 @@ __device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, int q, unsigned 
     u32x4 a, c;
     int spins = 0;
     for (;;) {
+        asm volatile("" ::: "memory");
         a = __builtin_amdgcn_raw_buffer_load_b128(r, q * 32, 0, AUX_POLL);
         c = __builtin_amdgcn_raw_buffer_load_b128(r, q * 32 + 16, 0, AUX_POLL);
         if ((a[1] == tag && a[3] == tag && c[1] == tag && c[3] == tag) || dead) break;
+#if OTR_POLL_SLEEP
+        __builtin_amdgcn_s_sleep(OTR_POLL_SLEEP);             // back off: failed polls compete with the stores they wait for
+#endif
         if ((++spins & 1023) == 0) {
             if (spins > SPIN_LIMIT) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) dead = true;
@@ -88,6 +115,10 @@ __device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, int q, unsigned 
     }
     return f32x4{__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(c[0]), __uint_as_float(c[2])};
 }
+
+// phase profile of workgroup 0 (p.prof != null; tools/probe/sk_prof.py): cycles of  0 A (u + column partials)  1 B (LDS combine +
+// partial store)  2 wait + stage of the slice  3 slice reduce + v store  4 wait + read of v  5 v sum
+#define OTR_CLK(i) if (p.prof) { const unsigned long long c_ = __builtin_readcyclecounter(); prof_acc[i] += c_ - tlast; tlast = c_; }
 
 template <int NCH, int RPW>
 __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentParams p) {
@@ -163,6 +194,8 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
     __syncthreads();
 
     const int cq = (NQ + G - 1) / G;           // float4 chunks of the exchange vector owned by one workgroup
+    unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = __builtin_readcyclecounter();
     for (int it = 0; it < p.T; ++it) {
         const unsigned tag_p = p.tag_base + 2u * it + 1u, tag_v = tag_p + 1u;
         // ---- A: u for the own rows, column partials ---------------------------------------------------------------
@@ -189,6 +222,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             pdpart = fmaf(Pd[k], u[k], pdpart);
         }
         u_last = (float)(n0 + 1) / (c0 * vsum + OT_EPS);              // dustbin row: marginal n0 + 1 (nets/layers.py:42)
+        OTR_CLK(0)
         // ---- B: workgroup partial vector ---------------------------------------------------------------------------
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -211,6 +245,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             stg4(rs_part, g * NQ + q, s, tag_p);
         }
         __syncthreads();                           // everyone is done with the wave partials in `red`
+        OTR_CLK(1)
         // ---- C: this workgroup's slice of columns over the G partial vectors -------------------------------------
         {
             f32x4* stage = reinterpret_cast<f32x4*>(red);             // [G][cq]
@@ -220,6 +255,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
                 stage[idx] = q < NQ ? ldg4(rs_part, w * NQ + q, tag_p, p.status, dead) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             __syncthreads();
+            OTR_CLK(2)
             // 8 threads per column, each over a contiguous eighth of the workgroups; then combined in order
             float* sub = red + (size_t)cq * G * 4;                    // [8][4 cq]
             const int ncol = 4 * cq;
@@ -247,9 +283,11 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
                 }
             }
         }
+        OTR_CLK(3)
         // ---- D: everybody reads v -----------------------------------------------------------------------------------
         for (int q = tid; q < NQ; q += 512) *reinterpret_cast<f32x4*>(vs + 4 * q) = ldg4(rs_v, q, tag_v, p.status, dead);
         __syncthreads();
+        OTR_CLK(4)
         {   // sum of v (every wave computes the same value in the same order: no further barrier)
             float s = 0.f;
 #pragma unroll
@@ -259,7 +297,10 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             }
             vsum = wave_sum(s) + vs[DCOL];
         }
+        OTR_CLK(5)
     }
+    if (p.prof && blockIdx.x == 0 && tid == 0)
+        for (int i = 0; i < 6; ++i) p.prof[i] = prof_acc[i];
 
     // ---- outputs ----------------------------------------------------------------------------------------------------
     const float vd = vs[DCOL];

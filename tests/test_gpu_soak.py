@@ -41,6 +41,6 @@ def test_random_case_vs_oracle(case):
     assert len(out['indices0']) == len(ref['indices0'])
     for i in range(len(ref['indices0'])):
         msg = compare_matches(out['indices0'][i].cpu().numpy(), out['mscores0'][i].cpu().numpy(), ref['indices0'][i].numpy(),
-                        ref['mscores0'][i].numpy(), 0.2, 1e-4, f'{case} [{i}]', low_score_flips=3)
+                        ref['mscores0'][i].numpy(), 0.2, 1e-4, f'{case} [{i}]', low_score_flips=4)
         if 'flips 0)' not in msg:
             print('SOAK-NOTE', msg)
