@@ -28,6 +28,7 @@ SYMBOLS = [
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
     'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear',
     'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_op_linear_planes', 'imp_trust_descriptor_planes', 'imp_time_layer_gemm', 'imp_estimate_pose',
+    'imp_sp_create', 'imp_sp_destroy', 'imp_sp_set_weight', 'imp_sp_finalize', 'imp_sp_detect', 'imp_sp_describe', 'imp_sp_dense', 'imp_sp_op_conv',
 ]
 
 
@@ -102,6 +103,15 @@ def lib():
     L.imp_trust_descriptor_planes.argtypes = [P, I]
     L.imp_time_layer_gemm.argtypes = [P, I, I, I, I, I, C.POINTER(C.c_float), P]
     L.imp_estimate_pose.argtypes = [P, P, I, P, P, C.c_double, I, C.c_uint, I, P, P, P, P, C.POINTER(C.c_int), P]
+    L.imp_sp_create.argtypes = [C.POINTER(C.c_void_p), I, I]
+    L.imp_sp_destroy.argtypes = [P]
+    L.imp_sp_destroy.restype = None
+    L.imp_sp_set_weight.argtypes = [P, C.c_char_p, P, C.c_int64]
+    L.imp_sp_finalize.argtypes = [P]
+    L.imp_sp_detect.argtypes = [P, P, I, I, I, I, F, I, I, I, P, C.POINTER(C.c_int)]
+    L.imp_sp_describe.argtypes = [P, I, P, P, P, P]
+    L.imp_sp_dense.argtypes = [P, P, P, P, P]
+    L.imp_sp_op_conv.argtypes = [P, I, P, I, I, I, P, I, I, P]
     _lib = L
     return L
 

@@ -716,6 +716,8 @@ __global__ void zero_masked_columns_kernel(float* prob, const uint8_t* mask, int
 }  // namespace
 
 // ================================================================================================
+int imp_fail(int code, const char* msg) { return fail(code, msg); }   // for the other translation units (superpoint.hip)
+
 extern "C" {
 
 const char* imp_last_error(void) { return g_err.c_str(); }

@@ -1,0 +1,930 @@
+// SuperPoint front-end for gfx950: image -> keypoints, scores, descriptors, all on the GPU.
+// Reference: nets/superpoint.py:49-63 (simple_nms), :66-79 (remove_borders, top_k_keypoints), :82-94 (sample_descriptors),
+// :97-137 (layers), :170-232 (forward), :140-168 (extract).
+//
+// Data layout: activations are NHWC float32 in HBM ([B][H][W][C], channels contiguous), so a 3x3 convolution is an implicit
+// GEMM whose K runs over (tap, channel) with 16-channel MFMA k-steps reading contiguous channels of a shifted pixel:
+//
+//   sp_conv1a_kernel     1 -> 64 channels, 9 taps on the VALU (K = 9 is no matrix shape), fused bias + ReLU
+//   sp_conv_kernel       every other convolution: split-half f16x3 MFMA (v_mfma_f32_32x32x16_f16, x = hi + lo, products
+//                        lo.hi + hi.lo + hi.hi, fp32 accumulate - the arithmetic of gemm_f32.hip, fp32-level results).
+//                        Workgroup = 8 x 16 output pixels x 64 output channels, 4 waves as 2 (pixels) x 2 (channels).  The input
+//                        tile with its halo is split once into hi / lo half planes in LDS (64 input channels at a time, 52.5 KB);
+//                        A fragments are ds_read_b128 of 8 consecutive channels of the lane's pixel shifted by the tap; the weights
+//                        are pre-split and pre-ordered on the host into MFMA B-fragment order, so a wave fetches a whole fragment
+//                        as ONE coalesced 1-KB load straight from L2 (every workgroup reads the same few hundred KB), prefetched
+//                        one tap (4 k-steps) ahead - the K loop has no barrier.  Epilogue: bias, ReLU and the 2x2 max-pool
+//                        (tile row m = 4 q + r puts the four pixels of pooling window q into ONE lane's four consecutive
+//                        accumulator registers, so pooling is three v_max per value and only the pooled map is written).
+//   sp_detector_kernel   convPb (256 -> 65, 1x1) + softmax over the 65 bins + drop the dustbin + 8x8 pixel shuffle, fp32 VALU
+//   sp_nms_kernel        the whole simple_nms chain (5 max-pools of radius R) for a 32 x 32 tile out of one LDS image with a 5R halo
+//   sp_rowcount / sp_scan / sp_compact   ordered compaction = torch.nonzero order (row major) with the border filter folded in
+//   sp_topk_kernel       top_k_keypoints: radix select (only above 16384 candidates) + bitonic sort of 64-bit keys in LDS
+//   sp_sample_kernel     sample_descriptors: one wave per keypoint, bilinear taps of the L2-normalised dense map, re-normalised
+//
+// LDS bank check for the A-fragment reads (cdna_hip_programming.md section 2: ds_read_b128 is served in the lane groups
+// {0-3,12-15,20-27} / {4-11,16-19,28-31} (+32)): lane l of a fragment reads pixel (x = 2 (l >> 2) + (l & 1), y = (l >> 1) & 1);
+// with 9 sixteen-byte slots per pixel and a row pitch = 8 slots (mod 16) each group's 16 addresses fall in 16 distinct slots.
+#include "../../include/imp_hip.h"
+#include "imp_kernels.h"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+int imp_fail(int code, const char* msg);   // context.hip: sets imp_last_error()
+
+namespace {
+
+constexpr int TH = 8, TW = 16;             // output pixels of one workgroup tile (before pooling)
+constexpr int PSLOT = 9;                   // 16-byte slots per pixel in an LDS plane: 64 halves + 8 halves of padding
+
+template <int TAPS>
+struct Geo {
+    static constexpr int HALO = TAPS == 9 ? 1 : 0;
+    static constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+    static constexpr int ROW_SLOTS = ((LW * PSLOT + 7) / 16) * 16 + 8;   // >= LW * PSLOT and = 8 (mod 16)
+    static constexpr int PLANE = LH * ROW_SLOTS * 16;                    // bytes of one half plane
+    static constexpr int LDS = 2 * PLANE;
+};
+
+struct SpConvParams {
+    const float* in;      // NHWC [B][H][W][in_ld], channels in_c0 .. in_c0 + cin
+    int in_ld, in_c0, cin;
+    int B, H, W;          // spatial size of the input = of the convolution output before pooling
+    const u32x4* wf;      // [cout / 32][ksteps][hi | lo][64 lanes] fragments, kstep = (chunk * TAPS + tap) * 4 + cc
+    const float* bias;
+    int cout;             // multiple of 64
+    float* out;           // NHWC [B][Ho][Wo][out_ld]
+    int out_ld;
+    int relu;
+    int tiles_x, tiles_y;
+};
+
+// bijective XCD-aware remap of a linear block id (hardware places block b on XCD b % 8): each XCD gets a contiguous chunk of
+// the logical order, in which the channel tiles of one pixel tile and neighbouring pixel tiles (shared halo) are adjacent
+__device__ __forceinline__ int xcd_remap(int lin, int total) {
+    const int q = total / 8, r = total % 8;
+    const int xcd = lin % 8, idx = lin / 8;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+template <int TAPS, int POOL>
+__global__ __launch_bounds__(256) void sp_conv_kernel(const SpConvParams p, int total) {
+    using G = Geo<TAPS>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5;
+    int z = xcd_remap(blockIdx.x, total);
+    const int nt = p.cout >> 6;
+    const int ntile = z % nt; z /= nt;
+    const int tx = z % p.tiles_x; z /= p.tiles_x;
+    const int ty = z % p.tiles_y;
+    const int b = z / p.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int H = p.H, W = p.W;
+
+    // the lane's A rows: fragment i covers tile rows m = 64 wm + 32 i + (lane & 31), m = 4 q + r, q = pooling window (4 x 8 per tile)
+    int aoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = 64 * wm + 32 * i + (lane & 31);
+        const int q = m >> 2, r = m & 3;
+        const int py = 2 * (q >> 3) + (r >> 1), px = 2 * (q & 7) + (r & 1);
+        aoff[i] = (py * G::ROW_SLOTS + px * PSLOT) * 16 + half * 16;
+    }
+    const int nchunk = p.cin >> 6;
+    const int ksteps = nchunk * TAPS * 4;
+    const u32x4* wp = p.wf + (size_t)(ntile * 2 + wn) * ksteps * 128 + lane;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    u32x4 bh[4], bl[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { bh[c] = wp[c * 128]; bl[c] = wp[c * 128 + 64]; }
+
+    // staging geometry: 16 threads per pixel (one float4 = 4 channels each), 16 pixels per pass
+    constexpr int NPIX = G::LH * G::LW;
+    constexpr int NPASS = (NPIX + 15) / 16;
+    const int sp_pix = tid >> 4, sp_c = (tid & 15) * 4;
+
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+        if (chunk > 0) __syncthreads();                    // every wave has read the previous chunk
+        {
+            const float* src = p.in + p.in_c0 + chunk * 64 + sp_c;
+            f32x4 v[NPASS];
+#pragma unroll
+            for (int s = 0; s < NPASS; ++s) {
+                const int pix = s * 16 + sp_pix;
+                const int ly = pix / G::LW, lx = pix - ly * G::LW;
+                const int gy = y0 - G::HALO + ly, gx = x0 - G::HALO + lx;
+                const bool ok = pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                v[s] = f32x4{0.f, 0.f, 0.f, 0.f};                                   // zero padding of the convolution
+                if (ok) v[s] = *reinterpret_cast<const f32x4*>(src + ((size_t)(b * H + gy) * W + gx) * p.in_ld);
+            }
+#pragma unroll
+            for (int s = 0; s < NPASS; ++s) {
+                const int pix = s * 16 + sp_pix;
+                if (pix < NPIX) {
+                    const int ly = pix / G::LW, lx = pix - ly * G::LW;
+                    u32x2 hi, lo;
+                    unsigned a, c;
+                    imp_split2(v[s][0], v[s][1], a, c); hi[0] = a; lo[0] = c;
+                    imp_split2(v[s][2], v[s][3], a, c); hi[1] = a; lo[1] = c;
+                    unsigned char* dst = sp_smem + (ly * G::ROW_SLOTS + lx * PSLOT) * 16 + sp_c * 2;
+                    *reinterpret_cast<u32x2*>(dst) = hi;
+                    *reinterpret_cast<u32x2*>(dst + G::PLANE) = lo;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const bool last = chunk == nchunk - 1 && tap == TAPS - 1;
+            u32x4 nh[4], nl[4];
+            const u32x4* wnext = wp + (last ? 0 : 512);      // (last tap: harmless re-load)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { nh[c] = wnext[c * 128]; nl[c] = wnext[c * 128 + 64]; }
+            const int toff = TAPS == 9 ? ((tap / 3) * G::ROW_SLOTS + (tap % 3) * PSLOT) * 16 : 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f16x8 ah[2], al[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ah[i] = *reinterpret_cast<const f16x8*>(sp_smem + aoff[i] + toff + c * 32);
+                    al[i] = *reinterpret_cast<const f16x8*>(sp_smem + G::PLANE + aoff[i] + toff + c * 32);
+                }
+                const f16x8 wh = __builtin_bit_cast(f16x8, bh[c]), wl = __builtin_bit_cast(f16x8, bl[c]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh, acc[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { bh[c] = nh[c]; bl[c] = nl[c]; }
+            wp = wnext;
+        }
+    }
+
+    // epilogue: accumulator register r of fragment i holds tile row 64 wm + 32 i + 4 half + (r & 3) + 8 (r >> 2), column lane & 31
+    const int ch = ntile * 64 + wn * 32 + (lane & 31);
+    const float bv = p.bias[ch];
+    const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int q = 16 * wm + 8 * i + half + 2 * g;
+            const int qy = q >> 3, qx = q & 7;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[i][4 * g + r] + bv;
+                if (p.relu) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (POOL) {
+                const int py = y0 / 2 + qy, px = x0 / 2 + qx;
+                if (py < Ho && px < Wo) p.out[((size_t)(b * Ho + py) * Wo + px) * p.out_ld + ch] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int y = y0 + 2 * qy + (r >> 1), x = x0 + 2 * qx + (r & 1);
+                    if (y < H && x < W) p.out[((size_t)(b * H + y) * W + x) * p.out_ld + ch] = v[r];
+                }
+            }
+        }
+}
+
+// conv1a (nets/superpoint.py:120,142): one input channel, 64 output channels; 16 threads per pixel, 4 channels each
+__global__ __launch_bounds__(256) void sp_conv1a_kernel(const float* __restrict__ img, const float* __restrict__ w /*[9][64]*/,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int B, int H, int W) {
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t pix = gid >> 4;
+    const int c = (int)(gid & 15) * 4;
+    if (pix >= (size_t)B * H * W) return;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const float* im = img + (pix - (size_t)y * W - x);       // start of this image
+    f32x4 a = *reinterpret_cast<const f32x4*>(bias + c);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? im[(size_t)yy * W + xx] : 0.f;
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + t * 64 + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = fmaf(v, wv[e], a[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.f);
+    *reinterpret_cast<f32x4*>(out + pix * 64 + c) = a;
+}
+
+// detector head tail (nets/superpoint.py:193-198): convPb (1x1, 256 -> 65) + softmax(65) + drop the dustbin + 8x8 pixel shuffle
+constexpr int DPX = 8;
+__global__ __launch_bounds__(256) void sp_detector_kernel(const float* __restrict__ in, int in_ld, const float* __restrict__ wt /*[256][65]*/,
+                                                          const float* __restrict__ bias, float* __restrict__ scores, int npix, int h, int w) {
+    __shared__ __attribute__((aligned(16))) float xs[DPX][256];
+    __shared__ float lg[DPX][68];
+    __shared__ float red[DPX][2];
+    const int tid = threadIdx.x;
+    const int p0 = blockIdx.x * DPX;
+    for (int i = tid; i < DPX * 64; i += 256) {
+        const int px = i >> 6, k4 = (i & 63) * 4;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p0 + px < npix) v = *reinterpret_cast<const f32x4*>(in + (size_t)(p0 + px) * in_ld + k4);
+        *reinterpret_cast<f32x4*>(&xs[px][k4]) = v;
+    }
+    __syncthreads();
+    for (int o = tid; o < DPX * 65; o += 256) {
+        const int px = o / 65, c = o - px * 65;
+        float s = bias[c];
+        for (int k = 0; k < 256; ++k) s = fmaf(xs[px][k], wt[k * 65 + c], s);
+        lg[px][c] = s;
+    }
+    __syncthreads();
+    if (tid < DPX) {
+        float mx = lg[tid][0];
+        for (int c = 1; c < 65; ++c) mx = fmaxf(mx, lg[tid][c]);
+        float sum = 0.f;
+        for (int c = 0; c < 65; ++c) sum += expf(lg[tid][c] - mx);
+        red[tid][0] = mx;
+        red[tid][1] = sum;
+    }
+    __syncthreads();
+    for (int o = tid; o < DPX * 64; o += 256) {
+        const int px = o >> 6, c = o & 63;
+        const int pi = p0 + px;
+        if (pi >= npix) continue;
+        const int xx = pi % w, yy = (pi / w) % h, b = pi / (w * h);
+        const float v = expf(lg[px][c] - red[px][0]) / red[px][1];
+        scores[((size_t)b * h * 8 + yy * 8 + (c >> 3)) * (size_t)(w * 8) + xx * 8 + (c & 7)] = v;
+    }
+}
+
+// simple_nms (nets/superpoint.py:49-63) for one 32 x 32 tile: every max-pool of the chain is evaluated on the whole LDS image
+// (tile + 5R halo, -inf outside the image = max_pool2d's padding); values within k R of the image edge are wrong after k pools,
+// the tile itself depends on 5 pools.
+// tile edge: 32 (16 above radius 6, where 32 + 10 R squared no longer fits the LDS)
+__device__ __forceinline__ void sp_pool(const float* in, float* tmp, float* out, int E, int R, int tid) {
+    const int n = E * E;
+    for (int i = tid; i < n; i += 256) {
+        const int y = i / E, x = i - y * E;
+        float m = -INFINITY;
+        const int lo = max(x - R, 0), hi = min(x + R, E - 1);
+        for (int xx = lo; xx <= hi; ++xx) m = fmaxf(m, in[y * E + xx]);
+        tmp[i] = m;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int y = i / E, x = i - y * E;
+        float m = -INFINITY;
+        const int lo = max(y - R, 0), hi = min(y + R, E - 1);
+        for (int yy = lo; yy <= hi; ++yy) m = fmaxf(m, tmp[yy * E + x]);
+        out[i] = m;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void sp_nms_kernel(const float* __restrict__ sin, float* __restrict__ sout, int Hs, int Ws, int R, int NT, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    const int E = NT + 10 * R, n = E * E;
+    float* s = reinterpret_cast<float*>(sp_smem);
+    float* a = s + n;
+    float* t = a + n;
+    float* P = t + n;
+    unsigned char* msk = reinterpret_cast<unsigned char*>(P + n);
+    const int tid = threadIdx.x;
+    int z = blockIdx.x;
+    const int tx = z % tiles_x; z /= tiles_x;
+    const int ty = z % tiles_y;
+    const int b = z / tiles_y;
+    const int y0 = ty * NT - 5 * R, x0 = tx * NT - 5 * R;
+    const float* src = sin + (size_t)b * Hs * Ws;
+    for (int i = tid; i < n; i += 256) {
+        const int y = i / E, x = i - y * E;
+        const int gy = y0 + y, gx = x0 + x;
+        s[i] = (gy >= 0 && gy < Hs && gx >= 0 && gx < Ws) ? src[(size_t)gy * Ws + gx] : -INFINITY;
+    }
+    __syncthreads();
+    sp_pool(s, t, P, E, R, tid);
+    for (int i = tid; i < n; i += 256) msk[i] = (s[i] > -INFINITY && s[i] == P[i]) ? 1 : 0;
+    __syncthreads();
+    for (int it = 0; it < 2; ++it) {
+        for (int i = tid; i < n; i += 256) a[i] = msk[i] ? 1.f : 0.f;
+        __syncthreads();
+        sp_pool(a, t, P, E, R, tid);
+        for (int i = tid; i < n; i += 256) {
+            const bool supp = P[i] > 0.f;
+            a[i] = supp ? (s[i] > -INFINITY ? 0.f : -INFINITY) : s[i];
+            msk[i] = (unsigned char)(msk[i] | (supp ? 2 : 0));           // bit 1: suppressed in this round
+        }
+        __syncthreads();
+        sp_pool(a, t, P, E, R, tid);
+        for (int i = tid; i < n; i += 256) {
+            const bool supp = (msk[i] & 2) != 0;
+            const bool nw = s[i] > -INFINITY && a[i] == P[i];
+            msk[i] = (unsigned char)((msk[i] & 1) | ((nw && !supp) ? 1 : 0));
+        }
+        __syncthreads();
+    }
+    float* dst = sout + (size_t)b * Hs * Ws;
+    for (int i = tid; i < NT * NT; i += 256) {
+        const int y = i / NT, x = i - y * NT;
+        const int gy = ty * NT + y, gx = tx * NT + x;
+        if (gy < Hs && gx < Ws) {
+            const int j = (y + 5 * R) * E + x + 5 * R;
+            dst[(size_t)gy * Ws + gx] = msk[j] ? s[j] : 0.f;
+        }
+    }
+}
+
+// keypoint extraction (nets/superpoint.py:203-211): torch.nonzero(s > threshold) order = row major, border filter of :66-71
+__device__ __forceinline__ bool sp_keep(float v, int x, int y, int Hs, int Ws, float thr, int border) {
+    return v > thr && y >= border && y < Hs - border && x >= border && x < Ws - border;
+}
+
+__global__ __launch_bounds__(64) void sp_rowcount_kernel(const float* __restrict__ nms, int Hs, int Ws, float thr, int border, int* __restrict__ rowcount) {
+    const int y = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const float* row = nms + ((size_t)b * Hs + y) * Ws;
+    int cnt = 0;
+    for (int x0 = 0; x0 < Ws; x0 += 64) {
+        const int x = x0 + lane;
+        const bool k = x < Ws && sp_keep(row[x], x, y, Hs, Ws, thr, border);
+        cnt += __popcll(__ballot(k));
+    }
+    if (lane == 0) rowcount[b * Hs + y] = cnt;
+}
+
+__global__ __launch_bounds__(1024) void sp_scan_kernel(const int* __restrict__ rowcount, int Hs, int* __restrict__ rowoff, int* __restrict__ count) {
+    __shared__ int part[1024];
+    __shared__ int carry;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < Hs; base += 1024) {
+        const int i = base + tid;
+        const int v = i < Hs ? rowcount[b * Hs + i] : 0;
+        part[tid] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int add = tid >= d ? part[tid - d] : 0;
+            __syncthreads();
+            part[tid] += add;
+            __syncthreads();
+        }
+        if (i < Hs) rowoff[b * Hs + i] = carry + part[tid] - v;
+        __syncthreads();
+        if (tid == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (tid == 0) count[b] = carry;
+}
+
+__global__ __launch_bounds__(64) void sp_compact_kernel(const float* __restrict__ nms, int Hs, int Ws, float thr, int border,
+                                                        const int* __restrict__ rowoff, float* __restrict__ kp, float* __restrict__ sc, size_t cap) {
+    const int y = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const float* row = nms + ((size_t)b * Hs + y) * Ws;
+    int off = rowoff[b * Hs + y];
+    float* kpb = kp + (size_t)b * cap * 2;
+    float* scb = sc + (size_t)b * cap;
+    for (int x0 = 0; x0 < Ws; x0 += 64) {
+        const int x = x0 + lane;
+        const float v = x < Ws ? row[x] : 0.f;
+        const bool k = x < Ws && sp_keep(v, x, y, Hs, Ws, thr, border);
+        const unsigned long long bal = __ballot(k);
+        if (k) {
+            const int r = off + __popcll(bal & ((1ull << lane) - 1ull));
+            kpb[2 * (size_t)r] = (float)x;                              // (x, y): torch.flip of (row, col), nets/superpoint.py:220
+            kpb[2 * (size_t)r + 1] = (float)y;
+            scb[r] = v;
+        }
+        off += __popcll(bal);
+    }
+}
+
+// top_k_keypoints (nets/superpoint.py:74-79): k >= n keeps everything in nonzero order; otherwise the k best scores, descending
+// (torch.topk), equal scores in index order.  Keys = score bits (scores are positive floats: the bit pattern is monotone) : ~index.
+constexpr int TOPK_CAP = 16384;
+__global__ __launch_bounds__(1024) void sp_topk_kernel(const float* __restrict__ kp, const float* __restrict__ sc, const int* __restrict__ count,
+                                                       size_t cap, int k, float* __restrict__ kp_out, float* __restrict__ sc_out,
+                                                       int* __restrict__ count_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(sp_smem);
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sel_prefix, sel_remaining, sel_count, eq_taken;
+    __shared__ int scan[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = count[b];
+    const float* kpb = kp + (size_t)b * cap * 2;
+    const float* scb = sc + (size_t)b * cap;
+    float* kpo = kp_out + (size_t)b * cap * 2;
+    float* sco = sc_out + (size_t)b * cap;
+    if (k < 0 || k >= n) {
+        for (int i = tid; i < n; i += 1024) {
+            kpo[2 * (size_t)i] = kpb[2 * (size_t)i];
+            kpo[2 * (size_t)i + 1] = kpb[2 * (size_t)i + 1];
+            sco[i] = scb[i];
+        }
+        if (tid == 0) count_out[b] = n;
+        return;
+    }
+    int m;      // number of keys in LDS
+    if (n <= TOPK_CAP) {
+        for (int i = tid; i < n; i += 1024) keys[i] = ((unsigned long long)__float_as_uint(scb[i]) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+        m = n;
+    } else {
+        // radix select of the k-th largest score bit pattern T, 8 bits per pass from the top
+        if (tid == 0) { sel_prefix = 0; sel_remaining = (unsigned)k; }
+        __syncthreads();
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const unsigned prefix = sel_prefix;
+            const unsigned himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+            for (int i = tid; i < n; i += 1024) {
+                const unsigned u = __float_as_uint(scb[i]);
+                if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned rem = sel_remaining;
+                int d = 255;
+                for (; d > 0; --d) {
+                    if (hist[d] >= rem) break;
+                    rem -= hist[d];
+                }
+                sel_prefix = prefix | ((unsigned)d << shift);
+                sel_remaining = rem;                          // how many of the elements with this prefix are still needed
+            }
+            __syncthreads();
+        }
+        const unsigned T = sel_prefix;
+        const unsigned need_eq = sel_remaining;               // elements == T to take, lowest index first
+        if (tid == 0) { sel_count = 0; eq_taken = 0; }
+        __syncthreads();
+        for (int base = 0; base < n; base += 1024) {
+            const int i = base + tid;
+            const unsigned u = i < n ? __float_as_uint(scb[i]) : 0u;
+            const bool gt = i < n && u > T, eq = i < n && u == T;
+            scan[tid] = eq ? 1 : 0;
+            __syncthreads();
+            for (int d = 1; d < 1024; d <<= 1) {
+                const int add = tid >= d ? scan[tid - d] : 0;
+                __syncthreads();
+                scan[tid] += add;
+                __syncthreads();
+            }
+            const unsigned eq_rank = eq_taken + (unsigned)scan[tid] - 1u;     // rank of this element among the == T ones
+            if (gt || (eq && eq_rank < need_eq)) {
+                const unsigned slot = atomicAdd(&sel_count, 1u);
+                if (slot < (unsigned)TOPK_CAP) keys[slot] = ((unsigned long long)u << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+            }
+            __syncthreads();
+            if (tid == 1023) eq_taken += (unsigned)scan[1023];
+            __syncthreads();
+        }
+        m = min((int)sel_count, TOPK_CAP);                    // == k (the host rejects k > TOPK_CAP)
+    }
+    int m2 = 1;
+    while (m2 < m) m2 <<= 1;
+    for (int i = m + tid; i < m2; i += 1024) keys[i] = 0ull;
+    __syncthreads();
+    for (int size = 2; size <= m2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (m2 >> 1); t += 1024) {
+                const int lo = 2 * t - (t & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const unsigned long long x = keys[lo], y = keys[hi];
+                if (desc ? x < y : x > y) { keys[lo] = y; keys[hi] = x; }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < k; i += 1024) {
+        const unsigned long long key = keys[i];
+        const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+        kpo[2 * (size_t)i] = kpb[2 * (size_t)idx];
+        kpo[2 * (size_t)i + 1] = kpb[2 * (size_t)idx + 1];
+        sco[i] = __uint_as_float((unsigned)(key >> 32));
+    }
+    if (tid == 0) count_out[b] = k;
+}
+
+// sample_descriptors (nets/superpoint.py:82-94): one wave per keypoint, lane = 4 channels (D <= 256, D % 4 == 0).  dmap is the raw
+// convDb output NHWC [h][w][D]; F.normalize(p=2, dim=1) of the dense map (:225, eps 1e-12) is applied to the four taps on the fly,
+// grid_sample is bilinear with zero padding and the align_corners the caller resolved, the result is normalised again (:92-93).
+__device__ __forceinline__ float sp_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void sp_sample_kernel(const float* __restrict__ kp, int n, const float* __restrict__ dmap, int h, int w, int D,
+                                                        int align_corners, float* __restrict__ out /*[D][n]*/) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const float s = 8.f;
+    float gx = kp[2 * (size_t)i] - s / 2 + 0.5f, gy = kp[2 * (size_t)i + 1] - s / 2 + 0.5f;
+    gx = gx / (w * s - s / 2 - 0.5f);
+    gy = gy / (h * s - s / 2 - 0.5f);
+    gx = gx * 2 - 1;
+    gy = gy * 2 - 1;
+    float ix, iy;
+    if (align_corners) {
+        ix = ((gx + 1) / 2) * (w - 1);
+        iy = ((gy + 1) / 2) * (h - 1);
+    } else {
+        ix = ((gx + 1) * w - 1) / 2;
+        iy = ((gy + 1) * h - 1) / 2;
+    }
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx1 = ix - fx, wy1 = iy - fy, wx0 = (fx + 1.f) - ix, wy0 = (fy + 1.f) - iy;
+    const int c = lane * 4;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+        const float wgt = ((t & 1) ? wx1 : wx0) * ((t >> 1) ? wy1 : wy0);
+        if (xx < 0 || xx >= w || yy < 0 || yy >= h) continue;             // zero padding (uniform per wave)
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < D) v = *reinterpret_cast<const f32x4*>(dmap + ((size_t)yy * w + xx) * D + c);
+        const float nrm = sqrtf(sp_wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]));
+        const float inv = 1.f / fmaxf(nrm, 1e-12f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] += (v[e] * inv) * wgt;
+    }
+    const float nrm = sqrtf(sp_wave_sum(acc[0] * acc[0] + acc[1] * acc[1] + acc[2] * acc[2] + acc[3] * acc[3]));
+    const float inv = 1.f / fmaxf(nrm, 1e-12f);
+    if (c < D)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[(size_t)(c + e) * n + i] = acc[e] * inv;
+}
+
+// dense descriptors of extract() (nets/superpoint.py:163-166): NHWC raw -> NCHW, L2-normalised over channels; one wave per pixel
+__global__ __launch_bounds__(256) void sp_dense_desc_kernel(const float* __restrict__ dmap, int npix_per_image, int total, int D, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= total) return;
+    const int c = lane * 4;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < D) v = *reinterpret_cast<const f32x4*>(dmap + (size_t)i * D + c);
+    const float nrm = sqrtf(sp_wave_sum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]));
+    const float inv = 1.f / fmaxf(nrm, 1e-12f);
+    const int b = i / npix_per_image, pi = i - b * npix_per_image;
+    if (c < D)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[((size_t)b * D + c + e) * npix_per_image + pi] = v[e] * inv;
+}
+
+// ------------------------------------------------------------------------------------------------------------ host side
+struct ConvW {
+    u32x4* wf = nullptr;
+    float* bias = nullptr;
+    int cin = 0, cout = 0, taps = 0;
+};
+
+struct HostT { std::vector<float> data; };
+
+}  // namespace
+
+struct imp_sp_ctx {
+    int device = 0, ddim = 256;
+    bool finalized = false;
+    std::map<std::string, HostT> raw;
+    float* w1a = nullptr;      // [9][64]
+    float* b1a = nullptr;
+    ConvW c1b, c2a, c2b, c3a, c3b, c4a, c4b, heads, db;
+    float* wpb = nullptr;      // [256][65]
+    float* bpb = nullptr;
+    // workspace of the last detect call
+    int B = 0, H = 0, W = 0, h = 0, w = 0;
+    size_t capA = 0, capB = 0, cap_small = 0, cap_map = 0, cap_rows = 0, cap_b = 0;
+    float *bufA = nullptr, *bufB = nullptr, *dmap = nullptr, *scores = nullptr, *nms = nullptr;
+    float *kp0 = nullptr, *sc0 = nullptr, *kp1 = nullptr, *sc1 = nullptr;
+    int *rowcount = nullptr, *rowoff = nullptr, *count0 = nullptr, *count1 = nullptr;
+    std::vector<int> counts;
+    int align_corners = 1;
+    bool detected = false;
+};
+
+namespace {
+
+#define SP_TRY(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return imp_fail(IMP_E_HIP, (std::string(#expr) + ": " + hipGetErrorString(_e)).c_str()); \
+    } while (0)
+
+// conv weight [cout][cin][k][k] (+ optional second tensor stacked along cout) -> split-half MFMA B fragments
+int pack_conv(imp_sp_ctx* c, const std::vector<std::string>& names, int cin, int taps, ConvW* out) {
+    int cout = 0;
+    std::vector<const HostT*> ws, bs;
+    for (const std::string& nm : names) {
+        auto iw = c->raw.find(nm + ".weight"), ib = c->raw.find(nm + ".bias");
+        if (iw == c->raw.end() || ib == c->raw.end()) return imp_fail(IMP_E_KEY, ("missing state_dict key: " + nm + ".weight / .bias").c_str());
+        const size_t co = ib->second.data.size();
+        if (iw->second.data.size() != co * cin * taps) return imp_fail(IMP_E_KEY, ("state_dict tensor " + nm + ".weight has an unexpected size").c_str());
+        ws.push_back(&iw->second);
+        bs.push_back(&ib->second);
+        cout += (int)co;
+    }
+    if (cout % 64 || cin % 64) return imp_fail(IMP_E_ARG, "convolution channels must be multiples of 64");
+    std::vector<float> Wall((size_t)cout * cin * taps), ball(cout);
+    {
+        size_t o = 0, ob = 0;
+        for (size_t i = 0; i < ws.size(); ++i) {
+            memcpy(Wall.data() + o, ws[i]->data.data(), ws[i]->data.size() * sizeof(float));
+            o += ws[i]->data.size();
+            memcpy(ball.data() + ob, bs[i]->data.data(), bs[i]->data.size() * sizeof(float));
+            ob += bs[i]->data.size();
+        }
+    }
+    const int nchunk = cin / 64, ksteps = nchunk * taps * 4;
+    std::vector<_Float16> frag((size_t)(cout / 32) * ksteps * 2 * 64 * 8);
+    for (int nt = 0; nt < cout / 32; ++nt)
+        for (int ks = 0; ks < ksteps; ++ks) {
+            const int chunk = ks / (taps * 4), tap = (ks / 4) % taps, cc = ks % 4;
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int n = nt * 32 + (lane & 31);
+                    const int ch = chunk * 64 + cc * 16 + 8 * (lane >> 5) + e;
+                    const float v = Wall[((size_t)n * cin + ch) * taps + tap];
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    const size_t base = ((size_t)(nt * ksteps + ks) * 2) * 64 * 8;
+                    frag[base + (size_t)lane * 8 + e] = hi;
+                    frag[base + 64 * 8 + (size_t)lane * 8 + e] = lo;
+                }
+        }
+    SP_TRY(hipMalloc(&out->wf, frag.size() * sizeof(_Float16)));
+    SP_TRY(hipMemcpy(out->wf, frag.data(), frag.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    SP_TRY(hipMalloc(&out->bias, ball.size() * sizeof(float)));
+    SP_TRY(hipMemcpy(out->bias, ball.data(), ball.size() * sizeof(float), hipMemcpyHostToDevice));
+    out->cin = cin; out->cout = cout; out->taps = taps;
+    return IMP_OK;
+}
+
+void free_conv(ConvW& w) {
+    if (w.wf) (void)hipFree(w.wf);
+    if (w.bias) (void)hipFree(w.bias);
+    w = ConvW();
+}
+
+template <int TAPS, int POOL>
+int launch_conv_t(const SpConvParams& p, hipStream_t st) {
+    const int total = p.B * p.tiles_x * p.tiles_y * (p.cout / 64);
+    const void* fn = reinterpret_cast<const void*>(&sp_conv_kernel<TAPS, POOL>);
+    SP_TRY(imp_grant_dynamic_lds(fn, Geo<TAPS>::LDS));
+    hipLaunchKernelGGL((sp_conv_kernel<TAPS, POOL>), dim3(total), dim3(256), Geo<TAPS>::LDS, st, p, total);
+    SP_TRY(hipGetLastError());
+    return IMP_OK;
+}
+
+int launch_conv(const ConvW& w, const float* in, int in_ld, int in_c0, int B, int H, int W, float* out, int out_ld, int relu, int pool, hipStream_t st) {
+    SpConvParams p;
+    p.in = in; p.in_ld = in_ld; p.in_c0 = in_c0; p.cin = w.cin;
+    p.B = B; p.H = H; p.W = W;
+    p.wf = w.wf; p.bias = w.bias; p.cout = w.cout;
+    p.out = out; p.out_ld = out_ld; p.relu = relu;
+    p.tiles_x = (W + TW - 1) / TW; p.tiles_y = (H + TH - 1) / TH;
+    if (w.taps == 9) return pool ? launch_conv_t<9, 1>(p, st) : launch_conv_t<9, 0>(p, st);
+    return launch_conv_t<1, 0>(p, st);
+}
+
+void free_ws(imp_sp_ctx* c) {
+    for (void* p : {(void*)c->bufA, (void*)c->bufB, (void*)c->dmap, (void*)c->scores, (void*)c->nms, (void*)c->kp0, (void*)c->sc0, (void*)c->kp1,
+                    (void*)c->sc1, (void*)c->rowcount, (void*)c->rowoff, (void*)c->count0, (void*)c->count1})
+        if (p) (void)hipFree(p);
+    c->bufA = c->bufB = c->dmap = c->scores = c->nms = c->kp0 = c->sc0 = c->kp1 = c->sc1 = nullptr;
+    c->rowcount = c->rowoff = c->count0 = c->count1 = nullptr;
+    c->capA = c->capB = c->cap_small = c->cap_map = c->cap_rows = c->cap_b = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int imp_sp_create(imp_sp_ctx** out, int device, int descriptor_dim) {
+    if (!out) return imp_fail(IMP_E_ARG, "imp_sp_create: null output");
+    if (descriptor_dim < 64 || descriptor_dim > 256 || descriptor_dim % 64) return imp_fail(IMP_E_ARG, "descriptor_dim must be 64, 128, 192 or 256");
+    int ndev = 0;
+    SP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return imp_fail(IMP_E_ARG, "imp_sp_create: no such device");
+    imp_sp_ctx* c = new imp_sp_ctx();
+    c->device = device;
+    c->ddim = descriptor_dim;
+    *out = c;
+    return IMP_OK;
+}
+
+void imp_sp_destroy(imp_sp_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    free_ws(c);
+    for (ConvW* w : {&c->c1b, &c->c2a, &c->c2b, &c->c3a, &c->c3b, &c->c4a, &c->c4b, &c->heads, &c->db}) free_conv(*w);
+    for (void* p : {(void*)c->w1a, (void*)c->b1a, (void*)c->wpb, (void*)c->bpb})
+        if (p) (void)hipFree(p);
+    delete c;
+}
+
+int imp_sp_set_weight(imp_sp_ctx* c, const char* name, const float* data, int64_t count) {
+    if (!c || !name || !data || count <= 0) return imp_fail(IMP_E_ARG, "imp_sp_set_weight: bad argument");
+    HostT t;
+    t.data.assign(data, data + count);
+    c->raw[name] = std::move(t);
+    c->finalized = false;
+    return IMP_OK;
+}
+
+int imp_sp_finalize(imp_sp_ctx* c) {
+    if (!c) return imp_fail(IMP_E_ARG, "imp_sp_finalize: null context");
+    SP_TRY(hipSetDevice(c->device));
+    SP_TRY(hipDeviceSynchronize());
+    for (ConvW* w : {&c->c1b, &c->c2a, &c->c2b, &c->c3a, &c->c3b, &c->c4a, &c->c4b, &c->heads, &c->db}) free_conv(*w);
+    for (float** p : {&c->w1a, &c->b1a, &c->wpb, &c->bpb})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    int rc;
+    if ((rc = pack_conv(c, {"conv1b"}, 64, 9, &c->c1b)) || (rc = pack_conv(c, {"conv2a"}, 64, 9, &c->c2a)) ||
+        (rc = pack_conv(c, {"conv2b"}, 64, 9, &c->c2b)) || (rc = pack_conv(c, {"conv3a"}, 64, 9, &c->c3a)) ||
+        (rc = pack_conv(c, {"conv3b"}, 128, 9, &c->c3b)) || (rc = pack_conv(c, {"conv4a"}, 128, 9, &c->c4a)) ||
+        (rc = pack_conv(c, {"conv4b"}, 128, 9, &c->c4b)) || (rc = pack_conv(c, {"convPa", "convDa"}, 128, 9, &c->heads)) ||
+        (rc = pack_conv(c, {"convDb"}, 256, 1, &c->db)))
+        return rc;
+    if (c->c1b.cout != 64 || c->c2a.cout != 64 || c->c2b.cout != 64 || c->c3a.cout != 128 || c->c3b.cout != 128 || c->c4a.cout != 128 ||
+        c->c4b.cout != 128 || c->heads.cout != 512 || c->db.cout != c->ddim)
+        return imp_fail(IMP_E_KEY, "state_dict shapes do not match nets/superpoint.py:118-137");
+    auto w1 = c->raw.find("conv1a.weight"), b1 = c->raw.find("conv1a.bias"), wp = c->raw.find("convPb.weight"), bp = c->raw.find("convPb.bias");
+    if (w1 == c->raw.end() || b1 == c->raw.end() || wp == c->raw.end() || bp == c->raw.end()) return imp_fail(IMP_E_KEY, "missing conv1a / convPb tensors");
+    if (w1->second.data.size() != 64 * 9 || b1->second.data.size() != 64 || wp->second.data.size() != 65 * 256 || bp->second.data.size() != 65)
+        return imp_fail(IMP_E_KEY, "conv1a / convPb tensors have unexpected sizes");
+    std::vector<float> w1t(9 * 64), wpt(256 * 65);
+    for (int o = 0; o < 64; ++o)
+        for (int t = 0; t < 9; ++t) w1t[t * 64 + o] = w1->second.data[o * 9 + t];
+    for (int o = 0; o < 65; ++o)
+        for (int k = 0; k < 256; ++k) wpt[k * 65 + o] = wp->second.data[o * 256 + k];
+    SP_TRY(hipMalloc(&c->w1a, w1t.size() * 4));
+    SP_TRY(hipMemcpy(c->w1a, w1t.data(), w1t.size() * 4, hipMemcpyHostToDevice));
+    SP_TRY(hipMalloc(&c->b1a, 64 * 4));
+    SP_TRY(hipMemcpy(c->b1a, b1->second.data.data(), 64 * 4, hipMemcpyHostToDevice));
+    SP_TRY(hipMalloc(&c->wpb, wpt.size() * 4));
+    SP_TRY(hipMemcpy(c->wpb, wpt.data(), wpt.size() * 4, hipMemcpyHostToDevice));
+    SP_TRY(hipMalloc(&c->bpb, 65 * 4));
+    SP_TRY(hipMemcpy(c->bpb, bp->second.data.data(), 65 * 4, hipMemcpyHostToDevice));
+    c->finalized = true;
+    return IMP_OK;
+}
+
+int imp_sp_detect(imp_sp_ctx* c, const float* image, int B, int H, int W, int nms_radius, float keypoint_threshold, int max_keypoints,
+                  int remove_borders, int align_corners, void* stream, int* counts) {
+    if (!c || !image || !counts) return imp_fail(IMP_E_ARG, "imp_sp_detect: null argument");
+    if (!c->finalized) return imp_fail(IMP_E_STATE, "imp_sp_detect: weights not finalised");
+    if (B < 1 || H < 8 || W < 8) return imp_fail(IMP_E_ARG, "imp_sp_detect: image must be at least 8 x 8");
+    if (nms_radius < 0 || nms_radius > 8) return imp_fail(IMP_E_ARG, "imp_sp_detect: nms_radius must be in 0..8");
+    if (max_keypoints == 0 || max_keypoints < -1) return imp_fail(IMP_E_ARG, "\"max_keypoints\" must be positive or \"-1\"");   // nets/superpoint.py:161-163
+    if (max_keypoints > TOPK_CAP) return imp_fail(IMP_E_ARG, "imp_sp_detect: max_keypoints above 16384 is not supported");
+    SP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, h = H4 / 2, w = W4 / 2;
+    const int Hs = h * 8, Ws = w * 8;
+    const size_t needA = (size_t)B * H * W * 64, needB = (size_t)B * H2 * W2 * 64, need_small = (size_t)B * h * w * 512, need_map = (size_t)B * Hs * Ws;
+    if (needA > c->capA || needB > c->capB || need_small > c->cap_small || need_map > c->cap_map || (size_t)B * Hs > c->cap_rows || (size_t)B > c->cap_b) {
+        SP_TRY(hipDeviceSynchronize());
+        free_ws(c);
+        SP_TRY(hipMalloc(&c->bufA, std::max(needA, need_small) * 4));
+        SP_TRY(hipMalloc(&c->bufB, needB * 4));
+        SP_TRY(hipMalloc(&c->dmap, (size_t)B * h * w * 256 * 4));
+        SP_TRY(hipMalloc(&c->scores, need_map * 4));
+        SP_TRY(hipMalloc(&c->nms, need_map * 4));
+        SP_TRY(hipMalloc(&c->kp0, need_map * 8));
+        SP_TRY(hipMalloc(&c->sc0, need_map * 4));
+        SP_TRY(hipMalloc(&c->kp1, need_map * 8));
+        SP_TRY(hipMalloc(&c->sc1, need_map * 4));
+        SP_TRY(hipMalloc(&c->rowcount, (size_t)B * Hs * 4));
+        SP_TRY(hipMalloc(&c->rowoff, (size_t)B * Hs * 4));
+        SP_TRY(hipMalloc(&c->count0, (size_t)B * 4));
+        SP_TRY(hipMalloc(&c->count1, (size_t)B * 4));
+        c->capA = std::max(needA, need_small); c->capB = needB; c->cap_small = need_small; c->cap_map = need_map;
+        c->cap_rows = (size_t)B * Hs; c->cap_b = (size_t)B;
+    }
+    c->detected = false;
+    c->B = B; c->H = H; c->W = W; c->h = h; c->w = w;
+    c->align_corners = align_corners ? 1 : 0;
+    int rc;
+    // encoder (nets/superpoint.py:172-183)
+    {
+        const size_t nthr = (size_t)B * H * W * 16;
+        hipLaunchKernelGGL(sp_conv1a_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, image, c->w1a, c->b1a, c->bufA, B, H, W);
+        SP_TRY(hipGetLastError());
+    }
+    if ((rc = launch_conv(c->c1b, c->bufA, 64, 0, B, H, W, c->bufB, 64, 1, 1, st))) return rc;          // -> [H2][W2][64]
+    if ((rc = launch_conv(c->c2a, c->bufB, 64, 0, B, H2, W2, c->bufA, 64, 1, 0, st))) return rc;
+    if ((rc = launch_conv(c->c2b, c->bufA, 64, 0, B, H2, W2, c->bufB, 64, 1, 1, st))) return rc;        // -> [H4][W4][64]
+    if ((rc = launch_conv(c->c3a, c->bufB, 64, 0, B, H4, W4, c->bufA, 128, 1, 0, st))) return rc;
+    if ((rc = launch_conv(c->c3b, c->bufA, 128, 0, B, H4, W4, c->bufB, 128, 1, 1, st))) return rc;      // -> [h][w][128]
+    if ((rc = launch_conv(c->c4a, c->bufB, 128, 0, B, h, w, c->bufA, 128, 1, 0, st))) return rc;
+    if ((rc = launch_conv(c->c4b, c->bufA, 128, 0, B, h, w, c->bufB, 128, 1, 0, st))) return rc;
+    // both heads' 3x3 convolutions as one launch: channels 0..255 = relu(convPa), 256..511 = relu(convDa)  (:186, :223)
+    if ((rc = launch_conv(c->heads, c->bufB, 128, 0, B, h, w, c->bufA, 512, 1, 0, st))) return rc;
+    if ((rc = launch_conv(c->db, c->bufA, 512, 256, B, h, w, c->dmap, c->ddim, 0, 0, st))) return rc;   // raw convDb (:224)
+    const int npix = B * h * w;
+    hipLaunchKernelGGL(sp_detector_kernel, dim3((npix + DPX - 1) / DPX), dim3(256), 0, st, c->bufA, 512, c->wpb, c->bpb, c->scores, npix, h, w);
+    SP_TRY(hipGetLastError());
+    {
+        const int NT = nms_radius <= 6 ? 32 : 16;
+        const int E = NT + 10 * nms_radius;
+        const size_t lds = (size_t)E * E * (4 * 4 + 1);
+        const int tx = (Ws + NT - 1) / NT, ty = (Hs + NT - 1) / NT;
+        SP_TRY(imp_grant_dynamic_lds(reinterpret_cast<const void*>(&sp_nms_kernel), lds));
+        hipLaunchKernelGGL(sp_nms_kernel, dim3(tx * ty * B), dim3(256), lds, st, c->scores, c->nms, Hs, Ws, nms_radius, NT, tx, ty);
+        SP_TRY(hipGetLastError());
+    }
+    const size_t cap = (size_t)Hs * Ws;
+    hipLaunchKernelGGL(sp_rowcount_kernel, dim3(Hs, B), dim3(64), 0, st, c->nms, Hs, Ws, keypoint_threshold, remove_borders, c->rowcount);
+    hipLaunchKernelGGL(sp_scan_kernel, dim3(B), dim3(1024), 0, st, c->rowcount, Hs, c->rowoff, c->count0);
+    hipLaunchKernelGGL(sp_compact_kernel, dim3(Hs, B), dim3(64), 0, st, c->nms, Hs, Ws, keypoint_threshold, remove_borders, c->rowoff, c->kp0, c->sc0, cap);
+    SP_TRY(hipGetLastError());
+    {
+        const size_t lds = (size_t)TOPK_CAP * 8;
+        SP_TRY(imp_grant_dynamic_lds(reinterpret_cast<const void*>(&sp_topk_kernel), lds));
+        hipLaunchKernelGGL(sp_topk_kernel, dim3(B), dim3(1024), lds, st, c->kp0, c->sc0, c->count0, cap, max_keypoints, c->kp1, c->sc1, c->count1);
+        SP_TRY(hipGetLastError());
+    }
+    SP_TRY(hipMemcpyAsync(counts, c->count1, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    SP_TRY(hipStreamSynchronize(st));
+    c->counts.assign(counts, counts + B);
+    c->detected = true;
+    return IMP_OK;
+}
+
+int imp_sp_describe(imp_sp_ctx* c, int b, float* keypoints, float* scores, float* descriptors, void* stream) {
+    if (!c) return imp_fail(IMP_E_ARG, "imp_sp_describe: null context");
+    if (!c->detected) return imp_fail(IMP_E_STATE, "imp_sp_describe: no imp_sp_detect result");
+    if (b < 0 || b >= c->B) return imp_fail(IMP_E_ARG, "imp_sp_describe: image index out of range");
+    const int n = c->counts[b];
+    if (n == 0) return IMP_OK;
+    if (!keypoints || !scores || !descriptors) return imp_fail(IMP_E_ARG, "imp_sp_describe: null output");
+    SP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t cap = (size_t)c->h * 8 * c->w * 8;
+    SP_TRY(hipMemcpyAsync(keypoints, c->kp1 + (size_t)b * cap * 2, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+    SP_TRY(hipMemcpyAsync(scores, c->sc1 + (size_t)b * cap, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(sp_sample_kernel, dim3((n + 3) / 4), dim3(256), 0, st, c->kp1 + (size_t)b * cap * 2, n,
+                       c->dmap + (size_t)b * c->h * c->w * c->ddim, c->h, c->w, c->ddim, c->align_corners, descriptors);
+    SP_TRY(hipGetLastError());
+    return IMP_OK;
+}
+
+int imp_sp_dense(imp_sp_ctx* c, float* scores, float* nms_scores, float* descriptors, void* stream) {
+    if (!c) return imp_fail(IMP_E_ARG, "imp_sp_dense: null context");
+    if (!c->detected) return imp_fail(IMP_E_STATE, "imp_sp_dense: no imp_sp_detect result");
+    SP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nmap = (size_t)c->B * c->h * 8 * c->w * 8;
+    if (scores) SP_TRY(hipMemcpyAsync(scores, c->scores, nmap * 4, hipMemcpyDeviceToDevice, st));
+    if (nms_scores) SP_TRY(hipMemcpyAsync(nms_scores, c->nms, nmap * 4, hipMemcpyDeviceToDevice, st));
+    if (descriptors) {
+        const int total = c->B * c->h * c->w;
+        hipLaunchKernelGGL(sp_dense_desc_kernel, dim3((total + 3) / 4), dim3(256), 0, st, c->dmap, c->h * c->w, total, c->ddim, descriptors);
+        SP_TRY(hipGetLastError());
+    }
+    return IMP_OK;
+}
+
+int imp_sp_op_conv(imp_sp_ctx* c, int layer, const float* in, int B, int H, int W, float* out, int relu, int pool, void* stream) {
+    if (!c || !in || !out) return imp_fail(IMP_E_ARG, "imp_sp_op_conv: null argument");
+    if (!c->finalized) return imp_fail(IMP_E_STATE, "imp_sp_op_conv: weights not finalised");
+    if (B < 1 || H < 1 || W < 1) return imp_fail(IMP_E_ARG, "imp_sp_op_conv: bad shape");
+    SP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (layer == 0) {
+        const size_t nthr = (size_t)B * H * W * 16;
+        hipLaunchKernelGGL(sp_conv1a_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, in, c->w1a, c->b1a, out, B, H, W);
+        SP_TRY(hipGetLastError());
+        return IMP_OK;
+    }
+    const ConvW* ws[] = {nullptr, &c->c1b, &c->c2a, &c->c2b, &c->c3a, &c->c3b, &c->c4a, &c->c4b, &c->heads, &c->db};
+    if (layer < 1 || layer > 9) return imp_fail(IMP_E_ARG, "imp_sp_op_conv: layer must be 0..9");
+    const ConvW& w = *ws[layer];
+    if (pool && w.taps != 9) return imp_fail(IMP_E_ARG, "imp_sp_op_conv: pooling is fused into the 3x3 kernels only");
+    return launch_conv(w, in, w.cin, 0, B, H, W, out, w.cout, relu, pool, st);
+}
+
+}  // extern "C"

@@ -181,3 +181,41 @@ class PoseStub:
         h = (np.floor(kpts0[:, 0]).astype(np.int64) * 31 + np.floor(kpts1[:, 1]).astype(np.int64) * 17
              + np.floor(kpts0[:, 1]).astype(np.int64) * 7) % self.keep_mod
         return np.eye(3), R, t, h < self.keep_below
+
+
+SUPERPOINT_LAYERS = [('conv1a', 1, 64, 3), ('conv1b', 64, 64, 3), ('conv2a', 64, 64, 3), ('conv2b', 64, 64, 3),
+                     ('conv3a', 64, 128, 3), ('conv3b', 128, 128, 3), ('conv4a', 128, 128, 3), ('conv4b', 128, 128, 3),
+                     ('convPa', 128, 256, 3), ('convPb', 256, 65, 1), ('convDa', 128, 256, 3), ('convDb', 256, 256, 1)]
+
+
+def make_superpoint_state_dict(seed: int = 0, descriptor_dim: int = 256, gain: float = 2.449, head_gain: float = 4.0):
+    """numpy state_dict with the key schema of nets/superpoint.py:120-137 (conv1a ... convDb, weight [out, in, k, k] + bias);
+    uniform(+-gain / sqrt(fan_in)): gain sqrt(6) keeps the activation scale through the ReLU stack; the last detector conv is
+    scaled by head_gain so the 65-way softmax is peaked and the keypoint threshold actually cuts (superpoint_v1.pth is not
+    available here)."""
+    sd = OrderedDict()
+    for name, cin, cout, k in SUPERPOINT_LAYERS:
+        if name == 'convDb':
+            cout = descriptor_dim
+        bound = gain * (head_gain if name == 'convPb' else 1.0) / np.sqrt(cin * k * k)
+        sd[name + '.weight'] = _rng_for(seed, 'sp.' + name + '.weight').uniform(-bound, bound, size=(cout, cin, k, k)).astype(np.float32)
+        sd[name + '.bias'] = _rng_for(seed, 'sp.' + name + '.bias').uniform(-bound, bound, size=(cout,)).astype(np.float32)
+    return sd
+
+
+def make_image(height: int, width: int, seed: int = 0, batch: int = 1):
+    """grayscale test image in (0, 1), float32 [B, 1, H, W]: random blobs and edges + fine noise, squashed with tanh instead of
+    clipped so that no region is exactly flat (flat regions give exactly equal detector scores, whose top-k order is arbitrary)"""
+    g = _rng_for(seed, 'image')
+    yy, xx = np.mgrid[0:height, 0:width].astype(np.float64)
+    out = np.zeros((batch, 1, height, width))
+    for b in range(batch):
+        img = 0.08 * g.standard_normal((height, width))
+        for _ in range(40):
+            cx, cy, r, a = g.uniform(0, width), g.uniform(0, height), g.uniform(3, 25), g.uniform(-0.5, 0.5)
+            img += a * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * r * r))
+        for _ in range(10):
+            th, off, a = g.uniform(0, np.pi), g.uniform(-100, 100), g.uniform(-0.3, 0.3)
+            img += a * ((xx * np.cos(th) + yy * np.sin(th) + off) > (width + height) / 4)
+        out[b, 0] = 0.5 + 0.45 * np.tanh(1.5 * img)
+    return out.astype(np.float32)

@@ -233,6 +233,37 @@ int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, const doubl
  * the resident path has been taken at all.  Synchronises. */
 int imp_resident_status(imp_ctx* ctx, int* status, int* used);
 
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * SuperPoint front-end: nets/superpoint.py:97-232.  Its own handle (independent of imp_ctx);
+ * bound to one device, not thread-safe, one image batch in flight.  Keypoint counts are data dependent, so the call is split
+ * the way the reference's variable-length lists force it to be: imp_sp_detect runs the network, NMS, threshold / border filter
+ * and top-k and returns the per-image counts (synchronises `stream`); the caller allocates outputs of those sizes and
+ * imp_sp_describe fills them (asynchronous on `stream`). */
+typedef struct imp_sp_ctx imp_sp_ctx;
+/* nets/superpoint.py:112-137 (module construction): descriptor_dim = config['descriptor_dim'] (64 / 128 / 192 / 256) */
+int imp_sp_create(imp_sp_ctx** out, int device, int descriptor_dim);
+void imp_sp_destroy(imp_sp_ctx* ctx);
+/* nets/superpoint.py:155-156 (load_state_dict): name = state_dict key ("conv1a.weight" ... "convDb.bias"), HOST float32 data in
+ * PyTorch layout ([out][in][k][k] for weights); imp_sp_finalize packs them for the kernels (split-half MFMA B fragments) */
+int imp_sp_set_weight(imp_sp_ctx* ctx, const char* name, const float* data, int64_t count);
+int imp_sp_finalize(imp_sp_ctx* ctx);
+/* nets/superpoint.py:170-217 (forward up to top_k_keypoints): image = DEVICE float32 [B][1][H][W] (H, W >= 8; sizes that are not
+ * multiples of 8 floor exactly as the three MaxPool2d(2, 2) do), nms_radius / keypoint_threshold / max_keypoints (-1 = all, at
+ * most 16384) / remove_borders = the config keys of :104-110; align_corners = what the caller resolved for :89 (the reference
+ * decides from the installed torch version string).  counts = HOST int[B].  Synchronises. */
+int imp_sp_detect(imp_sp_ctx* ctx, const float* image, int B, int H, int W, int nms_radius, float keypoint_threshold,
+                  int max_keypoints, int remove_borders, int align_corners, void* stream, int* counts);
+/* nets/superpoint.py:219-232 for image b of the last imp_sp_detect: DEVICE outputs keypoints [n][2] (x, y), scores [n],
+ * descriptors [D][n] (the reference's layout), n = counts[b]; n == 0 writes nothing */
+int imp_sp_describe(imp_sp_ctx* ctx, int b, float* keypoints, float* scores, float* descriptors, void* stream);
+/* nets/superpoint.py:140-168 (extract) and test probes, from the last imp_sp_detect; each output optional (NULL):
+ * scores [B][8h][8w] dense (before NMS), nms_scores [B][8h][8w] (after simple_nms), descriptors [B][D][h][w] L2-normalised */
+int imp_sp_dense(imp_sp_ctx* ctx, float* scores, float* nms_scores, float* descriptors, void* stream);
+/* test entry: ONE convolution of the stack on caller data, NHWC float32 device tensors: layer 0 = conv1a (in [B][H][W], out
+ * [B][H][W][64], always ReLU), 1..7 = conv1b, conv2a, conv2b, conv3a, conv3b, conv4a, conv4b, 8 = convPa|convDa stacked (512
+ * output channels), 9 = convDb (1x1).  in [B][H][W][Cin] -> out [B][Ho][Wo][Cout], pool != 0 fuses MaxPool2d(2, 2) (Ho = H / 2). */
+int imp_sp_op_conv(imp_sp_ctx* ctx, int layer, const float* in, int B, int H, int W, float* out, int relu, int pool, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from helpers import build_case, golden_names, load_golden
+from imp_release_amd import synthetic
 from oracle import imp_oracle as orc
 
 torch.set_num_threads(max(1, min(8, torch.get_num_threads())))
@@ -119,3 +120,34 @@ def test_empty_and_error_behaviour():
          'scores0': torch.zeros(1, 4), 'scores1': torch.zeros(1, 4)}
     with pytest.raises(ValueError):        # nets/gm.py:172
         o.produce_matches(d)
+
+
+# ------------------------------------------------------------------------------------------------ SuperPoint front-end (f-4)
+SP_SMALL = [n for n in golden_names(['superpoint_']) if '480x640' not in n]
+
+
+@pytest.mark.parametrize('name', SP_SMALL)
+def test_superpoint_oracle_vs_golden(name):
+    """oracle/superpoint_oracle.py against the outputs of the imported reference (tools/make_golden.py case_superpoint)"""
+    from oracle import superpoint_oracle as spo
+    spec, z = load_golden(name)
+    sd = synthetic.make_superpoint_state_dict(seed=spec['wseed'], descriptor_dim=spec.get('descriptor_dim', 256))
+    img = torch.from_numpy(synthetic.make_image(spec['height'], spec['width'], seed=spec['iseed'], batch=spec.get('batch', 1)))
+    cfg = {'nms_radius': 4, 'keypoint_threshold': 0.0025, 'max_keypoints': -1, 'remove_borders': 4, **spec['config']}
+    with torch.no_grad():
+        out = spo.forward(sd, img, nms_radius=cfg['nms_radius'], keypoint_threshold=cfg['keypoint_threshold'],
+                          max_keypoints=cfg['max_keypoints'], remove_borders=cfg['remove_borders'],
+                          align_corners=bool(int(z['align_corners'])))
+    for b in range(img.shape[0]):
+        assert np.array_equal(out['keypoints'][b].numpy(), z[f'keypoints_{b}'].astype(np.float32))
+        assert np.abs(out['scores'][b].numpy() - z[f'scores_{b}']).max() < 1e-6
+        de = out['descriptors'][b]
+        assert np.abs(de[:, :48].numpy() - z[f'desc_head_{b}']).max() < 1e-6
+        assert np.abs(de[::32].numpy() - z[f'desc_rows_{b}']).max() < 1e-6
+
+
+def test_superpoint_align_corners_rule():
+    """nets/superpoint.py:89 decides from ONE character of the version string: True for torch 1.3 ... 1.9 only"""
+    from imp_release_amd.superpoint import reference_align_corners
+    assert [reference_align_corners(v) for v in ('1.2.0', '1.3.1', '1.7.1', '1.9.0', '1.10.2', '1.13.1', '2.0.1', '2.10.0+rocm7.0')] == \
+        [False, True, True, True, False, False, False, False]

@@ -51,6 +51,11 @@ from imp_release_amd import synthetic  # noqa: E402
 from oracle import imp_oracle as orc   # noqa: E402
 
 GOLD = os.path.join(ROOT, 'tests', 'golden')
+ONLY = [a for a in sys.argv[1:] if not a.startswith('-')]      # optional name prefixes: regenerate only these cases
+
+
+def wanted(name):
+    return not ONLY or any(name.startswith(p) for p in ONLY)
 REF_CLS = {'GM': GM, 'DGNNS': DGNNS, 'AdaGMN': AdaGMN}
 
 
@@ -100,6 +105,8 @@ def score_probes(score):
 
 
 def case_produce(name, spec):
+    if not wanted(name):
+        return
     cfg, ref, oracle, data = build(spec)
     kw = dict(spec.get('call', {}))
     with torch.no_grad():
@@ -126,6 +133,8 @@ def case_produce(name, spec):
 
 
 def case_run(name, spec):
+    if not wanted(name):
+        return
     cfg, ref, oracle, data = build(spec)
     nk0 = orc.normalize_keypoints(data['keypoints0'], data['image0'].shape)
     nk1 = orc.normalize_keypoints(data['keypoints1'], data['image1'].shape)
@@ -148,6 +157,8 @@ def case_run(name, spec):
 
 
 def case_loop(name, spec, uncertainty):
+    if not wanted(name):
+        return
     """eval/matching.py loops.  spec['pose_schedule'] is None -> the pose step is stubbed out (estimate_pose -> None:
     no early exit, all 15 iterations); otherwise a fresh synthetic.PoseStub(schedule) per implementation makes the
     REFERENCE take eval/matching.py:84-117 (pose-change test, early exit returning inlier-filtered indices) and, with
@@ -218,6 +229,8 @@ def case_loop(name, spec, uncertainty):
 
 
 def case_pool_edges(name):
+    if not wanted(name):
+        return
     """AdaGMN.pool on hand-built inputs: small side (<= n_min_tokens), empty pids, even-count median."""
     cfg = eval_config(n_layers=1)
     ref = AdaGMN(cfg).eval()
@@ -247,6 +260,8 @@ def case_pool_edges(name):
 
 
 def case_metrics(name):
+    if not wanted(name):
+        return
     """metrics tail (tools/utils.py:425-457, components/utils/metrics.py:51-64) on seeded random inputs"""
     import tools.utils as ref_utils                       # needs the cv2 stub installed above
     # components/__init__.py pulls in h5py (not installed): register bare package shells so that only
@@ -275,6 +290,57 @@ def case_metrics(name):
     save(name, {'kind': 'metrics'}, dict(errs=errs, ths=np.array(ths), auc=np.array(auc), T=T, R=R, t=t, err_t=et, err_R=eR, x1=x1, x2=x2,
                                          E=E, mask=mask, dis=dis), f'mine_equal={ok}')
     assert ok
+
+
+def case_superpoint(name, spec):
+    """nets/superpoint.py forward() on seeded random weights (superpoint_v1.pth is not available offline) and a synthetic image.
+    spec['torch_version'] (optional) is patched over torch.__version__ during the call: nets/superpoint.py:89 picks grid_sample's
+    align_corners from that string (True only for '1.3'..'1.9'; False on the torch 2.x of this image)."""
+    if not wanted(name):
+        return
+    import tempfile
+    from nets.superpoint import SuperPoint
+    from oracle import superpoint_oracle as spo
+    sd = synthetic.make_superpoint_state_dict(seed=spec['wseed'], descriptor_dim=spec.get('descriptor_dim', 256))
+    tmp = tempfile.mktemp(suffix='.pth')
+    torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, tmp)
+    cfg = dict(spec['config'])
+    ref = SuperPoint({**cfg, 'weight_path': tmp}).eval()
+    os.remove(tmp)
+    img = torch.from_numpy(synthetic.make_image(spec['height'], spec['width'], seed=spec['iseed'], batch=spec.get('batch', 1)))
+    saved = torch.__version__
+    try:
+        if spec.get('torch_version'):
+            torch.__version__ = spec['torch_version']
+        ac = int(str(torch.__version__)[2]) > 2
+        with torch.no_grad():
+            out = ref({'image': img})
+            dense_scores, dense_desc = ref.extract({'image': img})
+    finally:
+        torch.__version__ = saved
+    with torch.no_grad():
+        o = spo.forward(sd, img, nms_radius=ref.config['nms_radius'], keypoint_threshold=ref.config['keypoint_threshold'],
+                        max_keypoints=ref.config['max_keypoints'], remove_borders=ref.config['remove_borders'], align_corners=ac)
+    arrays = {'align_corners': np.array(int(ac))}
+    worst = [0.0, 0.0]
+    for b in range(img.shape[0]):
+        kp, sc, de = out['keypoints'][b], out['scores'][b], out['descriptors'][b]
+        assert torch.equal(kp, o['keypoints'][b]), 'oracle keypoints differ from the reference'
+        worst[0] = max(worst[0], maxdiff(sc, o['scores'][b]))
+        worst[1] = max(worst[1], maxdiff(de, o['descriptors'][b]))
+        arrays[f'keypoints_{b}'] = kp.numpy().astype(np.int16)
+        arrays[f'scores_{b}'] = sc.numpy()
+        n = kp.shape[0]
+        arrays[f'desc_head_{b}'] = de[:, :min(n, 48)].numpy()                       # full descriptors of the first 48 keypoints
+        arrays[f'desc_rows_{b}'] = de[::32].numpy()                                 # 8 of the 256 dimensions for every keypoint
+        arrays[f'desc_sum_{b}'] = de.double().sum(0).numpy().astype(np.float32)     # per-keypoint checksum over all dimensions
+        # dense maps: coarse probes (every 8th pixel) + global checksums
+        arrays[f'dense_scores_probe_{b}'] = dense_scores[b, 3::8, 5::8].numpy()
+        arrays[f'dense_desc_probe_{b}'] = dense_desc[b, ::16, ::3, ::3].numpy()
+    arrays['dense_scores_sum'] = np.array(float(dense_scores.double().sum()))
+    save(name, {'kind': 'superpoint', **spec}, arrays,
+         f"n={[len(k) for k in out['keypoints']]} align_corners={ac} oracle: dscore={worst[0]:.1e} ddesc={worst[1]:.1e}")
+    assert worst[0] < 2e-6 and worst[1] < 2e-6
 
 
 def main():
@@ -341,6 +407,18 @@ def main():
     # (7) pool edge cases
     case_pool_edges('pool_edges')
     case_metrics('metrics')
+    # (7) SuperPoint front-end (f-4): seeded random weights; 640 x 480 with top-1024 is the configuration the evaluation scripts
+    # of the SuperGlue lineage use; the torch_version case pins the align_corners=True branch of nets/superpoint.py:89
+    case_superpoint('superpoint_96x128_all', dict(wseed=0, iseed=3, height=96, width=128, config=dict(max_keypoints=-1)))
+    case_superpoint('superpoint_240x320_top300', dict(wseed=0, iseed=4, height=240, width=320, config=dict(max_keypoints=300)))
+    case_superpoint('superpoint_480x640_top1024', dict(wseed=1, iseed=5, height=480, width=640, config=dict(max_keypoints=1024)))
+    case_superpoint('superpoint_b2_120x160', dict(wseed=2, iseed=6, height=120, width=160, batch=2, config=dict(max_keypoints=-1)))
+    case_superpoint('superpoint_ragged_100x150', dict(wseed=2, iseed=7, height=100, width=150,
+                                                      config=dict(max_keypoints=200, nms_radius=3, remove_borders=6, keypoint_threshold=0.01)))
+    case_superpoint('superpoint_aligned_120x160', dict(wseed=3, iseed=8, height=120, width=160, torch_version='1.7.1',
+                                                       config=dict(max_keypoints=-1)))
+    case_superpoint('superpoint_d128_96x96', dict(wseed=4, iseed=9, height=96, width=96, descriptor_dim=128,
+                                                  config=dict(max_keypoints=-1, descriptor_dim=128, nms_radius=2)))
 
 
 if __name__ == '__main__':
