@@ -29,6 +29,7 @@
 #include "imp_kernels.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -67,6 +68,9 @@ struct SpConvParams {
     int out_ld;
     int relu;
     int tiles_x, tiles_y;
+    const float* img;     // FIRST: the image [B][H][W]; the input tile is relu(conv1a(img)) computed while staging
+    const float* w1a;     // [9][64]
+    const float* b1a;
 };
 
 // bijective XCD-aware remap of a linear block id (hardware places block b on XCD b % 8): each XCD gets a contiguous chunk of
@@ -78,7 +82,7 @@ __device__ __forceinline__ int xcd_remap(int lin, int total) {
     return base + idx;
 }
 
-template <int TAPS, int POOL>
+template <int TAPS, int POOL, int FIRST>
 __global__ __launch_bounds__(256) void sp_conv_kernel(const SpConvParams p, int total) {
     using G = Geo<TAPS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
@@ -123,6 +127,42 @@ __global__ __launch_bounds__(256) void sp_conv_kernel(const SpConvParams p, int 
 
     for (int chunk = 0; chunk < nchunk; ++chunk) {
         if (chunk > 0) __syncthreads();                    // every wave has read the previous chunk
+        if (FIRST) {
+            // conv1a (nets/superpoint.py:120,172) on the fly: this thread's 4 channels of pixel pix from the 3 x 3 image patch, same
+            // fmaf order as sp_conv1a_kernel; pixels outside the image are conv1b's zero padding, not relu(bias)
+            f32x4 wv[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(p.w1a + t * 64 + sp_c);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b1a + sp_c);
+            const float* im = p.img + (size_t)b * H * W;
+#pragma unroll 2
+            for (int s = 0; s < NPASS; ++s) {
+                const int pix = s * 16 + sp_pix;
+                if (pix >= NPIX) break;
+                const int ly = pix / G::LW, lx = pix - ly * G::LW;
+                const int gy = y0 - G::HALO + ly, gx = x0 - G::HALO + lx;
+                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    a = bb;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int yy = gy + t / 3 - 1, xx = gx + t % 3 - 1;
+                        const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? im[(size_t)yy * W + xx] : 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a[e] = fmaf(v, wv[t][e], a[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.f);
+                }
+                u32x2 hi, lo;
+                unsigned ua, uc;
+                imp_split2(a[0], a[1], ua, uc); hi[0] = ua; lo[0] = uc;
+                imp_split2(a[2], a[3], ua, uc); hi[1] = ua; lo[1] = uc;
+                unsigned char* dst = sp_smem + (ly * G::ROW_SLOTS + lx * PSLOT) * 16 + sp_c * 2;
+                *reinterpret_cast<u32x2*>(dst) = hi;
+                *reinterpret_cast<u32x2*>(dst + G::PLANE) = lo;
+            }
+        } else
         {
             const float* src = p.in + p.in_c0 + chunk * 64 + sp_c;
             f32x4 v[NPASS];
@@ -276,6 +316,28 @@ __global__ __launch_bounds__(256) void sp_detector_kernel(const float* __restric
     }
 }
 
+
+// detector tail after the MFMA 1x1 convolution (convPb, 65 outputs padded to 128): softmax over the 65 bins, dustbin dropped, 8x8
+// pixel shuffle (nets/superpoint.py:194-198).  One wave per cell of the h x w grid: lane c holds bin c, the dustbin is read by all.
+__global__ __launch_bounds__(256) void sp_softmax_shuffle_kernel(const float* __restrict__ logits /*[npix][128]*/, float* __restrict__ scores,
+                                                                 int npix, int h, int w) {
+    const int lane = threadIdx.x & 63;
+    const int pi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pi >= npix) return;
+    const float l = logits[(size_t)pi * 128 + lane];
+    const float ld = logits[(size_t)pi * 128 + 64];
+    float mx = fmaxf(l, ld);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    const float e = expf(l - mx), ed = expf(ld - mx);
+    float sum = e;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum += ed;
+    const int xx = pi % w, yy = (pi / w) % h, b = pi / (w * h);
+    scores[((size_t)b * h * 8 + yy * 8 + (lane >> 3)) * (size_t)(w * 8) + xx * 8 + (lane & 7)] = e / sum;
+}
+
 // simple_nms (nets/superpoint.py:49-63) for one 32 x 32 tile: every max-pool of the chain is evaluated on the whole LDS image
 // (tile + 5R halo, -inf outside the image = max_pool2d's padding); values within k R of the image edge are wrong after k pools,
 // the tile itself depends on 5 pools.
@@ -353,6 +415,130 @@ __global__ __launch_bounds__(256) void sp_nms_kernel(const float* __restrict__ s
     }
 }
 
+
+// Fast path of simple_nms for radius 1..6 (compile-time R): same chain, same LDS image, but every pool is a register-blocked
+// separable pass - a thread produces 8 consecutive outputs from 8 + 2R inputs it holds in registers (horizontal: aligned float4
+// reads of a row padded with -inf columns; vertical: a column of the intermediate image, which has R rows of -inf above and
+// below) - and the vertical pass hands each pooled value straight to the comparison that consumes it, so the pooled image is
+// never stored.  3 float images + 1 byte mask = 74 KB for R = 4 (2 workgroups per CU).
+template <int R>
+struct NmsGeo {
+    static constexpr int T = 32;
+    static constexpr int E = ((T + 10 * R + 7) / 8) * 8;     // LDS image edge (tile + 5R halo, rounded up to the 8-wide blocks)
+    static constexpr int RP = ((R + 3) / 4) * 4;             // -inf columns on both sides of s / a rows (16-byte aligned)
+    static constexpr int ES = E + 2 * RP;
+    static constexpr int TR = E + 2 * R;                     // rows of the intermediate image
+    static constexpr int LDS = (2 * E * ES + TR * E) * 4 + E * E;
+};
+
+template <int R, class F>
+__device__ __forceinline__ void nms_pool(const float* in, float* t, int tid, F&& f) {
+    using G = NmsGeo<R>;
+    constexpr int E = G::E, RP = G::RP, ES = G::ES, SEG = E / 8;
+    for (int seg = tid; seg < E * SEG; seg += 256) {
+        const int y = seg / SEG, x0 = (seg - y * SEG) * 8;
+        float v[8 + 2 * RP];
+        const float* row = in + y * ES + x0;                 // padded index x0 = logical x0 - RP
+#pragma unroll
+        for (int j = 0; j < (8 + 2 * RP) / 4; ++j) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(row + 4 * j);
+            v[4 * j] = q[0]; v[4 * j + 1] = q[1]; v[4 * j + 2] = q[2]; v[4 * j + 3] = q[3];
+        }
+        f32x4 o[2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float m = v[RP - R + i];
+#pragma unroll
+            for (int j = 1; j <= 2 * R; ++j) m = fmaxf(m, v[RP - R + i + j]);
+            o[i >> 2][i & 3] = m;
+        }
+        float* dst = t + (y + R) * E + x0;
+        *reinterpret_cast<f32x4*>(dst) = o[0];
+        *reinterpret_cast<f32x4*>(dst + 4) = o[1];
+    }
+    __syncthreads();
+    for (int seg = tid; seg < E * SEG; seg += 256) {
+        const int yb = seg / E, x = seg - yb * E;
+        float v[8 + 2 * R];
+#pragma unroll
+        for (int j = 0; j < 8 + 2 * R; ++j) v[j] = t[(yb * 8 + j) * E + x];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float m = v[i];
+#pragma unroll
+            for (int j = 1; j <= 2 * R; ++j) m = fmaxf(m, v[i + j]);
+            f(yb * 8 + i, x, m);
+        }
+    }
+    __syncthreads();
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void sp_nms_fast_kernel(const float* __restrict__ sin, float* __restrict__ sout, int Hs, int Ws, int tiles_x, int tiles_y) {
+    using G = NmsGeo<R>;
+    constexpr int E = G::E, RP = G::RP, ES = G::ES, TR = G::TR, T = G::T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    float* s = reinterpret_cast<float*>(sp_smem);            // [E][ES]
+    float* a = s + E * ES;                                   // [E][ES]
+    float* t = a + E * ES;                                   // [TR][E]
+    unsigned char* msk = reinterpret_cast<unsigned char*>(t + TR * E);
+    const int tid = threadIdx.x;
+    int z = blockIdx.x;
+    const int tx = z % tiles_x; z /= tiles_x;
+    const int ty = z % tiles_y;
+    const int b = z / tiles_y;
+    const int y0 = ty * T - 5 * R, x0 = tx * T - 5 * R;
+    const float* src = sin + (size_t)b * Hs * Ws;
+    for (int i = tid; i < E * ES; i += 256) {
+        const int y = i / ES, xp = i - y * ES;
+        const int x = xp - RP;
+        const int gy = y0 + y, gx = x0 + x;
+        const bool in = x >= 0 && x < E && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
+        s[i] = in ? src[(size_t)gy * Ws + gx] : -INFINITY;
+        a[i] = -INFINITY;                                    // the column pads stay -inf; the interior is rewritten per pool
+    }
+    for (int i = tid; i < R * E; i += 256) {
+        t[i] = -INFINITY;
+        t[(E + R) * E + i] = -INFINITY;
+    }
+    __syncthreads();
+    nms_pool<R>(s, t, tid, [&](int y, int x, float P) {
+        const float v = s[y * ES + RP + x];
+        const bool m = v > -INFINITY && v == P;
+        msk[y * E + x] = m ? 1 : 0;
+        a[y * ES + RP + x] = m ? 1.f : 0.f;
+    });
+#pragma unroll 1
+    for (int it = 0; it < 2; ++it) {
+        nms_pool<R>(a, t, tid, [&](int y, int x, float P) {
+            const float v = s[y * ES + RP + x];
+            const bool supp = P > 0.f;
+            a[y * ES + RP + x] = supp ? (v > -INFINITY ? 0.f : -INFINITY) : v;
+            if (supp) msk[y * E + x] |= 2;
+        });
+        nms_pool<R>(a, t, tid, [&](int y, int x, float P) {
+            const float v = s[y * ES + RP + x];
+            const unsigned char mk = msk[y * E + x];
+            const bool nw = v > -INFINITY && a[y * ES + RP + x] == P;
+            const bool m = (mk & 1) || (nw && !(mk & 2));
+            msk[y * E + x] = m ? 1 : 0;
+            a[y * ES + RP + x] = m ? 1.f : 0.f;
+        });
+    }
+    float* dst = sout + (size_t)b * Hs * Ws;
+    for (int i = tid; i < T * T; i += 256) {
+        const int y = i / T, x = i - y * T;
+        const int gy = ty * T + y, gx = tx * T + x;
+        if (gy < Hs && gx < Ws) {
+            const int ly = y + 5 * R, lx = x + 5 * R;
+            dst[(size_t)gy * Ws + gx] = msk[ly * E + lx] ? s[ly * ES + RP + lx] : 0.f;
+        }
+    }
+}
+
+template <int R>
+int launch_nms_fast(const float* in, float* out, int B, int Hs, int Ws, hipStream_t st);
+
 // keypoint extraction (nets/superpoint.py:203-211): torch.nonzero(s > threshold) order = row major, border filter of :66-71
 __device__ __forceinline__ bool sp_keep(float v, int x, int y, int Hs, int Ws, float thr, int border) {
     return v > thr && y >= border && y < Hs - border && x >= border && x < Ws - border;
@@ -419,15 +605,38 @@ __global__ __launch_bounds__(64) void sp_compact_kernel(const float* __restrict_
 
 // top_k_keypoints (nets/superpoint.py:74-79): k >= n keeps everything in nonzero order; otherwise the k best scores, descending
 // (torch.topk), equal scores in index order.  Keys = score bits (scores are positive floats: the bit pattern is monotone) : ~index.
+// One workgroup of 1024 threads per image:
+//   n > 2048: radix select of the k-th largest score (digits of 12 / 10 / 10 bits from the top, LDS histogram, parallel suffix scan)
+//             cuts the candidates to exactly k keys in LDS;
+//   m <= 4096 keys: rank sort - a key's final position is the number of larger keys, counted against broadcast LDS reads (no
+//             barriers); more: bitonic sort in LDS.
 constexpr int TOPK_CAP = 16384;
+
+// inclusive prefix sum over the 1024 threads of the block (wave shuffles + one LDS hop); all threads must call
+__device__ __forceinline__ unsigned sp_block_scan(unsigned v, unsigned* wave_tot /*[16]*/, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    unsigned x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    __syncthreads();                       // previous users of wave_tot are done
+    if (lane == 63) wave_tot[wave] = x;
+    __syncthreads();
+    unsigned base = 0;
+    for (int wv = 0; wv < wave; ++wv) base += wave_tot[wv];
+    return x + base;
+}
+
 __global__ __launch_bounds__(1024) void sp_topk_kernel(const float* __restrict__ kp, const float* __restrict__ sc, const int* __restrict__ count,
                                                        size_t cap, int k, float* __restrict__ kp_out, float* __restrict__ sc_out,
                                                        int* __restrict__ count_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(sp_smem);
-    __shared__ unsigned hist[256];
+    __shared__ unsigned hist[4096];
+    __shared__ unsigned wave_tot[16];
     __shared__ unsigned sel_prefix, sel_remaining, sel_count, eq_taken;
-    __shared__ int scan[1024];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = count[b];
     const float* kpb = kp + (size_t)b * cap * 2;
@@ -444,61 +653,109 @@ __global__ __launch_bounds__(1024) void sp_topk_kernel(const float* __restrict__
         return;
     }
     int m;      // number of keys in LDS
-    if (n <= TOPK_CAP) {
+    if (n <= 2048) {
         for (int i = tid; i < n; i += 1024) keys[i] = ((unsigned long long)__float_as_uint(scb[i]) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
         m = n;
     } else {
-        // radix select of the k-th largest score bit pattern T, 8 bits per pass from the top
         if (tid == 0) { sel_prefix = 0; sel_remaining = (unsigned)k; }
         __syncthreads();
-        for (int shift = 24; shift >= 0; shift -= 8) {
-            if (tid < 256) hist[tid] = 0;
+#pragma unroll 1
+        for (int pass = 0; pass < 3; ++pass) {
+            const int shift = pass == 0 ? 20 : pass == 1 ? 10 : 0;
+            const int bits = pass == 0 ? 12 : 10;
+            const int nb = 1 << bits;
+            for (int i = tid; i < nb; i += 1024) hist[i] = 0;
             __syncthreads();
             const unsigned prefix = sel_prefix;
-            const unsigned himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+            const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + bits));
             for (int i = tid; i < n; i += 1024) {
                 const unsigned u = __float_as_uint(scb[i]);
-                if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1u);
+                if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & (nb - 1)], 1u);
             }
             __syncthreads();
-            if (tid == 0) {
-                unsigned rem = sel_remaining;
-                int d = 255;
-                for (; d > 0; --d) {
-                    if (hist[d] >= rem) break;
-                    rem -= hist[d];
+            // thread t owns the bins nb-1 - per*t - j (descending), so the prefix over threads is the suffix over bins
+            const int per = nb >> 10;                     // 4 or 1
+            unsigned mine = 0;
+            for (int j = 0; j < per; ++j) mine += hist[nb - 1 - per * tid - j];
+            const unsigned incl = sp_block_scan(mine, wave_tot, tid);
+            const unsigned rem = sel_remaining;
+            __syncthreads();                              // everyone has read sel_remaining
+            if (incl - mine < rem && rem <= incl) {       // exactly one thread: the k-th largest falls into its bins
+                unsigned r = rem - (incl - mine);
+                int d = nb - 1 - per * tid;
+                for (int j = 0; j < per; ++j, --d) {
+                    if (hist[d] >= r) break;
+                    r -= hist[d];
                 }
                 sel_prefix = prefix | ((unsigned)d << shift);
-                sel_remaining = rem;                          // how many of the elements with this prefix are still needed
+                sel_remaining = r;                        // how many of the elements with this prefix are still needed
             }
             __syncthreads();
         }
         const unsigned T = sel_prefix;
-        const unsigned need_eq = sel_remaining;               // elements == T to take, lowest index first
+        const unsigned need_eq = sel_remaining;           // elements == T to take
         if (tid == 0) { sel_count = 0; eq_taken = 0; }
         __syncthreads();
-        for (int base = 0; base < n; base += 1024) {
-            const int i = base + tid;
-            const unsigned u = i < n ? __float_as_uint(scb[i]) : 0u;
-            const bool gt = i < n && u > T, eq = i < n && u == T;
-            scan[tid] = eq ? 1 : 0;
-            __syncthreads();
-            for (int d = 1; d < 1024; d <<= 1) {
-                const int add = tid >= d ? scan[tid - d] : 0;
-                __syncthreads();
-                scan[tid] += add;
-                __syncthreads();
-            }
-            const unsigned eq_rank = eq_taken + (unsigned)scan[tid] - 1u;     // rank of this element among the == T ones
-            if (gt || (eq && eq_rank < need_eq)) {
+        // elements > T; and count the == T ones
+        for (int i = tid; i < n; i += 1024) {
+            const unsigned u = __float_as_uint(scb[i]);
+            if (u > T) {
                 const unsigned slot = atomicAdd(&sel_count, 1u);
                 if (slot < (unsigned)TOPK_CAP) keys[slot] = ((unsigned long long)u << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+            } else if (u == T) {
+                atomicAdd(&eq_taken, 1u);
             }
-            __syncthreads();
-            if (tid == 1023) eq_taken += (unsigned)scan[1023];
-            __syncthreads();
         }
-        m = min((int)sel_count, TOPK_CAP);                    // == k (the host rejects k > TOPK_CAP)
+        __syncthreads();
+        const unsigned n_eq = eq_taken, n_gt = sel_count;
+        __syncthreads();
+        if (n_eq == need_eq) {                            // (the usual case) every element == T is needed: order does not matter
+            for (int i = tid; i < n; i += 1024) {
+                const unsigned u = __float_as_uint(scb[i]);
+                if (u == T) {
+                    const unsigned slot = atomicAdd(&sel_count, 1u);
+                    if (slot < (unsigned)TOPK_CAP) keys[slot] = ((unsigned long long)u << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+                }
+            }
+        } else {                                          // exact ties at the cut: the first need_eq in index order (deterministic)
+            unsigned taken = 0;
+            for (int base = 0; base < n; base += 1024) {
+                const int i = base + tid;
+                const bool eq = i < n && __float_as_uint(scb[i]) == T;
+                const unsigned incl = sp_block_scan(eq ? 1u : 0u, wave_tot, tid);
+                const unsigned rank = taken + incl - 1u;
+                if (eq && rank < need_eq) keys[n_gt + rank] = ((unsigned long long)T << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+                __syncthreads();
+                if (tid == 1023) eq_taken = incl;         // block total of this chunk
+                __syncthreads();
+                taken += eq_taken;
+            }
+        }
+        __syncthreads();
+        m = k;                                            // n_gt + need_eq (the host rejects k > TOPK_CAP)
+    }
+    __syncthreads();
+    if (m <= 4096) {
+        // rank sort: thread owns keys tid, tid + 1024, ...; every key is read once by every wave (same address in all lanes)
+        unsigned long long mk[4];
+        unsigned rank[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mk[j] = tid + 1024 * j < m ? keys[tid + 1024 * j] : ~0ull;
+        for (int i = 0; i < m; ++i) {
+            const unsigned long long o = keys[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rank[j] += o > mk[j] ? 1u : 0u;
+        }
+        for (int j = 0; j < 4; ++j) {
+            if (tid + 1024 * j < m && rank[j] < (unsigned)k) {
+                const unsigned idx = 0xFFFFFFFFu - (unsigned)(mk[j] & 0xFFFFFFFFull);
+                kpo[2 * (size_t)rank[j]] = kpb[2 * (size_t)idx];
+                kpo[2 * (size_t)rank[j] + 1] = kpb[2 * (size_t)idx + 1];
+                sco[rank[j]] = __uint_as_float((unsigned)(mk[j] >> 32));
+            }
+        }
+        if (tid == 0) count_out[b] = k;
+        return;
     }
     int m2 = 1;
     while (m2 < m) m2 <<= 1;
@@ -534,11 +791,14 @@ __device__ __forceinline__ float sp_wave_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void sp_sample_kernel(const float* __restrict__ kp, int n, const float* __restrict__ dmap, int h, int w, int D,
-                                                        int align_corners, float* __restrict__ out /*[D][n]*/) {
+__global__ __launch_bounds__(256) void sp_sample_kernel(const float* __restrict__ kp, const float* __restrict__ sc, int n, const float* __restrict__ dmap,
+                                                        int h, int w, int D, int align_corners, float* __restrict__ kp_out,
+                                                        float* __restrict__ sc_out, float* __restrict__ out /*[D][n]*/) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
+    if (lane < 2) kp_out[2 * (size_t)i + lane] = kp[2 * (size_t)i + lane];
+    if (lane == 2) sc_out[i] = sc[i];
     const float s = 8.f;
     float gx = kp[2 * (size_t)i] - s / 2 + 0.5f, gy = kp[2 * (size_t)i + 1] - s / 2 + 0.5f;
     gx = gx / (w * s - s / 2 - 0.5f);
@@ -610,13 +870,13 @@ struct imp_sp_ctx {
     std::map<std::string, HostT> raw;
     float* w1a = nullptr;      // [9][64]
     float* b1a = nullptr;
-    ConvW c1b, c2a, c2b, c3a, c3b, c4a, c4b, heads, db;
+    ConvW c1b, c2a, c2b, c3a, c3b, c4a, c4b, heads, db, pb;
     float* wpb = nullptr;      // [256][65]
     float* bpb = nullptr;
     // workspace of the last detect call
     int B = 0, H = 0, W = 0, h = 0, w = 0;
     size_t capA = 0, capB = 0, cap_small = 0, cap_map = 0, cap_rows = 0, cap_b = 0;
-    float *bufA = nullptr, *bufB = nullptr, *dmap = nullptr, *scores = nullptr, *nms = nullptr;
+    float *bufA = nullptr, *bufB = nullptr, *dmap = nullptr, *logits = nullptr, *scores = nullptr, *nms = nullptr;
     float *kp0 = nullptr, *sc0 = nullptr, *kp1 = nullptr, *sc1 = nullptr;
     int *rowcount = nullptr, *rowoff = nullptr, *count0 = nullptr, *count1 = nullptr;
     std::vector<int> counts;
@@ -687,12 +947,12 @@ void free_conv(ConvW& w) {
     w = ConvW();
 }
 
-template <int TAPS, int POOL>
+template <int TAPS, int POOL, int FIRST>
 int launch_conv_t(const SpConvParams& p, hipStream_t st) {
     const int total = p.B * p.tiles_x * p.tiles_y * (p.cout / 64);
-    const void* fn = reinterpret_cast<const void*>(&sp_conv_kernel<TAPS, POOL>);
+    const void* fn = reinterpret_cast<const void*>(&sp_conv_kernel<TAPS, POOL, FIRST>);
     SP_TRY(imp_grant_dynamic_lds(fn, Geo<TAPS>::LDS));
-    hipLaunchKernelGGL((sp_conv_kernel<TAPS, POOL>), dim3(total), dim3(256), Geo<TAPS>::LDS, st, p, total);
+    hipLaunchKernelGGL((sp_conv_kernel<TAPS, POOL, FIRST>), dim3(total), dim3(256), Geo<TAPS>::LDS, st, p, total);
     SP_TRY(hipGetLastError());
     return IMP_OK;
 }
@@ -704,15 +964,41 @@ int launch_conv(const ConvW& w, const float* in, int in_ld, int in_c0, int B, in
     p.wf = w.wf; p.bias = w.bias; p.cout = w.cout;
     p.out = out; p.out_ld = out_ld; p.relu = relu;
     p.tiles_x = (W + TW - 1) / TW; p.tiles_y = (H + TH - 1) / TH;
-    if (w.taps == 9) return pool ? launch_conv_t<9, 1>(p, st) : launch_conv_t<9, 0>(p, st);
-    return launch_conv_t<1, 0>(p, st);
+    p.img = nullptr; p.w1a = nullptr; p.b1a = nullptr;
+    if (w.taps == 9) return pool ? launch_conv_t<9, 1, 0>(p, st) : launch_conv_t<9, 0, 0>(p, st);
+    return launch_conv_t<1, 0, 0>(p, st);
+}
+
+// conv1a + conv1b + ReLUs + max-pool in one kernel: the 64-channel full-resolution map never exists in memory
+int launch_conv_first(const imp_sp_ctx* c, const float* image, int B, int H, int W, float* out, hipStream_t st);
+
+template <int R>
+int launch_nms_fast(const float* in, float* out, int B, int Hs, int Ws, hipStream_t st) {
+    using G = NmsGeo<R>;
+    const int tx = (Ws + G::T - 1) / G::T, ty = (Hs + G::T - 1) / G::T;
+    SP_TRY(imp_grant_dynamic_lds(reinterpret_cast<const void*>(&sp_nms_fast_kernel<R>), G::LDS));
+    hipLaunchKernelGGL((sp_nms_fast_kernel<R>), dim3(tx * ty * B), dim3(256), G::LDS, st, in, out, Hs, Ws, tx, ty);
+    SP_TRY(hipGetLastError());
+    return IMP_OK;
+}
+
+int launch_conv_first(const imp_sp_ctx* c, const float* image, int B, int H, int W, float* out, hipStream_t st) {
+    const ConvW& w = c->c1b;
+    SpConvParams p;
+    p.in = nullptr; p.in_ld = 64; p.in_c0 = 0; p.cin = 64;
+    p.B = B; p.H = H; p.W = W;
+    p.wf = w.wf; p.bias = w.bias; p.cout = w.cout;
+    p.out = out; p.out_ld = 64; p.relu = 1;
+    p.tiles_x = (W + TW - 1) / TW; p.tiles_y = (H + TH - 1) / TH;
+    p.img = image; p.w1a = c->w1a; p.b1a = c->b1a;
+    return launch_conv_t<9, 1, 1>(p, st);
 }
 
 void free_ws(imp_sp_ctx* c) {
-    for (void* p : {(void*)c->bufA, (void*)c->bufB, (void*)c->dmap, (void*)c->scores, (void*)c->nms, (void*)c->kp0, (void*)c->sc0, (void*)c->kp1,
+    for (void* p : {(void*)c->bufA, (void*)c->bufB, (void*)c->dmap, (void*)c->logits, (void*)c->scores, (void*)c->nms, (void*)c->kp0, (void*)c->sc0, (void*)c->kp1,
                     (void*)c->sc1, (void*)c->rowcount, (void*)c->rowoff, (void*)c->count0, (void*)c->count1})
         if (p) (void)hipFree(p);
-    c->bufA = c->bufB = c->dmap = c->scores = c->nms = c->kp0 = c->sc0 = c->kp1 = c->sc1 = nullptr;
+    c->bufA = c->bufB = c->dmap = c->logits = c->scores = c->nms = c->kp0 = c->sc0 = c->kp1 = c->sc1 = nullptr;
     c->rowcount = c->rowoff = c->count0 = c->count1 = nullptr;
     c->capA = c->capB = c->cap_small = c->cap_map = c->cap_rows = c->cap_b = 0;
 }
@@ -739,7 +1025,7 @@ void imp_sp_destroy(imp_sp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     free_ws(c);
-    for (ConvW* w : {&c->c1b, &c->c2a, &c->c2b, &c->c3a, &c->c3b, &c->c4a, &c->c4b, &c->heads, &c->db}) free_conv(*w);
+    for (ConvW* w : {&c->c1b, &c->c2a, &c->c2b, &c->c3a, &c->c3b, &c->c4a, &c->c4b, &c->heads, &c->db, &c->pb}) free_conv(*w);
     for (void* p : {(void*)c->w1a, (void*)c->b1a, (void*)c->wpb, (void*)c->bpb})
         if (p) (void)hipFree(p);
     delete c;
@@ -758,7 +1044,7 @@ int imp_sp_finalize(imp_sp_ctx* c) {
     if (!c) return imp_fail(IMP_E_ARG, "imp_sp_finalize: null context");
     SP_TRY(hipSetDevice(c->device));
     SP_TRY(hipDeviceSynchronize());
-    for (ConvW* w : {&c->c1b, &c->c2a, &c->c2b, &c->c3a, &c->c3b, &c->c4a, &c->c4b, &c->heads, &c->db}) free_conv(*w);
+    for (ConvW* w : {&c->c1b, &c->c2a, &c->c2b, &c->c3a, &c->c3b, &c->c4a, &c->c4b, &c->heads, &c->db, &c->pb}) free_conv(*w);
     for (float** p : {&c->w1a, &c->b1a, &c->wpb, &c->bpb})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     int rc;
@@ -775,6 +1061,20 @@ int imp_sp_finalize(imp_sp_ctx* c) {
     if (w1 == c->raw.end() || b1 == c->raw.end() || wp == c->raw.end() || bp == c->raw.end()) return imp_fail(IMP_E_KEY, "missing conv1a / convPb tensors");
     if (w1->second.data.size() != 64 * 9 || b1->second.data.size() != 64 || wp->second.data.size() != 65 * 256 || bp->second.data.size() != 65)
         return imp_fail(IMP_E_KEY, "conv1a / convPb tensors have unexpected sizes");
+    {   // convPb as an MFMA 1x1 convolution: 65 output channels padded with zero rows to 128
+        HostT wpad, bpad;
+        wpad.data.assign((size_t)128 * 256, 0.f);
+        bpad.data.assign(128, 0.f);
+        memcpy(wpad.data.data(), wp->second.data.data(), (size_t)65 * 256 * sizeof(float));
+        memcpy(bpad.data.data(), bp->second.data.data(), 65 * sizeof(float));
+        c->raw["convPb_padded.weight"] = std::move(wpad);
+        c->raw["convPb_padded.bias"] = std::move(bpad);
+        rc = pack_conv(c, {"convPb_padded"}, 256, 1, &c->pb);
+        c->raw.erase("convPb_padded.weight");
+        c->raw.erase("convPb_padded.bias");
+        if (rc) return rc;
+        w1 = c->raw.find("conv1a.weight"); b1 = c->raw.find("conv1a.bias"); wp = c->raw.find("convPb.weight"); bp = c->raw.find("convPb.bias");
+    }
     std::vector<float> w1t(9 * 64), wpt(256 * 65);
     for (int o = 0; o < 64; ++o)
         for (int t = 0; t < 9; ++t) w1t[t * 64 + o] = w1->second.data[o * 9 + t];
@@ -811,6 +1111,7 @@ int imp_sp_detect(imp_sp_ctx* c, const float* image, int B, int H, int W, int nm
         SP_TRY(hipMalloc(&c->bufA, std::max(needA, need_small) * 4));
         SP_TRY(hipMalloc(&c->bufB, needB * 4));
         SP_TRY(hipMalloc(&c->dmap, (size_t)B * h * w * 256 * 4));
+        SP_TRY(hipMalloc(&c->logits, (size_t)B * h * w * 128 * 4));
         SP_TRY(hipMalloc(&c->scores, need_map * 4));
         SP_TRY(hipMalloc(&c->nms, need_map * 4));
         SP_TRY(hipMalloc(&c->kp0, need_map * 8));
@@ -829,12 +1130,12 @@ int imp_sp_detect(imp_sp_ctx* c, const float* image, int B, int H, int W, int nm
     c->align_corners = align_corners ? 1 : 0;
     int rc;
     // encoder (nets/superpoint.py:172-183)
-    {
+    if (getenv("IMP_SP_UNFUSED_CONV1A")) {
         const size_t nthr = (size_t)B * H * W * 16;
         hipLaunchKernelGGL(sp_conv1a_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, image, c->w1a, c->b1a, c->bufA, B, H, W);
         SP_TRY(hipGetLastError());
-    }
-    if ((rc = launch_conv(c->c1b, c->bufA, 64, 0, B, H, W, c->bufB, 64, 1, 1, st))) return rc;          // -> [H2][W2][64]
+        if ((rc = launch_conv(c->c1b, c->bufA, 64, 0, B, H, W, c->bufB, 64, 1, 1, st))) return rc;
+    } else if ((rc = launch_conv_first(c, image, B, H, W, c->bufB, st))) return rc;                     // conv1a + conv1b -> [H2][W2][64]
     if ((rc = launch_conv(c->c2a, c->bufB, 64, 0, B, H2, W2, c->bufA, 64, 1, 0, st))) return rc;
     if ((rc = launch_conv(c->c2b, c->bufA, 64, 0, B, H2, W2, c->bufB, 64, 1, 1, st))) return rc;        // -> [H4][W4][64]
     if ((rc = launch_conv(c->c3a, c->bufB, 64, 0, B, H4, W4, c->bufA, 128, 1, 0, st))) return rc;
@@ -845,9 +1146,24 @@ int imp_sp_detect(imp_sp_ctx* c, const float* image, int B, int H, int W, int nm
     if ((rc = launch_conv(c->heads, c->bufB, 128, 0, B, h, w, c->bufA, 512, 1, 0, st))) return rc;
     if ((rc = launch_conv(c->db, c->bufA, 512, 256, B, h, w, c->dmap, c->ddim, 0, 0, st))) return rc;   // raw convDb (:224)
     const int npix = B * h * w;
-    hipLaunchKernelGGL(sp_detector_kernel, dim3((npix + DPX - 1) / DPX), dim3(256), 0, st, c->bufA, 512, c->wpb, c->bpb, c->scores, npix, h, w);
+    if (getenv("IMP_SP_DETECTOR_VALU")) {
+        hipLaunchKernelGGL(sp_detector_kernel, dim3((npix + DPX - 1) / DPX), dim3(256), 0, st, c->bufA, 512, c->wpb, c->bpb, c->scores, npix, h, w);
+    } else {
+        if ((rc = launch_conv(c->pb, c->bufA, 512, 0, B, h, w, c->logits, 128, 0, 0, st))) return rc;     // convPb logits (:193)
+        hipLaunchKernelGGL(sp_softmax_shuffle_kernel, dim3((npix + 3) / 4), dim3(256), 0, st, c->logits, c->scores, npix, h, w);
+    }
     SP_TRY(hipGetLastError());
-    {
+    if (nms_radius >= 1 && nms_radius <= 6 && !getenv("IMP_SP_NMS_GENERIC")) {
+        switch (nms_radius) {
+            case 1: rc = launch_nms_fast<1>(c->scores, c->nms, B, Hs, Ws, st); break;
+            case 2: rc = launch_nms_fast<2>(c->scores, c->nms, B, Hs, Ws, st); break;
+            case 3: rc = launch_nms_fast<3>(c->scores, c->nms, B, Hs, Ws, st); break;
+            case 4: rc = launch_nms_fast<4>(c->scores, c->nms, B, Hs, Ws, st); break;
+            case 5: rc = launch_nms_fast<5>(c->scores, c->nms, B, Hs, Ws, st); break;
+            default: rc = launch_nms_fast<6>(c->scores, c->nms, B, Hs, Ws, st); break;
+        }
+        if (rc) return rc;
+    } else {
         const int NT = nms_radius <= 6 ? 32 : 16;
         const int E = NT + 10 * nms_radius;
         const size_t lds = (size_t)E * E * (4 * 4 + 1);
@@ -884,10 +1200,8 @@ int imp_sp_describe(imp_sp_ctx* c, int b, float* keypoints, float* scores, float
     SP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     const size_t cap = (size_t)c->h * 8 * c->w * 8;
-    SP_TRY(hipMemcpyAsync(keypoints, c->kp1 + (size_t)b * cap * 2, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
-    SP_TRY(hipMemcpyAsync(scores, c->sc1 + (size_t)b * cap, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(sp_sample_kernel, dim3((n + 3) / 4), dim3(256), 0, st, c->kp1 + (size_t)b * cap * 2, n,
-                       c->dmap + (size_t)b * c->h * c->w * c->ddim, c->h, c->w, c->ddim, c->align_corners, descriptors);
+    hipLaunchKernelGGL(sp_sample_kernel, dim3((n + 3) / 4), dim3(256), 0, st, c->kp1 + (size_t)b * cap * 2, c->sc1 + (size_t)b * cap, n,
+                       c->dmap + (size_t)b * c->h * c->w * c->ddim, c->h, c->w, c->ddim, c->align_corners, keypoints, scores, descriptors);
     SP_TRY(hipGetLastError());
     return IMP_OK;
 }

@@ -158,6 +158,37 @@ def test_top_k_above_the_lds_capacity_takes_the_radix_select_path():
                          want['scores'][0].numpy(), True)
 
 
+def test_top_k_above_4096_takes_the_bitonic_path():
+    from oracle import superpoint_oracle as spo
+    spec = dict(wseed=8, config=dict(max_keypoints=5000, nms_radius=0, keypoint_threshold=0.0, remove_borders=0))
+    sp, sd = _module(spec, align_corners=False)
+    img = torch.from_numpy(synthetic.make_image(200, 240, seed=13))
+    out = sp({'image': img.cuda()})
+    want = spo.forward(sd, img, nms_radius=0, keypoint_threshold=0.0, max_keypoints=5000, remove_borders=0, align_corners=False)
+    sc = out['scores'][0].cpu()
+    assert sc.shape[0] == 5000 and bool((sc[:-1] >= sc[1:]).all())
+    match_keypoint_lists(out['keypoints'][0].cpu().numpy(), sc.numpy(), want['keypoints'][0].numpy(), want['scores'][0].numpy(), True)
+
+
+def test_top_k_with_exact_ties_at_the_cut_is_deterministic():
+    """all scores equal (zero detector head): torch.topk's choice among equal values is unspecified; this implementation takes
+    the lowest indices, i.e. the first k keypoints in nonzero (row-major) order, on every run"""
+    from imp_release_amd.superpoint import SuperPoint
+    sd = synthetic.make_superpoint_state_dict(seed=6)
+    sd['convPb.weight'][:] = 0
+    sd['convPb.bias'][:] = 0
+    img = torch.from_numpy(synthetic.make_image(64, 72, seed=1)).cuda()
+    full = SuperPoint({'state_dict': sd, 'max_keypoints': -1}, device=torch.device('cuda:0'))({'image': img})
+    n = full['keypoints'][0].shape[0]
+    assert n == 56 * 64                                                   # every pixel inside the border is a maximum
+    for k in (100, 3000):                                                 # below / above the rank-sort-only size
+        sp = SuperPoint({'state_dict': sd, 'max_keypoints': k}, device=torch.device('cuda:0'))
+        for _ in range(2):
+            out = sp({'image': img})
+            assert torch.equal(out['keypoints'][0], full['keypoints'][0][:k])
+            assert torch.equal(out['descriptors'][0], full['descriptors'][0][:, :k])
+
+
 def test_no_keypoints_above_the_threshold():
     spec = dict(wseed=9, config=dict(keypoint_threshold=2.0))
     sp, _ = _module(spec)
