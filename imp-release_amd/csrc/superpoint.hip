@@ -19,7 +19,7 @@
 //   sp_detector_kernel   convPb (256 -> 65, 1x1) + softmax over the 65 bins + drop the dustbin + 8x8 pixel shuffle, fp32 VALU
 //   sp_nms_kernel        the whole simple_nms chain (5 max-pools of radius R) for a 32 x 32 tile out of one LDS image with a 5R halo
 //   sp_rowcount / sp_scan / sp_compact   ordered compaction = torch.nonzero order (row major) with the border filter folded in
-//   sp_topk_kernel       top_k_keypoints: radix select (only above 16384 candidates) + bitonic sort of 64-bit keys in LDS
+//   sp_topk_select / sp_topk_rank   top_k_keypoints: radix select of the k-th score on one CU, rank sort of the survivors on many
 //   sp_sample_kernel     sample_descriptors: one wave per keypoint, bilinear taps of the L2-normalised dense map, re-normalised
 //
 // LDS bank check for the A-fragment reads (cdna_hip_programming.md section 2: ds_read_b128 is served in the lane groups
@@ -134,7 +134,16 @@ __global__ __launch_bounds__(256) void sp_conv_kernel(const SpConvParams p, int 
 #pragma unroll
             for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(p.w1a + t * 64 + sp_c);
             const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b1a + sp_c);
+            // the (LH + 2) x (LW + 2) image patch under the tile, zero outside the image (conv1a's own padding), through LDS
+            constexpr int PW = G::LW + 2, PH = G::LH + 2;
+            float* patch = reinterpret_cast<float*>(sp_smem + G::LDS);
             const float* im = p.img + (size_t)b * H * W;
+            if (tid < PW * PH) {
+                const int py = tid / PW, px = tid - py * PW;
+                const int yy = y0 - G::HALO - 1 + py, xx = x0 - G::HALO - 1 + px;
+                patch[tid] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? im[(size_t)yy * W + xx] : 0.f;
+            }
+            __syncthreads();
 #pragma unroll 2
             for (int s = 0; s < NPASS; ++s) {
                 const int pix = s * 16 + sp_pix;
@@ -146,8 +155,7 @@ __global__ __launch_bounds__(256) void sp_conv_kernel(const SpConvParams p, int 
                     a = bb;
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
-                        const int yy = gy + t / 3 - 1, xx = gx + t % 3 - 1;
-                        const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? im[(size_t)yy * W + xx] : 0.f;
+                        const float v = patch[(ly + t / 3) * PW + lx + t % 3];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) a[e] = fmaf(v, wv[t][e], a[e]);
                     }
@@ -191,33 +199,45 @@ __global__ __launch_bounds__(256) void sp_conv_kernel(const SpConvParams p, int 
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const bool last = chunk == nchunk - 1 && tap == TAPS - 1;
-            u32x4 nh[4], nl[4];
-            const u32x4* wnext = wp + (last ? 0 : 512);      // (last tap: harmless re-load)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { nh[c] = wnext[c * 128]; nl[c] = wnext[c * 128 + 64]; }
+        // K loop of this chunk, software pipelined by hand: the A fragments of k-step s + 1 are requested from LDS before the six
+        // MFMAs of k-step s are issued (sched_barrier keeps the compiler from sinking the reads behind them), the B fragments
+        // of the next tap are requested from L2 at the start of each tap
+        constexpr int NS = TAPS * 4;
+        f16x8 fah[2][2], fal[2][2];
+        auto load_frag = [&](int st, int buf) {
+            const int tap = st >> 2, c = st & 3;
             const int toff = TAPS == 9 ? ((tap / 3) * G::ROW_SLOTS + (tap % 3) * PSLOT) * 16 : 0;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                f16x8 ah[2], al[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    ah[i] = *reinterpret_cast<const f16x8*>(sp_smem + aoff[i] + toff + c * 32);
-                    al[i] = *reinterpret_cast<const f16x8*>(sp_smem + G::PLANE + aoff[i] + toff + c * 32);
-                }
-                const f16x8 wh = __builtin_bit_cast(f16x8, bh[c]), wl = __builtin_bit_cast(f16x8, bl[c]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh, acc[i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl, acc[i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh, acc[i], 0, 0, 0);
+            for (int i = 0; i < 2; ++i) {
+                fah[buf][i] = *reinterpret_cast<const f16x8*>(sp_smem + aoff[i] + toff + c * 32);
+                fal[buf][i] = *reinterpret_cast<const f16x8*>(sp_smem + G::PLANE + aoff[i] + toff + c * 32);
             }
+        };
+        load_frag(0, 0);
+        u32x4 nh[4], nl[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { bh[c] = nh[c]; bl[c] = nl[c]; }
-            wp = wnext;
+        for (int st = 0; st < NS; ++st) {
+            const int c = st & 3;
+            if (st + 1 < NS) load_frag(st + 1, (st + 1) & 1);
+            if (c == 0) {
+                const bool last = chunk == nchunk - 1 && st == NS - 4;
+                const u32x4* wnext = wp + (last ? 0 : 512);      // (last tap: harmless re-load)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) { nh[cc] = wnext[cc * 128]; nl[cc] = wnext[cc * 128 + 64]; }
+                wp = wnext;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const f16x8 wh = __builtin_bit_cast(f16x8, bh[c]), wl = __builtin_bit_cast(f16x8, bl[c]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[st & 1][i], wh, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[st & 1][i], wl, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[st & 1][i], wh, acc[i], 0, 0, 0);
+            if (c == 3) {
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) { bh[cc] = nh[cc]; bl[cc] = nl[cc]; }
+            }
         }
     }
 
@@ -605,12 +625,13 @@ __global__ __launch_bounds__(64) void sp_compact_kernel(const float* __restrict_
 
 // top_k_keypoints (nets/superpoint.py:74-79): k >= n keeps everything in nonzero order; otherwise the k best scores, descending
 // (torch.topk), equal scores in index order.  Keys = score bits (scores are positive floats: the bit pattern is monotone) : ~index.
-// One workgroup of 1024 threads per image:
-//   n > 2048: radix select of the k-th largest score (digits of 12 / 10 / 10 bits from the top, LDS histogram, parallel suffix scan)
-//             cuts the candidates to exactly k keys in LDS;
-//   m <= 4096 keys: rank sort - a key's final position is the number of larger keys, counted against broadcast LDS reads (no
-//             barriers); more: bitonic sort in LDS.
+//   sp_topk_select_kernel (one workgroup of 1024 threads per image): n <= k copies; n <= 2048 hands every key on; otherwise a
+//     radix select of the k-th largest score (digits of 12 / 10 / 10 bits from the top, LDS histogram, parallel suffix scan)
+//     cuts the candidates to exactly k keys.
+//   sp_topk_rank_kernel (256 keys per workgroup, so the chip - not one CU - does the m^2 comparisons): rank sort, a key's final
+//     position is the number of larger keys, counted against broadcast LDS reads; no barriers in the loop.
 constexpr int TOPK_CAP = 16384;
+constexpr int TOPK_DIRECT = 2048;
 
 // inclusive prefix sum over the 1024 threads of the block (wave shuffles + one LDS hop); all threads must call
 __device__ __forceinline__ unsigned sp_block_scan(unsigned v, unsigned* wave_tot /*[16]*/, int tid) {
@@ -629,11 +650,14 @@ __device__ __forceinline__ unsigned sp_block_scan(unsigned v, unsigned* wave_tot
     return x + base;
 }
 
-__global__ __launch_bounds__(1024) void sp_topk_kernel(const float* __restrict__ kp, const float* __restrict__ sc, const int* __restrict__ count,
-                                                       size_t cap, int k, float* __restrict__ kp_out, float* __restrict__ sc_out,
-                                                       int* __restrict__ count_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(sp_smem);
+__device__ __forceinline__ unsigned long long sp_key(unsigned score_bits, int i) {
+    return ((unsigned long long)score_bits << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
+}
+
+__global__ __launch_bounds__(1024) void sp_topk_select_kernel(const float* __restrict__ kp, const float* __restrict__ sc, const int* __restrict__ count,
+                                                              size_t cap, int k, float* __restrict__ kp_out, float* __restrict__ sc_out,
+                                                              int* __restrict__ count_out, unsigned long long* __restrict__ selkeys /*[B][TOPK_CAP]*/,
+                                                              int* __restrict__ sel_m) {
     __shared__ unsigned hist[4096];
     __shared__ unsigned wave_tot[16];
     __shared__ unsigned sel_prefix, sel_remaining, sel_count, eq_taken;
@@ -641,145 +665,126 @@ __global__ __launch_bounds__(1024) void sp_topk_kernel(const float* __restrict__
     const int n = count[b];
     const float* kpb = kp + (size_t)b * cap * 2;
     const float* scb = sc + (size_t)b * cap;
-    float* kpo = kp_out + (size_t)b * cap * 2;
-    float* sco = sc_out + (size_t)b * cap;
+    unsigned long long* keys = selkeys + (size_t)b * TOPK_CAP;
     if (k < 0 || k >= n) {
+        float* kpo = kp_out + (size_t)b * cap * 2;
+        float* sco = sc_out + (size_t)b * cap;
         for (int i = tid; i < n; i += 1024) {
             kpo[2 * (size_t)i] = kpb[2 * (size_t)i];
             kpo[2 * (size_t)i + 1] = kpb[2 * (size_t)i + 1];
             sco[i] = scb[i];
         }
-        if (tid == 0) count_out[b] = n;
+        if (tid == 0) { count_out[b] = n; sel_m[b] = 0; }
         return;
     }
-    int m;      // number of keys in LDS
-    if (n <= 2048) {
-        for (int i = tid; i < n; i += 1024) keys[i] = ((unsigned long long)__float_as_uint(scb[i]) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
-        m = n;
-    } else {
-        if (tid == 0) { sel_prefix = 0; sel_remaining = (unsigned)k; }
-        __syncthreads();
+    if (n <= TOPK_DIRECT) {
+        for (int i = tid; i < n; i += 1024) keys[i] = sp_key(__float_as_uint(scb[i]), i);
+        if (tid == 0) { count_out[b] = k; sel_m[b] = n; }
+        return;
+    }
+    if (tid == 0) { sel_prefix = 0; sel_remaining = (unsigned)k; }
+    __syncthreads();
 #pragma unroll 1
-        for (int pass = 0; pass < 3; ++pass) {
-            const int shift = pass == 0 ? 20 : pass == 1 ? 10 : 0;
-            const int bits = pass == 0 ? 12 : 10;
-            const int nb = 1 << bits;
-            for (int i = tid; i < nb; i += 1024) hist[i] = 0;
-            __syncthreads();
-            const unsigned prefix = sel_prefix;
-            const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + bits));
-            for (int i = tid; i < n; i += 1024) {
-                const unsigned u = __float_as_uint(scb[i]);
-                if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & (nb - 1)], 1u);
-            }
-            __syncthreads();
-            // thread t owns the bins nb-1 - per*t - j (descending), so the prefix over threads is the suffix over bins
-            const int per = nb >> 10;                     // 4 or 1
-            unsigned mine = 0;
-            for (int j = 0; j < per; ++j) mine += hist[nb - 1 - per * tid - j];
-            const unsigned incl = sp_block_scan(mine, wave_tot, tid);
-            const unsigned rem = sel_remaining;
-            __syncthreads();                              // everyone has read sel_remaining
-            if (incl - mine < rem && rem <= incl) {       // exactly one thread: the k-th largest falls into its bins
-                unsigned r = rem - (incl - mine);
-                int d = nb - 1 - per * tid;
-                for (int j = 0; j < per; ++j, --d) {
-                    if (hist[d] >= r) break;
-                    r -= hist[d];
-                }
-                sel_prefix = prefix | ((unsigned)d << shift);
-                sel_remaining = r;                        // how many of the elements with this prefix are still needed
-            }
-            __syncthreads();
-        }
-        const unsigned T = sel_prefix;
-        const unsigned need_eq = sel_remaining;           // elements == T to take
-        if (tid == 0) { sel_count = 0; eq_taken = 0; }
+    for (int pass = 0; pass < 3; ++pass) {
+        const int shift = pass == 0 ? 20 : pass == 1 ? 10 : 0;
+        const int bits = pass == 0 ? 12 : 10;
+        const int nb = 1 << bits;
+        for (int i = tid; i < nb; i += 1024) hist[i] = 0;
         __syncthreads();
-        // elements > T; and count the == T ones
+        const unsigned prefix = sel_prefix;
+        const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + bits));
         for (int i = tid; i < n; i += 1024) {
             const unsigned u = __float_as_uint(scb[i]);
-            if (u > T) {
+            if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & (nb - 1)], 1u);
+        }
+        __syncthreads();
+        // thread t owns the bins nb-1 - per*t - j (descending), so the prefix over threads is the suffix over bins
+        const int per = nb >> 10;                     // 4 or 1
+        unsigned mine = 0;
+        for (int j = 0; j < per; ++j) mine += hist[nb - 1 - per * tid - j];
+        const unsigned incl = sp_block_scan(mine, wave_tot, tid);
+        const unsigned rem = sel_remaining;
+        __syncthreads();                              // everyone has read sel_remaining
+        if (incl - mine < rem && rem <= incl) {       // exactly one thread: the k-th largest falls into its bins
+            unsigned r = rem - (incl - mine);
+            int d = nb - 1 - per * tid;
+            for (int j = 0; j < per; ++j, --d) {
+                if (hist[d] >= r) break;
+                r -= hist[d];
+            }
+            sel_prefix = prefix | ((unsigned)d << shift);
+            sel_remaining = r;                        // how many of the elements with this prefix are still needed
+        }
+        __syncthreads();
+    }
+    const unsigned T = sel_prefix;
+    const unsigned need_eq = sel_remaining;           // elements == T to take
+    if (tid == 0) { sel_count = 0; eq_taken = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {             // elements > T; count the == T ones
+        const unsigned u = __float_as_uint(scb[i]);
+        if (u > T) {
+            const unsigned slot = atomicAdd(&sel_count, 1u);
+            if (slot < (unsigned)TOPK_CAP) keys[slot] = sp_key(u, i);
+        } else if (u == T) {
+            atomicAdd(&eq_taken, 1u);
+        }
+    }
+    __syncthreads();
+    const unsigned n_eq = eq_taken, n_gt = sel_count;
+    __syncthreads();
+    if (n_eq == need_eq) {                            // (the usual case) every element == T is needed: order does not matter
+        for (int i = tid; i < n; i += 1024) {
+            const unsigned u = __float_as_uint(scb[i]);
+            if (u == T) {
                 const unsigned slot = atomicAdd(&sel_count, 1u);
-                if (slot < (unsigned)TOPK_CAP) keys[slot] = ((unsigned long long)u << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
-            } else if (u == T) {
-                atomicAdd(&eq_taken, 1u);
+                if (slot < (unsigned)TOPK_CAP) keys[slot] = sp_key(u, i);
             }
         }
-        __syncthreads();
-        const unsigned n_eq = eq_taken, n_gt = sel_count;
-        __syncthreads();
-        if (n_eq == need_eq) {                            // (the usual case) every element == T is needed: order does not matter
-            for (int i = tid; i < n; i += 1024) {
-                const unsigned u = __float_as_uint(scb[i]);
-                if (u == T) {
-                    const unsigned slot = atomicAdd(&sel_count, 1u);
-                    if (slot < (unsigned)TOPK_CAP) keys[slot] = ((unsigned long long)u << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
-                }
-            }
-        } else {                                          // exact ties at the cut: the first need_eq in index order (deterministic)
-            unsigned taken = 0;
-            for (int base = 0; base < n; base += 1024) {
-                const int i = base + tid;
-                const bool eq = i < n && __float_as_uint(scb[i]) == T;
-                const unsigned incl = sp_block_scan(eq ? 1u : 0u, wave_tot, tid);
-                const unsigned rank = taken + incl - 1u;
-                if (eq && rank < need_eq) keys[n_gt + rank] = ((unsigned long long)T << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)i);
-                __syncthreads();
-                if (tid == 1023) eq_taken = incl;         // block total of this chunk
-                __syncthreads();
-                taken += eq_taken;
-            }
-        }
-        __syncthreads();
-        m = k;                                            // n_gt + need_eq (the host rejects k > TOPK_CAP)
-    }
-    __syncthreads();
-    if (m <= 4096) {
-        // rank sort: thread owns keys tid, tid + 1024, ...; every key is read once by every wave (same address in all lanes)
-        unsigned long long mk[4];
-        unsigned rank[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) mk[j] = tid + 1024 * j < m ? keys[tid + 1024 * j] : ~0ull;
-        for (int i = 0; i < m; ++i) {
-            const unsigned long long o = keys[i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) rank[j] += o > mk[j] ? 1u : 0u;
-        }
-        for (int j = 0; j < 4; ++j) {
-            if (tid + 1024 * j < m && rank[j] < (unsigned)k) {
-                const unsigned idx = 0xFFFFFFFFu - (unsigned)(mk[j] & 0xFFFFFFFFull);
-                kpo[2 * (size_t)rank[j]] = kpb[2 * (size_t)idx];
-                kpo[2 * (size_t)rank[j] + 1] = kpb[2 * (size_t)idx + 1];
-                sco[rank[j]] = __uint_as_float((unsigned)(mk[j] >> 32));
-            }
-        }
-        if (tid == 0) count_out[b] = k;
-        return;
-    }
-    int m2 = 1;
-    while (m2 < m) m2 <<= 1;
-    for (int i = m + tid; i < m2; i += 1024) keys[i] = 0ull;
-    __syncthreads();
-    for (int size = 2; size <= m2; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < (m2 >> 1); t += 1024) {
-                const int lo = 2 * t - (t & (stride - 1));
-                const int hi = lo + stride;
-                const bool desc = (lo & size) == 0;
-                const unsigned long long x = keys[lo], y = keys[hi];
-                if (desc ? x < y : x > y) { keys[lo] = y; keys[hi] = x; }
-            }
+    } else {                                          // exact ties at the cut: the first need_eq in index order (deterministic)
+        unsigned taken = 0;
+        for (int base = 0; base < n; base += 1024) {
+            const int i = base + tid;
+            const bool eq = i < n && __float_as_uint(scb[i]) == T;
+            const unsigned incl = sp_block_scan(eq ? 1u : 0u, wave_tot, tid);
+            const unsigned rank = taken + incl - 1u;
+            if (eq && rank < need_eq && n_gt + rank < (unsigned)TOPK_CAP) keys[n_gt + rank] = sp_key(T, i);
             __syncthreads();
+            if (tid == 1023) eq_taken = incl;         // block total of this chunk
+            __syncthreads();
+            taken += eq_taken;
         }
-    for (int i = tid; i < k; i += 1024) {
-        const unsigned long long key = keys[i];
-        const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
-        kpo[2 * (size_t)i] = kpb[2 * (size_t)idx];
-        kpo[2 * (size_t)i + 1] = kpb[2 * (size_t)idx + 1];
-        sco[i] = __uint_as_float((unsigned)(key >> 32));
     }
-    if (tid == 0) count_out[b] = k;
+    if (tid == 0) { count_out[b] = k; sel_m[b] = k; } // n_gt + need_eq == k (the host rejects k > TOPK_CAP)
+}
+
+__global__ __launch_bounds__(256) void sp_topk_rank_kernel(const float* __restrict__ kp, size_t cap, int k, const unsigned long long* __restrict__ selkeys,
+                                                           const int* __restrict__ sel_m, float* __restrict__ kp_out, float* __restrict__ sc_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(sp_smem);
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int m = sel_m[b];
+    const int mine_i = blockIdx.x * 256 + tid;
+    if (blockIdx.x * 256 >= m) return;                // (m == 0: nothing to sort for this image)
+    const unsigned long long* src = selkeys + (size_t)b * TOPK_CAP;
+    const int m2 = (m + 1) & ~1;
+    for (int i = tid; i < m2; i += 256) keys[i] = i < m ? src[i] : 0ull;
+    __syncthreads();
+    const unsigned long long mk = mine_i < m ? keys[mine_i] : ~0ull;
+    unsigned rank = 0;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    for (int i = 0; i < m2; i += 2) {                 // every lane reads the same 16 bytes: one broadcast LDS access per two keys
+        const u64x2 o = *reinterpret_cast<const u64x2*>(keys + i);
+        rank += (o[0] > mk ? 1u : 0u) + (o[1] > mk ? 1u : 0u);
+    }
+    if (mine_i < m && rank < (unsigned)k) {
+        const unsigned idx = 0xFFFFFFFFu - (unsigned)(mk & 0xFFFFFFFFull);
+        const float* kpb = kp + (size_t)b * cap * 2;
+        float* kpo = kp_out + (size_t)b * cap * 2;
+        kpo[2 * (size_t)rank] = kpb[2 * (size_t)idx];
+        kpo[2 * (size_t)rank + 1] = kpb[2 * (size_t)idx + 1];
+        sc_out[(size_t)b * cap + rank] = __uint_as_float((unsigned)(mk >> 32));
+    }
 }
 
 // sample_descriptors (nets/superpoint.py:82-94): one wave per keypoint, lane = 4 channels (D <= 256, D % 4 == 0).  dmap is the raw
@@ -878,7 +883,8 @@ struct imp_sp_ctx {
     size_t capA = 0, capB = 0, cap_small = 0, cap_map = 0, cap_rows = 0, cap_b = 0;
     float *bufA = nullptr, *bufB = nullptr, *dmap = nullptr, *logits = nullptr, *scores = nullptr, *nms = nullptr;
     float *kp0 = nullptr, *sc0 = nullptr, *kp1 = nullptr, *sc1 = nullptr;
-    int *rowcount = nullptr, *rowoff = nullptr, *count0 = nullptr, *count1 = nullptr;
+    int *rowcount = nullptr, *rowoff = nullptr, *count0 = nullptr, *count1 = nullptr, *sel_m = nullptr;
+    unsigned long long* selkeys = nullptr;
     std::vector<int> counts;
     int align_corners = 1;
     bool detected = false;
@@ -951,8 +957,9 @@ template <int TAPS, int POOL, int FIRST>
 int launch_conv_t(const SpConvParams& p, hipStream_t st) {
     const int total = p.B * p.tiles_x * p.tiles_y * (p.cout / 64);
     const void* fn = reinterpret_cast<const void*>(&sp_conv_kernel<TAPS, POOL, FIRST>);
-    SP_TRY(imp_grant_dynamic_lds(fn, Geo<TAPS>::LDS));
-    hipLaunchKernelGGL((sp_conv_kernel<TAPS, POOL, FIRST>), dim3(total), dim3(256), Geo<TAPS>::LDS, st, p, total);
+    constexpr size_t lds = Geo<TAPS>::LDS + (FIRST ? 1024 : 0);       // + the image patch of the fused conv1a
+    SP_TRY(imp_grant_dynamic_lds(fn, lds));
+    hipLaunchKernelGGL((sp_conv_kernel<TAPS, POOL, FIRST>), dim3(total), dim3(256), lds, st, p, total);
     SP_TRY(hipGetLastError());
     return IMP_OK;
 }
@@ -996,10 +1003,11 @@ int launch_conv_first(const imp_sp_ctx* c, const float* image, int B, int H, int
 
 void free_ws(imp_sp_ctx* c) {
     for (void* p : {(void*)c->bufA, (void*)c->bufB, (void*)c->dmap, (void*)c->logits, (void*)c->scores, (void*)c->nms, (void*)c->kp0, (void*)c->sc0, (void*)c->kp1,
-                    (void*)c->sc1, (void*)c->rowcount, (void*)c->rowoff, (void*)c->count0, (void*)c->count1})
+                    (void*)c->sc1, (void*)c->rowcount, (void*)c->rowoff, (void*)c->count0, (void*)c->count1, (void*)c->sel_m, (void*)c->selkeys})
         if (p) (void)hipFree(p);
     c->bufA = c->bufB = c->dmap = c->logits = c->scores = c->nms = c->kp0 = c->sc0 = c->kp1 = c->sc1 = nullptr;
-    c->rowcount = c->rowoff = c->count0 = c->count1 = nullptr;
+    c->rowcount = c->rowoff = c->count0 = c->count1 = c->sel_m = nullptr;
+    c->selkeys = nullptr;
     c->capA = c->capB = c->cap_small = c->cap_map = c->cap_rows = c->cap_b = 0;
 }
 
@@ -1122,6 +1130,8 @@ int imp_sp_detect(imp_sp_ctx* c, const float* image, int B, int H, int W, int nm
         SP_TRY(hipMalloc(&c->rowoff, (size_t)B * Hs * 4));
         SP_TRY(hipMalloc(&c->count0, (size_t)B * 4));
         SP_TRY(hipMalloc(&c->count1, (size_t)B * 4));
+        SP_TRY(hipMalloc(&c->sel_m, (size_t)B * 4));
+        SP_TRY(hipMalloc(&c->selkeys, (size_t)B * TOPK_CAP * 8));
         c->capA = std::max(needA, need_small); c->capB = needB; c->cap_small = need_small; c->cap_map = need_map;
         c->cap_rows = (size_t)B * Hs; c->cap_b = (size_t)B;
     }
@@ -1177,10 +1187,15 @@ int imp_sp_detect(imp_sp_ctx* c, const float* image, int B, int H, int W, int nm
     hipLaunchKernelGGL(sp_scan_kernel, dim3(B), dim3(1024), 0, st, c->rowcount, Hs, c->rowoff, c->count0);
     hipLaunchKernelGGL(sp_compact_kernel, dim3(Hs, B), dim3(64), 0, st, c->nms, Hs, Ws, keypoint_threshold, remove_borders, c->rowoff, c->kp0, c->sc0, cap);
     SP_TRY(hipGetLastError());
-    {
-        const size_t lds = (size_t)TOPK_CAP * 8;
-        SP_TRY(imp_grant_dynamic_lds(reinterpret_cast<const void*>(&sp_topk_kernel), lds));
-        hipLaunchKernelGGL(sp_topk_kernel, dim3(B), dim3(1024), lds, st, c->kp0, c->sc0, c->count0, cap, max_keypoints, c->kp1, c->sc1, c->count1);
+    hipLaunchKernelGGL(sp_topk_select_kernel, dim3(B), dim3(1024), 0, st, c->kp0, c->sc0, c->count0, cap, max_keypoints, c->kp1, c->sc1, c->count1,
+                       c->selkeys, c->sel_m);
+    SP_TRY(hipGetLastError());
+    if (max_keypoints >= 0) {
+        const int mmax = std::max(max_keypoints, TOPK_DIRECT);
+        const size_t lds = (size_t)mmax * 8;
+        SP_TRY(imp_grant_dynamic_lds(reinterpret_cast<const void*>(&sp_topk_rank_kernel), lds));
+        hipLaunchKernelGGL(sp_topk_rank_kernel, dim3((mmax + 255) / 256, B), dim3(256), lds, st, c->kp0, cap, max_keypoints, c->selkeys, c->sel_m,
+                           c->kp1, c->sc1);
         SP_TRY(hipGetLastError());
     }
     SP_TRY(hipMemcpyAsync(counts, c->count1, (size_t)B * 4, hipMemcpyDeviceToHost, st));

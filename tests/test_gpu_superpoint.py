@@ -146,8 +146,8 @@ def test_top_k_is_sorted_and_matches_the_oracle(k):
     assert float((out['descriptors'][0].cpu() - want['descriptors'][0][:, perm]).abs().max()) < 1e-4
 
 
-def test_top_k_above_the_lds_capacity_takes_the_radix_select_path():
-    """more than 16384 candidates (nms_radius 0 on a 200 x 240 map: every pixel above the threshold is a keypoint)"""
+def test_top_k_radix_select_path_with_48000_candidates():
+    """nms_radius 0 on a 200 x 240 map: every pixel above the threshold is a candidate"""
     from oracle import superpoint_oracle as spo
     spec = dict(wseed=8, config=dict(max_keypoints=500, nms_radius=0, keypoint_threshold=0.0, remove_borders=0))
     sp, sd = _module(spec, align_corners=False)
@@ -158,7 +158,7 @@ def test_top_k_above_the_lds_capacity_takes_the_radix_select_path():
                          want['scores'][0].numpy(), True)
 
 
-def test_top_k_above_4096_takes_the_bitonic_path():
+def test_top_k_of_5000_out_of_48000_candidates():
     from oracle import superpoint_oracle as spo
     spec = dict(wseed=8, config=dict(max_keypoints=5000, nms_radius=0, keypoint_threshold=0.0, remove_borders=0))
     sp, sd = _module(spec, align_corners=False)
@@ -181,7 +181,7 @@ def test_top_k_with_exact_ties_at_the_cut_is_deterministic():
     full = SuperPoint({'state_dict': sd, 'max_keypoints': -1}, device=torch.device('cuda:0'))({'image': img})
     n = full['keypoints'][0].shape[0]
     assert n == 56 * 64                                                   # every pixel inside the border is a maximum
-    for k in (100, 3000):                                                 # below / above the rank-sort-only size
+    for k in (100, 3000):
         sp = SuperPoint({'state_dict': sd, 'max_keypoints': k}, device=torch.device('cuda:0'))
         for _ in range(2):
             out = sp({'image': img})

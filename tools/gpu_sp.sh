@@ -11,4 +11,20 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/spprof -o sp -- python $R/tools/probe/sp_time.py 480 640 1024 30 > /tmp/spprof.log 2>&1
 f=$(find /tmp/spprof -name '*kernel_stats.csv' | head -1)
 cp "$f" $R/gpurun_out/sp/sp_480x640_kernel_stats.csv 2>/dev/null
-head -20 "$f" | cut -c1-200
+head -24 "$f" | cut -c1-200
+t=$(find /tmp/spprof -name '*kernel_trace.csv' | head -1)
+python - "$t" <<'PY' | tee $R/gpurun_out/sp/sp_480x640_per_layer.txt
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+agg = collections.OrderedDict()
+for r in rows:
+    name = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('(anonymous namespace)::', '')
+    if 'sp_' not in name:
+        continue
+    key = (name, r['Grid_Size_X'] if 'Grid_Size_X' in r else r.get('Grid_Size', '?'))
+    agg.setdefault(key, []).append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+print('per dispatch (kernel, grid threads): n, median us')
+for (name, grid), v in agg.items():
+    v = sorted(v)
+    print(f'  {name:40s} grid {grid:>9s}  n={len(v):3d}  median {v[len(v) // 2]:8.2f} us')
+PY
