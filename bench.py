@@ -149,8 +149,28 @@ def batch1_latencies(dev, args):
         out['eimp_n4096_ms_per_pair'] = timeit(
             lambda: matching.matching_iterative_uncertainty(d, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, trace=tr), 4, 1)
         out['eimp_n4096_trajectory'] = [(t['n0'], t['n1']) for t in tr[-7:]]
+        # the SuperPoint front-end (image -> keypoints + descriptors) that feeds the matcher, and the chain image
+        # pair -> 2 x SuperPoint -> GM (configs[1] shape: top-1024 keypoints per image), everything on the GPU
+        from imp_release_amd.superpoint import SuperPoint
+        sp = SuperPoint({'state_dict': synthetic.make_superpoint_state_dict(seed=1), 'max_keypoints': 1024}, device=dev)
+        imgs = [torch.from_numpy(synthetic.make_image(480, 640, seed=s)).to(dev) for s in (5, 6)]
+        out['superpoint_480x640_ms_per_image'] = timeit(lambda: sp({'image': imgs[0]}), 30, 3)
+        m = model_of('GM', eval_config(9, 100))
+
+        def chain():
+            dd = {}
+            for i, im in enumerate(imgs):
+                o = sp({'image': im})
+                dd[f'keypoints{i}'] = o['keypoints'][0][None]
+                dd[f'scores{i}'] = o['scores'][0][None]
+                dd[f'descriptors{i}'] = o['descriptors'][0].t()[None].contiguous()
+                dd[f'image{i}'] = im
+            return m.produce_matches(dd, p=0.2, only_last=True)
+        out['image_pair_to_matches_ms'] = timeit(chain, 20, 3)
     out['batch1_note'] = ('c2 = BASELINE configs[1] (GM, N=1024, 9 iterations, 100 Sinkhorn, batch 1, one call after the other); '
-                          'eimp = configs[3] (AdaGMN sliced loop from N=4096/4000, 15 iterations, 7 score+pool steps, bin_score 5, pose stubbed)')
+                          'eimp = configs[3] (AdaGMN sliced loop from N=4096/4000, 15 iterations, 7 score+pool steps, bin_score 5, pose stubbed); '
+                          'superpoint = nets/superpoint.py forward on one 480x640 image, top-1024, seeded random weights; image_pair_to_matches = '
+                          '2 x SuperPoint + GM (L=9, T=100) on the 1024 + 1024 keypoints it returns, batch 1')
     return out
 
 

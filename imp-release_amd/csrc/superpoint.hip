@@ -29,6 +29,7 @@
 #include "imp_kernels.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -71,6 +72,7 @@ struct SpConvParams {
     const float* img;     // FIRST: the image [B][H][W]; the input tile is relu(conv1a(img)) computed while staging
     const float* w1a;     // [9][64]
     const float* b1a;
+    unsigned long long* prof;   // probe (IMP_SP_PROF): [block][4] cycle stamps of wave 0: start, staged, K loop done, stored
 };
 
 // bijective XCD-aware remap of a linear block id (hardware places block b on XCD b % 8): each XCD gets a contiguous chunk of
@@ -96,6 +98,8 @@ __global__ __launch_bounds__(256) void sp_conv_kernel(const SpConvParams p, int 
     const int b = z / p.tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
     const int H = p.H, W = p.W;
+    unsigned long long t_start = 0, t_staged = 0, t_kdone = 0, t_stage_acc = 0, t_k_acc = 0;
+    if (p.prof) t_start = __builtin_readcyclecounter();
 
     // the lane's A rows: fragment i covers tile rows m = 64 wm + 32 i + (lane & 31), m = 4 q + r, q = pooling window (4 x 8 per tile)
     int aoff[2];
@@ -199,6 +203,7 @@ __global__ __launch_bounds__(256) void sp_conv_kernel(const SpConvParams p, int 
             }
         }
         __syncthreads();
+        if (p.prof) { t_staged = __builtin_readcyclecounter(); t_stage_acc += t_staged - (chunk ? t_kdone : t_start); }
         // K loop of this chunk, software pipelined by hand: the A fragments of k-step s + 1 are requested from LDS before the six
         // MFMAs of k-step s are issued (sched_barrier keeps the compiler from sinking the reads behind them), the B fragments
         // of the next tap are requested from L2 at the start of each tap
@@ -239,6 +244,7 @@ __global__ __launch_bounds__(256) void sp_conv_kernel(const SpConvParams p, int 
                 for (int cc = 0; cc < 4; ++cc) { bh[cc] = nh[cc]; bl[cc] = nl[cc]; }
             }
         }
+        if (p.prof) { t_kdone = __builtin_readcyclecounter(); t_k_acc += t_kdone - t_staged; }
     }
 
     // epilogue: accumulator register r of fragment i holds tile row 64 wm + 32 i + 4 half + (r & 3) + 8 (r >> 2), column lane & 31
@@ -268,6 +274,283 @@ __global__ __launch_bounds__(256) void sp_conv_kernel(const SpConvParams p, int 
                 }
             }
         }
+    if (p.prof && tid == 0) {
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        unsigned long long* o = p.prof + (size_t)blockIdx.x * 4;
+        o[0] = t_stage_acc; o[1] = t_k_acc; o[2] = t_end - t_kdone; o[3] = t_end - t_start;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Persistent producer / consumer form of the convolution (the default): one workgroup of 8 waves per CU loops over its share
+// of the (tile, 64-channel group) jobs.  Waves 4-7 are LOADERS - they stage the input tile of unit u + 1 (unit = one 64-channel
+// input chunk of a job) into the second LDS buffer, for the first layer computing conv1a on the way - while waves 0-3 run the
+// MFMA K loop of unit u out of the first; one barrier per unit swaps the roles of the buffers.  The two wave kinds share each
+// SIMD, so the loaders' global loads, conversions and LDS writes fill the issue slots the MFMA chain leaves free (measured on
+// the one-tile-per-workgroup kernel above: staging + epilogue were 45-55 % of a workgroup's life and idle time for the matrix
+// pipe).  The MFMA operands are swapped with respect to that kernel - weights first - so an accumulator register holds four
+// consecutive CHANNELS of the lane's pixel: the epilogue writes 16-byte vectors (8 stores per thread instead of 32) and the 2x2
+// max-pool is two DPP quad permutes (the four pixels of a pooling window are four adjacent lanes).
+__device__ __forceinline__ float sp_quad_max(float v) {
+    int x = __builtin_bit_cast(int, v);
+    float a = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+    v = fmaxf(v, a);
+    x = __builtin_bit_cast(int, v);
+    a = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true));            // quad_perm [2,3,0,1]
+    return fmaxf(v, a);
+}
+
+template <int TAPS, int POOL, int FIRST>
+__global__ __launch_bounds__(512) void sp_convp_kernel(const SpConvParams p, int njobs) {
+    using G = Geo<TAPS>;
+    constexpr int PATCH = FIRST ? 1024 : 0;
+    constexpr int BUF = G::LDS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];       // [2][BUF] tiles, then [2][PATCH] image patches
+    const int tid = threadIdx.x;
+    const bool loader = tid >= 256;
+    const int lt = tid & 255, lane = tid & 63, wave = lt >> 6;
+    const int H = p.H, W = p.W;
+    const int nchunk = p.cin >> 6, nt = p.cout >> 6;
+    const int nwg = gridDim.x;
+    const int myjobs = (njobs - (int)blockIdx.x + nwg - 1) / nwg;
+    const int U = myjobs * nchunk;
+
+    auto decode = [&](int unit, int& b, int& y0, int& x0, int& ntile, int& chunk) {
+        const int job = unit / nchunk;
+        chunk = unit - job * nchunk;
+        int z = xcd_remap((int)blockIdx.x + job * nwg, njobs);     // (nwg is a multiple of 8 whenever a workgroup has a second job)
+        ntile = z % nt; z /= nt;
+        const int tx = z % p.tiles_x; z /= p.tiles_x;
+        const int ty = z % p.tiles_y;
+        b = z / p.tiles_y;
+        y0 = ty * TH; x0 = tx * TW;
+    };
+
+    // ------------------------------------------------------------------------------------------------ loader side
+    constexpr int NPIX = G::LH * G::LW;
+    constexpr int NPASS = (NPIX + 15) / 16;
+    const int sp_pix = lt >> 4, sp_c = (lt & 15) * 4;
+    constexpr int PW = G::LW + 2, PH = G::LH + 2;
+    auto load_patch = [&](int unit) {                 // FIRST: the image patch under the tile of `unit`, zero outside the image
+        int b, y0, x0, ntile, chunk;
+        decode(unit, b, y0, x0, ntile, chunk);
+        float* patch = reinterpret_cast<float*>(sp_smem + 2 * BUF + (unit & 1) * PATCH);
+        if (lt < PW * PH) {
+            const int py = lt / PW, px = lt - py * PW;
+            const int yy = y0 - G::HALO - 1 + py, xx = x0 - G::HALO - 1 + px;
+            patch[lt] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? p.img[((size_t)b * H + yy) * W + xx] : 0.f;
+        }
+    };
+    auto stage = [&](int unit) {
+        int b, y0, x0, ntile, chunk;
+        decode(unit, b, y0, x0, ntile, chunk);
+        unsigned char* buf = sp_smem + (unit & 1) * BUF;
+        if (FIRST) {
+            f32x4 wv[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(p.w1a + t * 64 + sp_c);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b1a + sp_c);
+            const float* patch = reinterpret_cast<const float*>(sp_smem + 2 * BUF + (unit & 1) * PATCH);
+#pragma unroll 2
+            for (int s = 0; s < NPASS; ++s) {
+                const int pix = s * 16 + sp_pix;
+                if (pix >= NPIX) break;
+                const int ly = pix / G::LW, lx = pix - ly * G::LW;
+                const int gy = y0 - G::HALO + ly, gx = x0 - G::HALO + lx;
+                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    a = bb;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const float v = patch[(ly + t / 3) * PW + lx + t % 3];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a[e] = fmaf(v, wv[t][e], a[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.f);
+                }
+                u32x2 hi, lo;
+                unsigned ua, uc;
+                imp_split2(a[0], a[1], ua, uc); hi[0] = ua; lo[0] = uc;
+                imp_split2(a[2], a[3], ua, uc); hi[1] = ua; lo[1] = uc;
+                unsigned char* dst = buf + (ly * G::ROW_SLOTS + lx * PSLOT) * 16 + sp_c * 2;
+                *reinterpret_cast<u32x2*>(dst) = hi;
+                *reinterpret_cast<u32x2*>(dst + G::PLANE) = lo;
+            }
+        } else {
+            const float* src = p.in + p.in_c0 + chunk * 64 + sp_c;
+            f32x4 v[NPASS];
+#pragma unroll
+            for (int s = 0; s < NPASS; ++s) {
+                const int pix = s * 16 + sp_pix;
+                const int ly = pix / G::LW, lx = pix - ly * G::LW;
+                const int gy = y0 - G::HALO + ly, gx = x0 - G::HALO + lx;
+                const bool ok = pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                v[s] = f32x4{0.f, 0.f, 0.f, 0.f};                                   // zero padding of the convolution
+                if (ok) v[s] = *reinterpret_cast<const f32x4*>(src + ((size_t)(b * H + gy) * W + gx) * p.in_ld);
+            }
+#pragma unroll
+            for (int s = 0; s < NPASS; ++s) {
+                const int pix = s * 16 + sp_pix;
+                if (pix < NPIX) {
+                    const int ly = pix / G::LW, lx = pix - ly * G::LW;
+                    u32x2 hi, lo;
+                    unsigned a, c;
+                    imp_split2(v[s][0], v[s][1], a, c); hi[0] = a; lo[0] = c;
+                    imp_split2(v[s][2], v[s][3], a, c); hi[1] = a; lo[1] = c;
+                    unsigned char* dst = buf + (ly * G::ROW_SLOTS + lx * PSLOT) * 16 + sp_c * 2;
+                    *reinterpret_cast<u32x2*>(dst) = hi;
+                    *reinterpret_cast<u32x2*>(dst + G::PLANE) = lo;
+                }
+            }
+        }
+    };
+
+    // ------------------------------------------------------------------------------------------------ consumer side
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5;
+    int aoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = 64 * wm + 32 * i + (lane & 31);
+        const int q = m >> 2, r = m & 3;
+        const int py = 2 * (q >> 3) + (r >> 1), px = 2 * (q & 7) + (r & 1);
+        aoff[i] = (py * G::ROW_SLOTS + px * PSLOT) * 16 + half * 16;
+    }
+    const int ksteps = nchunk * TAPS * 4;
+    auto wbase = [&](int unit) -> const u32x4* {
+        int b, y0, x0, ntile, chunk;
+        decode(unit, b, y0, x0, ntile, chunk);
+        return p.wf + ((size_t)(ntile * 2 + wn) * ksteps + chunk * TAPS * 4) * 128 + lane;
+    };
+    f32x16 acc[2];
+    u32x4 bh[4], bl[4];
+    unsigned long long pa = 0, pb = 0, pc = 0, t0 = 0, t1 = 0;      // probe: loader: staging / barrier wait; consumer: K loop / epilogue / wait
+    const bool prof = p.prof != nullptr;
+
+    // ------------------------------------------------------------------------------------------------ pipeline
+    if (FIRST) {
+        if (loader) load_patch(0);
+        __syncthreads();
+    }
+    if (loader) {
+        stage(0);
+        if (FIRST && 1 < U) load_patch(1);
+    } else {
+        const u32x4* w0 = wbase(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { bh[c] = w0[c * 128]; bl[c] = w0[c * 128 + 64]; }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int u = 0; u < U; ++u) {
+        if (prof) t0 = __builtin_readcyclecounter();
+        if (loader) {
+            if (u + 1 < U) stage(u + 1);
+            if (FIRST && u + 2 < U) load_patch(u + 2);
+            if (prof) { t1 = __builtin_readcyclecounter(); pa += t1 - t0; }
+        } else {
+            int b, y0, x0, ntile, chunk;
+            decode(u, b, y0, x0, ntile, chunk);
+            const unsigned char* buf = sp_smem + (u & 1) * BUF;
+            if (chunk == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            }
+            const u32x4* wp = wbase(u);
+            const u32x4* wfollow = u + 1 < U ? wbase(u + 1) : wp;        // first tap of the next unit (or a harmless re-load)
+            constexpr int NS = TAPS * 4;
+            f16x8 fah[2][2], fal[2][2];
+            auto load_frag = [&](int st, int fb) {
+                const int tap = st >> 2, c = st & 3;
+                const int toff = TAPS == 9 ? ((tap / 3) * G::ROW_SLOTS + (tap % 3) * PSLOT) * 16 : 0;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fah[fb][i] = *reinterpret_cast<const f16x8*>(buf + aoff[i] + toff + c * 32);
+                    fal[fb][i] = *reinterpret_cast<const f16x8*>(buf + G::PLANE + aoff[i] + toff + c * 32);
+                }
+            };
+            load_frag(0, 0);
+            u32x4 nh[4], nl[4];
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                const int c = st & 3;
+                if (st + 1 < NS) load_frag(st + 1, (st + 1) & 1);
+                if (c == 0) {
+                    const u32x4* wnext = st == NS - 4 ? wfollow : wp + 512;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) { nh[cc] = wnext[cc * 128]; nl[cc] = wnext[cc * 128 + 64]; }
+                    wp = wnext;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const f16x8 wh = __builtin_bit_cast(f16x8, bh[c]), wl = __builtin_bit_cast(f16x8, bl[c]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fal[st & 1][i], acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, fah[st & 1][i], acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fah[st & 1][i], acc[i], 0, 0, 0);
+                if (c == 3) {
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) { bh[cc] = nh[cc]; bl[cc] = nl[cc]; }
+                }
+            }
+            if (prof) { t1 = __builtin_readcyclecounter(); pa += t1 - t0; t0 = t1; }
+            if (chunk == nchunk - 1) {
+                // epilogue: register r of fragment i = channel cb + 4 half + (r & 3) + 8 (r >> 2) of the lane's pixel m = 64 wm + 32 i + lane % 32
+                const int cb = ntile * 64 + wn * 32 + 4 * half;
+                f32x4 bv[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const f32x4*>(p.bias + cb + 8 * g);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int m = 64 * wm + 32 * i + (lane & 31);
+                    const int q = m >> 2, r = m & 3;
+                    if (POOL) {
+                        const int Ho = H / 2, Wo = W / 2;
+                        f32x4 sel = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[e] = sp_quad_max(acc[i][4 * g + e]) + bv[g][e];
+                                if (p.relu) v[e] = fmaxf(v[e], 0.f);
+                            }
+                            if (r == g) sel = v;                               // lane r of the quad stores channel group g = r
+                        }
+                        const int py = y0 / 2 + (q >> 3), px = x0 / 2 + (q & 7);
+                        if (py < Ho && px < Wo)
+                            *reinterpret_cast<f32x4*>(p.out + ((size_t)(b * Ho + py) * Wo + px) * p.out_ld + cb + 8 * r) = sel;
+                    } else {
+                        const int y = y0 + 2 * (q >> 3) + (r >> 1), x = x0 + 2 * (q & 7) + (r & 1);
+                        if (y < H && x < W) {
+                            float* o = p.out + ((size_t)(b * H + y) * W + x) * p.out_ld + cb;
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                f32x4 v;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    v[e] = acc[i][4 * g + e] + bv[g][e];
+                                    if (p.relu) v[e] = fmaxf(v[e], 0.f);
+                                }
+                                *reinterpret_cast<f32x4*>(o + 8 * g) = v;
+                            }
+                        }
+                    }
+                }
+            }
+            if (prof) { t1 = __builtin_readcyclecounter(); pb += t1 - t0; }
+        }
+        __syncthreads();
+        if (prof) pc += __builtin_readcyclecounter() - t1;
+    }
+    if (prof && (tid == 0 || tid == 256)) {
+        unsigned long long* o = p.prof + (size_t)blockIdx.x * 8 + (loader ? 4 : 0);
+        o[0] = pa; o[1] = pb; o[2] = pc; o[3] = (unsigned long long)U;
+    }
 }
 
 // conv1a (nets/superpoint.py:120,142): one input channel, 64 output channels; 16 threads per pixel, 4 channels each
@@ -767,15 +1050,21 @@ __global__ __launch_bounds__(256) void sp_topk_rank_kernel(const float* __restri
     const int mine_i = blockIdx.x * 256 + tid;
     if (blockIdx.x * 256 >= m) return;                // (m == 0: nothing to sort for this image)
     const unsigned long long* src = selkeys + (size_t)b * TOPK_CAP;
-    const int m2 = (m + 1) & ~1;
-    for (int i = tid; i < m2; i += 256) keys[i] = i < m ? src[i] : 0ull;
+    const int m2 = (m + 15) & ~15;
+    for (int i = tid; i < m2; i += 256) keys[i] = i < m ? src[i] : 0ull;      // (padding keys are smaller than every real key)
     __syncthreads();
     const unsigned long long mk = mine_i < m ? keys[mine_i] : ~0ull;
+    const unsigned mhi = (unsigned)(mk >> 32), mlo = (unsigned)mk;
     unsigned rank = 0;
-    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    for (int i = 0; i < m2; i += 2) {                 // every lane reads the same 16 bytes: one broadcast LDS access per two keys
-        const u64x2 o = *reinterpret_cast<const u64x2*>(keys + i);
-        rank += (o[0] > mk ? 1u : 0u) + (o[1] > mk ? 1u : 0u);
+    for (int i = 0; i < m2; i += 16) {                // every lane reads the same 16 bytes: one broadcast LDS access per two keys
+        u32x4 o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = *reinterpret_cast<const u32x4*>(keys + i + 2 * j);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                 // (little endian: [0] = ~index, [1] = score bits)
+            rank += (o[j][1] > mhi || (o[j][1] == mhi && o[j][0] > mlo)) ? 1u : 0u;
+            rank += (o[j][3] > mhi || (o[j][3] == mhi && o[j][2] > mlo)) ? 1u : 0u;
+        }
     }
     if (mine_i < m && rank < (unsigned)k) {
         const unsigned idx = 0xFFFFFFFFu - (unsigned)(mk & 0xFFFFFFFFull);
@@ -956,9 +1245,54 @@ void free_conv(ConvW& w) {
 template <int TAPS, int POOL, int FIRST>
 int launch_conv_t(const SpConvParams& p, hipStream_t st) {
     const int total = p.B * p.tiles_x * p.tiles_y * (p.cout / 64);
+    static const bool v1 = getenv("IMP_SP_CONV_V1") != nullptr;         // A/B: the one-tile-per-workgroup kernel
+    if (!v1) {
+        int dev = 0, ncu = 256;
+        SP_TRY(hipGetDevice(&dev));
+        SP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        const int nwg = total < ncu ? total : (ncu / 8) * 8;
+        constexpr size_t ldsp = 2 * Geo<TAPS>::LDS + (FIRST ? 2048 : 0);
+        const void* fnp = reinterpret_cast<const void*>(&sp_convp_kernel<TAPS, POOL, FIRST>);
+        SP_TRY(imp_grant_dynamic_lds(fnp, ldsp));
+        if (getenv("IMP_SP_PROF")) {                                    // probe: phase cycle counts per workgroup, printed per launch
+            SpConvParams q = p;
+            SP_TRY(hipMalloc(&q.prof, (size_t)nwg * 8 * sizeof(unsigned long long)));
+            hipLaunchKernelGGL((sp_convp_kernel<TAPS, POOL, FIRST>), dim3(nwg), dim3(512), ldsp, st, q, total);
+            SP_TRY(hipStreamSynchronize(st));
+            std::vector<unsigned long long> h((size_t)nwg * 8);
+            SP_TRY(hipMemcpy(h.data(), q.prof, h.size() * 8, hipMemcpyDeviceToHost));
+            (void)hipFree(q.prof);
+            double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < nwg; ++i)
+                for (int j = 0; j < 8; ++j) a[j] += (double)h[(size_t)i * 8 + j] / nwg;
+            fprintf(stderr, "[sp_convp<%d,%d,%d> %dx%d cin %d cout %d: %d jobs on %d workgroups, %.1f units each] mean cycles PER UNIT: consumer K loop %.0f "
+                    "epilogue %.0f barrier wait %.0f | loader staging %.0f barrier wait %.0f\n", TAPS, POOL, FIRST, p.H, p.W, p.cin, p.cout, total, nwg, a[3],
+                    a[0] / a[3], a[1] / a[3], a[2] / a[3], a[4] / a[7], a[6] / a[7]);
+            return IMP_OK;
+        }
+        hipLaunchKernelGGL((sp_convp_kernel<TAPS, POOL, FIRST>), dim3(nwg), dim3(512), ldsp, st, p, total);
+        SP_TRY(hipGetLastError());
+        return IMP_OK;
+    }
     const void* fn = reinterpret_cast<const void*>(&sp_conv_kernel<TAPS, POOL, FIRST>);
     constexpr size_t lds = Geo<TAPS>::LDS + (FIRST ? 1024 : 0);       // + the image patch of the fused conv1a
     SP_TRY(imp_grant_dynamic_lds(fn, lds));
+    static const bool prof = getenv("IMP_SP_PROF") != nullptr;          // probe: phase cycle counts per workgroup, printed per launch
+    if (prof) {
+        SpConvParams q = p;
+        SP_TRY(hipMalloc(&q.prof, (size_t)total * 4 * sizeof(unsigned long long)));
+        hipLaunchKernelGGL((sp_conv_kernel<TAPS, POOL, FIRST>), dim3(total), dim3(256), lds, st, q, total);
+        SP_TRY(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h((size_t)total * 4);
+        SP_TRY(hipMemcpy(h.data(), q.prof, h.size() * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(q.prof);
+        double a[4] = {0, 0, 0, 0};
+        for (int i = 0; i < total; ++i)
+            for (int j = 0; j < 4; ++j) a[j] += (double)h[(size_t)i * 4 + j] / total;
+        fprintf(stderr, "[sp_conv<%d,%d,%d> %dx%d cin %d cout %d: %d workgroups] mean cycles: staging %.0f  K loop %.0f  epilogue %.0f  total %.0f\n", TAPS, POOL,
+                FIRST, p.H, p.W, p.cin, p.cout, total, a[0], a[1], a[2], a[3]);
+        return IMP_OK;
+    }
     hipLaunchKernelGGL((sp_conv_kernel<TAPS, POOL, FIRST>), dim3(total), dim3(256), lds, st, p, total);
     SP_TRY(hipGetLastError());
     return IMP_OK;
@@ -971,7 +1305,7 @@ int launch_conv(const ConvW& w, const float* in, int in_ld, int in_c0, int B, in
     p.wf = w.wf; p.bias = w.bias; p.cout = w.cout;
     p.out = out; p.out_ld = out_ld; p.relu = relu;
     p.tiles_x = (W + TW - 1) / TW; p.tiles_y = (H + TH - 1) / TH;
-    p.img = nullptr; p.w1a = nullptr; p.b1a = nullptr;
+    p.img = nullptr; p.w1a = nullptr; p.b1a = nullptr; p.prof = nullptr;
     if (w.taps == 9) return pool ? launch_conv_t<9, 1, 0>(p, st) : launch_conv_t<9, 0, 0>(p, st);
     return launch_conv_t<1, 0, 0>(p, st);
 }
@@ -997,7 +1331,7 @@ int launch_conv_first(const imp_sp_ctx* c, const float* image, int B, int H, int
     p.wf = w.wf; p.bias = w.bias; p.cout = w.cout;
     p.out = out; p.out_ld = 64; p.relu = 1;
     p.tiles_x = (W + TW - 1) / TW; p.tiles_y = (H + TH - 1) / TH;
-    p.img = image; p.w1a = c->w1a; p.b1a = c->b1a;
+    p.img = image; p.w1a = c->w1a; p.b1a = c->b1a; p.prof = nullptr;
     return launch_conv_t<9, 1, 1>(p, st);
 }
 

@@ -16,9 +16,10 @@ t=$(find /tmp/spprof -name '*kernel_trace.csv' | head -1)
 python - "$t" <<'PY' | tee $R/gpurun_out/sp/sp_480x640_per_layer.txt
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
+print('columns:', list(rows[0].keys()) if rows else 'NO ROWS')
 agg = collections.OrderedDict()
 for r in rows:
-    name = r['Kernel_Name'].split('(')[0].replace('void ', '').replace('(anonymous namespace)::', '')
+    name = r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '').split('(')[0]
     if 'sp_' not in name:
         continue
     key = (name, r['Grid_Size_X'] if 'Grid_Size_X' in r else r.get('Grid_Size', '?'))
