@@ -49,14 +49,16 @@ namespace {
 constexpr int TH = 8, TW = 16;             // output pixels of one workgroup tile (before pooling)
 constexpr int PSLOT = 9;                   // 16-byte slots per pixel in an LDS plane: 64 halves + 8 halves of padding
 
-template <int TAPS>
-struct Geo {
+template <int TAPS, int TWc>
+struct GeoT {
     static constexpr int HALO = TAPS == 9 ? 1 : 0;
-    static constexpr int LH = TH + 2 * HALO, LW = TW + 2 * HALO;
+    static constexpr int LH = TH + 2 * HALO, LW = TWc + 2 * HALO;
     static constexpr int ROW_SLOTS = ((LW * PSLOT + 7) / 16) * 16 + 8;   // >= LW * PSLOT and = 8 (mod 16)
     static constexpr int PLANE = LH * ROW_SLOTS * 16;                    // bytes of one half plane
     static constexpr int LDS = 2 * PLANE;
 };
+template <int TAPS>
+using Geo = GeoT<TAPS, TW>;
 
 struct SpConvParams {
     const float* in;      // NHWC [B][H][W][in_ld], channels in_c0 .. in_c0 + cin
@@ -301,9 +303,11 @@ __device__ __forceinline__ float sp_quad_max(float v) {
     return fmaxf(v, a);
 }
 
-template <int TAPS, int POOL, int FIRST>
+template <int TAPS, int POOL, int FIRST, int TWc>
 __global__ __launch_bounds__(512) void sp_convp_kernel(const SpConvParams p, int njobs) {
-    using G = Geo<TAPS>;
+    using G = GeoT<TAPS, TWc>;
+    constexpr int MI = TWc / 8;                  // 32-row MFMA fragments per wave: tile = 8 x TWc pixels = 2 waves x MI x 32
+    constexpr int QW = TWc / 2;                  // pooling windows per tile row
     constexpr int PATCH = FIRST ? 1024 : 0;
     constexpr int BUF = G::LDS;
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];       // [2][BUF] tiles, then [2][PATCH] image patches
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(512) void sp_convp_kernel(const SpConvParams p, int
         const int tx = z % p.tiles_x; z /= p.tiles_x;
         const int ty = z % p.tiles_y;
         b = z / p.tiles_y;
-        y0 = ty * TH; x0 = tx * TW;
+        y0 = ty * TH; x0 = tx * TWc;
     };
 
     // ------------------------------------------------------------------------------------------------ loader side
@@ -409,12 +413,12 @@ __global__ __launch_bounds__(512) void sp_convp_kernel(const SpConvParams p, int
 
     // ------------------------------------------------------------------------------------------------ consumer side
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5;
-    int aoff[2];
+    int aoff[MI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = 64 * wm + 32 * i + (lane & 31);
+    for (int i = 0; i < MI; ++i) {
+        const int m = 32 * MI * wm + 32 * i + (lane & 31);
         const int q = m >> 2, r = m & 3;
-        const int py = 2 * (q >> 3) + (r >> 1), px = 2 * (q & 7) + (r & 1);
+        const int py = 2 * (q / QW) + (r >> 1), px = 2 * (q % QW) + (r & 1);
         aoff[i] = (py * G::ROW_SLOTS + px * PSLOT) * 16 + half * 16;
     }
     const int ksteps = nchunk * TAPS * 4;
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(512) void sp_convp_kernel(const SpConvParams p, int
         decode(unit, b, y0, x0, ntile, chunk);
         return p.wf + ((size_t)(ntile * 2 + wn) * ksteps + chunk * TAPS * 4) * 128 + lane;
     };
-    f32x16 acc[2];
+    f32x16 acc[MI];
     u32x4 bh[4], bl[4];
     unsigned long long pa = 0, pb = 0, pc = 0, t0 = 0, t1 = 0;      // probe: loader: staging / barrier wait; consumer: K loop / epilogue / wait
     const bool prof = p.prof != nullptr;
@@ -455,19 +459,19 @@ __global__ __launch_bounds__(512) void sp_convp_kernel(const SpConvParams p, int
             const unsigned char* buf = sp_smem + (u & 1) * BUF;
             if (chunk == 0) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
             }
             const u32x4* wp = wbase(u);
             const u32x4* wfollow = u + 1 < U ? wbase(u + 1) : wp;        // first tap of the next unit (or a harmless re-load)
             constexpr int NS = TAPS * 4;
-            f16x8 fah[2][2], fal[2][2];
+            f16x8 fah[2][MI], fal[2][MI];
             auto load_frag = [&](int st, int fb) {
                 const int tap = st >> 2, c = st & 3;
                 const int toff = TAPS == 9 ? ((tap / 3) * G::ROW_SLOTS + (tap % 3) * PSLOT) * 16 : 0;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < MI; ++i) {
                     fah[fb][i] = *reinterpret_cast<const f16x8*>(buf + aoff[i] + toff + c * 32);
                     fal[fb][i] = *reinterpret_cast<const f16x8*>(buf + G::PLANE + aoff[i] + toff + c * 32);
                 }
@@ -487,11 +491,11 @@ __global__ __launch_bounds__(512) void sp_convp_kernel(const SpConvParams p, int
                 __builtin_amdgcn_sched_barrier(0);
                 const f16x8 wh = __builtin_bit_cast(f16x8, bh[c]), wl = __builtin_bit_cast(f16x8, bl[c]);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fal[st & 1][i], acc[i], 0, 0, 0);
+                for (int i = 0; i < MI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fal[st & 1][i], acc[i], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, fah[st & 1][i], acc[i], 0, 0, 0);
+                for (int i = 0; i < MI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fah[st & 1][i], acc[i], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fah[st & 1][i], acc[i], 0, 0, 0);
+                for (int i = 0; i < MI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, fah[st & 1][i], acc[i], 0, 0, 0);
                 if (c == 3) {
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc) { bh[cc] = nh[cc]; bl[cc] = nl[cc]; }
@@ -505,8 +509,8 @@ __global__ __launch_bounds__(512) void sp_convp_kernel(const SpConvParams p, int
 #pragma unroll
                 for (int g = 0; g < 4; ++g) bv[g] = *reinterpret_cast<const f32x4*>(p.bias + cb + 8 * g);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int m = 64 * wm + 32 * i + (lane & 31);
+                for (int i = 0; i < MI; ++i) {
+                    const int m = 32 * MI * wm + 32 * i + (lane & 31);
                     const int q = m >> 2, r = m & 3;
                     if (POOL) {
                         const int Ho = H / 2, Wo = W / 2;
@@ -521,11 +525,11 @@ __global__ __launch_bounds__(512) void sp_convp_kernel(const SpConvParams p, int
                             }
                             if (r == g) sel = v;                               // lane r of the quad stores channel group g = r
                         }
-                        const int py = y0 / 2 + (q >> 3), px = x0 / 2 + (q & 7);
+                        const int py = y0 / 2 + q / QW, px = x0 / 2 + q % QW;
                         if (py < Ho && px < Wo)
                             *reinterpret_cast<f32x4*>(p.out + ((size_t)(b * Ho + py) * Wo + px) * p.out_ld + cb + 8 * r) = sel;
                     } else {
-                        const int y = y0 + 2 * (q >> 3) + (r >> 1), x = x0 + 2 * (q & 7) + (r & 1);
+                        const int y = y0 + 2 * (q / QW) + (r >> 1), x = x0 + 2 * (q % QW) + (r & 1);
                         if (y < H && x < W) {
                             float* o = p.out + ((size_t)(b * H + y) * W + x) * p.out_ld + cb;
 #pragma unroll
@@ -719,6 +723,10 @@ __global__ __launch_bounds__(256) void sp_nms_kernel(const float* __restrict__ s
 }
 
 
+__device__ __forceinline__ bool sp_keep(float v, int x, int y, int Hs, int Ws, float thr, int border) {
+    return v > thr && y >= border && y < Hs - border && x >= border && x < Ws - border;
+}
+
 // Fast path of simple_nms for radius 1..6 (compile-time R): same chain, same LDS image, but every pool is a register-blocked
 // separable pass - a thread produces 8 consecutive outputs from 8 + 2R inputs it holds in registers (horizontal: aligned float4
 // reads of a row padded with -inf columns; vertical: a column of the intermediate image, which has R rows of -inf above and
@@ -777,7 +785,8 @@ __device__ __forceinline__ void nms_pool(const float* in, float* t, int tid, F&&
 }
 
 template <int R>
-__global__ __launch_bounds__(256) void sp_nms_fast_kernel(const float* __restrict__ sin, float* __restrict__ sout, int Hs, int Ws, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256) void sp_nms_fast_kernel(const float* __restrict__ sin, float* __restrict__ sout, int Hs, int Ws, int tiles_x, int tiles_y,
+                                                          float thr, int border, int* __restrict__ tilecount /*[B][Hs][tiles_x]*/) {
     using G = NmsGeo<R>;
     constexpr int E = G::E, RP = G::RP, ES = G::ES, TR = G::TR, T = G::T;
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
@@ -832,20 +841,23 @@ __global__ __launch_bounds__(256) void sp_nms_fast_kernel(const float* __restric
     for (int i = tid; i < T * T; i += 256) {
         const int y = i / T, x = i - y * T;
         const int gy = ty * T + y, gx = tx * T + x;
+        float v = 0.f;
         if (gy < Hs && gx < Ws) {
             const int ly = y + 5 * R, lx = x + 5 * R;
-            dst[(size_t)gy * Ws + gx] = msk[ly * E + lx] ? s[ly * ES + RP + lx] : 0.f;
+            v = msk[ly * E + lx] ? s[ly * ES + RP + lx] : 0.f;
+            dst[(size_t)gy * Ws + gx] = v;
         }
+        // the keypoint candidates of this row segment (T = 32 = half a wave): what sp_rowcount_kernel would count
+        const bool keep = gy < Hs && gx < Ws && sp_keep(v, gx, gy, Hs, Ws, thr, border);
+        const unsigned long long bal = __ballot(keep);
+        if ((tid & 31) == 0 && gy < Hs) tilecount[((size_t)b * Hs + gy) * tiles_x + tx] = __popcll((tid & 32) ? (bal >> 32) : (bal & 0xFFFFFFFFull));
     }
 }
 
 template <int R>
-int launch_nms_fast(const float* in, float* out, int B, int Hs, int Ws, hipStream_t st);
+int launch_nms_fast(const float* in, float* out, int B, int Hs, int Ws, float thr, int border, int* tilecount, hipStream_t st);
 
 // keypoint extraction (nets/superpoint.py:203-211): torch.nonzero(s > threshold) order = row major, border filter of :66-71
-__device__ __forceinline__ bool sp_keep(float v, int x, int y, int Hs, int Ws, float thr, int border) {
-    return v > thr && y >= border && y < Hs - border && x >= border && x < Ws - border;
-}
 
 __global__ __launch_bounds__(64) void sp_rowcount_kernel(const float* __restrict__ nms, int Hs, int Ws, float thr, int border, int* __restrict__ rowcount) {
     const int y = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
@@ -859,7 +871,8 @@ __global__ __launch_bounds__(64) void sp_rowcount_kernel(const float* __restrict
     if (lane == 0) rowcount[b * Hs + y] = cnt;
 }
 
-__global__ __launch_bounds__(1024) void sp_scan_kernel(const int* __restrict__ rowcount, int Hs, int* __restrict__ rowoff, int* __restrict__ count) {
+__global__ __launch_bounds__(1024) void sp_scan_kernel(const int* __restrict__ rowcount, const int* __restrict__ tilecount, int tiles_x, int Hs,
+                                                       int* __restrict__ rowoff, int* __restrict__ count) {
     __shared__ int part[1024];
     __shared__ int carry;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -867,7 +880,14 @@ __global__ __launch_bounds__(1024) void sp_scan_kernel(const int* __restrict__ r
     __syncthreads();
     for (int base = 0; base < Hs; base += 1024) {
         const int i = base + tid;
-        const int v = i < Hs ? rowcount[b * Hs + i] : 0;
+        int v = 0;
+        if (i < Hs) {
+            if (tilecount) {                                   // per-tile counts of the fast NMS kernel
+                for (int t = 0; t < tiles_x; ++t) v += tilecount[((size_t)b * Hs + i) * tiles_x + t];
+            } else {
+                v = rowcount[b * Hs + i];
+            }
+        }
         part[tid] = v;
         __syncthreads();
         for (int d = 1; d < 1024; d <<= 1) {
@@ -911,8 +931,8 @@ __global__ __launch_bounds__(64) void sp_compact_kernel(const float* __restrict_
 //   sp_topk_select_kernel (one workgroup of 1024 threads per image): n <= k copies; n <= 2048 hands every key on; otherwise a
 //     radix select of the k-th largest score (digits of 12 / 10 / 10 bits from the top, LDS histogram, parallel suffix scan)
 //     cuts the candidates to exactly k keys.
-//   sp_topk_rank_kernel (256 keys per workgroup, so the chip - not one CU - does the m^2 comparisons): rank sort, a key's final
-//     position is the number of larger keys, counted against broadcast LDS reads; no barriers in the loop.
+//   sp_topk_rank_kernel (16 keys per workgroup, 16 threads per key, so the chip - not one CU - does the m^2 comparisons): rank
+//     sort, a key's final position is the number of larger keys; no barriers in the loop.
 constexpr int TOPK_CAP = 16384;
 constexpr int TOPK_DIRECT = 2048;
 
@@ -1043,20 +1063,21 @@ __global__ __launch_bounds__(1024) void sp_topk_select_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void sp_topk_rank_kernel(const float* __restrict__ kp, size_t cap, int k, const unsigned long long* __restrict__ selkeys,
                                                            const int* __restrict__ sel_m, float* __restrict__ kp_out, float* __restrict__ sc_out) {
+    // 16 keys per workgroup, 16 threads per key: thread (key, part) counts the larger keys among every 16th group of 16 keys
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(sp_smem);
     const int b = blockIdx.y, tid = threadIdx.x;
     const int m = sel_m[b];
-    const int mine_i = blockIdx.x * 256 + tid;
-    if (blockIdx.x * 256 >= m) return;                // (m == 0: nothing to sort for this image)
+    if (blockIdx.x * 16 >= m) return;                 // (m == 0: nothing to sort for this image)
     const unsigned long long* src = selkeys + (size_t)b * TOPK_CAP;
-    const int m2 = (m + 15) & ~15;
+    const int m2 = (m + 255) & ~255;
     for (int i = tid; i < m2; i += 256) keys[i] = i < m ? src[i] : 0ull;      // (padding keys are smaller than every real key)
     __syncthreads();
+    const int mine_i = blockIdx.x * 16 + (tid >> 4), part = tid & 15;
     const unsigned long long mk = mine_i < m ? keys[mine_i] : ~0ull;
     const unsigned mhi = (unsigned)(mk >> 32), mlo = (unsigned)mk;
     unsigned rank = 0;
-    for (int i = 0; i < m2; i += 16) {                // every lane reads the same 16 bytes: one broadcast LDS access per two keys
+    for (int i = part * 16; i < m2; i += 256) {
         u32x4 o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = *reinterpret_cast<const u32x4*>(keys + i + 2 * j);
@@ -1066,7 +1087,9 @@ __global__ __launch_bounds__(256) void sp_topk_rank_kernel(const float* __restri
             rank += (o[j][3] > mhi || (o[j][3] == mhi && o[j][2] > mlo)) ? 1u : 0u;
         }
     }
-    if (mine_i < m && rank < (unsigned)k) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) rank += __shfl_xor(rank, o);
+    if (part == 0 && mine_i < m && rank < (unsigned)k) {
         const unsigned idx = 0xFFFFFFFFu - (unsigned)(mk & 0xFFFFFFFFull);
         const float* kpb = kp + (size_t)b * cap * 2;
         float* kpo = kp_out + (size_t)b * cap * 2;
@@ -1172,7 +1195,8 @@ struct imp_sp_ctx {
     size_t capA = 0, capB = 0, cap_small = 0, cap_map = 0, cap_rows = 0, cap_b = 0;
     float *bufA = nullptr, *bufB = nullptr, *dmap = nullptr, *logits = nullptr, *scores = nullptr, *nms = nullptr;
     float *kp0 = nullptr, *sc0 = nullptr, *kp1 = nullptr, *sc1 = nullptr;
-    int *rowcount = nullptr, *rowoff = nullptr, *count0 = nullptr, *count1 = nullptr, *sel_m = nullptr;
+    int *rowcount = nullptr, *rowoff = nullptr, *count0 = nullptr, *count1 = nullptr, *sel_m = nullptr, *tilecount = nullptr;
+    int* count1_host = nullptr;    // count1 is the device view of this pinned, mapped host array: the kernel's store IS the read-back
     unsigned long long* selkeys = nullptr;
     std::vector<int> counts;
     int align_corners = 1;
@@ -1242,6 +1266,34 @@ void free_conv(ConvW& w) {
     w = ConvW();
 }
 
+template <int TAPS, int POOL, int FIRST, int TWc>
+int launch_convp(SpConvParams p, int total, int tiles_x, int ncu, hipStream_t st) {
+    p.tiles_x = tiles_x;
+    const int nwg = total < ncu ? total : (ncu / 8) * 8;
+    constexpr size_t ldsp = 2 * GeoT<TAPS, TWc>::LDS + (FIRST ? 2048 : 0);
+    const void* fnp = reinterpret_cast<const void*>(&sp_convp_kernel<TAPS, POOL, FIRST, TWc>);
+    SP_TRY(imp_grant_dynamic_lds(fnp, ldsp));
+    if (getenv("IMP_SP_PROF")) {                                        // probe: phase cycle counts per workgroup, printed per launch
+        SpConvParams q = p;
+        SP_TRY(hipMalloc(&q.prof, (size_t)nwg * 8 * sizeof(unsigned long long)));
+        hipLaunchKernelGGL((sp_convp_kernel<TAPS, POOL, FIRST, TWc>), dim3(nwg), dim3(512), ldsp, st, q, total);
+        SP_TRY(hipStreamSynchronize(st));
+        std::vector<unsigned long long> h((size_t)nwg * 8);
+        SP_TRY(hipMemcpy(h.data(), q.prof, h.size() * 8, hipMemcpyDeviceToHost));
+        (void)hipFree(q.prof);
+        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < nwg; ++i)
+            for (int j = 0; j < 8; ++j) a[j] += (double)h[(size_t)i * 8 + j] / nwg;
+        fprintf(stderr, "[sp_convp<%d,%d,%d,%d> %dx%d cin %d cout %d: %d jobs on %d workgroups, %.1f units each] mean cycles PER UNIT: consumer K loop %.0f "
+                "epilogue %.0f barrier wait %.0f | loader staging %.0f barrier wait %.0f\n", TAPS, POOL, FIRST, TWc, p.H, p.W, p.cin, p.cout, total, nwg, a[3],
+                a[0] / a[3], a[1] / a[3], a[2] / a[3], a[4] / a[7], a[6] / a[7]);
+        return IMP_OK;
+    }
+    hipLaunchKernelGGL((sp_convp_kernel<TAPS, POOL, FIRST, TWc>), dim3(nwg), dim3(512), ldsp, st, p, total);
+    SP_TRY(hipGetLastError());
+    return IMP_OK;
+}
+
 template <int TAPS, int POOL, int FIRST>
 int launch_conv_t(const SpConvParams& p, hipStream_t st) {
     const int total = p.B * p.tiles_x * p.tiles_y * (p.cout / 64);
@@ -1250,29 +1302,14 @@ int launch_conv_t(const SpConvParams& p, hipStream_t st) {
         int dev = 0, ncu = 256;
         SP_TRY(hipGetDevice(&dev));
         SP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-        const int nwg = total < ncu ? total : (ncu / 8) * 8;
-        constexpr size_t ldsp = 2 * Geo<TAPS>::LDS + (FIRST ? 2048 : 0);
-        const void* fnp = reinterpret_cast<const void*>(&sp_convp_kernel<TAPS, POOL, FIRST>);
-        SP_TRY(imp_grant_dynamic_lds(fnp, ldsp));
-        if (getenv("IMP_SP_PROF")) {                                    // probe: phase cycle counts per workgroup, printed per launch
-            SpConvParams q = p;
-            SP_TRY(hipMalloc(&q.prof, (size_t)nwg * 8 * sizeof(unsigned long long)));
-            hipLaunchKernelGGL((sp_convp_kernel<TAPS, POOL, FIRST>), dim3(nwg), dim3(512), ldsp, st, q, total);
-            SP_TRY(hipStreamSynchronize(st));
-            std::vector<unsigned long long> h((size_t)nwg * 8);
-            SP_TRY(hipMemcpy(h.data(), q.prof, h.size() * 8, hipMemcpyDeviceToHost));
-            (void)hipFree(q.prof);
-            double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int i = 0; i < nwg; ++i)
-                for (int j = 0; j < 8; ++j) a[j] += (double)h[(size_t)i * 8 + j] / nwg;
-            fprintf(stderr, "[sp_convp<%d,%d,%d> %dx%d cin %d cout %d: %d jobs on %d workgroups, %.1f units each] mean cycles PER UNIT: consumer K loop %.0f "
-                    "epilogue %.0f barrier wait %.0f | loader staging %.0f barrier wait %.0f\n", TAPS, POOL, FIRST, p.H, p.W, p.cin, p.cout, total, nwg, a[3],
-                    a[0] / a[3], a[1] / a[3], a[2] / a[3], a[4] / a[7], a[6] / a[7]);
-            return IMP_OK;
-        }
-        hipLaunchKernelGGL((sp_convp_kernel<TAPS, POOL, FIRST>), dim3(nwg), dim3(512), ldsp, st, p, total);
-        SP_TRY(hipGetLastError());
-        return IMP_OK;
+        // tile width 16 or 8 pixels: whichever needs less time for the busiest workgroup (a half tile costs ~0.55 of a full one:
+        // same loader work per pixel, twice the weight traffic per MFMA) - the layers below 240 x 320 have too few full tiles
+        const int tx8 = (p.W + 7) / 8;
+        const int jobs16 = total, jobs8 = p.B * tx8 * p.tiles_y * (p.cout / 64);
+        const double t16 = (double)((jobs16 + ncu - 1) / ncu), t8 = 0.55 * (double)((jobs8 + ncu - 1) / ncu);
+        static const char* force = getenv("IMP_SP_TILE");
+        const bool narrow = force ? atoi(force) == 8 : t8 < t16;
+        return narrow ? launch_convp<TAPS, POOL, FIRST, 8>(p, jobs8, tx8, ncu, st) : launch_convp<TAPS, POOL, FIRST, 16>(p, jobs16, p.tiles_x, ncu, st);
     }
     const void* fn = reinterpret_cast<const void*>(&sp_conv_kernel<TAPS, POOL, FIRST>);
     constexpr size_t lds = Geo<TAPS>::LDS + (FIRST ? 1024 : 0);       // + the image patch of the fused conv1a
@@ -1314,11 +1351,11 @@ int launch_conv(const ConvW& w, const float* in, int in_ld, int in_c0, int B, in
 int launch_conv_first(const imp_sp_ctx* c, const float* image, int B, int H, int W, float* out, hipStream_t st);
 
 template <int R>
-int launch_nms_fast(const float* in, float* out, int B, int Hs, int Ws, hipStream_t st) {
+int launch_nms_fast(const float* in, float* out, int B, int Hs, int Ws, float thr, int border, int* tilecount, hipStream_t st) {
     using G = NmsGeo<R>;
     const int tx = (Ws + G::T - 1) / G::T, ty = (Hs + G::T - 1) / G::T;
     SP_TRY(imp_grant_dynamic_lds(reinterpret_cast<const void*>(&sp_nms_fast_kernel<R>), G::LDS));
-    hipLaunchKernelGGL((sp_nms_fast_kernel<R>), dim3(tx * ty * B), dim3(256), G::LDS, st, in, out, Hs, Ws, tx, ty);
+    hipLaunchKernelGGL((sp_nms_fast_kernel<R>), dim3(tx * ty * B), dim3(256), G::LDS, st, in, out, Hs, Ws, tx, ty, thr, border, tilecount);
     SP_TRY(hipGetLastError());
     return IMP_OK;
 }
@@ -1337,8 +1374,10 @@ int launch_conv_first(const imp_sp_ctx* c, const float* image, int B, int H, int
 
 void free_ws(imp_sp_ctx* c) {
     for (void* p : {(void*)c->bufA, (void*)c->bufB, (void*)c->dmap, (void*)c->logits, (void*)c->scores, (void*)c->nms, (void*)c->kp0, (void*)c->sc0, (void*)c->kp1,
-                    (void*)c->sc1, (void*)c->rowcount, (void*)c->rowoff, (void*)c->count0, (void*)c->count1, (void*)c->sel_m, (void*)c->selkeys})
+                    (void*)c->sc1, (void*)c->rowcount, (void*)c->rowoff, (void*)c->count0, (void*)c->sel_m, (void*)c->selkeys, (void*)c->tilecount})
         if (p) (void)hipFree(p);
+    if (c->count1_host) (void)hipHostFree(c->count1_host);
+    c->count1_host = nullptr; c->tilecount = nullptr;
     c->bufA = c->bufB = c->dmap = c->logits = c->scores = c->nms = c->kp0 = c->sc0 = c->kp1 = c->sc1 = nullptr;
     c->rowcount = c->rowoff = c->count0 = c->count1 = c->sel_m = nullptr;
     c->selkeys = nullptr;
@@ -1463,7 +1502,9 @@ int imp_sp_detect(imp_sp_ctx* c, const float* image, int B, int H, int W, int nm
         SP_TRY(hipMalloc(&c->rowcount, (size_t)B * Hs * 4));
         SP_TRY(hipMalloc(&c->rowoff, (size_t)B * Hs * 4));
         SP_TRY(hipMalloc(&c->count0, (size_t)B * 4));
-        SP_TRY(hipMalloc(&c->count1, (size_t)B * 4));
+        SP_TRY(hipHostMalloc(&c->count1_host, (size_t)B * 4, hipHostMallocMapped));
+        SP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->count1), c->count1_host, 0));
+        SP_TRY(hipMalloc(&c->tilecount, (size_t)B * Hs * ((Ws + 31) / 32) * 4));
         SP_TRY(hipMalloc(&c->sel_m, (size_t)B * 4));
         SP_TRY(hipMalloc(&c->selkeys, (size_t)B * TOPK_CAP * 8));
         c->capA = std::max(needA, need_small); c->capB = needB; c->cap_small = need_small; c->cap_map = need_map;
@@ -1497,14 +1538,15 @@ int imp_sp_detect(imp_sp_ctx* c, const float* image, int B, int H, int W, int nm
         hipLaunchKernelGGL(sp_softmax_shuffle_kernel, dim3((npix + 3) / 4), dim3(256), 0, st, c->logits, c->scores, npix, h, w);
     }
     SP_TRY(hipGetLastError());
-    if (nms_radius >= 1 && nms_radius <= 6 && !getenv("IMP_SP_NMS_GENERIC")) {
+    const bool nms_fast = nms_radius >= 1 && nms_radius <= 6 && !getenv("IMP_SP_NMS_GENERIC");
+    if (nms_fast) {
         switch (nms_radius) {
-            case 1: rc = launch_nms_fast<1>(c->scores, c->nms, B, Hs, Ws, st); break;
-            case 2: rc = launch_nms_fast<2>(c->scores, c->nms, B, Hs, Ws, st); break;
-            case 3: rc = launch_nms_fast<3>(c->scores, c->nms, B, Hs, Ws, st); break;
-            case 4: rc = launch_nms_fast<4>(c->scores, c->nms, B, Hs, Ws, st); break;
-            case 5: rc = launch_nms_fast<5>(c->scores, c->nms, B, Hs, Ws, st); break;
-            default: rc = launch_nms_fast<6>(c->scores, c->nms, B, Hs, Ws, st); break;
+            case 1: rc = launch_nms_fast<1>(c->scores, c->nms, B, Hs, Ws, keypoint_threshold, remove_borders, c->tilecount, st); break;
+            case 2: rc = launch_nms_fast<2>(c->scores, c->nms, B, Hs, Ws, keypoint_threshold, remove_borders, c->tilecount, st); break;
+            case 3: rc = launch_nms_fast<3>(c->scores, c->nms, B, Hs, Ws, keypoint_threshold, remove_borders, c->tilecount, st); break;
+            case 4: rc = launch_nms_fast<4>(c->scores, c->nms, B, Hs, Ws, keypoint_threshold, remove_borders, c->tilecount, st); break;
+            case 5: rc = launch_nms_fast<5>(c->scores, c->nms, B, Hs, Ws, keypoint_threshold, remove_borders, c->tilecount, st); break;
+            default: rc = launch_nms_fast<6>(c->scores, c->nms, B, Hs, Ws, keypoint_threshold, remove_borders, c->tilecount, st); break;
         }
         if (rc) return rc;
     } else {
@@ -1517,8 +1559,8 @@ int imp_sp_detect(imp_sp_ctx* c, const float* image, int B, int H, int W, int nm
         SP_TRY(hipGetLastError());
     }
     const size_t cap = (size_t)Hs * Ws;
-    hipLaunchKernelGGL(sp_rowcount_kernel, dim3(Hs, B), dim3(64), 0, st, c->nms, Hs, Ws, keypoint_threshold, remove_borders, c->rowcount);
-    hipLaunchKernelGGL(sp_scan_kernel, dim3(B), dim3(1024), 0, st, c->rowcount, Hs, c->rowoff, c->count0);
+    if (!nms_fast) hipLaunchKernelGGL(sp_rowcount_kernel, dim3(Hs, B), dim3(64), 0, st, c->nms, Hs, Ws, keypoint_threshold, remove_borders, c->rowcount);
+    hipLaunchKernelGGL(sp_scan_kernel, dim3(B), dim3(1024), 0, st, c->rowcount, nms_fast ? c->tilecount : nullptr, (Ws + 31) / 32, Hs, c->rowoff, c->count0);
     hipLaunchKernelGGL(sp_compact_kernel, dim3(Hs, B), dim3(64), 0, st, c->nms, Hs, Ws, keypoint_threshold, remove_borders, c->rowoff, c->kp0, c->sc0, cap);
     SP_TRY(hipGetLastError());
     hipLaunchKernelGGL(sp_topk_select_kernel, dim3(B), dim3(1024), 0, st, c->kp0, c->sc0, c->count0, cap, max_keypoints, c->kp1, c->sc1, c->count1,
@@ -1526,14 +1568,14 @@ int imp_sp_detect(imp_sp_ctx* c, const float* image, int B, int H, int W, int nm
     SP_TRY(hipGetLastError());
     if (max_keypoints >= 0) {
         const int mmax = std::max(max_keypoints, TOPK_DIRECT);
-        const size_t lds = (size_t)mmax * 8;
+        const size_t lds = (size_t)((mmax + 255) & ~255) * 8;
         SP_TRY(imp_grant_dynamic_lds(reinterpret_cast<const void*>(&sp_topk_rank_kernel), lds));
-        hipLaunchKernelGGL(sp_topk_rank_kernel, dim3((mmax + 255) / 256, B), dim3(256), lds, st, c->kp0, cap, max_keypoints, c->selkeys, c->sel_m,
+        hipLaunchKernelGGL(sp_topk_rank_kernel, dim3((mmax + 15) / 16, B), dim3(256), lds, st, c->kp0, cap, max_keypoints, c->selkeys, c->sel_m,
                            c->kp1, c->sc1);
         SP_TRY(hipGetLastError());
     }
-    SP_TRY(hipMemcpyAsync(counts, c->count1, (size_t)B * 4, hipMemcpyDeviceToHost, st));
     SP_TRY(hipStreamSynchronize(st));
+    for (int b = 0; b < B; ++b) counts[b] = c->count1_host[b];
     c->counts.assign(counts, counts + B);
     c->detected = true;
     return IMP_OK;
