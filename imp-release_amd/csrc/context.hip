@@ -37,6 +37,8 @@ struct GnnLayer {
     Linear mlp3;     // [D][2D]
     // the same weights as planes (rows [K hi halves | K lo halves]) for gemm_planes.hip
     _Float16 *proj_p = nullptr, *mlp0f_p = nullptr, *mlp3_p = nullptr;
+    // ... and as MFMA fragments (gemm_wf.hip: wf_pack)
+    _Float16 *proj_wf = nullptr, *mlp0f_wf = nullptr, *mlp3_wf = nullptr;
 };
 struct AttnCache {   // cached operands of the last non-shared layer of a kind (self / cross)
     bool valid = false;
@@ -85,6 +87,7 @@ struct imp_ctx {
     AttnCache cache[2];
     // planes path (gemm_planes.hip): f16x3 arithmetic with the merge conv folded; IMP_GEMM_PLANES=0 keeps gemm_f32.hip
     int use_planes = 0;
+    int use_wf = 1;          // weight-fragment GEMMs (gemm_wf.hip) for the layer convolutions when f16x3, D = 256, relu + InstanceNorm; IMP_GEMM_WF=0 disables
     _Float16* xpl[2] = {};                 // planes of the current descriptors of image 0 / 1  [B][n][2D halves]
     const float* xpl_src[2] = {};          // fp32 tensor they were made from / written next to (trusted only inside one call chain)
     int xpl_b = 0, xpl_n[2] = {0, 0};
@@ -191,6 +194,15 @@ int upload_planes(imp_ctx* c, _Float16** dst, const float* W, size_t rows, size_
             h[r * 2 * K + k] = hi;
             h[r * 2 * K + K + k] = (_Float16)(x - (float)hi);
         }
+    int rc = dev_alloc(c, c->allocs_w, dst, h.size());
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(*dst, h.data(), h.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    return IMP_OK;
+}
+int upload_wf(imp_ctx* c, _Float16** dst, const float* W, int N, int K) {
+    if (!gemm_wf_supported(K, N)) { *dst = nullptr; return IMP_OK; }
+    std::vector<_Float16> h((size_t)N * K * 2);
+    wf_pack(W, N, K, h.data());
     int rc = dev_alloc(c, c->allocs_w, dst, h.size());
     if (rc) return rc;
     HIP_TRY(hipMemcpy(*dst, h.data(), h.size() * sizeof(_Float16), hipMemcpyHostToDevice));
@@ -415,6 +427,13 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
     // (worth it only when the panels fill the chip: one 64-row panel per workgroup, gemm_planes.hip)
     const long panels = (long)(((n[0] > n[1] ? n[0] : n[1]) + 63) / 64) * 2 * batch;
     const bool planes = c->prec == 1 && c->fuse_merge && c->use_planes && panels >= 96 && D % 128 == 0;
+    // weight-fragment GEMMs: the default for the f16x3 arithmetic (gemm_wf.hip)
+    // (64-row tiles, one workgroup each, whole K in LDS: measured 1.08x / 1.29x on the two MLP convolutions when the tiles cover
+    // the chip about once (B = 4, N = 2048: 256 tiles), 1.03x at twice that, slower than gemm_f32.hip's 64 x 64 tiles below; the
+    // K = 256 projection gains nothing.  IMP_GEMM_WF: 0 never, 1 by this rule (default), 2 always incl. the projection)
+    const long wf_tiles = (long)batch * ((n[0] + 63) / 64 + (n[1] + 63) / 64);
+    const bool wf = !planes && c->prec == 1 && c->use_wf && (c->use_wf > 1 || (wf_tiles >= 192 && wf_tiles <= 640));
+    const bool wf_mlp = wf && c->fuse_merge && cfg.norm_fn == IMP_NORM_IN && cfg.ac_fn == IMP_ACT_RELU && L.mlp0f_wf && L.mlp3_wf;
     if (planes) {
         for (int s = 0; s < 2; ++s) {
             const bool have = c->trust_planes && c->xpl_src[s] == desc[s] && c->xpl_b == batch && c->xpl_n[s] == n[s];
@@ -437,6 +456,18 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
         }
         p.bias = L.proj.b; p.lda = 2 * D; p.apw = D; p.ldw = 2 * D; p.ldc = 3 * D;
         HIP_TRY(launch_gemm_planes(p, batch, st));
+    } else if (wf && c->use_wf > 1 && L.proj_wf) {       // (measured: no gain for the K = 256 projection - it stays on gemm_f32.hip unless forced)
+        WfParams p;
+        memset(&p, 0, sizeof p);
+        p.K = D; p.ksplit = D; p.N = L.proj.out; p.nside = 2;
+        for (int s = 0; s < 2; ++s) {
+            WfSide& g = p.side[s];
+            g.A = desc[s]; g.M = n[s];
+            g.C = L.shared ? qkv[s] + 2 * D : qkv[s];
+            g.sA_b = (long)n[s] * D; g.sC_b = (long)n[s] * 3 * D;
+        }
+        p.Wf_ = L.proj_wf; p.bias = L.proj.b; p.lda = D; p.ldc = 3 * D;
+        HIP_TRY(launch_gemm_wf(p, batch, st));
     } else {
         GemmParams p = gemm_defaults(c, D);
         for (int s = 0; s < 2; ++s) {
@@ -501,6 +532,19 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
         p.bias = M0.b; p.lda = 2 * D; p.apw = D; p.lda2 = 2 * D; p.apw2 = D; p.ldw = 4 * D; p.ldc = 2 * D;
         bm0 = pgemm_stats_rows(p, batch);
         HIP_TRY(launch_gemm_planes(p, batch, st));
+    } else if (wf_mlp) {
+        WfParams p;
+        memset(&p, 0, sizeof p);
+        p.K = 2 * D; p.ksplit = D; p.N = 2 * D; p.nside = 2;
+        for (int s = 0; s < 2; ++s) {
+            WfSide& g = p.side[s];
+            g.A = desc[s]; g.A2 = c->attn_out[s]; g.C = c->hid[s]; g.M = n[s];
+            g.sA_b = (long)n[s] * D; g.sA2_b = (long)n[s] * D; g.sC_b = (long)n[s] * 2 * D;
+            g.out_stats = c->stats[s];
+        }
+        p.Wf_ = L.mlp0f_wf; p.bias = M0.b; p.lda = D; p.lda2 = D; p.ldc = 2 * D;
+        bm0 = gemm_wf_stats_rows();
+        HIP_TRY(launch_gemm_wf(p, batch, st));
     } else {
         GemmParams p = gemm_defaults(c, 2 * D);
         p.ksplit = D;
@@ -539,6 +583,18 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
         }
         p.bias = L.mlp3.b; p.ldaf = 2 * D; p.ldw = 4 * D; p.ldc = D; p.ldr = D; p.ldcp = 2 * D; p.cpw = D;
         HIP_TRY(launch_gemm_planes(p, batch, st));
+    } else if (wf_mlp) {
+        WfParams p;
+        memset(&p, 0, sizeof p);
+        p.K = 2 * D; p.ksplit = 2 * D; p.N = D; p.nside = 2;
+        for (int s = 0; s < 2; ++s) {
+            WfSide& g = p.side[s];
+            g.A = c->hid[s]; g.C = out[s]; g.R = desc[s]; g.M = n[s];
+            g.sA_b = (long)n[s] * 2 * D; g.sC_b = (long)n[s] * D; g.sR_b = (long)n[s] * D;
+            g.in_stats = c->nstat[s];
+        }
+        p.Wf_ = L.mlp3_wf; p.bias = L.mlp3.b; p.lda = 2 * D; p.ldc = D; p.ldr = D;
+        HIP_TRY(launch_gemm_wf(p, batch, st));
     } else {
         GemmParams p = gemm_defaults(c, 2 * D);
         p.flags = GEMM_PRO_NORM;
@@ -746,6 +802,7 @@ int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     // pre-split planes GEMMs (gemm_planes.hip) for the layer convs: measured SLOWER than gemm_f32.hip on MI355X,
     // kept as an opt-in experiment and A/B switch
     { const char* e = getenv("IMP_GEMM_PLANES"); c->use_planes = (e && atoi(e) != 0) ? 1 : 0; }
+    { const char* e = getenv("IMP_GEMM_WF"); c->use_wf = e ? atoi(e) : 1; }     // 0 off, 1 default (large launches), 2 always
     c->kenc_maxc = c->D;
     for (int i = 0; i < nk; ++i) if (cfg->kenc_channels[i] > c->kenc_maxc) c->kenc_maxc = cfg->kenc_channels[i];
     build_schema(c);
@@ -845,6 +902,7 @@ int imp_finalize_weights(imp_ctx* c) {
         if ((rc = upload(c, &L.proj.W, W))) return rc;
         if ((rc = upload(c, &L.proj.b, b))) return rc;
         if ((rc = upload_planes(c, &L.proj_p, W.data(), (size_t)nproj * D, D))) return rc;
+        if ((rc = upload_wf(c, &L.proj_wf, W.data(), nproj * D, D))) return rc;
         // merge, input columns permuted to head-major
         {
             const HostTensor* w = get(c, pa + ".merge.weight", (int64_t)D * D);
@@ -885,6 +943,7 @@ int imp_finalize_weights(imp_ctx* c) {
             if ((rc = upload(c, &L.mlp0f.W, Wf))) return rc;
             if ((rc = upload(c, &L.mlp0f.b, bf))) return rc;
             if ((rc = upload_planes(c, &L.mlp0f_p, Wf.data(), (size_t)2 * D, (size_t)2 * D))) return rc;
+            if ((rc = upload_wf(c, &L.mlp0f_wf, Wf.data(), 2 * D, 2 * D))) return rc;
         }
         if (cfg.norm_fn == IMP_NORM_BN)
             if ((rc = pack_norm(c, p + ".mlp.1", 2 * D, &L.bn))) return rc;
@@ -893,6 +952,7 @@ int imp_finalize_weights(imp_ctx* c) {
             const HostTensor* w3 = get(c, p + ".mlp.3.weight", (int64_t)2 * D * D);
             if (!w3) return IMP_E_KEY;
             if ((rc = upload_planes(c, &L.mlp3_p, w3->data.data(), (size_t)D, (size_t)2 * D))) return rc;
+            if ((rc = upload_wf(c, &L.mlp3_wf, w3->data.data(), D, 2 * D))) return rc;
         }
     }
     c->final_proj.assign(cfg.n_layers, Linear());
@@ -1298,6 +1358,25 @@ int imp_time_layer_gemm(imp_ctx* c, int batch, int n, int which, int dbg, int re
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     auto launch = [&]() -> hipError_t {
+        if (dbg <= -2) {                                        // gemm_wf.hip; -3 / -4 / -6: its probe switches 1 / 2 / 4
+            WfParams p;
+            memset(&p, 0, sizeof p);
+            p.nside = 2;
+            p.K = which == 0 ? D : 2 * D; p.ksplit = which == 1 ? D : p.K;
+            for (int s = 0; s < 2; ++s) {
+                WfSide& g = p.side[s];
+                g.M = n;
+                if (which == 0) { g.A = c->descw[s]; g.C = c->qkv[0][s]; g.sA_b = (long)n * D; g.sC_b = (long)n * 3 * D; }
+                if (which == 1) { g.A = c->descw[s]; g.A2 = c->attn_out[s]; g.C = c->hid[s]; g.sA_b = g.sA2_b = (long)n * D; g.sC_b = (long)n * 2 * D; g.out_stats = c->stats[s]; }
+                if (which == 2) { g.A = c->hid[s]; g.C = c->mdesc[s]; g.R = c->descw[s]; g.sA_b = (long)n * 2 * D; g.sC_b = (long)n * D; g.sR_b = (long)n * D; g.in_stats = c->nstat[s]; }
+            }
+            if (which == 0) { p.Wf_ = L.proj_wf; p.N = 3 * D; p.bias = L.proj.b; p.lda = D; p.ldc = 3 * D; }
+            if (which == 1) { p.Wf_ = L.mlp0f_wf; p.N = 2 * D; p.bias = L.mlp0f.b; p.lda = p.lda2 = D; p.ldc = 2 * D; }
+            if (which == 2) { p.Wf_ = L.mlp3_wf; p.N = D; p.bias = L.mlp3.b; p.lda = 2 * D; p.ldc = D; p.ldr = D; }
+            if (!p.Wf_) return hipErrorInvalidValue;
+            p.dbg = -dbg - 2;
+            return launch_gemm_wf(p, batch, st);
+        }
         if (dbg < 0) {
             GemmParams p = gemm_defaults(c, which == 0 ? D : 2 * D);
             if (which == 1) p.ksplit = D;

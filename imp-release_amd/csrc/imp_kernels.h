@@ -240,3 +240,31 @@ struct OtResidentParams {
 int ot_resident_plan(int batch, int n0, int n1, int max_wgs, int* nch, int* rpw, int* G);
 size_t ot_resident_ldx(int nch);
 hipError_t launch_ot_resident(const OtResidentParams& p, int nch, int rpw, hipStream_t stream);
+
+// ------------------------------------------------------------------------------------------------
+// weight-fragment split-half GEMM (gemm_wf.hip): static weights pre-split and pre-ordered into MFMA fragment order, the
+// activations of a 64-row tile converted once for the whole K extent.  K = 256 or 512, N a multiple of 128.
+struct WfSide {
+    const float* A;        // [b][M][lda], columns 0 .. ksplit
+    const float* A2;       // columns ksplit .. K come from here ([b][M][lda2], its column 0 = k - ksplit), or null
+    float* C;              // [b][M][ldc]
+    const float* R;        // residual [b][M][ldr] or null
+    const float* in_stats; // [b][K][2] finalised (mean, rstd): InstanceNorm + ReLU applied while staging, or null
+    float* out_stats;      // [b][row_tiles][N][2] per 64-row block (sum, M2 about the block mean), or null
+    long sA_b, sA2_b, sC_b, sR_b;
+    int M;
+};
+struct WfParams {
+    WfSide side[2];
+    const void* Wf_;       // (u32x4*) fragments of wf_pack
+    const float* bias;     // [N] or null
+    int K, ksplit, N;
+    int lda, lda2, ldc, ldr;
+    int nside;
+    int dbg;               // probe switches (tools/probe/gemm_wf_time.py): 1 no global stores, 2 no epilogue at all, 4 no residual / bias loads
+};
+hipError_t launch_gemm_wf(const WfParams& p, int batch, hipStream_t stream);
+bool gemm_wf_supported(int K, int N);
+int gemm_wf_stats_rows();
+// W [N][K] fp32 -> split-half MFMA fragments, 2 N K halves (host)
+void wf_pack(const float* W, int N, int K, _Float16* out);
