@@ -437,6 +437,52 @@ def test_opt_in_planes_gemm_path_agrees_with_the_default_path():
                               _cpu(a['mscores0'][-1]).numpy(), 0.2, TOL, f'planes path {n0}x{n1} B={B}'))
 
 
+WF_FIXTURES = ['gm_l3_alliters_b2', 'gm_l3_bigmean', 'gm_l9_t100_ragged', 'dgnns_l5_alliters', 'adagmn_masked_l9']
+
+
+@pytest.mark.parametrize('name', WF_FIXTURES)
+def test_weight_fragment_gemms_forced_vs_golden(name):
+    """csrc/gemm_wf.hip takes over the layer convolutions only for launches that cover the chip (IMP_GEMM_WF=1, default); forced
+    on everywhere (=2) it has to reproduce the reference fixtures like the default kernels do: ragged row counts, batch 2,
+    |mean| >> std channels in front of the InstanceNorm (its per-block (sum, M2) statistics), attention-sharing layers"""
+    import os
+    spec, z = load_golden(name)
+    cfg, sd, data = build_case(spec, device=DEV)
+    os.environ['IMP_GEMM_WF'] = '2'
+    try:
+        m = make_hip_model(spec, cfg, sd)
+        m._ensure_ctx()
+    finally:
+        del os.environ['IMP_GEMM_WF']
+    with torch.no_grad():
+        out = m.produce_matches(data, **spec.get('call', {}))
+    for i in range(int(z['n_emitted'])):
+        print(compare_matches(_cpu(out['indices0'][i]), _cpu(out['mscores0'][i]), z[f'indices0_{i}'], z[f'mscores0_{i}'],
+                              spec.get('call', {}).get('p', 0.2), TOL, f'{name}[{i}] wf forced'))
+
+
+def test_weight_fragment_gemms_default_rule_agrees_with_gemm_f32():
+    """B = 4, N = 2048 (the bench shape) takes the weight-fragment MLP kernels by default: same matches as with them switched off"""
+    import os
+    cfg = eval_config(n_layers=3, sinkhorn_iterations=20)
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=3)
+    on = make_hip_model('GM', cfg, sd)
+    os.environ['IMP_GEMM_WF'] = '0'
+    try:
+        off = make_hip_model('GM', cfg, sd)
+        off._ensure_ctx()
+    finally:
+        del os.environ['IMP_GEMM_WF']
+    pair = synthetic.make_correlated_pair(2048, 2048, seed=77, batch=4)
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+    with torch.no_grad():
+        a = off.produce_matches(data, p=0.2, only_last=True)
+        b = on.produce_matches(data, p=0.2, only_last=True)
+    print(compare_matches(_cpu(b['indices0'][-1]), _cpu(b['mscores0'][-1]), _cpu(a['indices0'][-1]).numpy(),
+                          _cpu(a['mscores0'][-1]).numpy(), 0.2, TOL, 'weight-fragment MLP kernels vs gemm_f32', strict=False))
+
+
 def test_sharded_eval_loop_single_rank():
     """BASELINE config 5 shape on one rank: several independent pairs through the EIMP loop, summary table out"""
     from imp_release_amd import eval_loop
