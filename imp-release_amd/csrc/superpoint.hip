@@ -1171,6 +1171,26 @@ __global__ __launch_bounds__(256) void sp_dense_desc_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------------ host side
+// A/B and probe switches, read from the environment once per process (README: knobs)
+struct SpSwitches {
+    bool prof, conv_v1, unfused_conv1a, detector_valu, nms_generic;
+    int tile;   // 0 = by rule, 8 or 16 forced
+};
+const SpSwitches& sp_switches() {
+    static const SpSwitches sw = [] {
+        SpSwitches x;
+        x.prof = getenv("IMP_SP_PROF") != nullptr;
+        x.conv_v1 = getenv("IMP_SP_CONV_V1") != nullptr;
+        x.unfused_conv1a = getenv("IMP_SP_UNFUSED_CONV1A") != nullptr;
+        x.detector_valu = getenv("IMP_SP_DETECTOR_VALU") != nullptr;
+        x.nms_generic = getenv("IMP_SP_NMS_GENERIC") != nullptr;
+        const char* t = getenv("IMP_SP_TILE");
+        x.tile = t ? atoi(t) : 0;
+        return x;
+    }();
+    return sw;
+}
+
 struct ConvW {
     u32x4* wf = nullptr;
     float* bias = nullptr;
@@ -1273,7 +1293,7 @@ int launch_convp(SpConvParams p, int total, int tiles_x, int ncu, hipStream_t st
     constexpr size_t ldsp = 2 * GeoT<TAPS, TWc>::LDS + (FIRST ? 2048 : 0);
     const void* fnp = reinterpret_cast<const void*>(&sp_convp_kernel<TAPS, POOL, FIRST, TWc>);
     SP_TRY(imp_grant_dynamic_lds(fnp, ldsp));
-    if (getenv("IMP_SP_PROF")) {                                        // probe: phase cycle counts per workgroup, printed per launch
+    if (sp_switches().prof) {                                           // probe: phase cycle counts per workgroup, printed per launch
         SpConvParams q = p;
         SP_TRY(hipMalloc(&q.prof, (size_t)nwg * 8 * sizeof(unsigned long long)));
         hipLaunchKernelGGL((sp_convp_kernel<TAPS, POOL, FIRST, TWc>), dim3(nwg), dim3(512), ldsp, st, q, total);
@@ -1297,8 +1317,7 @@ int launch_convp(SpConvParams p, int total, int tiles_x, int ncu, hipStream_t st
 template <int TAPS, int POOL, int FIRST>
 int launch_conv_t(const SpConvParams& p, hipStream_t st) {
     const int total = p.B * p.tiles_x * p.tiles_y * (p.cout / 64);
-    static const bool v1 = getenv("IMP_SP_CONV_V1") != nullptr;         // A/B: the one-tile-per-workgroup kernel
-    if (!v1) {
+    if (!sp_switches().conv_v1) {                                       // (A/B: IMP_SP_CONV_V1 = the one-tile-per-workgroup kernel)
         int dev = 0, ncu = 256;
         SP_TRY(hipGetDevice(&dev));
         SP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -1307,15 +1326,14 @@ int launch_conv_t(const SpConvParams& p, hipStream_t st) {
         const int tx8 = (p.W + 7) / 8;
         const int jobs16 = total, jobs8 = p.B * tx8 * p.tiles_y * (p.cout / 64);
         const double t16 = (double)((jobs16 + ncu - 1) / ncu), t8 = 0.55 * (double)((jobs8 + ncu - 1) / ncu);
-        static const char* force = getenv("IMP_SP_TILE");
-        const bool narrow = force ? atoi(force) == 8 : t8 < t16;
+        const int force = sp_switches().tile;
+        const bool narrow = force ? force == 8 : t8 < t16;
         return narrow ? launch_convp<TAPS, POOL, FIRST, 8>(p, jobs8, tx8, ncu, st) : launch_convp<TAPS, POOL, FIRST, 16>(p, jobs16, p.tiles_x, ncu, st);
     }
     const void* fn = reinterpret_cast<const void*>(&sp_conv_kernel<TAPS, POOL, FIRST>);
     constexpr size_t lds = Geo<TAPS>::LDS + (FIRST ? 1024 : 0);       // + the image patch of the fused conv1a
     SP_TRY(imp_grant_dynamic_lds(fn, lds));
-    static const bool prof = getenv("IMP_SP_PROF") != nullptr;          // probe: phase cycle counts per workgroup, printed per launch
-    if (prof) {
+    if (sp_switches().prof) {                                           // probe: phase cycle counts per workgroup, printed per launch
         SpConvParams q = p;
         SP_TRY(hipMalloc(&q.prof, (size_t)total * 4 * sizeof(unsigned long long)));
         hipLaunchKernelGGL((sp_conv_kernel<TAPS, POOL, FIRST>), dim3(total), dim3(256), lds, st, q, total);
@@ -1515,7 +1533,7 @@ int imp_sp_detect(imp_sp_ctx* c, const float* image, int B, int H, int W, int nm
     c->align_corners = align_corners ? 1 : 0;
     int rc;
     // encoder (nets/superpoint.py:172-183)
-    if (getenv("IMP_SP_UNFUSED_CONV1A")) {
+    if (sp_switches().unfused_conv1a) {
         const size_t nthr = (size_t)B * H * W * 16;
         hipLaunchKernelGGL(sp_conv1a_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, image, c->w1a, c->b1a, c->bufA, B, H, W);
         SP_TRY(hipGetLastError());
@@ -1531,14 +1549,14 @@ int imp_sp_detect(imp_sp_ctx* c, const float* image, int B, int H, int W, int nm
     if ((rc = launch_conv(c->heads, c->bufB, 128, 0, B, h, w, c->bufA, 512, 1, 0, st))) return rc;
     if ((rc = launch_conv(c->db, c->bufA, 512, 256, B, h, w, c->dmap, c->ddim, 0, 0, st))) return rc;   // raw convDb (:224)
     const int npix = B * h * w;
-    if (getenv("IMP_SP_DETECTOR_VALU")) {
+    if (sp_switches().detector_valu) {
         hipLaunchKernelGGL(sp_detector_kernel, dim3((npix + DPX - 1) / DPX), dim3(256), 0, st, c->bufA, 512, c->wpb, c->bpb, c->scores, npix, h, w);
     } else {
         if ((rc = launch_conv(c->pb, c->bufA, 512, 0, B, h, w, c->logits, 128, 0, 0, st))) return rc;     // convPb logits (:193)
         hipLaunchKernelGGL(sp_softmax_shuffle_kernel, dim3((npix + 3) / 4), dim3(256), 0, st, c->logits, c->scores, npix, h, w);
     }
     SP_TRY(hipGetLastError());
-    const bool nms_fast = nms_radius >= 1 && nms_radius <= 6 && !getenv("IMP_SP_NMS_GENERIC");
+    const bool nms_fast = nms_radius >= 1 && nms_radius <= 6 && !sp_switches().nms_generic;
     if (nms_fast) {
         switch (nms_radius) {
             case 1: rc = launch_nms_fast<1>(c->scores, c->nms, B, Hs, Ws, keypoint_threshold, remove_borders, c->tilecount, st); break;

@@ -189,6 +189,23 @@ def test_top_k_with_exact_ties_at_the_cut_is_deterministic():
             assert torch.equal(out['descriptors'][0], full['descriptors'][0][:, :k])
 
 
+def test_large_image_768x1024_top2048():
+    """a size the evaluation scripts of the SuperGlue lineage use for outdoor images; 6000+ tiles in the first layer, more candidates
+    than the direct-sort limit, k = 2048"""
+    from oracle import superpoint_oracle as spo
+    spec = dict(wseed=11, config=dict(max_keypoints=2048))
+    sp, sd = _module(spec, align_corners=False)
+    img = torch.from_numpy(synthetic.make_image(768, 1024, seed=31))
+    out = sp({'image': img.cuda()})
+    with torch.no_grad():
+        want = spo.forward(sd, img, max_keypoints=2048, align_corners=False)
+    perm, moved, boundary = match_keypoint_lists(out['keypoints'][0].cpu().numpy(), out['scores'][0].cpu().numpy(),
+                                                 want['keypoints'][0].numpy(), want['scores'][0].numpy(), True)
+    assert boundary <= 1
+    ok = perm >= 0
+    assert float((out['descriptors'][0].cpu()[:, ok] - want['descriptors'][0][:, perm[ok]]).abs().max()) < 1e-4
+
+
 def test_no_keypoints_above_the_threshold():
     spec = dict(wseed=9, config=dict(keypoint_threshold=2.0))
     sp, _ = _module(spec)
