@@ -30,8 +30,8 @@ FIELDS = ('K1', 'K2', 'R', 'T', 'e', 'f', 'kpt1', 'kpt2', 'desc1', 'desc2')
 
 
 def _finish(rec: dict, index: int, num_kpt: Optional[int]) -> dict:
-    t = np.asarray(rec['T'], dtype=np.float64).reshape(-1)
-    t = t / np.sqrt((t ** 2).sum())                                    # components/readers.py:17
+    t = np.asarray(rec['T'])
+    t = t / np.sqrt((t ** 2).sum())                                    # components/readers.py:16-17 (dtype and shape as stored)
     n = num_kpt if num_kpt else None
     return {'index': index, 'K1': np.asarray(rec['K1']), 'K2': np.asarray(rec['K2']), 'R': np.asarray(rec['R']), 't': t,
             'x1': np.asarray(rec['kpt1'])[:n], 'x2': np.asarray(rec['kpt2'])[:n],

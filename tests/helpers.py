@@ -126,3 +126,80 @@ def match_keypoint_lists(kp_got, sc_got, kp_ref, sc_ref, topk, tol=1e-5):
     if n_moved or n_boundary:
         EXCUSED.append(('superpoint top-k near-equal scores (moved, boundary)', n_moved + n_boundary))
     return perm, n_moved, n_boundary
+
+
+# ------------------------------------------------------------------------------------------------ reader pin
+class MemH5:
+    """Harness-side, in-memory stand-in for the slice of the `h5py` API that components/readers.py:8-33 and
+    imp_release_amd.data.H5PairStore use (h5py is not installed in the image): ``File(path)[group][name]`` -> dataset,
+    ``dataset[()]`` -> numpy array (a fresh copy), ``np.asarray(dataset)``, ``len(group)``, ``close()``.  String datasets of
+    shape [1] come back as object arrays of ``bytes`` like h5py's.  It replaces the FILE FORMAT only - the reference's reader
+    logic (field names, num_kpt cut, t normalisation, path decoding) runs unchanged on top of it.  Real HDF5 decoding stays
+    untested here."""
+    registry = {}
+
+    class Dataset:
+        def __init__(self, a):
+            self.a = a
+
+        def __getitem__(self, key):
+            return np.array(self.a[key]) if key != () else np.array(self.a)
+
+        def __array__(self, dtype=None, copy=None):
+            return np.array(self.a, dtype=dtype)
+
+        @property
+        def shape(self):
+            return self.a.shape
+
+    class Group(dict):
+        pass
+
+    class File:
+        def __init__(self, path, mode='r'):
+            self.root = MemH5.registry[path]
+
+        def __getitem__(self, k):
+            return self.root[k]
+
+        def close(self):
+            pass
+
+    @classmethod
+    def put(cls, path, records):
+        """records: list of dicts with the dump's field names (+ img_path1 / img_path2 strings), dump/dumper/base_dumper.py:78-111"""
+        root = {}
+        for k in ('K1', 'K2', 'R', 'T', 'e', 'f', 'desc1', 'desc2', 'kpt1', 'kpt2'):
+            root[k] = cls.Group({str(i): cls.Dataset(np.asarray(r[k])) for i, r in enumerate(records)})
+        for k in ('img_path1', 'img_path2'):
+            root[k] = cls.Group({str(i): cls.Dataset(np.array([r[k].encode('ascii')], dtype=object)) for i, r in enumerate(records)})
+        cls.registry[path] = root
+
+    @classmethod
+    def module(cls):
+        import types
+        m = types.ModuleType('h5py')
+        m.File = cls.File
+        return m
+
+
+def make_reader_records(seed: int = 0, n_pairs: int = 3, desc_dim: int = 32):
+    """seeded synthetic dump records with the dtypes the reference's dumper writes (kpt / desc float32 via write_feature, the
+    pair geometry as numpy float64) and image sizes per pair"""
+    g = np.random.default_rng(seed)
+    recs = []
+    for i in range(n_pairs):
+        n1, n2 = 180 + 11 * i, 140 + 17 * i                       # one side below num_kpt = 150 in the fixture
+        def kd(n):
+            kp = np.concatenate([g.uniform(0, 640, (n, 1)), g.uniform(0, 480, (n, 1)), g.uniform(0, 1, (n, 1))], 1).astype(np.float32)
+            de = g.standard_normal((n, desc_dim)).astype(np.float32)
+            return kp, de
+        k1, d1 = kd(n1)
+        k2, d2 = kd(n2)
+        q, _ = np.linalg.qr(g.standard_normal((3, 3)))
+        recs.append({'K1': np.array([[500. + i, 0, 320.], [0, 510., 240.], [0, 0, 1.]]), 'K2': np.array([[480., 0, 300.], [0, 470. + i, 250.], [0, 0, 1.]]),
+                     'R': q * np.sign(np.linalg.det(q)), 'T': g.standard_normal(3) * (2.0 + i), 'e': g.standard_normal((3, 3)),
+                     'f': g.standard_normal((3, 3)), 'kpt1': k1, 'kpt2': k2, 'desc1': d1, 'desc2': d2,
+                     'img_path1': f'seq{i}/images/a_{i}.jpg', 'img_path2': f'seq{i}/images/b_{i}.jpg',
+                     'size1': (480 - 8 * i, 640), 'size2': (360, 500 + 4 * i)})
+    return recs

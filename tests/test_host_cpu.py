@@ -256,3 +256,43 @@ def test_pair_store_roundtrip_and_feed_dict(tmp_path):
     except ImportError:
         with pytest.raises(ImportError, match='h5py'):
             data.H5PairStore(str(tmp_path / 'x.hdf5'), image_sizes=((480, 640), (480, 640)))
+
+
+def test_pair_stores_vs_the_reference_reader(tmp_path):
+    """`H5PairStore.record` / `NpzPairStore.record` against the outputs of the reference's own
+    `components/readers.py: standard_reader.run` (tests/golden/reader_standard.npz, captured by tools/make_golden.py
+    case_reader).  Both sides read the same seeded synthetic dump through the in-memory stand-in for the HDF5 FILE
+    (helpers.MemH5; h5py is not installed) - the reader logic is pinned, real HDF5 decoding is not."""
+    import sys
+    from helpers import MemH5, load_golden, make_reader_records
+    from imp_release_amd import data
+    spec, z = load_golden('reader_standard')
+    recs = make_reader_records(spec['seed'])
+    MemH5.put('mem://test', recs)
+    saved = sys.modules.get('h5py')
+    sys.modules['h5py'] = MemH5.module()
+    try:
+        sizes = lambda i: (recs[i]['size1'], recs[i]['size2'])             # noqa: E731
+        h5 = data.H5PairStore('mem://test', spec['num_kpt'], image_sizes=sizes)
+        assert data.convert_h5_to_npz('mem://test', str(tmp_path), image_sizes=sizes) == int(z['n_pairs'])
+    finally:
+        if saved is None:
+            del sys.modules['h5py']
+        else:
+            sys.modules['h5py'] = saved
+    npz = data.NpzPairStore(str(tmp_path), spec['num_kpt'])
+    assert len(h5) == len(npz) == int(z['n_pairs'])
+    for i in range(len(h5)):
+        for store in (h5, npz):
+            r = store.record(i)
+            for k in ('K1', 'K2', 'R', 't', 'x1', 'x2', 'desc1', 'desc2', 'e', 'f', 'r_gt', 't_gt'):
+                want = z[f'{k}_{i}']
+                got = np.asarray(r[k])
+                assert got.dtype == want.dtype and got.shape == want.shape and np.array_equal(got, want), (k, i, got.dtype, want.dtype)
+            assert r['index'] == i
+            d = data.feed_data(r, 'cpu')
+            # the reference uploads the decoded HWC image and the loops read only its shape (eval/eval_imp.py:56-57)
+            assert tuple(d['image0'].shape) == (1,) + tuple(int(v) for v in z[f'img1_shape_{i}'])
+            assert tuple(d['image1'].shape) == (1,) + tuple(int(v) for v in z[f'img2_shape_{i}'])
+            assert np.array_equal(d['T_0to1'], np.hstack([z[f'R_{i}'], z[f't_{i}'].reshape(3, 1)]))
+        assert h5.record(i)['img_path1'] == recs[i]['img_path1'] and h5.record(i)['img_path2'] == recs[i]['img_path2']

@@ -50,13 +50,13 @@ def main():
             k = state['n']
             state['n'] += a.workers
             d = {}
+            pair = torch.cat([imgs[(2 * k) % len(imgs)], imgs[(2 * k + 1) % len(imgs)]])       # both images in ONE front-end call
+            o = sp({'image': pair})
             for j in (0, 1):
-                im = imgs[(2 * k + j) % len(imgs)]
-                o = sp({'image': im})
-                d[f'keypoints{j}'] = o['keypoints'][0][None]
-                d[f'scores{j}'] = o['scores'][0][None]
-                d[f'descriptors{j}'] = o['descriptors'][0].t()[None].contiguous()
-                d[f'image{j}'] = im
+                d[f'keypoints{j}'] = o['keypoints'][j][None]
+                d[f'scores{j}'] = o['scores'][j][None]
+                d[f'descriptors{j}'] = o['descriptors'][j].t()[None].contiguous()
+                d[f'image{j}'] = pair[j:j + 1]
             out = gm.produce_matches(d, p=0.2, only_last=True)
             return out['indices0'][-1], out['mscores0'][-1]
         return step

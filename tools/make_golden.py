@@ -343,6 +343,44 @@ def case_superpoint(name, spec):
     assert worst[0] < 2e-6 and worst[1] < 2e-6
 
 
+def case_reader(name, seed=5, num_kpt=150):
+    """components/readers.py:8-33 (`standard_reader.run`) on a seeded synthetic dump.  h5py is not installed, so the FILE is the
+    in-memory stand-in tests/helpers.py:MemH5 (format only: the reference's reader logic runs unchanged on top of it) and
+    cv2.imread returns a zero image of the recorded size (the reference decodes the JPEGs only to read `.shape`)."""
+    if not wanted(name):
+        return
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import MemH5, make_reader_records
+    recs = make_reader_records(seed)
+    MemH5.put('mem://' + name, recs)
+    sizes = {}
+    for r in recs:
+        sizes[os.path.join('/raw', r['img_path1'])] = r['size1']
+        sizes[os.path.join('/raw', r['img_path2'])] = r['size2']
+    cv2.imread = lambda path: np.zeros(tuple(sizes[path]) + (3,), dtype=np.uint8)
+    saved = sys.modules.get('h5py')
+    sys.modules['h5py'] = MemH5.module()
+    try:
+        import importlib
+        readers = importlib.import_module('components.readers')
+        rd = readers.standard_reader({'rawdata_dir': '/raw', 'dataset_dir': 'mem://' + name, 'num_kpt': num_kpt})
+        arrays = {'n_pairs': np.array(len(rd))}
+        for i in range(len(rd)):
+            info = rd.run(i)
+            for k in ('K1', 'K2', 'R', 't', 'x1', 'x2', 'desc1', 'desc2', 'e', 'f', 'r_gt', 't_gt'):
+                arrays[f'{k}_{i}'] = np.asarray(info[k])
+            arrays[f'img1_shape_{i}'] = np.array(info['img1'].shape)
+            arrays[f'img2_shape_{i}'] = np.array(info['img2'].shape)
+            assert info['index'] == i
+        rd.close()
+    finally:
+        if saved is None:
+            del sys.modules['h5py']
+        else:
+            sys.modules['h5py'] = saved
+    save(name, {'kind': 'reader', 'seed': seed, 'num_kpt': num_kpt}, arrays, f'{len(recs)} pairs')
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -419,6 +457,8 @@ def main():
                                                        config=dict(max_keypoints=-1)))
     case_superpoint('superpoint_d128_96x96', dict(wseed=4, iseed=9, height=96, width=96, descriptor_dim=128,
                                                   config=dict(max_keypoints=-1, descriptor_dim=128, nms_radius=2)))
+    # (8) the reference's dataset reader (f-2) on an in-memory stand-in for the HDF5 file
+    case_reader('reader_standard')
 
 
 if __name__ == '__main__':
