@@ -41,3 +41,9 @@ def pytest_terminal_summary(terminalreporter):
                                 f'comparisons; golden-fixture comparisons are strict (0 allowed)')
     for what, c in helpers.EXCUSED:
         terminalreporter.write_line(f'  excused: {what}: {c}')
+    if helpers.SP_MOVED:
+        moved, cut = sum(m for _, m, _ in helpers.SP_MOVED), sum(b for _, _, b in helpers.SP_MOVED)
+        terminalreporter.write_line(f'superpoint (sorted top-k outputs): {moved} list positions differ inside runs of reference scores closer than the '
+                                    f'score tolerance, {cut} keypoints swapped with an equally scored one at the cut; everything else identical')
+        for what, _, _ in helpers.SP_MOVED:
+            terminalreporter.write_line(f'  {what}')

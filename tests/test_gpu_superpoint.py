@@ -206,6 +206,24 @@ def test_large_image_768x1024_top2048():
     assert float((out['descriptors'][0].cpu()[:, ok] - want['descriptors'][0][:, perm[ok]]).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize('H,W', [(8, 8), (9, 17), (31, 33), (16, 200), (200, 24)])
+def test_tiny_and_odd_image_sizes(H, W):
+    """the smallest legal image (one 8 x 8 cell), sizes that are not multiples of 8 or of the tile, extreme aspect ratios"""
+    from oracle import superpoint_oracle as spo
+    spec = dict(wseed=12, config=dict(max_keypoints=-1, remove_borders=1, nms_radius=2))
+    sp, sd = _module(spec, align_corners=True)
+    img = torch.from_numpy(synthetic.make_image(H, W, seed=H * 31 + W))
+    out = sp({'image': img.cuda()})
+    with torch.no_grad():
+        want = spo.forward(sd, img, nms_radius=2, remove_borders=1, align_corners=True)
+    assert torch.equal(out['keypoints'][0].cpu(), want['keypoints'][0])
+    if want['keypoints'][0].shape[0]:
+        assert float((out['scores'][0].cpu() - want['scores'][0]).abs().max()) < 1e-5
+        assert float((out['descriptors'][0].cpu() - want['descriptors'][0]).abs().max()) < 1e-4
+    dense, desc = sp.extract({'image': img.cuda()})
+    assert tuple(dense.shape) == (1, H // 8 * 8, W // 8 * 8) and tuple(desc.shape) == (1, 256, H // 8, W // 8)
+
+
 def test_no_keypoints_above_the_threshold():
     spec = dict(wseed=9, config=dict(keypoint_threshold=2.0))
     sp, _ = _module(spec)

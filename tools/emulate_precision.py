@@ -16,6 +16,7 @@ Schemes:
     bf16x3    same with bfloat16 components
     bf16x6    three bfloat16 components: all six products of order <= 2
     f16x1     a single half product (what a plain fp16 MFMA path would do)
+    f16x3+p1  f16x3, but the attention probabilities enter P.V as ONE half (2 products instead of 3 there) - an idea that was tested and rejected
 Sinkhorn storage: 23 (fp32), 15 (3-byte copy), 7 (2-byte, bfloat16-like), 10 (2-byte, half-like mantissa)
 """
 import argparse
@@ -56,6 +57,8 @@ def _components(x, kind, n):
 def make_matmul(scheme):
     if scheme == 'fp32':
         return _matmul
+    p_single = scheme.endswith('+p1')
+    scheme = scheme.replace('+p1', '')
     kind, n, pairs = {'f16x3': ('f16', 2, [(1, 0), (0, 1), (0, 0)]),
                       'bf16x3': ('bf16', 2, [(1, 0), (0, 1), (0, 0)]),
                       'bf16x6': ('bf16', 3, [(2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)]),
@@ -64,6 +67,10 @@ def make_matmul(scheme):
     def mm(a, b):
         if a.dtype != torch.float32 or b.dtype != torch.float32:
             return _matmul(a, b)
+        if p_single and a.dim() == 4 and b.dim() == 4:
+            # the probabilities x values product of attention (oracle: prob @ v) with P carried as ONE half: P_hi.V_lo + P_hi.V_hi
+            ca, cb = _components(a, kind, 1), _components(b, kind, 2)
+            return _matmul(ca[0], cb[1]) + _matmul(ca[0], cb[0])
         ca, cb = _components(a, kind, n), _components(b, kind, n)
         out = None
         for i, j in pairs:                       # small terms first, fp32 accumulation
@@ -157,7 +164,7 @@ def main():
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     names = [n for n in a.fixtures.split(',') if n] or golden_names(['gm_l', 'dgnns_l', 'adagmn_masked'])
-    variants = [('fp32', 23), ('f16x3', 23), ('bf16x3', 23), ('bf16x6', 23), ('f16x1', 23), ('fp32', 15), ('fp32', 10), ('fp32', 7)]
+    variants = [('fp32', 23), ('f16x3', 23), ('f16x3+p1', 23), ('bf16x3', 23), ('bf16x6', 23), ('f16x1', 23), ('fp32', 15), ('fp32', 10), ('fp32', 7)]
     print(f'{"fixture":26s} ' + ' '.join(f'{s + ("" if b == 23 else f"/P{b}"):>17s}' for s, b in variants))
     print(f'{"":26s} ' + ' '.join(f'{"idx-bad  max|dms|":>17s}' for _ in variants))
     tot = [[0, 0.0] for _ in variants]
