@@ -374,6 +374,9 @@ __device__ unsigned long long pp_prof[8][8];
 #ifndef PP_PKADD
 #define PP_PKADD 0          // row sums with v_pk_add_f32: measured 118 vs 95 us (the register pairing costs more than the adds save)
 #endif
+#ifndef PP_P1
+#define PP_P1 0             // EXPERIMENT (not the product): probabilities enter P.V as ONE half (2 MFMAs per product instead of 3 there);
+#endif                      // DESIGN.md section 4 has what it buys and what it costs in score accuracy
 #ifndef PP_LOADS_IN_X
 #define PP_LOADS_IN_X 0    // where the global loads of the staged tile are issued: matrix phase (1) or vector phase (0); measured equal
 #endif
@@ -532,7 +535,8 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 #pragma unroll
         for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[DT + d], ph[jb][s2], oacc[d], 0, 0, 0);
 #pragma unroll
-        for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[d], pl[jb][s2], oacc[d], 0, 0, 0);
+        for (int d = 0; d < DT; ++d)
+            if (!PP_P1) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[d], pl[jb][s2], oacc[d], 0, 0, 0);
 #pragma unroll
         for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[d], ph[jb][s2], oacc[d], 0, 0, 0);
     };

@@ -1318,9 +1318,16 @@ template <int TAPS, int POOL, int FIRST>
 int launch_conv_t(const SpConvParams& p, hipStream_t st) {
     const int total = p.B * p.tiles_x * p.tiles_y * (p.cout / 64);
     if (!sp_switches().conv_v1) {                                       // (A/B: IMP_SP_CONV_V1 = the one-tile-per-workgroup kernel)
-        int dev = 0, ncu = 256;
+        int dev = 0;
         SP_TRY(hipGetDevice(&dev));
-        SP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        static int ncu_of[64] = {0};                                      // CU count per device, looked up once
+        if (dev < 0 || dev >= 64) return imp_fail(IMP_E_ARG, "device index out of range");
+        if (!ncu_of[dev]) {
+            int n = 0;
+            SP_TRY(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+            ncu_of[dev] = n > 0 ? n : 256;
+        }
+        const int ncu = ncu_of[dev];
         // tile width 16 or 8 pixels: whichever needs less time for the busiest workgroup (a half tile costs ~0.55 of a full one:
         // same loader work per pixel, twice the weight traffic per MFMA) - the layers below 240 x 320 have too few full tiles
         const int tx8 = (p.W + 7) / 8;
