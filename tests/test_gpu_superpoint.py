@@ -224,6 +224,32 @@ def test_tiny_and_odd_image_sizes(H, W):
     assert tuple(dense.shape) == (1, H // 8 * 8, W // 8 * 8) and tuple(desc.shape) == (1, 256, H // 8, W // 8)
 
 
+@pytest.mark.parametrize('case', range(12))
+def test_randomised_configurations_vs_oracle(case):
+    """every fast NMS radius (1..6) and the generic ones (0, 7), borders, thresholds, top-k on / off, odd sizes, D = 128 / 256"""
+    from oracle import superpoint_oracle as spo
+    g = np.random.default_rng(1000 + case)
+    H, W = int(g.integers(40, 200)), int(g.integers(40, 260))
+    radius = [1, 2, 3, 4, 5, 6, 0, 7, 4, 3, 2, 5][case]
+    cfg = dict(nms_radius=radius, remove_borders=int(g.integers(0, 9)), keypoint_threshold=float(g.choice([0.0, 0.001, 0.0025, 0.01, 0.05])),
+               max_keypoints=int(g.choice([-1, -1, 50, 400])), descriptor_dim=int(g.choice([128, 256])))
+    spec = dict(wseed=100 + case, descriptor_dim=cfg['descriptor_dim'], config=cfg)
+    ac = bool(case & 1)
+    sp, sd = _module(spec, align_corners=ac)
+    img = torch.from_numpy(synthetic.make_image(H, W, seed=500 + case))
+    out = sp({'image': img.cuda()})
+    with torch.no_grad():
+        want = spo.forward(sd, img, nms_radius=radius, keypoint_threshold=cfg['keypoint_threshold'], max_keypoints=cfg['max_keypoints'],
+                           remove_borders=cfg['remove_borders'], align_corners=ac)
+    topk = cfg['max_keypoints'] >= 0 and want['keypoints'][0].shape[0] == cfg['max_keypoints']
+    perm, moved, boundary = match_keypoint_lists(out['keypoints'][0].cpu().numpy(), out['scores'][0].cpu().numpy(),
+                                                 want['keypoints'][0].numpy(), want['scores'][0].numpy(), topk)
+    assert boundary <= 1, (cfg, H, W)
+    ok = perm >= 0
+    if ok.any():
+        assert float((out['descriptors'][0].cpu()[:, ok] - want['descriptors'][0][:, perm[ok]]).abs().max()) < 1e-4
+
+
 def test_no_keypoints_above_the_threshold():
     spec = dict(wseed=9, config=dict(keypoint_threshold=2.0))
     sp, _ = _module(spec)
