@@ -704,6 +704,34 @@ unsigned resident_tags(imp_ctx* c, int iterations) {
 }
 
 // the resident launch on the device's lane, joined to `st` on both sides; returns IMP_OK, or >0 when not applicable
+// one resident launch over the pairs [b0, b0 + nb) of a batch (all per-pair arrays are indexed b * stride inside the kernel)
+int run_score_resident_launch(imp_ctx* c, int batch, int b0, int nb, int n0, int n1, const float* dist, float bin, int iterations, float* scores,
+                              bool want_max, bool want_uv, int nch, int rpw, int G, hipStream_t st) {
+    ResidentLane* lane = resident_lane(c->device);
+    if (!lane) return 1;
+    OtResidentParams p;
+    memset(&p, 0, sizeof p);
+    p.dist = dist + (size_t)b0 * n0 * n1; p.B = nb; p.n0 = n0; p.n1 = n1; p.T = iterations; p.G = G; p.bin = bin;
+    p.xpart = c->xpart; p.xv = c->xv; p.xmax = c->xmax; p.status = c->xstatus;
+    p.tag_base = resident_tags(c, iterations);
+    if (want_uv) {
+        p.ldu = (n0 + 1 + 3) & ~3; p.ldv = (n1 + 1 + 3) & ~3;
+        p.u = c->ot.u + (size_t)b0 * p.ldu; p.v = c->ot.v + (size_t)b0 * p.ldv;
+    }
+    p.scores = scores ? scores + (size_t)b0 * (n0 + 1) * (n1 + 1) : nullptr;
+    if (want_max) {
+        p.max0 = c->max0 + (size_t)b0 * n0; p.arg0 = c->arg0 + (size_t)b0 * n0;
+        p.max1 = c->max1 + (size_t)b0 * n1; p.arg1 = c->arg1 + (size_t)b0 * n1;
+    }
+    std::lock_guard<std::mutex> lock(lane->mu);
+    HIP_TRY(hipEventRecord(c->ev_in, st));
+    HIP_TRY(hipStreamWaitEvent(lane->stream, c->ev_in, 0));
+    HIP_TRY(launch_ot_resident(p, nch, rpw, lane->stream));
+    HIP_TRY(hipEventRecord(c->ev_out, lane->stream));
+    HIP_TRY(hipStreamWaitEvent(st, c->ev_out, 0));
+    return IMP_OK;
+}
+
 int run_score_resident(imp_ctx* c, int batch, int n0, int n1, const float* dist, float bin, int iterations, float* scores,
                        bool want_max, bool want_uv, hipStream_t st) {
     if (!c->ot_resident) return 1;
@@ -711,24 +739,20 @@ int run_score_resident(imp_ctx* c, int batch, int n0, int n1, const float* dist,
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 1;   // graphs: streaming path
     int rc = ensure_resident_buffers(c, batch);
     if (rc) return rc;
+    // EXPERIMENT (IMP_OT_SPLIT=k, default 1): the batch as k launches of batch / k pairs, each planned for num_cus / k workgroups,
+    // so that a launch holds the registers of only a part of the CUs and another stream's kernels can use the rest
+    static const int split = [] { const char* e = getenv("IMP_OT_SPLIT"); const int v = e ? atoi(e) : 1; return v > 1 ? v : 1; }();
+    const int nsub = (split > 1 && batch % split == 0) ? split : 1;
+    const int bsub = batch / nsub;
     int nch, rpw, G;
-    if (!ot_resident_plan(batch, n0, n1, c->num_cus, &nch, &rpw, &G)) return 1;
-    ResidentLane* lane = resident_lane(c->device);
-    if (!lane) return 1;
-    OtResidentParams p;
-    memset(&p, 0, sizeof p);
-    p.dist = dist; p.B = batch; p.n0 = n0; p.n1 = n1; p.T = iterations; p.G = G; p.bin = bin;
-    p.xpart = c->xpart; p.xv = c->xv; p.xmax = c->xmax; p.status = c->xstatus;
-    p.tag_base = resident_tags(c, iterations);
-    if (want_uv) { p.u = c->ot.u; p.ldu = (n0 + 1 + 3) & ~3; p.v = c->ot.v; p.ldv = (n1 + 1 + 3) & ~3; }
-    p.scores = scores;
-    if (want_max) { p.max0 = c->max0; p.arg0 = c->arg0; p.max1 = c->max1; p.arg1 = c->arg1; }
-    std::lock_guard<std::mutex> lock(lane->mu);
-    HIP_TRY(hipEventRecord(c->ev_in, st));
-    HIP_TRY(hipStreamWaitEvent(lane->stream, c->ev_in, 0));
-    HIP_TRY(launch_ot_resident(p, nch, rpw, lane->stream));
-    HIP_TRY(hipEventRecord(c->ev_out, lane->stream));
-    HIP_TRY(hipStreamWaitEvent(st, c->ev_out, 0));
+    if (!ot_resident_plan(bsub, n0, n1, c->num_cus / nsub, &nch, &rpw, &G)) {
+        if (nsub == 1 || !ot_resident_plan(batch, n0, n1, c->num_cus, &nch, &rpw, &G)) return 1;
+        return run_score_resident_launch(c, batch, 0, batch, n0, n1, dist, bin, iterations, scores, want_max, want_uv, nch, rpw, G, st);
+    }
+    for (int i = 0; i < nsub; ++i) {
+        rc = run_score_resident_launch(c, batch, i * bsub, bsub, n0, n1, dist, bin, iterations, scores, want_max, want_uv, nch, rpw, G, st);
+        if (rc) return rc;
+    }
     return IMP_OK;
 }
 
