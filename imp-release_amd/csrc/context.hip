@@ -704,15 +704,29 @@ unsigned resident_tags(imp_ctx* c, int iterations) {
 }
 
 // the resident launch on the device's lane, joined to `st` on both sides; returns IMP_OK, or >0 when not applicable
+// chooses the decomposition of a resident launch.  XCD-local (every pair on the 32 CUs of one XCD, exchanges through that XCD's
+// L2 instead of across the fabric) whenever a pair fits there: IMP_OT_LOCAL=0 disables.  Returns 0 when nothing fits.
+int plan_resident(imp_ctx* c, int batch, int n0, int n1, int max_wgs, int* nch, int* rpw, int* G, int* local) {
+    static const bool allow_local = [] { const char* e = getenv("IMP_OT_LOCAL"); return !(e && atoi(e) == 0); }();
+    *local = 0;
+    const int per_xcd = (batch + 7) / 8;
+    if (allow_local && max_wgs >= c->num_cus && per_xcd <= 32 && ot_resident_plan(1, n0, n1, 32 / per_xcd, nch, rpw, G)) {
+        *local = 1;
+        return 1;
+    }
+    return ot_resident_plan(batch, n0, n1, max_wgs, nch, rpw, G);
+}
+
 // one resident launch over the pairs [b0, b0 + nb) of a batch (all per-pair arrays are indexed b * stride inside the kernel)
 int run_score_resident_launch(imp_ctx* c, int batch, int b0, int nb, int n0, int n1, const float* dist, float bin, int iterations, float* scores,
-                              bool want_max, bool want_uv, int nch, int rpw, int G, hipStream_t st) {
+                              bool want_max, bool want_uv, int nch, int rpw, int G, int local, hipStream_t st) {
     ResidentLane* lane = resident_lane(c->device);
     if (!lane) return 1;
     OtResidentParams p;
     memset(&p, 0, sizeof p);
     p.dist = dist + (size_t)b0 * n0 * n1; p.B = nb; p.n0 = n0; p.n1 = n1; p.T = iterations; p.G = G; p.bin = bin;
     p.xpart = c->xpart; p.xv = c->xv; p.xmax = c->xmax; p.status = c->xstatus;
+    p.local = local;
     p.tag_base = resident_tags(c, iterations);
     if (want_uv) {
         p.ldu = (n0 + 1 + 3) & ~3; p.ldv = (n1 + 1 + 3) & ~3;
@@ -744,13 +758,13 @@ int run_score_resident(imp_ctx* c, int batch, int n0, int n1, const float* dist,
     static const int split = [] { const char* e = getenv("IMP_OT_SPLIT"); const int v = e ? atoi(e) : 1; return v > 1 ? v : 1; }();
     const int nsub = (split > 1 && batch % split == 0) ? split : 1;
     const int bsub = batch / nsub;
-    int nch, rpw, G;
-    if (!ot_resident_plan(bsub, n0, n1, c->num_cus / nsub, &nch, &rpw, &G)) {
-        if (nsub == 1 || !ot_resident_plan(batch, n0, n1, c->num_cus, &nch, &rpw, &G)) return 1;
-        return run_score_resident_launch(c, batch, 0, batch, n0, n1, dist, bin, iterations, scores, want_max, want_uv, nch, rpw, G, st);
+    int nch, rpw, G, local;
+    if (!plan_resident(c, bsub, n0, n1, c->num_cus / nsub, &nch, &rpw, &G, &local)) {
+        if (nsub == 1 || !plan_resident(c, batch, n0, n1, c->num_cus, &nch, &rpw, &G, &local)) return 1;
+        return run_score_resident_launch(c, batch, 0, batch, n0, n1, dist, bin, iterations, scores, want_max, want_uv, nch, rpw, G, local, st);
     }
     for (int i = 0; i < nsub; ++i) {
-        rc = run_score_resident_launch(c, batch, i * bsub, bsub, n0, n1, dist, bin, iterations, scores, want_max, want_uv, nch, rpw, G, st);
+        rc = run_score_resident_launch(c, batch, i * bsub, bsub, n0, n1, dist, bin, iterations, scores, want_max, want_uv, nch, rpw, G, local, st);
         if (rc) return rc;
     }
     return IMP_OK;
@@ -1315,16 +1329,17 @@ int imp_time_sinkhorn(imp_ctx* c, int batch, int n, int iterations, float* ms, v
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     float t = 0.f;
-    int nch, rpw, G;
+    int nch, rpw, G, local = 0;
     rc = c->ot_resident ? ensure_resident_buffers(c, batch) : 1;
     if (rc < 0) return rc;
-    if (rc == 0 && ot_resident_plan(batch, n, n, c->num_cus, &nch, &rpw, &G)) {
+    if (rc == 0 && plan_resident(c, batch, n, n, c->num_cus, &nch, &rpw, &G, &local)) {
         // resident path: per-iteration time = (launch with T iterations - launch with 0 iterations) / T, both on `st`
         // (nothing else runs during a timing call), events on the stream the kernel is launched on
         OtResidentParams p;
         memset(&p, 0, sizeof p);
         p.dist = c->dist; p.B = batch; p.n0 = n; p.n1 = n; p.G = G; p.bin = 1.f;
         p.xpart = c->xpart; p.xv = c->xv; p.xmax = c->xmax; p.status = c->xstatus;
+        p.local = local;
         float tt[2];
         for (int k = 0; k < 2; ++k) {
             p.T = k ? iterations : 0;

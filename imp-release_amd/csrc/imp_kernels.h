@@ -231,6 +231,7 @@ struct OtResidentParams {
     unsigned tag_base;        // tags of this launch are tag_base + 1 .. tag_base + 2 T + 1: never reused on these buffers
     int* status;              // device flag, set to 1 when a wait timed out
     unsigned long long* prof; // optional [6]: phase cycle counts of workgroup 0 (probe), null in the product
+    int local;                // XCD-local launch: every pair's G <= 32 workgroups on one XCD (plain stores, L2-served polls)
     float* u; int ldu;        // optional outputs in the layout of OtBuffers (u [B][ldu], v [B][ldv]); v is required with u
     float* v; int ldv;
     float* scores;            // optional [B][n0+1][n1+1]

@@ -89,12 +89,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 #endif
 constexpr int AUX_POLL = OTR_POLL_AUX;
 // four consecutive values of an exchange vector = 4 granules = 32 bytes at granule index 4 q
+// AUX = AUX_SC1: write-through, the line is dropped from the writer's L2 (readers on other XCDs fetch it across the fabric);
+// AUX = 0 (XCD-local launches): a plain store - the line stays in the ONE L2 that all workgroups of the pair share, and the
+// readers' sc1 polls (which bypass only their L1) are served from it
+template <int AUX>
 __device__ __forceinline__ void stg4(__amdgpu_buffer_rsrc_t r, int q, const f32x4 v, unsigned tag) {
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), tag, __float_as_uint(v[1]), tag}, r, q * 32, 0, AUX_SC1);
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[2]), tag, __float_as_uint(v[3]), tag}, r, q * 32 + 16, 0, AUX_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), tag, __float_as_uint(v[1]), tag}, r, q * 32, 0, AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[2]), tag, __float_as_uint(v[3]), tag}, r, q * 32 + 16, 0, AUX);
 }
+template <int AUX>
 __device__ __forceinline__ void stg1(__amdgpu_buffer_rsrc_t r, int idx, float v, unsigned tag) {
-    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v), tag}, r, idx * 8, 0, AUX_SC1);
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v), tag}, r, idx * 8, 0, AUX);
 }
 // poll until all four granules carry `tag`; `dead` (per thread) short-circuits every wait after a time-out
 __device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, int q, unsigned tag, int* status, bool& dead) {
@@ -120,8 +125,11 @@ __device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, int q, unsigned 
 // partial store)  2 wait + stage of the slice  3 slice reduce + v store  4 wait + read of v  5 v sum
 #define OTR_CLK(i) if (p.prof) { const unsigned long long c_ = __builtin_readcyclecounter(); prof_acc[i] += c_ - tlast; tlast = c_; }
 
-template <int NCH, int RPW>
+// LOCAL: every pair lives on ONE XCD (hardware places block i on XCD i % 8): block i serves pair (i % 8) + 8 * (slot / G), group slot % G with
+// slot = i / 8, so all G <= 32 workgroups of a pair share an L2 and the exchanges never cross the fabric
+template <int NCH, int RPW, int LOCAL>
 __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentParams p) {
+    constexpr int ST_AUX = LOCAL ? 0 : AUX_SC1;
     constexpr int DCOL = 256 * NCH;            // exchange vectors: inner columns | dustbin column | 3 pads
     constexpr int LDX = DCOL + 4;
     constexpr int NQ = LDX / 4;                // float4 chunks of an exchange vector
@@ -132,7 +140,16 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = p.G;
-    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    int b, g;
+    if (LOCAL) {
+        const int slot = blockIdx.x >> 3;
+        b = (int)(blockIdx.x & 7) + 8 * (slot / G);
+        g = slot % G;
+        if (b >= p.B) return;                  // uniform per workgroup, before any exchange
+    } else {
+        b = blockIdx.x / G;
+        g = blockIdx.x % G;
+    }
     const int n0 = p.n0, n1 = p.n1;
     const int r0 = g * ROWS + wave * RPW;
     bool dead = false;
@@ -242,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
                 const f32x4 t = *reinterpret_cast<const f32x4*>(red + w * LDX + 4 * q);
                 s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
             }
-            stg4(rs_part, g * NQ + q, s, tag_p);
+            stg4<ST_AUX>(rs_part, g * NQ + q, s, tag_p);
         }
         __syncthreads();                           // everyone is done with the wave partials in `red`
         OTR_CLK(1)
@@ -279,7 +296,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
                     const bool real = xi < n1 || dust;
                     const float t = fmaf(c0, u_last, s);              // + dustbin row entry * its u
                     const float marg = dust ? (float)(n1 + 1) : 1.f;  // nets/layers.py:43-44
-                    stg1(rs_v, xi, real ? marg / (t + OT_EPS) : 0.f, tag_v);
+                    stg1<ST_AUX>(rs_v, xi, real ? marg / (t + OT_EPS) : 0.f, tag_v);
                 }
             }
         }
@@ -299,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         }
         OTR_CLK(5)
     }
-    if (p.prof && blockIdx.x == 0 && tid == 0)
+    if (p.prof && b == 0 && g == 0 && tid == 0)
         for (int i = 0; i < 6; ++i) p.prof[i] = prof_acc[i];
 
     // ---- outputs ----------------------------------------------------------------------------------------------------
@@ -394,8 +411,8 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         const unsigned tag_m = p.tag_base + 2u * p.T + 1u;
         const __amdgpu_buffer_rsrc_t rs_mx = make_rsrc(p.xmax + (size_t)b * G * 4 * LDX, (unsigned)((size_t)G * 2 * LDX * 8));
         for (int q = tid; q < DCOL / 4; q += 512) {
-            stg4(rs_mx, g * 2 * NQ + q, *reinterpret_cast<const f32x4*>(mv + 4 * q), tag_m);
-            stg4(rs_mx, g * 2 * NQ + NQ + q, *reinterpret_cast<const f32x4*>(red + LDX + 4 * q), tag_m);
+            stg4<ST_AUX>(rs_mx, g * 2 * NQ + q, *reinterpret_cast<const f32x4*>(mv + 4 * q), tag_m);
+            stg4<ST_AUX>(rs_mx, g * 2 * NQ + NQ + q, *reinterpret_cast<const f32x4*>(red + LDX + 4 * q), tag_m);
         }
         __syncthreads();                           // mv / mi are about to be overwritten by the staging
         const int ncq = (DCOL / 4 + G - 1) / G;        // float4 column chunks per workgroup
@@ -437,8 +454,14 @@ hipError_t launch_one(const OtResidentParams& p, hipStream_t stream) {
     if (stage2 > red) red = stage2;
     const size_t lds = (LDX + red) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    if (hipError_t e = imp_grant_dynamic_lds((const void*)ot_resident_kernel<NCH, RPW>, lds)) return e;
-    hipLaunchKernelGGL((ot_resident_kernel<NCH, RPW>), dim3(p.B * p.G), dim3(512), lds, stream, p);
+    if (p.local) {
+        if (p.G * ((p.B + 7) / 8) > 32) return hipErrorInvalidValue;      // a pair's workgroups must fit the 32 CUs of its XCD
+        if (hipError_t e = imp_grant_dynamic_lds((const void*)ot_resident_kernel<NCH, RPW, 1>, lds)) return e;
+        hipLaunchKernelGGL((ot_resident_kernel<NCH, RPW, 1>), dim3(8 * p.G * ((p.B + 7) / 8)), dim3(512), lds, stream, p);
+        return hipGetLastError();
+    }
+    if (hipError_t e = imp_grant_dynamic_lds((const void*)ot_resident_kernel<NCH, RPW, 0>, lds)) return e;
+    hipLaunchKernelGGL((ot_resident_kernel<NCH, RPW, 0>), dim3(p.B * p.G), dim3(512), lds, stream, p);
     return hipGetLastError();
 }
 
