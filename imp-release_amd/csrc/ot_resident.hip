@@ -467,7 +467,7 @@ hipError_t launch_one(const OtResidentParams& p, hipStream_t stream) {
 
 struct Shape { int nch, rpw; };
 // (NCH, RPW) instantiations; NCH * RPW <= 32 float4 = 128 VGPRs of matrix per lane
-constexpr Shape kShapes[] = {{2, 2}, {2, 4}, {2, 8}, {4, 2}, {4, 4}, {4, 8}, {6, 2}, {6, 4}, {8, 2}, {8, 4}, {12, 2}, {16, 1}};
+constexpr Shape kShapes[] = {{2, 2}, {2, 4}, {2, 8}, {3, 2}, {3, 4}, {3, 8}, {4, 2}, {4, 4}, {4, 8}, {5, 2}, {5, 4}, {6, 2}, {6, 4}, {8, 2}, {8, 4}, {12, 2}, {16, 1}};
 // ((2, 16) and (16, 2) would also hold 128 matrix registers but spill at the 256-VGPR budget of 2 waves per SIMD)
 
 }  // namespace
@@ -493,8 +493,8 @@ size_t ot_resident_ldx(int nch) { return (size_t)256 * nch + 4; }
 
 hipError_t launch_ot_resident(const OtResidentParams& p, int nch, int rpw, hipStream_t stream) {
 #define IMP_OTR(N, R) if (nch == N && rpw == R) return launch_one<N, R>(p, stream)
-    IMP_OTR(2, 2); IMP_OTR(2, 4); IMP_OTR(2, 8); IMP_OTR(4, 2); IMP_OTR(4, 4); IMP_OTR(4, 8);
-    IMP_OTR(6, 2); IMP_OTR(6, 4); IMP_OTR(8, 2); IMP_OTR(8, 4); IMP_OTR(12, 2); IMP_OTR(16, 1);
+    IMP_OTR(2, 2); IMP_OTR(2, 4); IMP_OTR(2, 8); IMP_OTR(3, 2); IMP_OTR(3, 4); IMP_OTR(3, 8); IMP_OTR(4, 2); IMP_OTR(4, 4); IMP_OTR(4, 8);
+    IMP_OTR(5, 2); IMP_OTR(5, 4); IMP_OTR(6, 2); IMP_OTR(6, 4); IMP_OTR(8, 2); IMP_OTR(8, 4); IMP_OTR(12, 2); IMP_OTR(16, 1);
 #undef IMP_OTR
     return hipErrorInvalidValue;
 }
