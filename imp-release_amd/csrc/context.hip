@@ -410,6 +410,16 @@ int run_kenc(imp_ctx* c, int batch, const int n[2], const float* const kpts[2], 
     return IMP_OK;
 }
 
+// column-pass split of a weight-fragment GEMM launch: enough workgroups to cover the chip (the largest divisor of the pass count
+// that keeps tiles x split at or under ~1.5 workgroups per CU)
+int wf_pass_split(const imp_ctx* c, long tiles, int N) {
+    const int npass = N / 128;
+    int best = 1;
+    for (int d = 1; d <= npass; ++d)
+        if (npass % d == 0 && tiles * d <= (long)c->num_cus * 3 / 2) best = d;
+    return best;
+}
+
 int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const desc[2], float* const out[2],
               const uint8_t* const kmask[2], hipStream_t st) {
     const imp_config& cfg = c->cfg;
@@ -428,11 +438,13 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
     const long panels = (long)(((n[0] > n[1] ? n[0] : n[1]) + 63) / 64) * 2 * batch;
     const bool planes = c->prec == 1 && c->fuse_merge && c->use_planes && panels >= 96 && D % 128 == 0;
     // weight-fragment GEMMs: the default for the f16x3 arithmetic (gemm_wf.hip)
-    // (64-row tiles, one workgroup each, whole K in LDS: measured 1.08x / 1.29x on the two MLP convolutions when the tiles cover
-    // the chip about once (B = 4, N = 2048: 256 tiles), 1.03x at twice that, slower than gemm_f32.hip's 64 x 64 tiles below; the
-    // K = 256 projection gains nothing.  IMP_GEMM_WF: 0 never, 1 by this rule (default), 2 always incl. the projection)
+    // (64-row tiles with the whole K in LDS; small launches deal the column passes of a tile to several workgroups, wf_pass_split.
+    // Measured against gemm_f32.hip, MLP0 / MLP3: 1.06x / 1.32x at B = 4, N = 2048 (256 tiles), 1.14x / 1.15x at B = 1, N = 2048,
+    // 1.09x / 1.17x at B = 1, N = 1024, 1.06x / 0.99x at B = 8; the K = 256 projection: 1.21x at B = 1, N = 1024 (32 tiles), 0.91-0.97x
+    // from 64 tiles up - it stays on gemm_f32.hip there.  IMP_GEMM_WF: 0 never, 1 by this rule (default), 2 always incl. the projection)
     const long wf_tiles = (long)batch * ((n[0] + 63) / 64 + (n[1] + 63) / 64);
-    const bool wf = !planes && c->prec == 1 && c->use_wf && (c->use_wf > 1 || (wf_tiles >= 192 && wf_tiles <= 640));
+    const bool wf = !planes && c->prec == 1 && c->use_wf && (c->use_wf > 1 || wf_tiles <= 640);
+    const bool wf_proj = wf && (c->use_wf > 1 || wf_tiles <= 40);
     const bool wf_mlp = wf && c->fuse_merge && cfg.norm_fn == IMP_NORM_IN && cfg.ac_fn == IMP_ACT_RELU && L.mlp0f_wf && L.mlp3_wf;
     if (planes) {
         for (int s = 0; s < 2; ++s) {
@@ -456,7 +468,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
         }
         p.bias = L.proj.b; p.lda = 2 * D; p.apw = D; p.ldw = 2 * D; p.ldc = 3 * D;
         HIP_TRY(launch_gemm_planes(p, batch, st));
-    } else if (wf && c->use_wf > 1 && L.proj_wf) {       // (measured: no gain for the K = 256 projection - it stays on gemm_f32.hip unless forced)
+    } else if (wf_proj && L.proj_wf) {
         WfParams p;
         memset(&p, 0, sizeof p);
         p.K = D; p.ksplit = D; p.N = L.proj.out; p.nside = 2;
@@ -467,6 +479,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
             g.sA_b = (long)n[s] * D; g.sC_b = (long)n[s] * 3 * D;
         }
         p.Wf_ = L.proj_wf; p.bias = L.proj.b; p.lda = D; p.ldc = 3 * D;
+        p.pass_split = wf_pass_split(c, wf_tiles, p.N);
         HIP_TRY(launch_gemm_wf(p, batch, st));
     } else {
         GemmParams p = gemm_defaults(c, D);
@@ -543,6 +556,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
             g.out_stats = c->stats[s];
         }
         p.Wf_ = L.mlp0f_wf; p.bias = M0.b; p.lda = D; p.lda2 = D; p.ldc = 2 * D;
+        p.pass_split = wf_pass_split(c, wf_tiles, p.N);
         bm0 = gemm_wf_stats_rows();
         HIP_TRY(launch_gemm_wf(p, batch, st));
     } else {
@@ -594,6 +608,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
             g.in_stats = c->nstat[s];
         }
         p.Wf_ = L.mlp3_wf; p.bias = L.mlp3.b; p.lda = 2 * D; p.ldc = D; p.ldr = D;
+        p.pass_split = wf_pass_split(c, wf_tiles, p.N);
         HIP_TRY(launch_gemm_wf(p, batch, st));
     } else {
         GemmParams p = gemm_defaults(c, 2 * D);
@@ -1413,6 +1428,7 @@ int imp_time_layer_gemm(imp_ctx* c, int batch, int n, int which, int dbg, int re
             if (which == 1) { p.Wf_ = L.mlp0f_wf; p.N = 2 * D; p.bias = L.mlp0f.b; p.lda = p.lda2 = D; p.ldc = 2 * D; }
             if (which == 2) { p.Wf_ = L.mlp3_wf; p.N = D; p.bias = L.mlp3.b; p.lda = 2 * D; p.ldc = D; p.ldr = D; }
             if (!p.Wf_) return hipErrorInvalidValue;
+            p.pass_split = wf_pass_split(c, (long)batch * 2 * ((n + 63) / 64), p.N);
             p.dbg = -dbg - 2;
             return launch_gemm_wf(p, batch, st);
         }

@@ -44,6 +44,9 @@ __global__ __launch_bounds__(256) void gemm_wf_kernel(const WfParams p, int row_
     extern __shared__ __attribute__((aligned(16))) unsigned char wf_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     int z = blockIdx.x;
+    // small launches: the column passes of a tile are dealt to `psplit` workgroups (each stages the tile itself) to fill the chip
+    const int psplit = p.pass_split > 1 ? p.pass_split : 1;
+    const int pgrp = z % psplit; z /= psplit;
     const int rtile = z % row_tiles; z /= row_tiles;
     const int sidx = z % p.nside;
     const int b = z / p.nside;
@@ -101,16 +104,18 @@ __global__ __launch_bounds__(256) void gemm_wf_kernel(const WfParams p, int row_
     int aoff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) aoff[i] = (32 * i + (lane & 31)) * PITCH + half * 16;
-    const int npass = N >> 7;
+    const int npass_all = N >> 7;
+    const int npass = npass_all / psplit;          // passes of this workgroup: pbase .. pbase + npass
+    const int pbase = pgrp * npass;
     const u32x4* wbase = reinterpret_cast<const u32x4*>(p.Wf_) + lane;
     auto wptr = [&](int pass) { return wbase + (size_t)(pass * 4 + wave) * NS * 128; };
 
     // workgroups start at different column passes and wrap around: they all begin at the same time, and walking the weights in
     // the same order would have every CU ask the L2 for the same lines at the same moment
-    const int pass0 = (int)(blockIdx.x % (unsigned)npass);
+    const int pass0 = (int)((blockIdx.x / psplit) % (unsigned)npass);
     u32x4 bh[4], bl[4];
     {
-        const u32x4* w0 = wptr(pass0);
+        const u32x4* w0 = wptr(pbase + pass0);
 #pragma unroll
         for (int c = 0; c < 4; ++c) { bh[c] = w0[c * 128]; bl[c] = w0[c * 128 + 64]; }
     }
@@ -124,8 +129,9 @@ __global__ __launch_bounds__(256) void gemm_wf_kernel(const WfParams p, int row_
     const float* const Rb = S.R ? S.R + b * S.sR_b : nullptr;
 #pragma unroll 1
     for (int pi = 0; pi < npass; ++pi) {
-        const int pass = pass0 + pi < npass ? pass0 + pi : pass0 + pi - npass;
-        const int pnext = pass + 1 < npass ? pass + 1 : 0;
+        const int pl = pass0 + pi < npass ? pass0 + pi : pass0 + pi - npass;
+        const int pass = pbase + pl;
+        const int pnext = pbase + (pl + 1 < npass ? pl + 1 : 0);
         f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -279,13 +285,15 @@ hipError_t wf_launch(const WfParams& p, int batch, hipStream_t stream) {
     const int row_tiles = (maxm + WF_TM - 1) / WF_TM;
     constexpr size_t lds = (size_t)2 * WF_TM * (2 * K + 16) + 4 * 32 * 144;        // half planes + the waves' transposition buffers
     if (hipError_t e = imp_grant_dynamic_lds((const void*)gemm_wf_kernel<K, PRO, SWAP, STATS>, lds)) return e;
-    hipLaunchKernelGGL((gemm_wf_kernel<K, PRO, SWAP, STATS>), dim3(batch * p.nside * row_tiles), dim3(256), lds, stream, p, row_tiles);
+    const int psplit = p.pass_split > 1 ? p.pass_split : 1;
+    if ((p.N >> 7) % psplit) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((gemm_wf_kernel<K, PRO, SWAP, STATS>), dim3(batch * p.nside * row_tiles * psplit), dim3(256), lds, stream, p, row_tiles);
 #ifdef WF_PROFILE
     {
         static int calls = 0;
         if (++calls % 21 == 0) {
             (void)hipStreamSynchronize(stream);
-            const int nb = batch * p.nside * row_tiles < 4096 ? batch * p.nside * row_tiles : 4096;
+            const int nb = batch * p.nside * row_tiles * psplit < 4096 ? batch * p.nside * row_tiles * psplit : 4096;
             std::vector<unsigned long long> h((size_t)nb * 4);
             (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(wf_prof), h.size() * 8);
             double a[4] = {0, 0, 0, 0};

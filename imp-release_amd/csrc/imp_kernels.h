@@ -262,6 +262,7 @@ struct WfParams {
     int K, ksplit, N;
     int lda, lda2, ldc, ldr;
     int nside;
+    int pass_split;        // > 1: the N / 128 column passes of a row tile are dealt to this many workgroups (must divide N / 128)
     int dbg;               // probe switches (tools/probe/gemm_wf_time.py): 1 no global stores, 2 no epilogue at all, 4 no residual / bias loads
 };
 hipError_t launch_gemm_wf(const WfParams& p, int batch, hipStream_t stream);
