@@ -573,7 +573,10 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
         HIP_TRY(launch_gemm_f32(p, batch, st));
     }
     // 5. norm + activation while staging, conv 3, bias, residual add -> new descriptors
-    if (in_norm) {
+    // EXPERIMENT (IMP_WF_FUSE_STATS=1, off): the weight-fragment MLP3 kernel can merge the per-block statistics in its own prologue
+    // (one launch less per layer); measured SLOWER - every workgroup repeats T dependent loads per channel: configs[1] 1.61 -> 1.74 ms
+    static const bool fuse_stats = [] { const char* e = getenv("IMP_WF_FUSE_STATS"); return e && atoi(e) != 0; }();
+    if (in_norm && !(wf_mlp && fuse_stats)) {
         StatsSide ss[2];
         for (int s = 0; s < 2; ++s) ss[s] = StatsSide{c->stats[s], c->nstat[s], (n[s] + bm0 - 1) / bm0, n[s], bm0};
         HIP_TRY(launch_stats_finalize(ss, 2, batch, 2 * D, 1e-3f, st));
@@ -605,8 +608,10 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
             WfSide& g = p.side[s];
             g.A = c->hid[s]; g.C = out[s]; g.R = desc[s]; g.M = n[s];
             g.sA_b = (long)n[s] * 2 * D; g.sC_b = (long)n[s] * D; g.sR_b = (long)n[s] * D;
-            g.in_stats = c->nstat[s];
+            if (fuse_stats) { g.stat_part = c->stats[s]; g.stat_tiles = (n[s] + bm0 - 1) / bm0; }
+            else g.in_stats = c->nstat[s];
         }
+        p.stat_tile_rows = bm0; p.norm_eps = 1e-3f;
         p.Wf_ = L.mlp3_wf; p.bias = L.mlp3.b; p.lda = 2 * D; p.ldc = D; p.ldr = D;
         p.pass_split = wf_pass_split(c, wf_tiles, p.N);
         HIP_TRY(launch_gemm_wf(p, batch, st));
@@ -1422,8 +1427,10 @@ int imp_time_layer_gemm(imp_ctx* c, int batch, int n, int which, int dbg, int re
                 g.M = n;
                 if (which == 0) { g.A = c->descw[s]; g.C = c->qkv[0][s]; g.sA_b = (long)n * D; g.sC_b = (long)n * 3 * D; }
                 if (which == 1) { g.A = c->descw[s]; g.A2 = c->attn_out[s]; g.C = c->hid[s]; g.sA_b = g.sA2_b = (long)n * D; g.sC_b = (long)n * 2 * D; g.out_stats = c->stats[s]; }
-                if (which == 2) { g.A = c->hid[s]; g.C = c->mdesc[s]; g.R = c->descw[s]; g.sA_b = (long)n * 2 * D; g.sC_b = (long)n * D; g.sR_b = (long)n * D; g.in_stats = c->nstat[s]; }
+                if (which == 2) { g.A = c->hid[s]; g.C = c->mdesc[s]; g.R = c->descw[s]; g.sA_b = (long)n * 2 * D; g.sC_b = (long)n * D; g.sR_b = (long)n * D;
+                                  g.in_stats = c->nstat[s]; }
             }
+            p.stat_tile_rows = 64; p.norm_eps = 1e-3f;
             if (which == 0) { p.Wf_ = L.proj_wf; p.N = 3 * D; p.bias = L.proj.b; p.lda = D; p.ldc = 3 * D; }
             if (which == 1) { p.Wf_ = L.mlp0f_wf; p.N = 2 * D; p.bias = L.mlp0f.b; p.lda = p.lda2 = D; p.ldc = 2 * D; }
             if (which == 2) { p.Wf_ = L.mlp3_wf; p.N = D; p.bias = L.mlp3.b; p.lda = 2 * D; p.ldc = D; p.ldr = D; }

@@ -59,11 +59,41 @@ __global__ __launch_bounds__(256) void gemm_wf_kernel(const WfParams p, int row_
     unsigned long long t_k = 0, t_e = 0, t_x;
 #endif
 
+    // ---- PRO: the InstanceNorm constants (mean, rstd) of this batch element's K channels -> LDS.  Either finalised by
+    // stats_finalize_kernel (in_stats) or merged here from the producer's per-block (sum, M2) with Chan's formula in fp64, in the
+    // arithmetic and summation order of that kernel (4 block groups t = g, g + 4, ...; ((g0 + g1) + (g2 + g3)))
+    float* stl = reinterpret_cast<float*>(wf_smem + 2 * PLANE + 4 * 32 * 144);     // [K][2]
+    if (PRO) {
+        if (S.stat_part) {
+            const int T = S.stat_tiles, TR = p.stat_tile_rows;
+            for (int k = tid; k < K; k += 256) {
+                const float2* sp = reinterpret_cast<const float2*>(S.stat_part) + (long)b * T * K + k;
+                double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0}, a3[4] = {0, 0, 0, 0};
+                for (int t = 0; t < T; ++t) {
+                    const float2 v = sp[(long)t * K];
+                    const int nt = min(TR, M - t * TR);
+                    a1[t & 3] += (double)v.x; a2[t & 3] += (double)v.y; a3[t & 3] += (double)v.x * (double)v.x / (double)nt;
+                }
+                const double s1t = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+                const double m2w = (a2[0] + a2[1]) + (a2[2] + a2[3]);
+                const double sqn = (a3[0] + a3[1]) + (a3[2] + a3[3]);
+                const double mean = s1t / (double)M;
+                double m2 = m2w + (sqn - (double)M * mean * mean);
+                m2 = m2 < 0.0 ? 0.0 : m2;
+                stl[2 * k] = (float)mean;
+                stl[2 * k + 1] = (float)(1.0 / sqrt(m2 / (double)M + (double)p.norm_eps));
+            }
+        } else {
+            const float* st = S.in_stats + (long)b * K * 2;
+            for (int i = tid; i < 2 * K; i += 256) stl[i] = st[i];
+        }
+        __syncthreads();
+    }
     // ---- stage the tile: 64 rows x K fp32 -> hi / lo half planes (rows past M are clamped: they only feed rows that are never stored)
     {
         const float* A = S.A + b * S.sA_b;
         const float* A2 = S.A2 ? S.A2 + b * S.sA2_b : A;
-        const float* st = PRO ? S.in_stats + (long)b * K * 2 : nullptr;
+        const float* st = stl;
         constexpr int F4_ROW = K / 4;               // float4 per row
         constexpr int PER = WF_TM * F4_ROW / 256;   // float4 per thread
         f32x4 v[PER];
@@ -283,7 +313,7 @@ hipError_t wf_launch(const WfParams& p, int batch, hipStream_t stream) {
     int maxm = p.side[0].M;
     if (p.nside > 1 && p.side[1].M > maxm) maxm = p.side[1].M;
     const int row_tiles = (maxm + WF_TM - 1) / WF_TM;
-    constexpr size_t lds = (size_t)2 * WF_TM * (2 * K + 16) + 4 * 32 * 144;        // half planes + the waves' transposition buffers
+    constexpr size_t lds = (size_t)2 * WF_TM * (2 * K + 16) + 4 * 32 * 144 + (PRO ? 2 * K * 4 : 0);   // half planes + transposition buffers + norm constants
     if (hipError_t e = imp_grant_dynamic_lds((const void*)gemm_wf_kernel<K, PRO, SWAP, STATS>, lds)) return e;
     const int psplit = p.pass_split > 1 ? p.pass_split : 1;
     if ((p.N >> 7) % psplit) return hipErrorInvalidValue;
@@ -314,7 +344,7 @@ bool gemm_wf_supported(int K, int N) { return (K == 256 || K == 512) && N % 128 
 
 hipError_t launch_gemm_wf(const WfParams& p, int batch, hipStream_t stream) {
     const bool stats = p.side[0].out_stats != nullptr;
-    const bool pro = p.side[0].in_stats != nullptr;
+    const bool pro = p.side[0].in_stats != nullptr || p.side[0].stat_part != nullptr;
     if (!gemm_wf_supported(p.K, p.N)) return hipErrorInvalidValue;
     if (stats) {
         if (pro) return hipErrorInvalidValue;

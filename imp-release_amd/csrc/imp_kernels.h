@@ -252,6 +252,8 @@ struct WfSide {
     const float* R;        // residual [b][M][ldr] or null
     const float* in_stats; // [b][K][2] finalised (mean, rstd): InstanceNorm + ReLU applied while staging, or null
     float* out_stats;      // [b][row_tiles][N][2] per 64-row block (sum, M2 about the block mean), or null
+    const float* stat_part;// instead of in_stats: the producer's per-block (sum, M2) [b][stat_tiles][K][2]; every workgroup merges them itself
+    int stat_tiles;        //   (Chan's formula in fp64, the arithmetic and order of stats_finalize_kernel) - one launch less per layer
     long sA_b, sA2_b, sC_b, sR_b;
     int M;
 };
@@ -262,6 +264,8 @@ struct WfParams {
     int K, ksplit, N;
     int lda, lda2, ldc, ldr;
     int nside;
+    int stat_tile_rows;    // rows per statistics block of stat_part
+    float norm_eps;        // InstanceNorm eps for stat_part
     int pass_split;        // > 1: the N / 128 column passes of a row tile are dealt to this many workgroups (must divide N / 128)
     int dbg;               // probe switches (tools/probe/gemm_wf_time.py): 1 no global stores, 2 no epilogue at all, 4 no residual / bias loads
 };
