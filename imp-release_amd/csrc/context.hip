@@ -87,6 +87,7 @@ struct imp_ctx {
     AttnCache cache[2];
     // planes path (gemm_planes.hip): f16x3 arithmetic with the merge conv folded; IMP_GEMM_PLANES=0 keeps gemm_f32.hip
     int use_planes = 0;
+    int ot_local = 1;        // XCD-local resident Sinkhorn launches when a pair fits one XCD (IMP_OT_LOCAL=0 disables)
     int use_wf = 1;          // weight-fragment GEMMs (gemm_wf.hip) for the layer convolutions when f16x3, D = 256, relu + InstanceNorm; IMP_GEMM_WF=0 disables
     _Float16* xpl[2] = {};                 // planes of the current descriptors of image 0 / 1  [B][n][2D halves]
     const float* xpl_src[2] = {};          // fp32 tensor they were made from / written next to (trusted only inside one call chain)
@@ -727,7 +728,7 @@ unsigned resident_tags(imp_ctx* c, int iterations) {
 // chooses the decomposition of a resident launch.  XCD-local (every pair on the 32 CUs of one XCD, exchanges through that XCD's
 // L2 instead of across the fabric) whenever a pair fits there: IMP_OT_LOCAL=0 disables.  Returns 0 when nothing fits.
 int plan_resident(imp_ctx* c, int batch, int n0, int n1, int max_wgs, int* nch, int* rpw, int* G, int* local) {
-    static const bool allow_local = [] { const char* e = getenv("IMP_OT_LOCAL"); return !(e && atoi(e) == 0); }();
+    const bool allow_local = c->ot_local != 0;
     *local = 0;
     const int per_xcd = (batch + 7) / 8;
     if (allow_local && max_wgs >= c->num_cus && per_xcd <= 32 && ot_resident_plan(1, n0, n1, 32 / per_xcd, nch, rpw, G)) {
@@ -857,6 +858,7 @@ int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     { const char* e = getenv("IMP_PRECISION"); c->prec = (e && !strcmp(e, "f32")) ? 0 : 1; }
     { const char* e = getenv("IMP_OT_COMPACT"); c->ot_compact = (e && atoi(e) != 0) ? 1 : 0; }
     { const char* e = getenv("IMP_OT_RESIDENT"); c->ot_resident = (e && atoi(e) == 0) ? 0 : 1; }
+    { const char* e = getenv("IMP_OT_LOCAL"); c->ot_local = (e && atoi(e) == 0) ? 0 : 1; }
     // pre-split planes GEMMs (gemm_planes.hip) for the layer convs: measured SLOWER than gemm_f32.hip on MI355X,
     // kept as an opt-in experiment and A/B switch
     { const char* e = getenv("IMP_GEMM_PLANES"); c->use_planes = (e && atoi(e) != 0) ? 1 : 0; }

@@ -158,3 +158,26 @@ def test_pairs_in_flight_share_the_resident_lane():
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     for r in reps:
         assert r._ensure_ctx().resident_status() == (False, True)
+
+
+@pytest.mark.parametrize('n0,n1,B,T', [(1024, 1024, 1, 100), (1024, 1000, 4, 50), (700, 760, 8, 20), (512, 519, 3, 100), (1024, 1300, 2, 20)])
+def test_xcd_local_launch_agrees_with_the_chip_wide_one(n0, n1, B, T):
+    """pairs that fit the 32 CUs of one XCD run XCD-local (plain stores, L2-served polls, pair = block % 8); the same shapes with
+    IMP_OT_LOCAL=0 spread every pair over the chip.  Another decomposition (fewer, taller workgroups) = another summation order:
+    scores agree to 1e-6, the exchange never times out"""
+    cfg = eval_config(n_layers=1, sinkhorn_iterations=T)
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=7)
+    loc = make_hip_model('GM', cfg, sd)
+    os.environ['IMP_OT_LOCAL'] = '0'
+    try:
+        glob = make_hip_model('GM', cfg, sd)
+        glob._ensure_ctx()
+    finally:
+        del os.environ['IMP_OT_LOCAL']
+    dist = _dist(B, n0, n1, n0 + B).to(DEV)
+    with torch.no_grad():
+        a = loc.compute_score(dist, loc.bin_score, T)
+        b = glob.compute_score(dist, glob.bin_score, T)
+    assert loc._ensure_ctx().resident_status() == (False, True) and glob._ensure_ctx().resident_status() == (False, True)
+    assert float(((a - b).abs() / b.abs().clamp_min(1.0)).max()) < 2e-6          # (dustbin entries are O(10..100): relative there)
+    assert float((a[:, :-1, :-1] - b[:, :-1, :-1]).abs().max()) < 1e-6
