@@ -87,6 +87,8 @@ struct imp_ctx {
     AttnCache cache[2];
     // planes path (gemm_planes.hip): f16x3 arithmetic with the merge conv folded; IMP_GEMM_PLANES=0 keeps gemm_f32.hip
     int use_planes = 0;
+    float* xhalf = nullptr;  // resident Sinkhorn, two XCDs per pair: the half sums the XCDs swap
+    int ot_hier = 1;         // two-XCDs-per-pair resident launches (hierarchical column sums) when a pair fits 64 CUs and B <= 4 (IMP_OT_HIER=0 disables)
     int ot_local = 1;        // XCD-local resident Sinkhorn launches when a pair fits one XCD (IMP_OT_LOCAL=0 disables)
     int use_wf = 1;          // weight-fragment GEMMs (gemm_wf.hip) for the layer convolutions when f16x3, D = 256, relu + InstanceNorm; IMP_GEMM_WF=0 disables
     _Float16* xpl[2] = {};                 // planes of the current descriptors of image 0 / 1  [B][n][2D halves]
@@ -699,6 +701,8 @@ int ensure_resident_buffers(imp_ctx* c, int batch) {
     }
     if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xv, 2 * (size_t)cap * kResidentMaxLdx);
     if (!rc) HIP_TRY(hipMemset(c->xv, 0, 2 * (size_t)cap * kResidentMaxLdx * sizeof(float)));
+    if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xhalf, 2 * (size_t)cap * kResidentMaxLdx);
+    if (!rc) HIP_TRY(hipMemset(c->xhalf, 0, 2 * (size_t)cap * kResidentMaxLdx * sizeof(float)));
     if (rc) return rc;
     // the clears above run on the NULL stream, which the callers' (non-blocking) streams and the lane do not wait for:
     // they must have landed before the first resident kernel writes its tags into these buffers
@@ -710,13 +714,14 @@ int ensure_resident_buffers(imp_ctx* c, int batch) {
 // reserves the tags of one launch.  Tags must never repeat on the exchange buffers; when the 32-bit counter is about to
 // wrap (after ~20 million launches) the buffers are cleared and the count restarts.
 unsigned resident_tags(imp_ctx* c, int iterations) {
-    const unsigned need = 2u * (unsigned)iterations + 4u;
+    const unsigned need = 3u * (unsigned)iterations + 4u;
     if (c->xtag > 0xFFFFFFFFu - need - 8u) {
         (void)hipDeviceSynchronize();
         const size_t wgs = (size_t)c->num_cus;
         (void)hipMemset(c->xpart, 0, 2 * wgs * kResidentMaxLdx * sizeof(float));
         (void)hipMemset(c->xmax, 0, 4 * wgs * kResidentMaxLdx * sizeof(float));
         (void)hipMemset(c->xv, 0, 2 * (size_t)c->xcap_b * kResidentMaxLdx * sizeof(float));
+        (void)hipMemset(c->xhalf, 0, 2 * (size_t)c->xcap_b * kResidentMaxLdx * sizeof(float));
         c->xtag = 0;
     }
     const unsigned base = c->xtag;
@@ -735,6 +740,11 @@ int plan_resident(imp_ctx* c, int batch, int n0, int n1, int max_wgs, int* nch, 
         *local = 1;
         return 1;
     }
+    // two XCDs per pair: one fabric crossing per iteration instead of two (ot_resident.hip, LOCAL = 2)
+    if (c->ot_hier && max_wgs >= c->num_cus && batch <= 4 && ot_resident_plan(1, n0, n1, 64, nch, rpw, G) && ot_resident_hier_ok(*nch, *rpw, *G, batch)) {
+        *local = 2;
+        return 1;
+    }
     return ot_resident_plan(batch, n0, n1, max_wgs, nch, rpw, G);
 }
 
@@ -747,7 +757,7 @@ int run_score_resident_launch(imp_ctx* c, int batch, int b0, int nb, int n0, int
     memset(&p, 0, sizeof p);
     p.dist = dist + (size_t)b0 * n0 * n1; p.B = nb; p.n0 = n0; p.n1 = n1; p.T = iterations; p.G = G; p.bin = bin;
     p.xpart = c->xpart; p.xv = c->xv; p.xmax = c->xmax; p.status = c->xstatus;
-    p.local = local;
+    p.local = local; p.xhalf = c->xhalf;
     p.tag_base = resident_tags(c, iterations);
     if (want_uv) {
         p.ldu = (n0 + 1 + 3) & ~3; p.ldv = (n1 + 1 + 3) & ~3;
@@ -859,6 +869,7 @@ int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     { const char* e = getenv("IMP_OT_COMPACT"); c->ot_compact = (e && atoi(e) != 0) ? 1 : 0; }
     { const char* e = getenv("IMP_OT_RESIDENT"); c->ot_resident = (e && atoi(e) == 0) ? 0 : 1; }
     { const char* e = getenv("IMP_OT_LOCAL"); c->ot_local = (e && atoi(e) == 0) ? 0 : 1; }
+    { const char* e = getenv("IMP_OT_HIER"); c->ot_hier = (e && atoi(e) == 0) ? 0 : 1; }
     // pre-split planes GEMMs (gemm_planes.hip) for the layer convs: measured SLOWER than gemm_f32.hip on MI355X,
     // kept as an opt-in experiment and A/B switch
     { const char* e = getenv("IMP_GEMM_PLANES"); c->use_planes = (e && atoi(e) != 0) ? 1 : 0; }
@@ -1361,7 +1372,7 @@ int imp_time_sinkhorn(imp_ctx* c, int batch, int n, int iterations, float* ms, v
         memset(&p, 0, sizeof p);
         p.dist = c->dist; p.B = batch; p.n0 = n; p.n1 = n; p.G = G; p.bin = 1.f;
         p.xpart = c->xpart; p.xv = c->xv; p.xmax = c->xmax; p.status = c->xstatus;
-        p.local = local;
+        p.local = local; p.xhalf = c->xhalf;
         float tt[2];
         for (int k = 0; k < 2; ++k) {
             p.T = k ? iterations : 0;

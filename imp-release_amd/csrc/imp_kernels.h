@@ -231,7 +231,9 @@ struct OtResidentParams {
     unsigned tag_base;        // tags of this launch are tag_base + 1 .. tag_base + 2 T + 1: never reused on these buffers
     int* status;              // device flag, set to 1 when a wait timed out
     unsigned long long* prof; // optional [6]: phase cycle counts of workgroup 0 (probe), null in the product
-    int local;                // XCD-local launch: every pair's G <= 32 workgroups on one XCD (plain stores, L2-served polls)
+    int local;                // 1: XCD-local launch: every pair's G <= 32 workgroups on one XCD (plain stores, L2-served polls);
+                              // 2: two XCDs per pair (B <= 4), hierarchical column sums: one fabric crossing per iteration
+    float* xhalf;             // local == 2: [2 B][LDX] granules, the half sums the two XCDs of a pair swap
     float* u; int ldu;        // optional outputs in the layout of OtBuffers (u [B][ldu], v [B][ldv]); v is required with u
     float* v; int ldv;
     float* scores;            // optional [B][n0+1][n1+1]
@@ -240,6 +242,7 @@ struct OtResidentParams {
 };
 int ot_resident_plan(int batch, int n0, int n1, int max_wgs, int* nch, int* rpw, int* G);
 size_t ot_resident_ldx(int nch);
+bool ot_resident_hier_ok(int nch, int rpw, int G, int batch);
 hipError_t launch_ot_resident(const OtResidentParams& p, int nch, int rpw, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------

@@ -121,15 +121,36 @@ __device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, int q, unsigned 
     return f32x4{__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(c[0]), __uint_as_float(c[2])};
 }
 
+// one granule
+__device__ __forceinline__ float ldg1(__amdgpu_buffer_rsrc_t r, int idx, unsigned tag, int* status, bool& dead) {
+    u32x2 a;
+    int spins = 0;
+    for (;;) {
+        asm volatile("" ::: "memory");
+        a = __builtin_amdgcn_raw_buffer_load_b64(r, idx * 8, 0, AUX_POLL);
+        if (a[1] == tag || dead) break;
+        if ((++spins & 1023) == 0) {
+            if (spins > SPIN_LIMIT) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) dead = true;
+        }
+    }
+    return __uint_as_float(a[0]);
+}
+
 // phase profile of workgroup 0 (p.prof != null; tools/probe/sk_prof.py): cycles of  0 A (u + column partials)  1 B (LDS combine +
 // partial store)  2 wait + stage of the slice  3 slice reduce + v store  4 wait + read of v  5 v sum
 #define OTR_CLK(i) if (p.prof) { const unsigned long long c_ = __builtin_readcyclecounter(); prof_acc[i] += c_ - tlast; tlast = c_; }
 
 // LOCAL: every pair lives on ONE XCD (hardware places block i on XCD i % 8): block i serves pair (i % 8) + 8 * (slot / G), group slot % G with
 // slot = i / 8, so all G <= 32 workgroups of a pair share an L2 and the exchanges never cross the fabric
+// LOCAL = 2 (two XCDs per pair, B <= 4): pair b lives on XCDs 2b and 2b + 1, half of its workgroups on each.  The column sums are
+// formed hierarchically - every half reduces ITS workgroups' partials through its own L2, the two halves swap their half sums
+// across the fabric (the one remote hand-off of the iteration), both compute the same v and distribute it inside their XCD - so
+// an iteration has one fabric crossing instead of two.
 template <int NCH, int RPW, int LOCAL>
 __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentParams p) {
-    constexpr int ST_AUX = LOCAL ? 0 : AUX_SC1;
+    constexpr int ST_AUX = LOCAL ? 0 : AUX_SC1;            // partial vectors and v: readers share the writer's L2 when LOCAL
+    constexpr int MX_AUX = LOCAL == 1 ? 0 : AUX_SC1;       // the final column-maxima exchange runs over all workgroups of the pair
     constexpr int DCOL = 256 * NCH;            // exchange vectors: inner columns | dustbin column | 3 pads
     constexpr int LDX = DCOL + 4;
     constexpr int NQ = LDX / 4;                // float4 chunks of an exchange vector
@@ -140,12 +161,19 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = p.G;
-    int b, g;
-    if (LOCAL) {
+    int b, g, half = 0, H = G;                 // H workgroups exchange through one L2; this one is number gl = g - half * H of them
+    if (LOCAL == 1) {
         const int slot = blockIdx.x >> 3;
         b = (int)(blockIdx.x & 7) + 8 * (slot / G);
         g = slot % G;
         if (b >= p.B) return;                  // uniform per workgroup, before any exchange
+    } else if (LOCAL == 2) {
+        const int xcd = blockIdx.x & 7;
+        b = xcd >> 1;
+        half = xcd & 1;
+        H = G >> 1;
+        g = half * H + (int)(blockIdx.x >> 3);
+        if (b >= p.B) return;
     } else {
         b = blockIdx.x / G;
         g = blockIdx.x % G;
@@ -155,8 +183,11 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
     bool dead = false;
 
     // exchange buffers hold granules: 8 bytes per float
-    const __amdgpu_buffer_rsrc_t rs_part = make_rsrc(p.xpart + (size_t)b * G * LDX * 2, (unsigned)((size_t)G * LDX * 8));
-    const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(p.xv + (size_t)b * LDX * 2, (unsigned)(LDX * 8));
+    const int gl = g - half * H;
+    const __amdgpu_buffer_rsrc_t rs_part = make_rsrc(p.xpart + ((size_t)b * G + (size_t)half * H) * LDX * 2, (unsigned)((size_t)H * LDX * 8));
+    const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(p.xv + (size_t)(LOCAL == 2 ? 2 * b + half : b) * LDX * 2, (unsigned)(LDX * 8));
+    const __amdgpu_buffer_rsrc_t rs_h_own = make_rsrc(p.xhalf + (size_t)(2 * b + half) * LDX * 2, (unsigned)(LDX * 8));
+    const __amdgpu_buffer_rsrc_t rs_h_oth = make_rsrc(p.xhalf + (size_t)(2 * b + 1 - half) * LDX * 2, (unsigned)(LDX * 8));
 
     // ---- row softmax of the dustbin-augmented matrix (nets/layers.py:39-40,28) straight into registers -----------
     f32x4 P[RPW][NCH];
@@ -210,11 +241,11 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
     float u_last = 1.f;
     __syncthreads();
 
-    const int cq = (NQ + G - 1) / G;           // float4 chunks of the exchange vector owned by one workgroup
+    const int cq = (NQ + H - 1) / H;           // float4 chunks of the exchange vector owned by one workgroup (of its half)
     unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_readcyclecounter();
     for (int it = 0; it < p.T; ++it) {
-        const unsigned tag_p = p.tag_base + 2u * it + 1u, tag_v = tag_p + 1u;
+        const unsigned tag_p = p.tag_base + 3u * it + 1u, tag_h = tag_p + 1u, tag_v = tag_p + 2u;
         // ---- A: u for the own rows, column partials ---------------------------------------------------------------
         float acc[RPW];
 #pragma unroll
@@ -259,29 +290,29 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
                 const f32x4 t = *reinterpret_cast<const f32x4*>(red + w * LDX + 4 * q);
                 s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
             }
-            stg4<ST_AUX>(rs_part, g * NQ + q, s, tag_p);
+            stg4<ST_AUX>(rs_part, gl * NQ + q, s, tag_p);
         }
         __syncthreads();                           // everyone is done with the wave partials in `red`
         OTR_CLK(1)
         // ---- C: this workgroup's slice of columns over the G partial vectors -------------------------------------
         {
-            f32x4* stage = reinterpret_cast<f32x4*>(red);             // [G][cq]
-            for (int idx = tid; idx < cq * G; idx += 512) {
+            f32x4* stage = reinterpret_cast<f32x4*>(red);             // [H][cq]
+            for (int idx = tid; idx < cq * H; idx += 512) {
                 const int w = idx / cq, qq = idx - w * cq;
-                const int q = g * cq + qq;
+                const int q = gl * cq + qq;
                 stage[idx] = q < NQ ? ldg4(rs_part, w * NQ + q, tag_p, p.status, dead) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             __syncthreads();
             OTR_CLK(2)
             // 8 threads per column, each over a contiguous eighth of the workgroups; then combined in order
-            float* sub = red + (size_t)cq * G * 4;                    // [8][4 cq]
+            float* sub = red + (size_t)cq * H * 4;                    // [8][4 cq]
             const int ncol = 4 * cq;
-            const int seg = (G + 7) / 8;
+            const int seg = (H + 7) / 8;
             for (int t = tid; t < 8 * ncol; t += 512) {
                 const int h = t / ncol, cl = t - h * ncol;
                 const int qq = cl >> 2, e = cl & 3;
                 float s = 0.f;
-                const int w1 = min(G, (h + 1) * seg);
+                const int w1 = min(H, (h + 1) * seg);
                 for (int w = h * seg; w < w1; ++w) s += red[(size_t)(w * cq + qq) * 4 + e];
                 sub[h * ncol + cl] = s;
             }
@@ -290,8 +321,13 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
                 float s = sub[cl];
 #pragma unroll
                 for (int h = 1; h < 8; ++h) s += sub[h * ncol + cl];
-                const int xi = 4 * (g * cq) + cl;                     // index in the exchange layout
+                const int xi = 4 * (gl * cq) + cl;                    // index in the exchange layout
                 if (xi < LDX) {
+                    if (LOCAL == 2) {                                 // swap the half sums across the fabric; both halves add them in the same order
+                        stg1<AUX_SC1>(rs_h_own, xi, s, tag_h);
+                        const float o = ldg1(rs_h_oth, xi, tag_h, p.status, dead);
+                        s = half == 0 ? s + o : o + s;
+                    }
                     const bool dust = xi == DCOL;
                     const bool real = xi < n1 || dust;
                     const float t = fmaf(c0, u_last, s);              // + dustbin row entry * its u
@@ -408,11 +444,11 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             }
             __syncthreads();
         }
-        const unsigned tag_m = p.tag_base + 2u * p.T + 1u;
+        const unsigned tag_m = p.tag_base + 3u * p.T + 1u;
         const __amdgpu_buffer_rsrc_t rs_mx = make_rsrc(p.xmax + (size_t)b * G * 4 * LDX, (unsigned)((size_t)G * 2 * LDX * 8));
         for (int q = tid; q < DCOL / 4; q += 512) {
-            stg4<ST_AUX>(rs_mx, g * 2 * NQ + q, *reinterpret_cast<const f32x4*>(mv + 4 * q), tag_m);
-            stg4<ST_AUX>(rs_mx, g * 2 * NQ + NQ + q, *reinterpret_cast<const f32x4*>(red + LDX + 4 * q), tag_m);
+            stg4<MX_AUX>(rs_mx, g * 2 * NQ + q, *reinterpret_cast<const f32x4*>(mv + 4 * q), tag_m);
+            stg4<MX_AUX>(rs_mx, g * 2 * NQ + NQ + q, *reinterpret_cast<const f32x4*>(red + LDX + 4 * q), tag_m);
         }
         __syncthreads();                           // mv / mi are about to be overwritten by the staging
         const int ncq = (DCOL / 4 + G - 1) / G;        // float4 column chunks per workgroup
@@ -445,15 +481,26 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
 template <int NCH, int RPW>
 hipError_t launch_one(const OtResidentParams& p, hipStream_t stream) {
     constexpr int LDX = 256 * NCH + 4;
-    const int cq = (LDX / 4 + p.G - 1) / p.G;
-    // vs + max(8 wave vectors, slice staging [G][cq] float4 + [8][4 cq])
+    const int Hh = p.local == 2 ? p.G / 2 : p.G;
+    const int cq = (LDX / 4 + Hh - 1) / Hh;
+    // vs + max(8 wave vectors, slice staging [H][cq] float4 + [8][4 cq])
     size_t red = (size_t)8 * LDX;
-    const size_t stage = (size_t)cq * p.G * 4 + (size_t)8 * 4 * cq;
+    const size_t stage = (size_t)cq * Hh * 4 + (size_t)8 * 4 * cq;
     if (stage > red) red = stage;
     const size_t stage2 = (size_t)2 * p.G * ((256 * NCH / 4 + p.G - 1) / p.G) * 4;     // column-maxima staging
     if (stage2 > red) red = stage2;
     const size_t lds = (LDX + red) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (p.local == 2) {
+        if (p.B > 4 || (p.G & 1) || p.G / 2 > 32 || !p.xhalf) return hipErrorInvalidValue;     // two XCDs per pair
+        if constexpr (RPW == 4 && NCH >= 5 && NCH <= 8) {     // (the shapes ot_resident_hier_ok admits: 1024 < n1 <= 2048 columns, 32-row workgroups)
+            if (hipError_t e = imp_grant_dynamic_lds((const void*)ot_resident_kernel<NCH, RPW, 2>, lds)) return e;
+            hipLaunchKernelGGL((ot_resident_kernel<NCH, RPW, 2>), dim3(8 * (p.G / 2)), dim3(512), lds, stream, p);
+            return hipGetLastError();
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     if (p.local) {
         if (p.G * ((p.B + 7) / 8) > 32) return hipErrorInvalidValue;      // a pair's workgroups must fit the 32 CUs of its XCD
         if (hipError_t e = imp_grant_dynamic_lds((const void*)ot_resident_kernel<NCH, RPW, 1>, lds)) return e;
@@ -490,6 +537,8 @@ int ot_resident_plan(int batch, int n0, int n1, int max_wgs, int* nch, int* rpw,
 }
 
 size_t ot_resident_ldx(int nch) { return (size_t)256 * nch + 4; }
+
+bool ot_resident_hier_ok(int nch, int rpw, int G, int batch) { return rpw == 4 && nch >= 5 && nch <= 8 && !(G & 1) && G / 2 <= 32 && batch <= 4; }
 
 hipError_t launch_ot_resident(const OtResidentParams& p, int nch, int rpw, hipStream_t stream) {
 #define IMP_OTR(N, R) if (nch == N && rpw == R) return launch_one<N, R>(p, stream)
