@@ -381,9 +381,10 @@ def main():
                          'launches_per_step': layer_sides // 2,
                          'whole_path_tflops': pair_flops * n_total * args.steps / elapsed / 1e12 / world,
                          'sinkhorn_iteration': {
-                             'path': 'chip-resident (P in VGPRs for all T iterations, two tagged vector exchanges per iteration, no barrier)'
+                             'path': 'chip-resident (P in VGPRs for all T iterations, tagged vector exchanges without barriers; a pair lives on two XCDs: column '
+                                     'sums reduced inside each XCD L2, half sums swapped once across the fabric per iteration)'
                              if sk_resident else 'streaming (P read once per iteration, 2 launches)',
-                             'bound': 'latency (two store-to-load propagations across the chip per iteration)' if sk_resident else 'hbm',
+                             'bound': 'latency (one fabric crossing + two L2 hand-offs per iteration) and the per-iteration arithmetic' if sk_resident else 'hbm',
                              'iteration_ms': sk_ms, 'matrix_bytes': sk_bytes,
                              'matrix_bytes_per_iteration_time_GBs': sk_bytes / (sk_ms * 1e-3) / 1e9,
                              'peak_GBs': PEAK_HBM_GBS,
