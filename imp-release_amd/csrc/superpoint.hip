@@ -1272,6 +1272,7 @@ int pack_conv(imp_sp_ctx* c, const std::vector<std::string>& names, int cin, int
                     frag[base + 64 * 8 + (size_t)lane * 8 + e] = lo;
                 }
         }
+    // (a failure below leaves whatever was allocated in *out: imp_sp_finalize / imp_sp_destroy release it through free_conv)
     SP_TRY(hipMalloc(&out->wf, frag.size() * sizeof(_Float16)));
     SP_TRY(hipMemcpy(out->wf, frag.data(), frag.size() * sizeof(_Float16), hipMemcpyHostToDevice));
     SP_TRY(hipMalloc(&out->bias, ball.size() * sizeof(float)));
