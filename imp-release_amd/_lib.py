@@ -27,7 +27,7 @@ SYMBOLS = [
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
     'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear',
-    'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_op_linear_planes', 'imp_trust_descriptor_planes', 'imp_time_layer_gemm', 'imp_estimate_pose',
+    'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_time_layer_gemm', 'imp_estimate_pose',
     'imp_sp_create', 'imp_sp_destroy', 'imp_sp_set_weight', 'imp_sp_finalize', 'imp_sp_detect', 'imp_sp_describe', 'imp_sp_dense', 'imp_sp_op_conv',
 ]
 
@@ -99,8 +99,6 @@ def lib():
     L.imp_time_attention.argtypes = [P, I, I, I, C.POINTER(C.c_float), P]
     L.imp_time_sinkhorn.argtypes = [P, I, I, I, C.POINTER(C.c_float), P]
     L.imp_resident_status.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    L.imp_op_linear_planes.argtypes = [P, I, I, I, P, P, P, P, P, P, P]
-    L.imp_trust_descriptor_planes.argtypes = [P, I]
     L.imp_time_layer_gemm.argtypes = [P, I, I, I, I, I, C.POINTER(C.c_float), P]
     L.imp_estimate_pose.argtypes = [P, P, I, P, P, C.c_double, I, C.c_uint, I, P, P, P, P, C.POINTER(C.c_int), P]
     L.imp_sp_create.argtypes = [C.POINTER(C.c_void_p), I, I]
@@ -393,23 +391,7 @@ class Context:
         self._check(self.L.imp_resident_status(self.handle, C.byref(st), C.byref(used)))
         return bool(st.value), bool(used.value)
 
-    def trust_descriptor_planes(self, on: bool):
-        """promise (or withdraw the promise) that descriptors handed to consecutive forward_layer calls are the unmodified
-        outputs of the previous call when the tensors are the same (include/imp_hip.h imp_trust_descriptor_planes)"""
-        self._check(self.L.imp_trust_descriptor_planes(self.handle, 1 if on else 0))
-
-    def op_linear_planes(self, x, W, bias=None, residual=None, roundtrip=False):
-        x, W = _f32(x, 'x'), _f32(W, 'W')
-        M, K = x.shape
-        N = W.shape[0]
-        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
-        yp = torch.empty_like(y) if roundtrip else None
-        self._check(self.L.imp_op_linear_planes(self.handle, M, N, K, _ptr(x), _ptr(W), _ptr(None if bias is None else _f32(bias, 'bias')),
-                                                _ptr(None if residual is None else _f32(residual, 'residual')), _ptr(y), _ptr(yp),
-                                                _stream(self.device)))
-        return (y, yp) if roundtrip else y
-
-    def time_layer_gemm(self, batch, n, which, dbg=0, reps=20):
+    def time_layer_gemm(self, batch, n, which, dbg=-1, reps=20):
         ms = C.c_float()
         self._check(self.L.imp_time_layer_gemm(self.handle, batch, n, which, dbg, reps, C.byref(ms), _stream(self.device)))
         return ms.value

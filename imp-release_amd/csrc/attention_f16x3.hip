@@ -51,29 +51,12 @@ __device__ __forceinline__ void split4(const f32x4 x, u32x2& hi, u32x2& lo) {
 }
 __device__ __forceinline__ int swap23(int k) { return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1); }
 
-// a wave's 32 output rows (staged in LDS as ot[row][DH]) -> memory: fp32 rows, or - out_planes - the rows as planes
-// [D hi halves | D lo halves] for the split-half GEMM that consumes them (gemm_planes.hip)
+// a wave's 32 output rows (staged in LDS as ot[row][DH]) -> memory as fp32 rows
 template <int DH>
 __device__ __forceinline__ void store_attention_rows(const AttnParams& p, const AttnSide& S, int b, int h, int qbase, int nq,
                                                      const float* ot, int ldot, int lane) {
     const int half = lane >> 5, l31 = lane & 31;
     constexpr int RPP = 64 / DH;                 // rows per pass: DH = 64 -> 1 (lane = channel), DH = 32 -> 2
-    if (p.out_planes) {
-        _Float16* Op = reinterpret_cast<_Float16*>(S.out) + b * S.so_b + h * DH;
-        constexpr int D = IMP_NUM_HEADS * DH;
-#pragma unroll 4
-        for (int i = 0; i < 32 / RPP; ++i) {
-            const int qi = RPP == 1 ? i : 2 * i + half, ch = RPP == 1 ? lane : l31;
-            const int qrow = qbase + qi;
-            if (qrow < nq) {
-                const float x = ot[qi * ldot + ch];
-                const _Float16 hi = (_Float16)x;
-                Op[(long)qrow * p.ldo + ch] = hi;
-                Op[(long)qrow * p.ldo + D + ch] = (_Float16)(x - (float)hi);
-            }
-        }
-        return;
-    }
     float* Og = S.out + b * S.so_b + h * DH;
 #pragma unroll 4
     for (int i = 0; i < 32 / RPP; ++i) {

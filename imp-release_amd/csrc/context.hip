@@ -35,9 +35,7 @@ struct GnnLayer {
     Linear mlp0f;    // [2D][2D] with the merge conv folded in: [W1a | W1b.Wm], bias b1 + W1b.bm (fuse_merge)
     NormC bn;        // only norm_fn == 'bn'
     Linear mlp3;     // [D][2D]
-    // the same weights as planes (rows [K hi halves | K lo halves]) for gemm_planes.hip
-    _Float16 *proj_p = nullptr, *mlp0f_p = nullptr, *mlp3_p = nullptr;
-    // ... and as MFMA fragments (gemm_wf.hip: wf_pack)
+    // the same weights as split-half MFMA fragments (gemm_wf.hip: wf_pack)
     _Float16 *proj_wf = nullptr, *mlp0f_wf = nullptr, *mlp3_wf = nullptr;
 };
 struct AttnCache {   // cached operands of the last non-shared layer of a kind (self / cross)
@@ -85,19 +83,13 @@ struct imp_ctx {
     int *arg0 = nullptr, *arg1 = nullptr, *colpart_i = nullptr;
     float *colsum[4] = {}, *amass[4] = {}, *mass[2] = {};
     AttnCache cache[2];
-    // planes path (gemm_planes.hip): f16x3 arithmetic with the merge conv folded; IMP_GEMM_PLANES=0 keeps gemm_f32.hip
-    int use_planes = 0;
     float* xhalf = nullptr;  // resident Sinkhorn, two XCDs per pair: the half sums the XCDs swap
     int ot_hier = 1;         // two-XCDs-per-pair resident launches (hierarchical column sums) when a pair fits 64 CUs and B <= 4 (IMP_OT_HIER=0 disables)
     int ot_local = 1;        // XCD-local resident Sinkhorn launches when a pair fits one XCD (IMP_OT_LOCAL=0 disables)
     int use_wf = 1;          // weight-fragment GEMMs (gemm_wf.hip) for the layer convolutions when f16x3, D = 256, relu + InstanceNorm; IMP_GEMM_WF=0 disables
-    _Float16* xpl[2] = {};                 // planes of the current descriptors of image 0 / 1  [B][n][2D halves]
-    const float* xpl_src[2] = {};          // fp32 tensor they were made from / written next to (trusted only inside one call chain)
-    int xpl_b = 0, xpl_n[2] = {0, 0};
-    bool trust_planes = false;
     float* attn_split_ws = nullptr;        // key-split scratch of the attention kernel (grown on demand, allocs_x)
     unsigned* attn_split_cnt = nullptr;
-    size_t attn_split_cap = 0, attn_split_units = 0;             // imp_trust_descriptor_planes: consecutive imp_forward_layer calls chain unmodified outputs
+    size_t attn_split_cap = 0, attn_split_units = 0;
 };
 
 namespace {
@@ -187,21 +179,6 @@ const HostTensor* get(imp_ctx* c, const std::string& key, int64_t numel) {
     }
     return &it->second;
 }
-// rows [K] fp32 -> planes [K hi halves | K lo halves] (hi = f16(x), lo = f16(x - hi), both round to nearest even)
-int upload_planes(imp_ctx* c, _Float16** dst, const float* W, size_t rows, size_t K) {
-    std::vector<_Float16> h(rows * 2 * K);
-    for (size_t r = 0; r < rows; ++r)
-        for (size_t k = 0; k < K; ++k) {
-            const float x = W[r * K + k];
-            const _Float16 hi = (_Float16)x;
-            h[r * 2 * K + k] = hi;
-            h[r * 2 * K + K + k] = (_Float16)(x - (float)hi);
-        }
-    int rc = dev_alloc(c, c->allocs_w, dst, h.size());
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(*dst, h.data(), h.size() * sizeof(_Float16), hipMemcpyHostToDevice));
-    return IMP_OK;
-}
 int upload_wf(imp_ctx* c, _Float16** dst, const float* W, int N, int K) {
     if (!gemm_wf_supported(K, N)) { *dst = nullptr; return IMP_OK; }
     std::vector<_Float16> h((size_t)N * K * 2);
@@ -269,8 +246,6 @@ int ensure_workspace(imp_ctx* c, int batch, int n) {
         if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->mdesc[s], B * N * D);
         if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->nkp[s], B * N * 2);
         if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->mass[s], N + 4);
-        if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->xpl[s], B * N * 2 * D);
-        c->xpl_src[s] = nullptr;
     }
     const size_t ld = (N + 1 + 3) & ~(size_t)3;
     if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->dist, B * N * N);
@@ -435,43 +410,18 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
             return fail(IMP_E_STATE, "attention-sharing layer " + std::to_string(li) +
                                          " called without a matching cached attention of the same kind/shape");
     }
-    // planes path: split-half GEMMs on pre-split operands (gemm_planes.hip).  The descriptors' planes come from the previous
-    // layer's last GEMM when this call continues a trusted chain, otherwise they are made here.
-    // (worth it only when the panels fill the chip: one 64-row panel per workgroup, gemm_planes.hip)
-    const long panels = (long)(((n[0] > n[1] ? n[0] : n[1]) + 63) / 64) * 2 * batch;
-    const bool planes = c->prec == 1 && c->fuse_merge && c->use_planes && panels >= 96 && D % 128 == 0;
     // weight-fragment GEMMs: the default for the f16x3 arithmetic (gemm_wf.hip)
     // (64-row tiles with the whole K in LDS; small launches deal the column passes of a tile to several workgroups, wf_pass_split.
     // Measured against gemm_f32.hip, MLP0 / MLP3: 1.06x / 1.32x at B = 4, N = 2048 (256 tiles), 1.14x / 1.15x at B = 1, N = 2048,
     // 1.09x / 1.17x at B = 1, N = 1024, 1.06x / 0.99x at B = 8; the K = 256 projection: 1.21x at B = 1, N = 1024 (32 tiles), 0.91-0.97x
     // from 64 tiles up - it stays on gemm_f32.hip there.  IMP_GEMM_WF: 0 never, 1 by this rule (default), 2 always incl. the projection)
     const long wf_tiles = (long)batch * ((n[0] + 63) / 64 + (n[1] + 63) / 64);
-    const bool wf = !planes && c->prec == 1 && c->use_wf && (c->use_wf > 1 || wf_tiles <= 640);
+    const bool wf = c->prec == 1 && c->use_wf && (c->use_wf > 1 || wf_tiles <= 640);
     const bool wf_proj = wf && (c->use_wf > 1 || wf_tiles <= 40);
     const bool wf_mlp = wf && c->fuse_merge && cfg.norm_fn == IMP_NORM_IN && cfg.ac_fn == IMP_ACT_RELU && L.mlp0f_wf && L.mlp3_wf;
-    if (planes) {
-        for (int s = 0; s < 2; ++s) {
-            const bool have = c->trust_planes && c->xpl_src[s] == desc[s] && c->xpl_b == batch && c->xpl_n[s] == n[s];
-            if (!have) HIP_TRY(launch_make_planes(desc[s], c->xpl[s], (long)batch * n[s], D, D, 2 * D, st));
-            c->xpl_src[s] = desc[s]; c->xpl_n[s] = n[s];
-        }
-        c->xpl_b = batch;
-    }
     // 1. projections: q|k|v of both images in one GEMM (the layer's weights are shared by the two images);
     //    a sharing layer only refreshes the value slot and keeps last iteration's q,k (== its probabilities)
-    if (planes) {
-        PGemmParams p;
-        memset(&p, 0, sizeof p);
-        p.K = D; p.ksplit = D; p.nside = 2; p.nsub = 1;
-        for (int s = 0; s < 2; ++s) {
-            PGemmSide& g = p.side[s];
-            g.Ap = c->xpl[s]; g.Wp = L.proj_p; g.M = n[s]; g.N = L.proj.out;
-            g.C = L.shared ? qkv[s] + 2 * D : qkv[s];
-            g.sA_b = (long)n[s] * 2 * D; g.sC_b = (long)n[s] * 3 * D;
-        }
-        p.bias = L.proj.b; p.lda = 2 * D; p.apw = D; p.ldw = 2 * D; p.ldc = 3 * D;
-        HIP_TRY(launch_gemm_planes(p, batch, st));
-    } else if (wf_proj && L.proj_wf) {
+if (wf_proj && L.proj_wf) {
         WfParams p;
         memset(&p, 0, sizeof p);
         p.K = D; p.ksplit = D; p.N = L.proj.out; p.nside = 2;
@@ -517,9 +467,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
             g.kmask = cache.masked[src] ? c->cmask[kind][src] : nullptr;
             g.sq_b = (long)n[s] * 3 * D; g.sk_b = (long)n[src] * 3 * D; g.so_b = (long)n[s] * D;
             g.nq = n[s]; g.nk = n[src];
-            if (planes) g.so_b = (long)n[s] * 2 * D;        // output rows as planes [D hi | D lo] halves
         }
-        if (planes) { a.out_planes = 1; a.ldo = 2 * D; }
         if (int arc = launch_attention(c, a, batch, st)) return arc;
     }
     // 3. merge conv (skipped when it is folded into mlp.0's weights)
@@ -533,22 +481,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
     const bool in_norm = cfg.norm_fn == IMP_NORM_IN;
     const int maxn = n[0] > n[1] ? n[0] : n[1];
     int bm0 = gemm_stats_rows(maxn, 2 * D, 2 * batch);      // rows per statistics block of the MLP0 launch
-    if (planes) {
-        PGemmParams p;
-        memset(&p, 0, sizeof p);
-        p.K = 2 * D; p.ksplit = D; p.nside = 2; p.nsub = 1;
-        for (int s = 0; s < 2; ++s) {
-            PGemmSide& g = p.side[s];
-            g.Ap = c->xpl[s]; g.Ap2 = reinterpret_cast<const _Float16*>(c->attn_out[s]); g.Wp = L.mlp0f_p;
-            g.C = c->hid[s]; g.M = n[s]; g.N = 2 * D;
-            g.sA_b = (long)n[s] * 2 * D; g.sA2_b = (long)n[s] * 2 * D; g.sC_b = (long)n[s] * 2 * D;
-            g.out_stats = in_norm ? c->stats[s] : nullptr;
-        }
-        if (in_norm) p.flags |= PG_EPI_STATS;
-        p.bias = M0.b; p.lda = 2 * D; p.apw = D; p.lda2 = 2 * D; p.apw2 = D; p.ldw = 4 * D; p.ldc = 2 * D;
-        bm0 = pgemm_stats_rows(p, batch);
-        HIP_TRY(launch_gemm_planes(p, batch, st));
-    } else if (wf_mlp) {
+if (wf_mlp) {
         WfParams p;
         memset(&p, 0, sizeof p);
         p.K = 2 * D; p.ksplit = D; p.N = 2 * D; p.nside = 2;
@@ -584,26 +517,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
         for (int s = 0; s < 2; ++s) ss[s] = StatsSide{c->stats[s], c->nstat[s], (n[s] + bm0 - 1) / bm0, n[s], bm0};
         HIP_TRY(launch_stats_finalize(ss, 2, batch, 2 * D, 1e-3f, st));
     }
-    if (planes) {
-        PGemmParams p;
-        memset(&p, 0, sizeof p);
-        p.K = 2 * D; p.ksplit = 2 * D; p.nside = 2; p.nsub = 1;
-        p.act = cfg.ac_fn;
-        if (!in_norm) {
-            p.flags |= PG_PRO_AFFINE;
-            p.nm_mean = L.bn.mean; p.nm_rstd = L.bn.rstd; p.nm_gamma = L.bn.gamma; p.nm_beta = L.bn.beta;
-        }
-        for (int s = 0; s < 2; ++s) {
-            PGemmSide& g = p.side[s];
-            g.Af = c->hid[s]; g.Wp = L.mlp3_p; g.C = out[s]; g.R = desc[s]; g.M = n[s]; g.N = D;
-            g.Cp = c->xpl[s];                               // the new descriptors as planes for the next layer
-            g.sAf_b = (long)n[s] * 2 * D; g.sC_b = (long)n[s] * D; g.sR_b = (long)n[s] * D; g.sCp_b = (long)n[s] * 2 * D;
-            g.in_stats = in_norm ? c->nstat[s] : nullptr;
-            c->xpl_src[s] = out[s];
-        }
-        p.bias = L.mlp3.b; p.ldaf = 2 * D; p.ldw = 4 * D; p.ldc = D; p.ldr = D; p.ldcp = 2 * D; p.cpw = D;
-        HIP_TRY(launch_gemm_planes(p, batch, st));
-    } else if (wf_mlp) {
+if (wf_mlp) {
         WfParams p;
         memset(&p, 0, sizeof p);
         p.K = 2 * D; p.ksplit = 2 * D; p.N = D; p.nside = 2;
@@ -683,9 +597,6 @@ ResidentLane* resident_lane(int device) {
 constexpr size_t kResidentMaxLdx = 256 * 16 + 4;
 int ensure_resident_buffers(imp_ctx* c, int batch) {
     if (c->xpart && batch <= c->xcap_b) return IMP_OK;
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-    c->num_cus = prop.multiProcessorCount;
     const size_t wgs = (size_t)c->num_cus;
     int rc = 0;
     const int cap = batch < 8 ? 8 : batch;
@@ -870,10 +781,15 @@ int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     { const char* e = getenv("IMP_OT_RESIDENT"); c->ot_resident = (e && atoi(e) == 0) ? 0 : 1; }
     { const char* e = getenv("IMP_OT_LOCAL"); c->ot_local = (e && atoi(e) == 0) ? 0 : 1; }
     { const char* e = getenv("IMP_OT_HIER"); c->ot_hier = (e && atoi(e) == 0) ? 0 : 1; }
-    // pre-split planes GEMMs (gemm_planes.hip) for the layer convs: measured SLOWER than gemm_f32.hip on MI355X,
-    // kept as an opt-in experiment and A/B switch
-    { const char* e = getenv("IMP_GEMM_PLANES"); c->use_planes = (e && atoi(e) != 0) ? 1 : 0; }
     { const char* e = getenv("IMP_GEMM_WF"); c->use_wf = e ? atoi(e) : 1; }     // 0 off, 1 default (large launches), 2 always
+    {   // CU count: sizes the resident Sinkhorn launches and the column-pass split of small weight-fragment GEMM launches
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) {
+            delete c;
+            return fail(IMP_E_HIP, "imp_create: cannot query the CU count of the device");
+        }
+        c->num_cus = cus;
+    }
     c->kenc_maxc = c->D;
     for (int i = 0; i < nk; ++i) if (cfg->kenc_channels[i] > c->kenc_maxc) c->kenc_maxc = cfg->kenc_channels[i];
     build_schema(c);
@@ -972,7 +888,6 @@ int imp_finalize_weights(imp_ctx* c) {
         L.proj.out = nproj * D; L.proj.in = D;
         if ((rc = upload(c, &L.proj.W, W))) return rc;
         if ((rc = upload(c, &L.proj.b, b))) return rc;
-        if ((rc = upload_planes(c, &L.proj_p, W.data(), (size_t)nproj * D, D))) return rc;
         if ((rc = upload_wf(c, &L.proj_wf, W.data(), nproj * D, D))) return rc;
         // merge, input columns permuted to head-major
         {
@@ -1013,7 +928,6 @@ int imp_finalize_weights(imp_ctx* c) {
             L.mlp0f.out = 2 * D; L.mlp0f.in = 2 * D;
             if ((rc = upload(c, &L.mlp0f.W, Wf))) return rc;
             if ((rc = upload(c, &L.mlp0f.b, bf))) return rc;
-            if ((rc = upload_planes(c, &L.mlp0f_p, Wf.data(), (size_t)2 * D, (size_t)2 * D))) return rc;
             if ((rc = upload_wf(c, &L.mlp0f_wf, Wf.data(), 2 * D, 2 * D))) return rc;
         }
         if (cfg.norm_fn == IMP_NORM_BN)
@@ -1022,7 +936,6 @@ int imp_finalize_weights(imp_ctx* c) {
         {
             const HostTensor* w3 = get(c, p + ".mlp.3.weight", (int64_t)2 * D * D);
             if (!w3) return IMP_E_KEY;
-            if ((rc = upload_planes(c, &L.mlp3_p, w3->data.data(), (size_t)D, (size_t)2 * D))) return rc;
             if ((rc = upload_wf(c, &L.mlp3_wf, w3->data.data(), D, 2 * D))) return rc;
         }
     }
@@ -1074,13 +987,6 @@ int imp_forward_layer(imp_ctx* c, int layer_i, int batch, int n0, int n1, const 
     float* out[2] = {out0, out1};
     const uint8_t* km[2] = {key_mask0, key_mask1};
     return run_layer(c, layer_i, batch, n, de, out, km, S(stream));
-}
-
-int imp_trust_descriptor_planes(imp_ctx* c, int on) {
-    if (!c) return fail(IMP_E_ARG, "imp_trust_descriptor_planes: null context");
-    c->trust_planes = on != 0;
-    c->xpl_src[0] = c->xpl_src[1] = nullptr;
-    return IMP_OK;
 }
 
 int imp_attention_prob(imp_ctx* c, int which, float* prob, void* stream) {
@@ -1245,12 +1151,7 @@ int imp_match_pair(imp_ctx* c, int batch, int n0, int n1, const float* kpts0, co
     if ((rc = run_kenc(c, batch, n, kp, sc, width, height, de, dw, st))) return rc;   // desc + enc (nets/gm.py:177-178)
     const uint8_t* nomask[2] = {nullptr, nullptr};
     const float* dr[2] = {c->descw[0], c->descw[1]};
-    const bool trust_before = c->trust_planes;
-    c->xpl_src[0] = c->xpl_src[1] = nullptr;               // the encoder just rewrote the descriptors
-    c->trust_planes = true;                                // inside this call the layers chain their own outputs
     for (int li = 0; li < c->cfg.n_gnn_layers && !rc; ++li) rc = run_layer(c, li, batch, n, dr, dw, nomask, st);
-    c->trust_planes = trust_before;
-    c->xpl_src[0] = c->xpl_src[1] = nullptr;
     if (rc) return rc;
     if ((rc = run_distance(c, c->cfg.n_layers - 1, batch, n, dr, c->dist, st))) return rc;
     OtBuffers o;
@@ -1272,38 +1173,6 @@ int imp_op_linear(imp_ctx* c, int M, int N, int K, const float* x, const float* 
     g.A = x; g.W = W; g.C = y; g.M = M; g.N = N;
     p.bias = bias; p.lda = K; p.ldw = K; p.ldc = N;
     HIP_TRY(launch_gemm_f32(p, 1, S(stream)));
-    return IMP_OK;
-}
-
-int imp_op_linear_planes(imp_ctx* c, int M, int N, int K, const float* x, const float* W, const float* bias,
-                         const float* residual, float* y, float* y_planes_roundtrip, void* stream) {
-    if (!c || !x || !W || !y || K % 32 || N % 64) return fail(IMP_E_ARG, "imp_op_linear_planes: bad argument (K % 32 == 0, N % 64 == 0)");
-    HIP_TRY(hipSetDevice(c->device));
-    hipStream_t st = S(stream);
-    _Float16 *xp = nullptr, *wp = nullptr, *yp = nullptr;
-    HIP_TRY(hipMalloc(&xp, (size_t)M * 2 * K * 2));
-    HIP_TRY(hipMalloc(&wp, (size_t)N * 2 * K * 2));
-    HIP_TRY(hipMalloc(&yp, (size_t)M * 2 * N * 2));
-    HIP_TRY(launch_make_planes(x, xp, M, K, K, 2 * K, st));
-    HIP_TRY(launch_make_planes(W, wp, N, K, K, 2 * K, st));
-    PGemmParams p;
-    memset(&p, 0, sizeof p);
-    p.K = K; p.ksplit = K; p.nside = 1; p.nsub = 1;
-    PGemmSide& g = p.side[0];
-    g.Ap = xp; g.Wp = wp; g.C = y; g.Cp = y_planes_roundtrip ? yp : nullptr; g.R = residual; g.M = M; g.N = N;
-    p.bias = bias; p.lda = 2 * K; p.apw = K; p.ldw = 2 * K; p.ldc = N; p.ldr = N; p.ldcp = 2 * N; p.cpw = N;
-    HIP_TRY(launch_gemm_planes(p, 1, st));
-    if (y_planes_roundtrip) {      // y as planes -> hi + lo back to fp32 (checks the planes epilogue)
-        HIP_TRY(hipStreamSynchronize(st));
-        std::vector<_Float16> h((size_t)M * 2 * N);
-        HIP_TRY(hipMemcpy(h.data(), yp, h.size() * 2, hipMemcpyDeviceToHost));
-        std::vector<float> f((size_t)M * N);
-        for (int r = 0; r < M; ++r)
-            for (int k = 0; k < N; ++k) f[(size_t)r * N + k] = (float)h[(size_t)r * 2 * N + k] + (float)h[(size_t)r * 2 * N + N + k];
-        HIP_TRY(hipMemcpy(y_planes_roundtrip, f.data(), f.size() * 4, hipMemcpyHostToDevice));
-    }
-    HIP_TRY(hipStreamSynchronize(st));
-    (void)hipFree(xp); (void)hipFree(wp); (void)hipFree(yp);
     return IMP_OK;
 }
 
@@ -1418,7 +1287,7 @@ int imp_time_sinkhorn(imp_ctx* c, int batch, int n, int iterations, float* ms, v
 }
 
 // probe: average time of ONE of the three layer GEMMs of layer 0 on the context's workspace (which: 0 QKV, 1 MLP0, 2 MLP3),
-// planes kernel with probe switches `dbg` (gemm_planes.hip) or, dbg < 0, the gemm_f32.hip kernel
+// dbg == -1: the gemm_f32.hip kernel; dbg <= -2: gemm_wf.hip with its probe switches (-dbg - 2)
 int imp_time_layer_gemm(imp_ctx* c, int batch, int n, int which, int dbg, int reps, float* ms, void* stream) {
     int rc = check_ready(c, batch, n, n);
     if (rc) return rc;
@@ -1467,23 +1336,7 @@ int imp_time_layer_gemm(imp_ctx* c, int batch, int n, int which, int dbg, int re
             if (which == 2) { p.flags = GEMM_PRO_NORM; p.bias = L.mlp3.b; p.lda = 2 * D; p.ldw = 2 * D; p.ldc = D; p.ldr = D; }
             return launch_gemm_f32(p, batch, st);
         }
-        PGemmParams p;
-        memset(&p, 0, sizeof p);
-        p.nside = 2; p.nsub = 1; p.dbg = dbg;
-        p.K = which == 0 ? D : 2 * D; p.ksplit = which == 1 ? D : p.K;
-        for (int s = 0; s < 2; ++s) {
-            PGemmSide& g = p.side[s];
-            g.M = n;
-            if (which == 0) { g.Ap = c->xpl[s]; g.Wp = L.proj_p; g.C = c->qkv[0][s]; g.N = 3 * D; g.sA_b = (long)n * 2 * D; g.sC_b = (long)n * 3 * D; }
-            if (which == 1) { g.Ap = c->xpl[s]; g.Ap2 = reinterpret_cast<const _Float16*>(c->attn_out[s]); g.Wp = L.mlp0f_p; g.C = c->hid[s]; g.N = 2 * D;
-                              g.sA_b = g.sA2_b = (long)n * 2 * D; g.sC_b = (long)n * 2 * D; g.out_stats = c->stats[s]; }
-            if (which == 2) { g.Af = c->hid[s]; g.Wp = L.mlp3_p; g.C = c->mdesc[s]; g.R = c->descw[s]; g.Cp = c->xpl[s]; g.N = D; g.sAf_b = (long)n * 2 * D;
-                              g.sC_b = (long)n * D; g.sR_b = (long)n * D; g.sCp_b = (long)n * 2 * D; g.in_stats = c->nstat[s]; }
-        }
-        if (which == 0) { p.bias = L.proj.b; p.lda = 2 * D; p.apw = D; p.ldw = 2 * D; p.ldc = 3 * D; }
-        if (which == 1) { p.flags |= PG_EPI_STATS; p.bias = L.mlp0f.b; p.lda = p.lda2 = 2 * D; p.apw = p.apw2 = D; p.ldw = 4 * D; p.ldc = 2 * D; }
-        if (which == 2) { p.bias = L.mlp3.b; p.ldaf = 2 * D; p.ldw = 4 * D; p.ldc = D; p.ldr = D; p.ldcp = 2 * D; p.cpw = D; }
-        return launch_gemm_planes(p, batch, st);
+        return hipErrorInvalidValue;                            // (dbg >= 0 selected the retired planes kernel: tools/probe/gemm_planes.hip)
     };
     HIP_TRY(launch());
     HIP_TRY(hipEventRecord(e0, st));

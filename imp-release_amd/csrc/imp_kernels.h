@@ -81,46 +81,6 @@ int gemm_stats_rows(int M, int N, int total_z);
 int gemm_tile_m(int M, int N, int total_z);
 
 // ------------------------------------------------------------------------------------------------
-// split-half MFMA GEMM on pre-split operands ("planes": a row of a C-channel matrix = [C hi halves | C lo halves]),
-// LDS-DMA staging (gemm_planes.hip).  Same z decomposition as GemmParams.
-// ------------------------------------------------------------------------------------------------
-enum {
-    PG_PRO_AFFINE = 1 << 1,       // fp32-A prologue: norm has gamma/beta (BatchNorm)
-    PG_EPI_EXPROW = 1 << 2,       // v = exp(v - rowvec[row] * rowvec_scale)
-    PG_EPI_STATS = 1 << 3,        // per-tile per-column (sum, M2 about the tile mean) -> out_stats [b][row_tiles][N][2]
-    PG_EPI_EXP2 = 1 << 4,         // EXPROW in base 2
-};
-struct PGemmSide {
-    const _Float16* Ap;    // A planes [b][sub][M][lda halves], lo plane at + apw halves; null when Af is given
-    const _Float16* Ap2;   // optional second K-range source (k >= ksplit): [b][M][lda2], lo at + apw2
-    const float* Af;       // A as fp32 [b][M][ldaf]: normalised + activated + split while staging (in_stats or nm_*)
-    const _Float16* Wp;    // W planes [b][sub][N][ldw halves], lo plane at + K
-    float* C;              // fp32 output [b][sub][M][ldc] or null
-    _Float16* Cp;          // planes output [b][M][ldcp halves] in groups of cpw channels ([hi cpw | lo cpw] per group) or null
-    const float* R;        // fp32 residual [b][M][ldr] or null
-    const float* rowvec;   // [b][sub][M] or null
-    const float* in_stats; // [b][K][2] finalised (mean, rstd) or null
-    float* out_stats;      // [b][row_tiles][N][2]
-    long sA_b, sA_s, sA2_b, sAf_b, sW_b, sW_s, sC_b, sC_s, sCp_b, sR_b, sRV_b, sRV_s;
-    int M, N;
-};
-struct PGemmParams {
-    PGemmSide side[2];
-    const float* bias;
-    const float *nm_mean, *nm_rstd, *nm_gamma, *nm_beta;
-    int K, ksplit;
-    int lda, lda2, apw, apw2, ldaf, ldw, ldc, ldcp, cpw, ldr;
-    int nside, nsub, flags, act;
-    int bn_hint;           // 64 forces 64-column tiles
-    int scale_cols;        // output columns < scale_cols are multiplied by `scale` after the bias (multiple of 128)
-    float scale, rowvec_scale;
-    int dbg;               // probe switches (gemm_planes.hip), 0 in the product
-};
-hipError_t launch_gemm_planes(const PGemmParams& p, int batch, hipStream_t stream);
-int pgemm_stats_rows(const PGemmParams& p, int batch);   // rows per statistics tile of the kernel that will run
-hipError_t launch_make_planes(const float* x, _Float16* out, long rows, int C, long ldx, long ldo, hipStream_t stream);
-
-// ------------------------------------------------------------------------------------------------
 // attention (flash-style, softmax in registers; launch_attention_f16x3 = split-half MFMA, launch_attention_f32 = fp32 MFMA)
 // ------------------------------------------------------------------------------------------------
 struct AttnSide {
@@ -136,7 +96,6 @@ struct AttnSide {
 struct AttnParams {
     AttnSide side[2];
     int nside, ldq, ldk, ldo, dh;
-    int out_planes;        // f16x3 kernels only: `out` rows are planes [D hi halves | D lo halves]; ldo / so_b count halves
     // key-split scratch of the f16x3 ping-pong kernel (optional; null = never split): partial results
     // [unit][split][256 x dh + 512] and one zero-initialised, self re-arming ticket per unit, unit = (pair, side, head, query tile)
     float* split_ws;

@@ -48,12 +48,8 @@ def _normalize(model, data):
 def _loop(data, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method, estimate_pose, uncertainty,
           with_uncertainty, trace=None):
     ctx = model._ensure_ctx(check=True)
-    ctx.trust_descriptor_planes(True)        # this loop owns desc0 / desc1: the layers chain their own (in-place) outputs
-    try:
-        return _loop_body(ctx, data, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method, estimate_pose,
-                          uncertainty, with_uncertainty, trace)
-    finally:
-        ctx.trust_descriptor_planes(False)
+    return _loop_body(ctx, data, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method, estimate_pose,
+                      uncertainty, with_uncertainty, trace)
 
 
 def _loop_body(ctx, data, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method, estimate_pose, uncertainty,
@@ -78,8 +74,6 @@ def _loop_body(ctx, data, model, nI, match_ratio, min_kpts, error_th, stop_crite
                 desc1 = ctx.gather_rows(desc1, sel_ids1)
                 pts1_cpu = pts1_cpu[sel_host1 if sel_host1 is not None else sel_ids1.cpu().numpy()]
                 norm_kpts1 = norm_kpts1[:, sel_ids1, :]
-            if sel_ids0 is not None or sel_ids1 is not None:
-                ctx.trust_descriptor_planes(True)     # new tensors: forget the planes of the old ones
             sel_ids0 = sel_ids1 = sel_host0 = sel_host1 = None
         B, n0, n1 = desc0.shape[0], desc0.shape[1], desc1.shape[1]
         for li in (2 * it, 2 * it + 1):

@@ -204,19 +204,9 @@ int imp_time_attention(imp_ctx* ctx, int batch, int n, int reps, float* ms, void
  * shape (chip-resident kernel: time(T iterations) - time(0 iterations); streaming path: 2 launches per iteration);
  * *ms = average milliseconds per ITERATION */
 int imp_time_sinkhorn(imp_ctx* ctx, int batch, int n, int iterations, float* ms, void* stream);
-/* test entry of the pre-split ("planes") split-half GEMM (gemm_planes.hip): y = x W^T + bias (+ residual), x [M][K], W [N][K]
- * fp32 in memory, converted to planes and multiplied by the kernel the GNN layers use; y_planes_roundtrip (optional, [M][N])
- * receives the result as written by the planes epilogue (hi + lo).  K % 32 == 0, N % 64 == 0.  Synchronises. */
-int imp_op_linear_planes(imp_ctx* ctx, int M, int N, int K, const float* x, const float* W, const float* bias,
-                         const float* residual, float* y, float* y_planes_roundtrip, void* stream);
-/* The planes of the descriptors (the split-half operands of the layer GEMMs, nets/layers.py:145-149,210-218) are written by
- * every layer's last GEMM next to its fp32 output.  With on != 0 the caller promises that a descriptor tensor passed to
- * imp_forward_layer is the UNMODIFIED output of the previous imp_forward_layer call whenever the pointers and shapes match,
- * so the layer reuses those planes instead of re-splitting its input.  Default off; imp_match_pair always chains its own. */
-int imp_trust_descriptor_planes(imp_ctx* ctx, int on);
 /* probe (tools/probe/gemm_time.py): average milliseconds of one of the three GEMMs of GNN layer 0 (which: 0 q|k|v projection,
- * 1 MLP conv 0, 2 MLP conv 3) at [batch][n] on the context's workspace; dbg >= 0: gemm_planes.hip with its probe switches,
- * dbg < 0: gemm_f32.hip */
+ * 1 MLP conv 0, 2 MLP conv 3) at [batch][n] on the context's workspace; dbg == -1: gemm_f32.hip, dbg <= -2: gemm_wf.hip with
+ * its probe switches -dbg - 2 */
 int imp_time_layer_gemm(imp_ctx* ctx, int batch, int n, int which, int dbg, int reps, float* ms, void* stream);
 /* Pose step of the iterative loops (eval/pose_estimation.py:92-115 estimate_pose + :13-89 decompose_essential_mat) - SURVEY §8 f-1.
  * HOST arrays in, HOST arrays out (the matched keypoints of a loop iteration live on the host, eval/matching.py:68-87):

@@ -43,26 +43,6 @@ def test_linear_fp32_mfma(gm, M, N, K):
         assert (y.double() - ref.t()).abs().max().item() > 1e-2
 
 
-@pytest.mark.parametrize('M,N,K', [(300, 256, 256), (2048, 768, 256), (128, 64, 32), (1, 512, 512), (257, 128, 64),
-                                   (130, 256, 512), (4096, 512, 512), (1000, 192, 256), (16384, 256, 512)])
-def test_linear_on_presplit_planes(M, N, K):
-    """gemm_planes.hip (LDS-DMA staged split-half GEMM on pre-split operands): fp32 and planes outputs, bias, residual,
-    ragged row counts, both tile widths"""
-    cfg, sd, m, o = _model()
-    ctx = m._ensure_ctx()
-    x, W, b, r = _rand(M, K, seed=1), _rand(N, K, seed=2) / K ** .5, _rand(N, seed=3), _rand(M, N, seed=4)
-    y, yp = ctx.op_linear_planes(x.to(DEV), W.to(DEV), b.to(DEV), r.to(DEV), roundtrip=True)
-    ref = (x.double() @ W.double().t() + b.double() + r.double())
-    tol = 3e-6 * max(1.0, ref.abs().max().item()) * (K / 32) ** .5
-    err = (y.cpu().double() - ref).abs().max().item()
-    assert err < tol, f'planes linear {M}x{N}x{K}: max err {err:.3e}'
-    # the planes epilogue carries 22 significant bits of the same values
-    errp = (yp.cpu().double() - y.cpu().double()).abs().max().item()
-    assert errp <= 2.0 ** -21 * max(1.0, ref.abs().max().item()), f'planes output differs from fp32 output by {errp:.3e}'
-    y2 = ctx.op_linear_planes(x.to(DEV), W.to(DEV))
-    assert (y2.cpu().double() - x.double() @ W.double().t()).abs().max().item() < tol
-
-
 def _ref_attention(qkv_q, qkv_kv, D, mask=None):
     """fp64 reference of nets/layers.py:121-131 on packed head-major projections"""
     B, nq, _ = qkv_q.shape

@@ -412,31 +412,6 @@ def test_fused_call_is_hip_graph_capturable():
                         _cpu(eager['mscores0']).numpy(), 0.2, 1e-5, 'graph replay (streaming) vs eager (resident)')
 
 
-def test_opt_in_planes_gemm_path_agrees_with_the_default_path():
-    """IMP_GEMM_PLANES=1: the layer convs on pre-split operand planes (csrc/gemm_planes.hip: panel kernel, LDS-DMA staging,
-    attention output written as planes).  Slower than gemm_f32.hip on MI355X, kept as an experiment - and kept
-    correct: same matches as the default path, and as the oracle through the default path's own tests"""
-    import os
-    cfg = eval_config(n_layers=4, sinkhorn_iterations=20)
-    sd = synthetic.make_state_dict(cfg, 'DGNNS', seed=6)
-    base = make_hip_model('DGNNS', cfg, sd)
-    os.environ['IMP_GEMM_PLANES'] = '1'
-    try:
-        pl = make_hip_model('DGNNS', cfg, sd)
-        pl._ensure_ctx()
-    finally:
-        del os.environ['IMP_GEMM_PLANES']
-    for n0, n1, B in ((2048, 2000, 2), (1024, 1024, 4), (300, 280, 1)):       # panel kernel / panel kernel / too small: default kernels
-        pair = synthetic.make_correlated_pair(n0, n1, seed=n0 + B, batch=B)
-        data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
-        data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
-        with torch.no_grad():
-            a = base.produce_matches(data, p=0.2, only_last=True)
-            b = pl.produce_matches(data, p=0.2, only_last=True)
-        print(compare_matches(_cpu(b['indices0'][-1]), _cpu(b['mscores0'][-1]), _cpu(a['indices0'][-1]).numpy(),
-                              _cpu(a['mscores0'][-1]).numpy(), 0.2, TOL, f'planes path {n0}x{n1} B={B}'))
-
-
 WF_FIXTURES = ['gm_l3_alliters_b2', 'gm_l3_bigmean', 'gm_l9_t100_ragged', 'dgnns_l5_alliters', 'adagmn_masked_l9']
 
 

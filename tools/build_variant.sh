@@ -4,7 +4,7 @@
 set -e
 TAG=$1; shift
 C=imp-release_amd/csrc; V=$C/variants/$TAG; mkdir -p $V
-for f in gemm_f32 gemm_planes gemm_wf superpoint attention_f32 attention_f16x3 ot ot_resident pool_misc pose context; do
+for f in gemm_f32 gemm_wf superpoint attention_f32 attention_f16x3 ot ot_resident pool_misc pose context; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function "$@" -c $C/$f.hip -o $V/$f.o &
 done
 wait

@@ -24,7 +24,46 @@
 // section), exp(. - rowvec), + fp32 residual, per-tile column statistics (sum, M2 about the tile mean: merged with
 // Chan's formula, so a channel whose |mean| >> std loses no digits), fp32 output rows as float4, and / or the result
 // as planes for the next consumer.
-#include "imp_kernels.h"
+#include "../../imp-release_amd/csrc/imp_kernels.h"
+// RETIRED (round 3): measured slower than gemm_f32.hip / gemm_wf.hip on MI355X ("a negative result"); no longer
+// part of libimp_hip.so.  Its interface, formerly in imp_kernels.h, lives here so that the file still compiles on its own:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -c tools/probe/gemm_planes.hip
+enum {
+    PG_PRO_AFFINE = 1 << 1,       // fp32-A prologue: norm has gamma/beta (BatchNorm)
+    PG_EPI_EXPROW = 1 << 2,       // v = exp(v - rowvec[row] * rowvec_scale)
+    PG_EPI_STATS = 1 << 3,        // per-tile per-column (sum, M2 about the tile mean) -> out_stats [b][row_tiles][N][2]
+    PG_EPI_EXP2 = 1 << 4,         // EXPROW in base 2
+};
+struct PGemmSide {
+    const _Float16* Ap;    // A planes [b][sub][M][lda halves], lo plane at + apw halves; null when Af is given
+    const _Float16* Ap2;   // optional second K-range source (k >= ksplit): [b][M][lda2], lo at + apw2
+    const float* Af;       // A as fp32 [b][M][ldaf]: normalised + activated + split while staging (in_stats or nm_*)
+    const _Float16* Wp;    // W planes [b][sub][N][ldw halves], lo plane at + K
+    float* C;              // fp32 output [b][sub][M][ldc] or null
+    _Float16* Cp;          // planes output [b][M][ldcp halves] in groups of cpw channels ([hi cpw | lo cpw] per group) or null
+    const float* R;        // fp32 residual [b][M][ldr] or null
+    const float* rowvec;   // [b][sub][M] or null
+    const float* in_stats; // [b][K][2] finalised (mean, rstd) or null
+    float* out_stats;      // [b][row_tiles][N][2]
+    long sA_b, sA_s, sA2_b, sAf_b, sW_b, sW_s, sC_b, sC_s, sCp_b, sR_b, sRV_b, sRV_s;
+    int M, N;
+};
+struct PGemmParams {
+    PGemmSide side[2];
+    const float* bias;
+    const float *nm_mean, *nm_rstd, *nm_gamma, *nm_beta;
+    int K, ksplit;
+    int lda, lda2, apw, apw2, ldaf, ldw, ldc, ldcp, cpw, ldr;
+    int nside, nsub, flags, act;
+    int bn_hint;           // 64 forces 64-column tiles
+    int scale_cols;        // output columns < scale_cols are multiplied by `scale` after the bias (multiple of 128)
+    float scale, rowvec_scale;
+    int dbg;               // probe switches (gemm_planes.hip), 0 in the product
+};
+hipError_t launch_gemm_planes(const PGemmParams& p, int batch, hipStream_t stream);
+int pgemm_stats_rows(const PGemmParams& p, int batch);   // rows per statistics tile of the kernel that will run
+hipError_t launch_make_planes(const float* x, _Float16* out, long rows, int C, long ldx, long ldo, hipStream_t stream);
+
 #include <mutex>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -1,5 +1,5 @@
-"""Where the time of the three layer GEMMs goes (HIP events, 20 back-to-back launches each): product kernels, the planes
-kernel with parts switched off (stores / MFMA / DMA / epilogue), and the gemm_f32.hip kernel on the same shapes."""
+"""Where the time of the three layer GEMMs goes (HIP events, 20 back-to-back launches each): gemm_f32.hip and gemm_wf.hip with
+parts of the latter switched off.  (The round-2 pre-split planes kernel this probe was written for is retired: tools/probe/gemm_planes.hip.)"""
 import sys, torch
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 from helpers import eval_config, make_hip_model
@@ -14,6 +14,6 @@ m.produce_matches(d, p=0.2, only_last=True)
 names = ['QKV', 'MLP0', 'MLP3']
 for which in range(3):
     row = [names[which]]
-    for dbg, tag in ((-1, 'gemm_f32'), (0, 'panel'), (16, 'tile'), (1, 'no-stores'), (2, 'no-mfma'), (4, 'no-dma'), (8, 'no-epilogue'), (10, 'loads-only'), (14, 'empty')):
+    for dbg, tag in ((-1, 'gemm_f32'), (-2, 'gemm_wf'), (-3, 'wf no-stores'), (-4, 'wf no-epilogue'), (-6, 'wf no-bias/residual loads')):
         row.append(f'{tag} {ctx.time_layer_gemm(B, N, which, dbg) * 1e3:6.1f}')
     print(' | '.join(row))
