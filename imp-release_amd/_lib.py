@@ -27,7 +27,7 @@ SYMBOLS = [
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
     'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear',
-    'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_time_layer_gemm', 'imp_estimate_pose',
+    'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_time_layer_gemm', 'imp_estimate_pose',
     'imp_sp_create', 'imp_sp_destroy', 'imp_sp_set_weight', 'imp_sp_finalize', 'imp_sp_detect', 'imp_sp_describe', 'imp_sp_dense', 'imp_sp_op_conv',
 ]
 
@@ -40,6 +40,14 @@ class ImpError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f'libimp_hip error {code}: {msg}')
         self.code = code
+
+
+class ResidentSinkhornTimeout(ImpError):
+    """IMP_E_RESIDENT: a chip-resident Sinkhorn launch of an EARLIER call on this context was voided (its outputs are poisoned:
+    mscores NaN, indices -1).  The context has already recovered on a safer protocol; re-run the batch."""
+
+
+IMP_E_RESIDENT = -6
 
 
 class ImpConfig(C.Structure):
@@ -99,6 +107,8 @@ def lib():
     L.imp_time_attention.argtypes = [P, I, I, I, C.POINTER(C.c_float), P]
     L.imp_time_sinkhorn.argtypes = [P, I, I, I, C.POINTER(C.c_float), P]
     L.imp_resident_status.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.imp_resident_health.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.imp_set_resident_verify.argtypes = [P, I]
     L.imp_time_layer_gemm.argtypes = [P, I, I, I, I, I, C.POINTER(C.c_float), P]
     L.imp_estimate_pose.argtypes = [P, P, I, P, P, C.c_double, I, C.c_uint, I, P, P, P, P, C.POINTER(C.c_int), P]
     L.imp_sp_create.argtypes = [C.POINTER(C.c_void_p), I, I]
@@ -185,7 +195,7 @@ class Context:
 
     def _check(self, rc):
         if rc != 0:
-            raise ImpError(rc, self.L.imp_last_error().decode())
+            raise (ResidentSinkhornTimeout if rc == IMP_E_RESIDENT else ImpError)(rc, self.L.imp_last_error().decode())
 
     def close(self):
         if getattr(self, 'handle', None) and self.handle.value:
@@ -390,6 +400,22 @@ class Context:
         st, used = C.c_int(), C.c_int()
         self._check(self.L.imp_resident_status(self.handle, C.byref(st), C.byref(used)))
         return bool(st.value), bool(used.value)
+
+    def resident_health(self, raise_on_timeout=True):
+        """non-synchronising look at the health word of the chip-resident Sinkhorn kernel (call it after the results of a
+        step were synchronised to the host): raises ResidentSinkhornTimeout when a launch since the last look was voided (or
+        returns False), having already recovered the context; -> (voided launches so far, protocol level 0 / 1 / 2)"""
+        n, lvl = C.c_int(), C.c_int()
+        rc = self.L.imp_resident_health(self.handle, C.byref(n), C.byref(lvl))
+        if rc == IMP_E_RESIDENT and not raise_on_timeout:
+            return False
+        self._check(rc)
+        return n.value, lvl.value
+
+    def set_resident_verify(self, on: bool):
+        """every chip-resident Sinkhorn launch is awaited inside the call and a voided one is re-run there (one host
+        synchronisation per score; calls then always return valid results)"""
+        self._check(self.L.imp_set_resident_verify(self.handle, 1 if on else 0))
 
     def time_layer_gemm(self, batch, n, which, dbg=-1, reps=20):
         ms = C.c_float()

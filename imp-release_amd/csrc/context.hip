@@ -76,7 +76,15 @@ struct imp_ctx {
     int num_cus = 0;
     float *xpart = nullptr, *xv = nullptr, *xmax = nullptr;
     unsigned xtag = 0;       // tag base of the next resident launch (tags must never repeat on the exchange buffers)
-    int* xstatus = nullptr;
+    int* xstatus = nullptr;                        // device: [0] time-out flag, [4..11] per-XCC ticket counters of the LOCAL launches
+    int* xstatus_host = nullptr;                   // the same flag in mapped host memory: read at every entry without synchronising
+    int* xstatus_hostdev = nullptr;                //   its device address
+    unsigned ticket_base = 0;                      // value of the per-XCC ticket counters before the next LOCAL launch
+    int num_xccs = 0;
+    int ot_degrade = 0;      // raised by a time-out: 1 = no XCD-local launches any more (chip-wide exchange only), 2 = streaming kernels only
+    int ot_verify = 0;       // IMP_OT_VERIFY=1 / imp_set_resident_verify: wait for every resident launch and re-run a voided one inside the call
+    int ot_fake = 0;         // TEST HOOK IMP_OT_FAKE_PLACEMENT=1: LOCAL workgroups lie about their XCC (forces the time-out path)
+    int resident_timeouts = 0;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     int xcap_b = 0;
     float *max0 = nullptr, *max1 = nullptr, *colpart_v = nullptr;
@@ -274,12 +282,14 @@ int ensure_workspace(imp_ctx* c, int batch, int n) {
 }
 
 inline hipStream_t S(void* s) { return static_cast<hipStream_t>(s); }
+int resident_health(imp_ctx* c);
 
 int check_ready(imp_ctx* c, int batch, int n0, int n1) {
     if (!c) return fail(IMP_E_ARG, "null context");
     if (!c->finalized) return fail(IMP_E_STATE, "weights not finalised (imp_finalize_weights)");
     if (batch < 1 || n0 < 1 || n1 < 1) return fail(IMP_E_ARG, "batch, n0, n1 must be >= 1");
     HIP_TRY(hipSetDevice(c->device));
+    if (int hrc = resident_health(c)) return hrc;
     return ensure_workspace(c, batch, n0 > n1 ? n0 : n1);
 }
 
@@ -605,8 +615,18 @@ int ensure_resident_buffers(imp_ctx* c, int batch) {
         if (!rc) HIP_TRY(hipMemset(c->xpart, 0, 2 * wgs * kResidentMaxLdx * sizeof(float)));     // tag 0 = never written
         if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xmax, 4 * wgs * kResidentMaxLdx);
         if (!rc) HIP_TRY(hipMemset(c->xmax, 0, 4 * wgs * kResidentMaxLdx * sizeof(float)));
-        if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xstatus, 4);
-        if (!rc) HIP_TRY(hipMemset(c->xstatus, 0, 16));
+        if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xstatus, 16);
+        if (!rc) HIP_TRY(hipMemset(c->xstatus, 0, 64));
+        if (!rc) {
+            void* h = nullptr;
+            HIP_TRY(hipHostMalloc(&h, 64, hipHostMallocMapped));
+            c->xstatus_host = static_cast<int*>(h);
+            *c->xstatus_host = 0;
+            void* d = nullptr;
+            HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
+            c->xstatus_hostdev = static_cast<int*>(d);
+            c->ticket_base = 0;
+        }
         if (!rc) HIP_TRY(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
         if (!rc) HIP_TRY(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
     }
@@ -640,11 +660,49 @@ unsigned resident_tags(imp_ctx* c, int iterations) {
     return base;
 }
 
+
+// health plumbing of a resident launch: the mapped host word, and - LOCAL launches - the per-XCC ticket counters with the value
+// they hold before this launch (every XCC receives G * ceil(B / 8) resp. G / 2 workgroups of it)
+void resident_health_params(imp_ctx* c, OtResidentParams* p) {
+    p->host_status = c->xstatus_hostdev;
+    p->xcc_tickets = reinterpret_cast<unsigned*>(c->xstatus) + 4;
+    p->ticket_base = c->ticket_base;
+    p->fake_placement = c->ot_fake;
+    if (p->local == 1) c->ticket_base += (unsigned)(p->G * ((p->B + 7) / 8));
+    else if (p->local == 2) c->ticket_base += (unsigned)(p->G / 2);
+}
+
+// Non-synchronising health check, run at every compute entry point (check_ready): has a resident launch of this context
+// timed out since the last look?  Then the results of that EARLIER call are void (the kernel poisoned them: NaN scores, no
+// matches).  The context recovers - waits for its work, resets the exchange state, stops using the protocol that failed
+// (first the XCD-local launches, then the resident kernel altogether) - and the entry point that noticed returns
+// IMP_E_RESIDENT so that the caller re-runs the voided batch.
+int resident_health(imp_ctx* c) {
+    if (!c->xstatus_host) return IMP_OK;
+    const int st = *static_cast<volatile int*>(c->xstatus_host);
+    if (!st) return IMP_OK;
+    (void)hipDeviceSynchronize();
+    (void)hipMemset(c->xstatus, 0, 64);
+    (void)hipDeviceSynchronize();
+    *static_cast<volatile int*>(c->xstatus_host) = 0;
+    c->ticket_base = 0;
+    c->resident_timeouts += 1;
+    const int was = c->ot_degrade;
+    c->ot_degrade = was < 2 ? was + 1 : 2;
+    return fail(IMP_E_RESIDENT, std::string("a chip-resident Sinkhorn launch of this context ") +
+                                    (st == 2 ? "was not spread evenly over the XCCs" : "timed out in an exchange") +
+                                    ": the results of that call are void (scores NaN); the context now uses " +
+                                    (c->ot_degrade == 1 ? "the chip-wide exchange only" : "the streaming kernels") + " - re-run the batch");
+}
+
 // the resident launch on the device's lane, joined to `st` on both sides; returns IMP_OK, or >0 when not applicable
 // chooses the decomposition of a resident launch.  XCD-local (every pair on the 32 CUs of one XCD, exchanges through that XCD's
 // L2 instead of across the fabric) whenever a pair fits there: IMP_OT_LOCAL=0 disables.  Returns 0 when nothing fits.
 int plan_resident(imp_ctx* c, int batch, int n0, int n1, int max_wgs, int* nch, int* rpw, int* G, int* local) {
-    const bool allow_local = c->ot_local != 0;
+    // XCD-local protocols: only on the layout they were written for (8 XCCs x 32 CUs, SPX) and while no launch of this context
+    // ever timed out (ot_degrade)
+    const bool hw_local = c->num_xccs == 8 && c->num_cus == 256 && c->ot_degrade == 0;
+    const bool allow_local = c->ot_local != 0 && hw_local;
     *local = 0;
     const int per_xcd = (batch + 7) / 8;
     if (allow_local && max_wgs >= c->num_cus && per_xcd <= 32 && ot_resident_plan(1, n0, n1, 32 / per_xcd, nch, rpw, G)) {
@@ -652,7 +710,7 @@ int plan_resident(imp_ctx* c, int batch, int n0, int n1, int max_wgs, int* nch, 
         return 1;
     }
     // two XCDs per pair: one fabric crossing per iteration instead of two (ot_resident.hip, LOCAL = 2)
-    if (c->ot_hier && max_wgs >= c->num_cus && batch <= 4 && ot_resident_plan(1, n0, n1, 64, nch, rpw, G) && ot_resident_hier_ok(*nch, *rpw, *G, batch)) {
+    if (c->ot_hier && hw_local && max_wgs >= c->num_cus && batch <= 4 && ot_resident_plan(1, n0, n1, 64, nch, rpw, G) && ot_resident_hier_ok(*nch, *rpw, *G, batch)) {
         *local = 2;
         return 1;
     }
@@ -670,6 +728,7 @@ int run_score_resident_launch(imp_ctx* c, int batch, int b0, int nb, int n0, int
     p.xpart = c->xpart; p.xv = c->xv; p.xmax = c->xmax; p.status = c->xstatus;
     p.local = local; p.xhalf = c->xhalf;
     p.tag_base = resident_tags(c, iterations);
+    resident_health_params(c, &p);
     if (want_uv) {
         p.ldu = (n0 + 1 + 3) & ~3; p.ldv = (n1 + 1 + 3) & ~3;
         p.u = c->ot.u + (size_t)b0 * p.ldu; p.v = c->ot.v + (size_t)b0 * p.ldv;
@@ -695,21 +754,16 @@ int run_score_resident(imp_ctx* c, int batch, int n0, int n1, const float* dist,
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 1;   // graphs: streaming path
     int rc = ensure_resident_buffers(c, batch);
     if (rc) return rc;
-    // EXPERIMENT (IMP_OT_SPLIT=k, default 1): the batch as k launches of batch / k pairs, each planned for num_cus / k workgroups,
-    // so that a launch holds the registers of only a part of the CUs and another stream's kernels can use the rest
-    static const int split = [] { const char* e = getenv("IMP_OT_SPLIT"); const int v = e ? atoi(e) : 1; return v > 1 ? v : 1; }();
-    const int nsub = (split > 1 && batch % split == 0) ? split : 1;
-    const int bsub = batch / nsub;
-    int nch, rpw, G, local;
-    if (!plan_resident(c, bsub, n0, n1, c->num_cus / nsub, &nch, &rpw, &G, &local)) {
-        if (nsub == 1 || !plan_resident(c, batch, n0, n1, c->num_cus, &nch, &rpw, &G, &local)) return 1;
-        return run_score_resident_launch(c, batch, 0, batch, n0, n1, dist, bin, iterations, scores, want_max, want_uv, nch, rpw, G, local, st);
+    for (;;) {
+        if (c->ot_degrade >= 2) return 1;                                  // a chip-wide launch timed out before: streaming kernels only
+        int nch, rpw, G, local;
+        if (!plan_resident(c, batch, n0, n1, c->num_cus, &nch, &rpw, &G, &local)) return 1;
+        rc = run_score_resident_launch(c, batch, 0, batch, n0, n1, dist, bin, iterations, scores, want_max, want_uv, nch, rpw, G, local, st);
+        if (rc || !c->ot_verify) return rc;
+        // verified mode: wait for the launch; a voided one is re-run inside this call on the next protocol down
+        HIP_TRY(hipEventSynchronize(c->ev_out));
+        if (resident_health(c) == IMP_OK) return IMP_OK;
     }
-    for (int i = 0; i < nsub; ++i) {
-        rc = run_score_resident_launch(c, batch, i * bsub, bsub, n0, n1, dist, bin, iterations, scores, want_max, want_uv, nch, rpw, G, local, st);
-        if (rc) return rc;
-    }
-    return IMP_OK;
 }
 
 // scores (optional) and, with max_done, the row / column maxima of the inner block in c->max0/arg0/max1/arg1.
@@ -781,6 +835,8 @@ int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     { const char* e = getenv("IMP_OT_RESIDENT"); c->ot_resident = (e && atoi(e) == 0) ? 0 : 1; }
     { const char* e = getenv("IMP_OT_LOCAL"); c->ot_local = (e && atoi(e) == 0) ? 0 : 1; }
     { const char* e = getenv("IMP_OT_HIER"); c->ot_hier = (e && atoi(e) == 0) ? 0 : 1; }
+    { const char* e = getenv("IMP_OT_VERIFY"); c->ot_verify = (e && atoi(e) != 0) ? 1 : 0; }
+    { const char* e = getenv("IMP_OT_FAKE_PLACEMENT"); c->ot_fake = (e && atoi(e) != 0) ? 1 : 0; }
     { const char* e = getenv("IMP_GEMM_WF"); c->use_wf = e ? atoi(e) : 1; }     // 0 off, 1 default (large launches), 2 always
     {   // CU count: sizes the resident Sinkhorn launches and the column-pass split of small weight-fragment GEMM launches
         int cus = 0;
@@ -789,6 +845,9 @@ int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
             return fail(IMP_E_HIP, "imp_create: cannot query the CU count of the device");
         }
         c->num_cus = cus;
+        int xccs = 0;
+        if (hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, device) != hipSuccess) xccs = 0;
+        c->num_xccs = xccs;
     }
     c->kenc_maxc = c->D;
     for (int i = 0; i < nk; ++i) if (cfg->kenc_channels[i] > c->kenc_maxc) c->kenc_maxc = cfg->kenc_channels[i];
@@ -804,6 +863,7 @@ int imp_destroy(imp_ctx* c) {
     free_pool(c->allocs_w);
     free_pool(c->allocs_ws);
     free_pool(c->allocs_x);
+    if (c->xstatus_host) (void)hipHostFree(c->xstatus_host);
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     if (c->ev_out) (void)hipEventDestroy(c->ev_out);
     delete c;
@@ -1246,10 +1306,12 @@ int imp_time_sinkhorn(imp_ctx* c, int batch, int n, int iterations, float* ms, v
         for (int k = 0; k < 2; ++k) {
             p.T = k ? iterations : 0;
             p.tag_base = resident_tags(c, p.T);
+            resident_health_params(c, &p);
             HIP_TRY(launch_ot_resident(p, nch, rpw, st));   // warm
             HIP_TRY(hipEventRecord(e0, st));
             for (int r = 0; r < 3; ++r) {
                 p.tag_base = resident_tags(c, p.T);
+                resident_health_params(c, &p);
                 HIP_TRY(launch_ot_resident(p, nch, rpw, st));
             }
             HIP_TRY(hipEventRecord(e1, st));
@@ -1261,6 +1323,7 @@ int imp_time_sinkhorn(imp_ctx* c, int batch, int n, int iterations, float* ms, v
             unsigned long long* dprof = nullptr;
             HIP_TRY(hipMalloc(&dprof, 6 * sizeof(unsigned long long)));
             p.prof = dprof; p.T = iterations; p.tag_base = resident_tags(c, p.T);
+            resident_health_params(c, &p);
             HIP_TRY(launch_ot_resident(p, nch, rpw, st));
             unsigned long long hp[6];
             HIP_TRY(hipMemcpy(hp, dprof, sizeof hp, hipMemcpyDeviceToHost));
@@ -1356,7 +1419,25 @@ int imp_resident_status(imp_ctx* c, int* status, int* used) {
     HIP_TRY(hipSetDevice(c->device));
     *status = 0;
     if (used) *used = c->xstatus != nullptr;
-    if (c->xstatus) HIP_TRY(hipMemcpy(status, c->xstatus, sizeof(int), hipMemcpyDeviceToHost));
+    if (c->xstatus) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(status, c->xstatus, sizeof(int), hipMemcpyDeviceToHost));
+        if (!*status) *status = *static_cast<volatile int*>(c->xstatus_host);
+    }
+    return IMP_OK;
+}
+
+int imp_resident_health(imp_ctx* c, int* timeouts, int* level) {
+    if (!c) return fail(IMP_E_ARG, "imp_resident_health: null context");
+    const int rc = resident_health(c);
+    if (timeouts) *timeouts = c->resident_timeouts;
+    if (level) *level = c->ot_degrade;
+    return rc;
+}
+
+int imp_set_resident_verify(imp_ctx* c, int on) {
+    if (!c) return fail(IMP_E_ARG, "imp_set_resident_verify: null context");
+    c->ot_verify = on != 0;
     return IMP_OK;
 }
 

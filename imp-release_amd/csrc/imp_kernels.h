@@ -188,7 +188,11 @@ struct OtResidentParams {
     float* xv;                // [B][ldx][2]        v (inner columns | dustbin column)
     float* xmax;              // [B][G][2][ldx][2]  column maxima (values | row indices); used only with max0
     unsigned tag_base;        // tags of this launch are tag_base + 1 .. tag_base + 2 T + 1: never reused on these buffers
-    int* status;              // device flag, set to 1 when a wait timed out
+    int* status;              // device flag, set to 1 when a wait timed out (2: an XCC received more workgroups than its share)
+    int* host_status;         // the same word in mapped host memory (read by the library without synchronising), or null
+    unsigned* xcc_tickets;    // local != 0: [8] per-XCC ticket counters; a launch adds its per-XCC share to each of them
+    unsigned ticket_base;     //   value of the counters before this launch
+    int fake_placement;       // TEST HOOK (IMP_OT_FAKE_PLACEMENT=1): workgroups lie about the XCC they run on
     unsigned long long* prof; // optional [6]: phase cycle counts of workgroup 0 (probe), null in the product
     int local;                // 1: XCD-local launch: every pair's G <= 32 workgroups on one XCD (plain stores, L2-served polls);
                               // 2: two XCDs per pair (B <= 4), hierarchical column sums: one fabric crossing per iteration

@@ -497,7 +497,8 @@ __global__ __launch_bounds__(256) void mutual_kernel(int n0, int n1, const float
     if (t < n0) {
         const int j = a0[t];
         const bool mutual = (unsigned)j < (unsigned)n1 && a1[j] == t;
-        const float s = mutual ? m0[t] : 0.f;
+        float s = mutual ? m0[t] : 0.f;
+        if (j == 0x7fffffff && m0[t] != m0[t]) s = m0[t];       // voided by the resident Sinkhorn kernel (time-out): NaN, never a plausible 0
         if (ms0) ms0[(long)b * n0 + t] = s;
         if (ind0) ind0[(long)b * n0 + t] = (mutual && s > p) ? (int64_t)j : (int64_t)-1;
     }
@@ -509,7 +510,8 @@ __global__ __launch_bounds__(256) void mutual_kernel(int n0, int n1, const float
         const bool mutual0_i = ok_i && (unsigned)ji < (unsigned)n1 && a1[ji] == i;
         const float s0_i = mutual0_i ? m0[i] : 0.f;
         const bool valid0_i = mutual0_i && s0_i > p;
-        if (ms1) ms1[(long)b * n1 + t] = mutual1 ? s0_i : 0.f;
+        const bool voided = i == 0x7fffffff && max1[(long)b * n1 + t] != max1[(long)b * n1 + t];
+        if (ms1) ms1[(long)b * n1 + t] = voided ? max1[(long)b * n1 + t] : (mutual1 ? s0_i : 0.f);
         if (ind1) ind1[(long)b * n1 + t] = (mutual1 && valid0_i) ? (int64_t)i : (int64_t)-1;
     }
 }

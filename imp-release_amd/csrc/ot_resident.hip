@@ -25,9 +25,19 @@
 // each against ~8 us with __threadfence, tools/probe/barrier2_probe.hip - and see DESIGN.md for this protocol).  A
 // buffer is reused by the next iteration only after everyone has consumed it: a workgroup writes partial(t+1) after it
 // read v(t), which exists only once every slice owner has read all of partial(t); likewise for v.  Polls are bounded:
-// a time-out raises *status and every later wait of the launch falls through (garbage results, never a hang).  All
-// workgroups of a launch must be co-resident: the host launches at most one workgroup per CU and serialises resident
+// a time-out raises *status (device flag, polled by every waiter) AND *host_status (a word in mapped host memory the
+// library reads without synchronising at its next entry, context.hip resident_health), every later wait of the launch
+// falls through, and a workgroup that saw a time-out POISONS its outputs (maxima NaN, arg-maxima 0x7fffffff -> the match
+// kernel reports mscore NaN / index -1; first score of each own row NaN): unfinished exchanges can never pass as results.
+// All workgroups of a launch must be co-resident: the host launches at most one workgroup per CU and serialises resident
 // launches of a device on one lane stream (context.hip), so two of them can never hold each other's CUs.
+//
+// XCD placement (LOCAL = 1 / 2) is NOT assumed from blockIdx (HIP promises nothing about workgroup -> XCD placement,
+// MI355X_MICROARCH.md "Contract"): a workgroup reads the XCC it really runs on (s_getreg XCC_ID) and takes the next free
+// slot OF THAT XCC from a per-XCC ticket counter; its pair and row group follow from (xcc, slot).  So the workgroups that
+// exchange through plain stores share an L2 by construction, whatever order the dispatcher used.  What remains an
+// assumption - every XCC receives exactly its share of the grid - is checked: a ticket beyond the XCC's capacity raises
+// the status like a time-out and the launch is void.
 //
 // Fixed summation orders, no float atomics: bit-reproducible run to run.  Values differ from the streaming path in the last
 // bits (another summation order); both paths are checked against the same fixtures.
@@ -102,7 +112,15 @@ __device__ __forceinline__ void stg1(__amdgpu_buffer_rsrc_t r, int idx, float v,
     __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v), tag}, r, idx * 8, 0, AUX);
 }
 // poll until all four granules carry `tag`; `dead` (per thread) short-circuits every wait after a time-out
-__device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, int q, unsigned tag, int* status, bool& dead) {
+struct Health { int* status; int* host; };
+__device__ __forceinline__ void poll_health(const Health& h, int spins, bool& dead) {
+    if (spins > SPIN_LIMIT) {
+        __hip_atomic_store(h.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (h.host) __hip_atomic_store(h.host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (__hip_atomic_load(h.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) dead = true;
+}
+__device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, int q, unsigned tag, const Health& status, bool& dead) {
     u32x4 a, c;
     int spins = 0;
     for (;;) {
@@ -113,26 +131,20 @@ __device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, int q, unsigned 
 #if OTR_POLL_SLEEP
         __builtin_amdgcn_s_sleep(OTR_POLL_SLEEP);             // back off: failed polls compete with the stores they wait for
 #endif
-        if ((++spins & 1023) == 0) {
-            if (spins > SPIN_LIMIT) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) dead = true;
-        }
+        if ((++spins & 1023) == 0) poll_health(status, spins, dead);
     }
     return f32x4{__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(c[0]), __uint_as_float(c[2])};
 }
 
 // one granule
-__device__ __forceinline__ float ldg1(__amdgpu_buffer_rsrc_t r, int idx, unsigned tag, int* status, bool& dead) {
+__device__ __forceinline__ float ldg1(__amdgpu_buffer_rsrc_t r, int idx, unsigned tag, const Health& status, bool& dead) {
     u32x2 a;
     int spins = 0;
     for (;;) {
         asm volatile("" ::: "memory");
         a = __builtin_amdgcn_raw_buffer_load_b64(r, idx * 8, 0, AUX_POLL);
         if (a[1] == tag || dead) break;
-        if ((++spins & 1023) == 0) {
-            if (spins > SPIN_LIMIT) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) dead = true;
-        }
+        if ((++spins & 1023) == 0) poll_health(status, spins, dead);
     }
     return __uint_as_float(a[0]);
 }
@@ -141,8 +153,8 @@ __device__ __forceinline__ float ldg1(__amdgpu_buffer_rsrc_t r, int idx, unsigne
 // partial store)  2 wait + stage of the slice  3 slice reduce + v store  4 wait + read of v  5 v sum
 #define OTR_CLK(i) if (p.prof) { const unsigned long long c_ = __builtin_readcyclecounter(); prof_acc[i] += c_ - tlast; tlast = c_; }
 
-// LOCAL: every pair lives on ONE XCD (hardware places block i on XCD i % 8): block i serves pair (i % 8) + 8 * (slot / G), group slot % G with
-// slot = i / 8, so all G <= 32 workgroups of a pair share an L2 and the exchanges never cross the fabric
+// LOCAL: every pair lives on ONE XCD: a workgroup that runs on XCC x with ticket `slot` there serves pair x + 8 * (slot / G), group slot % G,
+// so all G <= 32 workgroups of a pair share an L2 and the exchanges never cross the fabric
 // LOCAL = 2 (two XCDs per pair, B <= 4): pair b lives on XCDs 2b and 2b + 1, half of its workgroups on each.  The column sums are
 // formed hierarchically - every half reduces ITS workgroups' partials through its own L2, the two halves swap their half sums
 // across the fabric (the one remote hand-off of the iteration), both compute the same v and distribute it inside their XCD - so
@@ -162,18 +174,36 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = p.G;
     int b, g, half = 0, H = G;                 // H workgroups exchange through one L2; this one is number gl = g - half * H of them
-    if (LOCAL == 1) {
-        const int slot = blockIdx.x >> 3;
-        b = (int)(blockIdx.x & 7) + 8 * (slot / G);
-        g = slot % G;
+    if (LOCAL) {
+        // the XCC this workgroup really runs on, and its ticket among the workgroups of the launch that landed there
+        __shared__ int s_place[2];
+        if (tid == 0) {
+            unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;       // XCC_ID[3:0] (hwreg 20 on gfx942 / gfx950)
+            if (p.fake_placement) xcc = (xcc + (blockIdx.x >> 3)) & 7u;                      // TEST HOOK: lie about the placement (still balanced)
+            const unsigned ticket = __hip_atomic_fetch_add(p.xcc_tickets + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_place[0] = (int)xcc;
+            s_place[1] = (int)(ticket - p.ticket_base);
+        }
+        __syncthreads();
+        const int xcc = s_place[0], slot = s_place[1];
+        const int cap = LOCAL == 1 ? G * ((p.B + 7) >> 3) : (G >> 1);
+        if (slot < 0 || slot >= cap) {             // this XCC received more workgroups than its share: the launch is void
+            if (tid == 0) {
+                __hip_atomic_store(p.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (p.host_status) __hip_atomic_store(p.host_status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+        if (LOCAL == 1) {
+            b = xcc + 8 * (slot / G);
+            g = slot % G;
+        } else {
+            b = xcc >> 1;
+            half = xcc & 1;
+            H = G >> 1;
+            g = half * H + slot;
+        }
         if (b >= p.B) return;                  // uniform per workgroup, before any exchange
-    } else if (LOCAL == 2) {
-        const int xcd = blockIdx.x & 7;
-        b = xcd >> 1;
-        half = xcd & 1;
-        H = G >> 1;
-        g = half * H + (int)(blockIdx.x >> 3);
-        if (b >= p.B) return;
     } else {
         b = blockIdx.x / G;
         g = blockIdx.x % G;
@@ -181,6 +211,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
     const int n0 = p.n0, n1 = p.n1;
     const int r0 = g * ROWS + wave * RPW;
     bool dead = false;
+    const Health health{p.status, p.host_status};
 
     // exchange buffers hold granules: 8 bytes per float
     const int gl = g - half * H;
@@ -300,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             for (int idx = tid; idx < cq * H; idx += 512) {
                 const int w = idx / cq, qq = idx - w * cq;
                 const int q = gl * cq + qq;
-                stage[idx] = q < NQ ? ldg4(rs_part, w * NQ + q, tag_p, p.status, dead) : f32x4{0.f, 0.f, 0.f, 0.f};
+                stage[idx] = q < NQ ? ldg4(rs_part, w * NQ + q, tag_p, health, dead) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             __syncthreads();
             OTR_CLK(2)
@@ -325,7 +356,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
                 if (xi < LDX) {
                     if (LOCAL == 2) {                                 // swap the half sums across the fabric; both halves add them in the same order
                         stg1<AUX_SC1>(rs_h_own, xi, s, tag_h);
-                        const float o = ldg1(rs_h_oth, xi, tag_h, p.status, dead);
+                        const float o = ldg1(rs_h_oth, xi, tag_h, health, dead);
                         s = half == 0 ? s + o : o + s;
                     }
                     const bool dust = xi == DCOL;
@@ -338,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         }
         OTR_CLK(3)
         // ---- D: everybody reads v -----------------------------------------------------------------------------------
-        for (int q = tid; q < NQ; q += 512) *reinterpret_cast<f32x4*>(vs + 4 * q) = ldg4(rs_v, q, tag_v, p.status, dead);
+        for (int q = tid; q < NQ; q += 512) *reinterpret_cast<f32x4*>(vs + 4 * q) = ldg4(rs_v, q, tag_v, health, dead);
         __syncthreads();
         OTR_CLK(4)
         {   // sum of v (every wave computes the same value in the same order: no further barrier)
@@ -457,7 +488,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             const int which = idx / (ncq * G), rem = idx - which * ncq * G;
             const int w = rem / ncq, qq = rem - w * ncq;
             const int q = g * ncq + qq;
-            stage[idx] = q < DCOL / 4 ? ldg4(rs_mx, w * 2 * NQ + which * NQ + q, tag_m, p.status, dead) : f32x4{0.f, 0.f, 0.f, 0.f};
+            stage[idx] = q < DCOL / 4 ? ldg4(rs_mx, w * 2 * NQ + which * NQ + q, tag_m, health, dead) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();
         for (int cl = tid; cl < 4 * ncq; cl += 512) {
@@ -473,6 +504,22 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
                 }
                 p.max1[(size_t)b * n1 + j] = best;
                 p.arg1[(size_t)b * n1 + j] = bi;
+            }
+        }
+    }
+    // ---- a workgroup in which any wait timed out voids what it wrote: unfinished exchanges must never pass as results
+    if (__syncthreads_or(dead ? 1 : 0)) {
+        const float nanv = __builtin_nanf("");
+        const int rend = min(n0, (g + 1) * ROWS);
+        for (int r = g * ROWS + tid; r < rend; r += 512) {
+            if (want_max) { p.max0[(size_t)b * n0 + r] = nanv; p.arg0[(size_t)b * n0 + r] = 0x7fffffff; }
+            if (p.scores) p.scores[((size_t)b * (n0 + 1) + r) * (n1 + 1)] = nanv;
+        }
+        if (want_max) {
+            const int ncq = (DCOL / 4 + G - 1) / G;
+            for (int cl = tid; cl < 4 * ncq; cl += 512) {
+                const int j = 4 * (g * ncq) + cl;
+                if (j < n1) { p.max1[(size_t)b * n1 + j] = nanv; p.arg1[(size_t)b * n1 + j] = 0x7fffffff; }
             }
         }
     }

@@ -20,6 +20,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from . import _lib
 from .dist import pack_matches, unpack_matches
 from .modules import VALID_ITS, _token_major
 
@@ -82,10 +83,17 @@ def _loop_body(ctx, data, model, nI, match_ratio, min_kpts, error_th, stop_crite
         if it not in VALID_ITS:
             continue
         dist = ctx.compute_distance(it, desc0, desc1)
-        pred_score = ctx.compute_score(dist, model._bin(None), model.sinkhorn_iterations, model.with_sinkhorn)
-        indices0, indices1, mscores0, mscores1 = ctx.compute_matches(pred_score, match_ratio)
-        # the one sync of this iteration: indices and scores of image 0 in a single device->host copy
-        packed = pack_matches(indices0[:1], mscores0[:1]).cpu()
+        for attempt in range(3):
+            pred_score = ctx.compute_score(dist, model._bin(None), model.sinkhorn_iterations, model.with_sinkhorn)
+            indices0, indices1, mscores0, mscores1 = ctx.compute_matches(pred_score, match_ratio)
+            # the one sync of this iteration: indices and scores of image 0 in a single device->host copy
+            packed = pack_matches(indices0[:1], mscores0[:1]).cpu()
+            # the copy synchronised: a voided chip-resident Sinkhorn launch (include/imp_hip.h, IMP_E_RESIDENT) shows now; the
+            # context has then already stepped down to a safer protocol and the score is simply computed again
+            if ctx.resident_health(raise_on_timeout=False) is not False:
+                break
+        else:
+            raise _lib.ResidentSinkhornTimeout(_lib.IMP_E_RESIDENT, 'the Sinkhorn score stayed void on every protocol')
         idx_h, ms_h = unpack_matches(packed, n0)
         indices0_cpu, mscores0_cpu = idx_h[0].numpy(), ms_h[0].numpy()
         if trace is not None:

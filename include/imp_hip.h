@@ -42,6 +42,8 @@ extern "C" {
 #define IMP_E_HIP (-3)      /* HIP runtime error */
 #define IMP_E_NOMEM (-4)
 #define IMP_E_KEY (-5)      /* unknown / missing state_dict key */
+#define IMP_E_RESIDENT (-6) /* a chip-resident Sinkhorn launch of an EARLIER call on this context timed out: that call's results are void
+                             * (poisoned: mscores NaN, indices -1); the context has recovered on a safer protocol - re-run the batch */
 
 /* model flavours: which GNN layers re-use the previous iteration's attention
  * (nets/gm.py:62 GM = none; nets/gms.py:17 DGNNS and nets/adgm.py:18 AdaGMN = [F,F]*2+[F,F,T,T]*21) */
@@ -218,10 +220,22 @@ int imp_time_layer_gemm(imp_ctx* ctx, int batch, int n, int which, int dbg, int 
 int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, const double* K0, const double* K1, double norm_thresh,
                       int iterations, unsigned seed, int device, double* E, double* R, double* t, unsigned char* mask,
                       int* n_inliers, void* stream);
-/* chip-resident Sinkhorn health (ot_resident.hip): *status != 0 when a group barrier ever timed out on this context
- * (results of that call are then garbage - never observed; the spin is bounded so that it cannot hang); *used = whether
- * the resident path has been taken at all.  Synchronises. */
+/* Chip-resident Sinkhorn health (csrc/ot_resident.hip; the kernel behind compute_score, nets/gm.py:297-303).  Its workgroups
+ * exchange vectors through memory with bounded waits.  A wait that times out (a second process on the GPU, a partition mode
+ * that places workgroups differently) voids the launch: the kernel poisons its outputs (maxima NaN -> mscores NaN, indices -1)
+ * and raises a flag in mapped host memory.  EVERY compute entry point of the context looks at that flag first (a host read,
+ * no synchronisation): if set it recovers (waits for the device, resets the exchange state, stops using the protocol that
+ * failed: XCD-local launches first, then the resident kernel altogether) and returns IMP_E_RESIDENT - the results of the
+ * earlier call are void, re-run the batch.
+ *  imp_resident_health: the same check on demand (after the caller synchronised, e.g. after its D2H copy of the matches);
+ *    *timeouts = voided launches so far, *level = 0 all protocols / 1 chip-wide exchange only / 2 streaming kernels only.
+ *  imp_set_resident_verify(1) (or IMP_OT_VERIFY=1): every resident launch is awaited inside the call and a voided one is
+ *    re-run there on the next protocol down - calls then always return valid results, at the price of one host
+ *    synchronisation per score.
+ *  imp_resident_status: raw flag after a device synchronisation (tests / bench). */
 int imp_resident_status(imp_ctx* ctx, int* status, int* used);
+int imp_resident_health(imp_ctx* ctx, int* timeouts, int* level);
+int imp_set_resident_verify(imp_ctx* ctx, int on);
 
 /* ---------------------------------------------------------------------------------------------------------------------------
  * SuperPoint front-end: nets/superpoint.py:97-232.  Its own handle (independent of imp_ctx);

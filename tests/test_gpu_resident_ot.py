@@ -181,3 +181,87 @@ def test_xcd_local_launch_agrees_with_the_chip_wide_one(n0, n1, B, T):
     assert loc._ensure_ctx().resident_status() == (False, True) and glob._ensure_ctx().resident_status() == (False, True)
     assert float(((a - b).abs() / b.abs().clamp_min(1.0)).max()) < 2e-6          # (dustbin entries are O(10..100): relative there)
     assert float((a[:, :-1, :-1] - b[:, :-1, :-1]).abs().max()) < 1e-6
+
+
+# ---- safety of the XCD-local protocols: a launch whose workgroups do not share the L2 they
+# think they share must never hand back plausible results with rc 0
+def _fake_placement_model():
+    cfg = eval_config(n_layers=2, sinkhorn_iterations=20)
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=5)
+    good = make_hip_model('GM', cfg, sd)
+    good._ensure_ctx()
+    os.environ['IMP_OT_FAKE_PLACEMENT'] = '1'            # LOCAL workgroups lie about the XCC they run on (ot_resident.hip)
+    try:
+        bad = make_hip_model('GM', cfg, sd)
+        bad._ensure_ctx()
+    finally:
+        del os.environ['IMP_OT_FAKE_PLACEMENT']
+    return good, bad
+
+
+def _pair_data(n0, n1, B, seed):
+    pair = synthetic.make_correlated_pair(n0, n1, seed=seed, batch=B)
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+    return data
+
+
+@pytest.mark.parametrize('n0,n1,B', [(1024, 1000, 1), (2048, 2048, 2)])      # XCD-local launch / two XCDs per pair
+def test_wrong_placement_is_an_error_at_the_next_call_never_silent_garbage(n0, n1, B):
+    from imp_release_amd._lib import ResidentSinkhornTimeout
+    good, bad = _fake_placement_model()
+    data = _pair_data(n0, n1, B, seed=n0 + B)
+    with torch.no_grad():
+        want = good.produce_matches(data, p=0.2, only_last=True)
+        got = bad.produce_matches(data, p=0.2, only_last=True)       # exchanges through L2s that are not shared: waits time out
+    torch.cuda.synchronize()
+    ms = got['mscores0'][-1].cpu()
+    assert torch.isnan(ms).any() and (got['indices0'][-1].cpu()[torch.isnan(ms)] == -1).all(), \
+        'a voided launch must poison its outputs (mscores NaN, indices -1)'
+    with pytest.raises(ResidentSinkhornTimeout):                      # the next entry point reports it (host word, no sync needed)
+        with torch.no_grad():
+            bad.produce_matches(data, p=0.2, only_last=True)
+    with torch.no_grad():                                             # ... and the context has recovered on the chip-wide exchange
+        again = bad.produce_matches(data, p=0.2, only_last=True)
+    torch.cuda.synchronize()
+    timeouts, level = bad._ensure_ctx().resident_health()
+    assert timeouts == 1 and level == 1
+    assert torch.equal(again['indices0'][-1].cpu(), want['indices0'][-1].cpu())
+    assert (again['mscores0'][-1].cpu() - want['mscores0'][-1].cpu()).abs().max().item() < 1e-5
+
+
+def test_wrong_placement_with_verification_is_repaired_inside_the_call():
+    good, bad = _fake_placement_model()
+    bad._ensure_ctx().set_resident_verify(True)
+    data = _pair_data(1024, 1024, 2, seed=11)
+    with torch.no_grad():
+        want = good.produce_matches(data, p=0.2, only_last=True)
+        got = bad.produce_matches(data, p=0.2, only_last=True)
+    torch.cuda.synchronize()
+    assert torch.equal(got['indices0'][-1].cpu(), want['indices0'][-1].cpu())
+    assert (got['mscores0'][-1].cpu() - want['mscores0'][-1].cpu()).abs().max().item() < 1e-5
+    assert bad._ensure_ctx().resident_health() == (1, 1)
+
+
+def test_the_loop_recomputes_a_voided_score():
+    """the iterative loops look at the health word after their one host synchronisation per iteration and recompute"""
+    from imp_release_amd.matching import matching_iterative
+    cfg = eval_config(n_layers=15, sinkhorn_iterations=20)
+    sd = synthetic.make_state_dict(cfg, 'DGNNS', seed=3)
+    good = make_hip_model('DGNNS', cfg, sd)
+    os.environ['IMP_OT_FAKE_PLACEMENT'] = '1'
+    try:
+        bad = make_hip_model('DGNNS', cfg, sd)
+        bad._ensure_ctx()
+    finally:
+        del os.environ['IMP_OT_FAKE_PLACEMENT']
+    pair = synthetic.make_correlated_pair(600, 580, seed=9)
+    def run(m):
+        data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+        data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+        data['pts0_cpu'], data['pts1_cpu'] = pair['keypoints0'][0], pair['keypoints1'][0]
+        with torch.no_grad():
+            return matching_iterative(data, m, 15, 0.1, 25, 1.0, {}, estimate_pose=None)
+    a, b = run(good), run(bad)
+    assert np.array_equal(a[0], b[0]) and np.abs(a[1] - b[1]).max() < 1e-5
+    assert bad._ensure_ctx().resident_health() == (1, 1)
