@@ -26,7 +26,7 @@ SYMBOLS = [
     'imp_last_error', 'imp_version', 'imp_create', 'imp_destroy', 'imp_load_tensor', 'imp_finalize_weights',
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
-    'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear',
+    'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear', 'imp_op_layer_gemm',
     'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_time_layer_gemm', 'imp_estimate_pose',
     'imp_sp_create', 'imp_sp_destroy', 'imp_sp_set_weight', 'imp_sp_finalize', 'imp_sp_detect', 'imp_sp_describe', 'imp_sp_dense', 'imp_sp_op_conv',
 ]
@@ -103,6 +103,7 @@ def lib():
     L.imp_gather_rows.argtypes = [P, I, I, I, I, P, P, P, P]
     L.imp_match_pair.argtypes = [P, I, I, I, P, P, P, P, P, P, F, F, F, I, I, F, P, P, P, P, P, P]
     L.imp_op_linear.argtypes = [P, I, I, I, P, P, P, P, P]
+    L.imp_op_layer_gemm.argtypes = [P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, P, I, P]
     L.imp_op_attention.argtypes = [P, I, I, I, I, P, P, P, P, P, P]
     L.imp_time_attention.argtypes = [P, I, I, I, C.POINTER(C.c_float), P]
     L.imp_time_sinkhorn.argtypes = [P, I, I, I, C.POINTER(C.c_float), P]
@@ -373,6 +374,23 @@ class Context:
         b = None if bias is None else _f32(bias, 'bias')
         self._check(self.L.imp_op_linear(self.handle, M, N, K, _ptr(x), _ptr(W), _ptr(b), _ptr(y), _stream(self.device)))
         return y
+
+    def op_layer_gemm(self, x, W, bias=None, x2=None, residual=None, stats_in=None, want_stats=False, W2=None, bias2=None, pass_split=1):
+        """csrc/gemm_wf.hip on its own (include/imp_hip.h imp_op_layer_gemm): x [B, M, ksplit] (+ x2 [B, M, K - ksplit]) -> y [B, M, N]
+        (+ (mean, rstd) [B, N, 2] of y, + the chained y2 [B, M, N2])"""
+        x, W = _f32(x, 'x'), _f32(W, 'W')
+        B, M, ks = x.shape
+        N, K = W.shape
+        dev = x.device
+        opt = lambda t, n: None if t is None else _f32(t, n)
+        x2, bias, residual, stats_in, W2, bias2 = opt(x2, 'x2'), opt(bias, 'bias'), opt(residual, 'residual'), opt(stats_in, 'stats_in'), opt(W2, 'W2'), opt(bias2, 'bias2')
+        y = torch.empty(B, M, N, device=dev, dtype=torch.float32)
+        so = torch.empty(B, N, 2, device=dev, dtype=torch.float32) if want_stats else None
+        N2 = 0 if W2 is None else W2.shape[0]
+        y2 = None if W2 is None else torch.empty(B, M, N2, device=dev, dtype=torch.float32)
+        self._check(self.L.imp_op_layer_gemm(self.handle, B, M, N, K, ks, _ptr(x), _ptr(x2), _ptr(W), _ptr(bias), _ptr(residual), _ptr(stats_in),
+                                             _ptr(y), _ptr(so), _ptr(W2), _ptr(bias2), N2, _ptr(y2), int(pass_split), _stream(self.device)))
+        return y, so, y2
 
     def op_attention(self, qkv_q, qkv_kv, key_mask=None, want_lse=True):
         qkv_q, qkv_kv = _f32(qkv_q, 'qkv_q'), _f32(qkv_kv, 'qkv_kv')

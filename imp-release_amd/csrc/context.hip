@@ -94,6 +94,9 @@ struct imp_ctx {
     float* xhalf = nullptr;  // resident Sinkhorn, two XCDs per pair: the half sums the XCDs swap
     int ot_hier = 1;         // two-XCDs-per-pair resident launches (hierarchical column sums) when a pair fits 64 CUs and B <= 4 (IMP_OT_HIER=0 disables)
     int ot_local = 1;        // XCD-local resident Sinkhorn launches when a pair fits one XCD (IMP_OT_LOCAL=0 disables)
+    unsigned* stat_cnt = nullptr;   // [cap_b][2] tickets of the statistics merge inside the MLP0 launch (gemm_wf.hip)
+    int wf_chain = 1;        // IMP_WF_CHAIN=0: never compute the next layer's projection inside the MLP3 launch
+    long wf_chain_min_tiles = 160, wf_max_tiles = 640, wf_proj_max_tiles = 40;     // IMP_WF_CHAIN_MIN / IMP_WF_MAX / IMP_WF_PROJ_MAX
     int use_wf = 1;          // weight-fragment GEMMs (gemm_wf.hip) for the layer convolutions when f16x3, D = 256, relu + InstanceNorm; IMP_GEMM_WF=0 disables
     float* attn_split_ws = nullptr;        // key-split scratch of the attention kernel (grown on demand, allocs_x)
     unsigned* attn_split_cnt = nullptr;
@@ -275,6 +278,11 @@ int ensure_workspace(imp_ctx* c, int batch, int n) {
         rc = dev_alloc(c, c->allocs_ws, &c->colsum[k], B * IMP_NUM_HEADS * N);
         if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->amass[k], B * N);
     }
+    if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->stat_cnt, B * 2 + 2);
+    if (!rc) {
+        HIP_TRY(hipMemset(c->stat_cnt, 0, (B * 2 + 2) * sizeof(unsigned)));
+        HIP_TRY(hipDeviceSynchronize());              // the clear runs on the NULL stream, which the callers' streams do not wait for
+    }
     if (rc) { free_pool(c->allocs_ws); return rc; }
     c->cap_b = batch;
     c->cap_n = n;
@@ -408,30 +416,36 @@ int wf_pass_split(const imp_ctx* c, long tiles, int N) {
     return best;
 }
 
+// One GNN layer (nets/layers.py:139-149 / :182-218) on both images.
+//   proj_done: this layer's q|k|v (or value) projection was already produced by the previous layer's chained launch
+//   chain_li:  >= 0: the caller will run layer chain_li next ON THE OUTPUT OF THIS CALL, unmodified and with no pooling in between:
+//              its projection may be computed here, in the epilogue tile of this layer's last convolution (gemm_wf.hip CHAIN);
+//              *chained reports whether it was
 int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const desc[2], float* const out[2],
-              const uint8_t* const kmask[2], hipStream_t st) {
+              const uint8_t* const kmask[2], hipStream_t st, bool proj_done = false, int chain_li = -1, bool* chained = nullptr) {
     const imp_config& cfg = c->cfg;
     const GnnLayer& L = c->layers[li];
     const int D = c->D, kind = L.cross ? 1 : 0;
     AttnCache& cache = c->cache[kind];
     float* const* qkv = c->qkv[kind];
+    if (chained) *chained = false;
     if (L.shared) {
         if (!cache.valid || cache.batch != batch || cache.n[0] != n[0] || cache.n[1] != n[1])
             return fail(IMP_E_STATE, "attention-sharing layer " + std::to_string(li) +
                                          " called without a matching cached attention of the same kind/shape");
     }
     // weight-fragment GEMMs: the default for the f16x3 arithmetic (gemm_wf.hip)
-    // (64-row tiles with the whole K in LDS; small launches deal the column passes of a tile to several workgroups, wf_pass_split.
-    // Measured against gemm_f32.hip, MLP0 / MLP3: 1.06x / 1.32x at B = 4, N = 2048 (256 tiles), 1.14x / 1.15x at B = 1, N = 2048,
-    // 1.09x / 1.17x at B = 1, N = 1024, 1.06x / 0.99x at B = 8; the K = 256 projection: 1.21x at B = 1, N = 1024 (32 tiles), 0.91-0.97x
-    // from 64 tiles up - it stays on gemm_f32.hip there.  IMP_GEMM_WF: 0 never, 1 by this rule (default), 2 always incl. the projection)
+    // (64-row tiles with the whole K in LDS, 8 waves in two groups that alternate between K loop and epilogue; small launches deal
+    // the column passes of a tile to several workgroups, wf_pass_split.  IMP_GEMM_WF: 0 never, 1 by this rule (default), 2 always)
     const long wf_tiles = (long)batch * ((n[0] + 63) / 64 + (n[1] + 63) / 64);
-    const bool wf = c->prec == 1 && c->use_wf && (c->use_wf > 1 || wf_tiles <= 640);
-    const bool wf_proj = wf && (c->use_wf > 1 || wf_tiles <= 40);
+    const bool wf = c->prec == 1 && c->use_wf && (c->use_wf > 1 || wf_tiles <= c->wf_max_tiles);
+    const bool wf_proj = wf && (c->use_wf > 1 || wf_tiles <= c->wf_proj_max_tiles);
     const bool wf_mlp = wf && c->fuse_merge && cfg.norm_fn == IMP_NORM_IN && cfg.ac_fn == IMP_ACT_RELU && L.mlp0f_wf && L.mlp3_wf;
     // 1. projections: q|k|v of both images in one GEMM (the layer's weights are shared by the two images);
     //    a sharing layer only refreshes the value slot and keeps last iteration's q,k (== its probabilities)
-if (wf_proj && L.proj_wf) {
+    if (proj_done) {
+        // (already in qkv[kind]: written by the chained launch of the previous layer)
+    } else if (wf_proj && L.proj_wf) {
         WfParams p;
         memset(&p, 0, sizeof p);
         p.K = D; p.ksplit = D; p.N = L.proj.out; p.nside = 2;
@@ -491,7 +505,7 @@ if (wf_proj && L.proj_wf) {
     const bool in_norm = cfg.norm_fn == IMP_NORM_IN;
     const int maxn = n[0] > n[1] ? n[0] : n[1];
     int bm0 = gemm_stats_rows(maxn, 2 * D, 2 * batch);      // rows per statistics block of the MLP0 launch
-if (wf_mlp) {
+    if (wf_mlp) {
         WfParams p;
         memset(&p, 0, sizeof p);
         p.K = 2 * D; p.ksplit = D; p.N = 2 * D; p.nside = 2;
@@ -500,10 +514,11 @@ if (wf_mlp) {
             g.A = desc[s]; g.A2 = c->attn_out[s]; g.C = c->hid[s]; g.M = n[s];
             g.sA_b = (long)n[s] * D; g.sA2_b = (long)n[s] * D; g.sC_b = (long)n[s] * 2 * D;
             g.out_stats = c->stats[s];
+            g.fin_stats = c->nstat[s];                      // (mean, rstd) by the last workgroup to arrive: no finalize launch
         }
+        p.stat_cnt = c->stat_cnt; p.norm_eps = 1e-3f;
         p.Wf_ = L.mlp0f_wf; p.bias = M0.b; p.lda = D; p.lda2 = D; p.ldc = 2 * D;
         p.pass_split = wf_pass_split(c, wf_tiles, p.N);
-        bm0 = gemm_wf_stats_rows();
         HIP_TRY(launch_gemm_wf(p, batch, st));
     } else {
         GemmParams p = gemm_defaults(c, 2 * D);
@@ -517,17 +532,14 @@ if (wf_mlp) {
         if (in_norm) p.flags |= GEMM_EPI_STATS;
         p.bias = M0.b; p.lda = D; p.lda2 = D; p.ldw = 2 * D; p.ldc = 2 * D;
         HIP_TRY(launch_gemm_f32(p, batch, st));
+        if (in_norm) {
+            StatsSide ss[2];
+            for (int s = 0; s < 2; ++s) ss[s] = StatsSide{c->stats[s], c->nstat[s], (n[s] + bm0 - 1) / bm0, n[s], bm0};
+            HIP_TRY(launch_stats_finalize(ss, 2, batch, 2 * D, 1e-3f, st));
+        }
     }
-    // 5. norm + activation while staging, conv 3, bias, residual add -> new descriptors
-    // EXPERIMENT (IMP_WF_FUSE_STATS=1, off): the weight-fragment MLP3 kernel can merge the per-block statistics in its own prologue
-    // (one launch less per layer); measured SLOWER - every workgroup repeats T dependent loads per channel: configs[1] 1.61 -> 1.74 ms
-    static const bool fuse_stats = [] { const char* e = getenv("IMP_WF_FUSE_STATS"); return e && atoi(e) != 0; }();
-    if (in_norm && !(wf_mlp && fuse_stats)) {
-        StatsSide ss[2];
-        for (int s = 0; s < 2; ++s) ss[s] = StatsSide{c->stats[s], c->nstat[s], (n[s] + bm0 - 1) / bm0, n[s], bm0};
-        HIP_TRY(launch_stats_finalize(ss, 2, batch, 2 * D, 1e-3f, st));
-    }
-if (wf_mlp) {
+    // 5. norm + activation while staging, conv 3, bias, residual add -> new descriptors; CHAIN: + the next layer's projection
+    if (wf_mlp) {
         WfParams p;
         memset(&p, 0, sizeof p);
         p.K = 2 * D; p.ksplit = 2 * D; p.N = D; p.nside = 2;
@@ -535,12 +547,24 @@ if (wf_mlp) {
             WfSide& g = p.side[s];
             g.A = c->hid[s]; g.C = out[s]; g.R = desc[s]; g.M = n[s];
             g.sA_b = (long)n[s] * 2 * D; g.sC_b = (long)n[s] * D; g.sR_b = (long)n[s] * D;
-            if (fuse_stats) { g.stat_part = c->stats[s]; g.stat_tiles = (n[s] + bm0 - 1) / bm0; }
-            else g.in_stats = c->nstat[s];
+            g.in_stats = c->nstat[s];
         }
-        p.stat_tile_rows = bm0; p.norm_eps = 1e-3f;
+        p.norm_eps = 1e-3f;
         p.Wf_ = L.mlp3_wf; p.bias = L.mlp3.b; p.lda = 2 * D; p.ldc = D; p.ldr = D;
         p.pass_split = wf_pass_split(c, wf_tiles, p.N);
+        const bool can_chain = chain_li >= 0 && chain_li < (int)c->layers.size() && c->wf_chain && D == 256 && wf_tiles >= c->wf_chain_min_tiles &&
+                               c->layers[chain_li].proj_wf && !kmask[0] && !kmask[1];
+        if (can_chain) {
+            const GnnLayer& NL = c->layers[chain_li];
+            float* const* nqkv = c->qkv[NL.cross ? 1 : 0];
+            for (int s = 0; s < 2; ++s) {
+                p.side[s].C2 = NL.shared ? nqkv[s] + 2 * D : nqkv[s];
+                p.side[s].sC2_b = (long)n[s] * 3 * D;
+            }
+            p.Wf2_ = NL.proj_wf; p.bias2 = NL.proj.b; p.N2 = NL.proj.out; p.ldc2 = 3 * D;
+            p.pass_split = 1;
+            if (chained) *chained = true;
+        }
         HIP_TRY(launch_gemm_wf(p, batch, st));
     } else {
         GemmParams p = gemm_defaults(c, 2 * D);
@@ -838,6 +862,10 @@ int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     { const char* e = getenv("IMP_OT_VERIFY"); c->ot_verify = (e && atoi(e) != 0) ? 1 : 0; }
     { const char* e = getenv("IMP_OT_FAKE_PLACEMENT"); c->ot_fake = (e && atoi(e) != 0) ? 1 : 0; }
     { const char* e = getenv("IMP_GEMM_WF"); c->use_wf = e ? atoi(e) : 1; }     // 0 off, 1 default (large launches), 2 always
+    { const char* e = getenv("IMP_WF_CHAIN"); c->wf_chain = e ? atoi(e) : 1; }
+    { const char* e = getenv("IMP_WF_CHAIN_MIN"); if (e) c->wf_chain_min_tiles = atol(e); }
+    { const char* e = getenv("IMP_WF_MAX"); if (e) c->wf_max_tiles = atol(e); }
+    { const char* e = getenv("IMP_WF_PROJ_MAX"); if (e) c->wf_proj_max_tiles = atol(e); }
     {   // CU count: sizes the resident Sinkhorn launches and the column-pass split of small weight-fragment GEMM launches
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) {
@@ -1211,7 +1239,12 @@ int imp_match_pair(imp_ctx* c, int batch, int n0, int n1, const float* kpts0, co
     if ((rc = run_kenc(c, batch, n, kp, sc, width, height, de, dw, st))) return rc;   // desc + enc (nets/gm.py:177-178)
     const uint8_t* nomask[2] = {nullptr, nullptr};
     const float* dr[2] = {c->descw[0], c->descw[1]};
-    for (int li = 0; li < c->cfg.n_gnn_layers && !rc; ++li) rc = run_layer(c, li, batch, n, dr, dw, nomask, st);
+    bool proj_done = false;                                // inside this call the layers chain: layer i's last launch also projects for layer i + 1
+    for (int li = 0; li < c->cfg.n_gnn_layers && !rc; ++li) {
+        bool chained = false;
+        rc = run_layer(c, li, batch, n, dr, dw, nomask, st, proj_done, li + 1 < c->cfg.n_gnn_layers ? li + 1 : -1, &chained);
+        proj_done = chained;
+    }
     if (rc) return rc;
     if ((rc = run_distance(c, c->cfg.n_layers - 1, batch, n, dr, c->dist, st))) return rc;
     OtBuffers o;
@@ -1233,6 +1266,59 @@ int imp_op_linear(imp_ctx* c, int M, int N, int K, const float* x, const float* 
     g.A = x; g.W = W; g.C = y; g.M = M; g.N = N;
     p.bias = bias; p.lda = K; p.ldw = K; p.ldc = N;
     HIP_TRY(launch_gemm_f32(p, 1, S(stream)));
+    return IMP_OK;
+}
+
+int imp_op_layer_gemm(imp_ctx* c, int B, int M, int N, int K, int ksplit, const float* x, const float* x2, const float* W, const float* bias,
+                      const float* residual, const float* stats_in, float* y, float* stats_out, const float* W2, const float* bias2, int N2,
+                      float* y2, int pass_split, void* stream) {
+    if (!c || !x || !W || !y || B < 1 || M < 1 || !gemm_wf_supported(K, N) || ksplit < 0 || ksplit > K || (ksplit < K && !x2) || ksplit % 4)
+        return fail(IMP_E_ARG, "imp_op_layer_gemm: bad argument (K 256 / 512, N % 128 == 0)");
+    if (W2 && (!y2 || !bias2 || N != 256 || K != 512 || !stats_in || stats_out || !gemm_wf_supported(256, N2) || N2 < 256))
+        return fail(IMP_E_ARG, "imp_op_layer_gemm: the chained projection needs K = 512, N = 256, stats_in, N2 % 128 == 0, N2 >= 256");
+    if (stats_out && (stats_in || N > 512)) return fail(IMP_E_ARG, "imp_op_layer_gemm: stats_out excludes stats_in; N <= 512");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = S(stream);
+    HIP_TRY(hipStreamSynchronize(st));
+    auto pack = [&](const float* Wd, int n, int k, _Float16** out) -> int {
+        std::vector<float> h((size_t)n * k);
+        HIP_TRY(hipMemcpy(h.data(), Wd, h.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<_Float16> f((size_t)n * k * 2);
+        wf_pack(h.data(), n, k, f.data());
+        HIP_TRY(hipMalloc(out, f.size() * 2));
+        HIP_TRY(hipMemcpy(*out, f.data(), f.size() * 2, hipMemcpyHostToDevice));
+        return IMP_OK;
+    };
+    _Float16 *wf = nullptr, *wf2 = nullptr;
+    float* part = nullptr;
+    unsigned* cnt = nullptr;
+    int rc = pack(W, N, K, &wf);
+    if (!rc && W2) rc = pack(W2, N2, 256, &wf2);
+    if (rc) return rc;
+    const int tiles = (M + 63) / 64;
+    if (stats_out) {
+        HIP_TRY(hipMalloc(&part, (size_t)B * tiles * N * 2 * sizeof(float)));
+        HIP_TRY(hipMalloc(&cnt, (size_t)B * sizeof(unsigned)));
+        HIP_TRY(hipMemset(cnt, 0, (size_t)B * sizeof(unsigned)));
+        HIP_TRY(hipDeviceSynchronize());
+    }
+    WfParams p;
+    memset(&p, 0, sizeof p);
+    p.K = K; p.ksplit = ksplit; p.N = N; p.nside = 1;
+    WfSide& g = p.side[0];
+    g.A = x; g.A2 = ksplit < K ? x2 : nullptr; g.C = y; g.R = residual; g.M = M;
+    g.sA_b = (long)M * ksplit; g.sA2_b = (long)M * (K - ksplit); g.sC_b = (long)M * N; g.sR_b = (long)M * N;
+    g.in_stats = stats_in; g.out_stats = part; g.fin_stats = stats_out;
+    g.C2 = y2; g.sC2_b = (long)M * N2;
+    p.Wf_ = wf; p.bias = bias; p.lda = ksplit; p.lda2 = K - ksplit; p.ldc = N; p.ldr = N;
+    p.norm_eps = 1e-3f; p.stat_cnt = cnt;
+    p.Wf2_ = wf2; p.bias2 = bias2; p.N2 = N2; p.ldc2 = N2;
+    p.pass_split = pass_split > 1 ? pass_split : 1;
+    const hipError_t e = launch_gemm_wf(p, B, st);
+    const hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipFree(wf); (void)hipFree(wf2); (void)hipFree(part); (void)hipFree(cnt);
+    HIP_TRY(e);
+    HIP_TRY(e2);
     return IMP_OK;
 }
 
@@ -1349,12 +1435,13 @@ int imp_time_sinkhorn(imp_ctx* c, int batch, int n, int iterations, float* ms, v
     return IMP_OK;
 }
 
-// probe: average time of ONE of the three layer GEMMs of layer 0 on the context's workspace (which: 0 QKV, 1 MLP0, 2 MLP3),
+// probe: average time of ONE of the three layer GEMMs of layer 0 on the context's workspace (which: 0 QKV, 1 MLP0, 2 MLP3, 3 MLP3 chained with QKV),
 // dbg == -1: the gemm_f32.hip kernel; dbg <= -2: gemm_wf.hip with its probe switches (-dbg - 2)
 int imp_time_layer_gemm(imp_ctx* c, int batch, int n, int which, int dbg, int reps, float* ms, void* stream) {
     int rc = check_ready(c, batch, n, n);
     if (rc) return rc;
-    if (!ms || reps < 1 || which < 0 || which > 2 || c->layers.empty()) return fail(IMP_E_ARG, "imp_time_layer_gemm: bad argument");
+    if (!ms || reps < 1 || which < 0 || which > 3 || c->layers.empty()) return fail(IMP_E_ARG, "imp_time_layer_gemm: bad argument");
+    if (which == 3 && dbg > -2) return fail(IMP_E_ARG, "imp_time_layer_gemm: which = 3 (MLP3 chained with the projection) exists only in gemm_wf.hip (dbg <= -2)");
     hipStream_t st = S(stream);
     const int D = c->D;
     const GnnLayer& L = c->layers[0];
@@ -1371,16 +1458,19 @@ int imp_time_layer_gemm(imp_ctx* c, int batch, int n, int which, int dbg, int re
                 WfSide& g = p.side[s];
                 g.M = n;
                 if (which == 0) { g.A = c->descw[s]; g.C = c->qkv[0][s]; g.sA_b = (long)n * D; g.sC_b = (long)n * 3 * D; }
-                if (which == 1) { g.A = c->descw[s]; g.A2 = c->attn_out[s]; g.C = c->hid[s]; g.sA_b = g.sA2_b = (long)n * D; g.sC_b = (long)n * 2 * D; g.out_stats = c->stats[s]; }
-                if (which == 2) { g.A = c->hid[s]; g.C = c->mdesc[s]; g.R = c->descw[s]; g.sA_b = (long)n * 2 * D; g.sC_b = (long)n * D; g.sR_b = (long)n * D;
+                if (which == 1) { g.A = c->descw[s]; g.A2 = c->attn_out[s]; g.C = c->hid[s]; g.sA_b = g.sA2_b = (long)n * D; g.sC_b = (long)n * 2 * D; g.out_stats = c->stats[s];
+                                  g.fin_stats = c->nstat[s]; }
+                if (which >= 2) { g.A = c->hid[s]; g.C = c->mdesc[s]; g.R = c->descw[s]; g.sA_b = (long)n * 2 * D; g.sC_b = (long)n * D; g.sR_b = (long)n * D;
                                   g.in_stats = c->nstat[s]; }
+                if (which == 3) { g.C2 = c->qkv[0][s]; g.sC2_b = (long)n * 3 * D; }
             }
-            p.stat_tile_rows = 64; p.norm_eps = 1e-3f;
+            p.norm_eps = 1e-3f; p.stat_cnt = c->stat_cnt;
             if (which == 0) { p.Wf_ = L.proj_wf; p.N = 3 * D; p.bias = L.proj.b; p.lda = D; p.ldc = 3 * D; }
             if (which == 1) { p.Wf_ = L.mlp0f_wf; p.N = 2 * D; p.bias = L.mlp0f.b; p.lda = p.lda2 = D; p.ldc = 2 * D; }
-            if (which == 2) { p.Wf_ = L.mlp3_wf; p.N = D; p.bias = L.mlp3.b; p.lda = 2 * D; p.ldc = D; p.ldr = D; }
-            if (!p.Wf_) return hipErrorInvalidValue;
-            p.pass_split = wf_pass_split(c, (long)batch * 2 * ((n + 63) / 64), p.N);
+            if (which >= 2) { p.Wf_ = L.mlp3_wf; p.N = D; p.bias = L.mlp3.b; p.lda = 2 * D; p.ldc = D; p.ldr = D; }
+            if (which == 3) { p.Wf2_ = L.proj_wf; p.bias2 = L.proj.b; p.N2 = L.proj.out; p.ldc2 = 3 * D; }
+            if (!p.Wf_ || (which == 3 && !p.Wf2_)) return hipErrorInvalidValue;
+            p.pass_split = which == 3 ? 1 : wf_pass_split(c, (long)batch * 2 * ((n + 63) / 64), p.N);
             p.dbg = -dbg - 2;
             return launch_gemm_wf(p, batch, st);
         }

@@ -1,22 +1,36 @@
-// Weight-fragment GEMM for the three 1x1 convolutions of a GNN layer (nets/layers.py:119-120 q|k|v, :145-149 / :210-218 the MLP):
+// Weight-fragment GEMMs for the 1x1 convolutions of a GNN layer (nets/layers.py:119-120 q|k|v, :145-149 / :210-218 the MLP):
 //
 //   C[M x N] = epilogue( prologue(A)[M x K] . W[N x K]^T ),   K = 256 or 512, N a multiple of 128, W static
 //
-// What is different from gemm_f32.hip (which converts and stages BOTH operands per K-tile behind two barriers): the weights are
-// split into f16 hi / lo halves and re-ordered into MFMA fragment order ONCE, when they are loaded (`wf_pack`), so a wave
-// fetches a fragment as one coalesced 1-KB load from L2 and the weights never touch LDS; the activations of a 64-row tile are
-// converted ONCE into hi / lo half planes covering the whole K extent (67.6 KB for K = 256: 2 workgroups per CU) and every
-// column pass of the tile re-reads them from LDS.  Between the staging barrier and the end of the workgroup there is no barrier:
-// 4 waves, each 64 rows x 32 columns of a 128-column pass, K loop software-pipelined by hand exactly like csrc/superpoint.hip
-// (A fragments one k-step ahead, B fragments four k-steps ahead).  Arithmetic: split-half f16x3, products lo.hi + hi.lo + hi.hi
-// in that order, fp32 accumulate - the scheme of gemm_f32.hip (PREC = 1).
+// and, CHAIN, a second GEMM on the tile the first one just produced (the NEXT layer's projection of the updated descriptors):
+//
+//   X' = X + mlp.3(relu(norm(H)))            [64 rows x 256]  -> memory AND, as split halves, back into LDS
+//   Q|K|V = X' . Wproj^T + b                 [64 rows x 768]  (or the value projection alone, 256 columns, for a sharing layer)
+//
+// Structure: the weights are split into f16 hi / lo halves and re-ordered into MFMA fragment order ONCE, when they are loaded
+// (`wf_pack`), so a wave fetches a fragment as one coalesced 1-KB load from L2 and the weights never touch LDS; the activations
+// of a 64-row tile are converted ONCE into hi / lo half planes covering the whole K extent and every column pass of the tile
+// re-reads them from LDS.  Arithmetic: split-half f16x3, products lo.hi + hi.lo + hi.hi in that order, fp32 accumulate - the
+// scheme of gemm_f32.hip (PREC = 1).
+//
+// Round 3: a workgroup is 8 waves = TWO groups of 4 (one wave of each group per SIMD).  A column pass (128 columns: 4 waves x
+// 64 rows x 32 columns) belongs to one group and the groups take alternate passes, so while a wave of one group runs its
+// epilogue (LDS transposition, bias / residual, 16-byte global stores - no MFMA) its SIMD partner of the other group streams
+// the MFMAs of ITS pass: the 4-wave kernel of round 2 left the matrix pipe idle for a third of a workgroup's life (K loop 3.3 k
+// cycles, epilogue 1.8 k per pass, one after the other; interleaving the stores into the same wave's K loop doubled its time -
+// stores and weight loads share one in-order counter).  Group 0 runs its K loops at raised priority, which keeps the two groups
+// out of phase.  Staging is shared by all 512 threads.
 //
 // LDS plane: row pitch = 2 K + 16 bytes = 1 (mod 16) sixteen-byte slots, so the 16 rows of a ds_read_b128 lane group
-// ({0-3,12-15,20-27} ...) fall into 16 distinct slots.
+// ({0-3,12-15,20-27} ...) fall into 16 distinct slots.  Epilogue: wave-private transposition of 16 rows x 32 columns at a time
+// (row pitch 144 bytes): whatever the accumulator layout, the tile is read back row-major - lane = 4 consecutive columns of one
+// of 8 rows - so bias and residual are coalesced 16-byte loads and every store instruction writes 8 FULL 128-byte lines.
 //
-// Two epilogue shapes: SWAP = 1 (weights as first MFMA operand: a register holds 4 consecutive columns of the lane's row, 16-byte
-// stores, bias and residual as 16-byte loads) and SWAP = 0 (a lane holds one column of 32 rows: the per-block InstanceNorm
-// statistics (sum, M2 about the block mean) of the MLP's first convolution are register reductions, as in gemm_f32.hip).
+// Two accumulator layouts: SWAP = 1 (weights as first MFMA operand: a register holds 4 consecutive columns of the lane's row)
+// and SWAP = 0 (a lane holds one column of 32 rows: the per-block InstanceNorm statistics (sum, M2 about the block mean) of
+// the MLP's first convolution are register reductions).  STATS launches finish with a ticket: the LAST workgroup of a
+// (pair, image) to arrive merges the per-block statistics into (mean, rstd) - Chan's formula in fp64, the arithmetic and
+// order of stats_finalize_kernel (gemm_f32.hip) - so the separate finalize launch of round 2 is gone.
 #include "imp_kernels.h"
 #include <cstdio>
 #include <cstdlib>
@@ -28,21 +42,207 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef WF_PRIO
+#define WF_PRIO 1               // group 0 runs its K loops at raised wave priority (A/B: tools/build_variant.sh x -DWF_PRIO=0)
+#endif
+
 namespace {
 
 constexpr int WF_TM = 64;       // rows of a tile
+constexpr int WF_TP = 144;      // row pitch of the transposition buffers (bytes)
+constexpr int WF_TROWS = 16;    // rows per transposition
+constexpr int WF_TBUF = WF_TROWS * WF_TP;   // bytes per wave
+constexpr int AUX_SC1 = 16;     // agent-scope coherent access (write-through store / cache-bypassing load)
 
-#ifdef WF_PROFILE   // tools/build_variant.sh -DWF_PROFILE: cycle stamps of wave 0 of every workgroup: staging, K loops, epilogues, total
-__device__ unsigned long long wf_prof[4096][4];
+struct WfLane { int lane, half, w4, grp; };
+
+#ifdef WF_PROFILE   // tools/build_variant.sh prof -DWF_PROFILE: cycle stamps of wave 0 of each group of every workgroup (staging, K loops, epilogues, total)
+__device__ unsigned long long wf_prof[2048][2][4];
+#define WF_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#else
+#define WF_T(x)
 #endif
 
-template <int K, int PRO, int SWAP, int STATS>
-__global__ __launch_bounds__(256) void gemm_wf_kernel(const WfParams p, int row_tiles) {
+// K loop of one column pass: acc[i] (i = rows 32 i .. 32 i + 31 of the tile) += A . W^T over KK, A fragments from the LDS planes
+// one k-step ahead, weight fragments four k-steps ahead (bh / bl hold the first four k-steps on entry and the first four of
+// `wfollow` on exit)
+template <int KK, int SWAP>
+__device__ __forceinline__ void wf_kloop(f32x16 (&acc)[2], const unsigned char* planes, const int (&aoff)[2], const u32x4* wp, const u32x4* wfollow,
+                                         u32x4 (&bh)[4], u32x4 (&bl)[4]) {
+    constexpr int PLANE = WF_TM * (2 * KK + 16);
+    constexpr int NS = KK / 16;
+    f16x8 fah[2][2], fal[2][2];
+    auto load_frag = [&](int st, int fb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fah[fb][i] = *reinterpret_cast<const f16x8*>(planes + aoff[i] + st * 32);
+            fal[fb][i] = *reinterpret_cast<const f16x8*>(planes + PLANE + aoff[i] + st * 32);
+        }
+    };
+    load_frag(0, 0);
+    u32x4 nh[4], nl[4];
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+        const int c = st & 3;
+        if (st + 1 < NS) load_frag(st + 1, (st + 1) & 1);
+        if (c == 0) {
+            const u32x4* wnext = st == NS - 4 ? wfollow : wp + 512;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) { nh[cc] = wnext[cc * 128]; nl[cc] = wnext[cc * 128 + 64]; }
+            wp = wnext;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const f16x8 wh = __builtin_bit_cast(f16x8, bh[c]), wl = __builtin_bit_cast(f16x8, bl[c]);
+        if (SWAP) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fal[st & 1][i], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, fah[st & 1][i], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fah[st & 1][i], acc[i], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[st & 1][i], wh, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[st & 1][i], wl, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[st & 1][i], wh, acc[i], 0, 0, 0);
+        }
+        if (c == 3) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) { bh[cc] = nh[cc]; bl[cc] = nl[cc]; }
+        }
+    }
+}
+
+// the residual of a wave's 64 x 32 output block in the read-back layout of the epilogue (requested before the K loop)
+__device__ __forceinline__ void wf_load_residual(f32x4 (&rres)[2][4], const float* Rb, int ldr, int row0, int M, int cb, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = min(row0 + 32 * i + 8 * j + (lane >> 3), M - 1);
+            rres[i][j] = *reinterpret_cast<const f32x4*>(Rb + (long)row * ldr + cb + (lane & 7) * 4);
+        }
+}
+
+// Epilogue of one column pass of one wave: accumulators -> (+ bias, + residual) -> C rows; optionally the same values as
+// split halves into the LDS planes of the chained GEMM (TOPLANES; `pl2` = plane base, column cb of a 256-wide tile).
+template <int SWAP, int TOPLANES>
+__device__ __forceinline__ void wf_epilogue(const f32x16 (&acc)[2], unsigned char* tbuf, const float* bias, const f32x4 (&rres)[2][4], bool has_res,
+                                            float* Cb, int ldc, int row0, int M, int cb, const WfLane& L, int dbg, unsigned char* pl2) {
+    constexpr int PITCH2 = 2 * 256 + 16, PLANE2 = WF_TM * PITCH2;
+    const int lane = L.lane, half = L.half;
+    const int c4 = (lane & 7) * 4;
+    const f32x4 bias4 = (bias && !(dbg & 4)) ? *reinterpret_cast<const f32x4*>(bias + cb + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {                            // rows 32 i + 16 c .. + 15 of the tile
+            if (SWAP) {                                          // register r = column 4 half + (r & 3) + 8 (r >> 2) of row lane % 32
+                if (((lane >> 4) & 1) == c) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * g + e];
+                        *reinterpret_cast<f32x4*>(tbuf + (lane & 15) * WF_TP + (4 * half + 8 * g) * 4) = v;
+                    }
+                }
+            } else {                                             // register r = row 4 half + (r & 3) + 8 (r >> 2) of column lane % 32
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr)
+                    *reinterpret_cast<float*>(tbuf + (4 * half + (rr & 3) + 8 * (rr >> 2)) * WF_TP + (lane & 31) * 4) = acc[i][8 * c + rr];
+            }
+            // lanes exchange values through the wave's LDS buffer: wave-scope release / acquire around it (no hardware cost: LDS
+            // operations of a wave execute in order; without it the compiler may keep a lane's EARLIER read of the same address
+            // when that lane itself wrote nothing in between - it did, when only half of the lanes wrote the chunk)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int lr = 8 * j + (lane >> 3);
+                const int trow = 32 * i + 16 * c + lr;           // row of the tile
+                const int row = row0 + trow;
+                f32x4 v = *reinterpret_cast<const f32x4*>(tbuf + lr * WF_TP + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bias4[e];
+                if (has_res && !(dbg & 4)) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += rres[i][2 * c + j][e];
+                }
+                if (row < M && (!(dbg & 1) || v[0] == 123.456f)) *reinterpret_cast<f32x4*>(Cb + (long)row * ldc + cb + c4) = v;
+                if (TOPLANES) {                                  // (rows past M repeat row M - 1: they feed only rows that are never stored)
+                    u32x2 hi, lo;
+                    unsigned a, d;
+                    imp_split2(v[0], v[1], a, d); hi[0] = a; lo[0] = d;
+                    imp_split2(v[2], v[3], a, d); hi[1] = a; lo[1] = d;
+                    unsigned char* dst = pl2 + trow * PITCH2 + (cb + c4) * 2;
+                    *reinterpret_cast<u32x2*>(dst) = hi;
+                    *reinterpret_cast<u32x2*>(dst + PLANE2) = lo;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the reads above precede the next chunk's writes of other lanes
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+}
+
+// per-block InstanceNorm statistics of one column pass (SWAP = 0 layout): (sum, M2 about the block mean) of the 64-row block for
+// the lane's column, on the values as stored (bias included); both halves of the wave return the same pair
+__device__ __forceinline__ void wf_block_stats(const f32x16 (&acc)[2], const float* bias, int row0, int M, int cb, const WfLane& L, float& sum_out,
+                                               float& m2_out) {
+    const int lane = L.lane, half = L.half;
+    const int col = cb + (lane & 31);
+    const float bvs = bias ? bias[col] : 0.f;
+    const int nvalid = min(WF_TM, M - row0);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + 32 * i + 4 * half + (r & 3) + 8 * (r >> 2);
+            if (row < M) sum += acc[i][r] + bvs;
+        }
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum / (float)nvalid;
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + 32 * i + 4 * half + (r & 3) + 8 * (r >> 2);
+            const float d = (acc[i][r] + bvs) - mean;
+            if (row < M) m2 = fmaf(d, d, m2);
+        }
+    m2 += __shfl_xor(m2, 32);
+    sum_out = sum;
+    m2_out = m2;
+}
+// ... written through to memory (the finalizing workgroup may sit on another XCD).  Called ONCE per wave, after its last pass: a
+// write-through store is acknowledged only by the memory side (microseconds), and a wave's loads and stores retire in order - a
+// statistics store between two passes stalled the next pass's first wait for weights (measured: +10 us per launch)
+__device__ __forceinline__ void wf_store_stats(float* out_stats, int b, int rtile, int M, int N, int cb, const WfLane& L, float sum, float m2) {
+    if (L.half == 0) {
+        const int tiles_side = (M + WF_TM - 1) / WF_TM;            // the buffer is [b][this side's blocks][N][2]
+        float* o = out_stats + (((long)b * tiles_side + rtile) * N + cb) * 2;      // wave-uniform base, lane = column
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)o, 0, 32u * 8u, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(sum), __float_as_uint(m2)}, rs, (L.lane & 31) * 8, 0, AUX_SC1);
+    }
+}
+
+template <int K, int PRO, int SWAP, int STATS, int CHAIN>
+__global__ __launch_bounds__(512) void gemm_wf_kernel(const WfParams p, int row_tiles) {
     constexpr int PITCH = 2 * K + 16;               // bytes per row of one half plane
     constexpr int PLANE = WF_TM * PITCH;
     constexpr int NS = K / 16;                      // k-steps
     extern __shared__ __attribute__((aligned(16))) unsigned char wf_smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int tid = threadIdx.x;
+    WfLane L;
+    L.lane = tid & 63; L.half = L.lane >> 5; L.w4 = (tid >> 6) & 3; L.grp = tid >> 8;
+    const int lane = L.lane, half = L.half, w4 = L.w4, grp = L.grp;
     int z = blockIdx.x;
     // small launches: the column passes of a tile are dealt to `psplit` workgroups (each stages the tile itself) to fill the chip
     const int psplit = p.pass_split > 1 ? p.pass_split : 1;
@@ -54,52 +254,30 @@ __global__ __launch_bounds__(256) void gemm_wf_kernel(const WfParams p, int row_
     const int M = S.M, N = p.N;
     const int row0 = rtile * WF_TM;
     if (row0 >= M) return;                          // uniform per workgroup, before any barrier
+    WF_T(t_begin);
 #ifdef WF_PROFILE
-    const unsigned long long t_begin = __builtin_readcyclecounter();
-    unsigned long long t_k = 0, t_e = 0, t_x;
+    unsigned long long t_k = 0, t_e = 0;
 #endif
 
-    // ---- PRO: the InstanceNorm constants (mean, rstd) of this batch element's K channels -> LDS.  Either finalised by
-    // stats_finalize_kernel (in_stats) or merged here from the producer's per-block (sum, M2) with Chan's formula in fp64, in the
-    // arithmetic and summation order of that kernel (4 block groups t = g, g + 4, ...; ((g0 + g1) + (g2 + g3)))
-    float* stl = reinterpret_cast<float*>(wf_smem + 2 * PLANE + 4 * 32 * 144);     // [K][2]
+    unsigned char* const tbase = wf_smem + 2 * PLANE;                   // 8 wave-private transposition buffers
+    // ---- PRO: the InstanceNorm constants (mean, rstd) of this batch element's K channels -> LDS (in the transposition area: it
+    // is not in use before the staging barrier)
+    float* stl = reinterpret_cast<float*>(tbase);                       // [K][2]
     if (PRO) {
-        if (S.stat_part) {
-            const int T = S.stat_tiles, TR = p.stat_tile_rows;
-            for (int k = tid; k < K; k += 256) {
-                const float2* sp = reinterpret_cast<const float2*>(S.stat_part) + (long)b * T * K + k;
-                double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0}, a3[4] = {0, 0, 0, 0};
-                for (int t = 0; t < T; ++t) {
-                    const float2 v = sp[(long)t * K];
-                    const int nt = min(TR, M - t * TR);
-                    a1[t & 3] += (double)v.x; a2[t & 3] += (double)v.y; a3[t & 3] += (double)v.x * (double)v.x / (double)nt;
-                }
-                const double s1t = (a1[0] + a1[1]) + (a1[2] + a1[3]);
-                const double m2w = (a2[0] + a2[1]) + (a2[2] + a2[3]);
-                const double sqn = (a3[0] + a3[1]) + (a3[2] + a3[3]);
-                const double mean = s1t / (double)M;
-                double m2 = m2w + (sqn - (double)M * mean * mean);
-                m2 = m2 < 0.0 ? 0.0 : m2;
-                stl[2 * k] = (float)mean;
-                stl[2 * k + 1] = (float)(1.0 / sqrt(m2 / (double)M + (double)p.norm_eps));
-            }
-        } else {
-            const float* st = S.in_stats + (long)b * K * 2;
-            for (int i = tid; i < 2 * K; i += 256) stl[i] = st[i];
-        }
+        const float* st = S.in_stats + (long)b * K * 2;
+        for (int i = tid; i < 2 * K; i += 512) stl[i] = st[i];
         __syncthreads();
     }
     // ---- stage the tile: 64 rows x K fp32 -> hi / lo half planes (rows past M are clamped: they only feed rows that are never stored)
     {
         const float* A = S.A + b * S.sA_b;
         const float* A2 = S.A2 ? S.A2 + b * S.sA2_b : A;
-        const float* st = stl;
         constexpr int F4_ROW = K / 4;               // float4 per row
-        constexpr int PER = WF_TM * F4_ROW / 256;   // float4 per thread
+        constexpr int PER = WF_TM * F4_ROW / 512;   // float4 per thread
         f32x4 v[PER];
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            const int e = j * 256 + tid;
+            const int e = j * 512 + tid;
             const int r = e / F4_ROW, k = (e - r * F4_ROW) * 4;
             const int gr = min(row0 + r, M - 1);
             const float* src = k < p.ksplit ? A + (long)gr * p.lda + k : A2 + (long)gr * p.lda2 + (k - p.ksplit);
@@ -107,11 +285,11 @@ __global__ __launch_bounds__(256) void gemm_wf_kernel(const WfParams p, int row_
         }
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            const int e = j * 256 + tid;
+            const int e = j * 512 + tid;
             const int r = e / F4_ROW, k = (e - r * F4_ROW) * 4;
             f32x4 x = v[j];
             if (PRO) {                              // InstanceNorm with the producer's finalised statistics + ReLU (nets/layers.py:67-76)
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(st + 2 * k), s1 = *reinterpret_cast<const f32x4*>(st + 2 * k + 4);
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(stl + 2 * k), s1 = *reinterpret_cast<const f32x4*>(stl + 2 * k + 4);
                 x[0] = fmaxf((x[0] - s0[0]) * s0[1], 0.f);
                 x[1] = fmaxf((x[1] - s0[2]) * s0[3], 0.f);
                 x[2] = fmaxf((x[2] - s1[0]) * s1[1], 0.f);
@@ -127,209 +305,218 @@ __global__ __launch_bounds__(256) void gemm_wf_kernel(const WfParams p, int row_
         }
     }
     __syncthreads();
-#ifdef WF_PROFILE
-    const unsigned long long t_staged = __builtin_readcyclecounter();
-#endif
+    WF_T(t_staged);
 
     int aoff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) aoff[i] = (32 * i + (lane & 31)) * PITCH + half * 16;
     const int npass_all = N >> 7;
-    const int npass = npass_all / psplit;          // passes of this workgroup: pbase .. pbase + npass
+    const int npass = npass_all / psplit;          // passes of this workgroup: pbase .. pbase + npass, dealt alternately to the two groups
     const int pbase = pgrp * npass;
     const u32x4* wbase = reinterpret_cast<const u32x4*>(p.Wf_) + lane;
-    auto wptr = [&](int pass) { return wbase + (size_t)(pass * 4 + wave) * NS * 128; };
-
-    // workgroups start at different column passes and wrap around: they all begin at the same time, and walking the weights in
-    // the same order would have every CU ask the L2 for the same lines at the same moment
-    const int pass0 = (int)((blockIdx.x / psplit) % (unsigned)npass);
-    u32x4 bh[4], bl[4];
-    {
-        const u32x4* w0 = wptr(pbase + pass0);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { bh[c] = w0[c * 128]; bl[c] = w0[c * 128 + 64]; }
-    }
-    // Epilogue through a wave-private LDS transposition (32 rows x 32 columns at a time, row pitch 144 bytes): whatever the
-    // accumulator layout, the tile is read back row-major - lane = 4 consecutive columns of one of 8 rows - so bias and residual
-    // are coalesced 16-byte loads and every store instruction writes 8 FULL 128-byte lines.  (Measured before, storing straight
-    // from the accumulator layout - 32 lines x 32 bytes per instruction -: 1.8 k cycles per pass against 3.3 k of K loop.)
-    constexpr int TP = 144;
-    unsigned char* const tbuf = wf_smem + 2 * PLANE + wave * (32 * TP);
+    auto wptr = [&](int pass) { return wbase + (size_t)(pass * 4 + w4) * NS * 128; };
+    unsigned char* const tbuf = tbase + (grp * 4 + w4) * WF_TBUF;
     float* const Cb = S.C + b * S.sC_b;
     const float* const Rb = S.R ? S.R + b * S.sR_b : nullptr;
-#pragma unroll 1
-    for (int pi = 0; pi < npass; ++pi) {
-        const int pl = pass0 + pi < npass ? pass0 + pi : pass0 + pi - npass;
-        const int pass = pbase + pl;
-        const int pnext = pbase + (pl + 1 < npass ? pl + 1 : 0);
+    // workgroups start at different column passes and wrap around: they all begin at the same time, and walking the weights in
+    // the same order would have every CU ask the L2 for the same lines at the same moment
+    const int mine = (npass + 1 - grp) >> 1;       // passes of this group: local indices grp, grp + 2, ...
+    const int rot = mine > 0 ? (int)((blockIdx.x / psplit) % (unsigned)mine) : 0;
+    auto pass_of = [&](int t) { int u = t + rot; if (u >= mine) u -= mine; return pbase + grp + 2 * u; };
+
+    if (CHAIN) {
+        // ================= first GEMM (N = 256: one pass per group), epilogue behind a barrier, then the chained projection =================
         f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        const u32x4* wp = wptr(pass);
-        const u32x4* wfollow = wptr(pnext);                                   // first group of the next pass (after the last: a harmless load)
-        f16x8 fah[2][2], fal[2][2];
-        auto load_frag = [&](int st, int fb) {
+        const int pass = grp;
+        const int cb = pass * 128 + w4 * 32;
+        f32x4 rres[2][4];
+        if (Rb && !(p.dbg & 4)) wf_load_residual(rres, Rb, p.ldr, row0, M, cb, lane);
+        u32x4 bh[4], bl[4];
+        {
+            const u32x4* w0 = wptr(pass);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fah[fb][i] = *reinterpret_cast<const f16x8*>(wf_smem + aoff[i] + st * 32);
-                fal[fb][i] = *reinterpret_cast<const f16x8*>(wf_smem + PLANE + aoff[i] + st * 32);
-            }
-        };
-#ifdef WF_PROFILE
-        t_x = __builtin_readcyclecounter();
+            for (int c = 0; c < 4; ++c) { bh[c] = w0[c * 128]; bl[c] = w0[c * 128 + 64]; }
+        }
+        constexpr int NS2 = 256 / 16;
+        const int npass2 = p.N2 >> 7;
+        const int mine2 = (npass2 + 1 - grp) >> 1;
+        const u32x4* wbase2 = reinterpret_cast<const u32x4*>(p.Wf2_) + lane;
+        auto wptr2 = [&](int ps) { return wbase2 + (size_t)(ps * 4 + w4) * NS2 * 128; };
+        wf_kloop<K, SWAP>(acc, wf_smem, aoff, wptr(pass), wptr2(grp), bh, bl);      // (bh / bl leave with the first fragments of the chained GEMM)
+        __syncthreads();                            // every wave is done with the K-wide planes: the new tile may overwrite them
+        wf_epilogue<SWAP, 1>(acc, tbuf, p.bias, rres, Rb != nullptr, Cb, p.ldc, row0, M, cb, L, p.dbg, wf_smem);
+        __syncthreads();                            // the 64 x 256 tile X' is complete in LDS (pitch 528 bytes, planes 64 x 528 apart)
+        constexpr int PITCH2 = 2 * 256 + 16;
+        int aoff2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) aoff2[i] = (32 * i + (lane & 31)) * PITCH2 + half * 16;
+        float* const C2 = S.C2 + b * S.sC2_b;
+        const f32x4 (&nores)[2][4] = rres;
+#if WF_PRIO
+        if (grp == 0) __builtin_amdgcn_s_setprio(1);
 #endif
+#pragma unroll 1
+        for (int t = 0; t < mine2; ++t) {
+            const int ps = grp + 2 * t;
+            const int pn = t + 1 < mine2 ? ps + 2 : ps;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            wf_kloop<256, SWAP>(acc, wf_smem, aoff2, wptr2(ps), wptr2(pn), bh, bl);
+            wf_epilogue<SWAP, 0>(acc, tbuf, p.bias2, nores, false, C2, p.ldc2, row0, M, ps * 128 + w4 * 32, L, p.dbg, nullptr);
+        }
+        return;
+    }
+
+    u32x4 bh[4], bl[4];
+    if (mine > 0) {
+        const u32x4* w0 = wptr(pass_of(0));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { bh[c] = w0[c * 128]; bl[c] = w0[c * 128 + 64]; }
+    }
+#if WF_PRIO
+    if (grp == 0) __builtin_amdgcn_s_setprio(1);
+#endif
+    float st_sum[4], st_m2[4];                      // STATS: (sum, M2) of this wave's passes, stored after the last one (N <= 1024: 4 passes per group)
+    int st_cb[4];
+#pragma unroll 1
+    for (int t = 0; t < mine; ++t) {
+        const int pass = pass_of(t);
+        const int pnext = pass_of(t + 1 < mine ? t + 1 : 0);      // (after the last: a harmless load)
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        const int cb = pass * 128 + w4 * 32;                     // first column of this wave in this pass
         // the residual of this pass in the read-back layout of the epilogue, requested now: it arrives under the K loop
         f32x4 rres[2][4];
-        if (Rb && !(p.dbg & 4)) {
+        if (Rb && !(p.dbg & 4)) wf_load_residual(rres, Rb, p.ldr, row0, M, cb, lane);
+        WF_T(t0);
+        wf_kloop<K, SWAP>(acc, wf_smem, aoff, wptr(pass), wptr(pnext), bh, bl);
+        WF_T(t1);
+        if (STATS) {                                               // (uniform selects instead of dynamic indexing: the arrays stay in registers)
+            float su, m2v;
+            wf_block_stats(acc, p.bias, row0, M, cb, L, su, m2v);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int row = min(row0 + 32 * i + 8 * j + (lane >> 3), M - 1);
-                    rres[i][j] = *reinterpret_cast<const f32x4*>(Rb + (long)row * p.ldr + pass * 128 + wave * 32 + (lane & 7) * 4);
-                }
-        }
-        load_frag(0, 0);
-        u32x4 nh[4], nl[4];
-#pragma unroll
-        for (int st = 0; st < NS; ++st) {
-            const int c = st & 3;
-            if (st + 1 < NS) load_frag(st + 1, (st + 1) & 1);
-            if (c == 0) {
-                const u32x4* wnext = st == NS - 4 ? wfollow : wp + 512;
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) { nh[cc] = wnext[cc * 128]; nl[cc] = wnext[cc * 128 + 64]; }
-                wp = wnext;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const f16x8 wh = __builtin_bit_cast(f16x8, bh[c]), wl = __builtin_bit_cast(f16x8, bl[c]);
-            if (SWAP) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fal[st & 1][i], acc[i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, fah[st & 1][i], acc[i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, fah[st & 1][i], acc[i], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[st & 1][i], wh, acc[i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[st & 1][i], wl, acc[i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[st & 1][i], wh, acc[i], 0, 0, 0);
-            }
-            if (c == 3) {
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) { bh[cc] = nh[cc]; bl[cc] = nl[cc]; }
-            }
-        }
-#ifdef WF_PROFILE
-        { const unsigned long long t = __builtin_readcyclecounter(); t_k += t - t_x; t_x = t; }
-#endif
-        const int cb = pass * 128 + wave * 32;                   // first column of this wave in this pass
-        if (STATS) {
-            // SWAP = 0: register r of fragment i = row 32 i + 4 half + (r & 3) + 8 (r >> 2) of column cb + lane % 32.
-            // (sum, M2 about the block mean) of this 64-row block per column, on the values as stored (bias included)
-            const int col = cb + (lane & 31);
-            const float bvs = p.bias ? p.bias[col] : 0.f;
-            const int nvalid = min(WF_TM, M - row0);
-            float sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + 32 * i + 4 * half + (r & 3) + 8 * (r >> 2);
-                    if (row < M) sum += acc[i][r] + bvs;
-                }
-            sum += __shfl_xor(sum, 32);
-            const float mean = sum / (float)nvalid;
-            float m2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + 32 * i + 4 * half + (r & 3) + 8 * (r >> 2);
-                    const float d = (acc[i][r] + bvs) - mean;
-                    if (row < M) m2 = fmaf(d, d, m2);
-                }
-            m2 += __shfl_xor(m2, 32);
-            if (half == 0) {
-                const int tiles_side = (M + WF_TM - 1) / WF_TM;            // the buffer is [b][this side's blocks][N][2] (stats_finalize_kernel)
-                float* o = S.out_stats + (((long)b * tiles_side + rtile) * N + col) * 2;
-                o[0] = sum;
-                o[1] = m2;
-            }
+            for (int q = 0; q < 4; ++q)
+                if (t == q) { st_sum[q] = su; st_m2[q] = m2v; st_cb[q] = cb; }
         }
         if (p.dbg & 2) { if (acc[0][0] == 123.456f) Cb[0] = acc[1][5]; continue; }
-        const int c4 = (lane & 7) * 4;
-        const f32x4 bias4 = (p.bias && !(p.dbg & 4)) ? *reinterpret_cast<const f32x4*>(p.bias + cb + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        wf_epilogue<SWAP, 0>(acc, tbuf, p.bias, rres, Rb != nullptr, Cb, p.ldc, row0, M, cb, L, p.dbg, nullptr);
+#ifdef WF_PROFILE
+        { __builtin_amdgcn_s_waitcnt(0); WF_T(t2); t_k += t1 - t0; t_e += t2 - t1; }
+#endif
+    }
+#ifdef WF_PROFILE
+    if (w4 == 0 && lane == 0 && blockIdx.x < 2048) {
+        wf_prof[blockIdx.x][grp][0] = t_staged - t_begin; wf_prof[blockIdx.x][grp][1] = t_k; wf_prof[blockIdx.x][grp][2] = t_e;
+        wf_prof[blockIdx.x][grp][3] = __builtin_readcyclecounter() - t_begin;
+    }
+#endif
+    if (STATS) {
+        // ---- ticket: the last workgroup of this (pair, image) to get here turns the per-block statistics into (mean, rstd)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (SWAP) {                                          // register r = column 4 half + (r & 3) + 8 (r >> 2) of row lane % 32
+        for (int t = 0; t < 4; ++t)
+            if (t < mine) wf_store_stats(S.out_stats, b, rtile, M, N, st_cb[t], L, st_sum[t], st_m2[t]);
+        if (!S.fin_stats) return;
+        __builtin_amdgcn_s_waitcnt(0);              // this wave's write-through stores are acknowledged
+        __syncthreads();
+        __shared__ int s_last;
+        const int tiles_side = (M + WF_TM - 1) / WF_TM;
+        if (tid == 0) {
+            unsigned* cnt = p.stat_cnt + b * p.nside + sidx;
+            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == (unsigned)(tiles_side * psplit) - 1u;
+            if (s_last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // re-armed for the next launch
+        }
+        __syncthreads();
+        if (!s_last) return;
+        // Chan's parallel-variance merge in fp64 in the arithmetic and order of stats_finalize_kernel: 4 block groups (group g takes
+        // blocks g, g + 4, ...), combined ((g0 + g1) + (g2 + g3)) through LDS.  Thread = (group, column mod 128); all loads of a
+        // round (up to 8 blocks x N / 128 columns) are issued before any is used - they are cache-bypassing and ~2 us each
+        const float* part = S.out_stats + (long)b * tiles_side * N * 2;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, (unsigned)((size_t)tiles_side * N * 8), 0x00020000);
+        double* sm = reinterpret_cast<double*>(wf_smem);              // [4 groups][3][N]: the planes are no longer needed
+        const int g = tid >> 7, kk = tid & 127;
+        constexpr int NR = 4;                                          // column rounds held in flight (N <= 512)
+        const int nr = N >> 7;
+        double a1[NR], a2[NR], a3[NR];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v;
+        for (int r = 0; r < NR; ++r) a1[r] = a2[r] = a3[r] = 0.0;
+        for (int t0 = g; t0 < tiles_side; t0 += 32) {
+            u32x2 raw[NR][8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][4 * g + e];
-                    *reinterpret_cast<f32x4*>(tbuf + (lane & 31) * TP + (4 * half + 8 * g) * 4) = v;
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = t0 + 4 * u;
+                    raw[r][u] = (r < nr && t < tiles_side) ? __builtin_amdgcn_raw_buffer_load_b64(rs, (t * N + kk + 128 * r) * 8, 0, AUX_SC1) : u32x2{0u, 0u};
                 }
-            } else {                                             // register r = row 4 half + (r & 3) + 8 (r >> 2) of column lane % 32
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    *reinterpret_cast<float*>(tbuf + (4 * half + (r & 3) + 8 * (r >> 2)) * TP + (lane & 31) * 4) = acc[i][r];
-            }
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + 4 * u;
+                if (t < tiles_side) {
+                    const int nt = min(WF_TM, M - t * WF_TM);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int lr = 8 * j + (lane >> 3);
-                const int row = row0 + 32 * i + lr;
-                f32x4 v = *reinterpret_cast<const f32x4*>(tbuf + lr * TP + c4 * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += bias4[e];
-                if (row < M) {
-                    if (Rb && !(p.dbg & 4)) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += rres[i][j][e];
+                    for (int r = 0; r < NR; ++r) {
+                        const double vx = (double)__uint_as_float(raw[r][u][0]), vy = (double)__uint_as_float(raw[r][u][1]);
+                        a1[r] += vx; a2[r] += vy; a3[r] += vx * vx / (double)nt;
                     }
-                    if (!(p.dbg & 1) || v[0] == 123.456f) *reinterpret_cast<f32x4*>(Cb + (long)row * p.ldc + cb + c4) = v;
                 }
             }
         }
-#ifdef WF_PROFILE
-        t_e += __builtin_readcyclecounter() - t_x;
-#endif
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (r < nr) {
+                const int k = kk + 128 * r;
+                sm[(g * 3 + 0) * N + k] = a1[r]; sm[(g * 3 + 1) * N + k] = a2[r]; sm[(g * 3 + 2) * N + k] = a3[r];
+            }
+        __syncthreads();
+        for (int k = tid; k < N; k += 512) {
+            const double s1t = (sm[(0 * 3 + 0) * N + k] + sm[(1 * 3 + 0) * N + k]) + (sm[(2 * 3 + 0) * N + k] + sm[(3 * 3 + 0) * N + k]);
+            const double m2w = (sm[(0 * 3 + 1) * N + k] + sm[(1 * 3 + 1) * N + k]) + (sm[(2 * 3 + 1) * N + k] + sm[(3 * 3 + 1) * N + k]);
+            const double sqn = (sm[(0 * 3 + 2) * N + k] + sm[(1 * 3 + 2) * N + k]) + (sm[(2 * 3 + 2) * N + k] + sm[(3 * 3 + 2) * N + k]);
+            const double mean = s1t / (double)M;
+            double m2 = m2w + (sqn - (double)M * mean * mean);
+            m2 = m2 < 0.0 ? 0.0 : m2;
+            float2 o;
+            o.x = (float)mean;
+            o.y = (float)(1.0 / sqrt(m2 / (double)M + (double)p.norm_eps));   // biased variance, eps inside the root (nets/layers.py:67-68)
+            reinterpret_cast<float2*>(S.fin_stats)[(long)b * N + k] = o;
+        }
     }
-#ifdef WF_PROFILE
-    if (tid == 0 && blockIdx.x < 4096) {
-        wf_prof[blockIdx.x][0] = t_staged - t_begin; wf_prof[blockIdx.x][1] = t_k; wf_prof[blockIdx.x][2] = t_e;
-        wf_prof[blockIdx.x][3] = __builtin_readcyclecounter() - t_begin;
-    }
-#endif
 }
 
-template <int K, int PRO, int SWAP, int STATS>
+template <int K, int PRO, int SWAP, int STATS, int CHAIN>
 hipError_t wf_launch(const WfParams& p, int batch, hipStream_t stream) {
     int maxm = p.side[0].M;
     if (p.nside > 1 && p.side[1].M > maxm) maxm = p.side[1].M;
     const int row_tiles = (maxm + WF_TM - 1) / WF_TM;
-    constexpr size_t lds = (size_t)2 * WF_TM * (2 * K + 16) + 4 * 32 * 144 + (PRO ? 2 * K * 4 : 0);   // half planes + transposition buffers + norm constants
-    if (hipError_t e = imp_grant_dynamic_lds((const void*)gemm_wf_kernel<K, PRO, SWAP, STATS>, lds)) return e;
+    constexpr size_t lds = (size_t)2 * WF_TM * (2 * K + 16) + 8 * WF_TBUF;   // half planes + transposition buffers (the norm constants borrow the latter)
+    static_assert(8 * WF_TBUF >= 2 * 512 * 4, "the norm constants live in the transposition area");
+    if (hipError_t e = imp_grant_dynamic_lds((const void*)gemm_wf_kernel<K, PRO, SWAP, STATS, CHAIN>, lds)) return e;
     const int psplit = p.pass_split > 1 ? p.pass_split : 1;
     if ((p.N >> 7) % psplit) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((gemm_wf_kernel<K, PRO, SWAP, STATS>), dim3(batch * p.nside * row_tiles * psplit), dim3(256), lds, stream, p, row_tiles);
+    hipLaunchKernelGGL((gemm_wf_kernel<K, PRO, SWAP, STATS, CHAIN>), dim3(batch * p.nside * row_tiles * psplit), dim3(512), lds, stream, p, row_tiles);
 #ifdef WF_PROFILE
-    {
+    if (!CHAIN) {
         static int calls = 0;
         if (++calls % 21 == 0) {
             (void)hipStreamSynchronize(stream);
-            const int nb = batch * p.nside * row_tiles * psplit < 4096 ? batch * p.nside * row_tiles * psplit : 4096;
-            std::vector<unsigned long long> h((size_t)nb * 4);
+            const int nb = batch * p.nside * row_tiles * psplit < 2048 ? batch * p.nside * row_tiles * psplit : 2048;
+            std::vector<unsigned long long> h((size_t)nb * 8);
             (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(wf_prof), h.size() * 8);
-            double a[4] = {0, 0, 0, 0};
-            for (int i = 0; i < nb; ++i) for (int j = 0; j < 4; ++j) a[j] += (double)h[(size_t)i * 4 + j] / nb;
-            fprintf(stderr, "[gemm_wf<%d,%d,%d,%d> N=%d, %d workgroups] mean cycles: staging %.0f  K loops %.0f  epilogues %.0f  total %.0f\n", K, PRO, SWAP, STATS, p.N, nb,
-                    a[0], a[1], a[2], a[3]);
+            double a[2][4] = {};
+            for (int i = 0; i < nb; ++i) for (int g = 0; g < 2; ++g) for (int j = 0; j < 4; ++j) a[g][j] += (double)h[((size_t)i * 2 + g) * 4 + j] / nb;
+            for (int g = 0; g < 2; ++g)
+                fprintf(stderr, "[gemm_wf<%d,%d,%d,%d> N=%d, %d workgroups, group %d] mean cycles (100 MHz-class counter): staging %.0f  K loops %.0f  epilogues %.0f  total %.0f\n",
+                        K, PRO, SWAP, STATS, p.N, nb, g, a[g][0], a[g][1], a[g][2], a[g][3]);
         }
     }
 #endif
@@ -344,14 +531,21 @@ bool gemm_wf_supported(int K, int N) { return (K == 256 || K == 512) && N % 128 
 
 hipError_t launch_gemm_wf(const WfParams& p, int batch, hipStream_t stream) {
     const bool stats = p.side[0].out_stats != nullptr;
-    const bool pro = p.side[0].in_stats != nullptr || p.side[0].stat_part != nullptr;
+    const bool pro = p.side[0].in_stats != nullptr;
+    const bool chain = p.Wf2_ != nullptr;
     if (!gemm_wf_supported(p.K, p.N)) return hipErrorInvalidValue;
+    if (chain) {
+        // the chained projection re-uses the first GEMM's output tile as its A operand: all 256 columns must be in this workgroup
+        if (!pro || stats || p.K != 512 || p.N != 256 || p.pass_split > 1 || !gemm_wf_supported(256, p.N2) || !p.side[0].C2) return hipErrorInvalidValue;
+        return wf_launch<512, 1, 1, 0, 1>(p, batch, stream);
+    }
     if (stats) {
         if (pro) return hipErrorInvalidValue;
-        return p.K == 256 ? wf_launch<256, 0, 0, 1>(p, batch, stream) : wf_launch<512, 0, 0, 1>(p, batch, stream);
+        if (p.N > 1024 || (p.side[0].fin_stats && (!p.stat_cnt || p.N > 512))) return hipErrorInvalidValue;
+        return p.K == 256 ? wf_launch<256, 0, 0, 1, 0>(p, batch, stream) : wf_launch<512, 0, 0, 1, 0>(p, batch, stream);
     }
-    if (pro) return p.K == 256 ? wf_launch<256, 1, 1, 0>(p, batch, stream) : wf_launch<512, 1, 1, 0>(p, batch, stream);
-    return p.K == 256 ? wf_launch<256, 0, 1, 0>(p, batch, stream) : wf_launch<512, 0, 1, 0>(p, batch, stream);
+    if (pro) return p.K == 256 ? wf_launch<256, 1, 1, 0, 0>(p, batch, stream) : wf_launch<512, 1, 1, 0, 0>(p, batch, stream);
+    return p.K == 256 ? wf_launch<256, 0, 1, 0, 0>(p, batch, stream) : wf_launch<512, 0, 1, 0, 0>(p, batch, stream);
 }
 
 // W [N][K] fp32 -> MFMA fragment order [N / 32][K / 16][hi | lo][64 lanes][8 halves]: lane (col = lane % 32, k-half = lane / 32)

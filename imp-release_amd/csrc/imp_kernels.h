@@ -218,9 +218,10 @@ struct WfSide {
     const float* R;        // residual [b][M][ldr] or null
     const float* in_stats; // [b][K][2] finalised (mean, rstd): InstanceNorm + ReLU applied while staging, or null
     float* out_stats;      // [b][row_tiles][N][2] per 64-row block (sum, M2 about the block mean), or null
-    const float* stat_part;// instead of in_stats: the producer's per-block (sum, M2) [b][stat_tiles][K][2]; every workgroup merges them itself
-    int stat_tiles;        //   (Chan's formula in fp64, the arithmetic and order of stats_finalize_kernel) - one launch less per layer
-    long sA_b, sA2_b, sC_b, sR_b;
+    float* fin_stats;      // with out_stats: [b][N][2] (mean, rstd), written by the LAST workgroup of the (pair, image) to arrive
+                           //   (WfParams::stat_cnt ticket; replaces the stats_finalize launch), or null
+    float* C2;             // chained projection output [b][M][ldc2] (WfParams::Wf2_), or null
+    long sA_b, sA2_b, sC_b, sR_b, sC2_b;
     int M;
 };
 struct WfParams {
@@ -230,9 +231,14 @@ struct WfParams {
     int K, ksplit, N;
     int lda, lda2, ldc, ldr;
     int nside;
-    int stat_tile_rows;    // rows per statistics block of stat_part
-    float norm_eps;        // InstanceNorm eps for stat_part
-    int pass_split;        // > 1: the N / 128 column passes of a row tile are dealt to this many workgroups (must divide N / 128)
+    float norm_eps;        // InstanceNorm eps for fin_stats
+    unsigned* stat_cnt;    // [batch][nside] zero-initialised, self re-arming tickets (fin_stats)
+    // chained second GEMM on the output tile (K = 512, N = 256 launches with in_stats only): C2 = C_tile . W2^T + bias2, K2 = 256,
+    // N2 a multiple of 128 and >= 256 - the next layer's q|k|v (or value) projection of the updated descriptors
+    const void* Wf2_;      // fragments of the [N2][256] weights, or null
+    const float* bias2;
+    int N2, ldc2;
+    int pass_split;        // > 1: the N / 128 column passes of a row tile are dealt to this many workgroups (must divide N / 128; not with Wf2_)
     int dbg;               // probe switches (tools/probe/gemm_wf_time.py): 1 no global stores, 2 no epilogue at all, 4 no residual / bias loads
 };
 hipError_t launch_gemm_wf(const WfParams& p, int batch, hipStream_t stream);

@@ -195,6 +195,18 @@ int imp_match_pair(imp_ctx* ctx, int batch, int n0, int n1,
 /* y[M][N] = x[M][K] @ W[N][K]^T + bias   (fp32 MFMA GEMM that every 1x1 conv maps to) */
 int imp_op_linear(imp_ctx* ctx, int M, int N, int K, const float* x, const float* W, const float* bias,
                   float* y, void* stream);
+/* test entry of the weight-fragment layer GEMM (csrc/gemm_wf.hip: the kernel behind the three 1x1 convolutions of a GNN layer,
+ * nets/layers.py:119-120,145-149,210-218), one image side, B batch elements, device pointers, row-major:
+ *   h = x, or - stats_in [B][ksplit][2] (mean, rstd per input channel) given - relu((x - mean) * rstd)        (InstanceNorm + ReLU)
+ *   y [B][M][N] = [h | x2] @ W[N][K]^T + bias (+ residual [B][M][N]);  x [B][M][ksplit], x2 [B][M][K - ksplit] (ksplit == K: x2 unused)
+ *   stats_out (optional) [B][N][2]: (mean, 1 / sqrt(biased var + 1e-3)) of y over the M rows of each batch element - the per-block
+ *     statistics epilogue + the last-arrival merge inside the launch
+ *   W2 [N2][256], bias2, y2 [B][M][N2] (optional; K = 512, N = 256, stats_in): y2 = y @ W2^T + bias2 on the tile still in LDS
+ *   pass_split: column passes of a row tile dealt to this many workgroups (1 = none; must divide N / 128)
+ * K = 256 or 512, N % 128 == 0.  Packs the weights on the fly; synchronises. */
+int imp_op_layer_gemm(imp_ctx* ctx, int B, int M, int N, int K, int ksplit, const float* x, const float* x2, const float* W,
+                      const float* bias, const float* residual, const float* stats_in, float* y, float* stats_out,
+                      const float* W2, const float* bias2, int N2, float* y2, int pass_split, void* stream);
 /* multi-head attention core on packed projections: qkv_q [B][nq][3D], qkv_kv [B][nk][3D]
  * (q | k | v, head-major), out [B][nq][D], lse [B][4][nq] (optional).  nets/layers.py:121-131 */
 int imp_op_attention(imp_ctx* ctx, int batch, int nq, int nk, int dim, const float* qkv_q,

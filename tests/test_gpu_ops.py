@@ -43,6 +43,56 @@ def test_linear_fp32_mfma(gm, M, N, K):
         assert (y.double() - ref.t()).abs().max().item() > 1e-2
 
 
+# (B, M, K, ksplit, N, variant, pass_split): every instantiation of csrc/gemm_wf.hip, ragged row counts, single rows, pass splits
+WF_CASES = [(2, 300, 256, 256, 768, 'plain', 1), (1, 64, 256, 256, 256, 'plain', 2), (1, 1, 256, 256, 768, 'plain', 6), (3, 1000, 256, 256, 768, 'plain', 3),
+            (2, 300, 512, 256, 512, 'stats', 1), (1, 129, 512, 256, 512, 'stats', 4), (4, 2048, 512, 256, 512, 'stats', 1), (1, 5, 512, 256, 512, 'stats', 2),
+            (1, 4100, 512, 256, 512, 'stats', 1), (2, 300, 512, 512, 256, 'norm', 1), (1, 70, 512, 512, 256, 'norm', 2), (2, 2048, 512, 512, 256, 'norm', 1),
+            (2, 300, 512, 512, 256, 'chain768', 1), (1, 1, 512, 512, 256, 'chain256', 1), (4, 2048, 512, 512, 256, 'chain768', 1),
+            (1, 130, 512, 512, 256, 'chain256', 1), (2, 200, 256, 256, 512, 'stats', 2)]
+
+
+@pytest.mark.parametrize('B,M,K,ks,N,variant,psplit', WF_CASES)
+def test_weight_fragment_layer_gemm(gm, B, M, K, ks, N, variant, psplit):
+    """csrc/gemm_wf.hip alone against fp64: plain projection, MLP conv 0 (K-split concat + InstanceNorm statistics merged by the last
+    workgroup to arrive), MLP conv 3 (norm + ReLU prologue, residual) and the chained conv 3 + next-layer projection"""
+    ctx = gm[2]._ensure_ctx()
+    x = _rand(B, M, ks, seed=1)
+    x2 = _rand(B, M, K - ks, seed=2) if ks < K else None
+    W, b = _rand(N, K, seed=3) / K ** .5, _rand(N, seed=4)
+    kw = {}
+    xin = x.double()
+    if variant in ('norm', 'chain768', 'chain256'):
+        # |mean| >> std on some channels, like the fixture gm_l3_bigmean
+        x = x + torch.linspace(-20, 20, ks)[None, None, :]
+        mean = x.double().mean(1)
+        rstd = 1.0 / (x.double().var(1, unbiased=False) + 1e-3).sqrt()
+        kw['stats_in'] = torch.stack([mean, rstd], -1).float().to(DEV)
+        kw['residual'] = _rand(B, M, N, seed=5).to(DEV)
+        xin = torch.relu((x.double() - kw['stats_in'][..., 0].cpu().double()[:, None]) * kw['stats_in'][..., 1].cpu().double()[:, None])
+    if variant.startswith('chain'):
+        N2 = int(variant[5:])
+        W2, b2 = _rand(N2, 256, seed=6) / 16, _rand(N2, seed=7)
+        kw['W2'], kw['bias2'] = W2.to(DEV), b2.to(DEV)
+    y, so, y2 = ctx.op_layer_gemm(x.to(DEV), W.to(DEV), b.to(DEV), x2=None if x2 is None else x2.to(DEV), want_stats=variant == 'stats',
+                                  pass_split=psplit, **kw)
+    a = xin if x2 is None else torch.cat([xin, x2.double()], -1)
+    ref = a @ W.double().t() + b.double()
+    if 'residual' in kw:
+        ref = ref + kw['residual'].cpu().double()
+    tol = 3e-6 * max(1.0, ref.abs().max().item()) * (K / 32) ** .5
+    err = (y.cpu().double() - ref).abs().max().item()
+    assert err < tol, f'{variant} {B}x{M}x{N}x{K}: max err {err:.3e} (tol {tol:.1e})'
+    if variant == 'stats':
+        yd = y.cpu().double()
+        mean, rstd = yd.mean(1), 1.0 / (yd.var(1, unbiased=False) + 1e-3).sqrt()
+        assert (so[..., 0].cpu().double() - mean).abs().max().item() < 2e-6 * max(1.0, mean.abs().max().item())
+        assert ((so[..., 1].cpu().double() - rstd) / rstd).abs().max().item() < 2e-6
+    if y2 is not None:
+        ref2 = y.cpu().double() @ W2.double().t() + b2.double()      # from the stored y: the chained GEMM reads exactly those values
+        err2 = (y2.cpu().double() - ref2).abs().max().item()
+        assert err2 < 3e-6 * max(1.0, ref2.abs().max().item()) * (256 / 32) ** .5, f'chained projection: max err {err2:.3e}'
+
+
 def _ref_attention(qkv_q, qkv_kv, D, mask=None):
     """fp64 reference of nets/layers.py:121-131 on packed head-major projections"""
     B, nq, _ = qkv_q.shape

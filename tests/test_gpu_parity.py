@@ -424,16 +424,47 @@ def test_weight_fragment_gemms_forced_vs_golden(name):
     spec, z = load_golden(name)
     cfg, sd, data = build_case(spec, device=DEV)
     os.environ['IMP_GEMM_WF'] = '2'
+    os.environ['IMP_WF_CHAIN_MIN'] = '1'        # ... and the chained launch (conv 3 + the next layer's projection) at every size
     try:
         m = make_hip_model(spec, cfg, sd)
         m._ensure_ctx()
     finally:
         del os.environ['IMP_GEMM_WF']
+        del os.environ['IMP_WF_CHAIN_MIN']
     with torch.no_grad():
         out = m.produce_matches(data, **spec.get('call', {}))
     for i in range(int(z['n_emitted'])):
         print(compare_matches(_cpu(out['indices0'][i]), _cpu(out['mscores0'][i]), z[f'indices0_{i}'], z[f'mscores0_{i}'],
                               spec.get('call', {}).get('p', 0.2), TOL, f'{name}[{i}] wf forced'))
+
+
+@pytest.mark.parametrize('model,n0,n1,B', [('GM', 2048, 2048, 4), ('DGNNS', 1000, 1100, 3), ('GM', 130, 97, 2), ('DGNNS', 64, 64, 1), ('GM', 1, 5, 1)])
+def test_chained_projection_is_bit_identical_to_the_separate_launches(model, n0, n1, B):
+    """gemm_wf.hip CHAIN computes layer i + 1's q|k|v (value only for a sharing layer) from the tile layer i's last convolution
+    just produced: the same arithmetic on the same operands as the separate projection launch, so the matches must be IDENTICAL
+    bit for bit (both with the weight-fragment kernels forced on, so that the projection kernel is the same one)"""
+    import os
+    cfg = eval_config(n_layers=5 if model == 'DGNNS' else 3, sinkhorn_iterations=20)
+    sd = synthetic.make_state_dict(cfg, model, seed=8)
+    models = []
+    for chain in ('1', '0'):
+        os.environ['IMP_GEMM_WF'] = '2'
+        os.environ['IMP_WF_CHAIN'] = chain
+        os.environ['IMP_WF_CHAIN_MIN'] = '1'
+        try:
+            m = make_hip_model(model, cfg, sd)
+            m._ensure_ctx()
+            models.append(m)
+        finally:
+            for k in ('IMP_GEMM_WF', 'IMP_WF_CHAIN', 'IMP_WF_CHAIN_MIN'):
+                del os.environ[k]
+    pair = synthetic.make_correlated_pair(n0, n1, seed=n0 + B, batch=B)
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+    with torch.no_grad():
+        a = models[0].produce_matches(data, p=0.2, only_last=True)
+        b = models[1].produce_matches(data, p=0.2, only_last=True)
+    assert torch.equal(a['indices0'][-1], b['indices0'][-1]) and torch.equal(a['mscores0'][-1], b['mscores0'][-1])
 
 
 def test_weight_fragment_gemms_default_rule_agrees_with_gemm_f32():
