@@ -415,14 +415,22 @@ __global__ __launch_bounds__(256) void pose_cheirality_kernel(const double2* __r
     if (threadIdx.x < 4 && cnt[threadIdx.x]) atomicAdd(&good[threadIdx.x], cnt[threadIdx.x]);
 }
 
-// the vote: most points in front, first candidate on ties (eval/pose_estimation.py:80-89); final mask = inlier of E AND in front (:113-114)
+// the vote: most points in front, first candidate on ties (eval/pose_estimation.py:80-89).  Two masks:
+//   inl     the geometric one: in the consensus of E AND in front of both cameras
+//   refmask the one the reference returns (:113-114): `mask = E_mask.ravel() >= 0` is all True, then only the consensus entries are
+//           overwritten with the cheirality result - matches OUTSIDE the consensus stay True.  The loops take their inlier ratio and
+//           their early-exit indices from this mask (eval/matching.py:89-90,113), so the drop-in has to reproduce it
 __global__ __launch_bounds__(256) void pose_vote_kernel(int n, const int* __restrict__ good, const unsigned char* __restrict__ bits,
-                                                        unsigned char* __restrict__ inl, double* __restrict__ out) {
+                                                        unsigned char* __restrict__ inl, unsigned char* __restrict__ refmask, double* __restrict__ out) {
     if (out[23] == 0.0) return;
     const int best = max(max(good[0], good[1]), max(good[2], good[3]));
     const int k = good[0] == best ? 0 : (good[1] == best ? 1 : (good[2] == best ? 2 : 3));
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n && inl[i]) inl[i] = (bits[i] >> k) & 1;
+    if (i < n) {
+        const unsigned char front = (bits[i] >> k) & 1;
+        refmask[i] = inl[i] ? front : 1;
+        if (inl[i]) inl[i] = front;
+    }
     if (i == 0) {
         for (int j = 0; j < 9; ++j) out[9 + j] = out[24 + (k & 1) * 9 + j];
         for (int j = 0; j < 3; ++j) out[18 + j] = (k >= 2 ? -1.0 : 1.0) * out[42 + j];
@@ -436,14 +444,14 @@ struct PoseWs {
     double2 *x0 = nullptr, *x1 = nullptr;
     double *Eh = nullptr, *out = nullptr;
     int *valid = nullptr, *counts = nullptr, *good = nullptr;
-    unsigned char *inl = nullptr, *bits = nullptr;
+    unsigned char *inl = nullptr, *bits = nullptr, *refmask = nullptr;
 };
 
 }  // namespace
 
 extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, const double* K0, const double* K1, double norm_thresh,
                                  int iterations, unsigned seed, int device, double* E, double* R, double* t, unsigned char* mask,
-                                 int* n_inliers, void* stream) {
+                                 unsigned char* consensus, int* n_inliers, void* stream) {
     if (!kpts0 || !kpts1 || !K0 || !K1 || !E || !R || !t || !mask || !n_inliers || iterations < 1) return IMP_E_ARG;
     *n_inliers = 0;
     if (n < 8) return 1;                                   // (the reference returns None below 5 points; the 8-point solver needs 8)
@@ -451,7 +459,7 @@ extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, 
     hipStream_t st = (hipStream_t)stream;
     static thread_local PoseWs ws;
     if (ws.device != device || (size_t)n > ws.cap_n || (size_t)iterations > ws.cap_h) {
-        for (void* p : {(void*)ws.x0, (void*)ws.x1, (void*)ws.Eh, (void*)ws.out, (void*)ws.valid, (void*)ws.counts, (void*)ws.inl, (void*)ws.good, (void*)ws.bits})
+        for (void* p : {(void*)ws.x0, (void*)ws.x1, (void*)ws.Eh, (void*)ws.out, (void*)ws.valid, (void*)ws.counts, (void*)ws.inl, (void*)ws.good, (void*)ws.bits, (void*)ws.refmask})
             if (p) (void)hipFree(p);
         ws = PoseWs();
         const size_t cn = (size_t)n < 4096 ? 4096 : (size_t)n, ch = (size_t)iterations < 2048 ? 2048 : (size_t)iterations;
@@ -459,7 +467,7 @@ extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, 
             hipMalloc(&ws.Eh, ch * 9 * sizeof(double)) != hipSuccess || hipMalloc(&ws.out, 48 * sizeof(double)) != hipSuccess ||
             hipMalloc(&ws.good, 4 * sizeof(int)) != hipSuccess || hipMalloc(&ws.bits, cn) != hipSuccess ||
             hipMalloc(&ws.valid, ch * sizeof(int)) != hipSuccess || hipMalloc(&ws.counts, ch * sizeof(int)) != hipSuccess ||
-            hipMalloc(&ws.inl, cn) != hipSuccess)
+            hipMalloc(&ws.inl, cn) != hipSuccess || hipMalloc(&ws.refmask, cn) != hipSuccess)
             return IMP_E_NOMEM;
         ws.device = device; ws.cap_n = cn; ws.cap_h = ch;
     }
@@ -479,10 +487,11 @@ extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, 
     hipLaunchKernelGGL(pose_consensus_kernel, dim3(1), dim3(1024), 0, st, ws.x0, ws.x1, n, iterations, ws.Eh, ws.counts, thr * thr, ws.inl, ws.out);
     if (hipMemsetAsync(ws.good, 0, 4 * sizeof(int), st) != hipSuccess) return IMP_E_HIP;
     hipLaunchKernelGGL(pose_cheirality_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws.x0, ws.x1, n, ws.out, ws.inl, 1000.0, ws.bits, ws.good);
-    hipLaunchKernelGGL(pose_vote_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, ws.good, ws.bits, ws.inl, ws.out);
+    hipLaunchKernelGGL(pose_vote_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, ws.good, ws.bits, ws.inl, ws.refmask, ws.out);
     double out[24];
     if (hipMemcpyAsync(out, ws.out, sizeof out, hipMemcpyDeviceToHost, st) != hipSuccess) return IMP_E_HIP;
-    if (hipMemcpyAsync(mask, ws.inl, n, hipMemcpyDeviceToHost, st) != hipSuccess) return IMP_E_HIP;
+    if (hipMemcpyAsync(mask, ws.refmask, n, hipMemcpyDeviceToHost, st) != hipSuccess) return IMP_E_HIP;
+    if (consensus && hipMemcpyAsync(consensus, ws.inl, n, hipMemcpyDeviceToHost, st) != hipSuccess) return IMP_E_HIP;
     if (hipStreamSynchronize(st) != hipSuccess) return IMP_E_HIP;
     if (hipGetLastError() != hipSuccess) return IMP_E_HIP;
     if (out[23] == 0.0) return 1;

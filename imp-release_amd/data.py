@@ -133,7 +133,7 @@ def feed_data(rec: dict, device, host_buffers: Optional[dict] = None, stream=Non
     out['image1'] = torch.empty((1,) + tuple(rec['size2']) + (3,), device='meta')
     out.update({'K0': rec['K1'], 'K1': rec['K2'], 'T_0to1': np.hstack([rec['R'], rec['t'].reshape(3, 1)]),
                 'pts0_cpu': np.ascontiguousarray(x0[:, :2]), 'pts1_cpu': np.ascontiguousarray(x1[:, :2]),
-                'index': rec['index']})
+                'E': rec.get('e'), 'index': rec['index']})
     return out
 
 

@@ -3,8 +3,11 @@
 
 Pairs are partitioned over ranks with :func:`imp_release_amd.dist.shard_range` (no data-path collective); each rank
 runs ``matching_iterative`` (IMP) or ``matching_iterative_uncertainty`` (EIMP) on its pairs, and ONE all-gather at the
-end collects a fixed-size summary row per pair: (n_iterations, n_matches, mean match score, n_kept0, n_kept1).
-``estimate_pose`` is injected (the reference's cv2 MAGSAC step is out of scope); ``None`` = no early exit.
+end collects a fixed-size summary row per pair (``SUMMARY_COLUMNS``: pose errors, precision, matching score - the metrics tail of
+eval/eval_imp.py:112-141,190-225 through :mod:`imp_release_amd.metrics` - and the loop statistics); :func:`aggregate` turns the
+table into the reference's report (AUC@5/10/20/50, precision, matching score).
+``estimate_pose`` is injected (``imp_release_amd.pose.estimate_pose`` = the GPU pose step; the reference's cv2 MAGSAC call when
+available); ``None`` = no pose, no early exit, infinite pose errors.
 
 Pairs in flight: one pair at batch 1 cannot fill the GPU (every kernel of the loop is a few workgroups, the step is
 bound by ~7 us of dependent-launch latency per kernel), and the reference's loop additionally parks the GPU during
@@ -26,19 +29,74 @@ import torch.distributed as dist
 from . import matching
 from .dist import shard_range
 
-SUMMARY_COLUMNS = ('n_iterations', 'n_matches', 'mean_mscore', 'n_kept0', 'n_kept1')
+# one row per pair = what eval/eval_imp.py:112-141,190-225 accumulates for its report: pose errors (degrees; inf = no pose),
+# precision and matching score of the final matches against the ground-truth essential matrix, plus the loop statistics
+SUMMARY_COLUMNS = ('err_R', 'err_t', 'precision', 'matching_score', 'mean_mscore', 'n_iterations', 'n_matches', 'n_kept0', 'n_kept1')
+AUC_THRESHOLDS = (5, 10, 20, 50)             # eval/eval_imp.py:36
 
 
-def summarize(out, eimp: bool) -> np.ndarray:
+def normalize_intrinsic(x, K):
+    """components/utils/evaluation_utils.py:6-8"""
+    K = np.asarray(K, dtype=np.float64)
+    return (np.asarray(x, dtype=np.float64) - K[:2, 2]) / np.diag(K)[:2]
+
+
+def summarize(out, eimp: bool, data: Optional[dict] = None, estimate_pose=None, error_th: float = 1.0) -> np.ndarray:
+    """the metrics tail of eval/eval_imp.py for one pair (:112-141 iterative branch): final matches -> epipolar precision /
+    matching score against the ground-truth E (``data['E']``, inlier_th 0.005 in intrinsics-normalised coordinates), pose error
+    of the loop's pose - or, when the loop found none, of ``estimate_pose`` on the final matches - against ``data['T_0to1']``.
+    Rows of pairs without ground truth carry NaN in the first four columns.  (For the EIMP loop the reference re-uses the
+    loop's image-size-normalised keypoint tensor as if it were intrinsics-normalised, eval/eval_imp.py:95,127-128; this
+    function normalises the loop's surviving pixel coordinates with K, which is what the formula expects.)"""
+    from . import metrics
     if eimp:
-        pts0, pts1, _, _, indices0, mscores0, _, _, n_iter = out
+        pts0, pts1, _, _, indices0, mscores0, pred_R, pred_t, n_iter = out
         k0, k1 = pts0.shape[0], pts1.shape[0]
     else:
-        indices0, mscores0, _, _, n_iter = out
+        indices0, mscores0, pred_R, pred_t, n_iter = out
         k0 = k1 = -1
+        pts0 = None if data is None else data.get('pts0_cpu')
+        pts1 = None if data is None else data.get('pts1_cpu')
     valid = indices0 > -1
     mean = float(mscores0[valid].mean()) if valid.any() else 0.0
-    return np.array([n_iter, int(valid.sum()), mean, k0, k1], dtype=np.float64)
+    err_R = err_t = precision = mscore = float('nan')
+    if data is not None and pts0 is not None and 'K0' in data and 'T_0to1' in data:
+        K0, K1 = np.asarray(data['K0'], dtype=np.float64), np.asarray(data['K1'], dtype=np.float64)
+        mk0, mk1 = np.asarray(pts0)[valid], np.asarray(pts1)[indices0[valid]]
+        if data.get('E') is not None:
+            correct = metrics.compute_epi_inlier(normalize_intrinsic(mk0, K0), normalize_intrinsic(mk1, K1),
+                                                 np.asarray(data['E'], dtype=np.float64), 0.005) if len(mk0) else np.zeros(0, dtype=bool)
+            precision = float(np.mean(correct)) if len(correct) > 0 else 0.0
+            mscore = float(np.sum(correct)) / len(pts0) if len(pts0) > 0 else 0.0
+        R, t = pred_R, pred_t
+        if R is None and estimate_pose is not None:
+            ret = estimate_pose(kpts0=mk0, kpts1=mk1, K0=K0, K1=K1, norm_thresh=error_th)
+            if ret is not None:
+                R, t = ret[1], ret[2]
+        if R is None:
+            err_t, err_R = float('inf'), float('inf')
+        else:
+            err_t, err_R = (float(v) for v in metrics.compute_pose_error(np.asarray(data['T_0to1'], dtype=np.float64), R, t))
+    return np.array([err_R, err_t, precision, mscore, mean, n_iter, int(valid.sum()), k0, k1], dtype=np.float64)
+
+
+def aggregate(table: np.ndarray) -> dict:
+    """the report of eval/eval_imp.py:213-227 from the gathered table: pose AUC@5/10/20/50 of max(err_R, err_t) (tools/utils.py:445-457),
+    mean precision / matching score (percent), mean loop statistics"""
+    from . import metrics
+    col = {n: table[:, i] for i, n in enumerate(SUMMARY_COLUMNS)}
+    out = {'pairs': int(table.shape[0])}
+    have = ~np.isnan(col['err_R'])
+    if have.any():
+        pose_errors = np.maximum(col['err_R'][have], col['err_t'][have])
+        for th, a in zip(AUC_THRESHOLDS, metrics.pose_auc(pose_errors, AUC_THRESHOLDS)):
+            out[f'auc@{th}'] = round(100.0 * a, 2)
+        out['precision'] = round(100.0 * float(np.nanmean(col['precision'][have])), 2)
+        out['matching_score'] = round(100.0 * float(np.nanmean(col['matching_score'][have])), 2)
+        out['pose_found'] = round(float(np.mean(np.isfinite(pose_errors))), 3)
+    for n in ('mean_mscore', 'n_iterations', 'n_matches', 'n_kept0', 'n_kept1'):
+        out[n] = round(float(col[n].mean()), 3)
+    return out
 
 
 def replicate(model, n: int) -> list:
@@ -55,7 +113,7 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
                       match_ratio: float = 0.1, min_kpts: int = 25, error_th: float = 1.0,
                       stop_criteria: Optional[dict] = None, estimate_pose=None, group=None, workers: int = 1,
                       replicas: Optional[Sequence] = None) -> np.ndarray:
-    """-> [n_pairs, 5] summary table, identical on every rank.  ``pair_provider(pair_id)`` returns the reference's
+    """-> [n_pairs, len(SUMMARY_COLUMNS)] summary table, identical on every rank.  ``pair_provider(pair_id)`` returns the reference's
     per-pair ``data`` dict (GPU tensors + pts*_cpu / K*), exactly what eval/matching.py consumes.
     ``workers`` > 1: that many pairs in flight on this rank (see module docstring); ``replicas`` may pass pre-built
     model instances (else they are created with :func:`replicate`)."""
@@ -68,8 +126,9 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
     loop = matching.matching_iterative_uncertainty if eimp else matching.matching_iterative
 
     def run_one(m, pid):
-        out = loop(pair_provider(pid), m, nI, match_ratio, min_kpts, error_th, stop_criteria, estimate_pose=estimate_pose)
-        return summarize(out, eimp)
+        data = pair_provider(pid)
+        out = loop(data, m, nI, match_ratio, min_kpts, error_th, stop_criteria, estimate_pose=estimate_pose)
+        return summarize(out, eimp, data, estimate_pose, error_th)
 
     workers = max(1, min(int(workers), e - s))
     if workers == 1:

@@ -23,8 +23,13 @@ from . import _lib
 
 
 def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, mask=None, iterations=4096, seed=1,
-                  device=None, stream=None):
-    """eval/pose_estimation.py:92-115 -> None | (E [3,3], R [3,3], t [3], mask [n] bool)."""
+                  device=None, stream=None, return_consensus=False):
+    """eval/pose_estimation.py:92-115 -> None | (E [3,3], R [3,3], t [3], mask [n] bool).
+
+    ``mask`` has the reference's semantics (:113-114: ``mask = E_mask.ravel() >= 0`` is all True, then only the consensus entries
+    are overwritten with the cheirality result): matches OUTSIDE the consensus stay True.  ``return_consensus=True`` appends the
+    geometric mask (in the consensus of E AND in front of both cameras).  Fewer than 8 matches -> None (the reference: fewer
+    than 5; an 8-point minimal solver cannot go lower - behind the loops' ``min_kpts = 25`` the difference is never reached)."""
     import torch
     k0 = np.ascontiguousarray(np.asarray(kpts0, dtype=np.float32))
     k1 = np.ascontiguousarray(np.asarray(kpts1, dtype=np.float32))
@@ -39,13 +44,16 @@ def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, 
     Kb = np.ascontiguousarray(np.asarray(K1, dtype=np.float64).reshape(3, 3))
     E, R, t = np.zeros(9), np.zeros(9), np.zeros(3)
     m = np.zeros(n, dtype=np.uint8)
+    cons = np.zeros(n, dtype=np.uint8)
     ninl = C.c_int()
     st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
     P = lambda a: a.ctypes.data_as(C.c_void_p)      # noqa: E731
     rc = L.imp_estimate_pose(P(k0), P(k1), n, P(Ka), P(Kb), C.c_double(float(norm_thresh)), int(iterations), C.c_uint(seed), dev,
-                             P(E), P(R), P(t), P(m), C.byref(ninl), C.c_void_p(st))
+                             P(E), P(R), P(t), P(m), P(cons), C.byref(ninl), C.c_void_p(st))
     if rc == 1:
         return None
     if rc != 0:
         raise _lib.ImpError(rc, 'imp_estimate_pose failed')
+    if return_consensus:
+        return E.reshape(3, 3), R.reshape(3, 3), t, m.astype(bool), cons.astype(bool)
     return E.reshape(3, 3), R.reshape(3, 3), t, m.astype(bool)

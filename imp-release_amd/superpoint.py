@@ -10,10 +10,13 @@ Weights: ``config['weight_path']`` (a ``torch.save``d state_dict such as superpo
 in the tests - the released checkpoint is not available offline).
 
 ``align_corners`` of ``sample_descriptors``: the reference passes ``align_corners=True`` to ``grid_sample`` only when
-``int(torch.__version__[2]) > 2`` (nets/superpoint.py:89), i.e. for torch 1.3 ... 1.9; on every torch 2.x - including the one in
-this image - that test is False and ``grid_sample`` runs with its default ``align_corners=False``.  ``config['align_corners']``
-= None (default) applies the same rule to the installed torch, so both implementations agree wherever they are run side by
-side; True / False force either behaviour.
+``int(torch.__version__[2]) > 2`` (nets/superpoint.py:89).  Character 2 of the version string is the first digit of the MINOR
+version, so the test is True for torch 1.3 ... 1.9 and 2.3 ... 2.9 and False for x.0 ... x.2 and for every two-digit minor
+(1.10 ... 1.13, 2.10 ... - including the 2.10 of this image: ``'2.10.0'[2] == '1'``); False means ``grid_sample``'s default
+``align_corners=False``.  ``config['align_corners']`` = None (default) applies the same rule to the installed torch, so both
+implementations agree wherever they are run side by side; True / False force either behaviour.  Both branches are pinned by
+reference-generated fixtures (``superpoint_aligned_*`` captured with the version string patched), and
+``tests/test_host_cpu.py::test_superpoint_align_corners_rule`` pins the rule itself on version strings.
 """
 from __future__ import annotations
 

@@ -153,6 +153,45 @@ def make_correlated_pair(n0: int, n1: int, desc_dim: int = 256, seed: int = 0, b
     return out
 
 
+def make_two_view_pair(n0: int, n1: int, desc_dim: int = 256, seed: int = 0, overlap: float = 0.6, noise_px: float = 0.5,
+                       desc_noise: float = 0.25, angle_deg: float = 12.0, width: int = 640, height: int = 480):
+    """A pair with GEOMETRY: image 0 sees random 3D points, image 1 re-observes a fraction ``overlap`` of them from a second camera
+    (rotation ``angle_deg`` about a random axis, unit baseline, pixel noise ``noise_px``, descriptors perturbed like
+    :func:`make_correlated_pair`); every other keypoint of either image is an unrelated distractor.  On such pairs the pose step and
+    the metrics tail of the evaluation loop (eval/eval_imp.py:112-141) measure something: returns the ``data`` keys of
+    :func:`make_pair` (batch 1) plus ``K0, K1`` (3x3), ``T_0to1`` (3x4 [R|t], |t| = 1) and the ground-truth essential matrix ``E``
+    in intrinsics-normalised coordinates, as the reference's dumps carry them (components/readers.py:14-33)."""
+    out = make_pair(n0, n1, desc_dim, seed, 1, width, height)
+    g = _rng_for(seed, 'pair.twoview')
+    K = np.array([[520., 0, width / 2.], [0, 520., height / 2.], [0, 0, 1.]])
+    ax = g.normal(size=3); ax /= np.linalg.norm(ax)
+    a = np.deg2rad(angle_deg)
+    Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(a) * Kx + (1 - np.cos(a)) * Kx @ Kx
+    t = g.normal(size=3); t /= np.linalg.norm(t)
+    k = int(min(n0, n1) * overlap)
+    src = g.permutation(n0)[:k]
+    dst = g.permutation(n1)[:k]
+    # 3D points behind the chosen keypoints of image 0 (depth 4..9), seen again in image 1 when they project inside it
+    x0 = out['keypoints0'][0, src].astype(np.float64)
+    depth = g.uniform(4.0, 9.0, size=k)
+    X = np.concatenate([(x0 - K[:2, 2]) / np.diag(K)[:2], np.ones((k, 1))], 1) * depth[:, None]
+    Xc = X @ R.T + t
+    x1 = Xc[:, :2] / Xc[:, 2:] * np.diag(K)[:2] + K[:2, 2]
+    x1 += g.normal(0, noise_px, size=x1.shape)
+    ok = (Xc[:, 2] > 0.1) & (x1[:, 0] >= 0) & (x1[:, 0] < width) & (x1[:, 1] >= 0) & (x1[:, 1] < height)
+    src, dst, x1 = src[ok], dst[ok], x1[ok]
+    d = out['descriptors0'][0, src] + desc_noise * g.standard_normal(size=(len(src), desc_dim)).astype(np.float32) / np.sqrt(desc_dim)
+    d /= np.maximum(np.linalg.norm(d, axis=-1, keepdims=True), 1e-12)
+    out['descriptors1'][0, dst] = d.astype(np.float32)
+    out['keypoints1'][0, dst] = x1.astype(np.float32)
+    out['scores1'][0, dst] = np.clip(out['scores0'][0, src] + 0.05 * g.standard_normal(size=len(src)), 0.01, 0.99).astype(np.float32)
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    out.update({'K0': K.copy(), 'K1': K.copy(), 'T_0to1': np.hstack([R, t.reshape(3, 1)]), 'E': tx @ R,
+                'true_matches': np.stack([src, dst], 1)})
+    return out
+
+
 class PoseStub:
     """Deterministic stand-in for ``eval/pose_estimation.py:92-115 estimate_pose`` (cv2 MAGSAC is absent here) with the
     reference's keyword signature, so that the SAME object can drive the imported reference loop, the oracle loop and

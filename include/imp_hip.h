@@ -226,12 +226,16 @@ int imp_time_layer_gemm(imp_ctx* ctx, int batch, int n, int which, int dbg, int 
  * HOST arrays in, HOST arrays out (the matched keypoints of a loop iteration live on the host, eval/matching.py:68-87):
  * kpts0 / kpts1 [n][2] pixels, K0 / K1 row-major 3x3, norm_thresh in pixels (divided by the mean focal length inside).
  * `iterations` seeded 8-point hypotheses + consensus refits + cheirality vote on the GPU `device`, on `stream`; synchronises.
- * Returns 0 and E, R (row-major 3x3), t, mask [n] (1 = inlier of E that also passes the cheirality test), *n_inliers;
- * 1 = no pose (fewer than 8 matches / no consensus: the reference returns None); < 0 = error.
+ * Returns 0 and E, R (row-major 3x3), t, *n_inliers (consensus matches in front of both cameras) and two masks [n]:
+ *   mask       what the reference returns (:113-114): all True, with only the CONSENSUS entries overwritten by the cheirality result -
+ *              matches outside the consensus stay 1.  The loops derive their inlier ratio and early-exit indices from it
+ *              (eval/matching.py:89-90,113), so the drop-in reproduces the quirk;
+ *   consensus  (optional) the geometric mask: inlier of E AND in front of both cameras.
+ * 1 = no pose (fewer than 8 matches / no consensus: the reference returns None - below 5 matches); < 0 = error.
  * NOT OpenCV's USAC_MAGSAC: parity with that third-party solver is unpinned (see csrc/pose.hip). */
 int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, const double* K0, const double* K1, double norm_thresh,
                       int iterations, unsigned seed, int device, double* E, double* R, double* t, unsigned char* mask,
-                      int* n_inliers, void* stream);
+                      unsigned char* consensus, int* n_inliers, void* stream);
 /* Chip-resident Sinkhorn health (csrc/ot_resident.hip; the kernel behind compute_score, nets/gm.py:297-303).  Its workgroups
  * exchange vectors through memory with bounded waits.  A wait that times out (a second process on the GPU, a partition mode
  * that places workgroups differently) voids the launch: the kernel poisons its outputs (maxima NaN -> mscores NaN, indices -1)

@@ -121,9 +121,11 @@ def sampson_sq(E, x0, x1):
     return num / np.maximum(den, 1e-30)
 
 
-def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, mask=None, iterations=4096, seed=1):
-    """Signature of eval/pose_estimation.py:92 -> None | (E, R, t, inlier_mask).  Threshold: norm_thresh pixels divided by the
-    mean focal length, applied to the Sampson distance in normalised coordinates."""
+def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, mask=None, iterations=4096, seed=1, return_consensus=False):
+    """Signature of eval/pose_estimation.py:92 -> None | (E, R, t, mask).  Threshold: norm_thresh pixels divided by the
+    mean focal length, applied to the Sampson distance in normalised coordinates.  ``mask`` follows :113-114 literally: all True,
+    only the consensus entries overwritten by the cheirality result; ``return_consensus`` appends the geometric mask
+    (consensus AND in front of both cameras)."""
     n = len(kpts0)
     if n < 8:
         return None
@@ -152,8 +154,12 @@ def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, 
         if same and rnd > 0:
             break
     R, t, mP = decompose_essential_mat(bestE, np.asarray(kpts0)[inl], np.asarray(kpts1)[inl], K0, K1)
-    m = np.zeros(n, dtype=bool)
-    m[np.nonzero(inl)[0]] = mP                           # eval/pose_estimation.py:113-114
+    m = np.ones(n, dtype=bool)                           # eval/pose_estimation.py:113: `E_mask.ravel() >= 0` - every entry True
+    m[np.nonzero(inl)[0]] = mP                           # :114
+    if return_consensus:
+        geo = np.zeros(n, dtype=bool)
+        geo[np.nonzero(inl)[0]] = mP
+        return bestE, R, t, m, geo
     return bestE, R, t, m
 
 

@@ -25,13 +25,14 @@ def _ang_vec(a, b):
 def test_gpu_pose_equals_its_cpu_twin(n, outliers, noise, seed):
     k0, k1, K, R, t, truth = po.synthetic_scene(n, outliers=outliers, noise=noise, seed=seed)
     its = 512
-    g = hip_pose.estimate_pose(k0, k1, K, K, 1.0, iterations=its, seed=11)
-    c = po.estimate_pose(k0, k1, K, K, 1.0, iterations=its, seed=11)
+    g = hip_pose.estimate_pose(k0, k1, K, K, 1.0, iterations=its, seed=11, return_consensus=True)
+    c = po.estimate_pose(k0, k1, K, K, 1.0, iterations=its, seed=11, return_consensus=True)
     assert (g is None) == (c is None)
     if g is None:
         return
-    Eg, Rg, tg, mg = g
-    Ec, Rc, tc, mc = c
+    Eg, Rg, tg, mrg, mg = g
+    Ec, Rc, tc, mrc, mc = c
+    assert (mrg != mrc).sum() <= max(1, n // 500) and (mrg | ~mg).all()       # the reference-semantics mask: consensus outsiders stay True
     # same hypotheses, same algebra (fp64 both): the same consensus up to points sitting exactly on the threshold
     assert (mg != mc).sum() <= max(1, n // 500), (mg != mc).sum()
     assert _ang_mat(Rg, Rc) < 1e-3 and _ang_vec(tg, tc) < 1e-2
@@ -43,11 +44,11 @@ def test_gpu_pose_equals_its_cpu_twin(n, outliers, noise, seed):
 @pytest.mark.parametrize('seed', range(4))
 def test_gpu_pose_recovers_known_poses(seed):
     k0, k1, K, R, t, truth = po.synthetic_scene(1200, outliers=0.35, noise=0.3, seed=20 + seed, angle_deg=8 + 5 * seed)
-    E, Re, te, m = hip_pose.estimate_pose(k0, k1, K, K, 1.0)
+    E, Re, te, mref, m = hip_pose.estimate_pose(k0, k1, K, K, 1.0, return_consensus=True)
     assert _ang_mat(R, Re) < 1.5 and _ang_vec(t, te) < 6.0, (_ang_mat(R, Re), _ang_vec(t, te))
     assert (m & ~truth).sum() <= 0.05 * m.sum() and m.sum() >= 0.6 * truth.sum()
-    again = hip_pose.estimate_pose(k0, k1, K, K, 1.0)
-    assert np.array_equal(again[3], m) and np.array_equal(again[1], Re)          # deterministic (seeded)
+    again = hip_pose.estimate_pose(k0, k1, K, K, 1.0, return_consensus=True)
+    assert np.array_equal(again[4], m) and np.array_equal(again[3], mref) and np.array_equal(again[1], Re)          # deterministic (seeded)
 
 
 def test_no_pose_cases():

@@ -123,11 +123,44 @@ def test_metrics_tail_vs_reference_golden():
 
 def test_eval_loop_summary_rows():
     from imp_release_amd import eval_loop
+    C = eval_loop.SUMMARY_COLUMNS
     i0 = np.array([3, -1, 0, -1]); ms = np.array([0.5, 0.0, 0.3, 0.0], dtype=np.float32)
-    r = eval_loop.summarize((i0, ms, None, None, 15), eimp=False)
-    assert r.tolist()[:2] == [15, 2] and abs(r[2] - 0.4) < 1e-6 and r[3] == -1
-    r = eval_loop.summarize((np.zeros((7, 2)), np.zeros((9, 2)), None, None, i0, ms, None, None, 12), eimp=True)
-    assert r.tolist() == [12, 2, r[2], 7, 9]
+    r = dict(zip(C, eval_loop.summarize((i0, ms, None, None, 15), eimp=False)))
+    assert (r['n_iterations'], r['n_matches'], r['n_kept0']) == (15, 2, -1) and abs(r['mean_mscore'] - 0.4) < 1e-6
+    assert np.isnan(r['err_R']) and np.isnan(r['precision'])          # no ground truth given
+    r = dict(zip(C, eval_loop.summarize((np.zeros((7, 2)), np.zeros((9, 2)), None, None, i0, ms, None, None, 12), eimp=True)))
+    assert (r['n_iterations'], r['n_matches'], r['n_kept0'], r['n_kept1']) == (12, 2, 7, 9)
+
+
+def test_eval_loop_metrics_tail_on_a_two_view_pair():
+    """eval/eval_imp.py:112-141 through eval_loop.summarize / aggregate: precision and matching score against the ground-truth E,
+    pose error of the loop's pose or - when it found none - of estimate_pose on the final matches, AUC of max(err_R, err_t)"""
+    from imp_release_amd import eval_loop, metrics
+    from oracle import pose_oracle
+    p = synthetic.make_two_view_pair(500, 470, seed=4)
+    tm = p['true_matches']
+    data = {'pts0_cpu': p['keypoints0'][0], 'pts1_cpu': p['keypoints1'][0], **{k: p[k] for k in ('K0', 'K1', 'T_0to1', 'E')}}
+    i0 = -np.ones(500, dtype=np.int64)
+    i0[tm[:, 0]] = tm[:, 1]
+    wrong = tm[:40, 0]
+    i0[wrong] = (i0[wrong] + 17) % 470                           # 40 wrong matches
+    ms = (i0 > -1).astype(np.float32) * 0.5
+    C = eval_loop.SUMMARY_COLUMNS
+    pose = lambda **k: pose_oracle.estimate_pose(iterations=512, **k)
+    r = dict(zip(C, eval_loop.summarize((i0, ms, None, None, 15), False, data, pose, 1.0)))
+    n = int((i0 > -1).sum())
+    assert abs(r['precision'] - (n - 40) / n) < 0.02 and abs(r['matching_score'] - (n - 40) / 500) < 0.02
+    assert r['err_R'] < 1.0 and r['err_t'] < 3.0                  # the pose step recovers the pose from the final matches
+    # the loop's own pose wins over a fresh estimate (eval/eval_imp.py:139-140)
+    R_gt, t_gt = p['T_0to1'][:, :3], p['T_0to1'][:, 3]
+    r2 = dict(zip(C, eval_loop.summarize((i0, ms, R_gt, t_gt, 9), False, data, None, 1.0)))
+    assert r2['err_R'] < 1e-6 and r2['err_t'] < 1e-4 and r2['n_iterations'] == 9
+    # no pose at all: infinite error, counted as a miss by the AUC
+    r3 = eval_loop.summarize((i0, ms, None, None, 15), False, data, None, 1.0)
+    assert np.isinf(r3[0]) and np.isinf(r3[1])
+    rep = eval_loop.aggregate(np.stack([np.array(list(r.values())), r3]))
+    assert rep['pairs'] == 2 and rep['pose_found'] == 0.5 and 40.0 < rep['auc@20'] <= 50.0
+    assert abs(rep['auc@5'] - 100 * metrics.pose_auc([max(r['err_R'], r['err_t']), np.inf], [5])[0]) < 0.01
 
 
 _WORKER = r'''
@@ -146,7 +179,7 @@ assert torch.equal(gi, full_i) and torch.equal(gm, full_m), rank
 # per-pair summary rows of the sharded evaluation loop
 import numpy as np
 from imp_release_amd import eval_loop
-table = np.arange(7 * 5, dtype=np.float64).reshape(7, 5)
+table = np.arange(7 * 9, dtype=np.float64).reshape(7, 9)
 s2, e2 = pdist.shard_range(7, rank, world)
 got = eval_loop.gather_rows_across_ranks(table[s2:e2], 7)
 assert np.array_equal(got, table), rank
@@ -296,3 +329,10 @@ def test_pair_stores_vs_the_reference_reader(tmp_path):
             assert tuple(d['image1'].shape) == (1,) + tuple(int(v) for v in z[f'img2_shape_{i}'])
             assert np.array_equal(d['T_0to1'], np.hstack([z[f'R_{i}'], z[f't_{i}'].reshape(3, 1)]))
         assert h5.record(i)['img_path1'] == recs[i]['img_path1'] and h5.record(i)['img_path2'] == recs[i]['img_path2']
+
+
+def test_superpoint_align_corners_rule():
+    """nets/superpoint.py:89 `int(torch.__version__[2]) > 2`: the third CHARACTER of the version string"""
+    from imp_release_amd.superpoint import reference_align_corners as rule
+    assert [rule(v) for v in ('1.2.0', '1.3.1', '1.7.1', '1.9.0', '1.10.2', '1.12.1', '2.0.1', '2.2.0', '2.3.0', '2.9.1', '2.10.0+rocm7.0')] == \
+        [False, True, True, True, False, False, False, False, True, True, False]

@@ -69,7 +69,7 @@ def main():
     if rank == 0:
         print(json.dumps({'model': a.model, 'pairs': n, 'n_gpus': world, 'workers_per_gpu': a.workers, 'pairs_per_s': n / dt,
                           'pose_step': 'reference cv2' if estimate_pose else 'none (no early exit)',
-                          'mean': dict(zip(eval_loop.SUMMARY_COLUMNS, table.mean(0).round(3).tolist()))}))
+                          'report': eval_loop.aggregate(table)}))
     if world > 1:
         dist.destroy_process_group()
 

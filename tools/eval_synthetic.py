@@ -5,8 +5,11 @@ N independent synthetic pairs through the iterative loop, sharded over the ranks
     python tools/eval_synthetic.py --pairs 16 --model EIMP --kpts 2048
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/eval_synthetic.py --pairs 4000 --model EIMP
 
---pose none: no pose is ever found (the loops run all 15 iterations); --pose gpu: the GPU pose step (imp_release_amd.pose, csrc/pose.hip:
-seeded 8-point RANSAC + cheirality vote, NOT OpenCV's MAGSAC) sits in the loop's estimate_pose slot, 7 calls per pair."""
+Pairs are two-view consistent (synthetic.make_two_view_pair: a known relative pose behind the re-observed keypoints), so the report
+of eval/eval_imp.py:213-227 - pose AUC@5/10/20/50, precision, matching score - is computed and printed like the reference's
+(on seeded random weights the numbers say how the pipeline behaves, not how well a trained matcher does).
+--pose none: no pose is ever found (the loops run all 15 iterations, pose errors are infinite); --pose gpu: the GPU pose step
+(imp_release_amd.pose, csrc/pose.hip: NOT OpenCV's MAGSAC) sits in the loop's estimate_pose slot, up to 7 calls per pair + 1."""
 import argparse, json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,7 +24,9 @@ def main():
     ap.add_argument('--kpts', type=int, default=2048)
     ap.add_argument('--bin-score', type=float, default=5.0)
     ap.add_argument('--workers', type=int, default=1, help='pairs in flight per GPU (model replicas + streams)')
-    ap.add_argument('--pose', choices=['none', 'gpu'], default='none')
+    ap.add_argument('--pose', choices=['none', 'gpu'], default='gpu')
+    ap.add_argument('--overlap', type=float, default=0.6)
+    ap.add_argument('--noise-px', type=float, default=0.5)
     a = ap.parse_args()
     rank, world, lr = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(lr)
@@ -42,15 +47,15 @@ def main():
 
     def host_pair(pid):
         if pid not in cache:
-            cache[pid] = synthetic.make_correlated_pair(a.kpts, a.kpts - 37, seed=1000 + pid)
+            cache[pid] = synthetic.make_two_view_pair(a.kpts, a.kpts - 37, seed=1000 + pid, overlap=a.overlap, noise_px=a.noise_px)
         return cache[pid]
 
     def provider(pid):
         pair = host_pair(pid)
-        d = {k: torch.from_numpy(v).to(dev) for k, v in pair.items() if k != 'image_shape'}
-        d['image0'] = d['image1'] = torch.zeros(pair['image_shape'], device=dev)
+        d = {k: torch.from_numpy(pair[k]).to(dev) for k in ('keypoints0', 'keypoints1', 'scores0', 'scores1', 'descriptors0', 'descriptors1')}
+        d['image0'] = d['image1'] = torch.empty(pair['image_shape'], device='meta')      # only .shape is read
         d['pts0_cpu'] = pair['keypoints0'][0]; d['pts1_cpu'] = pair['keypoints1'][0]
-        d['K0'] = d['K1'] = np.array([[520., 0, 320.], [0, 520., 240.], [0, 0, 1.]])
+        d.update({k: pair[k] for k in ('K0', 'K1', 'T_0to1', 'E')})
         return d
 
     s0, e0 = __import__('imp_release_amd').dist.shard_range(a.pairs, rank, world)
@@ -60,7 +65,7 @@ def main():
     kw = dict(eimp=a.model == 'EIMP', workers=a.workers, replicas=reps)
     if a.pose == 'gpu':
         from imp_release_amd import pose as gpose
-        kw['estimate_pose'] = lambda **k: gpose.estimate_pose(**{x: v for x, v in k.items() if x != 'method'})
+        kw['estimate_pose'] = gpose.estimate_pose
     eval_loop.run_pairs_sharded(m, provider, min(a.pairs, 2 * world * a.workers), **kw)      # warm-up
     torch.cuda.synchronize(); t0 = time.perf_counter()
     table = eval_loop.run_pairs_sharded(m, provider, a.pairs, **kw)
@@ -68,7 +73,7 @@ def main():
     if rank == 0:
         print(json.dumps({'model': a.model, 'pairs': a.pairs, 'n_gpus': world, 'kpts': a.kpts, 'workers_per_gpu': a.workers, 'pose': a.pose, 'pairs_per_s': a.pairs / dt,
                           'includes': 'H2D upload of every pair on the host path of each rank (pairs pre-generated)',
-                          'mean': dict(zip(eval_loop.SUMMARY_COLUMNS, table.mean(0).round(3).tolist()))}))
+                          'report': eval_loop.aggregate(table)}))
     if world > 1:
         dist.destroy_process_group()
 

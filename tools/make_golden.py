@@ -295,7 +295,7 @@ def case_metrics(name):
 def case_superpoint(name, spec):
     """nets/superpoint.py forward() on seeded random weights (superpoint_v1.pth is not available offline) and a synthetic image.
     spec['torch_version'] (optional) is patched over torch.__version__ during the call: nets/superpoint.py:89 picks grid_sample's
-    align_corners from that string (True only for '1.3'..'1.9'; False on the torch 2.x of this image)."""
+    align_corners from that string (True for minor versions 3..9 of torch 1.x / 2.x; False on the 2.10 of this image: '2.10.0'[2] == '1')."""
     if not wanted(name):
         return
     import tempfile
