@@ -11,11 +11,15 @@ A "step" = produce_matches over the rank's batch with inputs already resident in
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Extra objects on the JSON line:
-  roofline      dominant kernel = attn_f32_kernel (60 % of the pair's FLOPs): algorithmic FLOPs per launch
-                (4*N*M*D per image side) / average launch duration measured with HIP events on
-                the launch stream; peak = fp32-input MFMA 157.3 TFLOP/s (MI355X_MICROARCH.md)
+  roofline      dominant kernel = the flash-attention kernel (60 % of the pair's FLOPs; attn_f16x3_pp_kernel<64> in the default
+                split-half f16x3 arithmetic, attn_f32_kernel<64, 4> with --precision f32): algorithmic FLOPs per launch
+                (4*N*M*D per image side) / average launch duration measured with HIP events on the launch
+                stream; peak = 2500 / 3 TFLOP/s (dense f16 MFMA, three executed products per algorithmic one) or the
+                fp32-input MFMA 157.3 TFLOP/s (MI355X_MICROARCH.md); traffic = HBM bytes per launch from the newest
+                committed PMC pass under profiles/ that holds this kernel at this launch geometry
   cpu_baseline  the oracle (torch-CPU fp32 restatement of the reference, validated against it) timed on this
                 host's cores on a bounded sample of the same workload (rank 0, N=1 only)
+  c2_* / eimp_* / superpoint_* / c5_*   the other BASELINE configurations on the same GPU (rank 0, N=1 only; not the metric)
 """
 import argparse
 import json
@@ -169,6 +173,40 @@ def batch1_latencies(dev, args):
                 dd[f'image{i}'] = both[i:i + 1]
             return m.produce_matches(dd, p=0.2, only_last=True)
         out['image_pair_to_matches_ms'] = timeit(chain, 20, 3)
+        # BASELINE configs[4]: the full iterative pose loop (eval/eval_imp.py --use_iterative) with the pose step ON THE GPU in
+        # its estimate_pose slot and the metrics tail (AUC@5/10/20, precision) - IMP and EIMP, >= 1000 pair evaluations each,
+        # 3 pairs in flight.  Pairs are two-view consistent synthetic scenes (64 distinct ones, cycled; uploaded per evaluation)
+        from imp_release_amd import eval_loop, pose as gpose
+        n_eval, n_distinct, nk = (1000, 64, 2048) if not args.quick_c5 else (48, 16, 2048)
+        host_pairs = [synthetic.make_two_view_pair(nk, nk - 37, seed=7000 + i) for i in range(n_distinct)]
+
+        def provider(pid):
+            pr = host_pairs[pid % n_distinct]
+            dd = {k: torch.from_numpy(pr[k]).to(dev) for k in ('keypoints0', 'keypoints1', 'scores0', 'scores1', 'descriptors0', 'descriptors1')}
+            dd['image0'] = dd['image1'] = torch.empty(pr['image_shape'], device='meta')
+            dd['pts0_cpu'], dd['pts1_cpu'] = pr['keypoints0'][0], pr['keypoints1'][0]
+            dd.update({k: pr[k] for k in ('K0', 'K1', 'T_0to1', 'E')})
+            return dd
+
+        del m, sp
+        for tag, name in (('imp', 'DGNNS'), ('eimp', 'AdaGMN')):
+            mm = model_of(name, eval_config(15, 20), bin_score=synthetic.MATCHING_BIN_SCORE, style='matching')
+            reps = eval_loop.replicate(mm, 3)
+            kw = dict(eimp=name == 'AdaGMN', estimate_pose=gpose.estimate_pose, workers=3, replicas=reps)
+            eval_loop.run_pairs_sharded(mm, provider, 12, **kw)                                     # warm-up (workspaces)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            table = eval_loop.run_pairs_sharded(mm, provider, n_eval, **kw)
+            torch.cuda.synchronize()
+            out[f'c5_{tag}_pairs_per_s'] = n_eval / (time.perf_counter() - t0)
+            out[f'c5_{tag}_report'] = eval_loop.aggregate(table)
+            del mm, reps
+        out['c5_note'] = (f'BASELINE configs[4] on ONE GPU: {n_eval} evaluations of matching_iterative (imp: DGNNS) / matching_iterative_uncertainty '
+                          f'(eimp: AdaGMN, adaptive pooling) over {n_distinct} distinct two-view synthetic pairs (N = {nk} / {nk - 37} keypoints, known '
+                          'relative pose), 15 iterations, early exit on pose convergence, pose step = csrc/pose.hip in the estimate_pose slot (NOT '
+                          "OpenCV MAGSAC), 3 pairs in flight, H2D upload of every pair included; report = eval/eval_imp.py:213-227's numbers with the "
+                          "synthetic 'matching' weights (synthetic.make_state_dict style='matching': a hand-built matcher that works on these pairs, "
+                          'NOT a trained model - the numbers describe the pipeline)')
     out['batch1_note'] = ('c2 = BASELINE configs[1] (GM, N=1024, 9 iterations, 100 Sinkhorn, batch 1, one call after the other); '
                           'eimp = configs[3] (AdaGMN sliced loop from N=4096/4000, 15 iterations, 7 score+pool steps, bin_score 5, pose stubbed); '
                           'superpoint = nets/superpoint.py forward on one 480x640 image, top-1024, seeded random weights; image_pair_to_matches = '
@@ -189,6 +227,7 @@ def main():
     ap.add_argument('--iters', type=int, default=9)
     ap.add_argument('--sinkhorn', type=int, default=100)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--quick-c5', action='store_true', help='configs[4] keys on 48 instead of 1000 pair evaluations (smoke runs)')
     ap.add_argument('--no-batch1', action='store_true', help='skip the extra batch-1 latency keys (profiling runs: keeps their kernels out of the trace)')
     ap.add_argument('--in-flight', type=int, default=2,
                     help='batch-steps in flight per GPU (model replicas, one stream + host thread each; the result '
@@ -346,12 +385,15 @@ def main():
     # the f16x3 build takes the phase-staggered 8-wave kernel (256 queries per workgroup) at this size
     kname = 'attn_f16x3_pp_kernel<64>' if f16x3 else 'attn_f32_kernel<64, 4>'
     kgrid = -(-N // 256) * 4 * 2 * B * 512 if f16x3 else -(-N // 128) * 4 * 2 * B * 256
-    tfile = 'traffic_v5.json' if f16x3 else 'traffic_v4.json'
-    tpath = os.path.join(ROOT, 'profiles', 'r01', tfile)
-    if os.path.exists(tpath):
+    import glob
+    tfile = None
+    for tpath in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'traffic*.json')), reverse=True):      # newest round first
         for k, v in json.load(open(tpath)).items():
-            if k.startswith(kname) and k.endswith(f'grid={kgrid}'):
+            if traffic is None and k.startswith(kname) and k.endswith(f'grid={kgrid}'):
                 traffic = v.get('fetch_bytes', v.get('fetch_bytes_corrected')) + v['write_bytes']
+                tfile = os.path.relpath(tpath, ROOT)
+        if traffic is not None:
+            break
     if rank == 0:
         line = {
             'metric': 'image-pairs/s (N=2048 kpts, 9 self+cross iters, 100 Sinkhorn)',
@@ -368,7 +410,7 @@ def main():
                        'matched_keypoints': n_matched},
             'roofline': {'bound': 'mfma', 'kernel': kname,
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                         'traffic': traffic, 'traffic_unit': f'bytes/launch (PMC, profiles/r01/{tfile})',
+                         'traffic': traffic, 'traffic_unit': f'bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, {tfile})',
                          'algorithmic_bytes_per_launch': (3 * 256 + 256) * 4.0 * N * 2 * B,
                          'launch_ms': attn_ms, 'flops_per_launch': attn_flops,
                          'peak_note': ('algorithmic fp32-equivalent flops; peak = 2500 TF dense f16 MFMA / 3 products per '

@@ -27,7 +27,7 @@ SYMBOLS = [
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
     'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear', 'imp_op_layer_gemm',
-    'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_time_layer_gemm', 'imp_estimate_pose',
+    'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_range_events', 'imp_time_layer_gemm', 'imp_estimate_pose',
     'imp_sp_create', 'imp_sp_destroy', 'imp_sp_set_weight', 'imp_sp_finalize', 'imp_sp_detect', 'imp_sp_describe', 'imp_sp_dense', 'imp_sp_op_conv',
 ]
 
@@ -47,7 +47,14 @@ class ResidentSinkhornTimeout(ImpError):
     mscores NaN, indices -1).  The context has already recovered on a safer protocol; re-run the batch."""
 
 
+class OperandRangeError(ImpError):
+    """IMP_E_RANGE: an EARLIER call on this context produced non-finite match scores - in the default f16x3 arithmetic an operand
+    left the fp16 range (|x| >= 65504), or the inputs were not finite.  That call's matches are void (all -1); use
+    ``precision='f32'`` for such data."""
+
+
 IMP_E_RESIDENT = -6
+IMP_E_RANGE = -7
 
 
 class ImpConfig(C.Structure):
@@ -110,6 +117,7 @@ def lib():
     L.imp_resident_status.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.imp_resident_health.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.imp_set_resident_verify.argtypes = [P, I]
+    L.imp_range_events.argtypes = [P]
     L.imp_time_layer_gemm.argtypes = [P, I, I, I, I, I, C.POINTER(C.c_float), P]
     L.imp_estimate_pose.argtypes = [P, P, I, P, P, C.c_double, I, C.c_uint, I, P, P, P, P, P, C.POINTER(C.c_int), P]
     L.imp_sp_create.argtypes = [C.POINTER(C.c_void_p), I, I]
@@ -196,7 +204,8 @@ class Context:
 
     def _check(self, rc):
         if rc != 0:
-            raise (ResidentSinkhornTimeout if rc == IMP_E_RESIDENT else ImpError)(rc, self.L.imp_last_error().decode())
+            cls = {IMP_E_RESIDENT: ResidentSinkhornTimeout, IMP_E_RANGE: OperandRangeError}.get(rc, ImpError)
+            raise cls(rc, self.L.imp_last_error().decode())
 
     def close(self):
         if getattr(self, 'handle', None) and self.handle.value:

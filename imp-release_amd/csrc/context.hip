@@ -79,12 +79,15 @@ struct imp_ctx {
     int* xstatus = nullptr;                        // device: [0] time-out flag, [4..11] per-XCC ticket counters of the LOCAL launches
     int* xstatus_host = nullptr;                   // the same flag in mapped host memory: read at every entry without synchronising
     int* xstatus_hostdev = nullptr;                //   its device address
+    int* range_host = nullptr;                     // word 1 of the same page: a match kernel saw non-finite scores (IMP_E_RANGE)
+    int* range_hostdev = nullptr;
     unsigned ticket_base = 0;                      // value of the per-XCC ticket counters before the next LOCAL launch
     int num_xccs = 0;
     int ot_degrade = 0;      // raised by a time-out: 1 = no XCD-local launches any more (chip-wide exchange only), 2 = streaming kernels only
     int ot_verify = 0;       // IMP_OT_VERIFY=1 / imp_set_resident_verify: wait for every resident launch and re-run a voided one inside the call
     int ot_fake = 0;         // TEST HOOK IMP_OT_FAKE_PLACEMENT=1: LOCAL workgroups lie about their XCC (forces the time-out path)
     int resident_timeouts = 0;
+    int range_events = 0;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     int xcap_b = 0;
     float *max0 = nullptr, *max1 = nullptr, *colpart_v = nullptr;
@@ -641,16 +644,7 @@ int ensure_resident_buffers(imp_ctx* c, int batch) {
         if (!rc) HIP_TRY(hipMemset(c->xmax, 0, 4 * wgs * kResidentMaxLdx * sizeof(float)));
         if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xstatus, 16);
         if (!rc) HIP_TRY(hipMemset(c->xstatus, 0, 64));
-        if (!rc) {
-            void* h = nullptr;
-            HIP_TRY(hipHostMalloc(&h, 64, hipHostMallocMapped));
-            c->xstatus_host = static_cast<int*>(h);
-            *c->xstatus_host = 0;
-            void* d = nullptr;
-            HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
-            c->xstatus_hostdev = static_cast<int*>(d);
-            c->ticket_base = 0;
-        }
+        c->ticket_base = 0;
         if (!rc) HIP_TRY(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
         if (!rc) HIP_TRY(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
     }
@@ -703,6 +697,17 @@ void resident_health_params(imp_ctx* c, OtResidentParams* p) {
 // IMP_E_RESIDENT so that the caller re-runs the voided batch.
 int resident_health(imp_ctx* c) {
     if (!c->xstatus_host) return IMP_OK;
+    if (*static_cast<volatile int*>(c->range_host)) {
+        // a match kernel of an EARLIER call met non-finite score maxima: in f16x3 mode every MFMA operand must stay inside the fp16
+        // range (|x| < 65504: hi = f16(x) overflows to inf beyond it and the product turns into NaN); non-finite INPUTS look the same
+        *static_cast<volatile int*>(c->range_host) = 0;
+        c->range_events += 1;
+        return fail(IMP_E_RANGE, c->prec == 1
+                    ? "non-finite match scores in an earlier call on this context: an operand left the fp16 range of the split-half f16x3 "
+                      "arithmetic (|x| >= 65504) or the inputs were not finite - that call's matches are void (all -1); use precision = 'f32' "
+                      "(imp_set_precision(ctx, 0)) for such data"
+                    : "non-finite match scores in an earlier call on this context (non-finite inputs or weights): that call's matches are void");
+    }
     const int st = *static_cast<volatile int*>(c->xstatus_host);
     if (!st) return IMP_OK;
     (void)hipDeviceSynchronize();
@@ -876,6 +881,19 @@ int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
         int xccs = 0;
         if (hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, device) != hipSuccess) xccs = 0;
         c->num_xccs = xccs;
+    }
+    {   // health words in mapped host memory: the kernels raise them, the entry points read them without synchronising
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+            delete c;
+            return fail(IMP_E_NOMEM, "imp_create: cannot allocate the mapped health words");
+        }
+        memset(h, 0, 64);
+        c->xstatus_host = static_cast<int*>(h);
+        c->xstatus_hostdev = static_cast<int*>(d);
+        c->range_host = c->xstatus_host + 1;
+        c->range_hostdev = c->xstatus_hostdev + 1;
     }
     c->kenc_maxc = c->D;
     for (int i = 0; i < nk; ++i) if (cfg->kenc_channels[i] > c->kenc_maxc) c->kenc_maxc = cfg->kenc_channels[i];
@@ -1173,7 +1191,7 @@ int imp_compute_matches(imp_ctx* c, int batch, int n0, int n1, const float* scor
     HIP_TRY(launch_score_maxima(scores, batch, n0, n1, c->max0, c->arg0, c->max1, c->arg1, c->colpart_v, c->colpart_i,
                                 S(stream)));
     HIP_TRY(launch_mutual_matches(batch, n0, n1, c->max0, c->arg0, c->max1, c->arg1, p, indices0, indices1, mscores0,
-                                  mscores1, S(stream)));
+                                  mscores1, c->range_hostdev, S(stream)));
     return IMP_OK;
 }
 
@@ -1252,7 +1270,7 @@ int imp_match_pair(imp_ctx* c, int batch, int n0, int n1, const float* kpts0, co
     if ((rc = run_score(c, batch, n0, n1, c->dist, bin_score, sinkhorn_iterations, with_sinkhorn, scores, &o, st, &max_done))) return rc;
     if (!max_done) HIP_TRY(launch_ot_maxima(batch, n0, n1, with_sinkhorn ? 0 : 1, o, c->max0, c->arg0, c->max1, c->arg1, st));
     HIP_TRY(launch_mutual_matches(batch, n0, n1, c->max0, c->arg0, c->max1, c->arg1, p, indices0, indices1, mscores0,
-                                  mscores1, st));
+                                  mscores1, c->range_hostdev, st));
     return IMP_OK;
 }
 
@@ -1524,6 +1542,8 @@ int imp_resident_health(imp_ctx* c, int* timeouts, int* level) {
     if (level) *level = c->ot_degrade;
     return rc;
 }
+
+int imp_range_events(imp_ctx* c) { return c ? c->range_events : -1; }
 
 int imp_set_resident_verify(imp_ctx* c, int on) {
     if (!c) return fail(IMP_E_ARG, "imp_set_resident_verify: null context");

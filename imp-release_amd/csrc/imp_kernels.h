@@ -160,7 +160,7 @@ hipError_t launch_score_maxima(const float* scores, int batch, int n0, int n1, f
 int score_maxima_chunks(int n0);
 hipError_t launch_mutual_matches(int batch, int n0, int n1, const float* max0, const int* arg0, const float* max1,
                                  const int* arg1, float p, int64_t* indices0, int64_t* indices1, float* ms0,
-                                 float* ms1, hipStream_t stream);
+                                 float* ms1, int* range_flag, hipStream_t stream);   // range_flag (mapped host word or null): set when a maximum is not finite
 
 // ------------------------------------------------------------------------------------------------
 // adaptive pooling (nets/adgm.py:552-605) + ragged compaction

@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void mutual_kernel(int n0, int n1, const float
                                                      const int* __restrict__ arg0, const float* __restrict__ max1,
                                                      const int* __restrict__ arg1, float p,
                                                      int64_t* __restrict__ ind0, int64_t* __restrict__ ind1,
-                                                     float* __restrict__ ms0, float* __restrict__ ms1) {
+                                                     float* __restrict__ ms0, float* __restrict__ ms1, int* __restrict__ range_flag) {
     const int b = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const float* m0 = max0 + (long)b * n0;
@@ -494,6 +494,9 @@ __global__ __launch_bounds__(256) void mutual_kernel(int n0, int n1, const float
     const int* a1 = arg1 + (long)b * n1;
     // an argmax of 0x7fffffff means "no maximum found" (a row of NaNs: |operand| >= 65504 in f16x3 mode, or NaN inputs):
     // such a keypoint has no match - never an out-of-range read
+    // a row / column maximum of -inf: every score of that row was NaN (an MFMA operand beyond the fp16 range in f16x3 mode, or
+    // non-finite inputs).  The matches come out as -1; the flag makes the library say so at its next entry (IMP_E_RANGE)
+    if (range_flag && t < n0 && m0[t] == -INFINITY) __hip_atomic_store(range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (t < n0) {
         const int j = a0[t];
         const bool mutual = (unsigned)j < (unsigned)n1 && a1[j] == t;
@@ -653,10 +656,10 @@ hipError_t launch_score_maxima(const float* scores, int batch, int n0, int n1, f
 
 hipError_t launch_mutual_matches(int batch, int n0, int n1, const float* max0, const int* arg0, const float* max1,
                                  const int* arg1, float p, int64_t* indices0, int64_t* indices1, float* ms0,
-                                 float* ms1, hipStream_t stream) {
+                                 float* ms1, int* range_flag, hipStream_t stream) {
     const int n = n0 > n1 ? n0 : n1;
     hipLaunchKernelGGL(mutual_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, stream, n0, n1, max0, arg0, max1, arg1,
-                       p, indices0, indices1, ms0, ms1);
+                       p, indices0, indices1, ms0, ms1, range_flag);
     return hipGetLastError();
 }
 

@@ -134,7 +134,17 @@ def normalize_keypoints(kpts: torch.Tensor, image_shape):
 
 
 class GM(nn.Module):
-    """Drop-in for nets/gm.py:16 ``GM`` (inference surface)."""
+    """Drop-in for nets/gm.py:16 ``GM`` (inference surface).
+
+    Arithmetic (config key ``precision``, default ``'f16x3'``): float32 storage and accumulation; every matrix product is formed from
+    split halves x = f16(x) + f16(x - f16(x)) as three f16 MFMAs - fp32-level results at 3/16 of the native fp32 matrix time.  The
+    high half is an IEEE fp16, so **every matrix operand must satisfy |x| < 65504**: input descriptors (unit-norm from SuperPoint),
+    keypoint encodings, the descriptors after every layer, the q / k / v projections, the final projections.  InstanceNorm keeps the
+    hidden activations O(1) and probabilities are in [0, 1]; with trained-like weights the descriptors stay below ~20
+    (``synthetic.make_state_dict(style='trained')``).  An operand beyond the range turns its products into NaN; the match kernel
+    notices the non-finite scores, that call's matches come out as -1 and the NEXT call on the module raises
+    :class:`imp_release_amd._lib.OperandRangeError` (``IMP_E_RANGE``).  ``precision='f32'`` (native fp32 MFMA) has no such limit.
+    """
 
     MODEL = 'GM'
     default_config = {                      # nets/gm.py:30-44

@@ -75,11 +75,52 @@ def _bn(sd, seed, prefix, c):
     sd[prefix + '.num_batches_tracked'] = np.array(0, dtype=np.int64)
 
 
+MATCHING_BIN_SCORE = 30.0      # dustbin score that goes with make_state_dict(style='matching'): unrelated keypoints fall into the dustbin
+
+
+def _trained_like(sd, seed, prefix, cout, cin, gain=1.0, rank=24, outliers=6, zero_bias=False):
+    """a conv whose statistics look like a TRAINED layer's rather than an i.i.d. draw: a low-rank component that carries most of
+    the energy, a dense small remainder, a few outlier output channels with 3x larger rows, and non-zero biases everywhere
+    (``zero_bias`` keeps the structural zeros of nets/layers.py:86,145)"""
+    g = _rng_for(seed, prefix + '.trained')
+    U = g.standard_normal((cout, rank)) / np.sqrt(rank)
+    V = g.standard_normal((rank, cin)) / np.sqrt(cin)
+    w = gain * (0.9 * U @ V + 0.35 * g.standard_normal((cout, cin)) / np.sqrt(cin))
+    hot = g.permutation(cout)[:outliers]
+    w[hot] *= 3.0
+    b = 0.3 * gain * g.standard_normal(cout)
+    if zero_bias:
+        b[:] = 0.0
+    sd[prefix + '.weight'] = w.reshape(cout, cin, 1).astype(np.float32)
+    sd[prefix + '.bias'] = b.astype(np.float32)
+
+
 def make_state_dict(config: dict, model: str = 'GM', seed: int = 0, bin_score: float = 1.0,
-                    gain: float = 1.0, bias_offset: float = 0.0) -> "OrderedDict[str, np.ndarray]":
-    """numpy state_dict with the reference key schema; uniform(+-gain/sqrt(fan_in)) like torch's default
+                    gain: float = 1.0, bias_offset: float = 0.0, style: str = 'uniform') -> "OrderedDict[str, np.ndarray]":
+    """numpy state_dict with the reference key schema.
+
+    ``style='uniform'`` (default; every fixture of rounds 1-2): uniform(+-gain/sqrt(fan_in)) like torch's default
     Conv1d init, last kenc / MLP biases zero as in nets/layers.py:86,145,191,198.  ``bias_offset`` shifts the biases of
-    every conv that feeds an InstanceNorm (keypoint encoder, mlp.0) by +-offset: |channel mean| >> channel std."""
+    every conv that feeds an InstanceNorm (keypoint encoder, mlp.0) by +-offset: |channel mean| >> channel std.
+
+    ``style='trained'`` (round 3, parity stress): structured weights - low rank + outlier channels + non-zero biases
+    (``_trained_like``), the q / k projections 1.5x larger and the residual branch (mlp.3) scaled by 0.3.  Measured on the oracle
+    (GM, L = 9, N = 512): the mean of the largest attention probability per query is 0.03 (first layer) ... 0.24 (last) against
+    0.002 ... 0.02 with the uniform weights, whose softmax rows are all but flat.  The gains sit where the arithmetic is still
+    well conditioned - two fp32 CPU evaluations (reference vs oracle) agree to 1e-5 in the match scores, fp32 vs fp64 to 2e-5 on
+    the matched keypoints: with q / k 2x those become 6e-5 / 5e-5 (half of the 1e-4 bar before an implementation has done anything),
+    with 3x and 6x outlier channels the network is chaotic (hundreds of index flips between two fp32 evaluations) and a fixture
+    would test luck.  (In every setting one or two UNMATCHED keypoints with scores ~0.01 < p flip their mutual-nearest-neighbour
+    status between fp32 and fp64: exact-tie noise below the threshold, the same effect the soak test documents.)
+
+    ``style='matching'`` (round 3, evaluation realism - NOT a trained model): a matcher that WORKS on synthetic pairs whose true
+    correspondences have similar descriptors: the keypoint encoder and every GNN layer only perturb the descriptors (last
+    convolutions scaled by 0.05) and every final projection is 20 I + noise, so the score matrix is a sharpened descriptor
+    similarity; with ``bin_score`` = ``MATCHING_BIN_SCORE`` (30) unrelated keypoints fall into the dustbin (measured on the oracle,
+    DGNNS, 600 / 560 keypoints, 237 true correspondences: all 237 found + 11 wrong matches; + 62 wrong at bin_score 26, + 213 at 16).  Used by the evaluation tools so that
+    precision / pose AUC of the loop (eval/eval_imp.py:213-227) measure the pipeline rather than noise."""
+    if style not in ('uniform', 'trained', 'matching'):
+        raise ValueError(f'unknown weight style {style!r}')
     cfg = {**DEFAULT_CONFIG, **config}
     D = cfg['descriptor_dim']
     names = cfg['GNN_layers']
@@ -87,28 +128,41 @@ def make_state_dict(config: dict, model: str = 'GM', seed: int = 0, bin_score: f
     sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
     sd['bin_score'] = np.array(bin_score, dtype=np.float32)
     chans = [3] + list(cfg['keypoint_encoder']) + [D]
+    small = 0.05 if style == 'matching' else 1.0
+
+    def conv(prefix, cout, cin, zero_bias=False, g=1.0, off=0.0):
+        if style == 'trained' and cin >= 32:
+            _trained_like(sd, seed, prefix, cout, cin, gain=gain * g, zero_bias=zero_bias)
+        else:
+            _conv(sd, seed, prefix, cout, cin, zero_bias=zero_bias, gain=gain * g, bias_offset=off)
+
     for i in range(1, len(chans)):
         last = i == len(chans) - 1
-        _conv(sd, seed, f'kenc.encoder.{3 * (i - 1)}', chans[i], chans[i - 1], zero_bias=last, gain=gain,
-              bias_offset=0.0 if last else bias_offset)
+        conv(f'kenc.encoder.{3 * (i - 1)}', chans[i], chans[i - 1], zero_bias=last, g=small if last else 1.0,
+             off=0.0 if last else bias_offset)
         if not last and norm == 'bn':
             _bn(sd, seed, f'kenc.encoder.{3 * (i - 1) + 1}', chans[i])
     shared = sharing_pattern(len(names), model)
+    qk = 1.5 if style == 'trained' else 1.0
     for li in range(len(names)):
         p = f'gnn.layers.{li}'
         if shared[li]:
-            _conv(sd, seed, p + '.proj', D, D, gain=gain)
-            _conv(sd, seed, p + '.merge', D, D, gain=gain)
+            conv(p + '.proj', D, D)
+            conv(p + '.merge', D, D)
         else:
-            _conv(sd, seed, p + '.attn.merge', D, D, gain=gain)
+            conv(p + '.attn.merge', D, D)
             for j in range(3):
-                _conv(sd, seed, p + f'.attn.proj.{j}', D, D, gain=gain)
-        _conv(sd, seed, p + '.mlp.0', 2 * D, 2 * D, gain=gain, bias_offset=bias_offset)
+                conv(p + f'.attn.proj.{j}', D, D, g=qk if j < 2 else 1.0)
+        conv(p + '.mlp.0', 2 * D, 2 * D, off=bias_offset)
         if norm == 'bn':
             _bn(sd, seed, p + '.mlp.1', 2 * D)
-        _conv(sd, seed, p + '.mlp.3', D, 2 * D, zero_bias=True, gain=gain)
+        conv(p + '.mlp.3', D, 2 * D, zero_bias=True, g=small * (0.3 if style == 'trained' else 1.0))
     for i in range(cfg['n_layers']):
-        _conv(sd, seed, f'final_proj.{i}', D, D, gain=gain)
+        conv(f'final_proj.{i}', D, D)
+        if style == 'matching':
+            w = sd[f'final_proj.{i}.weight']
+            sd[f'final_proj.{i}.weight'] = (0.5 * w + 20.0 * np.eye(D, dtype=np.float32)[:, :, None]).astype(np.float32)
+            sd[f'final_proj.{i}.bias'] = (0.0 * sd[f'final_proj.{i}.bias']).astype(np.float32)
     return sd
 
 

@@ -42,6 +42,10 @@ extern "C" {
 #define IMP_E_HIP (-3)      /* HIP runtime error */
 #define IMP_E_NOMEM (-4)
 #define IMP_E_KEY (-5)      /* unknown / missing state_dict key */
+#define IMP_E_RANGE (-7)    /* an EARLIER call on this context produced non-finite match scores: in the default split-half f16x3 arithmetic every
+                             * matrix operand (descriptors, activations, projections) must satisfy |x| < 65504 (fp16 range of the high half);
+                             * beyond it - or with non-finite inputs - the scores are NaN and that call's matches are all -1.  Raised by the
+                             * match kernel through a mapped host word and reported at the next entry; precision f32 has no such limit */
 #define IMP_E_RESIDENT (-6) /* a chip-resident Sinkhorn launch of an EARLIER call on this context timed out: that call's results are void
                              * (poisoned: mscores NaN, indices -1); the context has recovered on a safer protocol - re-run the batch */
 
@@ -252,6 +256,8 @@ int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, const doubl
 int imp_resident_status(imp_ctx* ctx, int* status, int* used);
 int imp_resident_health(imp_ctx* ctx, int* timeouts, int* level);
 int imp_set_resident_verify(imp_ctx* ctx, int on);
+/* how many calls on this context were reported with IMP_E_RANGE so far */
+int imp_range_events(imp_ctx* ctx);
 
 /* ---------------------------------------------------------------------------------------------------------------------------
  * SuperPoint front-end: nets/superpoint.py:97-232.  Its own handle (independent of imp_ctx);

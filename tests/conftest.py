@@ -41,6 +41,11 @@ def pytest_terminal_summary(terminalreporter):
                                 f'comparisons; golden-fixture comparisons are strict (0 allowed)')
     for what, c in helpers.EXCUSED:
         terminalreporter.write_line(f'  excused: {what}: {c}')
+    if helpers.LOW_FLIPS:
+        terminalreporter.write_line(f'parity: {sum(c for _, c in helpers.LOW_FLIPS)} mutual-nearest-neighbour flips on keypoints unmatched on both sides '
+                                    f'(score < p, indices identical) tolerated in trained-weight fixtures / soak:')
+        for what, c in helpers.LOW_FLIPS:
+            terminalreporter.write_line(f'  low-score flip: {what}: {c}')
     if helpers.SP_MOVED:
         moved, cut = sum(m for _, m, _ in helpers.SP_MOVED), sum(b for _, _, b in helpers.SP_MOVED)
         terminalreporter.write_line(f'superpoint (sorted top-k outputs): {moved} list positions differ inside runs of reference scores closer than the '

@@ -372,3 +372,31 @@ def test_attention_extreme_logits(gm, scale, B, nq, nk):
     # the logits themselves carry an absolute fp32 error ~ |S| * 1e-6, which the exponential turns into a relative one
     assert e_out < 3e-5 * max(1.0, scale * scale), f'attention out err {e_out:.3e}'
     assert e_lse < 2e-5, f'attention lse rel err {e_lse:.3e}'
+
+
+def test_operand_beyond_the_fp16_range_is_reported_not_silent():
+    """f16x3 arithmetic: |x| >= 65504 in a matrix operand makes the scores NaN.  The match kernel notices, the matches of that call
+    are void (-1) and the next entry point raises IMP_E_RANGE; precision f32 handles the same data (VERDICT r2 weak #2)"""
+    from imp_release_amd._lib import OperandRangeError
+    cfg = eval_config(n_layers=2, sinkhorn_iterations=10)
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=3)
+    pair = synthetic.make_correlated_pair(300, 280, seed=5)
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+    big = dict(data)
+    big['descriptors0'] = data['descriptors0'] * 1.0
+    big['descriptors0'][0, 7, 3] = 7.0e4                           # one operand beyond the fp16 range
+    m = make_hip_model('GM', cfg, sd)
+    with torch.no_grad():
+        out = m.produce_matches(big, p=0.2, only_last=True)
+        torch.cuda.synchronize()
+        assert (out['indices0'][-1] == -1).all()                   # void, never plausible garbage
+        with pytest.raises(OperandRangeError):
+            m.produce_matches(data, p=0.2, only_last=True)
+        good = m.produce_matches(data, p=0.2, only_last=True)      # the context keeps working
+        assert (good['indices0'][-1] >= 0).any()
+        m32 = make_hip_model('GM', cfg, sd, precision='f32')
+        o32 = m32.produce_matches(big, p=0.2, only_last=True)      # native fp32 MFMA: no such limit
+        m32.produce_matches(data, p=0.2, only_last=True)           # ... and nothing to report
+    torch.cuda.synchronize()
+    assert torch.isfinite(o32['mscores0'][-1]).all() and m._ensure_ctx().L.imp_range_events(m._ensure_ctx().handle) == 1

@@ -21,7 +21,7 @@ def _cpu(x):
 
 
 @pytest.mark.parametrize('precision', ['f16x3', 'f32'])
-@pytest.mark.parametrize('name', golden_names(['gm_l', 'dgnns_l', 'adagmn_masked']))
+@pytest.mark.parametrize('name', golden_names(['gm_l', 'dgnns_l', 'adagmn_masked', 'gm_trained', 'dgnns_trained']))
 def test_produce_matches_vs_golden(name, precision):
     spec, z = load_golden(name)
     cfg, sd, data = build_case(spec, DEV)
@@ -75,7 +75,8 @@ def _loop_data(data):
 
 
 LOOPS = [('imp_loop_n400', False), ('imp_loop_exit_n400', False), ('eimp_loop_sliced_n1024', True),
-         ('eimp_loop_uncert_exit_n1024', True), ('eimp_loop_uncert_full_n700', True)]
+         ('eimp_loop_uncert_exit_n1024', True), ('eimp_loop_uncert_full_n700', True),
+         ('eimp_loop_trained_n1024', True)]       # trained-like weights (synthetic style='trained'): peaky attention
 
 
 def _check_loop_against_golden(name, z, data, ret, trace, stub):
@@ -88,8 +89,11 @@ def _check_loop_against_golden(name, z, data, ret, trace, stub):
     for k, t_ in enumerate(trace):
         assert np.array_equal(t_['pts0'], k0[z[f'it{k}_keep0']]) and np.array_equal(t_['pts1'], k1[z[f'it{k}_keep1']]), \
             f'{name}: keep set it{k}'
+        # trained-like weights (peaky attention): one or two UNMATCHED keypoints with scores ~0.01 < p sit on exact mutual-nearest-
+        # neighbour ties that flip between any two fp32 evaluations (reference fp32 vs fp64 shows the same, synthetic.make_state_dict);
+        # indices stay identical.  Tolerated there, counted in the terminal summary; every other fixture: none
         compare_matches(t_['indices0'], t_['mscores0'], z[f'it{k}_indices0'], z[f'it{k}_mscores0'], 0.1, TOL,
-                        f'{name} it{t_["it"]}')
+                        f'{name} it{t_["it"]}', low_score_flips=2 if 'trained' in name else 0)
     assert np.array_equal(p0, z['pts0_final']) and np.array_equal(p1, z['pts1_final']), f'{name}: final keypoint sets'
     # the returned indices: after an early exit they are the inlier-filtered matches (eval/matching.py:112-113)
     assert np.array_equal(i0, z['indices0']), f'{name}: returned indices ({(i0 != z["indices0"]).sum()} differ)'
@@ -518,7 +522,7 @@ def test_evaluation_tail_on_two_view_pairs_with_the_gpu_pose_step(eimp):
     from imp_release_amd import pose as gpose
     name = 'AdaGMN' if eimp else 'DGNNS'
     cfg = eval_config()
-    sd = synthetic.make_state_dict(cfg, name, seed=9, bin_score=5.0)
+    sd = synthetic.make_state_dict(cfg, name, seed=9, bin_score=synthetic.MATCHING_BIN_SCORE, style='matching')
     m = make_hip_model(name, cfg, sd)
 
     def provider(pid):
@@ -536,8 +540,8 @@ def test_evaluation_tail_on_two_view_pairs_with_the_gpu_pose_step(eimp):
     rep = eval_loop.aggregate(seq)
     print(name, rep)
     assert rep['pairs'] == 6 and not np.isnan(seq[:, :4]).any()
-    # the re-observed keypoints carry near-identical descriptors: even a random-weight matcher pairs them up, so the final matches are
-    # mostly epipolar-consistent and the pose is recovered
+    # style='matching' weights pair up the re-observed keypoints (near-identical descriptors), so the final matches are mostly
+    # epipolar-consistent and the pose is recovered
     assert rep['precision'] > 60.0 and rep['pose_found'] == 1.0 and rep['auc@20'] > 50.0
 
 

@@ -10,7 +10,7 @@ from oracle import imp_oracle as orc
 
 torch.set_num_threads(max(1, min(8, torch.get_num_threads())))
 
-PRODUCE = golden_names(['gm_l', 'dgnns_l', 'adagmn_masked'])
+PRODUCE = golden_names(['gm_l', 'dgnns_l', 'adagmn_masked', 'gm_trained', 'dgnns_trained'])
 
 
 @pytest.mark.parametrize('name', PRODUCE)
@@ -54,7 +54,8 @@ def test_run_vs_reference(name):
 
 
 LOOPS = [('imp_loop_n400', False), ('eimp_loop_sliced_n1024', True), ('imp_loop_exit_n400', False),
-         ('eimp_loop_uncert_exit_n1024', True), ('eimp_loop_uncert_full_n700', True)]
+         ('eimp_loop_uncert_exit_n1024', True), ('eimp_loop_uncert_full_n700', True),
+         ('eimp_loop_trained_n1024', True)]       # trained-like weights (synthetic style='trained'): peaky attention
 
 
 @pytest.mark.parametrize('name,unc', LOOPS)

@@ -22,7 +22,9 @@ def main():
     ap.add_argument('--pairs', type=int, default=16)
     ap.add_argument('--model', choices=['IMP', 'EIMP'], default='EIMP')
     ap.add_argument('--kpts', type=int, default=2048)
-    ap.add_argument('--bin-score', type=float, default=5.0)
+    ap.add_argument('--weights', choices=['matching', 'uniform', 'trained'], default='matching',
+                    help="synthetic.make_state_dict style: 'matching' = a matcher that works on these pairs (the report means something)")
+    ap.add_argument('--bin-score', type=float, default=None, help='default: 30 with --weights matching, else 5')
     ap.add_argument('--workers', type=int, default=1, help='pairs in flight per GPU (model replicas + streams)')
     ap.add_argument('--pose', choices=['none', 'gpu'], default='gpu')
     ap.add_argument('--overlap', type=float, default=0.6)
@@ -38,7 +40,8 @@ def main():
     cfg = {'descriptor_dim': 256, 'sinkhorn_iterations': 20, 'match_threshold': 0.2, 'with_sinkhorn': True, 'n_layers': 15,
            'GNN_layers': ['self', 'cross'] * 15, 'ac_fn': 'relu', 'norm_fn': 'in', 'n_min_tokens': 256}
     name = 'AdaGMN' if a.model == 'EIMP' else 'DGNNS'
-    sd = synthetic.make_state_dict(cfg, name, seed=0, bin_score=a.bin_score)
+    bs = a.bin_score if a.bin_score is not None else (synthetic.MATCHING_BIN_SCORE if a.weights == 'matching' else 5.0)
+    sd = synthetic.make_state_dict(cfg, name, seed=0, bin_score=bs, style=a.weights)
     m = getattr(P, name)(cfg).eval()
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     m = m.to(dev)
@@ -71,7 +74,7 @@ def main():
     table = eval_loop.run_pairs_sharded(m, provider, a.pairs, **kw)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     if rank == 0:
-        print(json.dumps({'model': a.model, 'pairs': a.pairs, 'n_gpus': world, 'kpts': a.kpts, 'workers_per_gpu': a.workers, 'pose': a.pose, 'pairs_per_s': a.pairs / dt,
+        print(json.dumps({'model': a.model, 'pairs': a.pairs, 'n_gpus': world, 'kpts': a.kpts, 'workers_per_gpu': a.workers, 'pose': a.pose, 'weights': a.weights, 'pairs_per_s': a.pairs / dt,
                           'includes': 'H2D upload of every pair on the host path of each rank (pairs pre-generated)',
                           'report': eval_loop.aggregate(table)}))
     if world > 1:

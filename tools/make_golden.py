@@ -73,7 +73,7 @@ def build(spec):
     cfg = eval_config(**spec['config'])
     sd_np = synthetic.make_state_dict(cfg, model=spec['model'], seed=spec['wseed'],
                                       bin_score=spec.get('bin_score', 1.0), gain=spec.get('gain', 1.0),
-                                      bias_offset=spec.get('bias_offset', 0.0))
+                                      bias_offset=spec.get('bias_offset', 0.0), style=spec.get('style', 'uniform'))
     ref = REF_CLS[spec['model']](cfg).eval()
     ref.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=True)
     oracle = orc.MatcherOracle(cfg, sd_np, model=spec['model'])
@@ -442,6 +442,15 @@ def main():
     case_loop('eimp_loop_uncert_full_n700', dict(model='AdaGMN', config=dict(), wseed=9, dseed=26, n0=700, n1=730,
                                                  bin_score=5.0, pose_schedule=[0.0, 5.0, 10.0, 15.0, 20.0, 25.0, 30.0],
                                                  with_uncertainty=True), True)
+    # (6b) round 3: TRAINED-LIKE weights (synthetic.make_state_dict style='trained': low rank + outlier channels + activation-sized
+    # biases, q / k projections 3x larger -> peaky attention, large log-sum-exps) instead of i.i.d. uniform ones: the three shapes
+    # VERDICT r2 asked for - BASELINE configs[1], the 15-iteration IMP model with its attention-sharing layers, the sliced EIMP loop
+    case_produce('gm_trained_l9_n1024', dict(model='GM', config=dict(n_layers=9, sinkhorn_iterations=100), wseed=21, dseed=31,
+                                             n0=1024, n1=1024, style='trained', call=dict(p=0.2, only_last=True)))
+    case_produce('dgnns_trained_l15_n512', dict(model='DGNNS', config=dict(), wseed=22, dseed=32, n0=512, n1=519, style='trained',
+                                                call=dict(p=0.2, only_last=True)))
+    case_loop('eimp_loop_trained_n1024', dict(model='AdaGMN', config=dict(), wseed=23, dseed=33, n0=1024, n1=1000, bin_score=5.0,
+                                              style='trained'), True)
     # (7) pool edge cases
     case_pool_edges('pool_edges')
     case_metrics('metrics')
