@@ -456,6 +456,11 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
         for (int j = 0; j < LK; ++j) {
             const int f = tid + j * NT;
             const int row = f / (DH / 4), c4 = (f % (DH / 4)) * 4;
+            if (p.kv_planes) {                 // EXPERIMENT: the rows already ARE the [hi | lo] image (16-byte chunk c4 / 4 of it): plain copy
+                *reinterpret_cast<f32x4*>(ks + row * KROW + c4) = rk[j];
+                *reinterpret_cast<f32x4*>(vs + row * VROW + c4) = rv[j];
+                continue;
+            }
             u32x2 hi, lo;
             split4(rk[j], hi, lo);
             *reinterpret_cast<u32x2*>(ks + row * KROW + (c4 >> 1)) = hi;
@@ -836,6 +841,46 @@ size_t attention_f16x3_split_units(const AttnParams& p, int batch) {
     return (size_t)((maxq + 255) / 256) * IMP_NUM_HEADS * p.nside * batch;
 }
 
+// EXPERIMENT support: k / v head segments -> [hi | lo] half images in place (one wave per (row, head); lane = channel, 2 per lane at dh = 32)
+__global__ __launch_bounds__(256) void attn_kv_planes_kernel(float* base, long rows, int ld, int col0, int dh) {
+    const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (unit >= rows * IMP_NUM_HEADS) return;
+    const long row = unit / IMP_NUM_HEADS;
+    const int h = (int)(unit % IMP_NUM_HEADS);
+    float* seg = base + row * ld + col0 + h * dh;
+    const float x = lane < dh ? seg[lane] : 0.f;
+    const _Float16 hi = (_Float16)x;
+    const _Float16 lo = (_Float16)(x - (float)hi);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    _Float16* o = reinterpret_cast<_Float16*>(seg);
+    if (lane < dh) { o[lane] = hi; o[dh + lane] = lo; }
+}
+
+// the inverse for readers that want fp32 (pooling's column sums, probability materialisation): x' = hi + lo, exact in fp32 (22 bits)
+__global__ __launch_bounds__(256) void attn_kv_unplanes_kernel(const float* base, long rows, int ld, int col0, int dh, float* out, int ldo) {
+    const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (unit >= rows * IMP_NUM_HEADS) return;
+    const long row = unit / IMP_NUM_HEADS;
+    const int h = (int)(unit % IMP_NUM_HEADS);
+    const _Float16* seg = reinterpret_cast<const _Float16*>(base + row * ld + col0 + h * dh);
+    if (lane < dh) out[row * ldo + h * dh + lane] = (float)seg[lane] + (float)seg[dh + lane];
+}
+
+hipError_t launch_attn_kv_unplanes(const float* base, long rows, int ld, int col0, int dh, float* out, int ldo, hipStream_t stream) {
+    const long units = rows * IMP_NUM_HEADS;
+    hipLaunchKernelGGL(attn_kv_unplanes_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, stream, base, rows, ld, col0, dh, out, ldo);
+    return hipGetLastError();
+}
+
+hipError_t launch_attn_kv_planes(float* base, long rows, int ld, int col0, int dh, hipStream_t stream) {
+    const long units = rows * IMP_NUM_HEADS;
+    hipLaunchKernelGGL(attn_kv_planes_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, stream, base, rows, ld, col0, dh);
+    return hipGetLastError();
+}
+
 hipError_t launch_attention_f16x3(const AttnParams& p, int batch, hipStream_t stream) {
     int maxq = p.side[0].nq;
     if (p.nside == 2 && p.side[1].nq > maxq) maxq = p.side[1].nq;
@@ -856,6 +901,8 @@ hipError_t launch_attention_f16x3(const AttnParams& p, int batch, hipStream_t st
     };
     if (force_waves) return lockstep(force_waves);
     const int nsplit = attention_f16x3_splits(p, batch);
+    if (p.kv_planes)              // split-half K / V images are staged by the ping-pong kernel only (any size: rows past nq / nk are clamped / masked)
+        return p.dh == 64 ? launch_pp<64>(p, batch, maxq, nsplit, stream) : launch_pp<32>(p, batch, maxq, nsplit, stream);
     if (variant == 2) return p.dh == 64 ? launch_pp<64>(p, batch, maxq, nsplit, stream) : launch_pp<32>(p, batch, maxq, nsplit, stream);
     // The phase-staggered 256-query kernel wins whenever its workgroups cover a good part of the chip (measured equal or
     // faster than the lock-step kernels from 64 workgroups up: 78 vs 101 us at B = 3, N = 2048).  Below that (one pair of

@@ -42,6 +42,7 @@ struct AttnCache {   // cached operands of the last non-shared layer of a kind (
     bool valid = false;
     int batch = 0, n[2] = {0, 0};
     bool masked[2] = {false, false};   // key mask of image 0 / image 1 in effect when it was computed
+    bool kv_image = false;             // the k | v slots of qkv[kind] hold split-half images (AttnParams::kv_planes), not fp32
 };
 
 }  // namespace
@@ -98,6 +99,8 @@ struct imp_ctx {
     int ot_hier = 1;         // two-XCDs-per-pair resident launches (hierarchical column sums) when a pair fits 64 CUs and B <= 4 (IMP_OT_HIER=0 disables)
     int ot_local = 1;        // XCD-local resident Sinkhorn launches when a pair fits one XCD (IMP_OT_LOCAL=0 disables)
     unsigned* stat_cnt = nullptr;   // [cap_b][2] tickets of the statistics merge inside the MLP0 launch (gemm_wf.hip)
+    int kv_image = 1;        // IMP_KV_IMAGE=0: projections write K / V as fp32 (round-2 format) instead of the split-half image attention copies
+    float* kf32[2] = {};     // per image: K of a cached attention converted back to fp32 [B][n][D] (pooling / probability readers)
     int wf_chain = 1;        // IMP_WF_CHAIN=0: never compute the next layer's projection inside the MLP3 launch
     long wf_chain_min_tiles = 160, wf_max_tiles = 640, wf_proj_max_tiles = 40;     // IMP_WF_CHAIN_MIN / IMP_WF_MAX / IMP_WF_PROJ_MAX
     int use_wf = 1;          // weight-fragment GEMMs (gemm_wf.hip) for the layer convolutions when f16x3, D = 256, relu + InstanceNorm; IMP_GEMM_WF=0 disables
@@ -260,6 +263,7 @@ int ensure_workspace(imp_ctx* c, int batch, int n) {
         if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->mdesc[s], B * N * D);
         if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->nkp[s], B * N * 2);
         if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->mass[s], N + 4);
+        if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->kf32[s], B * N * D);
     }
     const size_t ld = (N + 1 + 3) & ~(size_t)3;
     if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->dist, B * N * N);
@@ -327,6 +331,12 @@ int launch_attention(imp_ctx* c, AttnParams& a, int batch, hipStream_t st) {
     }
     HIP_TRY(launch_attention_f16x3(a, batch, st));
     return IMP_OK;
+}
+WfParams wf_defaults() {
+    WfParams p;
+    memset(&p, 0, sizeof p);
+    p.kv_image_col = p.kv_image_col2 = 1 << 30;         // no column is written as a split-half image
+    return p;
 }
 GemmParams gemm_defaults(const imp_ctx* c, int K) {
     GemmParams p;
@@ -442,15 +452,23 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
     // the column passes of a tile to several workgroups, wf_pass_split.  IMP_GEMM_WF: 0 never, 1 by this rule (default), 2 always)
     const long wf_tiles = (long)batch * ((n[0] + 63) / 64 + (n[1] + 63) / 64);
     const bool wf = c->prec == 1 && c->use_wf && (c->use_wf > 1 || wf_tiles <= c->wf_max_tiles);
-    const bool wf_proj = wf && (c->use_wf > 1 || wf_tiles <= c->wf_proj_max_tiles);
+    // K / V as split-half images (round 3): the projection's epilogue writes, per 64-channel head segment, [64 hi halves | 64 lo halves]
+    // - exactly what every attention workgroup used to build while staging (each K / V element was converted N / 256 times per launch)
+    // - and the ping-pong attention kernel stages rows by plain copy.  Needs the weight-fragment projection kernel (D = 256).  A sharing
+    // layer refreshes only V and must keep the format of the cached q | k
+    const bool img_ok = c->prec == 1 && c->kv_image && c->use_wf && D == 256 && L.proj_wf != nullptr;
+    const bool kv_image = L.shared ? cache.kv_image : img_ok;
+    if (L.shared && kv_image && !img_ok)
+        return fail(IMP_E_STATE, "attention-sharing layer " + std::to_string(li) + ": the cached attention holds K / V as split-half images but the "
+                                 "precision / kernel switches changed since; run the non-sharing layer of that kind again");
+    const bool wf_proj = (wf && (c->use_wf > 1 || wf_tiles <= c->wf_proj_max_tiles)) || kv_image;
     const bool wf_mlp = wf && c->fuse_merge && cfg.norm_fn == IMP_NORM_IN && cfg.ac_fn == IMP_ACT_RELU && L.mlp0f_wf && L.mlp3_wf;
     // 1. projections: q|k|v of both images in one GEMM (the layer's weights are shared by the two images);
     //    a sharing layer only refreshes the value slot and keeps last iteration's q,k (== its probabilities)
     if (proj_done) {
         // (already in qkv[kind]: written by the chained launch of the previous layer)
     } else if (wf_proj && L.proj_wf) {
-        WfParams p;
-        memset(&p, 0, sizeof p);
+        WfParams p = wf_defaults();
         p.K = D; p.ksplit = D; p.N = L.proj.out; p.nside = 2;
         for (int s = 0; s < 2; ++s) {
             WfSide& g = p.side[s];
@@ -459,6 +477,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
             g.sA_b = (long)n[s] * D; g.sC_b = (long)n[s] * 3 * D;
         }
         p.Wf_ = L.proj_wf; p.bias = L.proj.b; p.lda = D; p.ldc = 3 * D;
+        if (kv_image) p.kv_image_col = L.shared ? 0 : D;     // (a sharing layer's launch writes the value slot only)
         p.pass_split = wf_pass_split(c, wf_tiles, p.N);
         HIP_TRY(launch_gemm_wf(p, batch, st));
     } else {
@@ -479,6 +498,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
                 HIP_TRY(hipMemcpyAsync(c->cmask[kind][img], kmask[img], (size_t)batch * n[img], hipMemcpyDeviceToDevice, st));
         }
         cache.valid = true; cache.batch = batch; cache.n[0] = n[0]; cache.n[1] = n[1];
+        cache.kv_image = kv_image;
     }
     // 2. attention (nets/layers.py:121-131), sources: self -> same image, cross -> the other image
     {
@@ -495,6 +515,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
             g.sq_b = (long)n[s] * 3 * D; g.sk_b = (long)n[src] * 3 * D; g.so_b = (long)n[s] * D;
             g.nq = n[s]; g.nk = n[src];
         }
+        a.kv_planes = kv_image ? 1 : 0;
         if (int arc = launch_attention(c, a, batch, st)) return arc;
     }
     // 3. merge conv (skipped when it is folded into mlp.0's weights)
@@ -509,8 +530,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
     const int maxn = n[0] > n[1] ? n[0] : n[1];
     int bm0 = gemm_stats_rows(maxn, 2 * D, 2 * batch);      // rows per statistics block of the MLP0 launch
     if (wf_mlp) {
-        WfParams p;
-        memset(&p, 0, sizeof p);
+        WfParams p = wf_defaults();
         p.K = 2 * D; p.ksplit = D; p.N = 2 * D; p.nside = 2;
         for (int s = 0; s < 2; ++s) {
             WfSide& g = p.side[s];
@@ -543,8 +563,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
     }
     // 5. norm + activation while staging, conv 3, bias, residual add -> new descriptors; CHAIN: + the next layer's projection
     if (wf_mlp) {
-        WfParams p;
-        memset(&p, 0, sizeof p);
+        WfParams p = wf_defaults();
         p.K = 2 * D; p.ksplit = 2 * D; p.N = D; p.nside = 2;
         for (int s = 0; s < 2; ++s) {
             WfSide& g = p.side[s];
@@ -565,6 +584,8 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
                 p.side[s].sC2_b = (long)n[s] * 3 * D;
             }
             p.Wf2_ = NL.proj_wf; p.bias2 = NL.proj.b; p.N2 = NL.proj.out; p.ldc2 = 3 * D;
+            const bool nimg = NL.shared ? c->cache[NL.cross ? 1 : 0].kv_image : img_ok;      // the format the next layer will expect
+            if (nimg) p.kv_image_col2 = NL.shared ? 0 : D;
             p.pass_split = 1;
             if (chained) *chained = true;
         }
@@ -820,6 +841,19 @@ int run_score(imp_ctx* c, int batch, int n0, int n1, const float* dist, float bi
     return IMP_OK;
 }
 
+// K of the cached attention `kind`, image `side`, as fp32 rows: the k slot itself (*ld = 3 D), or - when the projection wrote split-half
+// images - their exact fp32 value hi + lo converted into the context's scratch (*ld = D).  (The attention kernel multiplied exactly these
+// values: readers that recompute probabilities from q, k and the stored log-sum-exp see the operands it saw.)
+const float* cached_k_fp32(imp_ctx* c, int kind, int side, long* ld, hipStream_t st, hipError_t* err) {
+    const AttnCache& cache = c->cache[kind];
+    const int D = c->D;
+    *err = hipSuccess;
+    if (!cache.kv_image) { *ld = 3 * D; return c->qkv[kind][side] + D; }
+    *err = launch_attn_kv_unplanes(c->qkv[kind][side], (long)cache.batch * cache.n[side], 3 * D, D, c->dh, c->kf32[side], D, st);
+    *ld = D;
+    return c->kf32[side];
+}
+
 struct ProbSpec { int kind, qside, kside; };
 // which: 0 self img0, 1 self img1, 2 cross img0<-img1 (reference cross_prob1), 3 cross img1<-img0 (cross_prob0)
 const ProbSpec kProb[4] = {{0, 0, 0}, {0, 1, 1}, {1, 0, 1}, {1, 1, 0}};
@@ -868,6 +902,7 @@ int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     { const char* e = getenv("IMP_OT_FAKE_PLACEMENT"); c->ot_fake = (e && atoi(e) != 0) ? 1 : 0; }
     { const char* e = getenv("IMP_GEMM_WF"); c->use_wf = e ? atoi(e) : 1; }     // 0 off, 1 default (large launches), 2 always
     { const char* e = getenv("IMP_WF_CHAIN"); c->wf_chain = e ? atoi(e) : 1; }
+    { const char* e = getenv("IMP_KV_IMAGE"); c->kv_image = e ? atoi(e) : 1; }
     { const char* e = getenv("IMP_WF_CHAIN_MIN"); if (e) c->wf_chain_min_tiles = atol(e); }
     { const char* e = getenv("IMP_WF_MAX"); if (e) c->wf_max_tiles = atol(e); }
     { const char* e = getenv("IMP_WF_PROJ_MAX"); if (e) c->wf_proj_max_tiles = atol(e); }
@@ -1105,13 +1140,17 @@ int imp_attention_prob(imp_ctx* c, int which, float* prob, void* stream) {
     GemmParams p = gemm_defaults(c, dh);
     p.nside = 1; p.nsub = IMP_NUM_HEADS;
     GemmSide& g = p.side[0];
-    g.A = c->qkv[ps.kind][ps.qside]; g.W = c->qkv[ps.kind][ps.kside] + D; g.C = prob;
+    long ldk = 0;
+    hipError_t kerr;
+    const float* kf = cached_k_fp32(c, ps.kind, ps.kside, &ldk, S(stream), &kerr);
+    HIP_TRY(kerr);
+    g.A = c->qkv[ps.kind][ps.qside]; g.W = kf; g.C = prob;
     g.rowvec = c->lse[ps.kind][ps.qside];
     g.M = nq; g.N = nk;
-    g.sA_b = (long)nq * 3 * D; g.sA_s = dh; g.sW_b = (long)nk * 3 * D; g.sW_s = dh;
+    g.sA_b = (long)nq * 3 * D; g.sA_s = dh; g.sW_b = (long)nk * ldk; g.sW_s = dh;
     g.sC_b = (long)IMP_NUM_HEADS * nq * nk; g.sC_s = (long)nq * nk;
     g.sRV_b = (long)IMP_NUM_HEADS * nq; g.sRV_s = nq;
-    p.lda = 3 * D; p.ldw = 3 * D; p.ldc = nk;
+    p.lda = 3 * D; p.ldw = (int)ldk; p.ldc = nk;
     p.flags = GEMM_EPI_DIV | GEMM_EPI_EXPROW;
     p.div = (float)std::sqrt((double)dh);
     HIP_TRY(launch_gemm_f32(p, cache.batch, S(stream)));
@@ -1133,12 +1172,16 @@ int imp_attention_received(imp_ctx* c, int which, float* out, void* stream) {
     const int D = c->D, nq = cache.n[ps.qside], nk = cache.n[ps.kside];
     ColsumParams p;
     memset(&p, 0, sizeof p);
-    p.nside = 1; p.ldq = p.ldk = 3 * D; p.dh = c->dh;
+    long ldk = 0;
+    hipError_t kerr;
+    const float* kf = cached_k_fp32(c, ps.kind, ps.kside, &ldk, S(stream), &kerr);
+    HIP_TRY(kerr);
+    p.nside = 1; p.ldq = 3 * D; p.ldk = (int)ldk; p.dh = c->dh;
     ColsumSide& g = p.side[0];
-    g.q = c->qkv[ps.kind][ps.qside]; g.k = c->qkv[ps.kind][ps.kside] + D; g.lse = c->lse[ps.kind][ps.qside];
+    g.q = c->qkv[ps.kind][ps.qside]; g.k = kf; g.lse = c->lse[ps.kind][ps.qside];
     g.out = c->colsum[which];
     g.kmask = cache.masked[ps.kside] ? c->cmask[ps.kind][ps.kside] : nullptr;
-    g.nq = nq; g.nk = nk; g.sq_b = (long)nq * 3 * D; g.sk_b = (long)nk * 3 * D;
+    g.nq = nq; g.nk = nk; g.sq_b = (long)nq * 3 * D; g.sk_b = (long)nk * ldk;
     HIP_TRY(launch_attn_colsum(p, cache.batch, c->prec, S(stream)));
     for (int b = 0; b < cache.batch; ++b)
         HIP_TRY(launch_attn_mass_normalize(c->colsum[which] + (size_t)b * IMP_NUM_HEADS * nk, nk, out + (size_t)b * nk,
@@ -1209,16 +1252,20 @@ int imp_pool(imp_ctx* c, int n0, int n1, const float* scores, float mscore_th, f
     for (int kind = 0; kind < 2; ++kind) {
         ColsumParams p;
         memset(&p, 0, sizeof p);
-        p.nside = 2; p.ldq = p.ldk = 3 * D; p.dh = c->dh;
+        p.nside = 2; p.ldq = 3 * D; p.dh = c->dh;
+        long ldk = 3 * D;
         for (int keyside = 0; keyside < 2; ++keyside) {
             const int qside = kind == 0 ? keyside : 1 - keyside;
             ColsumSide& g = p.side[keyside];
-            g.q = c->qkv[kind][qside]; g.k = c->qkv[kind][keyside] + D; g.lse = c->lse[kind][qside];
+            hipError_t kerr;
+            g.q = c->qkv[kind][qside]; g.k = cached_k_fp32(c, kind, keyside, &ldk, st, &kerr); g.lse = c->lse[kind][qside];
+            HIP_TRY(kerr);
+            p.ldk = (int)ldk;
             g.out = c->colsum[kind * 2 + keyside];
             g.kmask = c->cache[kind].masked[keyside] ? c->cmask[kind][keyside] : nullptr;   // masked keys received exactly 0
             g.nq = kind == 0 ? (keyside ? n1 : n0) : (qside ? n1 : n0);
             g.nk = keyside ? n1 : n0;
-            g.sq_b = (long)g.nq * 3 * D; g.sk_b = (long)g.nk * 3 * D;
+            g.sq_b = (long)g.nq * 3 * D; g.sk_b = (long)g.nk * ldk;
         }
         HIP_TRY(launch_attn_colsum(p, 1, c->prec, st));
         for (int keyside = 0; keyside < 2; ++keyside)
@@ -1320,8 +1367,7 @@ int imp_op_layer_gemm(imp_ctx* c, int B, int M, int N, int K, int ksplit, const 
         HIP_TRY(hipMemset(cnt, 0, (size_t)B * sizeof(unsigned)));
         HIP_TRY(hipDeviceSynchronize());
     }
-    WfParams p;
-    memset(&p, 0, sizeof p);
+    WfParams p = wf_defaults();
     p.K = K; p.ksplit = ksplit; p.N = N; p.nside = 1;
     WfSide& g = p.side[0];
     g.A = x; g.A2 = ksplit < K ? x2 : nullptr; g.C = y; g.R = residual; g.M = M;
@@ -1351,6 +1397,22 @@ int imp_op_attention(imp_ctx* c, int batch, int nq, int nk, int dim, const float
     g.q = qkv_q; g.k = qkv_kv + dim; g.v = qkv_kv + 2 * dim; g.out = out; g.lse = lse; g.kmask = key_mask;
     g.sq_b = (long)nq * 3 * dim; g.sk_b = (long)nk * 3 * dim; g.so_b = (long)nq * dim;
     g.nq = nq; g.nk = nk;
+    // EXPERIMENT (IMP_ATTN_KV_PLANES=1): the same call on a pre-split copy of k | v (only launches the ping-pong kernel takes; synchronises)
+    static const bool kvp = [] { const char* e = getenv("IMP_ATTN_KV_PLANES"); return e && atoi(e) != 0; }();
+    if (kvp && c->prec == 1 && nq > 192) {
+        float* tmp = nullptr;
+        const size_t bytes = (size_t)batch * nk * 3 * dim * sizeof(float);
+        HIP_TRY(hipMalloc(&tmp, bytes));
+        HIP_TRY(hipMemcpyAsync(tmp, qkv_kv, bytes, hipMemcpyDeviceToDevice, S(stream)));
+        HIP_TRY(launch_attn_kv_planes(tmp, (long)batch * nk, 3 * dim, dim, a.dh, S(stream)));
+        HIP_TRY(launch_attn_kv_planes(tmp, (long)batch * nk, 3 * dim, 2 * dim, a.dh, S(stream)));
+        g.k = tmp + dim; g.v = tmp + 2 * dim;
+        a.kv_planes = 1;
+        const int arc = launch_attention(c, a, batch, S(stream));
+        (void)hipStreamSynchronize(S(stream));
+        (void)hipFree(tmp);
+        return arc;
+    }
     if (int arc = launch_attention(c, a, batch, S(stream))) return arc;
     return IMP_OK;
 }
@@ -1368,6 +1430,29 @@ int imp_time_attention(imp_ctx* c, int batch, int n, int reps, float* ms, void* 
         AttnSide& g = a.side[s];
         g.q = c->qkv[0][s]; g.k = c->qkv[0][s] + D; g.v = c->qkv[0][s] + 2 * D; g.out = c->attn_out[s];
         g.sq_b = g.sk_b = (long)n * 3 * D; g.so_b = (long)n * D; g.nq = g.nk = n;
+    }
+    // the launch the product makes: with K / V as split-half images (default in f16x3 mode, D = 256) the q | k | v slots are first filled by
+    // the layer-0 projection kernel itself from whatever descriptors the workspace holds.  IMP_ATTN_KV_PLANES=0|1 forces either staging
+    // path for A/B timing (tools/probe/attn_kv_planes.py)
+    {
+        const char* e = getenv("IMP_ATTN_KV_PLANES");
+        const bool img_ok = c->prec == 1 && c->kv_image && c->use_wf && D == 256 && !c->layers.empty() && c->layers[0].proj_wf && !c->layers[0].shared;
+        const bool kvp = c->prec == 1 && D == 256 && !c->layers.empty() && c->layers[0].proj_wf && !c->layers[0].shared && (e ? atoi(e) != 0 : img_ok);
+        if (c->prec == 1 && D == 256 && !c->layers.empty() && c->layers[0].proj_wf && !c->layers[0].shared) {
+            const GnnLayer& L = c->layers[0];
+            WfParams p = wf_defaults();
+            p.K = D; p.ksplit = D; p.N = L.proj.out; p.nside = 2;
+            for (int s = 0; s < 2; ++s) {
+                WfSide& g = p.side[s];
+                g.A = c->descw[s]; g.M = n; g.C = c->qkv[0][s];
+                g.sA_b = (long)n * D; g.sC_b = (long)n * 3 * D;
+            }
+            p.Wf_ = L.proj_wf; p.bias = L.proj.b; p.lda = D; p.ldc = 3 * D;
+            if (kvp) p.kv_image_col = D;
+            p.pass_split = wf_pass_split(c, (long)batch * 2 * ((n + 63) / 64), p.N);
+            HIP_TRY(launch_gemm_wf(p, batch, st));
+        }
+        a.kv_planes = kvp ? 1 : 0;
     }
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
@@ -1468,8 +1553,7 @@ int imp_time_layer_gemm(imp_ctx* c, int batch, int n, int which, int dbg, int re
     HIP_TRY(hipEventCreate(&e1));
     auto launch = [&]() -> hipError_t {
         if (dbg <= -2) {                                        // gemm_wf.hip; -3 / -4 / -6: its probe switches 1 / 2 / 4
-            WfParams p;
-            memset(&p, 0, sizeof p);
+            WfParams p = wf_defaults();
             p.nside = 2;
             p.K = which == 0 ? D : 2 * D; p.ksplit = which == 1 ? D : p.K;
             for (int s = 0; s < 2; ++s) {

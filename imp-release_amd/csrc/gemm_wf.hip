@@ -128,9 +128,11 @@ __device__ __forceinline__ void wf_load_residual(f32x4 (&rres)[2][4], const floa
 
 // Epilogue of one column pass of one wave: accumulators -> (+ bias, + residual) -> C rows; optionally the same values as
 // split halves into the LDS planes of the chained GEMM (TOPLANES; `pl2` = plane base, column cb of a 256-wide tile).
+// `kv_image` (wave-uniform): this pass's columns are written as the split-half image the attention kernel stages by plain copy - per
+// 64-channel head segment [64 hi halves | 64 lo halves] in the bytes of its 64 floats (attention_f16x3.hip, AttnParams::kv_planes)
 template <int SWAP, int TOPLANES>
 __device__ __forceinline__ void wf_epilogue(const f32x16 (&acc)[2], unsigned char* tbuf, const float* bias, const f32x4 (&rres)[2][4], bool has_res,
-                                            float* Cb, int ldc, int row0, int M, int cb, const WfLane& L, int dbg, unsigned char* pl2) {
+                                            float* Cb, int ldc, int row0, int M, int cb, const WfLane& L, int dbg, unsigned char* pl2, bool kv_image = false) {
     constexpr int PITCH2 = 2 * 256 + 16, PLANE2 = WF_TM * PITCH2;
     const int lane = L.lane, half = L.half;
     const int c4 = (lane & 7) * 4;
@@ -172,7 +174,18 @@ __device__ __forceinline__ void wf_epilogue(const f32x16 (&acc)[2], unsigned cha
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += rres[i][2 * c + j][e];
                 }
-                if (row < M && (!(dbg & 1) || v[0] == 123.456f)) *reinterpret_cast<f32x4*>(Cb + (long)row * ldc + cb + c4) = v;
+                if (kv_image) {
+                    if (row < M && !(dbg & 1)) {
+                        u32x2 hi, lo;
+                        unsigned a, d;
+                        imp_split2(v[0], v[1], a, d); hi[0] = a; lo[0] = d;
+                        imp_split2(v[2], v[3], a, d); hi[1] = a; lo[1] = d;
+                        const int col = cb + c4;                                  // head segment col & ~63, channel col & 63
+                        unsigned char* seg = reinterpret_cast<unsigned char*>(Cb + (long)row * ldc + (col & ~63)) + (col & 63) * 2;
+                        *reinterpret_cast<u32x2*>(seg) = hi;
+                        *reinterpret_cast<u32x2*>(seg + 128) = lo;
+                    }
+                } else if (row < M && (!(dbg & 1) || v[0] == 123.456f)) *reinterpret_cast<f32x4*>(Cb + (long)row * ldc + cb + c4) = v;
                 if (TOPLANES) {                                  // (rows past M repeat row M - 1: they feed only rows that are never stored)
                     u32x2 hi, lo;
                     unsigned a, d;
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(512) void gemm_wf_kernel(const WfParams p, int row_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
             wf_kloop<256, SWAP>(acc, wf_smem, aoff2, wptr2(ps), wptr2(pn), bh, bl);
-            wf_epilogue<SWAP, 0>(acc, tbuf, p.bias2, nores, false, C2, p.ldc2, row0, M, ps * 128 + w4 * 32, L, p.dbg, nullptr);
+            wf_epilogue<SWAP, 0>(acc, tbuf, p.bias2, nores, false, C2, p.ldc2, row0, M, ps * 128 + w4 * 32, L, p.dbg, nullptr, ps * 128 >= p.kv_image_col2);
         }
         return;
     }
@@ -408,7 +421,7 @@ __global__ __launch_bounds__(512) void gemm_wf_kernel(const WfParams p, int row_
                 if (t == q) { st_sum[q] = su; st_m2[q] = m2v; st_cb[q] = cb; }
         }
         if (p.dbg & 2) { if (acc[0][0] == 123.456f) Cb[0] = acc[1][5]; continue; }
-        wf_epilogue<SWAP, 0>(acc, tbuf, p.bias, rres, Rb != nullptr, Cb, p.ldc, row0, M, cb, L, p.dbg, nullptr);
+        wf_epilogue<SWAP, 0>(acc, tbuf, p.bias, rres, Rb != nullptr, Cb, p.ldc, row0, M, cb, L, p.dbg, nullptr, SWAP && pass * 128 >= p.kv_image_col);
 #ifdef WF_PROFILE
         { __builtin_amdgcn_s_waitcnt(0); WF_T(t2); t_k += t1 - t0; t_e += t2 - t1; }
 #endif

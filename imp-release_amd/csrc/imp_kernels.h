@@ -100,7 +100,13 @@ struct AttnParams {
     // [unit][split][256 x dh + 512] and one zero-initialised, self re-arming ticket per unit, unit = (pair, side, head, query tile)
     float* split_ws;
     unsigned* split_cnt;
+    int kv_planes;         // EXPERIMENT (ping-pong kernel only): k / v rows hold, per head, [dh hi halves | dh lo halves] (the split-half image the
+                           // kernel otherwise builds while staging) in the bytes of the head's dh floats: staged by plain copy
 };
+// in place: the dh-float head segments of columns [col0, col0 + 4 dh) of `rows` rows -> [dh hi halves | dh lo halves]
+hipError_t launch_attn_kv_planes(float* base, long rows, int ld, int col0, int dh, hipStream_t stream);
+// ... and back: out[row][h * dh + ch] = hi + lo (exact in fp32)
+hipError_t launch_attn_kv_unplanes(const float* base, long rows, int ld, int col0, int dh, float* out, int ldo, hipStream_t stream);
 int attention_f16x3_splits(const AttnParams& p, int batch);                        // splits launch_attention_f16x3 will use
 size_t attention_f16x3_split_floats(const AttnParams& p, int batch, int nsplit);   // floats of split_ws it needs
 size_t attention_f16x3_split_units(const AttnParams& p, int batch);                // tickets it needs
@@ -238,6 +244,8 @@ struct WfParams {
     const void* Wf2_;      // fragments of the [N2][256] weights, or null
     const float* bias2;
     int N2, ldc2;
+    int kv_image_col, kv_image_col2;   // columns >= this of C / C2 (multiples of 128; INT_MAX-like = none) are written as the split-half image the
+                           // attention kernel stages by plain copy: per 64-channel head segment [64 hi halves | 64 lo halves] (AttnParams::kv_planes)
     int pass_split;        // > 1: the N / 128 column passes of a row tile are dealt to this many workgroups (must divide N / 128; not with Wf2_)
     int dbg;               // probe switches (tools/probe/gemm_wf_time.py): 1 no global stores, 2 no epilogue at all, 4 no residual / bias loads
 };

@@ -651,3 +651,32 @@ def test_odd_and_tiny_shapes_vs_oracle(model, precision):
         compare_matches(_cpu(got['indices0'][-1]), _cpu(got['mscores0'][-1]), ref['indices0'][-1].numpy(),
                         ref['mscores0'][-1].numpy(), 0.2, TOL, f'{model} {precision} n0={n0} n1={n1}')
         assert torch.isfinite(got['mscores0'][-1]).all()
+
+
+@pytest.mark.parametrize('model,n0,n1,B', [('GM', 1024, 1000, 2), ('DGNNS', 300, 280, 1), ('GM', 150, 97, 3)])
+def test_kv_split_half_images_do_not_change_the_matches(model, n0, n1, B):
+    """round 3: the projections write K / V as the split-half image [hi | lo] the attention kernel used to build while staging.  The
+    matrix pipe sees bit-identical operands either way, so a one-shot match is IDENTICAL with the round-2 format (IMP_KV_IMAGE=0);
+    (sizes <= 192 queries additionally move from the lock-step kernels to the ping-pong kernel: another summation order)"""
+    import os
+    cfg = eval_config(n_layers=5 if model == 'DGNNS' else 3, sinkhorn_iterations=20)
+    sd = synthetic.make_state_dict(cfg, model, seed=12)
+    on = make_hip_model(model, cfg, sd)
+    on._ensure_ctx()
+    os.environ['IMP_KV_IMAGE'] = '0'
+    try:
+        off = make_hip_model(model, cfg, sd)
+        off._ensure_ctx()
+    finally:
+        del os.environ['IMP_KV_IMAGE']
+    pair = synthetic.make_correlated_pair(n0, n1, seed=n0 + B, batch=B)
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+    with torch.no_grad():
+        a = on.produce_matches(data, p=0.2, only_last=True)
+        b = off.produce_matches(data, p=0.2, only_last=True)
+    if min(n0, n1) > 192:
+        assert torch.equal(a['indices0'][-1], b['indices0'][-1]) and torch.equal(a['mscores0'][-1], b['mscores0'][-1])
+    else:
+        print(compare_matches(_cpu(a['indices0'][-1]), _cpu(a['mscores0'][-1]), _cpu(b['indices0'][-1]).numpy(), _cpu(b['mscores0'][-1]).numpy(),
+                              0.2, 1e-5, f'kv image vs fp32 format {n0}x{n1}', strict=False))
