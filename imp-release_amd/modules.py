@@ -310,8 +310,16 @@ class GM(nn.Module):
             return (torch.sum(((indices0 - gt) == 0) * (indices0 != -1) * (gt < last)) / (nB * nI),
                     torch.sum((indices0 == -1) * (gt == last)) / (nB * nI),
                     torch.sum(gt < last) / (nB * nI), torch.sum(gt == last) / (nB * nI))
-        z = torch.zeros(size=[], device=dev)
-        return z + 0, z + 0, z + 1, z + 1
+        return self._const_stats(dev)
+
+    def _const_stats(self, dev):
+        """(0, 0, 1, 1) as 0-d tensors on `dev` (the reference builds them with `torch.zeros(...) + k` on every call,
+        nets/gm.py:214-219: five tiny kernels per call here); made once per device and handed out read-only"""
+        key = str(dev)
+        cache = self.__dict__.setdefault('_const_stats_cache', {})
+        if key not in cache:
+            cache[key] = tuple(torch.full((), v, device=dev) for v in (0., 0., 1., 1.))
+        return cache[key]
 
     def _run_iterations(self, data, p, only_last, want_scores):
         """shared body of GM / DGNNS produce_matches: returns per-emitted-iteration lists"""
@@ -502,9 +510,9 @@ class AdaGMN(GM):
                     mask0[bi, g0] = 1
                     mask1[bi, g1] = 1
             all_i0.append(b_i0); all_m0.append(b_m0)
-        z = torch.zeros(size=[], device=dev)
-        return {'scores': [pred_score], 'indices0': all_i0, 'mscores0': all_m0, 'acc_corr': [z + 0],
-                'acc_incorr': [z + 0], 'total_acc_corr': [z + 1], 'total_acc_incorr': [z + 1]}
+        a, b_, c_, d_ = self._const_stats(dev)
+        return {'scores': [pred_score], 'indices0': all_i0, 'mscores0': all_m0, 'acc_corr': [a],
+                'acc_incorr': [b_], 'total_acc_corr': [c_], 'total_acc_incorr': [d_]}
 
     def run(self, data):
         """nets/adgm.py:607-635"""

@@ -13,5 +13,9 @@ cd /tmp && export TMPDIR=/tmp
 (timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/final_${T}_c2 -o c2 -- python $R/tools/probe/c2_run.py 1024 1 2>&1 | tail -1) > $O/final_${T}_c2.log 2>&1
 cd $R
 (timeout 200 python tools/gpu_configs.py 2>&1 | tail -7) > $O/final_${T}_configs.log 2>&1
-(timeout 200 python tools/eval_synthetic.py --pairs 24 --model EIMP --kpts 2048 --workers 3 --pose none 2>&1 | tail -1; timeout 200 python tools/eval_synthetic.py --pairs 24 --model EIMP --kpts 2048 --workers 3 --pose gpu 2>&1 | tail -1) > $O/final_${T}_loop.log 2>&1
-tail -4 $O/final_${T}_pytest.log; tail -2 $O/final_${T}_smoke.log; cut -c1-1800 $O/final_${T}_bench.json; echo; head -9 $O/final_${T}_prof1/bench_kernel_stats.csv | cut -c1-150; cat $O/final_${T}_configs.log
+(for M in IMP EIMP; do timeout 300 python tools/eval_synthetic.py --pairs 1000 --model $M --kpts 2048 --workers 3 --pose gpu 2>&1 | tail -1; done; timeout 200 python tools/eval_synthetic.py --pairs 200 --model EIMP --kpts 2048 --workers 3 --pose none --weights uniform 2>&1 | tail -1) > $O/final_${T}_loop.log 2>&1
+# PMC passes (own runs, --pmc with --kernel-trace only): matrix-pipe / VALU / LDS counters and the HBM traffic of every product kernel
+bash tools/gpu_pmc.sh $T "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_INSTS_VALU" "FETCH_SIZE" "WRITE_SIZE" > $O/final_${T}_pmc.log 2>&1
+python tools/pmc_summary.py $T $O/final_${T}_pmc_per_kernel.csv
+(for K in 1 2 3; do timeout 200 python bench.py --steps 40 --warmup 6 --no-cpu-baseline --no-batch1 --in-flight $K 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('in-flight $K: %.1f pairs/s' % d['value'])"; done) > $O/final_${T}_inflight.log 2>&1
+tail -4 $O/final_${T}_pytest.log; tail -2 $O/final_${T}_smoke.log; cut -c1-1800 $O/final_${T}_bench.json; echo; head -9 $O/final_${T}_prof1/bench_kernel_stats.csv | cut -c1-150; cat $O/final_${T}_configs.log; cat $O/final_${T}_loop.log $O/final_${T}_inflight.log; head -12 $O/final_${T}_pmc_per_kernel.csv | cut -c1-250
