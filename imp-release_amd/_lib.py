@@ -119,7 +119,7 @@ def lib():
     L.imp_set_resident_verify.argtypes = [P, I]
     L.imp_range_events.argtypes = [P]
     L.imp_time_layer_gemm.argtypes = [P, I, I, I, I, I, C.POINTER(C.c_float), P]
-    L.imp_estimate_pose.argtypes = [P, P, I, P, P, C.c_double, I, C.c_uint, I, P, P, P, P, P, C.POINTER(C.c_int), P]
+    L.imp_estimate_pose.argtypes = [P, P, I, P, P, C.c_double, I, C.c_uint, I, P, P, P, P, P, C.POINTER(C.c_int), I, P]
     L.imp_sp_create.argtypes = [C.POINTER(C.c_void_p), I, I]
     L.imp_sp_destroy.argtypes = [P]
     L.imp_sp_destroy.restype = None

@@ -171,6 +171,24 @@ __device__ __forceinline__ double sampson_sq(const double* E, double x0, double 
     return num * num / fmax(a0 * a0 + a1 * a1 + b0 * b0 + b1 * b1, 1e-30);
 }
 
+// MAGSAC++ (Barath et al., CVPR 2020) sigma-marginalised weight of a residual: the noise scale sigma is unknown, uniform on (0, sigma_max];
+// residuals are chi-distributed with nu = 4 degrees of freedom (the paper's choice for epipolar geometry with the Sampson distance), a point
+// is an inlier of scale sigma while r < k sigma, k = 3.64 (0.99 quantile).  Marginalising the inlier likelihood over sigma gives
+//     w(r) ~ Gamma_u((nu - 1) / 2, r^2 / (2 sigma_max^2)) - Gamma_u((nu - 1) / 2, k^2 / 2)     for r < k sigma_max, else 0
+// with the upper incomplete gamma function Gamma_u(3/2, x) = sqrt(pi) / 2 erfc(sqrt x) + sqrt x e^-x; normalised here to w(0) = 1.
+// The quality of a model is sum_i w(r_i) and its refinement is a least-squares fit weighted by w (the paper's IRLS step).
+constexpr double MAGSAC_K = 3.64;
+__host__ __device__ inline double gamma_u_3_2(double x) {
+    const double rx = sqrt(x);
+    return 0.88622692545275801 * erfc(rx) + rx * exp(-x);
+}
+__host__ __device__ inline double magsac_weight(double r2, double sigma_max2) {
+    if (!(r2 < MAGSAC_K * MAGSAC_K * sigma_max2)) return 0.0;
+    const double gk = gamma_u_3_2(0.5 * MAGSAC_K * MAGSAC_K);
+    return (gamma_u_3_2(0.5 * r2 / sigma_max2) - gk) / (0.88622692545275801 - gk);
+}
+constexpr double QUALITY_SCALE = 4096.0;     // qualities are compared as integers floor(Q x 4096): ties resolve to the lowest hypothesis index
+
 // one thread per hypothesis
 __global__ __launch_bounds__(64) void pose_hypotheses_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n,
                                                              int H, unsigned seed, double* __restrict__ Eh, int* __restrict__ valid) {
@@ -242,22 +260,28 @@ __global__ __launch_bounds__(64) void pose_hypotheses_kernel(const double2* __re
     if (ok) for (int i = 0; i < 9; ++i) Eh[(long)h * 9 + i] = E[i / 3][i % 3];
 }
 
-// one workgroup per hypothesis: inlier count
+// one workgroup per hypothesis: inlier count (magsac == 0) or sigma-marginalised quality floor(4096 sum_i w(r_i)) (magsac != 0)
 __global__ __launch_bounds__(256) void pose_score_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n,
-                                                         const double* __restrict__ Eh, const int* __restrict__ valid, double thr2,
+                                                         const double* __restrict__ Eh, const int* __restrict__ valid, double thr2, int magsac,
                                                          int* __restrict__ counts) {
     const int h = blockIdx.x;
-    __shared__ int red[4];
-    int c = 0;
+    __shared__ double red[4];
+    double c = 0;
     if (valid[h]) {
         double E[9];
         for (int i = 0; i < 9; ++i) E[i] = Eh[(long)h * 9 + i];
-        for (int i = threadIdx.x; i < n; i += 256) c += sampson_sq(E, x0[i].x, x0[i].y, x1[i].x, x1[i].y) < thr2;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const double r2 = sampson_sq(E, x0[i].x, x0[i].y, x1[i].x, x1[i].y);
+            c += magsac ? magsac_weight(r2, thr2) : (r2 < thr2 ? 1.0 : 0.0);
+        }
     }
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) counts[h] = valid[h] ? red[0] + red[1] + red[2] + red[3] : -1;
+    if (threadIdx.x == 0) {
+        const double q = (red[0] + red[1]) + (red[2] + red[3]);
+        counts[h] = valid[h] ? (magsac ? (int)floor(q * QUALITY_SCALE) : (int)q) : -1;
+    }
 }
 
 __device__ double block_sum(double v, double* sm) {        // 1024 threads
@@ -272,7 +296,7 @@ __device__ double block_sum(double v, double* sm) {        // 1024 threads
 
 // one workgroup: first best hypothesis -> consensus refits -> decomposition of E
 __global__ __launch_bounds__(1024) void pose_consensus_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n, int H,
-                                                           const double* __restrict__ Eh, const int* __restrict__ counts, double thr2,
+                                                           const double* __restrict__ Eh, const int* __restrict__ counts, double thr2, int magsac,
                                                            unsigned char* __restrict__ inl, double* __restrict__ out) {
     // out: [0..8] E, [9..17] R, [18..20] t, [21] inliers of E, [22] cheirality inliers, [23] ok flag, [24..32] R1, [33..41] R2, [42..44] t
     __shared__ double sm[16 * 45];
@@ -297,29 +321,34 @@ __global__ __launch_bounds__(1024) void pose_consensus_kernel(const double2* __r
         }
         __syncthreads();
     }
-    if (s_best < 0 || s_cnt < 8) { if (tid == 0) out[23] = 0.0; return; }
+    if (s_best < 0 || s_cnt < (magsac ? (int)(8 * QUALITY_SCALE / 2) : 8)) { if (tid == 0) out[23] = 0.0; return; }
+    // per-point weight of the current model: 0 / 1 membership of the consensus set, or the sigma-marginalised weight (IRLS)
+    auto weight = [&](const double* E, int i) {
+        const double r2 = sampson_sq(E, x0[i].x, x0[i].y, x1[i].x, x1[i].y);
+        return magsac ? magsac_weight(r2, thr2) : (r2 < thr2 ? 1.0 : 0.0);
+    };
     for (int i = tid; i < n; i += 1024) inl[i] = sampson_sq(Es, x0[i].x, x0[i].y, x1[i].x, x1[i].y) < thr2;
     __syncthreads();
     for (int round = 0; round < 3; ++round) {
-        // conditioning of the consensus set
+        // conditioning of the (weighted) consensus set
         double c = 0, sx0 = 0, sy0 = 0, sx1 = 0, sy1 = 0;
-        for (int i = tid; i < n; i += 1024) if (inl[i]) { c += 1; sx0 += x0[i].x; sy0 += x0[i].y; sx1 += x1[i].x; sy1 += x1[i].y; }
+        for (int i = tid; i < n; i += 1024) { const double w = weight(Es, i); if (w > 0) { c += w; sx0 += w * x0[i].x; sy0 += w * x0[i].y; sx1 += w * x1[i].x; sy1 += w * x1[i].y; } }
         const double cnt = block_sum(c, sm);
         const double cx0 = block_sum(sx0, sm) / cnt, cy0 = block_sum(sy0, sm) / cnt, cx1 = block_sum(sx1, sm) / cnt, cy1 = block_sum(sy1, sm) / cnt;
         double d0 = 0, d1 = 0;
-        for (int i = tid; i < n; i += 1024) if (inl[i]) {
-            d0 += sqrt((x0[i].x - cx0) * (x0[i].x - cx0) + (x0[i].y - cy0) * (x0[i].y - cy0));
-            d1 += sqrt((x1[i].x - cx1) * (x1[i].x - cx1) + (x1[i].y - cy1) * (x1[i].y - cy1));
-        }
+        for (int i = tid; i < n; i += 1024) { const double w = weight(Es, i); if (w > 0) {
+            d0 += w * sqrt((x0[i].x - cx0) * (x0[i].x - cx0) + (x0[i].y - cy0) * (x0[i].y - cy0));
+            d1 += w * sqrt((x1[i].x - cx1) * (x1[i].x - cx1) + (x1[i].y - cy1) * (x1[i].y - cy1));
+        } }
         const double s0 = 1.4142135623730951 / fmax(block_sum(d0, sm) / cnt, 1e-12), s1 = 1.4142135623730951 / fmax(block_sum(d1, sm) / cnt, 1e-12);
         double acc[45];
         for (int k = 0; k < 45; ++k) acc[k] = 0.0;
-        for (int i = tid; i < n; i += 1024) if (inl[i]) {
+        for (int i = tid; i < n; i += 1024) { const double w = weight(Es, i); if (w > 0) {
             const double ax = (x0[i].x - cx0) * s0, ay = (x0[i].y - cy0) * s0, bx = (x1[i].x - cx1) * s1, by = (x1[i].y - cy1) * s1;
             const double r[9] = {bx * ax, bx * ay, bx, by * ax, by * ay, by, ax, ay, 1.0};
             int k = 0;
-            for (int a = 0; a < 9; ++a) for (int b2 = a; b2 < 9; ++b2) acc[k++] += r[a] * r[b2];
-        }
+            for (int a = 0; a < 9; ++a) for (int b2 = a; b2 < 9; ++b2) acc[k++] += w * r[a] * r[b2];
+        } }
         for (int k = 0; k < 45; ++k) for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
         __syncthreads();
         if ((tid & 63) == 0) for (int k = 0; k < 45; ++k) sm[(tid >> 6) * 45 + k] = acc[k];
@@ -349,8 +378,9 @@ __global__ __launch_bounds__(1024) void pose_consensus_kernel(const double2* __r
         __syncthreads();
         if (!s_ok) break;
         double c2 = 0;
-        for (int i = tid; i < n; i += 1024) c2 += sampson_sq(Et, x0[i].x, x0[i].y, x1[i].x, x1[i].y) < thr2;
-        const int cnt2 = (int)block_sum(c2, sm);
+        for (int i = tid; i < n; i += 1024) c2 += weight(Et, i);
+        const double q2 = block_sum(c2, sm);
+        const int cnt2 = magsac ? (int)floor(q2 * QUALITY_SCALE) : (int)q2;
         if (cnt2 < s_cnt) break;                                   // uniform: kept only while not worse
         const bool same = cnt2 == s_cnt;
         __syncthreads();
@@ -373,7 +403,7 @@ __global__ __launch_bounds__(1024) void pose_consensus_kernel(const double2* __r
             }
         for (int r = 0; r < 3; ++r) out[42 + r] = U[r][2];
         for (int i = 0; i < 9; ++i) out[i] = Es[i];
-        out[21] = (double)s_cnt; out[23] = 1.0;
+        out[21] = (double)s_cnt; out[23] = 1.0;                    // (magsac: [21] holds the quality x 4096; the inlier count follows from the mask)
     }
 }
 
@@ -451,7 +481,7 @@ struct PoseWs {
 
 extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, const double* K0, const double* K1, double norm_thresh,
                                  int iterations, unsigned seed, int device, double* E, double* R, double* t, unsigned char* mask,
-                                 unsigned char* consensus, int* n_inliers, void* stream) {
+                                 unsigned char* consensus, int* n_inliers, int flags, void* stream) {
     if (!kpts0 || !kpts1 || !K0 || !K1 || !E || !R || !t || !mask || !n_inliers || iterations < 1) return IMP_E_ARG;
     *n_inliers = 0;
     if (n < 8) return 1;                                   // (the reference returns None below 5 points; the 8-point solver needs 8)
@@ -481,10 +511,10 @@ extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, 
     if (hipMemcpyAsync(ws.x1, h1.data(), n * sizeof(double2), hipMemcpyHostToDevice, st) != hipSuccess) return IMP_E_HIP;
     const double thr = norm_thresh / ((K0[0] + K0[4] + K1[0] + K1[4]) / 4.0);
     hipLaunchKernelGGL(pose_hypotheses_kernel, dim3((iterations + 63) / 64), dim3(64), 0, st, ws.x0, ws.x1, n, iterations, seed, ws.Eh, ws.valid);
-    hipLaunchKernelGGL(pose_score_kernel, dim3(iterations), dim3(256), 0, st, ws.x0, ws.x1, n, ws.Eh, ws.valid, thr * thr, ws.counts);
+    hipLaunchKernelGGL(pose_score_kernel, dim3(iterations), dim3(256), 0, st, ws.x0, ws.x1, n, ws.Eh, ws.valid, thr * thr, flags & 1, ws.counts);
     // the cheirality step of the reference normalises with K = (K0 + K1) / 2 (eval/pose_estimation.py:29-33): with K0 == K1 (every
     // caller in the repo) these are the coordinates above; a caller with two different cameras gets per-camera normalisation
-    hipLaunchKernelGGL(pose_consensus_kernel, dim3(1), dim3(1024), 0, st, ws.x0, ws.x1, n, iterations, ws.Eh, ws.counts, thr * thr, ws.inl, ws.out);
+    hipLaunchKernelGGL(pose_consensus_kernel, dim3(1), dim3(1024), 0, st, ws.x0, ws.x1, n, iterations, ws.Eh, ws.counts, thr * thr, flags & 1, ws.inl, ws.out);
     if (hipMemsetAsync(ws.good, 0, 4 * sizeof(int), st) != hipSuccess) return IMP_E_HIP;
     hipLaunchKernelGGL(pose_cheirality_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws.x0, ws.x1, n, ws.out, ws.inl, 1000.0, ws.bits, ws.good);
     hipLaunchKernelGGL(pose_vote_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, ws.good, ws.bits, ws.inl, ws.refmask, ws.out);

@@ -23,12 +23,14 @@ from . import _lib
 
 
 def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, mask=None, iterations=4096, seed=1,
-                  device=None, stream=None, return_consensus=False):
+                  device=None, stream=None, return_consensus=False, scoring='magsac'):
     """eval/pose_estimation.py:92-115 -> None | (E [3,3], R [3,3], t [3], mask [n] bool).
 
     ``mask`` has the reference's semantics (:113-114: ``mask = E_mask.ravel() >= 0`` is all True, then only the consensus entries
     are overwritten with the cheirality result): matches OUTSIDE the consensus stay True.  ``return_consensus=True`` appends the
-    geometric mask (in the consensus of E AND in front of both cameras).  Fewer than 8 matches -> None (the reference: fewer
+    geometric mask (in the consensus of E AND in front of both cameras).  ``scoring='magsac'`` (default): hypotheses ranked by the
+    sigma-marginalised quality of MAGSAC++ and the winner refined by IRLS with those weights (the published algorithm behind the
+    reference's ``cv2.USAC_MAGSAC``; OpenCV's implementation itself stays unpinned); ``'count'``: plain inlier counting + consensus refits.  Fewer than 8 matches -> None (the reference: fewer
     than 5; an 8-point minimal solver cannot go lower - behind the loops' ``min_kpts = 25`` the difference is never reached)."""
     import torch
     k0 = np.ascontiguousarray(np.asarray(kpts0, dtype=np.float32))
@@ -36,6 +38,8 @@ def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, 
     n = k0.shape[0]
     if n < 8 or k1.shape[0] != n:
         return None
+    if scoring not in ('magsac', 'count'):
+        raise ValueError("scoring must be 'magsac' or 'count'")
     if mask is not None:
         raise NotImplementedError('an input mask is not supported (no caller in the reference passes one)')
     L = _lib.lib()
@@ -49,7 +53,7 @@ def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, 
     st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
     P = lambda a: a.ctypes.data_as(C.c_void_p)      # noqa: E731
     rc = L.imp_estimate_pose(P(k0), P(k1), n, P(Ka), P(Kb), C.c_double(float(norm_thresh)), int(iterations), C.c_uint(seed), dev,
-                             P(E), P(R), P(t), P(m), P(cons), C.byref(ninl), C.c_void_p(st))
+                             P(E), P(R), P(t), P(m), P(cons), C.byref(ninl), 1 if scoring == 'magsac' else 0, C.c_void_p(st))
     if rc == 1:
         return None
     if rc != 0:

@@ -239,7 +239,12 @@ int imp_time_layer_gemm(imp_ctx* ctx, int batch, int n, int which, int dbg, int 
  * NOT OpenCV's USAC_MAGSAC: parity with that third-party solver is unpinned (see csrc/pose.hip). */
 int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, const double* K0, const double* K1, double norm_thresh,
                       int iterations, unsigned seed, int device, double* E, double* R, double* t, unsigned char* mask,
-                      unsigned char* consensus, int* n_inliers, void* stream);
+                      unsigned char* consensus, int* n_inliers, int flags, void* stream);
+/* flags bit 0 (IMP_POSE_MAGSAC): hypotheses are ranked by the sigma-marginalised quality of MAGSAC++ (Barath et al. 2020: sum of the weights
+ * w(r) of the Sampson residuals, noise scale uniform on (0, sigma_max], sigma_max = the threshold, nu = 4, k = 3.64) instead of the inlier
+ * count, and the winner is refined by weighted least squares with those weights (IRLS) instead of refits on the consensus set.  The masks
+ * still use the hard threshold.  This follows the PUBLISHED algorithm; OpenCV's USAC_MAGSAC implementation itself remains unpinned. */
+#define IMP_POSE_MAGSAC 1
 /* Chip-resident Sinkhorn health (csrc/ot_resident.hip; the kernel behind compute_score, nets/gm.py:297-303).  Its workgroups
  * exchange vectors through memory with bounded waits.  A wait that times out (a second process on the GPU, a partition mode
  * that places workgroups differently) voids the launch: the kernel poisons its outputs (maxima NaN -> mscores NaN, indices -1)

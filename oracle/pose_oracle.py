@@ -121,38 +121,91 @@ def sampson_sq(E, x0, x1):
     return num / np.maximum(den, 1e-30)
 
 
-def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, mask=None, iterations=4096, seed=1, return_consensus=False):
+MAGSAC_K = 3.64
+QUALITY_SCALE = 4096.0
+
+
+def _gamma_u_3_2(x):
+    from scipy.special import erfc
+    rx = np.sqrt(x)
+    return 0.88622692545275801 * erfc(rx) + rx * np.exp(-x)
+
+
+def magsac_weight(r2, sigma_max2):
+    """MAGSAC++ (Barath et al., CVPR 2020) sigma-marginalised weight of a squared residual, normalised to w(0) = 1: noise scale uniform
+    on (0, sigma_max], residuals chi-distributed with 4 degrees of freedom, inlier of scale sigma while r < 3.64 sigma (csrc/pose.hip)"""
+    r2 = np.asarray(r2, dtype=np.float64)
+    gk = _gamma_u_3_2(0.5 * MAGSAC_K ** 2)
+    w = (_gamma_u_3_2(0.5 * r2 / sigma_max2) - gk) / (0.88622692545275801 - gk)
+    return np.where(r2 < MAGSAC_K ** 2 * sigma_max2, w, 0.0)
+
+
+def _weighted_essential(x0, x1, w):
+    """weighted 8-point fit (weights w >= 0) with weighted Hartley conditioning, projected onto the essential manifold"""
+    def cond(x):
+        c = (w[:, None] * x).sum(0) / w.sum()
+        s = np.sqrt(2.0) / max((w * np.sqrt(((x - c) ** 2).sum(1))).sum() / w.sum(), 1e-12)
+        T = np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1.]])
+        return (x - c) * s, T
+    a, T0 = cond(x0)
+    b, T1 = cond(x1)
+    A = np.stack([b[:, 0] * a[:, 0], b[:, 0] * a[:, 1], b[:, 0], b[:, 1] * a[:, 0], b[:, 1] * a[:, 1], b[:, 1],
+                  a[:, 0], a[:, 1], np.ones(len(a))], axis=1)
+    _, V = np.linalg.eigh((A * w[:, None]).T @ A)
+    E = T1.T @ V[:, 0].reshape(3, 3) @ T0
+    U, sv, Vt = np.linalg.svd(E)
+    if not (sv[1] > 1e-12 * sv[0] and sv[0] > 0):
+        return None
+    return U @ np.diag([1., 1., 0.]) @ Vt
+
+
+def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, mask=None, iterations=4096, seed=1, return_consensus=False,
+                  scoring='magsac'):
     """Signature of eval/pose_estimation.py:92 -> None | (E, R, t, mask).  Threshold: norm_thresh pixels divided by the
     mean focal length, applied to the Sampson distance in normalised coordinates.  ``mask`` follows :113-114 literally: all True,
     only the consensus entries overwritten by the cheirality result; ``return_consensus`` appends the geometric mask
-    (consensus AND in front of both cameras)."""
+    (consensus AND in front of both cameras).  ``scoring``: 'magsac' = sigma-marginalised quality + IRLS refinement (MAGSAC++ as
+    published), 'count' = inlier counting + refits on the consensus set.  CPU twin of csrc/pose.hip in both modes."""
     n = len(kpts0)
     if n < 8:
         return None
+    mag = scoring == 'magsac'
     x0, x1 = normalise(kpts0, K0), normalise(kpts1, K1)
     K0a, K1a = np.asarray(K0, dtype=np.float64), np.asarray(K1, dtype=np.float64)
     thr = norm_thresh / ((K0a[0, 0] + K0a[1, 1] + K1a[0, 0] + K1a[1, 1]) / 4.0)
+
+    def weights(E):
+        r2 = sampson_sq(E, x0, x1)
+        return magsac_weight(r2, thr * thr) if mag else (r2 < thr * thr).astype(np.float64)
+
+    def quality(E):
+        q = weights(E).sum()
+        return int(np.floor(q * QUALITY_SCALE)) if mag else int(q)
+
     best, bestE = -1, None
     for h in range(iterations):
         ids = [sample_index(seed, h, k, n) for k in range(8)]
         if len(set(ids)) < 8:
             continue
         E = essential_from(x0[ids], x1[ids])
-        cnt = int((sampson_sq(E, x0, x1) < thr * thr).sum())
+        cnt = quality(E)
         if cnt > best:
             best, bestE = cnt, E
-    if bestE is None or best < 8:
+    if bestE is None or best < (4 * QUALITY_SCALE if mag else 8):
         return None
-    inl = sampson_sq(bestE, x0, x1) < thr * thr
-    for rnd in range(3):                                 # least-squares refits on the consensus set, kept while not worse
-        E2 = essential_from(x0[inl], x1[inl])
-        inl2 = sampson_sq(E2, x0, x1) < thr * thr
-        if inl2.sum() < inl.sum():
+    for rnd in range(3):                                 # (weighted) least-squares refits, kept while not worse
+        w = weights(bestE)
+        E2 = _weighted_essential(x0, x1, w)
+        if E2 is None:
             break
-        same = inl2.sum() == inl.sum()
-        bestE, inl = E2, inl2
+        q2 = quality(E2)
+        if q2 < best:
+            break
+        same = q2 == best
+        bestE, best = E2, q2
         if same and rnd > 0:
             break
+    inl = sampson_sq(bestE, x0, x1) < thr * thr
     R, t, mP = decompose_essential_mat(bestE, np.asarray(kpts0)[inl], np.asarray(kpts1)[inl], K0, K1)
     m = np.ones(n, dtype=bool)                           # eval/pose_estimation.py:113: `E_mask.ravel() >= 0` - every entry True
     m[np.nonzero(inl)[0]] = mP                           # :114

@@ -20,13 +20,15 @@ def _ang_vec(a, b):
     return np.rad2deg(np.arccos(np.clip(a @ b / np.linalg.norm(a) / np.linalg.norm(b), -1, 1)))
 
 
+@pytest.mark.parametrize('scoring', ['magsac', 'count'])
 @pytest.mark.parametrize('n,outliers,noise,seed', [(400, 0.3, 0.3, 0), (1500, 0.4, 0.5, 1), (60, 0.2, 0.2, 2), (3000, 0.5, 0.4, 3),
                                                    (9, 0.0, 0.0, 4)])
-def test_gpu_pose_equals_its_cpu_twin(n, outliers, noise, seed):
+def test_gpu_pose_equals_its_cpu_twin(n, outliers, noise, seed, scoring):
+    """both rankings: the sigma-marginalised quality of MAGSAC++ with IRLS refinement (default) and plain inlier counting"""
     k0, k1, K, R, t, truth = po.synthetic_scene(n, outliers=outliers, noise=noise, seed=seed)
     its = 512
-    g = hip_pose.estimate_pose(k0, k1, K, K, 1.0, iterations=its, seed=11, return_consensus=True)
-    c = po.estimate_pose(k0, k1, K, K, 1.0, iterations=its, seed=11, return_consensus=True)
+    g = hip_pose.estimate_pose(k0, k1, K, K, 1.0, iterations=its, seed=11, return_consensus=True, scoring=scoring)
+    c = po.estimate_pose(k0, k1, K, K, 1.0, iterations=its, seed=11, return_consensus=True, scoring=scoring)
     assert (g is None) == (c is None)
     if g is None:
         return

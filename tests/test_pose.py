@@ -56,10 +56,23 @@ def test_decompose_returns_proper_rotations_and_unit_translation():
         assert np.isclose(np.linalg.norm(t), 1.0)
 
 
+def test_magsac_weight_function():
+    """MAGSAC++ weight: 1 at r = 0, monotone, 0 from r = 3.64 sigma_max on, and the closed form of the incomplete gamma function
+    Gamma_u(3/2, x) = sqrt(pi)/2 erfc(sqrt x) + sqrt x e^-x against scipy"""
+    from scipy.special import gammaincc, gamma
+    x = np.linspace(0, 9, 50)
+    assert np.allclose(po._gamma_u_3_2(x), gammaincc(1.5, x) * gamma(1.5), atol=1e-12)
+    s2 = 0.002 ** 2
+    r = np.linspace(0, 4.0, 200) * 0.002
+    w = po.magsac_weight(r ** 2, s2)
+    assert abs(w[0] - 1.0) < 1e-12 and (np.diff(w) <= 1e-15).all() and (w[r >= 3.64 * 0.002] == 0).all() and w[r < 3.6 * 0.002].min() > 0
+
+
+@pytest.mark.parametrize('scoring', ['magsac', 'count'])
 @pytest.mark.parametrize('seed,outliers', [(0, 0.2), (1, 0.3), (2, 0.35)])
-def test_ransac_twin_recovers_a_known_pose(seed, outliers):
+def test_ransac_twin_recovers_a_known_pose(seed, outliers, scoring):
     k0, k1, K, R, t, truth = po.synthetic_scene(500, outliers=outliers, noise=0.3, seed=seed)
-    r = po.estimate_pose(k0, k1, K, K, 1.0, iterations=2048, seed=7, return_consensus=True)
+    r = po.estimate_pose(k0, k1, K, K, 1.0, iterations=2048, seed=7, return_consensus=True, scoring=scoring)
     assert r is not None
     E, Re, te, mref, m = r
     assert (mref | ~m).all() and (mref & ~m).sum() > 0      # the reference's mask (eval/pose_estimation.py:113-114) keeps non-consensus matches True
