@@ -3,18 +3,25 @@
 //   decompose_essential_mat    eval/pose_estimation.py:13-89      4-way cheirality vote (R1 | R2, +-t)
 //
 // The reference parks the GPU during every pose estimate (cv2.findEssentialMat(USAC_MAGSAC) on the host, 7 times per pair,
-// eval/matching.py:84-87).  Here the estimate is a batch of tiny kernels: H seeded 8-point hypotheses in parallel (one
-// thread each: Hartley conditioning, null vector of the 8x9 system by Gauss-Jordan, projection onto the essential manifold), a
-// Sampson-distance inlier count per hypothesis (one workgroup each), then ONE workgroup that picks the first best
-// hypothesis, refits on its consensus set (up to 3 times, kept while not worse), decomposes E and takes the cheirality vote
-// with per-point DLT triangulation.  Everything in fp64 (n <= a few thousand correspondences: the work is microseconds).
+// eval/matching.py:84-87).  Here the estimate is a batch of small kernels:
+//   * H seeded minimal samples in parallel, one thread each: FIVE-POINT solver (round 3, default; pose_fivept.h: up to 10 essential
+//     matrices per sample, like the minimal solver inside cv2.findEssentialMat) or the linear eight-point solver of round 2 (Hartley
+//     conditioning, null vector by Gauss-Jordan, projection onto the essential manifold);
+//   * one workgroup per candidate model: MAGSAC++ sigma-marginalised quality (round 3, default) or the Sampson inlier count;
+//   * ONE workgroup picks the first best model and refines it by (weighted) least squares - IRLS with the MAGSAC++ weights, or refits
+//     on the consensus set - up to 3 times while not worse, then decomposes E;
+//   * the 4-way cheirality vote with per-point DLT triangulation, and the masks (the reference's all-True-outside-the-consensus mask and
+//     the geometric one).
+// Everything in fp64 (n <= a few thousand correspondences).
 //
-// PARITY: the solver is NOT OpenCV's MAGSAC - that is a third-party randomized algorithm with no golden vectors in the
-// reference and cv2 is absent from the build image: parity with it is unpinned and not claimed.  What IS pinned: these
-// kernels against their CPU twin oracle/pose_oracle.py (same hypothesis sampling, same algebra), and the cheirality vote
-// against the geometric definition (tests/test_pose.py, tests/test_gpu_pose.py).
+// PARITY: the solver follows the PUBLISHED algorithms behind the reference's call (five-point minimal solver, MAGSAC++ quality and IRLS)
+// but it is NOT OpenCV's implementation - a third-party randomized solver with its own sampler, termination and local optimisation, no
+// golden vectors in the reference, and cv2 is absent from the build image: parity with it is unpinned and not claimed.  What IS pinned:
+// these kernels against their CPU twin oracle/pose_oracle.py (same samples, same algebra, every mode), the five-point header against the
+// twin on the host (tests/test_pose.py), the cheirality vote against the geometric definition, recovery of known poses.
 #include "imp_kernels.h"
 #include "../../include/imp_hip.h"
+#include "pose_fivept.h"
 #include <mutex>
 #include <vector>
 
@@ -260,6 +267,32 @@ __global__ __launch_bounds__(64) void pose_hypotheses_kernel(const double2* __re
     if (ok) for (int i = 0; i < 9; ++i) Eh[(long)h * 9 + i] = E[i / 3][i % 3];
 }
 
+// five-point sampler: one thread per minimal sample, up to 10 models each (pose_fivept.h); candidate c of sample h lives at slot 10 h + c.
+// The solver is one long dependent chain of run-time-indexed array accesses: with the arrays in scratch memory (an L2 round trip each) a
+// call took 1.84 ms however few samples it had; every thread gets its Work in LDS instead (8 threads per workgroup = 47 KB)
+constexpr int FP_THREADS = 8;
+__global__ __launch_bounds__(64) void pose_hypotheses5_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n,
+                                                              int H, unsigned seed, double* __restrict__ Eh, int* __restrict__ valid) {
+    __shared__ fivept::Work work[FP_THREADS];
+    if (threadIdx.x >= FP_THREADS) return;
+    const int h = blockIdx.x * FP_THREADS + threadIdx.x;
+    if (h >= H) return;
+    int ids[5];
+    bool ok = true;
+    for (int k = 0; k < 5; ++k) {
+        ids[k] = (int)(pose_rand(seed, (unsigned)h, (unsigned)k) % (unsigned)n);
+        for (int j = 0; j < k; ++j) ok &= ids[j] != ids[k];
+    }
+    int nsol = 0;
+    double* Eo = Eh + (long)h * 90;
+    if (ok) {
+        double a[5][2], b[5][2];
+        for (int k = 0; k < 5; ++k) { a[k][0] = x0[ids[k]].x; a[k][1] = x0[ids[k]].y; b[k][0] = x1[ids[k]].x; b[k][1] = x1[ids[k]].y; }
+        nsol = fivept::five_point(a, b, Eo, work[threadIdx.x]);
+    }
+    for (int c = 0; c < 10; ++c) valid[(long)h * 10 + c] = c < nsol ? 1 : 0;
+}
+
 // one workgroup per hypothesis: inlier count (magsac == 0) or sigma-marginalised quality floor(4096 sum_i w(r_i)) (magsac != 0)
 __global__ __launch_bounds__(256) void pose_score_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n,
                                                          const double* __restrict__ Eh, const int* __restrict__ valid, double thr2, int magsac,
@@ -296,7 +329,7 @@ __device__ double block_sum(double v, double* sm) {        // 1024 threads
 
 // one workgroup: first best hypothesis -> consensus refits -> decomposition of E
 __global__ __launch_bounds__(1024) void pose_consensus_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n, int H,
-                                                           const double* __restrict__ Eh, const int* __restrict__ counts, double thr2, int magsac,
+                                                           const double* __restrict__ Eh, const int* __restrict__ counts, double thr2, int magsac, int nsample,
                                                            unsigned char* __restrict__ inl, double* __restrict__ out) {
     // out: [0..8] E, [9..17] R, [18..20] t, [21] inliers of E, [22] cheirality inliers, [23] ok flag, [24..32] R1, [33..41] R2, [42..44] t
     __shared__ double sm[16 * 45];
@@ -321,7 +354,8 @@ __global__ __launch_bounds__(1024) void pose_consensus_kernel(const double2* __r
         }
         __syncthreads();
     }
-    if (s_best < 0 || s_cnt < (magsac ? (int)(8 * QUALITY_SCALE / 2) : 8)) { if (tid == 0) out[23] = 0.0; return; }
+    // nsample = size of the minimal sample (5 or 8): a model has to explain at least that many matches (half of it in weight units)
+    if (s_best < 0 || s_cnt < (magsac ? (int)(nsample * QUALITY_SCALE / 2) : nsample)) { if (tid == 0) out[23] = 0.0; return; }
     // per-point weight of the current model: 0 / 1 membership of the consensus set, or the sigma-marginalised weight (IRLS)
     auto weight = [&](const double* E, int i) {
         const double r2 = sampson_sq(E, x0[i].x, x0[i].y, x1[i].x, x1[i].y);
@@ -329,7 +363,7 @@ __global__ __launch_bounds__(1024) void pose_consensus_kernel(const double2* __r
     };
     for (int i = tid; i < n; i += 1024) inl[i] = sampson_sq(Es, x0[i].x, x0[i].y, x1[i].x, x1[i].y) < thr2;
     __syncthreads();
-    for (int round = 0; round < 3; ++round) {
+    for (int round = 0; round < (n >= 8 ? 3 : 0); ++round) {      // the linear refit needs 8 correspondences
         // conditioning of the (weighted) consensus set
         double c = 0, sx0 = 0, sy0 = 0, sx1 = 0, sy1 = 0;
         for (int i = tid; i < n; i += 1024) { const double w = weight(Es, i); if (w > 0) { c += w; sx0 += w * x0[i].x; sy0 += w * x0[i].y; sx1 += w * x1[i].x; sy1 += w * x1[i].y; } }
@@ -484,7 +518,8 @@ extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, 
                                  unsigned char* consensus, int* n_inliers, int flags, void* stream) {
     if (!kpts0 || !kpts1 || !K0 || !K1 || !E || !R || !t || !mask || !n_inliers || iterations < 1) return IMP_E_ARG;
     *n_inliers = 0;
-    if (n < 8) return 1;                                   // (the reference returns None below 5 points; the 8-point solver needs 8)
+    const bool eight = (flags & 2) != 0;                   // IMP_POSE_8PT: the linear eight-point sampler of round 2
+    if (n < (eight ? 8 : 5)) return 1;                     // eval/pose_estimation.py:93: None below 5 matches (8 for the eight-point sampler)
     if (hipSetDevice(device) != hipSuccess) return IMP_E_HIP;
     hipStream_t st = (hipStream_t)stream;
     static thread_local PoseWs ws;
@@ -494,9 +529,9 @@ extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, 
         ws = PoseWs();
         const size_t cn = (size_t)n < 4096 ? 4096 : (size_t)n, ch = (size_t)iterations < 2048 ? 2048 : (size_t)iterations;
         if (hipMalloc(&ws.x0, cn * sizeof(double2)) != hipSuccess || hipMalloc(&ws.x1, cn * sizeof(double2)) != hipSuccess ||
-            hipMalloc(&ws.Eh, ch * 9 * sizeof(double)) != hipSuccess || hipMalloc(&ws.out, 48 * sizeof(double)) != hipSuccess ||
+            hipMalloc(&ws.Eh, ch * 10 * 9 * sizeof(double)) != hipSuccess || hipMalloc(&ws.out, 48 * sizeof(double)) != hipSuccess ||
             hipMalloc(&ws.good, 4 * sizeof(int)) != hipSuccess || hipMalloc(&ws.bits, cn) != hipSuccess ||
-            hipMalloc(&ws.valid, ch * sizeof(int)) != hipSuccess || hipMalloc(&ws.counts, ch * sizeof(int)) != hipSuccess ||
+            hipMalloc(&ws.valid, ch * 10 * sizeof(int)) != hipSuccess || hipMalloc(&ws.counts, ch * 10 * sizeof(int)) != hipSuccess ||
             hipMalloc(&ws.inl, cn) != hipSuccess || hipMalloc(&ws.refmask, cn) != hipSuccess)
             return IMP_E_NOMEM;
         ws.device = device; ws.cap_n = cn; ws.cap_h = ch;
@@ -510,11 +545,13 @@ extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, 
     if (hipMemcpyAsync(ws.x0, h0.data(), n * sizeof(double2), hipMemcpyHostToDevice, st) != hipSuccess) return IMP_E_HIP;
     if (hipMemcpyAsync(ws.x1, h1.data(), n * sizeof(double2), hipMemcpyHostToDevice, st) != hipSuccess) return IMP_E_HIP;
     const double thr = norm_thresh / ((K0[0] + K0[4] + K1[0] + K1[4]) / 4.0);
-    hipLaunchKernelGGL(pose_hypotheses_kernel, dim3((iterations + 63) / 64), dim3(64), 0, st, ws.x0, ws.x1, n, iterations, seed, ws.Eh, ws.valid);
-    hipLaunchKernelGGL(pose_score_kernel, dim3(iterations), dim3(256), 0, st, ws.x0, ws.x1, n, ws.Eh, ws.valid, thr * thr, flags & 1, ws.counts);
+    const int ncand = eight ? iterations : iterations * 10;
+    if (eight) hipLaunchKernelGGL(pose_hypotheses_kernel, dim3((iterations + 63) / 64), dim3(64), 0, st, ws.x0, ws.x1, n, iterations, seed, ws.Eh, ws.valid);
+    else hipLaunchKernelGGL(pose_hypotheses5_kernel, dim3((iterations + FP_THREADS - 1) / FP_THREADS), dim3(64), 0, st, ws.x0, ws.x1, n, iterations, seed, ws.Eh, ws.valid);
+    hipLaunchKernelGGL(pose_score_kernel, dim3(ncand), dim3(256), 0, st, ws.x0, ws.x1, n, ws.Eh, ws.valid, thr * thr, flags & 1, ws.counts);
     // the cheirality step of the reference normalises with K = (K0 + K1) / 2 (eval/pose_estimation.py:29-33): with K0 == K1 (every
     // caller in the repo) these are the coordinates above; a caller with two different cameras gets per-camera normalisation
-    hipLaunchKernelGGL(pose_consensus_kernel, dim3(1), dim3(1024), 0, st, ws.x0, ws.x1, n, iterations, ws.Eh, ws.counts, thr * thr, flags & 1, ws.inl, ws.out);
+    hipLaunchKernelGGL(pose_consensus_kernel, dim3(1), dim3(1024), 0, st, ws.x0, ws.x1, n, ncand, ws.Eh, ws.counts, thr * thr, flags & 1, eight ? 8 : 5, ws.inl, ws.out);
     if (hipMemsetAsync(ws.good, 0, 4 * sizeof(int), st) != hipSuccess) return IMP_E_HIP;
     hipLaunchKernelGGL(pose_cheirality_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws.x0, ws.x1, n, ws.out, ws.inl, 1000.0, ws.bits, ws.good);
     hipLaunchKernelGGL(pose_vote_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, ws.good, ws.bits, ws.inl, ws.refmask, ws.out);

@@ -229,13 +229,13 @@ int imp_time_layer_gemm(imp_ctx* ctx, int batch, int n, int which, int dbg, int 
 /* Pose step of the iterative loops (eval/pose_estimation.py:92-115 estimate_pose + :13-89 decompose_essential_mat) - SURVEY §8 f-1.
  * HOST arrays in, HOST arrays out (the matched keypoints of a loop iteration live on the host, eval/matching.py:68-87):
  * kpts0 / kpts1 [n][2] pixels, K0 / K1 row-major 3x3, norm_thresh in pixels (divided by the mean focal length inside).
- * `iterations` seeded 8-point hypotheses + consensus refits + cheirality vote on the GPU `device`, on `stream`; synchronises.
+ * `iterations` seeded minimal samples (five-point solver by default) + refits + cheirality vote on the GPU `device`, on `stream`; synchronises.
  * Returns 0 and E, R (row-major 3x3), t, *n_inliers (consensus matches in front of both cameras) and two masks [n]:
  *   mask       what the reference returns (:113-114): all True, with only the CONSENSUS entries overwritten by the cheirality result -
  *              matches outside the consensus stay 1.  The loops derive their inlier ratio and early-exit indices from it
  *              (eval/matching.py:89-90,113), so the drop-in reproduces the quirk;
  *   consensus  (optional) the geometric mask: inlier of E AND in front of both cameras.
- * 1 = no pose (fewer than 8 matches / no consensus: the reference returns None - below 5 matches); < 0 = error.
+ * 1 = no pose (fewer than 5 matches - 8 with IMP_POSE_8PT - or no consensus: the reference returns None); < 0 = error.
  * NOT OpenCV's USAC_MAGSAC: parity with that third-party solver is unpinned (see csrc/pose.hip). */
 int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, const double* K0, const double* K1, double norm_thresh,
                       int iterations, unsigned seed, int device, double* E, double* R, double* t, unsigned char* mask,
@@ -245,6 +245,10 @@ int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, const doubl
  * count, and the winner is refined by weighted least squares with those weights (IRLS) instead of refits on the consensus set.  The masks
  * still use the hard threshold.  This follows the PUBLISHED algorithm; OpenCV's USAC_MAGSAC implementation itself remains unpinned. */
 #define IMP_POSE_MAGSAC 1
+/* flags bit 1 (IMP_POSE_8PT): minimal samples of 8 matches through the linear eight-point solver (round 2) instead of 5 matches through the
+ * five-point solver (Nister / Stewenius-Engels-Nister: up to 10 models per sample; csrc/pose_fivept.h), which is the default: like the
+ * reference it then answers from 5 matches on (eval/pose_estimation.py:93) */
+#define IMP_POSE_8PT 2
 /* Chip-resident Sinkhorn health (csrc/ot_resident.hip; the kernel behind compute_score, nets/gm.py:297-303).  Its workgroups
  * exchange vectors through memory with bounded waits.  A wait that times out (a second process on the GPU, a partition mode
  * that places workgroups differently) voids the launch: the kernel poisons its outputs (maxima NaN -> mscores NaN, indices -1)

@@ -121,6 +121,140 @@ def sampson_sq(E, x0, x1):
     return num / np.maximum(den, 1e-30)
 
 
+# ------------------------------------------------------------------------------------------------ five-point minimal solver
+# Nister's problem in Stewenius' formulation (H. Stewenius, C. Engels, D. Nister, "Recent developments on direct relative orientation",
+# ISPRS J. 2006): E lives in the 4-dimensional null space of the 5 epipolar constraints, E = x X + y Y + z Z + W; det(E) = 0 and
+# 2 E E^T E - tr(E E^T) E = 0 are ten cubics in (x, y, z); after elimination of the ten degree-3 monomials the multiplication-by-x map
+# on the quotient-ring basis [x^2, xy, xz, y^2, yz, z^2, x, y, z, 1] is a 10 x 10 matrix whose real eigenpairs are the solutions.
+# This is the minimal solver inside cv2.findEssentialMat; restated here from the publication (cv2 is absent), twin of csrc/pose.hip.
+_MON3 = [(3, 0, 0), (2, 1, 0), (2, 0, 1), (1, 2, 0), (1, 1, 1), (1, 0, 2), (0, 3, 0), (0, 2, 1), (0, 1, 2), (0, 0, 3),
+         (2, 0, 0), (1, 1, 0), (1, 0, 1), (0, 2, 0), (0, 1, 1), (0, 0, 2), (1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 0, 0)]
+_MON2 = _MON3[10:]                                   # quadratic polynomials: 10 coefficients in this order
+_MON1 = [(1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 0, 0)]
+_I3 = {m: i for i, m in enumerate(_MON3)}
+_I2 = {m: i for i, m in enumerate(_MON2)}
+LL = [[_I2[tuple(a + b for a, b in zip(_MON1[i], _MON1[j]))] for j in range(4)] for i in range(4)]       # linear x linear -> quadratic slot
+QL = [[_I3[tuple(a + b for a, b in zip(_MON2[i], _MON1[j]))] for j in range(4)] for i in range(10)]     # quadratic x linear -> cubic slot
+
+
+def _mul_ll(a, b):
+    out = np.zeros(10)
+    for i in range(4):
+        for j in range(4):
+            out[LL[i][j]] += a[i] * b[j]
+    return out
+
+
+def _mul_ql(a, b):
+    out = np.zeros(20)
+    for i in range(10):
+        for j in range(4):
+            out[QL[i][j]] += a[i] * b[j]
+    return out
+
+
+def null_basis_5x9(Q):
+    """4 vectors spanning the null space of the 5 x 9 system: Gauss-Jordan with full pivoting (largest |entry| of the remaining rows,
+    first in row-major order on ties); free column f gives the vector with 1 at f and -R[i][f] at pivot column i.  Returns None if rank < 5"""
+    A = np.array(Q, dtype=np.float64)
+    piv = []
+    for r in range(5):
+        sub = np.abs(A[r:, :])
+        k = int(np.argmax(sub))
+        pr, pc = r + k // 9, k % 9
+        if not sub.flat[k] > 1e-14:
+            return None
+        A[[r, pr]] = A[[pr, r]]
+        A[r] /= A[r, pc]
+        for i in range(5):
+            if i != r:
+                A[i] -= A[i, pc] * A[r]
+        piv.append(pc)
+    free = [c for c in range(9) if c not in piv]
+    basis = []
+    for f in free:
+        v = np.zeros(9)
+        v[f] = 1.0
+        for i, pc in enumerate(piv):
+            v[pc] = -A[i, f]
+        basis.append(v)
+    return basis
+
+
+def _solve_6x5(C, d):
+    """consistent 6 x 5 system by Gauss-Jordan with full pivoting over all six rows (csrc/pose_fivept.h solve_yz: same pivot rule)"""
+    G = np.concatenate([C, d[:, None]], axis=1).astype(np.float64)
+    perm = list(range(5))
+    for c in range(5):
+        sub = np.abs(G[c:, c:5])
+        k = int(np.argmax(sub))
+        pr, pc = c + k // (5 - c), c + k % (5 - c)
+        if not sub.flat[k] > 0.0:
+            return None
+        G[[c, pr]] = G[[pr, c]]
+        if pc != c:
+            G[:, [c, pc]] = G[:, [pc, c]]
+            perm[c], perm[pc] = perm[pc], perm[c]
+        G[c, c:] /= G[c, c]
+        for i in range(6):
+            if i != c and G[i, c] != 0.0:
+                G[i, c:] -= G[i, c] * G[c, c:]
+    u = np.zeros(5)
+    for c in range(5):
+        u[perm[c]] = G[c, 5]
+    return u
+
+
+def five_point(x0, x1):
+    """x0, x1 [5, 2] normalised points -> up to 10 essential matrices (Frobenius norm 1, x1h^T E x0h = 0), in ascending order of the
+    eigenvalue (= the coefficient x of the first null vector)"""
+    Q = np.stack([np.array([b[0] * a[0], b[0] * a[1], b[0], b[1] * a[0], b[1] * a[1], b[1], a[0], a[1], 1.0]) for a, b in zip(x0, x1)])
+    basis = null_basis_5x9(Q)
+    if basis is None:
+        return []
+    X, Y, Z, W = basis
+    E = [[np.array([X[3 * i + j], Y[3 * i + j], Z[3 * i + j], W[3 * i + j]]) for j in range(3)] for i in range(3)]      # linear polynomials
+    d = lambda a, b, c, e: _mul_ll(a, e) - _mul_ll(b, c)          # 2 x 2 minor
+    det = _mul_ql(d(E[1][1], E[1][2], E[2][1], E[2][2]), E[0][0]) - _mul_ql(d(E[1][0], E[1][2], E[2][0], E[2][2]), E[0][1]) \
+        + _mul_ql(d(E[1][0], E[1][1], E[2][0], E[2][1]), E[0][2])
+    EEt = [[sum(_mul_ll(E[i][k], E[j][k]) for k in range(3)) for j in range(3)] for i in range(3)]
+    tr = EEt[0][0] + EEt[1][1] + EEt[2][2]
+    A = np.zeros((10, 20))
+    A[0] = det
+    for i in range(3):
+        for j in range(3):
+            A[1 + 3 * i + j] = 2.0 * sum(_mul_ql(EEt[i][k], E[k][j]) for k in range(3)) - _mul_ql(tr, E[i][j])
+    try:
+        B = np.linalg.solve(A[:, :10], A[:, 10:])
+    except np.linalg.LinAlgError:
+        return []
+    M = np.zeros((10, 10))
+    M[0:6] = -B[0:6]                 # x . [x^2, xy, xz, y^2, yz, z^2] = the degree-3 monomials x^3, x^2 y, x^2 z, x y^2, xyz, x z^2
+    M[6, 0] = M[7, 1] = M[8, 2] = M[9, 6] = 1.0
+    w = np.linalg.eigvals(M)
+    out = []
+    for lam in sorted(float(v.real) for v in w if v.imag == 0.0 and np.isfinite(v.real)):
+        # the eigenvector b = [x^2, xy, xz, y^2, yz, z^2, x, y, z, 1] of M for x = lam: rows 6..9 of M are unit rows, so b6 = lam, b0 = lam^2,
+        # b1 = lam b7, b2 = lam b8 (b9 = 1), and rows 0..5 of (M - lam I) b = 0 are six consistent equations in u = (y^2, yz, z^2, y, z)
+        C = np.zeros((6, 5))
+        d = np.zeros(6)
+        S = M - lam * np.eye(10)
+        for r in range(6):
+            C[r] = [S[r, 3], S[r, 4], S[r, 5], M[r, 7] + lam * S[r, 1], M[r, 8] + lam * S[r, 2]]
+            d[r] = -(lam * lam * S[r, 0] + lam * M[r, 6] + M[r, 9])
+        u = _solve_6x5(C, d)
+        if u is None:
+            continue
+        x, y, z = lam, u[3], u[4]
+        if not (np.isfinite(y) and np.isfinite(z)):
+            continue
+        Es = (x * X + y * Y + z * Z + W).reshape(3, 3)
+        nrm = np.linalg.norm(Es)
+        if nrm > 0 and np.isfinite(nrm):
+            out.append(Es / nrm)
+    return out
+
+
 MAGSAC_K = 3.64
 QUALITY_SCALE = 4096.0
 
@@ -160,14 +294,16 @@ def _weighted_essential(x0, x1, w):
 
 
 def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, mask=None, iterations=4096, seed=1, return_consensus=False,
-                  scoring='magsac'):
+                  scoring='magsac', sampler='5pt'):
     """Signature of eval/pose_estimation.py:92 -> None | (E, R, t, mask).  Threshold: norm_thresh pixels divided by the
     mean focal length, applied to the Sampson distance in normalised coordinates.  ``mask`` follows :113-114 literally: all True,
     only the consensus entries overwritten by the cheirality result; ``return_consensus`` appends the geometric mask
     (consensus AND in front of both cameras).  ``scoring``: 'magsac' = sigma-marginalised quality + IRLS refinement (MAGSAC++ as
-    published), 'count' = inlier counting + refits on the consensus set.  CPU twin of csrc/pose.hip in both modes."""
+    published), 'count' = inlier counting + refits on the consensus set.  ``sampler``: '5pt' = five-point minimal solver (up to 10 models
+    per sample; the reference's minimum of 5 matches, eval/pose_estimation.py:93), '8pt' = the linear eight-point solver of round 2
+    (needs 8).  CPU twin of csrc/pose.hip in every mode."""
     n = len(kpts0)
-    if n < 8:
+    if n < (5 if sampler == '5pt' else 8):
         return None
     mag = scoring == 'magsac'
     x0, x1 = normalise(kpts0, K0), normalise(kpts1, K1)
@@ -183,17 +319,19 @@ def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, 
         return int(np.floor(q * QUALITY_SCALE)) if mag else int(q)
 
     best, bestE = -1, None
+    ns = 5 if sampler == '5pt' else 8
     for h in range(iterations):
-        ids = [sample_index(seed, h, k, n) for k in range(8)]
-        if len(set(ids)) < 8:
+        ids = [sample_index(seed, h, k, n) for k in range(ns)]
+        if len(set(ids)) < ns:
             continue
-        E = essential_from(x0[ids], x1[ids])
-        cnt = quality(E)
-        if cnt > best:
-            best, bestE = cnt, E
-    if bestE is None or best < (4 * QUALITY_SCALE if mag else 8):
+        cands = five_point(x0[ids], x1[ids]) if sampler == '5pt' else [essential_from(x0[ids], x1[ids])]
+        for E in cands:                                  # first best: lowest hypothesis, then lowest candidate index
+            cnt = quality(E)
+            if cnt > best:
+                best, bestE = cnt, E
+    if bestE is None or best < ((ns / 2) * QUALITY_SCALE if mag else ns):
         return None
-    for rnd in range(3):                                 # (weighted) least-squares refits, kept while not worse
+    for rnd in range(3 if n >= 8 else 0):                # (weighted) least-squares refits (need 8 points), kept while not worse
         w = weights(bestE)
         E2 = _weighted_essential(x0, x1, w)
         if E2 is None:

@@ -20,15 +20,16 @@ def _ang_vec(a, b):
     return np.rad2deg(np.arccos(np.clip(a @ b / np.linalg.norm(a) / np.linalg.norm(b), -1, 1)))
 
 
-@pytest.mark.parametrize('scoring', ['magsac', 'count'])
+@pytest.mark.parametrize('sampler,scoring', [('5pt', 'magsac'), ('5pt', 'count'), ('8pt', 'magsac'), ('8pt', 'count')])
 @pytest.mark.parametrize('n,outliers,noise,seed', [(400, 0.3, 0.3, 0), (1500, 0.4, 0.5, 1), (60, 0.2, 0.2, 2), (3000, 0.5, 0.4, 3),
-                                                   (9, 0.0, 0.0, 4)])
-def test_gpu_pose_equals_its_cpu_twin(n, outliers, noise, seed, scoring):
-    """both rankings: the sigma-marginalised quality of MAGSAC++ with IRLS refinement (default) and plain inlier counting"""
+                                                   (9, 0.0, 0.0, 4), (6, 0.0, 0.1, 5)])
+def test_gpu_pose_equals_its_cpu_twin(n, outliers, noise, seed, scoring, sampler):
+    """both samplers (five-point minimal solver, default; linear eight-point) and both rankings (sigma-marginalised MAGSAC++ quality with
+    IRLS refinement, default; plain inlier counting) against the numpy twin: same samples, same algebra, same consensus"""
     k0, k1, K, R, t, truth = po.synthetic_scene(n, outliers=outliers, noise=noise, seed=seed)
-    its = 512
-    g = hip_pose.estimate_pose(k0, k1, K, K, 1.0, iterations=its, seed=11, return_consensus=True, scoring=scoring)
-    c = po.estimate_pose(k0, k1, K, K, 1.0, iterations=its, seed=11, return_consensus=True, scoring=scoring)
+    its = 128 if sampler == '5pt' else 512
+    g = hip_pose.estimate_pose(k0, k1, K, K, 1.0, iterations=its, seed=11, return_consensus=True, scoring=scoring, sampler=sampler)
+    c = po.estimate_pose(k0, k1, K, K, 1.0, iterations=its, seed=11, return_consensus=True, scoring=scoring, sampler=sampler)
     assert (g is None) == (c is None)
     if g is None:
         return
@@ -55,7 +56,8 @@ def test_gpu_pose_recovers_known_poses(seed):
 
 def test_no_pose_cases():
     k0, k1, K, *_ = po.synthetic_scene(7, seed=1)
-    assert hip_pose.estimate_pose(k0, k1, K, K, 1.0) is None
+    assert hip_pose.estimate_pose(k0, k1, K, K, 1.0, sampler='8pt') is None
+    assert hip_pose.estimate_pose(k0[:4], k1[:4], K, K, 1.0) is None            # eval/pose_estimation.py:93: fewer than 5 matches
     g = np.random.default_rng(0)
     k0 = g.uniform(0, 640, (50, 2)).astype(np.float32)
     k1 = g.uniform(0, 480, (50, 2)).astype(np.float32)                            # pure noise: whatever comes out is well formed

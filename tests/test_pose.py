@@ -68,11 +68,56 @@ def test_magsac_weight_function():
     assert abs(w[0] - 1.0) < 1e-12 and (np.diff(w) <= 1e-15).all() and (w[r >= 3.64 * 0.002] == 0).all() and w[r < 3.6 * 0.002].min() > 0
 
 
-@pytest.mark.parametrize('scoring', ['magsac', 'count'])
+def test_five_point_solver_contains_the_true_essential_matrix():
+    """the five-point minimal solver (oracle twin of csrc/pose_fivept.h): on exact correspondences one of its <= 10 solutions is the true
+    E = [t]x R, every solution satisfies the five epipolar constraints and the essential-matrix constraints"""
+    found = 0
+    for seed in range(20):
+        k0, k1, K, R, t, _ = po.synthetic_scene(5, outliers=0.0, noise=0.0, seed=seed, angle_deg=5 + 2 * seed)
+        x0, x1 = po.normalise(k0, K), po.normalise(k1, K)
+        Et = _skew(t) @ R
+        Et /= np.linalg.norm(Et)
+        sols = po.five_point(x0, x1)
+        assert 1 <= len(sols) <= 10
+        for E in sols:
+            h0, h1 = np.c_[x0, np.ones(5)], np.c_[x1, np.ones(5)]
+            assert np.abs(np.einsum('ni,ij,nj->n', h1, E, h0)).max() < 1e-9
+            assert abs(np.linalg.det(E)) < 1e-9 and np.abs(2 * E @ E.T @ E - np.trace(E @ E.T) * E).max() < 1e-8
+        found += min(min(np.abs(E - Et).max(), np.abs(E + Et).max()) for E in sols) < 1e-4      # (keypoints are stored as fp32)
+    assert found >= 18
+
+
+def test_five_point_header_of_the_gpu_kernel_equals_the_twin(tmp_path):
+    """csrc/pose_fivept.h is plain C++: built for the host it must return the twin's solutions, in the twin's order"""
+    import os, shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which('g++') is None:
+        pytest.skip('no g++')
+    exe = str(tmp_path / 'fivept_host')
+    subprocess.run(['g++', '-O2', '-std=c++17', os.path.join(root, 'tools', 'probe', 'fivept_host.cpp'), '-o', exe], check=True)
+    scenes, lines = [], []
+    for s in range(24):
+        k0, k1, K, *_ = po.synthetic_scene(5, outliers=0.0 if s < 12 else 0.4, noise=0.0 if s < 6 else 0.5, seed=s)
+        x0, x1 = po.normalise(k0, K), po.normalise(k1, K)
+        scenes.append((x0, x1))
+        lines += ['%.17g %.17g %.17g %.17g' % (a[0], a[1], b[0], b[1]) for a, b in zip(x0, x1)]
+    out = subprocess.run([exe], input='\n'.join(lines) + '\n', capture_output=True, text=True, check=True).stdout.split('\n')
+    pos = 0
+    for x0, x1 in scenes:
+        n = int(out[pos]); pos += 1
+        got = [np.array(out[pos + k].split(), dtype=float).reshape(3, 3) for k in range(n)]; pos += n
+        ref = po.five_point(x0, x1)
+        assert len(ref) == n
+        for a, b in zip(got, ref):
+            assert np.abs(a - b).max() < 1e-7
+
+
+@pytest.mark.parametrize('sampler,scoring', [('5pt', 'magsac'), ('5pt', 'count'), ('8pt', 'magsac'), ('8pt', 'count')])
 @pytest.mark.parametrize('seed,outliers', [(0, 0.2), (1, 0.3), (2, 0.35)])
-def test_ransac_twin_recovers_a_known_pose(seed, outliers, scoring):
+def test_ransac_twin_recovers_a_known_pose(seed, outliers, scoring, sampler):
     k0, k1, K, R, t, truth = po.synthetic_scene(500, outliers=outliers, noise=0.3, seed=seed)
-    r = po.estimate_pose(k0, k1, K, K, 1.0, iterations=2048, seed=7, return_consensus=True, scoring=scoring)
+    r = po.estimate_pose(k0, k1, K, K, 1.0, iterations=256 if sampler == '5pt' else 2048, seed=7, return_consensus=True, scoring=scoring,
+                         sampler=sampler)
     assert r is not None
     E, Re, te, mref, m = r
     assert (mref | ~m).all() and (mref & ~m).sum() > 0      # the reference's mask (eval/pose_estimation.py:113-114) keeps non-consensus matches True
@@ -83,7 +128,8 @@ def test_ransac_twin_recovers_a_known_pose(seed, outliers, scoring):
 
 def test_too_few_matches_give_none():
     k0, k1, K, *_ = po.synthetic_scene(7, seed=1)
-    assert po.estimate_pose(k0, k1, K, K, 1.0) is None
+    assert po.estimate_pose(k0, k1, K, K, 1.0, sampler='8pt') is None
+    assert po.estimate_pose(k0[:4], k1[:4], K, K, 1.0) is None                  # eval/pose_estimation.py:93
 
 
 def test_sampling_hash_is_the_documented_one():
