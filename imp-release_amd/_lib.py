@@ -26,7 +26,7 @@ SYMBOLS = [
     'imp_last_error', 'imp_version', 'imp_create', 'imp_destroy', 'imp_load_tensor', 'imp_finalize_weights',
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
-    'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear', 'imp_op_layer_gemm',
+    'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_pool_select_pair', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear', 'imp_op_layer_gemm',
     'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_range_events', 'imp_time_layer_gemm', 'imp_estimate_pose',
     'imp_sp_create', 'imp_sp_destroy', 'imp_sp_set_weight', 'imp_sp_finalize', 'imp_sp_detect', 'imp_sp_describe', 'imp_sp_dense', 'imp_sp_op_conv',
 ]
@@ -107,6 +107,7 @@ def lib():
     L.imp_pool.argtypes = [P, I, I, P, F, F, I, P, P, P, P]
     L.imp_score_mass.argtypes = [P, I, I, P, P, P, P]
     L.imp_pool_select.argtypes = [P, I, P, P, P, F, P, P, P]
+    L.imp_pool_select_pair.argtypes = [P, I, P, P, P, I, P, I, P, P, P, I, P, F, P, P]
     L.imp_gather_rows.argtypes = [P, I, I, I, I, P, P, P, P]
     L.imp_match_pair.argtypes = [P, I, I, I, P, P, P, P, P, P, F, F, F, I, I, F, P, P, P, P, P, P]
     L.imp_op_linear.argtypes = [P, I, I, I, P, P, P, P, P]
@@ -344,6 +345,20 @@ class Context:
                                            _ptr(ids), _ptr(counts), _stream(self.device)))
         c = counts.tolist()
         return ids[:c[0]] if c[0] >= 0 else None
+
+    def pool_select_pair(self, mass0, a_self0, a_cross0, skip0, mass1, a_self1, a_cross1, skip1, thr):
+        """both images of a pair in one launch and ONE count read-back: -> (ids0 | None, ids1 | None) (None: side skipped or nothing confident)"""
+        v = [_f32(t, 'pool vector') for t in (mass0, a_self0, a_cross0, mass1, a_self1, a_cross1)]
+        n0, n1 = v[0].numel(), v[3].numel()
+        dev = v[0].device
+        ids0 = torch.empty(n0, device=dev, dtype=torch.int64)
+        ids1 = torch.empty(n1, device=dev, dtype=torch.int64)
+        counts = torch.empty(4, device=dev, dtype=torch.int32)
+        self._check(self.L.imp_pool_select_pair(self.handle, n0, _ptr(v[0]), _ptr(v[1]), _ptr(v[2]), 1 if skip0 else 0, _ptr(ids0),
+                                                n1, _ptr(v[3]), _ptr(v[4]), _ptr(v[5]), 1 if skip1 else 0, _ptr(ids1), float(thr),
+                                                _ptr(counts), _stream(self.device)))
+        c = counts.tolist()
+        return (ids0[:c[0]] if c[0] >= 0 else None), (ids1[:c[2]] if c[2] >= 0 else None)
 
     def gather_rows(self, x, ids):
         x = _f32(x, 'x')

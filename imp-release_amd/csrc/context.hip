@@ -874,7 +874,7 @@ int imp_fail(int code, const char* msg) { return fail(code, msg); }   // for the
 extern "C" {
 
 const char* imp_last_error(void) { return g_err.c_str(); }
-const char* imp_version(void) { return "imp_hip 0.2 gfx950 f16x3-mfma|f32-mfma"; }
+const char* imp_version(void) { return "imp_hip 0.3 gfx950 f16x3-mfma|f32-mfma"; }
 
 int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     if (!out || !cfg) return fail(IMP_E_ARG, "imp_create: null argument");
@@ -1205,6 +1205,19 @@ int imp_pool_select(imp_ctx* c, int n, const float* mass, const float* a_self, c
     ps[0] = PoolSide{mass, a_self, a_cross, ids, n, 0};
     ps[1] = ps[0];
     HIP_TRY(launch_pool_select(ps, 1, thr, counts, S(stream)));
+    return IMP_OK;
+}
+
+int imp_pool_select_pair(imp_ctx* c, int n0, const float* mass0, const float* a_self0, const float* a_cross0, int skip0, int64_t* ids0,
+                         int n1, const float* mass1, const float* a_self1, const float* a_cross1, int skip1, int64_t* ids1, float thr,
+                         int32_t* counts, void* stream) {
+    if (!c || !mass0 || !a_self0 || !a_cross0 || !ids0 || !mass1 || !a_self1 || !a_cross1 || !ids1 || !counts || n0 < 1 || n1 < 1)
+        return fail(IMP_E_ARG, "imp_pool_select_pair: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    PoolSide ps[2];
+    ps[0] = PoolSide{mass0, a_self0, a_cross0, ids0, n0, skip0 ? 1 : 0};
+    ps[1] = PoolSide{mass1, a_self1, a_cross1, ids1, n1, skip1 ? 1 : 0};
+    HIP_TRY(launch_pool_select(ps, 2, thr, counts, S(stream)));
     return IMP_OK;
 }
 

@@ -498,12 +498,12 @@ class AdaGMN(GM):
                 if updating:
                     thr = mscore_th * uncertainty_ratio
                     mass0, mass1 = ctx.score_mass(score[0])
-                    if not (n_min > 0 and g0.numel() <= n_min):               # nets/adgm.py:465 (N, not N+1)
-                        f0 = ctx.pool_select(mass0, a00[bi][g0], a01[bi][g0], thr)
+                    skip0 = n_min > 0 and g0.numel() <= n_min                 # nets/adgm.py:465 (N, not N+1)
+                    skip1 = n_min > 0 and g1.numel() <= n_min
+                    if not (skip0 and skip1):                                 # both images in one launch, one count read-back
+                        f0, f1 = ctx.pool_select_pair(mass0, a00[bi][g0], a01[bi][g0], skip0, mass1, a11[bi][g1], a10[bi][g1], skip1, thr)
                         if f0 is not None:
                             g0 = g0[f0]
-                    if not (n_min > 0 and g1.numel() <= n_min):
-                        f1 = ctx.pool_select(mass1, a11[bi][g1], a10[bi][g1], thr)
                         if f1 is not None:
                             g1 = g1[f1]
                     gids0[bi], gids1[bi] = g0, g1

@@ -177,6 +177,12 @@ int imp_score_mass(imp_ctx* ctx, int n0, int n1, const float* scores, float* mas
  * ids int64 [n]; counts int32[2] DEVICE = {n_keep or -1 when nothing is confident, n_confident}. */
 int imp_pool_select(imp_ctx* ctx, int n, const float* mass, const float* a_self, const float* a_cross, float thr,
                     int64_t* ids, int32_t* counts, void* stream);
+/* Both images of a pair in ONE launch (one count read-back per pair and updating iteration instead of two): side s is skipped
+ * (counts[2 s] = -1, nets/adgm.py:465-473: no more than n_min_tokens keypoints left) when skip_s != 0.  counts int32[4] DEVICE =
+ * {n_keep0 | -1, n_confident0, n_keep1 | -1, n_confident1}. */
+int imp_pool_select_pair(imp_ctx* ctx, int n0, const float* mass0, const float* a_self0, const float* a_cross0, int skip0, int64_t* ids0,
+                         int n1, const float* mass1, const float* a_self1, const float* a_cross1, int skip1, int64_t* ids1, float thr,
+                         int32_t* counts, void* stream);
 
 /* desc[:, :, sel_ids] of eval/matching.py:166-174 on token-major data: out[b][i][:] = in[b][ids[i]][:] */
 int imp_gather_rows(imp_ctx* ctx, int batch, int n_in, int n_out, int dim, const float* in,
