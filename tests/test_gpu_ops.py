@@ -374,10 +374,13 @@ def test_attention_extreme_logits(gm, scale, B, nq, nk):
     assert e_lse < 2e-5, f'attention lse rel err {e_lse:.3e}'
 
 
-def test_operand_beyond_the_fp16_range_is_reported_not_silent():
+@pytest.mark.parametrize('resident', ['1', '0'])
+def test_operand_beyond_the_fp16_range_is_reported_not_silent(resident):
     """f16x3 arithmetic: |x| >= 65504 in a matrix operand makes the scores NaN.  The match kernel notices, the matches of that call
     are void (-1) and the next entry point raises IMP_E_RANGE; precision f32 handles the same data (VERDICT r2 weak #2)"""
     from imp_release_amd._lib import OperandRangeError
+    import os
+    os.environ['IMP_OT_RESIDENT'] = resident            # chip-resident and streaming Sinkhorn kernels: both end in the same match kernel
     cfg = eval_config(n_layers=2, sinkhorn_iterations=10)
     sd = synthetic.make_state_dict(cfg, 'GM', seed=3)
     pair = synthetic.make_correlated_pair(300, 280, seed=5)
@@ -386,7 +389,11 @@ def test_operand_beyond_the_fp16_range_is_reported_not_silent():
     big = dict(data)
     big['descriptors0'] = data['descriptors0'] * 1.0
     big['descriptors0'][0, 7, 3] = 7.0e4                           # one operand beyond the fp16 range
-    m = make_hip_model('GM', cfg, sd)
+    try:
+        m = make_hip_model('GM', cfg, sd)
+        m._ensure_ctx()
+    finally:
+        del os.environ['IMP_OT_RESIDENT']
     with torch.no_grad():
         out = m.produce_matches(big, p=0.2, only_last=True)
         torch.cuda.synchronize()
