@@ -229,7 +229,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--quick-c5', action='store_true', help='configs[4] keys on 48 instead of 1000 pair evaluations (smoke runs)')
     ap.add_argument('--no-batch1', action='store_true', help='skip the extra batch-1 latency keys (profiling runs: keeps their kernels out of the trace)')
-    ap.add_argument('--in-flight', type=int, default=2,
+    ap.add_argument('--in-flight', type=int, default=3,
                     help='batch-steps in flight per GPU (model replicas, one stream + host thread each; the result '
                          'exchange stays one ordered lane). 1 = strictly one step after the other')
     ap.add_argument('--h2d', action='store_true',
