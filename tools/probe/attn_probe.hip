@@ -2,11 +2,14 @@
 // prints per-wave cycle counts of the ping-pong phases + launch timings.   hipcc --offload-arch=gfx950 -O3 -DPP_PROFILE
 #include "../../imp-release_amd/csrc/attention_f16x3.hip"
 #include <stdio.h>
+// (the library keeps the granted sizes per device in gemm_f32.hip; the probe just grants)
+hipError_t imp_grant_dynamic_lds(const void* kernel, size_t bytes) { return bytes > 48 * 1024 ? hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) : hipSuccess; }
 #include <string.h>
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 4, n = argc > 2 ? atoi(argv[2]) : 2048, D = 256;
+    const int kvp = argc > 3 ? atoi(argv[3]) : 1;            // K / V as split-half images staged by plain copy (the product's format)
     const size_t qkv = (size_t)B * n * 3 * D;
     std::vector<float> h(qkv);
     unsigned s = 12345;
@@ -24,6 +27,10 @@ int main(int argc, char** argv) {
         AttnSide& g = a.side[i];
         g.q = qs[i]; g.k = qs[1 - i] + D; g.v = qs[1 - i] + 2 * D; g.out = os[i];
         g.sq_b = g.sk_b = (long)n * 3 * D; g.so_b = (long)n * D; g.nq = g.nk = n;
+    }
+    if (kvp) {
+        for (float* q : {q0, q1}) { CK(launch_attn_kv_planes(q, (long)B * n, 3 * D, D, 64, 0)); CK(launch_attn_kv_planes(q, (long)B * n, 3 * D, 2 * D, 64, 0)); }
+        a.kv_planes = 1;
     }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
