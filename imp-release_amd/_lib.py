@@ -26,7 +26,7 @@ SYMBOLS = [
     'imp_last_error', 'imp_version', 'imp_create', 'imp_destroy', 'imp_load_tensor', 'imp_finalize_weights',
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
-    'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_pool_select_pair', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear', 'imp_op_layer_gemm',
+    'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_pool_select_pair', 'imp_masked_commit', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear', 'imp_op_layer_gemm',
     'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_range_events', 'imp_time_layer_gemm', 'imp_estimate_pose',
     'imp_sp_create', 'imp_sp_destroy', 'imp_sp_set_weight', 'imp_sp_finalize', 'imp_sp_detect', 'imp_sp_describe', 'imp_sp_dense', 'imp_sp_op_conv',
 ]
@@ -109,6 +109,7 @@ def lib():
     L.imp_pool_select.argtypes = [P, I, P, P, P, F, P, P, P]
     L.imp_pool_select_pair.argtypes = [P, I, P, P, P, I, P, I, P, P, P, I, P, F, P, P]
     L.imp_gather_rows.argtypes = [P, I, I, I, I, P, P, P, P]
+    L.imp_masked_commit.argtypes = [P, I, P, P, P, P, P, P, P, I, P, I, P, P, P, P, P]
     L.imp_match_pair.argtypes = [P, I, I, I, P, P, P, P, P, P, F, F, F, I, I, F, P, P, P, P, P, P]
     L.imp_op_linear.argtypes = [P, I, I, I, P, P, P, P, P]
     L.imp_op_layer_gemm.argtypes = [P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, P, I, P]
@@ -359,6 +360,24 @@ class Context:
                                                 _ptr(counts), _stream(self.device)))
         c = counts.tolist()
         return (ids0[:c[0]] if c[0] >= 0 else None), (ids1[:c[2]] if c[2] >= 0 else None)
+
+    def masked_commit(self, g0, g1, i0, m0, out_i_row, out_m_row, keep0=None, keep1=None, mask0_row=None, mask1_row=None, update=False):
+        """masked AdaGMN bookkeeping of one pair in one launch (include/imp_hip.h imp_masked_commit): scatters the matches of the kept
+        keypoints into the pair's full-size rows; with ``update`` also returns the id lists composed with the pool's selection
+        (``keep_s`` None: unchanged) after entering them into the mask rows.  No synchronisation."""
+        n0sel = g0.numel()
+        ng0 = ng1 = None
+        nk0 = nk1 = 0
+        if update:
+            nk0 = keep0.numel() if keep0 is not None else g0.numel()
+            nk1 = keep1.numel() if keep1 is not None else g1.numel()
+            ng0 = torch.empty(nk0, device=g0.device, dtype=torch.int64)
+            ng1 = torch.empty(nk1, device=g1.device, dtype=torch.int64)
+        N = lambda t: _ptr(t) if t is not None else None      # noqa: E731
+        self._check(self.L.imp_masked_commit(self.handle, n0sel, _ptr(g0), _ptr(g1), _ptr(i0), _ptr(m0), _ptr(out_i_row), _ptr(out_m_row),
+                                             N(keep0), nk0, N(keep1), nk1, N(ng0), N(ng1), N(mask0_row if update else None),
+                                             N(mask1_row if update else None), _stream(self.device)))
+        return ng0, ng1
 
     def gather_rows(self, x, ids):
         x = _f32(x, 'x')

@@ -1301,6 +1301,19 @@ int imp_gather_rows(imp_ctx* c, int batch, int n_in, int n_out, int dim, const f
     return IMP_OK;
 }
 
+int imp_masked_commit(imp_ctx* c, int n0sel, const int64_t* gids0, const int64_t* gids1, const int64_t* indices0, const float* mscores0,
+                      int64_t* out_indices0, float* out_mscores0, const int64_t* keep0, int nkeep0, const int64_t* keep1, int nkeep1,
+                      int64_t* new_gids0, int64_t* new_gids1, uint8_t* mask0, uint8_t* mask1, void* stream) {
+    if (!c || n0sel < 0 || !gids0 || !gids1 || !indices0 || !mscores0 || !out_indices0 || !out_mscores0)
+        return fail(IMP_E_ARG, "imp_masked_commit: bad argument");
+    if ((new_gids0 != nullptr) != (new_gids1 != nullptr) || (new_gids0 && (!mask0 || !mask1 || nkeep0 < 0 || nkeep1 < 0)))
+        return fail(IMP_E_ARG, "imp_masked_commit: the id-list update needs both lists and both mask rows");
+    HIP_TRY(hipSetDevice(c->device));
+    MaskedCommit p{gids0, gids1, indices0, mscores0, out_indices0, out_mscores0, n0sel, keep0, keep1, nkeep0, nkeep1, new_gids0, new_gids1, mask0, mask1};
+    HIP_TRY(launch_masked_commit(p, S(stream)));
+    return IMP_OK;
+}
+
 int imp_match_pair(imp_ctx* c, int batch, int n0, int n1, const float* kpts0, const float* scores0, const float* desc0,
                    const float* kpts1, const float* scores1, const float* desc1, float width, float height,
                    float bin_score, int sinkhorn_iterations, int with_sinkhorn, float p, int64_t* indices0,

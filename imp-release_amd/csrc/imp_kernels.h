@@ -181,6 +181,19 @@ hipError_t launch_pool_select(const PoolSide sides[2], int nsides, float thr, in
 hipError_t launch_attn_mass_normalize(const float* colsum, int n, float* out, hipStream_t stream);
 hipError_t launch_gather_rows(const float* in, const int64_t* ids, float* out, int batch, int n_in, int n_out, int dim,
                               hipStream_t stream);
+// masked AdaGMN bookkeeping of one pair (pool_misc.hip masked_commit_kernel)
+struct MaskedCommit {
+    const int64_t *g0, *g1;        // kept ids of image 0 / 1 (unique)
+    const int64_t* i0;             // [n0sel] match of kept keypoint t among the kept keypoints of image 1, or -1
+    const float* m0;               // [n0sel]
+    int64_t* out_i; float* out_m;  // full-size rows of this pair
+    int n0sel;
+    const int64_t *keep0, *keep1;  // positions selected by the pool, or null (list unchanged)
+    int nk0, nk1;
+    int64_t *ng0, *ng1;            // composed id lists (null: no update this iteration)
+    uint8_t *mask0, *mask1;        // full-size key-mask rows of this pair (zeroed by the caller)
+};
+hipError_t launch_masked_commit(const MaskedCommit& p, hipStream_t stream);
 
 // ------------------------------------------------------------------------------------------------
 // chip-resident Sinkhorn: row softmax + T iterations + scores + maxima in ONE launch (ot_resident.hip)

@@ -450,6 +450,28 @@ __global__ __launch_bounds__(64) void gather_rows_kernel(const float* __restrict
     for (int c = threadIdx.x; c < dim / 4; c += 64) d[c] = s[c];
 }
 
+// masked AdaGMN, one pair of one iteration (nets/adgm.py:447-453 and :498-504): the matches found among the kept keypoints go back to
+// full-size rows (out_i[g0[t]] = i0[t] >= 0 ? g1[i0[t]] : -1, out_m[g0[t]] = m0[t]); with ng0 / ng1 the kept id lists are composed with
+// the pool's selection (ng[t] = keep ? g[keep[t]] : g[t]) and entered into the key masks of the next layers.  Id lists hold unique ids.
+__global__ __launch_bounds__(256) void masked_commit_kernel(const MaskedCommit p) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < p.n0sel) {
+        const long g = p.g0[t], i = p.i0[t];
+        p.out_i[g] = i >= 0 ? p.g1[i] : -1;
+        p.out_m[g] = p.m0[t];
+    }
+    if (p.ng0 && t < p.nk0) {
+        const long g = p.keep0 ? p.g0[p.keep0[t]] : p.g0[t];
+        p.ng0[t] = g;
+        p.mask0[g] = 1;
+    }
+    if (p.ng1 && t < p.nk1) {
+        const long g = p.keep1 ? p.g1[p.keep1[t]] : p.g1[t];
+        p.ng1[t] = g;
+        p.mask1[g] = 1;
+    }
+}
+
 }  // namespace
 
 hipError_t launch_normalize_kpts(const float* kpts, long count, float width, float height, float* out,
@@ -507,5 +529,14 @@ hipError_t launch_gather_rows(const float* in, const int64_t* ids, float* out, i
                               hipStream_t stream) {
     if (n_out <= 0) return hipSuccess;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(n_out, batch), dim3(64), 0, stream, in, ids, out, n_in, n_out, dim);
+    return hipGetLastError();
+}
+
+hipError_t launch_masked_commit(const MaskedCommit& p, hipStream_t stream) {
+    int n = p.n0sel;
+    if (p.ng0 && p.nk0 > n) n = p.nk0;
+    if (p.ng1 && p.nk1 > n) n = p.nk1;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(masked_commit_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p);
     return hipGetLastError();
 }

@@ -490,25 +490,20 @@ class AdaGMN(GM):
                 score = ctx.compute_score(ctx.compute_distance(ni, s0, s1), binv, self.sinkhorn_iterations,
                                           self.with_sinkhorn)
                 i0, _, m0, _ = ctx.compute_matches(score, p)
-                i0, m0 = i0[0], m0[0]
-                v0 = i0 >= 0
-                b_i0[bi, g0[v0]] = g1[i0[v0]]
-                b_m0[bi, g0] = m0
                 pred_score = score
+                keep0 = keep1 = None
                 if updating:
                     thr = mscore_th * uncertainty_ratio
                     mass0, mass1 = ctx.score_mass(score[0])
                     skip0 = n_min > 0 and g0.numel() <= n_min                 # nets/adgm.py:465 (N, not N+1)
                     skip1 = n_min > 0 and g1.numel() <= n_min
                     if not (skip0 and skip1):                                 # both images in one launch, one count read-back
-                        f0, f1 = ctx.pool_select_pair(mass0, a00[bi][g0], a01[bi][g0], skip0, mass1, a11[bi][g1], a10[bi][g1], skip1, thr)
-                        if f0 is not None:
-                            g0 = g0[f0]
-                        if f1 is not None:
-                            g1 = g1[f1]
-                    gids0[bi], gids1[bi] = g0, g1
-                    mask0[bi, g0] = 1
-                    mask1[bi, g1] = 1
+                        keep0, keep1 = ctx.pool_select_pair(mass0, a00[bi][g0], a01[bi][g0], skip0, mass1, a11[bi][g1], a10[bi][g1], skip1, thr)
+                # matches -> the pair's full-size rows, kept ids composed with the pool's selection, key masks of the next layers: one launch
+                ng0, ng1 = ctx.masked_commit(g0, g1, i0[0], m0[0], b_i0[bi], b_m0[bi], keep0, keep1,
+                                             mask0[bi] if updating else None, mask1[bi] if updating else None, update=updating)
+                if updating:
+                    gids0[bi], gids1[bi] = ng0, ng1
             all_i0.append(b_i0); all_m0.append(b_m0)
         a, b_, c_, d_ = self._const_stats(dev)
         return {'scores': [pred_score], 'indices0': all_i0, 'mscores0': all_m0, 'acc_corr': [a],

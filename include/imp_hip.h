@@ -184,6 +184,16 @@ int imp_pool_select_pair(imp_ctx* ctx, int n0, const float* mass0, const float* 
                          int n1, const float* mass1, const float* a_self1, const float* a_cross1, int skip1, int64_t* ids1, float thr,
                          int32_t* counts, void* stream);
 
+/* Masked AdaGMN.produce_matches, bookkeeping of ONE pair in one launch (nets/adgm.py:447-453: batch_indices0[bi, gids0[valid0]] =
+ * gids1[indices0[valid0]], batch_mscores0[bi, gids0] = mscores0; :498-504: the kept id lists and the masks M00/M01/M11/M10 of the next
+ * layers).  gids0 [n0sel] / gids1: kept ids (unique); indices0 / mscores0 [n0sel]: matches among the kept keypoints; out_* : this
+ * pair's full-size rows (pre-filled -1 / 0).  With new_gids0/1 != NULL the lists are composed with the pool's selection
+ * (new_gids_s[t] = keep_s ? gids_s[keep_s[t]] : gids_s[t], t < nkeep_s; keep_s NULL: list unchanged, nkeep_s = its length) and
+ * mask_s[new id] = 1 (uint8 rows of this pair, zeroed by the caller).  No synchronisation, no read-back. */
+int imp_masked_commit(imp_ctx* ctx, int n0sel, const int64_t* gids0, const int64_t* gids1, const int64_t* indices0, const float* mscores0,
+                      int64_t* out_indices0, float* out_mscores0, const int64_t* keep0, int nkeep0, const int64_t* keep1, int nkeep1,
+                      int64_t* new_gids0, int64_t* new_gids1, uint8_t* mask0, uint8_t* mask1, void* stream);
+
 /* desc[:, :, sel_ids] of eval/matching.py:166-174 on token-major data: out[b][i][:] = in[b][ids[i]][:] */
 int imp_gather_rows(imp_ctx* ctx, int batch, int n_in, int n_out, int dim, const float* in,
                     const int64_t* ids, float* out, void* stream);

@@ -323,6 +323,45 @@ def test_pool_select_fuzz_with_ties_and_duplicates():
             assert got is not None and torch.equal(got.cpu(), ref), (trial, n, thr, levels)
 
 
+def test_masked_commit_equals_the_reference_index_arithmetic():
+    """imp_masked_commit (masked AdaGMN bookkeeping of one pair, one launch) against nets/adgm.py:447-453,498-504 written with torch
+    indexing: matches scattered to full-size rows, id lists composed with the pool's selection, key masks - exact"""
+    ctx = _model('AdaGMN', n_layers=2)[2]._ensure_ctx()
+    g = torch.Generator().manual_seed(77)
+    for trial in range(40):
+        nK0, nK1 = int(torch.randint(1, 3000, (1,), generator=g)), int(torch.randint(1, 3000, (1,), generator=g))
+        n0 = int(torch.randint(1, nK0 + 1, (1,), generator=g)); n1 = int(torch.randint(1, nK1 + 1, (1,), generator=g))
+        g0 = torch.randperm(nK0, generator=g)[:n0].sort().values
+        g1 = torch.randperm(nK1, generator=g)[:n1].sort().values
+        i0 = torch.randint(-1, n1, (n0,), generator=g)
+        if trial % 5 == 0:
+            i0[:] = -1
+        m0 = torch.rand(n0, generator=g)
+        update = trial % 3 != 0
+        keep0 = None if trial % 4 == 1 else torch.randperm(n0, generator=g)[:int(torch.randint(1, n0 + 1, (1,), generator=g))].sort().values
+        keep1 = None if trial % 4 == 2 else torch.randperm(n1, generator=g)[:int(torch.randint(1, n1 + 1, (1,), generator=g))].sort().values
+        ref_i = torch.full((nK0,), -1, dtype=torch.long); ref_m = torch.zeros(nK0)
+        v = i0 >= 0
+        ref_i[g0[v]] = g1[i0[v]]
+        ref_m[g0] = m0
+        out_i = torch.full((2, nK0), -1, dtype=torch.long, device=DEV); out_m = torch.zeros(2, nK0, device=DEV)
+        mk0 = torch.zeros(2, nK0, dtype=torch.uint8, device=DEV); mk1 = torch.zeros(2, nK1, dtype=torch.uint8, device=DEV)
+        D = lambda t: None if t is None else t.to(DEV)      # noqa: E731
+        ng0, ng1 = ctx.masked_commit(D(g0), D(g1), D(i0), D(m0), out_i[1], out_m[1], D(keep0), D(keep1), mk0[1], mk1[1], update=update)
+        torch.cuda.synchronize()
+        assert torch.equal(out_i[1].cpu(), ref_i) and torch.equal(out_m[1].cpu(), ref_m), trial
+        assert (out_i[0] == -1).all() and (out_m[0] == 0).all() and (mk0[0] == 0).all() and (mk1[0] == 0).all()     # only this pair's rows
+        if update:
+            r0 = g0 if keep0 is None else g0[keep0]
+            r1 = g1 if keep1 is None else g1[keep1]
+            assert torch.equal(ng0.cpu(), r0) and torch.equal(ng1.cpu(), r1), trial
+            e0 = torch.zeros(nK0, dtype=torch.uint8); e0[r0] = 1
+            e1 = torch.zeros(nK1, dtype=torch.uint8); e1[r1] = 1
+            assert torch.equal(mk0[1].cpu(), e0) and torch.equal(mk1[1].cpu(), e1), trial
+        else:
+            assert ng0 is None and ng1 is None and (mk0 == 0).all() and (mk1 == 0).all()
+
+
 @pytest.mark.parametrize('n0,n1,T', [(64, 64, 20), (300, 307, 100), (1, 5, 3), (1024, 1000, 100), (2048, 2048, 100)])
 def test_sinkhorn_on_the_three_byte_copy(n0, n1, T):
     """opt-in storage mode (imp_set_sinkhorn_storage(3)): the iterations stream a 3-byte copy of P, the scores are still
