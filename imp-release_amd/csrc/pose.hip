@@ -22,8 +22,8 @@
 #include "imp_kernels.h"
 #include "../../include/imp_hip.h"
 #include "pose_fivept.h"
-#include <mutex>
-#include <vector>
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -36,80 +36,49 @@ __host__ __device__ inline unsigned pose_rand(unsigned seed, unsigned h, unsigne
 }
 
 // cyclic Jacobi eigen-decomposition of a symmetric N x N matrix (a is destroyed: eigenvalues on its diagonal); v = eigenvectors (columns)
+// (N <= 4: the rotation loops are unrolled, so the arrays are registers, not scratch memory)
 template <int N>
 __device__ void jacobi_eig(double (&a)[N][N], double (&v)[N][N]) {
+#pragma unroll
     for (int i = 0; i < N; ++i)
+#pragma unroll
         for (int j = 0; j < N; ++j) v[i][j] = i == j ? 1.0 : 0.0;
+#pragma clang loop unroll(disable)
     for (int sweep = 0; sweep < 30; ++sweep) {
         double off = 0.0, diag = 0.0;
+#pragma unroll
         for (int i = 0; i < N; ++i) {
             diag += a[i][i] * a[i][i];
+#pragma unroll
             for (int j = i + 1; j < N; ++j) off += a[i][j] * a[i][j];
         }
         if (off <= 1e-26 * diag || off == 0.0) break;     // off-diagonal norm below 1e-13 of the diagonal: converged in fp64
+#pragma unroll
         for (int p = 0; p < N - 1; ++p)
+#pragma unroll
             for (int q = p + 1; q < N; ++q) {
                 if (a[p][q] == 0.0) continue;
                 const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
                 const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
                 const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
                 for (int k = 0; k < N; ++k) {
                     const double akp = a[k][p], akq = a[k][q];
                     a[k][p] = c * akp - s * akq;
                     a[k][q] = s * akp + c * akq;
                 }
+#pragma unroll
                 for (int k = 0; k < N; ++k) {
                     const double apk = a[p][k], aqk = a[q][k];
                     a[p][k] = c * apk - s * aqk;
                     a[q][k] = s * apk + c * aqk;
                 }
+#pragma unroll
                 for (int k = 0; k < N; ++k) {
                     const double vkp = v[k][p], vkq = v[k][q];
                     v[k][p] = c * vkp - s * vkq;
                     v[k][q] = s * vkp + c * vkq;
                 }
-            }
-    }
-}
-
-// the same cyclic Jacobi for a 9 x 9 matrix held in LDS, executed by ONE wave: lane k owns row / column k of every rotation, the
-// rotation angle is computed redundantly by all lanes (a single thread walking a 9 x 9 array in scratch memory takes ~1 ms)
-__device__ void jacobi9_wave(double* A, double* V, int lane) {
-    auto sync = [] { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
-    for (int i = lane; i < 81; i += 64) V[i] = (i / 9 == i % 9) ? 1.0 : 0.0;
-    sync();
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        double off = 0.0, diag = 0.0;
-        for (int i = lane; i < 81; i += 64) {
-            const int r = i / 9, c = i % 9;
-            const double x = A[i];
-            if (r == c) diag += x * x; else if (r < c) off += x * x;
-        }
-        for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o); diag += __shfl_xor(diag, o); }
-        if (off <= 1e-26 * diag || off == 0.0) break;
-        for (int p = 0; p < 8; ++p)
-            for (int q = p + 1; q < 9; ++q) {
-                const double apq = A[p * 9 + q];
-                if (apq == 0.0) continue;                         // uniform
-                const double theta = (A[q * 9 + q] - A[p * 9 + p]) / (2.0 * apq);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                sync();
-                if (lane < 9) {
-                    const double akp = A[lane * 9 + p], akq = A[lane * 9 + q];
-                    A[lane * 9 + p] = c * akp - s * akq;
-                    A[lane * 9 + q] = s * akp + c * akq;
-                    const double vkp = V[lane * 9 + p], vkq = V[lane * 9 + q];
-                    V[lane * 9 + p] = c * vkp - s * vkq;
-                    V[lane * 9 + q] = s * vkp + c * vkq;
-                }
-                sync();
-                if (lane < 9) {
-                    const double apk = A[p * 9 + lane], aqk = A[q * 9 + lane];
-                    A[p * 9 + lane] = c * apk - s * aqk;
-                    A[q * 9 + lane] = s * apk + c * aqk;
-                }
-                sync();
             }
     }
 }
@@ -120,16 +89,26 @@ __device__ void svd3(const double (&E)[3][3], double (&U)[3][3], double (&s)[3],
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) a[i][j] = E[0][i] * E[0][j] + E[1][i] * E[1][j] + E[2][i] * E[2][j];
     jacobi_eig<3>(a, ev);
-    int idx[3] = {0, 1, 2};
+    double lam[3] = {a[0][0], a[1][1], a[2][2]};
+    // descending order by compare-and-swap of (eigenvalue, eigenvector column) pairs - static indices: everything stays in registers
+#pragma unroll
     for (int i = 0; i < 2; ++i)
-        for (int j = i + 1; j < 3; ++j)
-            if (a[idx[j]][idx[j]] > a[idx[i]][idx[i]]) { const int t = idx[i]; idx[i] = idx[j]; idx[j] = t; }
+#pragma unroll
+        for (int j = i + 1; j < 3; ++j) {
+            const bool sw = lam[j] > lam[i];
+            const double t = lam[i]; lam[i] = sw ? lam[j] : t; lam[j] = sw ? t : lam[j];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { const double u = ev[r][i]; ev[r][i] = sw ? ev[r][j] : u; ev[r][j] = sw ? u : ev[r][j]; }
+        }
+#pragma unroll
     for (int c = 0; c < 2; ++c) {
-        s[c] = sqrt(fmax(a[idx[c]][idx[c]], 0.0));
-        for (int r = 0; r < 3; ++r) V[r][c] = ev[r][idx[c]];
+        s[c] = sqrt(fmax(lam[c], 0.0));
+#pragma unroll
+        for (int r = 0; r < 3; ++r) V[r][c] = ev[r][c];
+#pragma unroll
         for (int r = 0; r < 3; ++r) U[r][c] = (E[r][0] * V[0][c] + E[r][1] * V[1][c] + E[r][2] * V[2][c]) / fmax(s[c], 1e-300);
     }
-    s[2] = sqrt(fmax(a[idx[2]][idx[2]], 0.0));
+    s[2] = sqrt(fmax(lam[2], 0.0));
     V[0][2] = V[1][0] * V[2][1] - V[2][0] * V[1][1];
     V[1][2] = V[2][0] * V[0][1] - V[0][0] * V[2][1];
     V[2][2] = V[0][0] * V[1][1] - V[1][0] * V[0][1];
@@ -160,17 +139,6 @@ __device__ bool essential_from_F(const double (&F)[3][3], const double (&T0)[3],
         for (int c = 0; c < 3; ++c) Eo[r][c] = U[r][0] * V[c][0] + U[r][1] * V[c][1];
     return true;
 }
-// least-squares form: smallest eigenvector of the 9x9 normal matrix of conditioned correspondences
-__device__ bool essential_from_normal(double (&ata)[9][9], const double (&T0)[3], const double (&T1)[3], double (&Eo)[3][3]) {
-    double v[9][9];
-    jacobi_eig<9>(ata, v);
-    int m = 0;
-    for (int i = 1; i < 9; ++i) if (ata[i][i] < ata[m][m]) m = i;
-    double F[3][3];
-    for (int i = 0; i < 9; ++i) F[i / 3][i % 3] = v[i][m];
-    return essential_from_F(F, T0, T1, Eo);
-}
-
 __device__ __forceinline__ double sampson_sq(const double* E, double x0, double y0, double x1, double y1) {
     const double a0 = E[0] * x0 + E[1] * y0 + E[2], a1 = E[3] * x0 + E[4] * y0 + E[5], a2 = E[6] * x0 + E[7] * y0 + E[8];
     const double b0 = E[0] * x1 + E[3] * y1 + E[6], b1 = E[1] * x1 + E[4] * y1 + E[7];
@@ -267,16 +235,18 @@ __global__ __launch_bounds__(64) void pose_hypotheses_kernel(const double2* __re
     if (ok) for (int i = 0; i < 9; ++i) Eh[(long)h * 9 + i] = E[i / 3][i % 3];
 }
 
-// five-point sampler: one thread per minimal sample, up to 10 models each (pose_fivept.h); candidate c of sample h lives at slot 10 h + c.
-// The solver is one long dependent chain of run-time-indexed array accesses: with the arrays in scratch memory (an L2 round trip each) a
-// call took 1.84 ms however few samples it had; every thread gets its Work in LDS instead (8 threads per workgroup = 47 KB)
-constexpr int FP_THREADS = 8;
+// five-point sampler: a group of FP_L lanes per minimal sample (pose_fivept.h: the linear algebra of a solve is dealt to the lanes of
+// the group, its matrices live in LDS), 64 / FP_L samples per wave; up to 10 models per sample, candidate c of sample h lives at slot
+// 10 h + c.  History of this kernel at 1024 samples: one thread per sample with its arrays in scratch memory 1.84 ms, in LDS 0.65 ms,
+// blocked inner loops 0.49 ms (73 % of it the QR iteration of the 10 x 10 action matrix), groups of 16 lanes: see profiles/r03.
+constexpr int FP_L = 64;
 __global__ __launch_bounds__(64) void pose_hypotheses5_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n,
                                                               int H, unsigned seed, double* __restrict__ Eh, int* __restrict__ valid) {
-    __shared__ fivept::Work work[FP_THREADS];
-    if (threadIdx.x >= FP_THREADS) return;
-    const int h = blockIdx.x * FP_THREADS + threadIdx.x;
-    if (h >= H) return;
+    __shared__ fivept::Work work[64 / FP_L];
+    const int g = threadIdx.x / FP_L, lane = threadIdx.x % FP_L;
+    const int h = blockIdx.x * (64 / FP_L) + g;
+    if (h >= H) return;                                     // whole groups leave together
+    fivept::Work& w = work[g];
     int ids[5];
     bool ok = true;
     for (int k = 0; k < 5; ++k) {
@@ -284,13 +254,25 @@ __global__ __launch_bounds__(64) void pose_hypotheses5_kernel(const double2* __r
         for (int j = 0; j < k; ++j) ok &= ids[j] != ids[k];
     }
     int nsol = 0;
-    double* Eo = Eh + (long)h * 90;
     if (ok) {
-        double a[5][2], b[5][2];
-        for (int k = 0; k < 5; ++k) { a[k][0] = x0[ids[k]].x; a[k][1] = x0[ids[k]].y; b[k][0] = x1[ids[k]].x; b[k][1] = x1[ids[k]].y; }
-        nsol = fivept::five_point(a, b, Eo, work[threadIdx.x]);
+        if (lane < 5) {
+            int id = ids[0];
+            for (int k = 1; k < 5; ++k) id = lane == k ? ids[k] : id;
+            const double2 a = x0[id], b = x1[id];
+            w.pts[lane][0] = a.x; w.pts[lane][1] = a.y; w.pts[lane][2] = b.x; w.pts[lane][3] = b.y;
+        }
+        fivept::group_fence<FP_L>();
+#ifdef FP_PROFILE
+        unsigned long long prof[6] = {0, 0, 0, 0, 0, 0};
+        nsol = fivept::five_point<FP_L>(Eh + (long)h * 90, w, lane, prof);
+        if (lane == 0 && (h & 255) == 0)      // 100 MHz counter: x 10 ns
+            printf("fivept h=%d nsol=%d: null space %llu  cubics %llu  gauss-jordan %llu  eigenvalues %llu  eigenvectors %llu  (x 10 ns)\n", h, nsol,
+                   prof[1] - prof[0], prof[2] - prof[1], prof[3] - prof[2], prof[4] - prof[3], prof[5] - prof[4]);
+#else
+        nsol = fivept::five_point<FP_L>(Eh + (long)h * 90, w, lane);
+#endif
     }
-    for (int c = 0; c < 10; ++c) valid[(long)h * 10 + c] = c < nsol ? 1 : 0;
+    if (lane < 10) valid[(long)h * 10 + lane] = lane < nsol ? 1 : 0;
 }
 
 // one workgroup per hypothesis: inlier count (magsac == 0) or sigma-marginalised quality floor(4096 sum_i w(r_i)) (magsac != 0)
@@ -317,37 +299,127 @@ __global__ __launch_bounds__(256) void pose_score_kernel(const double2* __restri
     }
 }
 
-__device__ double block_sum(double v, double* sm) {        // 1024 threads
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// ---- refinement of the best hypothesis ----------------------------------------------------------------------------------------------
+constexpr int CT = 512;            // threads of the consensus workgroup
+constexpr int CPT = 8;             // correspondences a thread keeps in registers (coordinates + current weight): n <= 4096; beyond that recomputed
+
+// value of lane `src` (wave-uniform) in every lane
+__device__ __forceinline__ double wave_bcast(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+// sums of K per-thread values over the workgroup (CT threads = 8 waves): wave reduction, then the 8 partials in a fixed order.
+// The totals land in red[0 .. K); the caller reads them after the trailing barrier.
+template <int K>
+__device__ void block_sums(double (&v)[K], double* part, double* red) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+    __syncthreads();                                   // the previous user of part / red is done
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) part[(threadIdx.x >> 6) * K + k] = v[k];
+    }
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    if (threadIdx.x < K) {
+        double t = 0;
+        for (int w = 0; w < CT / 64; ++w) t += part[w * K + threadIdx.x];
+        red[threadIdx.x] = t;
+    }
     __syncthreads();
-    double t = 0;
-    for (int w = 0; w < 16; ++w) t += sm[w];
-    return t;
 }
 
-// one workgroup: first best hypothesis -> consensus refits -> decomposition of E
-__global__ __launch_bounds__(1024) void pose_consensus_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n, int H,
+// Eigenvector of the smallest eigenvalue of the 9 x 9 normal matrix M (LDS, row-major, symmetric positive semi-definite), by ONE wave:
+// LDL^T factorisation of M + delta I and inverse iteration from v0 - the conditioned current model, already close to the answer, so
+// every iteration multiplies the error by lambda_1 / lambda_2 of a matrix whose smallest eigenvalue is the (tiny) fit residual.
+// Lane i owns row i of L and component i of the vectors; pivots and solution components travel by v_readlane.  (A cyclic Jacobi sweep
+// of the same matrix is 36 dependent rotations of ~1000 cycles each: 0.1 ms per fit, half of this kernel before.)
+__device__ void smallest_eigvec9_wave(const double* M, const double* v0, double* vout, int lane) {
+    double Lr[9];                                        // row `lane` of the factor (columns < lane), D on the diagonal
+    const int li = lane < 9 ? lane : 8;
+    double tr = 0.0;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) { Lr[j] = M[li * 9 + j]; tr += M[j * 9 + j]; }
+    const double delta = 1e-15 * tr + 1e-300;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) Lr[j] += j == li ? delta : 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const double dk = wave_bcast(Lr[k], k);          // D_k (row k, column k)
+        const double lik = Lr[k] / dk;                   // l_ik for the rows below k
+#pragma unroll
+        for (int j = k + 1; j < 9; ++j) {
+            const double ajk = wave_bcast(Lr[k], j);     // a_jk = l_jk D_k, still unscaled in row j
+            Lr[j] -= li > k ? lik * ajk : 0.0;           // only the lower triangle (j <= i) is used later
+        }
+        Lr[k] = li > k ? lik : Lr[k];
+    }
+    double Lt[9];                                        // column `lane` of L below the diagonal: Lt[k] = l_k,lane
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { const double x = wave_bcast(Lr[j], k); t = j == li ? x : t; }
+        Lt[k] = t;
+    }
+    double v = v0[li];
+    {
+        double nn = lane < 9 ? v * v : 0.0;
+        for (int o = 8; o > 0; o >>= 1) nn += __shfl_xor(nn, o, 16);
+        v /= sqrt(nn);
+    }
+    double dii = Lr[0];                                  // D_i sits on the diagonal of row i
+#pragma unroll
+    for (int j = 1; j < 9; ++j) dii = li == j ? Lr[j] : dii;
+#pragma clang loop unroll(disable)
+    for (int it = 0; it < 24; ++it) {
+        double b = v;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {                    // L y = b
+            const double yk = wave_bcast(b, k);
+            b -= li > k ? Lr[k] * yk : 0.0;
+        }
+        b /= dii;                                        // D z = y
+#pragma unroll
+        for (int k = 8; k >= 0; --k) {                   // L^T x = z
+            const double xk = wave_bcast(b, k);
+            b -= li < k ? Lt[k] * xk : 0.0;
+        }
+        double nn = lane < 9 ? b * b : 0.0, dot = lane < 9 ? b * v : 0.0;
+        for (int o = 8; o > 0; o >>= 1) { nn += __shfl_xor(nn, o, 16); dot += __shfl_xor(dot, o, 16); }
+        nn = wave_bcast(nn, 0); dot = wave_bcast(dot, 0);
+        const double x = b / (dot >= 0.0 ? sqrt(nn) : -sqrt(nn));
+        double diff = lane < 9 ? fabs(x - v) : 0.0;
+        for (int o = 8; o > 0; o >>= 1) diff = fmax(diff, __shfl_xor(diff, o, 16));
+        diff = wave_bcast(diff, 0);
+        v = x;
+        if (diff <= 2e-15) break;                        // wave-uniform
+    }
+    if (lane < 9) vout[lane] = v;
+}
+
+// one workgroup: first best hypothesis -> (weighted) least-squares refits kept while not worse -> decomposition of E
+__global__ __launch_bounds__(CT) void pose_consensus_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n, int H,
                                                            const double* __restrict__ Eh, const int* __restrict__ counts, double thr2, int magsac, int nsample,
-                                                           unsigned char* __restrict__ inl, double* __restrict__ out) {
+                                                           unsigned char* __restrict__ inl, double* __restrict__ out, int* __restrict__ good) {
     // out: [0..8] E, [9..17] R, [18..20] t, [21] inliers of E, [22] cheirality inliers, [23] ok flag, [24..32] R1, [33..41] R2, [42..44] t
-    __shared__ double sm[16 * 45];
-    __shared__ double Es[9], Et[9];
+    __shared__ double part[(CT / 64) * 45], red[48];
+    __shared__ double Es[9], Et[9], JA[81], Fv[9], F0[9];
     __shared__ int s_best, s_cnt, s_ok;
     const int tid = threadIdx.x;
+    if (tid < 4) good[tid] = 0;                                   // the vote counters of the cheirality kernel that follows
     {   // first best hypothesis (largest count, lowest index): strided scan + wave / workgroup reduction
         int best = -1, bi = 0x7fffffff;
-        for (int h = tid; h < H; h += 1024) { const int c = counts[h]; if (c > best) { best = c; bi = h; } }
+        for (int h = tid; h < H; h += CT) { const int c = counts[h]; if (c > best) { best = c; bi = h; } }
         for (int o = 32; o > 0; o >>= 1) {
             const int ob = __shfl_xor(best, o), oi = __shfl_xor(bi, o);
             if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
         }
-        int* smi = reinterpret_cast<int*>(sm);
+        int* smi = reinterpret_cast<int*>(part);
         if ((tid & 63) == 0) { smi[2 * (tid >> 6)] = best; smi[2 * (tid >> 6) + 1] = bi; }
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < 16; ++w)
+            for (int w = 1; w < CT / 64; ++w)
                 if (smi[2 * w] > best || (smi[2 * w] == best && smi[2 * w + 1] < bi)) { best = smi[2 * w]; bi = smi[2 * w + 1]; }
             s_best = best >= 0 ? bi : -1; s_cnt = best;
             if (best >= 0) for (int i = 0; i < 9; ++i) Es[i] = Eh[(long)bi * 9 + i];
@@ -356,54 +428,82 @@ __global__ __launch_bounds__(1024) void pose_consensus_kernel(const double2* __r
     }
     // nsample = size of the minimal sample (5 or 8): a model has to explain at least that many matches (half of it in weight units)
     if (s_best < 0 || s_cnt < (magsac ? (int)(nsample * QUALITY_SCALE / 2) : nsample)) { if (tid == 0) out[23] = 0.0; return; }
-    // per-point weight of the current model: 0 / 1 membership of the consensus set, or the sigma-marginalised weight (IRLS)
-    auto weight = [&](const double* E, int i) {
-        const double r2 = sampson_sq(E, x0[i].x, x0[i].y, x1[i].x, x1[i].y);
+    // per-point weight of a model: 0 / 1 membership of the consensus set, or the sigma-marginalised weight (IRLS)
+    auto weight_of = [&](const double* E, double ax, double ay, double bx, double by) {
+        const double r2 = sampson_sq(E, ax, ay, bx, by);
         return magsac ? magsac_weight(r2, thr2) : (r2 < thr2 ? 1.0 : 0.0);
     };
-    for (int i = tid; i < n; i += 1024) inl[i] = sampson_sq(Es, x0[i].x, x0[i].y, x1[i].x, x1[i].y) < thr2;
-    __syncthreads();
+    // the first CPT points of a thread stay in registers with their weight under the current model; the rest (n > 4096) is recomputed
+    double pax[CPT], pay[CPT], pbx[CPT], pby[CPT], pw[CPT], pn[CPT];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        const int i = tid + u * CT;
+        const bool in = i < n;
+        const double2 a = x0[in ? i : 0], b = x1[in ? i : 0];
+        pax[u] = a.x; pay[u] = a.y; pbx[u] = b.x; pby[u] = b.y;
+        pw[u] = in ? weight_of(Es, a.x, a.y, b.x, b.y) : 0.0;
+        if (in) inl[i] = sampson_sq(Es, a.x, a.y, b.x, b.y) < thr2;
+    }
+    for (int i = tid + CPT * CT; i < n; i += CT) inl[i] = sampson_sq(Es, x0[i].x, x0[i].y, x1[i].x, x1[i].y) < thr2;
+    // f(ax, ay, bx, by, w) over all points with their weight under Es
+    auto for_points = [&](auto&& f) {
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) if (pw[u] > 0) f(pax[u], pay[u], pbx[u], pby[u], pw[u]);
+        for (int i = tid + CPT * CT; i < n; i += CT) {
+            const double w = weight_of(Es, x0[i].x, x0[i].y, x1[i].x, x1[i].y);
+            if (w > 0) f(x0[i].x, x0[i].y, x1[i].x, x1[i].y, w);
+        }
+    };
     for (int round = 0; round < (n >= 8 ? 3 : 0); ++round) {      // the linear refit needs 8 correspondences
         // conditioning of the (weighted) consensus set
-        double c = 0, sx0 = 0, sy0 = 0, sx1 = 0, sy1 = 0;
-        for (int i = tid; i < n; i += 1024) { const double w = weight(Es, i); if (w > 0) { c += w; sx0 += w * x0[i].x; sy0 += w * x0[i].y; sx1 += w * x1[i].x; sy1 += w * x1[i].y; } }
-        const double cnt = block_sum(c, sm);
-        const double cx0 = block_sum(sx0, sm) / cnt, cy0 = block_sum(sy0, sm) / cnt, cx1 = block_sum(sx1, sm) / cnt, cy1 = block_sum(sy1, sm) / cnt;
-        double d0 = 0, d1 = 0;
-        for (int i = tid; i < n; i += 1024) { const double w = weight(Es, i); if (w > 0) {
-            d0 += w * sqrt((x0[i].x - cx0) * (x0[i].x - cx0) + (x0[i].y - cy0) * (x0[i].y - cy0));
-            d1 += w * sqrt((x1[i].x - cx1) * (x1[i].x - cx1) + (x1[i].y - cy1) * (x1[i].y - cy1));
-        } }
-        const double s0 = 1.4142135623730951 / fmax(block_sum(d0, sm) / cnt, 1e-12), s1 = 1.4142135623730951 / fmax(block_sum(d1, sm) / cnt, 1e-12);
+        double m5[5] = {0, 0, 0, 0, 0};
+        for_points([&](double ax, double ay, double bx, double by, double w) { m5[0] += w; m5[1] += w * ax; m5[2] += w * ay; m5[3] += w * bx; m5[4] += w * by; });
+        block_sums<5>(m5, part, red);
+        const double cnt = red[0], cx0 = red[1] / cnt, cy0 = red[2] / cnt, cx1 = red[3] / cnt, cy1 = red[4] / cnt;
+        double d2[2] = {0, 0};
+        for_points([&](double ax, double ay, double bx, double by, double w) {
+            d2[0] += w * sqrt((ax - cx0) * (ax - cx0) + (ay - cy0) * (ay - cy0));
+            d2[1] += w * sqrt((bx - cx1) * (bx - cx1) + (by - cy1) * (by - cy1));
+        });
+        block_sums<2>(d2, part, red);
+        const double s0 = 1.4142135623730951 / fmax(red[0] / cnt, 1e-12), s1 = 1.4142135623730951 / fmax(red[1] / cnt, 1e-12);
         double acc[45];
+#pragma unroll
         for (int k = 0; k < 45; ++k) acc[k] = 0.0;
-        for (int i = tid; i < n; i += 1024) { const double w = weight(Es, i); if (w > 0) {
-            const double ax = (x0[i].x - cx0) * s0, ay = (x0[i].y - cy0) * s0, bx = (x1[i].x - cx1) * s1, by = (x1[i].y - cy1) * s1;
+        for_points([&](double ax0, double ay0, double bx0, double by0, double w) {
+            const double ax = (ax0 - cx0) * s0, ay = (ay0 - cy0) * s0, bx = (bx0 - cx1) * s1, by = (by0 - cy1) * s1;
             const double r[9] = {bx * ax, bx * ay, bx, by * ax, by * ay, by, ax, ay, 1.0};
             int k = 0;
-            for (int a = 0; a < 9; ++a) for (int b2 = a; b2 < 9; ++b2) acc[k++] += w * r[a] * r[b2];
-        } }
-        for (int k = 0; k < 45; ++k) for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
-        __syncthreads();
-        if ((tid & 63) == 0) for (int k = 0; k < 45; ++k) sm[(tid >> 6) * 45 + k] = acc[k];
-        __syncthreads();
-        __shared__ double JA[81], JV[81];
-        if (tid < 45) {                                            // assemble the symmetric normal matrix (fixed summation order)
+#pragma unroll
+            for (int a = 0; a < 9; ++a)
+#pragma unroll
+                for (int b2 = a; b2 < 9; ++b2) acc[k++] += w * r[a] * r[b2];
+        });
+        block_sums<45>(acc, part, red);
+        if (tid < 45) {                                            // the symmetric normal matrix
             int a = 0, rem = tid;
             while (rem >= 9 - a) { rem -= 9 - a; ++a; }
             const int b2 = a + rem;
-            double t = 0;
-            for (int w = 0; w < 16; ++w) t += sm[w * 45 + tid];
-            JA[a * 9 + b2] = JA[b2 * 9 + a] = t;
+            JA[a * 9 + b2] = JA[b2 * 9 + a] = red[tid];
+        }
+        if (tid == 64) {                                           // the current model in conditioned coordinates: F0 = T1^-T Es T0^-1
+            // T^-1 = [[1/s, 0, cx], [0, 1/s, cy], [0, 0, 1]]
+            double G[3][3];
+            for (int r = 0; r < 3; ++r) {
+                G[r][0] = Es[r * 3] / s0; G[r][1] = Es[r * 3 + 1] / s0;
+                G[r][2] = Es[r * 3] * cx0 + Es[r * 3 + 1] * cy0 + Es[r * 3 + 2];
+            }
+            for (int c = 0; c < 3; ++c) {
+                F0[c] = G[0][c] / s1; F0[3 + c] = G[1][c] / s1;
+                F0[6 + c] = cx1 * G[0][c] + cy1 * G[1][c] + G[2][c];
+            }
         }
         __syncthreads();
-        if (tid < 64) jacobi9_wave(JA, JV, tid);
+        if (tid < 64) smallest_eigvec9_wave(JA, F0, Fv, tid);
         __syncthreads();
         if (tid == 0) {
-            int m = 0;
-            for (int i = 1; i < 9; ++i) if (JA[i * 9 + i] < JA[m * 9 + m]) m = i;
             double F[3][3];
-            for (int i = 0; i < 9; ++i) F[i / 3][i % 3] = JV[i * 9 + m];
+            for (int i = 0; i < 9; ++i) F[i / 3][i % 3] = Fv[i];
             const double T0[3] = {s0, cx0, cy0}, T1[3] = {s1, cx1, cy1};
             double E2[3][3];
             s_ok = essential_from_F(F, T0, T1, E2) ? 1 : 0;
@@ -411,17 +511,24 @@ __global__ __launch_bounds__(1024) void pose_consensus_kernel(const double2* __r
         }
         __syncthreads();
         if (!s_ok) break;
-        double c2 = 0;
-        for (int i = tid; i < n; i += 1024) c2 += weight(Et, i);
-        const double q2 = block_sum(c2, sm);
-        const int cnt2 = magsac ? (int)floor(q2 * QUALITY_SCALE) : (int)q2;
+        double c2[1] = {0};
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) { pn[u] = tid + u * CT < n ? weight_of(Et, pax[u], pay[u], pbx[u], pby[u]) : 0.0; c2[0] += pn[u]; }
+        for (int i = tid + CPT * CT; i < n; i += CT) c2[0] += weight_of(Et, x0[i].x, x0[i].y, x1[i].x, x1[i].y);
+        block_sums<1>(c2, part, red);
+        const int cnt2 = magsac ? (int)floor(red[0] * QUALITY_SCALE) : (int)red[0];
         if (cnt2 < s_cnt) break;                                   // uniform: kept only while not worse
         const bool same = cnt2 == s_cnt;
         __syncthreads();
         if (tid == 0) { s_cnt = cnt2; for (int i = 0; i < 9; ++i) Es[i] = Et[i]; }
         __syncthreads();
-        for (int i = tid; i < n; i += 1024) inl[i] = sampson_sq(Es, x0[i].x, x0[i].y, x1[i].x, x1[i].y) < thr2;
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            pw[u] = pn[u];
+            const int i = tid + u * CT;
+            if (i < n) inl[i] = sampson_sq(Es, pax[u], pay[u], pbx[u], pby[u]) < thr2;
+        }
+        for (int i = tid + CPT * CT; i < n; i += CT) inl[i] = sampson_sq(Es, x0[i].x, x0[i].y, x1[i].x, x1[i].y) < thr2;
         if (same && round > 0) break;
     }
     // decomposition (cv2.decomposeEssentialMat): U, V^T with positive determinant, R1 = U W V^T, R2 = U W^T V^T, t = u2
@@ -446,35 +553,48 @@ __global__ __launch_bounds__(1024) void pose_consensus_kernel(const double2* __r
 __global__ __launch_bounds__(256) void pose_cheirality_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n,
                                                               const double* __restrict__ out, const unsigned char* __restrict__ inl,
                                                               double dist_thresh, unsigned char* __restrict__ bits, int* __restrict__ good) {
+    // one thread per (point, candidate): the four lanes of a point sit next to each other in the wave
     __shared__ int cnt[4];
     if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (out[23] != 0.0 && i < n && inl[i]) {
-        unsigned char bb = 0;
-        for (int k = 0; k < 4; ++k) {
-            const double* R = out + 24 + (k & 1) * 9;
-            const double sg = k >= 2 ? -1.0 : 1.0;
-            const double P[3][4] = {{R[0], R[1], R[2], sg * out[42]}, {R[3], R[4], R[5], sg * out[43]}, {R[6], R[7], R[8], sg * out[44]}};
-            // DLT rows (cv2.triangulatePoints): x P0[2] - P0[0], y P0[2] - P0[1] with P0 = [I | 0], and the same for P
-            const double A[4][4] = {{-1, 0, x0[i].x, 0}, {0, -1, x0[i].y, 0},
-                                    {x1[i].x * P[2][0] - P[0][0], x1[i].x * P[2][1] - P[0][1], x1[i].x * P[2][2] - P[0][2], x1[i].x * P[2][3] - P[0][3]},
-                                    {x1[i].y * P[2][0] - P[1][0], x1[i].y * P[2][1] - P[1][1], x1[i].y * P[2][2] - P[1][2], x1[i].y * P[2][3] - P[1][3]}};
-            double ata[4][4], ev[4][4];
-            for (int a = 0; a < 4; ++a) for (int b2 = 0; b2 < 4; ++b2) ata[a][b2] = A[0][a] * A[0][b2] + A[1][a] * A[1][b2] + A[2][a] * A[2][b2] + A[3][a] * A[3][b2];
-            jacobi_eig<4>(ata, ev);
-            int m = 0;
-            for (int a = 1; a < 4; ++a) if (ata[a][a] < ata[m][m]) m = a;
-            const double Q[4] = {ev[0][m], ev[1][m], ev[2][m], ev[3][m]};
-            bool ok = Q[2] * Q[3] > 0;
-            const double X = Q[0] / Q[3], Y = Q[1] / Q[3], Z = Q[2] / Q[3];
-            ok = ok && Z < dist_thresh;
-            const double zc = P[2][0] * X + P[2][1] * Y + P[2][2] * Z + P[2][3];
-            ok = ok && zc > 0 && zc < dist_thresh;
-            if (ok) { bb |= 1u << k; atomicAdd(&cnt[k], 1); }
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t >> 2, k = t & 3;
+    const bool live = out[23] != 0.0 && i < n && inl[i < n ? i : 0];
+    unsigned bb = 0;
+    if (live) {
+        const double* R = out + 24 + (k & 1) * 9;
+        const double sg = k >= 2 ? -1.0 : 1.0;
+        const double P[3][4] = {{R[0], R[1], R[2], sg * out[42]}, {R[3], R[4], R[5], sg * out[43]}, {R[6], R[7], R[8], sg * out[44]}};
+        const double2 a = x0[i], b = x1[i];
+        // DLT rows (cv2.triangulatePoints): x P0[2] - P0[0], y P0[2] - P0[1] with P0 = [I | 0], and the same for P
+        const double A[4][4] = {{-1, 0, a.x, 0}, {0, -1, a.y, 0},
+                                {b.x * P[2][0] - P[0][0], b.x * P[2][1] - P[0][1], b.x * P[2][2] - P[0][2], b.x * P[2][3] - P[0][3]},
+                                {b.y * P[2][0] - P[1][0], b.y * P[2][1] - P[1][1], b.y * P[2][2] - P[1][2], b.y * P[2][3] - P[1][3]}};
+        double ata[4][4], ev[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ata[r][c] = A[0][r] * A[0][c] + A[1][r] * A[1][c] + A[2][r] * A[2][c] + A[3][r] * A[3][c];
+        jacobi_eig<4>(ata, ev);
+        double lmin = ata[0][0];
+        double Q[4] = {ev[0][0], ev[1][0], ev[2][0], ev[3][0]};
+#pragma unroll
+        for (int c = 1; c < 4; ++c) {
+            const bool lt = ata[c][c] < lmin;
+            lmin = lt ? ata[c][c] : lmin;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Q[r] = lt ? ev[r][c] : Q[r];
         }
-        bits[i] = bb;
+        bool ok = Q[2] * Q[3] > 0;
+        const double X = Q[0] / Q[3], Y = Q[1] / Q[3], Z = Q[2] / Q[3];
+        ok = ok && Z < dist_thresh;
+        const double zc = P[2][0] * X + P[2][1] * Y + P[2][2] * Z + P[2][3];
+        ok = ok && zc > 0 && zc < dist_thresh;
+        if (ok) { bb = 1u << k; atomicAdd(&cnt[k], 1); }
     }
+    bb |= __shfl_xor(bb, 1);
+    bb |= __shfl_xor(bb, 2);
+    if (live && k == 0) bits[i] = (unsigned char)bb;
     __syncthreads();
     if (threadIdx.x < 4 && cnt[threadIdx.x]) atomicAdd(&good[threadIdx.x], cnt[threadIdx.x]);
 }
@@ -502,13 +622,31 @@ __global__ __launch_bounds__(256) void pose_vote_kernel(int n, const int* __rest
     }
 }
 
+// pixel coordinates (float, in the host's pinned staging buffer, read over the bus by this kernel) -> normalised camera coordinates:
+// (x - cx) / fx, (y - cy) / fy per camera, in fp64 like the host loop it replaces.  A hipMemcpyAsync of more than a few KB takes the
+// runtime's staged path here: ~55-70 us before the first kernel starts; this is 3-5 us.
+__global__ __launch_bounds__(256) void pose_upload_kernel(const float* __restrict__ k0, const float* __restrict__ k1, int n, double cx0, double fx0,
+                                                          double cy0, double fy0, double cx1, double fx1, double cy1, double fy1,
+                                                          double2* __restrict__ x0, double2* __restrict__ x1) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float2 a = reinterpret_cast<const float2*>(k0)[i], b = reinterpret_cast<const float2*>(k1)[i];
+    x0[i] = double2{((double)a.x - cx0) / fx0, ((double)a.y - cy0) / fy0};
+    x1[i] = double2{((double)b.x - cx1) / fx1, ((double)b.y - cy1) / fy1};
+}
+
+// per-thread workspace.  Device: x = [x0 | x1], res = [out 48 doubles | refmask | inl] (one read-back); host: pinned
+// staging for both, so neither copy goes through the runtime's pageable-memory path (three staged uploads cost ~0.15 ms per call)
 struct PoseWs {
     int device = -1;
     size_t cap_n = 0, cap_h = 0;
-    double2 *x0 = nullptr, *x1 = nullptr;
-    double *Eh = nullptr, *out = nullptr;
+    double2* x = nullptr;
+    unsigned char* res = nullptr;
+    double* Eh = nullptr;
     int *valid = nullptr, *counts = nullptr, *good = nullptr;
-    unsigned char *inl = nullptr, *bits = nullptr, *refmask = nullptr;
+    unsigned char* bits = nullptr;
+    unsigned char* pin = nullptr;      // hipHostMalloc: the float keypoints on the way in (16 n bytes), the results on the way out (384 + 2 n bytes)
+    unsigned char* pin_dev = nullptr;  // the same buffer as the device sees it
 };
 
 }  // namespace
@@ -524,43 +662,46 @@ extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, 
     hipStream_t st = (hipStream_t)stream;
     static thread_local PoseWs ws;
     if (ws.device != device || (size_t)n > ws.cap_n || (size_t)iterations > ws.cap_h) {
-        for (void* p : {(void*)ws.x0, (void*)ws.x1, (void*)ws.Eh, (void*)ws.out, (void*)ws.valid, (void*)ws.counts, (void*)ws.inl, (void*)ws.good, (void*)ws.bits, (void*)ws.refmask})
+        for (void* p : {(void*)ws.x, (void*)ws.res, (void*)ws.Eh, (void*)ws.valid, (void*)ws.counts, (void*)ws.good, (void*)ws.bits})
             if (p) (void)hipFree(p);
+        if (ws.pin) (void)hipHostFree(ws.pin);
         ws = PoseWs();
         const size_t cn = (size_t)n < 4096 ? 4096 : (size_t)n, ch = (size_t)iterations < 2048 ? 2048 : (size_t)iterations;
-        if (hipMalloc(&ws.x0, cn * sizeof(double2)) != hipSuccess || hipMalloc(&ws.x1, cn * sizeof(double2)) != hipSuccess ||
-            hipMalloc(&ws.Eh, ch * 10 * 9 * sizeof(double)) != hipSuccess || hipMalloc(&ws.out, 48 * sizeof(double)) != hipSuccess ||
-            hipMalloc(&ws.good, 4 * sizeof(int)) != hipSuccess || hipMalloc(&ws.bits, cn) != hipSuccess ||
-            hipMalloc(&ws.valid, ch * 10 * sizeof(int)) != hipSuccess || hipMalloc(&ws.counts, ch * 10 * sizeof(int)) != hipSuccess ||
-            hipMalloc(&ws.inl, cn) != hipSuccess || hipMalloc(&ws.refmask, cn) != hipSuccess)
+        if (hipMalloc(&ws.x, 2 * cn * sizeof(double2)) != hipSuccess || hipMalloc(&ws.res, 48 * sizeof(double) + 2 * cn) != hipSuccess ||
+            hipMalloc(&ws.Eh, ch * 10 * 9 * sizeof(double)) != hipSuccess || hipMalloc(&ws.good, 4 * sizeof(int)) != hipSuccess ||
+            hipMalloc(&ws.bits, cn) != hipSuccess || hipMalloc(&ws.valid, ch * 10 * sizeof(int)) != hipSuccess ||
+            hipMalloc(&ws.counts, ch * 10 * sizeof(int)) != hipSuccess || hipHostMalloc(&ws.pin, 2 * cn * sizeof(double2)) != hipSuccess ||
+            hipHostGetDevicePointer(reinterpret_cast<void**>(&ws.pin_dev), ws.pin, 0) != hipSuccess)
             return IMP_E_NOMEM;
         ws.device = device; ws.cap_n = cn; ws.cap_h = ch;
     }
-    // normalised coordinates on the host (n is small): (x - cx) / fx, (y - cy) / fy per camera
-    std::vector<double2> h0(n), h1(n);
-    for (int i = 0; i < n; ++i) {
-        h0[i] = double2{((double)kpts0[2 * i] - K0[2]) / K0[0], ((double)kpts0[2 * i + 1] - K0[5]) / K0[4]};
-        h1[i] = double2{((double)kpts1[2 * i] - K1[2]) / K1[0], ((double)kpts1[2 * i + 1] - K1[5]) / K1[4]};
-    }
-    if (hipMemcpyAsync(ws.x0, h0.data(), n * sizeof(double2), hipMemcpyHostToDevice, st) != hipSuccess) return IMP_E_HIP;
-    if (hipMemcpyAsync(ws.x1, h1.data(), n * sizeof(double2), hipMemcpyHostToDevice, st) != hipSuccess) return IMP_E_HIP;
+    double2* const x0 = ws.x;
+    double2* const x1 = ws.x + n;
+    double* const dout = reinterpret_cast<double*>(ws.res);
+    unsigned char* const refmask = ws.res + 48 * sizeof(double);
+    unsigned char* const inl = refmask + n;
+    memcpy(ws.pin, kpts0, (size_t)n * 2 * sizeof(float));
+    memcpy(ws.pin + (size_t)n * 2 * sizeof(float), kpts1, (size_t)n * 2 * sizeof(float));
+    hipLaunchKernelGGL(pose_upload_kernel, dim3((n + 255) / 256), dim3(256), 0, st, reinterpret_cast<const float*>(ws.pin_dev),
+                       reinterpret_cast<const float*>(ws.pin_dev) + (size_t)n * 2, n, K0[2], K0[0], K0[5], K0[4], K1[2], K1[0], K1[5], K1[4], x0, x1);
     const double thr = norm_thresh / ((K0[0] + K0[4] + K1[0] + K1[4]) / 4.0);
     const int ncand = eight ? iterations : iterations * 10;
-    if (eight) hipLaunchKernelGGL(pose_hypotheses_kernel, dim3((iterations + 63) / 64), dim3(64), 0, st, ws.x0, ws.x1, n, iterations, seed, ws.Eh, ws.valid);
-    else hipLaunchKernelGGL(pose_hypotheses5_kernel, dim3((iterations + FP_THREADS - 1) / FP_THREADS), dim3(64), 0, st, ws.x0, ws.x1, n, iterations, seed, ws.Eh, ws.valid);
-    hipLaunchKernelGGL(pose_score_kernel, dim3(ncand), dim3(256), 0, st, ws.x0, ws.x1, n, ws.Eh, ws.valid, thr * thr, flags & 1, ws.counts);
+    if (eight) hipLaunchKernelGGL(pose_hypotheses_kernel, dim3((iterations + 63) / 64), dim3(64), 0, st, x0, x1, n, iterations, seed, ws.Eh, ws.valid);
+    else hipLaunchKernelGGL(pose_hypotheses5_kernel, dim3((iterations + 64 / FP_L - 1) / (64 / FP_L)), dim3(64), 0, st, x0, x1, n, iterations, seed, ws.Eh, ws.valid);
+    hipLaunchKernelGGL(pose_score_kernel, dim3(ncand), dim3(256), 0, st, x0, x1, n, ws.Eh, ws.valid, thr * thr, flags & 1, ws.counts);
     // the cheirality step of the reference normalises with K = (K0 + K1) / 2 (eval/pose_estimation.py:29-33): with K0 == K1 (every
     // caller in the repo) these are the coordinates above; a caller with two different cameras gets per-camera normalisation
-    hipLaunchKernelGGL(pose_consensus_kernel, dim3(1), dim3(1024), 0, st, ws.x0, ws.x1, n, ncand, ws.Eh, ws.counts, thr * thr, flags & 1, eight ? 8 : 5, ws.inl, ws.out);
-    if (hipMemsetAsync(ws.good, 0, 4 * sizeof(int), st) != hipSuccess) return IMP_E_HIP;
-    hipLaunchKernelGGL(pose_cheirality_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws.x0, ws.x1, n, ws.out, ws.inl, 1000.0, ws.bits, ws.good);
-    hipLaunchKernelGGL(pose_vote_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, ws.good, ws.bits, ws.inl, ws.refmask, ws.out);
-    double out[24];
-    if (hipMemcpyAsync(out, ws.out, sizeof out, hipMemcpyDeviceToHost, st) != hipSuccess) return IMP_E_HIP;
-    if (hipMemcpyAsync(mask, ws.refmask, n, hipMemcpyDeviceToHost, st) != hipSuccess) return IMP_E_HIP;
-    if (consensus && hipMemcpyAsync(consensus, ws.inl, n, hipMemcpyDeviceToHost, st) != hipSuccess) return IMP_E_HIP;
+    hipLaunchKernelGGL(pose_consensus_kernel, dim3(1), dim3(CT), 0, st, x0, x1, n, ncand, ws.Eh, ws.counts, thr * thr, flags & 1, eight ? 8 : 5, inl, dout, ws.good);
+    hipLaunchKernelGGL(pose_cheirality_kernel, dim3((4 * n + 255) / 256), dim3(256), 0, st, x0, x1, n, dout, inl, 1000.0, ws.bits, ws.good);
+    hipLaunchKernelGGL(pose_vote_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, ws.good, ws.bits, inl, refmask, dout);
+    // one read-back: the 24 result doubles, the reference-semantics mask and the geometric mask
+    const size_t res_bytes = 48 * sizeof(double) + 2 * (size_t)n;
+    if (hipMemcpyAsync(ws.pin, ws.res, res_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return IMP_E_HIP;
     if (hipStreamSynchronize(st) != hipSuccess) return IMP_E_HIP;
     if (hipGetLastError() != hipSuccess) return IMP_E_HIP;
+    const double* out = reinterpret_cast<const double*>(ws.pin);
+    memcpy(mask, ws.pin + 48 * sizeof(double), n);
+    if (consensus) memcpy(consensus, ws.pin + 48 * sizeof(double) + n, n);
     if (out[23] == 0.0) return 1;
     for (int i = 0; i < 9; ++i) { E[i] = out[i]; R[i] = out[9 + i]; }
     for (int i = 0; i < 3; ++i) t[i] = out[18 + i];

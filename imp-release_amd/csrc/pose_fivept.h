@@ -4,107 +4,223 @@
 //   E = x X + y Y + z Z + W in the 4-dimensional null space of the five epipolar constraints; det(E) = 0 and 2 E E^T E - tr(E E^T) E = 0
 //   are ten cubics in (x, y, z); eliminating the ten degree-3 monomials leaves the multiplication-by-x map on the quotient-ring basis
 //   [x^2, xy, xz, y^2, yz, z^2, x, y, z, 1] as a 10 x 10 matrix whose real eigenpairs are the (up to ten) solutions.
-// Plain fp64 scalar code, one hypothesis per GPU thread; also compiled for the host by the unit test of the algebra (tests/test_pose.py
-// builds tools/probe/fivept_host.cpp with g++).  CPU twin: oracle/pose_oracle.py five_point (same elimination order, same candidate order).
+// fp64.  CPU twin: oracle/pose_oracle.py five_point (same elimination order, same candidate order).
+//
+// One solve is executed by a GROUP of L lanes of a wave over matrices in LDS (struct Work); L = 1 is plain sequential C++ and is what the
+// host unit test of the algebra builds (tests/test_pose.py compiles tools/probe/fivept_host.cpp with g++).  Why a group, measured on
+// gfx950 with 1024 samples per call:
+//   * one thread per sample, run-time-indexed arrays in scratch memory: an L2 round trip per access, ~25 k of them: 1.84 ms per call;
+//   * the same in LDS, element by element: 0.65 ms; inner loops as fixed-width register blocks: 0.49 ms - of which the eigenvalues of the
+//     10 x 10 action matrix (Hessenberg + ~30 double-shift QR sweeps) are 0.33 ms: one lane issues every instruction of every sweep;
+//   * everything unrolled into registers: 112 KB of straight-line code per wave, the instruction cache becomes the bottleneck (0.49 ms).
+// So the rows / columns of every elimination step and of every QR sweep are dealt to the lanes of the group (`for (j = j0 + lane; j <= j1;
+// j += L)`), the scalar bookkeeping between them is computed redundantly by all lanes from LDS (same values, same control flow for the
+// whole group), pivot searches are group reductions, and the (up to ten) eigenvector systems are solved one per lane.  Within a group
+// the LDS operations of consecutive instructions execute in program order (one wave), so the only synchronisation is a compiler fence.
 #pragma once
 #include <math.h>
 
 #ifdef __HIPCC__
-#define FP_HD __host__ __device__
+#define FP_HD __host__ __device__ inline __attribute__((always_inline))
 #else
-#define FP_HD
+#define FP_HD inline
+#endif
+#if defined(__clang__)
+#define FP_UNROLL _Pragma("unroll")
+#define FP_LOOP _Pragma("clang loop unroll(disable)")
+#else
+#define FP_UNROLL
+#define FP_LOOP
 #endif
 
 namespace fivept {
 
-// Scratch of one solve.  On the GPU a thread's private arrays with run-time indices live in scratch memory (an L2 round trip per access;
-// the solver is one long dependent chain, ~25 k such accesses: 1.8 ms per call); the kernel therefore hands every thread a Work in LDS.
+// Scratch of one solve (LDS on the GPU): 8240 bytes
 struct Work {
-    double Q[5][9], B[4][9], E[3][3][4], A[10][20], EEt[3][3][10], tr[10], m[10], M[10][10], H[11][11], wr[11], wi[11], lam[10];
-    double C[6][5], d[6], G[6][6];
+    double pts[5][4];          // the sample: x0, y0, x1, y1 (normalised coordinates)
+    double Q[5][9];            // epipolar constraints -> reduced row echelon form
+    double B[4][9];            // null-space basis X, Y, Z, W: entry (i, j) of E is the linear polynomial B[0..3][3 i + j] in [x, y, z, 1]
+    double minors[3][10];      // 2 x 2 minors of rows 1, 2 of E (quadratic polynomials)
+    double EEt[9][10];         // E E^T
+    double tr[10];             // trace(E E^T)
+    double A[10][20];          // the ten cubics [degree-3 monomials | quotient basis] -> A1^-1 A2
+    double H[11][11];          // action matrix, 1-based (EISPACK)
+    double wr[11], wi[11];     // eigenvalues; wr is reused for the sorted real ones
+    double G[10][6][6];        // eigenvector system of each real eigenvalue
+    double Es[10][9];          // candidate essential matrices
+    int ok[10];
+    int pad[2];
 };
+
+// ---- group primitives (L lanes of one wave; L = 1: nothing to do) ----
+template <int L> FP_HD void group_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (L > 1) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+#endif
+}
+// arg max over the group: the largest v wins, the smallest key among equal v (keys are unique per candidate)
+template <int L> FP_HD void group_argmax(double& v, int& key) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (L > 1) {
+        FP_UNROLL for (int o = L / 2; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(v, o, L);
+            const int ok = __shfl_xor(key, o, L);
+            const bool take = ov > v || (ov == v && ok < key);
+            v = take ? ov : v; key = take ? ok : key;
+        }
+    }
+#endif
+}
 
 // slot tables of the polynomial products (monomial orders: linear [x, y, z, 1]; quadratic [x^2, xy, xz, y^2, yz, z^2, x, y, z, 1];
 // cubic [x^3, x^2 y, x^2 z, x y^2, xyz, x z^2, y^3, y^2 z, y z^2, z^3 | the quadratic list])
-FP_HD inline int ll_slot(int i, int j) {          // linear x linear -> quadratic
+FP_HD int ll_slot(int i, int j) {          // linear x linear -> quadratic
     const int t[4][4] = {{0, 1, 2, 6}, {1, 3, 4, 7}, {2, 4, 5, 8}, {6, 7, 8, 9}};
     return t[i][j];
 }
-FP_HD inline int ql_slot(int i, int j) {          // quadratic x linear -> cubic
+FP_HD int ql_slot(int i, int j) {          // quadratic x linear -> cubic
     const int t[10][4] = {{0, 1, 2, 10}, {1, 3, 4, 11}, {2, 4, 5, 12}, {3, 6, 7, 13}, {4, 7, 8, 14}, {5, 8, 9, 15},
                           {10, 11, 12, 16}, {11, 13, 14, 17}, {12, 14, 15, 18}, {16, 17, 18, 19}};
     return t[i][j];
 }
-FP_HD inline void mul_ll(const double* a, const double* b, double* out, double sign, bool accumulate) {
-    if (!accumulate) for (int k = 0; k < 10; ++k) out[k] = 0.0;
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) out[ll_slot(i, j)] += sign * a[i] * b[j];
+// out (registers) += sign * a * b for two linear polynomials = columns ca, cb of the basis
+FP_HD void mul_ll(const double (&B)[4][9], int ca, int cb, double (&out)[10], double sign) {
+    double a[4], b[4];
+    FP_UNROLL for (int k = 0; k < 4; ++k) { a[k] = B[k][ca]; b[k] = B[k][cb]; }
+    FP_UNROLL for (int i = 0; i < 4; ++i) {
+        FP_UNROLL for (int j = 0; j < 4; ++j) out[ll_slot(i, j)] += sign * a[i] * b[j];
+    }
 }
-FP_HD inline void mul_ql(const double* a, const double* b, double* out, double sign) {      // accumulates
-    for (int i = 0; i < 10; ++i)
-        for (int j = 0; j < 4; ++j) out[ql_slot(i, j)] += sign * a[i] * b[j];
+// out (registers) += sign * a * b for a quadratic polynomial a[10] and the linear polynomial in column cb of the basis
+FP_HD void mul_ql(const double* a10, const double (&B)[4][9], int cb, double (&out)[20], double sign) {
+    double a[10], b[4];
+    FP_UNROLL for (int k = 0; k < 10; ++k) a[k] = a10[k];
+    FP_UNROLL for (int k = 0; k < 4; ++k) b[k] = B[k][cb];
+    FP_UNROLL for (int i = 0; i < 10; ++i) {
+        FP_UNROLL for (int j = 0; j < 4; ++j) out[ql_slot(i, j)] += sign * a[i] * b[j];
+    }
 }
 
 // 4 vectors spanning the null space of the 5 x 9 system: Gauss-Jordan with full pivoting (largest |entry| of the remaining rows, first in
-// row-major order on ties); free column f gives the vector with 1 at f and -R[i][f] at pivot column i
-FP_HD inline bool null_basis_5x9(double (&A)[5][9], double (&basis)[4][9]) {
-    int piv[5];
-    for (int r = 0; r < 5; ++r) {
-        int pr = r, pc = 0;
+// row-major order on ties); free column f gives the vector with 1 at f and -R[i][f] at pivot column i.  Lane j owns column j.
+template <int L>
+FP_HD bool null_basis_5x9(double (&A)[5][9], double (&basis)[4][9], int lane) {
+    unsigned piv = 0;                                     // pivot column of row r in bits 4 r .. 4 r + 3
+    FP_LOOP for (int r = 0; r < 5; ++r) {
         double best = -1.0;
-        for (int i = r; i < 5; ++i)
-            for (int j = 0; j < 9; ++j)
-                if (fabs(A[i][j]) > best) { best = fabs(A[i][j]); pr = i; pc = j; }
+        int key = r * 9;
+        FP_LOOP for (int t = lane; t < (5 - r) * 9; t += L) {
+            const int i = r + t / 9, j = t - (t / 9) * 9;
+            const double v = fabs(A[i][j]);
+            if (v > best) { best = v; key = i * 9 + j; }
+        }
+        group_argmax<L>(best, key);
         if (!(best > 1e-14)) return false;
-        if (pr != r) for (int j = 0; j < 9; ++j) { const double t = A[r][j]; A[r][j] = A[pr][j]; A[pr][j] = t; }
-        const double d = A[r][pc];
-        for (int j = 0; j < 9; ++j) A[r][j] /= d;
-        for (int i = 0; i < 5; ++i)
-            if (i != r) {
-                const double f = A[i][pc];
-                for (int j = 0; j < 9; ++j) A[i][j] -= f * A[r][j];
+        const int pr = key / 9, pc = key - pr * 9;
+        const double inv = 1.0 / A[pr][pc];               // one division per pivot, then products
+        double f[5];                                       // column pc of the rows as they stand AFTER rows r and pr have changed places
+        FP_UNROLL for (int i = 0; i < 5; ++i) f[i] = A[i == pr ? r : i][pc];
+        group_fence<L>();
+        FP_LOOP for (int j = lane; j < 9; j += L) {
+            const double a = A[r][j], b = A[pr][j];
+            const double row = b * inv;
+            A[pr][j] = a;
+            A[r][j] = row;
+            FP_UNROLL for (int i = 0; i < 5; ++i) {
+                const double v = A[i][j];
+                A[i][j] = i == r ? v : v - f[i] * row;
             }
-        piv[r] = pc;
+        }
+        group_fence<L>();
+        piv |= (unsigned)pc << (4 * r);
     }
     int nb = 0;
-    for (int f = 0; f < 9; ++f) {
+    FP_LOOP for (int f = 0; f < 9; ++f) {
         bool is_piv = false;
-        for (int r = 0; r < 5; ++r) is_piv |= piv[r] == f;
+        FP_UNROLL for (int r = 0; r < 5; ++r) is_piv |= (int)((piv >> (4 * r)) & 15u) == f;
         if (is_piv) continue;
-        for (int j = 0; j < 9; ++j) basis[nb][j] = 0.0;
-        basis[nb][f] = 1.0;
-        for (int r = 0; r < 5; ++r) basis[nb][piv[r]] = -A[r][f];
+        if (nb < 4) {
+            FP_LOOP for (int j = lane; j < 9; j += L) {
+                double v = j == f ? 1.0 : 0.0;
+                FP_UNROLL for (int r = 0; r < 5; ++r) v = (int)((piv >> (4 * r)) & 15u) == j ? -A[r][f] : v;
+                basis[nb][j] = v;
+            }
+        }
         ++nb;
     }
+    group_fence<L>();
     return nb == 4;
 }
 
+// [A1 | A2] -> [I | A1^-1 A2] by Gauss-Jordan with partial (row) pivoting, first largest on ties.  Lane j owns columns j, j + L, ...
+template <int L>
+FP_HD bool gauss_jordan_10x20(double (&A)[10][20], int lane) {
+    FP_LOOP for (int c = 0; c < 10; ++c) {
+        double best = -1.0;
+        int pr = c;
+        FP_LOOP for (int i = c + lane; i < 10; i += L) {
+            const double v = fabs(A[i][c]);
+            if (v > best) { best = v; pr = i; }
+        }
+        group_argmax<L>(best, pr);
+        if (!(best > 1e-300)) return false;
+        const double inv = 1.0 / A[pr][c];
+        double f[10];                                      // column c of the rows as they stand AFTER rows c and pr have changed places
+        FP_UNROLL for (int i = 0; i < 10; ++i) f[i] = A[i == pr ? c : i][c];
+        group_fence<L>();
+        FP_LOOP for (int j = lane; j < 20; j += L) {
+            const double a = A[c][j], b = A[pr][j];
+            const double row = b * inv;
+            A[pr][j] = a;
+            A[c][j] = row;
+            double col[10];
+            FP_UNROLL for (int i = 0; i < 10; ++i) col[i] = A[i][j];
+            FP_UNROLL for (int i = 0; i < 10; ++i) A[i][j] = i == c ? col[i] : col[i] - f[i] * row;
+        }
+        group_fence<L>();
+    }
+    return true;
+}
+
 // reduction to upper Hessenberg form by stabilised elementary similarity transformations, then the eigenvalues by the shifted QR
-// algorithm with implicit double shifts (EISPACK elmhes / hqr, 1-based indexing kept as published); returns false if an eigenvalue
-// needs more than 60 iterations
-FP_HD inline bool eig_real_nonsym(double (&a)[11][11], int n, double* wr, double* wi) {
-    for (int m = 2; m < n; ++m) {
-        double x = 0.0;
+// algorithm with implicit double shifts (EISPACK elmhes / hqr, 1-based indexing kept as published, n = 10); returns false if an
+// eigenvalue needs more than 60 iterations.  The arithmetic is the published one, element for element; the row / column loops are
+// dealt to the lanes, everything else is computed by every lane of the group (identical values).
+template <int L>
+FP_HD bool eig_real_nonsym(double (&a)[11][11], double* wr, double* wi, int lane) {
+    constexpr int n = 10;
+    FP_LOOP for (int m = 2; m < n; ++m) {
+        double best = 0.0;
         int i = m;
-        for (int j = m; j <= n; ++j)
-            if (fabs(a[j][m - 1]) > fabs(x)) { x = a[j][m - 1]; i = j; }
+        FP_LOOP for (int j = m + lane; j <= n; j += L) {
+            const double v = fabs(a[j][m - 1]);
+            if (v > best) { best = v; i = j; }
+        }
+        group_argmax<L>(best, i);
+        const double x = best > 0.0 ? a[i][m - 1] : 0.0;
+        group_fence<L>();
         if (i != m) {
-            for (int j = m - 1; j <= n; ++j) { const double t = a[i][j]; a[i][j] = a[m][j]; a[m][j] = t; }
-            for (int j = 1; j <= n; ++j) { const double t = a[j][i]; a[j][i] = a[j][m]; a[j][m] = t; }
+            FP_LOOP for (int j = m - 1 + lane; j <= n; j += L) { const double t = a[i][j]; a[i][j] = a[m][j]; a[m][j] = t; }
+            group_fence<L>();
+            FP_LOOP for (int j = 1 + lane; j <= n; j += L) { const double t = a[j][i]; a[j][i] = a[j][m]; a[j][m] = t; }
+            group_fence<L>();
         }
         if (x != 0.0)
-            for (i = m + 1; i <= n; ++i) {
-                double y = a[i][m - 1];
+            FP_LOOP for (int ii = m + 1; ii <= n; ++ii) {
+                double y = a[ii][m - 1];
                 if (y != 0.0) {
                     y /= x;
-                    a[i][m - 1] = y;
-                    for (int j = m; j <= n; ++j) a[i][j] -= y * a[m][j];
-                    for (int j = 1; j <= n; ++j) a[j][m] += y * a[j][i];
+                    a[ii][m - 1] = y;                                      // every lane: the same value
+                    FP_LOOP for (int j = m + lane; j <= n; j += L) a[ii][j] -= y * a[m][j];
+                    group_fence<L>();
+                    FP_LOOP for (int j = 1 + lane; j <= n; j += L) a[j][m] += y * a[j][ii];
+                    group_fence<L>();
                 }
             }
     }
-    for (int i = 3; i <= n; ++i)
+    FP_LOOP for (int i = 3 + lane; i <= n; i += L)
         for (int j = 1; j <= i - 2; ++j) a[i][j] = 0.0;
+    group_fence<L>();
     double anorm = 0.0;
     for (int i = 1; i <= n; ++i)
         for (int j = (i - 1 > 1 ? i - 1 : 1); j <= n; ++j) anorm += fabs(a[i][j]);
@@ -143,7 +259,9 @@ FP_HD inline bool eig_real_nonsym(double (&a)[11][11], int n, double* wr, double
                     if (its == 60) return false;
                     if (its == 10 || its == 20 || its == 40) {
                         t += x;
-                        for (int i = 1; i <= nn; ++i) a[i][i] -= x;
+                        group_fence<L>();
+                        FP_LOOP for (int i = 1 + lane; i <= nn; i += L) a[i][i] -= x;
+                        group_fence<L>();
                         s = fabs(a[nn][nn - 1]) + fabs(a[nn - 1][nn - 2]);
                         y = x = 0.75 * s;
                         w = -0.4375 * s * s;
@@ -180,26 +298,30 @@ FP_HD inline bool eig_real_nonsym(double (&a)[11][11], int n, double* wr, double
                         s = p >= 0.0 ? nrm : -nrm;
                         if (s != 0.0) {
                             if (k == m) {
-                                if (l != m) a[k][k - 1] = -a[k][k - 1];
+                                if (l != m) a[k][k - 1] = -a[k][k - 1];    // every lane reads, then every lane writes the same value
                             } else {
                                 a[k][k - 1] = -s * x;
                             }
                             p += s;
                             x = p / s; y = q / s; z = r / s;
                             q /= p; r /= p;
-                            for (int j = k; j <= nn; ++j) {
-                                p = a[k][j] + q * a[k + 1][j];
-                                if (k != nn - 1) { p += r * a[k + 2][j]; a[k + 2][j] -= p * z; }
-                                a[k + 1][j] -= p * y;
-                                a[k][j] -= p * x;
+                            const bool three = k != nn - 1;
+                            group_fence<L>();
+                            FP_LOOP for (int j = k + lane; j <= nn; j += L) {                 // row modification
+                                double pp = a[k][j] + q * a[k + 1][j];
+                                if (three) { pp += r * a[k + 2][j]; a[k + 2][j] -= pp * z; }
+                                a[k + 1][j] -= pp * y;
+                                a[k][j] -= pp * x;
                             }
+                            group_fence<L>();
                             const int mmin = nn < k + 3 ? nn : k + 3;
-                            for (int i = l; i <= mmin; ++i) {
-                                p = x * a[i][k] + y * a[i][k + 1];
-                                if (k != nn - 1) { p += z * a[i][k + 2]; a[i][k + 2] -= p * r; }
-                                a[i][k + 1] -= p * q;
-                                a[i][k] -= p;
+                            FP_LOOP for (int i = l + lane; i <= mmin; i += L) {               // column modification
+                                double pp = x * a[i][k] + y * a[i][k + 1];
+                                if (three) { pp += z * a[i][k + 2]; a[i][k + 2] -= pp * r; }
+                                a[i][k + 1] -= pp * q;
+                                a[i][k] -= pp;
                             }
+                            group_fence<L>();
                         }
                     }
                 }
@@ -212,137 +334,167 @@ FP_HD inline bool eig_real_nonsym(double (&a)[11][11], int n, double* wr, double
 // Eigenvector of the action matrix M for a real eigenvalue lambda, i.e. the basis monomials b = [x^2, xy, xz, y^2, yz, z^2, x, y, z, 1]
 // at a solution: rows 6..9 of M are unit rows (x.x = x^2, x.y = xy, x.z = xz, x.1 = x), so with b9 = 1: b6 = lambda, b0 = lambda^2,
 // b1 = lambda b7, b2 = lambda b8, and rows 0..5 of (M - lambda I) b = 0 are six linear equations in the five unknowns
-// u = (b3, b4, b5, b7, b8) = (y^2, yz, z^2, y, z): a consistent 6 x 5 system, solved by elimination with full pivoting.  ~200 operations instead of a 10 x 10 elimination per eigenvalue.  Returns (y, z).
-FP_HD inline bool solve_yz(Work& w, double lam, double* y, double* z) {
-    double (&M)[10][10] = w.M;
-    double (&C)[6][5] = w.C;
-    double (&d)[6] = w.d;
-    for (int r = 0; r < 6; ++r) {
+// u = (b3, b4, b5, b7, b8) = (y^2, yz, z^2, y, z): a consistent 6 x 5 system, solved by elimination with full pivoting (no normal
+// equations, which would square the condition number).  M[r][j] = -A[r][10 + j], the six non-trivial rows of the action matrix.
+// One lane per eigenvalue (G = that lane's 6 x 6 scratch).  Returns (y, z).
+FP_HD bool solve_yz(const double (&A)[10][20], double (&G)[6][6], double lam, double* y, double* z) {
+    FP_LOOP for (int r = 0; r < 6; ++r) {
+        double M[10];
+        FP_UNROLL for (int j = 0; j < 10; ++j) M[j] = -A[r][10 + j];
         // (M - lam I)[r] . b = 0 with b = [lam^2, lam b7, lam b8, b3, b4, b5, lam, b7, b8, 1]
-        const double m0 = M[r][0] - (r == 0 ? lam : 0.0), m1 = M[r][1] - (r == 1 ? lam : 0.0), m2 = M[r][2] - (r == 2 ? lam : 0.0);
-        C[r][0] = M[r][3] - (r == 3 ? lam : 0.0);
-        C[r][1] = M[r][4] - (r == 4 ? lam : 0.0);
-        C[r][2] = M[r][5] - (r == 5 ? lam : 0.0);
-        C[r][3] = M[r][7] + lam * m1;
-        C[r][4] = M[r][8] + lam * m2;
-        d[r] = -(lam * lam * m0 + lam * M[r][6] + M[r][9]);
+        const double m0 = M[0] - (r == 0 ? lam : 0.0), m1 = M[1] - (r == 1 ? lam : 0.0), m2 = M[2] - (r == 2 ? lam : 0.0);
+        G[r][0] = M[3] - (r == 3 ? lam : 0.0);
+        G[r][1] = M[4] - (r == 4 ? lam : 0.0);
+        G[r][2] = M[5] - (r == 5 ? lam : 0.0);
+        G[r][3] = M[7] + lam * m1;
+        G[r][4] = M[8] + lam * m2;
+        G[r][5] = -(lam * lam * m0 + lam * M[6] + M[9]);
     }
-    // the system is consistent (rank 5): Gaussian elimination with full pivoting over the 6 rows picks five of them (no normal equations,
-    // which would square the condition number)
-    double (&G)[6][6] = w.G;
     int colperm[5] = {0, 1, 2, 3, 4};
-    for (int r = 0; r < 6; ++r) { for (int j = 0; j < 5; ++j) G[r][j] = C[r][j]; G[r][5] = d[r]; }
-    for (int c = 0; c < 5; ++c) {
+    FP_LOOP for (int c = 0; c < 5; ++c) {
         int pr = c, pc = c;
         double best = -1.0;
-        for (int i = c; i < 6; ++i)
-            for (int j = c; j < 5; ++j)
-                if (fabs(G[i][j]) > best) { best = fabs(G[i][j]); pr = i; pc = j; }
-        if (!(best > 0.0)) return false;
-        if (pr != c) for (int j = 0; j < 6; ++j) { const double t = G[c][j]; G[c][j] = G[pr][j]; G[pr][j] = t; }
-        if (pc != c) {
-            for (int i = 0; i < 6; ++i) { const double t = G[i][c]; G[i][c] = G[i][pc]; G[i][pc] = t; }
-            const int t = colperm[c]; colperm[c] = colperm[pc]; colperm[pc] = t;
+        FP_LOOP for (int i = c; i < 6; ++i) {
+            double v[5];
+            FP_UNROLL for (int j = 0; j < 5; ++j) v[j] = fabs(G[i][j]);
+            FP_UNROLL for (int j = 0; j < 5; ++j) {
+                const bool gt = j >= c && v[j] > best;
+                best = gt ? v[j] : best; pr = gt ? i : pr; pc = gt ? j : pc;
+            }
         }
-        const double piv = G[c][c];
-        for (int j = c; j < 6; ++j) G[c][j] /= piv;
-        for (int i = 0; i < 6; ++i)
+        if (!(best > 0.0)) return false;
+        {   // row pr <-> row c, then column pc <-> column c (all rows)
+            double rp[6], rc[6];
+            FP_UNROLL for (int j = 0; j < 6; ++j) { rp[j] = G[pr][j]; rc[j] = G[c][j]; }
+            FP_UNROLL for (int j = 0; j < 6; ++j) { G[pr][j] = rc[j]; }
+            FP_UNROLL for (int j = 0; j < 6; ++j) { G[c][j] = rp[j]; }
+            double cp[6], cc[6];
+            FP_UNROLL for (int i = 0; i < 6; ++i) { cp[i] = G[i][pc]; cc[i] = G[i][c]; }
+            FP_UNROLL for (int i = 0; i < 6; ++i) { G[i][pc] = cc[i]; }
+            FP_UNROLL for (int i = 0; i < 6; ++i) { G[i][c] = cp[i]; }
+            int v = colperm[0], u = colperm[0];
+            FP_UNROLL for (int j = 1; j < 5; ++j) { v = pc == j ? colperm[j] : v; u = c == j ? colperm[j] : u; }
+            FP_UNROLL for (int j = 0; j < 5; ++j) colperm[j] = j == c ? v : (j == pc ? u : colperm[j]);
+        }
+        double row[6];
+        FP_UNROLL for (int j = 0; j < 6; ++j) row[j] = G[c][j];
+        const double inv = 1.0 / G[c][c];
+        FP_UNROLL for (int j = 0; j < 6; ++j) row[j] = j >= c ? row[j] * inv : row[j];
+        FP_UNROLL for (int j = 0; j < 6; ++j) G[c][j] = row[j];
+        FP_LOOP for (int i = 0; i < 6; ++i) {
             if (i != c) {
                 const double f = G[i][c];
-                if (f != 0.0) for (int j = c; j < 6; ++j) G[i][j] -= f * G[c][j];
+                double ri[6];
+                FP_UNROLL for (int j = 0; j < 6; ++j) ri[j] = G[i][j];
+                FP_UNROLL for (int j = 0; j < 6; ++j) G[i][j] = j >= c ? ri[j] - f * row[j] : ri[j];
             }
+        }
     }
-    double u[5];
-    for (int c = 0; c < 5; ++c) u[colperm[c]] = G[c][5];
-    *y = u[3];
-    *z = u[4];
-    return isfinite(*y) && isfinite(*z);
+    double yy = 0.0, zz = 0.0;
+    FP_UNROLL for (int c = 0; c < 5; ++c) { yy = colperm[c] == 3 ? G[c][5] : yy; zz = colperm[c] == 4 ? G[c][5] : zz; }
+    *y = yy;
+    *z = zz;
+    return isfinite(yy) && isfinite(zz);
 }
 
-// x0, x1: 5 normalised correspondences (x1h^T E x0h = 0).  Writes up to 10 essential matrices (row-major, Frobenius norm 1; Eout [10][9])
-// in ascending order of the eigenvalue and returns their number
-FP_HD inline int five_point(const double (&x0)[5][2], const double (&x1)[5][2], double* Eout, Work& w) {
-    double (&Q)[5][9] = w.Q;
-    for (int i = 0; i < 5; ++i) {
-        const double ax = x0[i][0], ay = x0[i][1], bx = x1[i][0], by = x1[i][1];
+#if defined(FP_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define FP_STAMP(k) prof[k] = wall_clock64()
+#else
+#define FP_STAMP(k)
+#endif
+
+// w.pts: 5 normalised correspondences (x1h^T E x0h = 0), written by the caller (all lanes of the group see them).  Writes up to 10
+// essential matrices (row-major, Frobenius norm 1; Eout [10][9]) in ascending order of the eigenvalue and returns their number (the same
+// value on every lane of the group).
+template <int L>
+FP_HD int five_point(double* Eout, Work& w, int lane, unsigned long long* prof = nullptr) {
+    (void)prof;
+    FP_STAMP(0);
+    FP_LOOP for (int i = lane; i < 5; i += L) {
+        const double ax = w.pts[i][0], ay = w.pts[i][1], bx = w.pts[i][2], by = w.pts[i][3];
         const double row[9] = {bx * ax, bx * ay, bx, by * ax, by * ay, by, ax, ay, 1.0};
-        for (int j = 0; j < 9; ++j) Q[i][j] = row[j];
+        FP_UNROLL for (int j = 0; j < 9; ++j) w.Q[i][j] = row[j];
     }
+    group_fence<L>();
     double (&B)[4][9] = w.B;
-    if (!null_basis_5x9(Q, B)) return 0;
-    double (&E)[3][3][4] = w.E;                                            // entries as linear polynomials [x, y, z, 1]
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
-            for (int k = 0; k < 4; ++k) E[i][j][k] = B[k][3 * i + j];
-    double (&A)[10][20] = w.A;
-    for (int i = 0; i < 10; ++i)
-        for (int j = 0; j < 20; ++j) A[i][j] = 0.0;
-    {   // det(E) by the first row
-        double (&m)[10] = w.m;
-        mul_ll(E[1][1], E[2][2], m, 1.0, false); mul_ll(E[1][2], E[2][1], m, -1.0, true); mul_ql(m, E[0][0], A[0], 1.0);
-        mul_ll(E[1][0], E[2][2], m, 1.0, false); mul_ll(E[1][2], E[2][0], m, -1.0, true); mul_ql(m, E[0][1], A[0], -1.0);
-        mul_ll(E[1][0], E[2][1], m, 1.0, false); mul_ll(E[1][1], E[2][0], m, -1.0, true); mul_ql(m, E[0][2], A[0], 1.0);
-    }
-    double (&EEt)[3][3][10] = w.EEt;
-    double (&tr)[10] = w.tr;
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            mul_ll(E[i][0], E[j][0], EEt[i][j], 1.0, false);
-            mul_ll(E[i][1], E[j][1], EEt[i][j], 1.0, true);
-            mul_ll(E[i][2], E[j][2], EEt[i][j], 1.0, true);
+    if (!null_basis_5x9<L>(w.Q, B, lane)) return 0;
+    FP_STAMP(1);
+    // entry (i, j) of E = column 3 i + j of the basis.  Jobs 0..2: the 2 x 2 minors of rows 1, 2 (det(E) by the first row; minor t leaves
+    // out column t); jobs 3..11: the entries of E E^T
+    FP_LOOP for (int job = lane; job < 12; job += L) {
+        double m[10];
+        FP_UNROLL for (int k = 0; k < 10; ++k) m[k] = 0.0;
+        if (job < 3) {
+            const int c1 = job == 0 ? 1 : 0, c2 = job == 2 ? 1 : 2;
+            mul_ll(B, 3 + c1, 6 + c2, m, 1.0);
+            mul_ll(B, 3 + c2, 6 + c1, m, -1.0);
+            FP_UNROLL for (int k = 0; k < 10; ++k) w.minors[job][k] = m[k];
+        } else {
+            const int ij = job - 3, i = ij / 3, j = ij - 3 * i;
+            FP_LOOP for (int k = 0; k < 3; ++k) mul_ll(B, 3 * i + k, 3 * j + k, m, 1.0);
+            FP_UNROLL for (int k = 0; k < 10; ++k) w.EEt[ij][k] = m[k];
         }
-    for (int k = 0; k < 10; ++k) tr[k] = EEt[0][0][k] + EEt[1][1][k] + EEt[2][2][k];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            double* row = A[1 + 3 * i + j];
-            for (int k = 0; k < 3; ++k) mul_ql(EEt[i][k], E[k][j], row, 2.0);
-            mul_ql(tr, E[i][j], row, -1.0);
-        }
-    // [A1 | A2] -> A1^-1 A2 by Gauss-Jordan with partial pivoting
-    for (int c = 0; c < 10; ++c) {
-        int pr = c;
-        for (int i = c + 1; i < 10; ++i) if (fabs(A[i][c]) > fabs(A[pr][c])) pr = i;
-        if (!(fabs(A[pr][c]) > 1e-300)) return 0;
-        if (pr != c) for (int j = 0; j < 20; ++j) { const double t = A[c][j]; A[c][j] = A[pr][j]; A[pr][j] = t; }
-        const double d = A[c][c];
-        for (int j = c; j < 20; ++j) A[c][j] /= d;
-        for (int i = 0; i < 10; ++i)
-            if (i != c) {
-                const double f = A[i][c];
-                if (f != 0.0) for (int j = c; j < 20; ++j) A[i][j] -= f * A[c][j];
-            }
     }
+    group_fence<L>();
+    FP_LOOP for (int k = lane; k < 10; k += L) w.tr[k] = w.EEt[0][k] + w.EEt[4][k] + w.EEt[8][k];
+    group_fence<L>();
+    // the ten cubics: det(E) = 0 and the nine entries of 2 E E^T E - tr(E E^T) E = 0; a row per lane
+    FP_LOOP for (int r = lane; r < 10; r += L) {
+        double row[20];
+        FP_UNROLL for (int k = 0; k < 20; ++k) row[k] = 0.0;
+        const int i = r == 0 ? 0 : (r - 1) / 3, j = r == 0 ? 0 : (r - 1) - 3 * i;
+        FP_LOOP for (int k = 0; k < (r == 0 ? 3 : 4); ++k) {
+            const double* a = r == 0 ? w.minors[k] : (k < 3 ? w.EEt[3 * i + k] : w.tr);
+            const int cb = r == 0 ? k : (k < 3 ? 3 * k + j : 3 * i + j);
+            const double sign = r == 0 ? (k == 1 ? -1.0 : 1.0) : (k < 3 ? 2.0 : -1.0);
+            mul_ql(a, B, cb, row, sign);
+        }
+        FP_UNROLL for (int k = 0; k < 20; ++k) w.A[r][k] = row[k];
+    }
+    group_fence<L>();
+    FP_STAMP(2);
+    if (!gauss_jordan_10x20<L>(w.A, lane)) return 0;
+    FP_STAMP(3);
     // multiplication by x on [x^2, xy, xz, y^2, yz, z^2, x, y, z, 1]: x . (first six) = the degree-3 monomials x^3, x^2 y, x^2 z, x y^2, xyz, x z^2
-    double (&M)[10][10] = w.M;
-    for (int i = 0; i < 10; ++i)
-        for (int j = 0; j < 10; ++j) M[i][j] = i < 6 ? -A[i][10 + j] : 0.0;
-    M[6][0] = M[7][1] = M[8][2] = M[9][6] = 1.0;
-    double (&H)[11][11] = w.H;
-    double (&wr)[11] = w.wr;
-    double (&wi)[11] = w.wi;
-    for (int i = 0; i < 10; ++i)
-        for (int j = 0; j < 10; ++j) H[i + 1][j + 1] = M[i][j];
-    if (!eig_real_nonsym(H, 10, wr, wi)) return 0;
-    double (&lam)[10] = w.lam;
+    FP_LOOP for (int t = lane; t < 100; t += L) {
+        const int i = t / 10, j = t - 10 * i;
+        const bool unit = (i == 6 && j == 0) || (i == 7 && j == 1) || (i == 8 && j == 2) || (i == 9 && j == 6);
+        w.H[i + 1][j + 1] = i < 6 ? -w.A[i][10 + j] : (unit ? 1.0 : 0.0);
+    }
+    group_fence<L>();
+    if (!eig_real_nonsym<L>(w.H, w.wr, w.wi, lane)) return 0;
+    FP_STAMP(4);
+    // the real eigenvalues in ascending order, in place: wr[0 .. nl) (step i writes below index i and reads index i and above); every lane
     int nl = 0;
-    for (int i = 1; i <= 10; ++i)
-        if (wi[i] == 0.0 && isfinite(wr[i])) {                     // insertion sort, ascending
+    FP_LOOP for (int i = 1; i <= 10; ++i) {
+        const double re = w.wr[i], im = w.wi[i];
+        if (im == 0.0 && isfinite(re)) {
             int k = nl++;
-            while (k > 0 && lam[k - 1] > wr[i]) { lam[k] = lam[k - 1]; --k; }
-            lam[k] = wr[i];
+            while (k > 0 && w.wr[k - 1] > re) { w.wr[k] = w.wr[k - 1]; --k; }
+            w.wr[k] = re;
         }
-    int nout = 0;
-    for (int e = 0; e < nl; ++e) {
+    }
+    group_fence<L>();
+    FP_LOOP for (int e = lane; e < nl; e += L) {          // an eigenvalue per lane
+        const double x = w.wr[e];
         double y, z;
-        if (!solve_yz(w, lam[e], &y, &z)) continue;
-        const double x = lam[e];
-        double nrm = 0.0, Es[9];
-        for (int k = 0; k < 9; ++k) { Es[k] = x * B[0][k] + y * B[1][k] + z * B[2][k] + B[3][k]; nrm += Es[k] * Es[k]; }
+        bool ok = solve_yz(w.A, w.G[e], x, &y, &z);
+        double nrm = 0.0, Es[9], b0[9], b1[9], b2[9], b3[9];
+        FP_UNROLL for (int k = 0; k < 9; ++k) { b0[k] = B[0][k]; b1[k] = B[1][k]; b2[k] = B[2][k]; b3[k] = B[3][k]; }
+        FP_UNROLL for (int k = 0; k < 9; ++k) { Es[k] = ok ? x * b0[k] + y * b1[k] + z * b2[k] + b3[k] : 0.0; nrm += Es[k] * Es[k]; }
         nrm = sqrt(nrm);
-        if (!(nrm > 0.0) || !isfinite(nrm)) continue;
-        for (int k = 0; k < 9; ++k) Eout[nout * 9 + k] = Es[k] / nrm;
+        ok = ok && nrm > 0.0 && isfinite(nrm);
+        FP_UNROLL for (int k = 0; k < 9; ++k) w.Es[e][k] = Es[k] / nrm;
+        w.ok[e] = ok ? 1 : 0;
+    }
+    group_fence<L>();
+    int nout = 0;
+    FP_LOOP for (int e = 0; e < nl; ++e) {
+        if (!w.ok[e]) continue;
+        FP_LOOP for (int k = lane; k < 9; k += L) Eout[nout * 9 + k] = w.Es[e][k];
         ++nout;
     }
+    FP_STAMP(5);
     return nout;
 }
 

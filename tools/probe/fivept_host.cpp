@@ -10,7 +10,8 @@ int main() {
             if (scanf("%lf %lf %lf %lf", &x0[i][0], &x0[i][1], &x1[i][0], &x1[i][1]) != 4) return 0;
         double E[10][9];
         fivept::Work w;
-        const int n = fivept::five_point(x0, x1, &E[0][0], w);
+        for (int i = 0; i < 5; ++i) { w.pts[i][0] = x0[i][0]; w.pts[i][1] = x0[i][1]; w.pts[i][2] = x1[i][0]; w.pts[i][3] = x1[i][1]; }
+        const int n = fivept::five_point<1>(&E[0][0], w, 0);      // a group of one lane = plain sequential code
         printf("%d\n", n);
         for (int k = 0; k < n; ++k) {
             for (int j = 0; j < 9; ++j) printf("%.17g ", E[k][j]);
