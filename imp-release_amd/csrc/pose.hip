@@ -162,6 +162,20 @@ __host__ __device__ inline double magsac_weight(double r2, double sigma_max2) {
     const double gk = gamma_u_3_2(0.5 * MAGSAC_K * MAGSAC_K);
     return (gamma_u_3_2(0.5 * r2 / sigma_max2) - gk) / (0.88622692545275801 - gk);
 }
+// The kernels take the weight from a table, like the published implementation of MAGSAC++ tabulates the incomplete gamma function:
+// WLUT_N intervals in s = r / (k sigma_max) in [0, 1] (uniform in r, where w is smooth: w = 1 - O(r^3) at 0), linear interpolation,
+// |table - closed form| < 1e-6.  erfc + exp in fp64 are ~400 instructions, and in the scoring kernel ONE lane of a wave inside the band of
+// a bad model made the whole wave pay them: 0.1 ms per call at n = 3000.  The CPU twin reads the same table (oracle/pose_oracle.py).
+constexpr int WLUT_N = 2048;
+__device__ __forceinline__ double magsac_weight_lut(double r2, double inv_k2s2, const double* __restrict__ T) {
+    const double s2 = r2 * inv_k2s2;                       // (r / (k sigma_max))^2
+    if (!(s2 < 1.0)) return 0.0;
+    const double u = sqrt(s2) * (double)WLUT_N;
+    int j = (int)u;
+    j = j < WLUT_N - 1 ? j : WLUT_N - 1;
+    const double f = u - (double)j, a = T[j], b = T[j + 1];
+    return a + f * (b - a);
+}
 constexpr double QUALITY_SCALE = 4096.0;     // qualities are compared as integers floor(Q x 4096): ties resolve to the lowest hypothesis index
 
 // one thread per hypothesis
@@ -263,11 +277,11 @@ __global__ __launch_bounds__(64) void pose_hypotheses5_kernel(const double2* __r
         }
         fivept::group_fence<FP_L>();
 #ifdef FP_PROFILE
-        unsigned long long prof[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long prof[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         nsol = fivept::five_point<FP_L>(Eh + (long)h * 90, w, lane, prof);
         if (lane == 0 && (h & 255) == 0)      // 100 MHz counter: x 10 ns
-            printf("fivept h=%d nsol=%d: null space %llu  cubics %llu  gauss-jordan %llu  eigenvalues %llu  eigenvectors %llu  (x 10 ns)\n", h, nsol,
-                   prof[1] - prof[0], prof[2] - prof[1], prof[3] - prof[2], prof[4] - prof[3], prof[5] - prof[4]);
+            printf("fivept h=%d nsol=%d: null space %llu  cubics %llu  gauss-jordan %llu  eigenvalues %llu (hessenberg %llu, %llu QR sweeps, %llu bulge steps)  eigenvectors %llu  (x 10 ns)\n", h, nsol,
+                   prof[1] - prof[0], prof[2] - prof[1], prof[3] - prof[2], prof[4] - prof[3], prof[6] - prof[3], prof[7], prof[8], prof[5] - prof[4]);
 #else
         nsol = fivept::five_point<FP_L>(Eh + (long)h * 90, w, lane);
 #endif
@@ -275,27 +289,65 @@ __global__ __launch_bounds__(64) void pose_hypotheses5_kernel(const double2* __r
     if (lane < 10) valid[(long)h * 10 + lane] = lane < nsol ? 1 : 0;
 }
 
-// one workgroup per hypothesis: inlier count (magsac == 0) or sigma-marginalised quality floor(4096 sum_i w(r_i)) (magsac != 0)
-__global__ __launch_bounds__(256) void pose_score_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n,
-                                                         const double* __restrict__ Eh, const int* __restrict__ valid, double thr2, int magsac,
-                                                         int* __restrict__ counts) {
-    const int h = blockIdx.x;
-    __shared__ double red[4];
-    double c = 0;
-    if (valid[h]) {
-        double E[9];
-        for (int i = 0; i < 9; ++i) E[i] = Eh[(long)h * 9 + i];
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const double r2 = sampson_sq(E, x0[i].x, x0[i].y, x1[i].x, x1[i].y);
-            c += magsac ? magsac_weight(r2, thr2) : (r2 < thr2 ? 1.0 : 0.0);
-        }
+// Quality of every candidate model: inlier count (magsac == 0) or sigma-marginalised quality floor(4096 sum_i w(r_i)) (magsac != 0).
+// One workgroup per SCORE_C consecutive candidate slots; SCORE_C = 1 (measured at n = 3000: 43 us; 5 candidates per workgroup share
+// the point loads but are 79 us, 16 in a loop 164 us - the kernel lives on the parallelism of ~10 k independent workgroups, not on
+// memory traffic).  Per candidate the summation order is fixed: thread-strided partial sums, wave shuffle tree, (w0 + w1) + (w2 + w3).
+#ifndef SCORE_C_N
+#define SCORE_C_N 1
+#endif
+constexpr int SCORE_C = SCORE_C_N;
+__global__ __launch_bounds__(256) void pose_score_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n, int ncand,
+                                                         const double* __restrict__ Eh, const int* __restrict__ valid, double thr2,
+                                                         const double* __restrict__ wlut, int* __restrict__ counts) {
+    __shared__ double red[SCORE_C][4];
+    const bool magsac = wlut != nullptr;
+    const double inv_k2s2 = 1.0 / (MAGSAC_K * MAGSAC_K * thr2);
+    const int h0 = blockIdx.x * SCORE_C;
+    double E[SCORE_C][9], c[SCORE_C];
+    bool ok[SCORE_C];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < SCORE_C; ++k) {
+        ok[k] = h0 + k < ncand && valid[h0 + k < ncand ? h0 + k : 0];
+        any |= ok[k];
+        c[k] = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) E[k][i] = ok[k] ? Eh[(long)(h0 + k) * 9 + i] : 0.0;
     }
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double q = (red[0] + red[1]) + (red[2] + red[3]);
-        counts[h] = valid[h] ? (magsac ? (int)floor(q * QUALITY_SCALE) : (int)q) : -1;
+    if (any) {                                             // uniform
+        // most points of most candidates are far outside: those are recognised without the division of the Sampson distance
+        // (num^2 >= limit x den with a margin far above the rounding of either side); everything else takes the exact path
+        const double limit = (magsac ? MAGSAC_K * MAGSAC_K * thr2 : thr2) * (1.0 + 1e-9);
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const double2 p0 = x0[i], p1 = x1[i];
+#pragma unroll
+            for (int k = 0; k < SCORE_C; ++k) {
+                if (!ok[k]) continue;                      // uniform
+                const double* Ek = E[k];
+                const double a0 = Ek[0] * p0.x + Ek[1] * p0.y + Ek[2], a1 = Ek[3] * p0.x + Ek[4] * p0.y + Ek[5], a2 = Ek[6] * p0.x + Ek[7] * p0.y + Ek[8];
+                const double b0 = Ek[0] * p1.x + Ek[3] * p1.y + Ek[6], b1 = Ek[1] * p1.x + Ek[4] * p1.y + Ek[7];
+                const double num = p1.x * a0 + p1.y * a1 + a2;
+                const double den = fmax(a0 * a0 + a1 * a1 + b0 * b0 + b1 * b1, 1e-30);
+                if (num * num >= limit * den) continue;
+                const double r2 = num * num / den;
+                c[k] += magsac ? magsac_weight_lut(r2, inv_k2s2, wlut) : (r2 < thr2 ? 1.0 : 0.0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < SCORE_C; ++k) {
+            for (int o = 32; o > 0; o >>= 1) c[k] += __shfl_xor(c[k], o);
+            if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = c[k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < SCORE_C && h0 + (int)threadIdx.x < ncand) {
+        const int k = threadIdx.x;
+        bool okk = false;
+#pragma unroll
+        for (int j = 0; j < SCORE_C; ++j) okk = j == k ? ok[j] : okk;
+        const double q = any ? (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]) : 0.0;
+        counts[h0 + k] = okk ? (magsac ? (int)floor(q * QUALITY_SCALE) : (int)q) : -1;
     }
 }
 
@@ -400,13 +452,15 @@ __device__ void smallest_eigvec9_wave(const double* M, const double* v0, double*
 
 // one workgroup: first best hypothesis -> (weighted) least-squares refits kept while not worse -> decomposition of E
 __global__ __launch_bounds__(CT) void pose_consensus_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n, int H,
-                                                           const double* __restrict__ Eh, const int* __restrict__ counts, double thr2, int magsac, int nsample,
+                                                           const double* __restrict__ Eh, const int* __restrict__ counts, double thr2, const double* __restrict__ wlut, int nsample,
                                                            unsigned char* __restrict__ inl, double* __restrict__ out, int* __restrict__ good) {
     // out: [0..8] E, [9..17] R, [18..20] t, [21] inliers of E, [22] cheirality inliers, [23] ok flag, [24..32] R1, [33..41] R2, [42..44] t
     __shared__ double part[(CT / 64) * 45], red[48];
     __shared__ double Es[9], Et[9], JA[81], Fv[9], F0[9];
     __shared__ int s_best, s_cnt, s_ok;
     const int tid = threadIdx.x;
+    const bool magsac = wlut != nullptr;
+    const double inv_k2s2 = 1.0 / (MAGSAC_K * MAGSAC_K * thr2);
     if (tid < 4) good[tid] = 0;                                   // the vote counters of the cheirality kernel that follows
     {   // first best hypothesis (largest count, lowest index): strided scan + wave / workgroup reduction
         int best = -1, bi = 0x7fffffff;
@@ -431,7 +485,7 @@ __global__ __launch_bounds__(CT) void pose_consensus_kernel(const double2* __res
     // per-point weight of a model: 0 / 1 membership of the consensus set, or the sigma-marginalised weight (IRLS)
     auto weight_of = [&](const double* E, double ax, double ay, double bx, double by) {
         const double r2 = sampson_sq(E, ax, ay, bx, by);
-        return magsac ? magsac_weight(r2, thr2) : (r2 < thr2 ? 1.0 : 0.0);
+        return magsac ? magsac_weight_lut(r2, inv_k2s2, wlut) : (r2 < thr2 ? 1.0 : 0.0);
     };
     // the first CPT points of a thread stay in registers with their weight under the current model; the rest (n > 4096) is recomputed
     double pax[CPT], pay[CPT], pbx[CPT], pby[CPT], pw[CPT], pn[CPT];
@@ -645,6 +699,7 @@ struct PoseWs {
     double* Eh = nullptr;
     int *valid = nullptr, *counts = nullptr, *good = nullptr;
     unsigned char* bits = nullptr;
+    double* wlut = nullptr;            // MAGSAC++ weight table (WLUT_N + 1 doubles)
     unsigned char* pin = nullptr;      // hipHostMalloc: the float keypoints on the way in (16 n bytes), the results on the way out (384 + 2 n bytes)
     unsigned char* pin_dev = nullptr;  // the same buffer as the device sees it
 };
@@ -662,7 +717,7 @@ extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, 
     hipStream_t st = (hipStream_t)stream;
     static thread_local PoseWs ws;
     if (ws.device != device || (size_t)n > ws.cap_n || (size_t)iterations > ws.cap_h) {
-        for (void* p : {(void*)ws.x, (void*)ws.res, (void*)ws.Eh, (void*)ws.valid, (void*)ws.counts, (void*)ws.good, (void*)ws.bits})
+        for (void* p : {(void*)ws.x, (void*)ws.res, (void*)ws.Eh, (void*)ws.valid, (void*)ws.counts, (void*)ws.good, (void*)ws.bits, (void*)ws.wlut})
             if (p) (void)hipFree(p);
         if (ws.pin) (void)hipHostFree(ws.pin);
         ws = PoseWs();
@@ -671,8 +726,17 @@ extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, 
             hipMalloc(&ws.Eh, ch * 10 * 9 * sizeof(double)) != hipSuccess || hipMalloc(&ws.good, 4 * sizeof(int)) != hipSuccess ||
             hipMalloc(&ws.bits, cn) != hipSuccess || hipMalloc(&ws.valid, ch * 10 * sizeof(int)) != hipSuccess ||
             hipMalloc(&ws.counts, ch * 10 * sizeof(int)) != hipSuccess || hipHostMalloc(&ws.pin, 2 * cn * sizeof(double2)) != hipSuccess ||
-            hipHostGetDevicePointer(reinterpret_cast<void**>(&ws.pin_dev), ws.pin, 0) != hipSuccess)
+            hipHostGetDevicePointer(reinterpret_cast<void**>(&ws.pin_dev), ws.pin, 0) != hipSuccess ||
+            hipMalloc(&ws.wlut, (WLUT_N + 1) * sizeof(double)) != hipSuccess)
             return IMP_E_NOMEM;
+        {   // w at s = j / WLUT_N, i.e. r = s k sigma_max (sigma_max = 1); the last entry is the cut-off: exactly 0
+            double* T = reinterpret_cast<double*>(ws.pin);
+            for (int j = 0; j <= WLUT_N; ++j) {
+                const double sj = (double)j / (double)WLUT_N;
+                T[j] = j == WLUT_N ? 0.0 : magsac_weight(sj * sj * MAGSAC_K * MAGSAC_K, 1.0);
+            }
+            if (hipMemcpy(ws.wlut, T, (WLUT_N + 1) * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return IMP_E_HIP;
+        }
         ws.device = device; ws.cap_n = cn; ws.cap_h = ch;
     }
     double2* const x0 = ws.x;
@@ -688,10 +752,10 @@ extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, 
     const int ncand = eight ? iterations : iterations * 10;
     if (eight) hipLaunchKernelGGL(pose_hypotheses_kernel, dim3((iterations + 63) / 64), dim3(64), 0, st, x0, x1, n, iterations, seed, ws.Eh, ws.valid);
     else hipLaunchKernelGGL(pose_hypotheses5_kernel, dim3((iterations + 64 / FP_L - 1) / (64 / FP_L)), dim3(64), 0, st, x0, x1, n, iterations, seed, ws.Eh, ws.valid);
-    hipLaunchKernelGGL(pose_score_kernel, dim3(ncand), dim3(256), 0, st, x0, x1, n, ws.Eh, ws.valid, thr * thr, flags & 1, ws.counts);
+    hipLaunchKernelGGL(pose_score_kernel, dim3((ncand + SCORE_C - 1) / SCORE_C), dim3(256), 0, st, x0, x1, n, ncand, ws.Eh, ws.valid, thr * thr, (flags & 1) ? ws.wlut : nullptr, ws.counts);
     // the cheirality step of the reference normalises with K = (K0 + K1) / 2 (eval/pose_estimation.py:29-33): with K0 == K1 (every
     // caller in the repo) these are the coordinates above; a caller with two different cameras gets per-camera normalisation
-    hipLaunchKernelGGL(pose_consensus_kernel, dim3(1), dim3(CT), 0, st, x0, x1, n, ncand, ws.Eh, ws.counts, thr * thr, flags & 1, eight ? 8 : 5, inl, dout, ws.good);
+    hipLaunchKernelGGL(pose_consensus_kernel, dim3(1), dim3(CT), 0, st, x0, x1, n, ncand, ws.Eh, ws.counts, thr * thr, (flags & 1) ? ws.wlut : nullptr, eight ? 8 : 5, inl, dout, ws.good);
     hipLaunchKernelGGL(pose_cheirality_kernel, dim3((4 * n + 255) / 256), dim3(256), 0, st, x0, x1, n, dout, inl, 1000.0, ws.bits, ws.good);
     hipLaunchKernelGGL(pose_vote_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, ws.good, ws.bits, inl, refmask, dout);
     // one read-back: the 24 result doubles, the reference-semantics mask and the geometric mask

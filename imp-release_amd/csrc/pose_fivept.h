@@ -33,6 +33,14 @@
 #define FP_LOOP
 #endif
 
+#if defined(FP_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define FP_STAMP(k) prof[k] = wall_clock64()
+#define FP_COUNT(k) prof[k] += 1
+#else
+#define FP_STAMP(k)
+#define FP_COUNT(k)
+#endif
+
 namespace fivept {
 
 // Scratch of one solve (LDS on the GPU): 8240 bytes
@@ -70,6 +78,18 @@ template <int L> FP_HD void group_argmax(double& v, int& key) {
         }
     }
 #endif
+}
+
+// the value lane `src` of the group holds (src is the same on every lane of the group)
+template <int L> FP_HD double group_bcast(double v, int src) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (L == 64) {                                         // the group is the wave: src is wave-uniform, v_readlane needs no LDS round trip
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+        return __hiloint2double(hi, lo);
+    }
+    if (L > 1) return __shfl(v, src, L);
+#endif
+    return v;
 }
 
 // slot tables of the polynomial products (monomial orders: linear [x, y, z, 1]; quadratic [x^2, xy, xz, y^2, yz, z^2, x, y, z, 1];
@@ -187,7 +207,8 @@ FP_HD bool gauss_jordan_10x20(double (&A)[10][20], int lane) {
 // eigenvalue needs more than 60 iterations.  The arithmetic is the published one, element for element; the row / column loops are
 // dealt to the lanes, everything else is computed by every lane of the group (identical values).
 template <int L>
-FP_HD bool eig_real_nonsym(double (&a)[11][11], double* wr, double* wi, int lane) {
+FP_HD bool eig_real_nonsym(double (&a)[11][11], double* wr, double* wi, int lane, unsigned long long* prof = nullptr) {
+    (void)prof;
     constexpr int n = 10;
     FP_LOOP for (int m = 2; m < n; ++m) {
         double best = 0.0;
@@ -224,15 +245,24 @@ FP_HD bool eig_real_nonsym(double (&a)[11][11], double* wr, double* wi, int lane
     double anorm = 0.0;
     for (int i = 1; i <= n; ++i)
         for (int j = (i - 1 > 1 ? i - 1 : 1); j <= n; ++j) anorm += fabs(a[i][j]);
+    FP_STAMP(6);
     int nn = n;
-    double t = 0.0, p = 0.0, q = 0.0, r = 0.0, s, x, y, z, w, u, v;
+    double t = 0.0, p = 0.0, q = 0.0, r = 0.0, s, x, y, z, w;
     while (nn >= 1) {
         int its = 0, l;
         do {
-            for (l = nn; l >= 2; --l) {
-                s = fabs(a[l - 1][l - 1]) + fabs(a[l][l]);
-                if (s == 0.0) s = anorm;
-                if (fabs(a[l][l - 1]) + s == s) { a[l][l - 1] = 0.0; break; }
+            {   // the largest l in [2, nn] with a negligible subdiagonal element a[l][l-1], else 1: the candidates are tested by the lanes
+                double hit = 0.0;
+                int key = 1;
+                FP_LOOP for (int ll = 2 + lane; ll <= nn; ll += L) {
+                    double ss = fabs(a[ll - 1][ll - 1]) + fabs(a[ll][ll]);
+                    if (ss == 0.0) ss = anorm;
+                    if (fabs(a[ll][ll - 1]) + ss == ss) { hit = (double)ll; key = ll; }
+                }
+                group_argmax<L>(hit, key);
+                l = key;
+                if (l >= 2) a[l][l - 1] = 0.0;
+                group_fence<L>();
             }
             x = a[nn][nn];
             if (l == nn) {
@@ -267,33 +297,53 @@ FP_HD bool eig_real_nonsym(double (&a)[11][11], double* wr, double* wi, int lane
                         w = -0.4375 * s * s;
                     }
                     ++its;
+                    FP_COUNT(7);
                     int m;
-                    for (m = nn - 2; m >= l; --m) {
+                    {   // start row of the double-shift sweep: the largest m in (l, nn - 2] whose subdiagonal coupling is negligible, else l;
+                        // every candidate m with its own (p, q, r) on a lane, the winner's values broadcast
+                        double hit = -1.0, pm = 0.0, qm = 0.0, rm = 0.0;
+                        int key = l;
+                        FP_LOOP for (int mm = l + lane; mm <= nn - 2; mm += L) {
+                            const double zz = a[mm][mm];
+                            double rr = x - zz, ss = y - zz;
+                            double pp = (rr * ss - w) / a[mm + 1][mm] + a[mm][mm + 1];
+                            double qq = a[mm + 1][mm + 1] - zz - rr - ss;
+                            rr = a[mm + 2][mm + 1];
+                            ss = fabs(pp) + fabs(qq) + fabs(rr);
+                            pp /= ss; qq /= ss; rr /= ss;
+                            bool take = mm == l;
+                            if (!take) {
+                                const double uu = fabs(a[mm][mm - 1]) * (fabs(qq) + fabs(rr));
+                                const double vv = fabs(pp) * (fabs(a[mm - 1][mm - 1]) + fabs(zz) + fabs(a[mm + 1][mm + 1]));
+                                take = uu + vv == vv;
+                            }
+                            if (take) { hit = (double)mm; key = mm; pm = pp; qm = qq; rm = rr; }
+                        }
+                        group_argmax<L>(hit, key);
+                        m = key;
+                        const int owner = (m - l) % L;
+                        p = group_bcast<L>(pm, owner); q = group_bcast<L>(qm, owner); r = group_bcast<L>(rm, owner);
                         z = a[m][m];
-                        r = x - z;
-                        s = y - z;
-                        p = (r * s - w) / a[m + 1][m] + a[m][m + 1];
-                        q = a[m + 1][m + 1] - z - r - s;
-                        r = a[m + 2][m + 1];
-                        s = fabs(p) + fabs(q) + fabs(r);
-                        p /= s; q /= s; r /= s;
-                        if (m == l) break;
-                        u = fabs(a[m][m - 1]) * (fabs(q) + fabs(r));
-                        v = fabs(p) * (fabs(a[m - 1][m - 1]) + fabs(z) + fabs(a[m + 1][m + 1]));
-                        if (u + v == v) break;
                     }
                     for (int i = m + 2; i <= nn; ++i) {
                         a[i][i - 2] = 0.0;
                         if (i != m + 2) a[i][i - 3] = 0.0;
                     }
+                    double pn = 0.0, qn = 0.0, rn = 0.0;               // the bulge column the next step starts from, taken from the lanes that wrote it
+                    bool have_next = false;
                     for (int k = m; k <= nn - 1; ++k) {
                         if (k != m) {
-                            p = a[k][k - 1];
-                            q = a[k + 1][k - 1];
-                            r = 0.0;
-                            if (k != nn - 1) r = a[k + 2][k - 1];
-                            if ((x = fabs(p) + fabs(q) + fabs(r)) != 0.0) { p /= x; q /= x; r /= x; }
+                            if (have_next) { p = pn; q = qn; r = rn; }
+                            else {
+                                p = a[k][k - 1];
+                                q = a[k + 1][k - 1];
+                                r = 0.0;
+                                if (k != nn - 1) r = a[k + 2][k - 1];
+                            }
+                            if ((x = fabs(p) + fabs(q) + fabs(r)) != 0.0) { const double ix = 1.0 / x; p *= ix; q *= ix; r *= ix; }
                         }
+                        have_next = false;
+                        FP_COUNT(8);
                         const double nrm = sqrt(p * p + q * q + r * r);
                         s = p >= 0.0 ? nrm : -nrm;
                         if (s != 0.0) {
@@ -303,8 +353,11 @@ FP_HD bool eig_real_nonsym(double (&a)[11][11], double* wr, double* wi, int lane
                                 a[k][k - 1] = -s * x;
                             }
                             p += s;
-                            x = p / s; y = q / s; z = r / s;
-                            q /= p; r /= p;
+                            {   // two reciprocals instead of five divisions (a division is ~12 dependent instructions)
+                                const double is = 1.0 / s, ip = 1.0 / p;
+                                x = p * is; y = q * is; z = r * is;
+                                q *= ip; r *= ip;
+                            }
                             const bool three = k != nn - 1;
                             group_fence<L>();
                             FP_LOOP for (int j = k + lane; j <= nn; j += L) {                 // row modification
@@ -315,13 +368,22 @@ FP_HD bool eig_real_nonsym(double (&a)[11][11], double* wr, double* wi, int lane
                             }
                             group_fence<L>();
                             const int mmin = nn < k + 3 ? nn : k + 3;
+                            double mine = 0.0;                                               // this lane's new a[i][k] (a lane has at most one row: mmin - l < L)
                             FP_LOOP for (int i = l + lane; i <= mmin; i += L) {               // column modification
                                 double pp = x * a[i][k] + y * a[i][k + 1];
                                 if (three) { pp += z * a[i][k + 2]; a[i][k + 2] -= pp * r; }
                                 a[i][k + 1] -= pp * q;
-                                a[i][k] -= pp;
+                                const double nv = a[i][k] - pp;
+                                a[i][k] = nv;
+                                if (L > 1) mine = nv;
                             }
                             group_fence<L>();
+                            if (L > 1 && k + 1 <= nn - 1) {                                  // next step's p, q, r = a[k+1 .. k+3][k]
+                                pn = group_bcast<L>(mine, (k + 1 - l) % L);
+                                qn = group_bcast<L>(mine, (k + 2 - l) % L);
+                                rn = k + 1 != nn - 1 ? group_bcast<L>(mine, (k + 3 - l) % L) : 0.0;
+                                have_next = true;
+                            }
                         }
                     }
                 }
@@ -397,11 +459,6 @@ FP_HD bool solve_yz(const double (&A)[10][20], double (&G)[6][6], double lam, do
     return isfinite(yy) && isfinite(zz);
 }
 
-#if defined(FP_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-#define FP_STAMP(k) prof[k] = wall_clock64()
-#else
-#define FP_STAMP(k)
-#endif
 
 // w.pts: 5 normalised correspondences (x1h^T E x0h = 0), written by the caller (all lanes of the group see them).  Writes up to 10
 // essential matrices (row-major, Frobenius norm 1; Eout [10][9]) in ascending order of the eigenvalue and returns their number (the same
@@ -462,7 +519,7 @@ FP_HD int five_point(double* Eout, Work& w, int lane, unsigned long long* prof =
         w.H[i + 1][j + 1] = i < 6 ? -w.A[i][10 + j] : (unit ? 1.0 : 0.0);
     }
     group_fence<L>();
-    if (!eig_real_nonsym<L>(w.H, w.wr, w.wi, lane)) return 0;
+    if (!eig_real_nonsym<L>(w.H, w.wr, w.wi, lane, prof)) return 0;
     FP_STAMP(4);
     // the real eigenvalues in ascending order, in place: wr[0 .. nl) (step i writes below index i and reads index i and above); every lane
     int nl = 0;

@@ -265,13 +265,41 @@ def _gamma_u_3_2(x):
     return 0.88622692545275801 * erfc(rx) + rx * np.exp(-x)
 
 
-def magsac_weight(r2, sigma_max2):
+def magsac_weight_exact(r2, sigma_max2):
     """MAGSAC++ (Barath et al., CVPR 2020) sigma-marginalised weight of a squared residual, normalised to w(0) = 1: noise scale uniform
     on (0, sigma_max], residuals chi-distributed with 4 degrees of freedom, inlier of scale sigma while r < 3.64 sigma (csrc/pose.hip)"""
     r2 = np.asarray(r2, dtype=np.float64)
     gk = _gamma_u_3_2(0.5 * MAGSAC_K ** 2)
     w = (_gamma_u_3_2(0.5 * r2 / sigma_max2) - gk) / (0.88622692545275801 - gk)
     return np.where(r2 < MAGSAC_K ** 2 * sigma_max2, w, 0.0)
+
+
+WLUT_N = 2048
+_WLUT = None
+
+
+def _wlut():
+    """the table of csrc/pose.hip (magsac_weight_lut): w at s = r / (k sigma_max) = j / WLUT_N; the last entry (the cut-off) is exactly 0"""
+    global _WLUT
+    if _WLUT is None:
+        sj = np.arange(WLUT_N + 1, dtype=np.float64) / WLUT_N
+        _WLUT = magsac_weight_exact(sj * sj * MAGSAC_K * MAGSAC_K, 1.0)
+        _WLUT[WLUT_N] = 0.0
+    return _WLUT
+
+
+def magsac_weight(r2, sigma_max2):
+    """the weight the kernels use: magsac_weight_exact tabulated in s = r / (k sigma_max) (WLUT_N intervals, linear interpolation; the
+    published implementation tabulates the incomplete gamma function too) - same table, same arithmetic as csrc/pose.hip"""
+    T = _wlut()
+    r2 = np.asarray(r2, dtype=np.float64)
+    s2 = r2 * (1.0 / (MAGSAC_K * MAGSAC_K * sigma_max2))
+    inside = s2 < 1.0
+    u = np.sqrt(np.where(inside, s2, 0.0)) * float(WLUT_N)
+    j = np.minimum(u.astype(np.int64), WLUT_N - 1)
+    f = u - j
+    w = T[j] + f * (T[j + 1] - T[j])
+    return np.where(inside, w, 0.0)
 
 
 def _weighted_essential(x0, x1, w):

@@ -64,8 +64,11 @@ def test_magsac_weight_function():
     assert np.allclose(po._gamma_u_3_2(x), gammaincc(1.5, x) * gamma(1.5), atol=1e-12)
     s2 = 0.002 ** 2
     r = np.linspace(0, 4.0, 200) * 0.002
-    w = po.magsac_weight(r ** 2, s2)
-    assert abs(w[0] - 1.0) < 1e-12 and (np.diff(w) <= 1e-15).all() and (w[r >= 3.64 * 0.002] == 0).all() and w[r < 3.6 * 0.002].min() > 0
+    for fn in (po.magsac_weight_exact, po.magsac_weight):       # the closed form, and the table the kernels (and the twin) read
+        w = fn(r ** 2, s2)
+        assert abs(w[0] - 1.0) < 1e-12 and (np.diff(w) <= 1e-15).all() and (w[r >= 3.64 * 0.002] == 0).all() and w[r < 3.6 * 0.002].min() > 0
+    rr = np.random.default_rng(0).uniform(0, 3.7, 20000) * 0.002
+    assert np.abs(po.magsac_weight(rr ** 2, s2) - po.magsac_weight_exact(rr ** 2, s2)).max() < 1e-6
 
 
 def test_five_point_solver_contains_the_true_essential_matrix():
