@@ -179,10 +179,12 @@ def batch1_latencies(dev, args):
         from imp_release_amd import eval_loop, pose as gpose
         n_eval, n_distinct, nk = (1000, 64, 2048) if not args.quick_c5 else (48, 16, 2048)
         host_pairs = [synthetic.make_two_view_pair(nk, nk - 37, seed=7000 + i) for i in range(n_distinct)]
+        UP = ('keypoints0', 'keypoints1', 'scores0', 'scores1', 'descriptors0', 'descriptors1')
+        pinned = [{k: torch.from_numpy(pr[k]).pin_memory() for k in UP} for pr in host_pairs]      # a loader's pinned staging buffers
 
         def provider(pid):
             pr = host_pairs[pid % n_distinct]
-            dd = {k: torch.from_numpy(pr[k]).to(dev) for k in ('keypoints0', 'keypoints1', 'scores0', 'scores1', 'descriptors0', 'descriptors1')}
+            dd = {k: pinned[pid % n_distinct][k].to(dev, non_blocking=True) for k in UP}           # six async uploads on the worker's stream
             dd['image0'] = dd['image1'] = torch.empty(pr['image_shape'], device='meta')
             dd['pts0_cpu'], dd['pts1_cpu'] = pr['keypoints0'][0], pr['keypoints1'][0]
             dd.update({k: pr[k] for k in ('K0', 'K1', 'T_0to1', 'E')})
