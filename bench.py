@@ -222,8 +222,10 @@ def main():
         return
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    # defaults: 40 timed steps after 10 untimed ones (0.2 s of GPU time).  A 3-step warm-up (12 ms) ends while the clocks are still settling and
+    # a 20-step region (80 ms) spreads +-4 % from run to run on one box (profiles/r03/README.md)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--kpts', type=int, default=2048)
     ap.add_argument('--pairs-per-gpu', type=int, default=4)
     ap.add_argument('--iters', type=int, default=9)
