@@ -344,6 +344,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_f16x3_kernel(const AttnPa
 #define PP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #ifdef PP_PROFILE     // tools/probe/attn_probe.hip: per-wave cycle counts of the phases of workgroup 0
 __device__ unsigned long long pp_prof[8][8];
+__device__ unsigned long long pp_span[8][3];    // per wave of workgroup 0: prologue, key loop, epilogue
 #define PP_CLK(i) { const unsigned long long c_ = __builtin_readcyclecounter(); prof[i] += c_ - tlast; tlast = c_; }
 #else
 #define PP_CLK(i)
@@ -375,6 +376,9 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     constexpr int LK = KT * DH / 4 / NT;         // float4 of K (and of V) per thread and tile: 2 / 1
     constexpr float P_SUM_LIMIT = 16384.f;       // per-lane partial row sum that forces a reference update
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef PP_PROFILE
+    const unsigned long long t_entry = __builtin_readcyclecounter();
+#endif
     float* Ks = smem;                           // [4][KT][KROW]
     float* Vs = Ks + 4 * KT * KROW;             // [4][KT][VROW]   V stays key-major: the PV operand is read transposed
     float* Bs = Vs + 4 * KT * VROW;             // [4][KT]
@@ -597,6 +601,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 #ifdef PP_PROFILE
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_readcyclecounter();
+    const unsigned long long t_loop = tlast;
 #endif
     auto tile_step = [&](int t, f32x4 (&rk)[LK], f32x4 (&rv)[LK], unsigned char& rb, f32x4 (&rk2)[LK], f32x4 (&rv2)[LK], unsigned char& rb2) {
         PP_CLK(7);
@@ -674,6 +679,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     }
     pv_mfmas((nt - 1) & 3, -1);
 #ifdef PP_PROFILE
+    const unsigned long long t_loop_end = __builtin_readcyclecounter();
     if (blockIdx.x == 0 && lane == 0)
         for (int i = 0; i < 8; ++i) pp_prof[wave][i] = prof[i];
 #endif
@@ -788,6 +794,12 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     }
     __syncthreads();
     store_attention_rows<DH>(p, S, b, h, q0 + wave * 32, nq, ot, LDO, lane);
+#ifdef PP_PROFILE
+    __builtin_amdgcn_s_waitcnt(0);              // the stores of this wave are out
+    if (blockIdx.x == 0 && lane == 0) {
+        pp_span[wave][0] = t_loop - t_entry; pp_span[wave][1] = t_loop_end - t_loop; pp_span[wave][2] = __builtin_readcyclecounter() - t_loop_end;
+    }
+#endif
 }
 
 template <int DH>

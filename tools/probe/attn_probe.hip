@@ -51,6 +51,10 @@ int main(int argc, char** argv) {
     for (int w = 0; w < 8; ++w)
         printf("  wave %d: X %6.0f  wait %6.0f  softmax %6.0f  stage %6.0f  wait %6.0f  other %6.0f\n", w, (double)prof[w][0] / nt,
                (double)prof[w][1] / nt, (double)prof[w][2] / nt, (double)prof[w][3] / nt, (double)prof[w][4] / nt, (double)prof[w][7] / nt);
+    unsigned long long span[8][3];
+    CK(hipMemcpyFromSymbol(span, HIP_SYMBOL(pp_span), sizeof span));
+    printf("per wave of workgroup 0 (cycles): prologue (Q tile, first staged tiles, phase offset)  key loop  epilogue (normalise, transpose, store)\n");
+    for (int w = 0; w < 8; ++w) printf("  wave %d: prologue %7llu  loop %8llu  epilogue %7llu\n", w, span[w][0], span[w][1], span[w][2]);
 #endif
     float chk = 0; std::vector<float> ho((size_t)B * n * D);
     CK(hipMemcpy(ho.data(), o0, ho.size() * 4, hipMemcpyDeviceToHost));
