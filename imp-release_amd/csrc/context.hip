@@ -77,7 +77,9 @@ struct imp_ctx {
     int num_cus = 0;
     float *xpart = nullptr, *xv = nullptr, *xmax = nullptr;
     unsigned xtag = 0;       // tag base of the next resident launch (tags must never repeat on the exchange buffers)
-    int* xstatus = nullptr;                        // device: [0] time-out flag, [4..11] per-XCC ticket counters of the LOCAL launches
+    int ot_graph = 1;
+    int* xstatus = nullptr;                        // device, 32 words: [0] time-out flag, [4..11] per-XCC ticket counters of the LOCAL launches;
+                                                   //   launches recorded into a hipGraph: [16] tag base, [17] ticket base, [18] workgroups done, [20..27] their tickets
     int* xstatus_host = nullptr;                   // the same flag in mapped host memory: read at every entry without synchronising
     int* xstatus_hostdev = nullptr;                //   its device address
     int* range_host = nullptr;                     // word 1 of the same page: a match kernel saw non-finite scores (IMP_E_RANGE)
@@ -663,8 +665,9 @@ int ensure_resident_buffers(imp_ctx* c, int batch) {
         if (!rc) HIP_TRY(hipMemset(c->xpart, 0, 2 * wgs * kResidentMaxLdx * sizeof(float)));     // tag 0 = never written
         if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xmax, 4 * wgs * kResidentMaxLdx);
         if (!rc) HIP_TRY(hipMemset(c->xmax, 0, 4 * wgs * kResidentMaxLdx * sizeof(float)));
-        if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xstatus, 16);
-        if (!rc) HIP_TRY(hipMemset(c->xstatus, 0, 64));
+        if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xstatus, 32);
+        if (!rc) HIP_TRY(hipMemset(c->xstatus, 0, 128));
+        if (!rc) { const unsigned graph_tags = 0x80000000u; HIP_TRY(hipMemcpy(c->xstatus + 16, &graph_tags, 4, hipMemcpyHostToDevice)); }   // graph launches tag in the upper half
         c->ticket_base = 0;
         if (!rc) HIP_TRY(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
         if (!rc) HIP_TRY(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
@@ -685,7 +688,7 @@ int ensure_resident_buffers(imp_ctx* c, int batch) {
 // wrap (after ~20 million launches) the buffers are cleared and the count restarts.
 unsigned resident_tags(imp_ctx* c, int iterations) {
     const unsigned need = 3u * (unsigned)iterations + 4u;
-    if (c->xtag > 0xFFFFFFFFu - need - 8u) {
+    if (c->xtag > 0x7FFFFFFFu - need - 8u) {           // (the upper half of the tag space belongs to launches replayed from hipGraphs)
         (void)hipDeviceSynchronize();
         const size_t wgs = (size_t)c->num_cus;
         (void)hipMemset(c->xpart, 0, 2 * wgs * kResidentMaxLdx * sizeof(float));
@@ -733,6 +736,7 @@ int resident_health(imp_ctx* c) {
     if (!st) return IMP_OK;
     (void)hipDeviceSynchronize();
     (void)hipMemset(c->xstatus, 0, 64);
+    (void)hipMemset(c->xstatus + 17, 0, 44);           // graph launches: ticket base, done counter, tickets (their tag base [16] keeps counting)
     (void)hipDeviceSynchronize();
     *static_cast<volatile int*>(c->xstatus_host) = 0;
     c->ticket_base = 0;
@@ -797,11 +801,38 @@ int run_score_resident_launch(imp_ctx* c, int batch, int b0, int nb, int n0, int
     return IMP_OK;
 }
 
+// A resident launch recorded into a hipGraph: on the capturing stream itself (no lane: the replay knows no host mutex), with the tag and
+// ticket bases in device memory (OtResidentParams::dev_base) so that every replay exchanges under fresh tags.  Nothing may be allocated
+// or synchronised under capture: the buffers must exist (one ordinary call before the capture), else the streaming kernels are recorded.
+// A graph that holds such a launch must not be replayed while another resident launch of the process runs (another context, another
+// graph): nothing serialises them, a collision shows as a time-out (NaN outputs, IMP_E_RESIDENT at the next entry point) - detected, not prevented.
+int run_score_resident_graph(imp_ctx* c, int batch, int n0, int n1, const float* dist, float bin, int iterations, float* scores,
+                             bool want_max, bool want_uv, hipStream_t st) {
+    if (!c->xpart || batch > c->xcap_b || c->ot_degrade >= 2 || c->ot_graph == 0) return 1;
+    int nch, rpw, G, local;
+    if (!plan_resident(c, batch, n0, n1, c->num_cus, &nch, &rpw, &G, &local)) return 1;
+    OtResidentParams p;
+    memset(&p, 0, sizeof p);
+    p.dist = dist; p.B = batch; p.n0 = n0; p.n1 = n1; p.T = iterations; p.G = G; p.bin = bin;
+    p.xpart = c->xpart; p.xv = c->xv; p.xmax = c->xmax; p.status = c->xstatus;
+    p.local = local; p.xhalf = c->xhalf;
+    p.host_status = c->xstatus_hostdev;
+    p.dev_base = reinterpret_cast<unsigned*>(c->xstatus) + 16;
+    p.xcc_tickets = reinterpret_cast<unsigned*>(c->xstatus) + 20;
+    p.fake_placement = c->ot_fake;
+    if (want_uv) { p.ldu = (n0 + 1 + 3) & ~3; p.ldv = (n1 + 1 + 3) & ~3; p.u = c->ot.u; p.v = c->ot.v; }
+    p.scores = scores;
+    if (want_max) { p.max0 = c->max0; p.arg0 = c->arg0; p.max1 = c->max1; p.arg1 = c->arg1; }
+    HIP_TRY(launch_ot_resident(p, nch, rpw, st));
+    return IMP_OK;
+}
+
 int run_score_resident(imp_ctx* c, int batch, int n0, int n1, const float* dist, float bin, int iterations, float* scores,
                        bool want_max, bool want_uv, hipStream_t st) {
     if (!c->ot_resident) return 1;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return 1;   // graphs: streaming path
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) return 1;
+    if (cap != hipStreamCaptureStatusNone) return run_score_resident_graph(c, batch, n0, n1, dist, bin, iterations, scores, want_max, want_uv, st);
     int rc = ensure_resident_buffers(c, batch);
     if (rc) return rc;
     for (;;) {
@@ -899,6 +930,7 @@ int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     { const char* e = getenv("IMP_OT_LOCAL"); c->ot_local = (e && atoi(e) == 0) ? 0 : 1; }
     { const char* e = getenv("IMP_OT_HIER"); c->ot_hier = (e && atoi(e) == 0) ? 0 : 1; }
     { const char* e = getenv("IMP_OT_VERIFY"); c->ot_verify = (e && atoi(e) != 0) ? 1 : 0; }
+    { const char* e = getenv("IMP_OT_GRAPH"); c->ot_graph = (e && atoi(e) == 0) ? 0 : 1; }      // 0: hipGraph captures record the streaming Sinkhorn (round 2 / 3)
     { const char* e = getenv("IMP_OT_FAKE_PLACEMENT"); c->ot_fake = (e && atoi(e) != 0) ? 1 : 0; }
     { const char* e = getenv("IMP_GEMM_WF"); c->use_wf = e ? atoi(e) : 1; }     // 0 off, 1 default (large launches), 2 always
     { const char* e = getenv("IMP_WF_CHAIN"); c->wf_chain = e ? atoi(e) : 1; }

@@ -211,6 +211,9 @@ struct OtResidentParams {
     int* host_status;         // the same word in mapped host memory (read by the library without synchronising), or null
     unsigned* xcc_tickets;    // local != 0: [8] per-XCC ticket counters; a launch adds its per-XCC share to each of them
     unsigned ticket_base;     //   value of the counters before this launch
+    unsigned* dev_base;       // launches recorded into a hipGraph: {tag base, ticket base, workgroups done} in DEVICE memory - a replay must not
+                              //   reuse its tags, so the launch takes both bases from here and its last workgroup advances them (tag_base /
+                              //   ticket_base above are ignored); null for ordinary launches
     int fake_placement;       // TEST HOOK (IMP_OT_FAKE_PLACEMENT=1): workgroups lie about the XCC they run on
     unsigned long long* prof; // optional [6]: phase cycle counts of workgroup 0 (probe), null in the product
     int local;                // 1: XCD-local launch: every pair's G <= 32 workgroups on one XCD (plain stores, L2-served polls);

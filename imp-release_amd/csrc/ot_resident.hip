@@ -173,6 +173,26 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = p.G;
+    // tag / ticket bases: launch parameters, or - for a launch that lives in a hipGraph and is replayed with the same parameters - two
+    // device words that the LAST workgroup of every launch advances (every workgroup has read them by then: it reads them before it counts itself done)
+    unsigned tag_base = p.tag_base, ticket_base = p.ticket_base;
+    if (p.dev_base) {
+        tag_base = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p.dev_base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        ticket_base = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p.dev_base + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    auto leave = [&]() {                       // every exit of the kernel, workgroup-uniform
+        if (p.dev_base && tid == 0) {
+            const unsigned done = __hip_atomic_fetch_add(p.dev_base + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (done == gridDim.x - 1) {
+                unsigned nb = tag_base + 3u * (unsigned)p.T + 4u;
+                if (nb > 0xFFFFF000u) nb = 0x80000000u;                    // graph launches tag in the upper half of the 32-bit space
+                const unsigned share = LOCAL == 1 ? (unsigned)(G * ((p.B + 7) >> 3)) : (LOCAL == 2 ? (unsigned)(G >> 1) : 0u);
+                __hip_atomic_store(p.dev_base, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.dev_base + 1, ticket_base + share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.dev_base + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
     int b, g, half = 0, H = G;                 // H workgroups exchange through one L2; this one is number gl = g - half * H of them
     if (LOCAL) {
         // the XCC this workgroup really runs on, and its ticket among the workgroups of the launch that landed there
@@ -182,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             if (p.fake_placement) xcc = (xcc + (blockIdx.x >> 3)) & 7u;                      // TEST HOOK: lie about the placement (still balanced)
             const unsigned ticket = __hip_atomic_fetch_add(p.xcc_tickets + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_place[0] = (int)xcc;
-            s_place[1] = (int)(ticket - p.ticket_base);
+            s_place[1] = (int)(ticket - ticket_base);
         }
         __syncthreads();
         const int xcc = s_place[0], slot = s_place[1];
@@ -192,6 +212,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
                 __hip_atomic_store(p.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (p.host_status) __hip_atomic_store(p.host_status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
+            leave();
             return;
         }
         if (LOCAL == 1) {
@@ -203,7 +224,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             H = G >> 1;
             g = half * H + slot;
         }
-        if (b >= p.B) return;                  // uniform per workgroup, before any exchange
+        if (b >= p.B) { leave(); return; }     // uniform per workgroup, before any exchange
     } else {
         b = blockIdx.x / G;
         g = blockIdx.x % G;
@@ -276,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
     unsigned long long prof_acc[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long tlast = __builtin_readcyclecounter();
     for (int it = 0; it < p.T; ++it) {
-        const unsigned tag_p = p.tag_base + 3u * it + 1u, tag_h = tag_p + 1u, tag_v = tag_p + 2u;
+        const unsigned tag_p = tag_base + 3u * it + 1u, tag_h = tag_p + 1u, tag_v = tag_p + 2u;
         // ---- A: u for the own rows, column partials ---------------------------------------------------------------
         float acc[RPW];
 #pragma unroll
@@ -475,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             }
             __syncthreads();
         }
-        const unsigned tag_m = p.tag_base + 3u * p.T + 1u;
+        const unsigned tag_m = tag_base + 3u * p.T + 1u;
         const __amdgpu_buffer_rsrc_t rs_mx = make_rsrc(p.xmax + (size_t)b * G * 4 * LDX, (unsigned)((size_t)G * 2 * LDX * 8));
         for (int q = tid; q < DCOL / 4; q += 512) {
             stg4<MX_AUX>(rs_mx, g * 2 * NQ + q, *reinterpret_cast<const f32x4*>(mv + 4 * q), tag_m);
@@ -523,6 +544,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             }
         }
     }
+    leave();
 }
 
 template <int NCH, int RPW>

@@ -380,9 +380,11 @@ def test_eimp_pruning_path_at_4096():
 
 def test_fused_call_is_hip_graph_capturable():
     """imp_match_pair never synchronises or allocates once the workspace is sized: the whole pair can be captured in a HIP
-    graph and replayed.  Under capture the Sinkhorn iterations take the streaming kernels (the chip-resident kernel joins a
-    device-wide lane stream, which a capture must not pull in): bitwise equal to the eager streaming path, and equal in
-    indices / within 1e-5 in scores to the default eager path (resident kernel, another summation order)."""
+    graph and replayed.  Since round 3 a capture records the chip-resident Sinkhorn too - on the capturing stream itself, with its
+    exchange tags and XCC tickets taken from device memory and advanced by the launch's last workgroup, so that every replay
+    exchanges under fresh tags: five replays, each bitwise equal to the eager resident call, then an eager call,
+    then a replay again (both kinds of launch share the exchange buffers).  IMP_OT_GRAPH=0 keeps the round-2 behaviour (the capture
+    records the streaming kernels): bitwise equal to the eager streaming path."""
     import os
     cfg = eval_config(n_layers=3)
     sd = synthetic.make_state_dict(cfg, 'DGNNS', seed=2)
@@ -393,27 +395,44 @@ def test_fused_call_is_hip_graph_capturable():
         ms._ensure_ctx()
     finally:
         del os.environ['IMP_OT_RESIDENT']
+    os.environ['IMP_OT_GRAPH'] = '0'
+    try:
+        mg0 = make_hip_model('DGNNS', cfg, sd)
+        mg0._ensure_ctx()
+    finally:
+        del os.environ['IMP_OT_GRAPH']
     pair = synthetic.make_correlated_pair(300, 280, seed=9, batch=2)
     d = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
     args = (d['keypoints0'], d['scores0'], d['descriptors0'], d['keypoints1'], d['scores1'], d['descriptors1'],
             640., 480., 1.0, 20, True, 0.2)
     eager_stream = ms._ensure_ctx().match_pair(*args, want_side1=True)
-    ctx = m._ensure_ctx()
-    eager = ctx.match_pair(*args, want_side1=True)
-    out = {k: torch.zeros_like(v) for k, v in eager.items()}
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        ctx.match_pair(*args, out=out)
-    for _ in range(2):
-        for v in out.values():
-            v.zero_()
-        g.replay()
+    for model, want, what in ((m, None, 'resident'), (mg0, eager_stream, 'streaming')):
+        ctx = model._ensure_ctx()
+        eager = ctx.match_pair(*args, want_side1=True)
+        want = eager if want is None else want
+        out = {k: torch.zeros_like(v) for k, v in eager.items()}
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            ctx.match_pair(*args, out=out)
+
+        def replay_and_check():
+            for v in out.values():
+                v.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            for k in want:
+                assert torch.equal(out[k], want[k]), (what, k)
+        for _ in range(5):
+            replay_and_check()
+        again = ctx.match_pair(*args, want_side1=True)              # an ordinary launch between replays
         torch.cuda.synchronize()
         for k in eager:
-            assert torch.equal(out[k], eager_stream[k]), k
-        compare_matches(_cpu(out['indices0']), _cpu(out['mscores0']), _cpu(eager['indices0']).numpy(),
-                        _cpu(eager['mscores0']).numpy(), 0.2, 1e-5, 'graph replay (streaming) vs eager (resident)')
+            assert torch.equal(again[k], eager[k]), (what, k)
+        replay_and_check()
+        assert ctx.resident_health(raise_on_timeout=False) is not False
+        compare_matches(_cpu(out['indices0']), _cpu(out['mscores0']), _cpu(eager_stream['indices0']).numpy(),
+                        _cpu(eager_stream['mscores0']).numpy(), 0.2, 1e-5, f'graph replay ({what}) vs eager streaming')
 
 
 WF_FIXTURES = ['gm_l3_alliters_b2', 'gm_l3_bigmean', 'gm_l9_t100_ragged', 'dgnns_l5_alliters', 'adagmn_masked_l9']
