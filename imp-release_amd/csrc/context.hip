@@ -100,7 +100,7 @@ struct imp_ctx {
     float* xhalf = nullptr;  // resident Sinkhorn, two XCDs per pair: the half sums the XCDs swap
     int ot_hier = 1;         // two-XCDs-per-pair resident launches (hierarchical column sums) when a pair fits 64 CUs and B <= 4 (IMP_OT_HIER=0 disables)
     int ot_local = 1;        // XCD-local resident Sinkhorn launches when a pair fits one XCD (IMP_OT_LOCAL=0 disables)
-    unsigned* stat_cnt = nullptr;   // [cap_b][2] tickets of the statistics merge inside the MLP0 launch (gemm_wf.hip)
+    unsigned* stat_cnt = nullptr;   // [cap_b][2][WF_MAX_PSPLIT] tickets of the statistics merge inside the MLP0 launch (gemm_wf.hip)
     int kv_image = 1;        // IMP_KV_IMAGE=0: projections write K / V as fp32 (round-2 format) instead of the split-half image attention copies
     float* kf32[2] = {};     // per image: K of a cached attention converted back to fp32 [B][n][D] (pooling / probability readers)
     int wf_chain = 1;        // IMP_WF_CHAIN=0: never compute the next layer's projection inside the MLP3 launch
@@ -287,9 +287,9 @@ int ensure_workspace(imp_ctx* c, int batch, int n) {
         rc = dev_alloc(c, c->allocs_ws, &c->colsum[k], B * IMP_NUM_HEADS * N);
         if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->amass[k], B * N);
     }
-    if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->stat_cnt, B * 2 + 2);
+    if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->stat_cnt, (B * 2 + 2) * WF_MAX_PSPLIT);
     if (!rc) {
-        HIP_TRY(hipMemset(c->stat_cnt, 0, (B * 2 + 2) * sizeof(unsigned)));
+        HIP_TRY(hipMemset(c->stat_cnt, 0, (B * 2 + 2) * WF_MAX_PSPLIT * sizeof(unsigned)));
         HIP_TRY(hipDeviceSynchronize());              // the clear runs on the NULL stream, which the callers' streams do not wait for
     }
     if (rc) { free_pool(c->allocs_ws); return rc; }
@@ -1421,8 +1421,8 @@ int imp_op_layer_gemm(imp_ctx* c, int B, int M, int N, int K, int ksplit, const 
     const int tiles = (M + 63) / 64;
     if (stats_out) {
         HIP_TRY(hipMalloc(&part, (size_t)B * tiles * N * 2 * sizeof(float)));
-        HIP_TRY(hipMalloc(&cnt, (size_t)B * sizeof(unsigned)));
-        HIP_TRY(hipMemset(cnt, 0, (size_t)B * sizeof(unsigned)));
+        HIP_TRY(hipMalloc(&cnt, (size_t)B * WF_MAX_PSPLIT * sizeof(unsigned)));
+        HIP_TRY(hipMemset(cnt, 0, (size_t)B * WF_MAX_PSPLIT * sizeof(unsigned)));
         HIP_TRY(hipDeviceSynchronize());
     }
     WfParams p = wf_defaults();

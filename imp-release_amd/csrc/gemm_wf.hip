@@ -421,6 +421,13 @@ __global__ __launch_bounds__(512) void gemm_wf_kernel(const WfParams p, int row_
                 if (t == q) { st_sum[q] = su; st_m2[q] = m2v; st_cb[q] = cb; }
         }
         if (p.dbg & 2) { if (acc[0][0] == 123.456f) Cb[0] = acc[1][5]; continue; }
+        if (STATS && t == mine - 1) {
+            // the write-through statistics stores of this wave leave before its LAST epilogue (no load follows them any more, so they
+            // stall nothing): their acknowledgement - which the ticket below has to wait for - travels under the epilogue's stores
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q < mine) wf_store_stats(S.out_stats, b, rtile, M, N, st_cb[q], L, st_sum[q], st_m2[q]);
+        }
         wf_epilogue<SWAP, 0>(acc, tbuf, p.bias, rres, Rb != nullptr, Cb, p.ldc, row0, M, cb, L, p.dbg, nullptr, SWAP && pass * 128 >= p.kv_image_col);
 #ifdef WF_PROFILE
         { __builtin_amdgcn_s_waitcnt(0); WF_T(t2); t_k += t1 - t0; t_e += t2 - t1; }
@@ -434,31 +441,32 @@ __global__ __launch_bounds__(512) void gemm_wf_kernel(const WfParams p, int row_
 #endif
     if (STATS) {
         // ---- ticket: the last workgroup of this (pair, image) to get here turns the per-block statistics into (mean, rstd)
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (t < mine) wf_store_stats(S.out_stats, b, rtile, M, N, st_cb[t], L, st_sum[t], st_m2[t]);
         if (!S.fin_stats) return;
         __builtin_amdgcn_s_waitcnt(0);              // this wave's write-through stores are acknowledged
         __syncthreads();
         __shared__ int s_last;
         const int tiles_side = (M + WF_TM - 1) / WF_TM;
         if (tid == 0) {
-            unsigned* cnt = p.stat_cnt + b * p.nside + sidx;
+            // one ticket per (pair, image, pass group): with the column passes of a tile dealt to several workgroups (small launches) every
+            // pass group finishes the statistics of ITS columns - the merge of a launch is then psplit last-arrivers working side by side
+            // instead of one (the serial tail of a 32-tile launch was 5-6 us of 15)
+            unsigned* cnt = p.stat_cnt + (b * p.nside + sidx) * WF_MAX_PSPLIT + pgrp;
             const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = old == (unsigned)(tiles_side * psplit) - 1u;
+            s_last = old == (unsigned)tiles_side - 1u;
             if (s_last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // re-armed for the next launch
         }
         __syncthreads();
         if (!s_last) return;
         // Chan's parallel-variance merge in fp64 in the arithmetic and order of stats_finalize_kernel: 4 block groups (group g takes
         // blocks g, g + 4, ...), combined ((g0 + g1) + (g2 + g3)) through LDS.  Thread = (group, column mod 128); all loads of a
-        // round (up to 8 blocks x N / 128 columns) are issued before any is used - they are cache-bypassing and ~2 us each
+        // round (up to 8 blocks x the pass group's columns / 128) are issued before any is used - they are cache-bypassing and ~2 us each
         const float* part = S.out_stats + (long)b * tiles_side * N * 2;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, (unsigned)((size_t)tiles_side * N * 8), 0x00020000);
         double* sm = reinterpret_cast<double*>(wf_smem);              // [4 groups][3][N]: the planes are no longer needed
         const int g = tid >> 7, kk = tid & 127;
         constexpr int NR = 4;                                          // column rounds held in flight (N <= 512)
-        const int nr = N >> 7;
+        const int nr = npass;                                          // this pass group's columns: [c0, c0 + 128 nr)
+        const int c0 = pbase * 128;
         double a1[NR], a2[NR], a3[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) a1[r] = a2[r] = a3[r] = 0.0;
@@ -469,7 +477,7 @@ __global__ __launch_bounds__(512) void gemm_wf_kernel(const WfParams p, int row_
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int t = t0 + 4 * u;
-                    raw[r][u] = (r < nr && t < tiles_side) ? __builtin_amdgcn_raw_buffer_load_b64(rs, (t * N + kk + 128 * r) * 8, 0, AUX_SC1) : u32x2{0u, 0u};
+                    raw[r][u] = (r < nr && t < tiles_side) ? __builtin_amdgcn_raw_buffer_load_b64(rs, (t * N + c0 + kk + 128 * r) * 8, 0, AUX_SC1) : u32x2{0u, 0u};
                 }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(512) void gemm_wf_kernel(const WfParams p, int row_
                 sm[(g * 3 + 0) * N + k] = a1[r]; sm[(g * 3 + 1) * N + k] = a2[r]; sm[(g * 3 + 2) * N + k] = a3[r];
             }
         __syncthreads();
-        for (int k = tid; k < N; k += 512) {
+        for (int k = tid; k < 128 * nr; k += 512) {
             const double s1t = (sm[(0 * 3 + 0) * N + k] + sm[(1 * 3 + 0) * N + k]) + (sm[(2 * 3 + 0) * N + k] + sm[(3 * 3 + 0) * N + k]);
             const double m2w = (sm[(0 * 3 + 1) * N + k] + sm[(1 * 3 + 1) * N + k]) + (sm[(2 * 3 + 1) * N + k] + sm[(3 * 3 + 1) * N + k]);
             const double sqn = (sm[(0 * 3 + 2) * N + k] + sm[(1 * 3 + 2) * N + k]) + (sm[(2 * 3 + 2) * N + k] + sm[(3 * 3 + 2) * N + k]);
@@ -501,7 +509,7 @@ __global__ __launch_bounds__(512) void gemm_wf_kernel(const WfParams p, int row_
             float2 o;
             o.x = (float)mean;
             o.y = (float)(1.0 / sqrt(m2 / (double)M + (double)p.norm_eps));   // biased variance, eps inside the root (nets/layers.py:67-68)
-            reinterpret_cast<float2*>(S.fin_stats)[(long)b * N + k] = o;
+            reinterpret_cast<float2*>(S.fin_stats)[(long)b * N + c0 + k] = o;
         }
     }
 }

@@ -268,5 +268,6 @@ struct WfParams {
 hipError_t launch_gemm_wf(const WfParams& p, int batch, hipStream_t stream);
 bool gemm_wf_supported(int K, int N);
 int gemm_wf_stats_rows();
+constexpr int WF_MAX_PSPLIT = 8;      // WfParams::stat_cnt holds batch x nside x WF_MAX_PSPLIT tickets (one per pass group)
 // W [N][K] fp32 -> split-half MFMA fragments, 2 N K halves (host)
 void wf_pack(const float* W, int N, int K, _Float16* out);
