@@ -143,6 +143,21 @@ def batch1_latencies(dev, args):
         m = model_of('GM', eval_config(9, 100))
         d = data_of(1024, 1024, 5)
         out['c2_latency_ms'] = timeit(lambda: m.produce_matches(d, p=0.2, only_last=True), 20, 3)
+        # the same pair with the fused call captured once in a hipGraph and replayed (the capture keeps the chip-resident Sinkhorn)
+        try:
+            ctx = m._ensure_ctx()
+            margs = (d['keypoints0'], d['scores0'], d['descriptors0'], d['keypoints1'], d['scores1'], d['descriptors1'],
+                     float(d['image0'].shape[-1]), float(d['image0'].shape[-2]), float(m._bin(None)), 100, True, 0.2)
+            gout = ctx.match_pair(*margs)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                ctx.match_pair(*margs, out=gout)
+            out['c2_latency_graph_ms'] = timeit(graph.replay, 20, 3)
+            del graph
+        except Exception as ex:                       # noqa: BLE001 - the key is optional
+            out['c2_latency_graph_ms'] = None
+            out['c2_latency_graph_error'] = repr(ex)[:200]
         del m
         cfg = eval_config(15, 20)
         m = model_of('AdaGMN', cfg, bin_score=5.0)
@@ -209,7 +224,8 @@ def batch1_latencies(dev, args):
                           "OpenCV MAGSAC), 3 pairs in flight, H2D upload of every pair included; report = eval/eval_imp.py:213-227's numbers with the "
                           "synthetic 'matching' weights (synthetic.make_state_dict style='matching': a hand-built matcher that works on these pairs, "
                           'NOT a trained model - the numbers describe the pipeline)')
-    out['batch1_note'] = ('c2 = BASELINE configs[1] (GM, N=1024, 9 iterations, 100 Sinkhorn, batch 1, one call after the other); '
+    out['batch1_note'] = ('c2 = BASELINE configs[1] (GM, N=1024, 9 iterations, 100 Sinkhorn, batch 1, one call after the other; c2_latency_graph_ms: the fused call '
+                          'imp_match_pair captured in a hipGraph and replayed); '
                           'eimp = configs[3] (AdaGMN sliced loop from N=4096/4000, 15 iterations, 7 score+pool steps, bin_score 5, pose stubbed); '
                           'superpoint = nets/superpoint.py forward on one 480x640 image, top-1024, seeded random weights; image_pair_to_matches = '
                           'SuperPoint on both images (one call, batch 2) + GM (L=9, T=100) on the 1024 + 1024 keypoints it returns, batch 1')
