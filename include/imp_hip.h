@@ -201,7 +201,11 @@ int imp_gather_rows(imp_ctx* ctx, int batch, int n_in, int n_out, int dim, const
 /* Fused one-shot matcher = GM/DGNNS.produce_matches(data, p, only_last=True)
  * (nets/gm.py:145-247, nets/gms.py:139-258): normalise (if width>0, else kpts are already
  * normalised), encode, all GNN layers, final_proj[n_layers-1], Sinkhorn / dual-softmax, mutual matches.
- * Nothing is synchronised; outputs: indices0 int64 [B][n0], mscores0 [B][n0] (+ optional indices1,
+ * Nothing is synchronised or allocated once the workspace is sized, so the call can be recorded into a hipGraph (stream capture) and
+ * replayed: the chip-resident Sinkhorn launch is recorded too (its exchange tags live in device memory and advance with every
+ * replay; IMP_OT_GRAPH=0: the streaming kernels instead).  Such a graph must not be replayed while another resident launch of the
+ * process runs - a collision is reported like any voided resident launch (NaN scores, IMP_E_RESIDENT at the next entry point).
+ * Outputs: indices0 int64 [B][n0], mscores0 [B][n0] (+ optional indices1,
  * mscores1, scores [B][n0+1][n1+1], any of which may be NULL). */
 int imp_match_pair(imp_ctx* ctx, int batch, int n0, int n1,
                    const float* kpts0, const float* scores0, const float* desc0,
