@@ -105,6 +105,11 @@ struct imp_ctx {
     float* kf32[2] = {};     // per image: K of a cached attention converted back to fp32 [B][n][D] (pooling / probability readers)
     int wf_chain = 1;        // IMP_WF_CHAIN=0: never compute the next layer's projection inside the MLP3 launch
     long wf_chain_min_tiles = 160, wf_max_tiles = 640, wf_proj_max_tiles = 40;     // IMP_WF_CHAIN_MIN / IMP_WF_MAX / IMP_WF_PROJ_MAX
+    int wf_fused = 1;        // IMP_WF_FUSED=0: never run a layer's MLP0 -> InstanceNorm -> MLP3 (-> next projection) as ONE launch (gemm_wf.hip fused kernel)
+    long wf_fused_min_tiles = 160;   // IMP_WF_FUSED_MIN
+    int wf_fused_fake = 0;   // TEST HOOK IMP_WF_FUSED_FAKE=1: one workgroup of every fused launch withholds its statistics (forces the time-out path)
+    float *fx_rec[2] = {}, *fx_fin[2] = {};   // fused layer: statistics granules [B][tiles][512] x 16 B and (mean, rstd) granules [B][512] x 16 B per image
+    unsigned fx_tag = 0;     // tag of the last fused launch (tags never repeat on fx_rec / fx_fin)
     int use_wf = 1;          // weight-fragment GEMMs (gemm_wf.hip) for the layer convolutions when f16x3, D = 256, relu + InstanceNorm; IMP_GEMM_WF=0 disables
     float* attn_split_ws = nullptr;        // key-split scratch of the attention kernel (grown on demand, allocs_x)
     unsigned* attn_split_cnt = nullptr;
@@ -721,6 +726,34 @@ void resident_health_params(imp_ctx* c, OtResidentParams* p) {
 // IMP_E_RESIDENT so that the caller re-runs the voided batch.
 int resident_health(imp_ctx* c) {
     if (!c->xstatus_host) return IMP_OK;
+    // the resident word first: a voided launch leaves NaN maxima behind, which the match kernel also reports through the range word -
+    // that is one event (IMP_E_RESIDENT), not two
+    const int st = *static_cast<volatile int*>(c->xstatus_host);
+    if (st) {
+        (void)hipSetDevice(c->device);                     // (the caller's thread may have another device current: imp_resident_health)
+        (void)hipDeviceSynchronize();
+        (void)hipMemset(c->xstatus, 0, 64);
+        (void)hipMemset(c->xstatus + 17, 0, 44);           // graph launches: ticket base, done counter, tickets (their tag base [16] keeps counting)
+        (void)hipDeviceSynchronize();
+        *static_cast<volatile int*>(c->xstatus_host) = 0;
+        *static_cast<volatile int*>(c->range_host) = 0;    // (raised by the match kernel that met the poisoned maxima)
+        c->ticket_base = 0;
+        c->resident_timeouts += 1;
+        if (st == 3) {
+            // a fused layer launch (gemm_wf.hip gemm_wf_fused_kernel) timed out in its statistics exchange: the descriptors it wrote are NaN
+            c->wf_fused = 0;
+            return fail(IMP_E_RESIDENT, "a fused GNN-layer launch of this context timed out in its InstanceNorm statistics exchange: the results of "
+                                        "that call are void (scores NaN, no matches); the context now runs the layer's MLP as two launches - re-run the batch. "
+                                        "Every call on this context since its last health check is void");
+        }
+        const int was = c->ot_degrade;
+        c->ot_degrade = was < 2 ? was + 1 : 2;
+        return fail(IMP_E_RESIDENT, std::string("a chip-resident Sinkhorn launch of this context ") +
+                                        (st == 2 ? "was not spread evenly over the XCCs" : "timed out in an exchange") +
+                                        ": the results of that call - and of every call on this context since its last health check - are void "
+                                        "(scores NaN, no matches); the context now uses " +
+                                        (c->ot_degrade == 1 ? "the chip-wide exchange only" : "the streaming kernels") + " - re-run the batch");
+    }
     if (*static_cast<volatile int*>(c->range_host)) {
         // a match kernel of an EARLIER call met non-finite score maxima: in f16x3 mode every MFMA operand must stay inside the fp16
         // range (|x| < 65504: hi = f16(x) overflows to inf beyond it and the product turns into NaN); non-finite INPUTS look the same
@@ -732,21 +765,7 @@ int resident_health(imp_ctx* c) {
                       "(imp_set_precision(ctx, 0)) for such data"
                     : "non-finite match scores in an earlier call on this context (non-finite inputs or weights): that call's matches are void");
     }
-    const int st = *static_cast<volatile int*>(c->xstatus_host);
-    if (!st) return IMP_OK;
-    (void)hipDeviceSynchronize();
-    (void)hipMemset(c->xstatus, 0, 64);
-    (void)hipMemset(c->xstatus + 17, 0, 44);           // graph launches: ticket base, done counter, tickets (their tag base [16] keeps counting)
-    (void)hipDeviceSynchronize();
-    *static_cast<volatile int*>(c->xstatus_host) = 0;
-    c->ticket_base = 0;
-    c->resident_timeouts += 1;
-    const int was = c->ot_degrade;
-    c->ot_degrade = was < 2 ? was + 1 : 2;
-    return fail(IMP_E_RESIDENT, std::string("a chip-resident Sinkhorn launch of this context ") +
-                                    (st == 2 ? "was not spread evenly over the XCCs" : "timed out in an exchange") +
-                                    ": the results of that call are void (scores NaN); the context now uses " +
-                                    (c->ot_degrade == 1 ? "the chip-wide exchange only" : "the streaming kernels") + " - re-run the batch");
+    return IMP_OK;
 }
 
 // the resident launch on the device's lane, joined to `st` on both sides; returns IMP_OK, or >0 when not applicable
@@ -843,7 +862,8 @@ int run_score_resident(imp_ctx* c, int batch, int n0, int n1, const float* dist,
         if (rc || !c->ot_verify) return rc;
         // verified mode: wait for the launch; a voided one is re-run inside this call on the next protocol down
         HIP_TRY(hipEventSynchronize(c->ev_out));
-        if (resident_health(c) == IMP_OK) return IMP_OK;
+        const int hrc = resident_health(c);
+        if (hrc != IMP_E_RESIDENT) return hrc;                 // IMP_OK, or an event of another kind (IMP_E_RANGE of an earlier call): the caller's
     }
 }
 

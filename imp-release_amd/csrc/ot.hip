@@ -425,11 +425,14 @@ __global__ __launch_bounds__(256) void score_rowmax_kernel(const float* __restri
     const float* row = scores + ((long)b * (n0 + 1) + r) * (n1 + 1);
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int c = lane; c < n1; c += 64) {
+    bool nan = false;                     // a NaN score voids the row's maximum (torch.max propagates NaN; a voided resident Sinkhorn
+    for (int c = lane; c < n1; c += 64) { // launch poisons its rows with NaN: the matches must come out void, not plausible)
         const float val = row[c];
+        nan |= val != val;
         if (val > best) { best = val; bi = c; }
     }
     wave_argmax(best, bi);
+    if (__any(nan)) { best = __builtin_nanf(""); bi = 0x7fffffff; }
     if (lane == 0) { maxv[(long)b * n0 + r] = best; argv[(long)b * n0 + r] = bi; }
 }
 
@@ -450,6 +453,7 @@ __global__ __launch_bounds__(256) void score_colmax_part_kernel(const float* __r
         const int rend = min(n0, (chunk + 1) * COL_CHUNK);
         for (int r = chunk * COL_CHUNK + rg; r < rend; r += 4) {
             const float val = base[(long)r * (n1 + 1) + c];
+            if (val != val) { best = val; bi = 0x7fffffff; break; }      // NaN voids the column (sticky: see score_rowmax_kernel)
             if (val > best) { best = val; bi = r; }
         }
     }
@@ -459,6 +463,8 @@ __global__ __launch_bounds__(256) void score_colmax_part_kernel(const float* __r
 #pragma unroll
         for (int k = 1; k < 4; ++k) {
             const float ov = sv[k][cx]; const int oi = si[k][cx];
+            if (best != best) break;
+            if (ov != ov) { best = ov; bi = 0x7fffffff; break; }
             if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
         }
         pv[((long)b * chunks + chunk) * n1 + c] = best;
@@ -476,6 +482,7 @@ __global__ __launch_bounds__(256) void colmax_combine_kernel(const float* __rest
     for (int k = 0; k < chunks; ++k) {   // ascending row chunks: strict > keeps the first maximal row
         const float ov = pv[((long)b * chunks + k) * n1 + c];
         const int oi = pi[((long)b * chunks + k) * n1 + c];
+        if (ov != ov) { best = ov; bi = 0x7fffffff; break; }             // a NaN partial voids the column
         if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
     }
     maxv[(long)b * n1 + c] = best; argv[(long)b * n1 + c] = bi;
@@ -496,7 +503,9 @@ __global__ __launch_bounds__(256) void mutual_kernel(int n0, int n1, const float
     // such a keypoint has no match - never an out-of-range read
     // a row / column maximum of -inf: every score of that row was NaN (an MFMA operand beyond the fp16 range in f16x3 mode, or
     // non-finite inputs).  The matches come out as -1; the flag makes the library say so at its next entry (IMP_E_RANGE)
-    if (range_flag && t < n0 && m0[t] == -INFINITY) __hip_atomic_store(range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (a NaN maximum: the maxima were taken from a score TENSOR that holds NaN - the same causes, or rows poisoned by a voided resident
+    // Sinkhorn launch; the library looks at the resident word first, so a void is reported as IMP_E_RESIDENT, not as a range error)
+    if (range_flag && t < n0 && (m0[t] == -INFINITY || m0[t] != m0[t])) __hip_atomic_store(range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (t < n0) {
         const int j = a0[t];
         const bool mutual = (unsigned)j < (unsigned)n1 && a1[j] == t;

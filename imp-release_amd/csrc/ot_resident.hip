@@ -532,10 +532,15 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
     if (__syncthreads_or(dead ? 1 : 0)) {
         const float nanv = __builtin_nanf("");
         const int rend = min(n0, (g + 1) * ROWS);
-        for (int r = g * ROWS + tid; r < rend; r += 512) {
+        for (int r = g * ROWS + tid; r < rend; r += 512)
             if (want_max) { p.max0[(size_t)b * n0 + r] = nanv; p.arg0[(size_t)b * n0 + r] = 0x7fffffff; }
-            if (p.scores) p.scores[((size_t)b * (n0 + 1) + r) * (n1 + 1)] = nanv;
-        }
+        // the WHOLE own rows of the score tensor (with only the first score of a row poisoned, maxima recomputed from the
+        // tensor - imp_compute_matches after imp_compute_score - skipped the NaN and returned plausible matches from garbage)
+        if (p.scores)
+            for (int r = g * ROWS + wave; r < rend; r += 8) {
+                float* srow = p.scores + ((size_t)b * (n0 + 1) + r) * (n1 + 1);
+                for (int j = lane; j <= n1; j += 64) srow[j] = nanv;
+            }
         if (want_max) {
             const int ncq = (DCOL / 4 + G - 1) / G;
             for (int cl = tid; cl < 4 * ncq; cl += 512) {

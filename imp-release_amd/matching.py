@@ -84,10 +84,15 @@ def _loop_body(ctx, data, model, nI, match_ratio, min_kpts, error_th, stop_crite
             continue
         dist = ctx.compute_distance(it, desc0, desc1)
         for attempt in range(3):
-            pred_score = ctx.compute_score(dist, model._bin(None), model.sinkhorn_iterations, model.with_sinkhorn)
-            indices0, indices1, mscores0, mscores1 = ctx.compute_matches(pred_score, match_ratio)
-            # the one sync of this iteration: indices and scores of image 0 in a single device->host copy
-            packed = pack_matches(indices0[:1], mscores0[:1]).cpu()
+            try:
+                pred_score = ctx.compute_score(dist, model._bin(None), model.sinkhorn_iterations, model.with_sinkhorn)
+                indices0, indices1, mscores0, mscores1 = ctx.compute_matches(pred_score, match_ratio)
+                # the one sync of this iteration: indices and scores of image 0 in a single device->host copy
+                packed = pack_matches(indices0[:1], mscores0[:1]).cpu()
+            except _lib.ResidentSinkhornTimeout:
+                # the health word was already raised when compute_matches (or the copy's entry check) looked at it - e.g. an uneven
+                # spread over the XCCs is flagged at kernel start: the same event as the one caught below, the same cure
+                continue
             # the copy synchronised: a voided chip-resident Sinkhorn launch (include/imp_hip.h, IMP_E_RESIDENT) shows now; the
             # context has then already stepped down to a safer protocol and the score is simply computed again
             if ctx.resident_health(raise_on_timeout=False) is not False:

@@ -314,12 +314,14 @@ class GM(nn.Module):
 
     def _const_stats(self, dev):
         """(0, 0, 1, 1) as 0-d tensors on `dev` (the reference builds them with `torch.zeros(...) + k` on every call,
-        nets/gm.py:214-219: five tiny kernels per call here); made once per device and handed out read-only"""
-        key = str(dev)
+        nets/gm.py:214-219: five tiny kernels per call here).  The constants are kept once per device index and every call
+        hands out views of a FRESH copy (one small kernel): like the reference's, the tensors a caller receives are its own -
+        accumulating into them in place cannot reach a later call's results, nor the replicas of eval_loop.replicate"""
+        key = (dev.type, dev.index) if isinstance(dev, torch.device) else str(dev)
         cache = self.__dict__.setdefault('_const_stats_cache', {})
         if key not in cache:
-            cache[key] = tuple(torch.full((), v, device=dev) for v in (0., 0., 1., 1.))
-        return cache[key]
+            cache[key] = torch.tensor([0., 0., 1., 1.], device=dev)
+        return cache[key].clone().unbind(0)
 
     def _run_iterations(self, data, p, only_last, want_scores):
         """shared body of GM / DGNNS produce_matches: returns per-emitted-iteration lists"""

@@ -1,5 +1,7 @@
 """CPU: the oracle (oracle/imp_oracle.py) against the golden vectors captured from the imported reference
 (tools/make_golden.py).  This is the oracle's parity pin, re-checked on every run."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -29,8 +31,9 @@ def test_produce_matches_vs_reference(name):
     if 'score_rowsum' in z.files and out.get('scores'):
         s = out['scores'][-1][0]
         tol = 4 if 'bigmean' in name else 1
-        np.testing.assert_allclose(s.sum(-1).numpy(), z['score_rowsum'], atol=5e-5 * tol, rtol=0)
-        np.testing.assert_allclose(s.sum(-2).numpy(), z['score_colsum'], atol=5e-5 * tol, rtol=0)
+        # (rtol: the dustbin row / column hold N + 1 entries that sum to ~N - one fp32 ulp of 2049 is 2.4e-4)
+        np.testing.assert_allclose(s.sum(-1).numpy(), z['score_rowsum'], atol=5e-5 * tol, rtol=5e-7)
+        np.testing.assert_allclose(s.sum(-2).numpy(), z['score_colsum'], atol=5e-5 * tol, rtol=5e-7)
         np.testing.assert_allclose(s[:8, :8].numpy(), z['score_corner'], atol=2e-5 * tol, rtol=0)
 
 
@@ -56,6 +59,10 @@ def test_run_vs_reference(name):
 LOOPS = [('imp_loop_n400', False), ('eimp_loop_sliced_n1024', True), ('imp_loop_exit_n400', False),
          ('eimp_loop_uncert_exit_n1024', True), ('eimp_loop_uncert_full_n700', True),
          ('eimp_loop_trained_n1024', True)]       # trained-like weights (synthetic style='trained'): peaky attention
+# BASELINE configs[3] (N = 4096 / 4000 sliced EIMP loop, round 4): ~1.5 min of oracle CPU time, so this pin is re-checked on request
+# only (IMP_SLOW=1; tools/make_golden.py asserts the same equality whenever the fixture is generated)
+if os.environ.get('IMP_SLOW'):
+    LOOPS.append(('eimp_loop_sliced_n4096', True))
 
 
 @pytest.mark.parametrize('name,unc', LOOPS)

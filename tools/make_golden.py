@@ -451,6 +451,20 @@ def main():
                                                 call=dict(p=0.2, only_last=True)))
     case_loop('eimp_loop_trained_n1024', dict(model='AdaGMN', config=dict(), wseed=23, dseed=33, n0=1024, n1=1000, bin_score=5.0,
                                               style='trained'), True)
+    # (6c) round 4: the HEADLINE sizes pinned to the reference itself instead of to the oracle - BASELINE.json's metric
+    # configuration (GM, N = M = 2048, 9 iterations, 100 Sinkhorn) on the exact seeds of tests/test_gpu_parity.py's full-size tests
+    # (batch 2 / seed 31, the bench's batch of four / seed 77, four ragged pairs with their own weights), one trained-style pair, and
+    # BASELINE configs[3]: the sliced EIMP loop from N = 4096 / 4000
+    case_produce('gm_l9_t100_n2048_b2', dict(model='GM', config=dict(n_layers=9, sinkhorn_iterations=100), wseed=1, dseed=31,
+                                             n0=2048, n1=2048, batch=2, call=dict(p=0.2, only_last=True)))
+    case_produce('gm_l9_t100_n2048_b4', dict(model='GM', config=dict(n_layers=9, sinkhorn_iterations=100), wseed=1, dseed=77,
+                                             n0=2048, n1=2048, batch=4, call=dict(p=0.2, only_last=True)))
+    for seed in (101, 102, 103, 104):
+        case_produce(f'gm_l9_t100_n2048_s{seed}', dict(model='GM', config=dict(n_layers=9, sinkhorn_iterations=100), wseed=seed, dseed=seed,
+                                                       n0=2048, n1=2048 - 3 * (seed % 7), call=dict(p=0.2, only_last=True)))
+    case_produce('gm_trained_l9_n2048', dict(model='GM', config=dict(n_layers=9, sinkhorn_iterations=100), wseed=21, dseed=34,
+                                             n0=2048, n1=2048, style='trained', call=dict(p=0.2, only_last=True)))
+    case_loop('eimp_loop_sliced_n4096', dict(model='AdaGMN', config=dict(), wseed=9, dseed=41, n0=4096, n1=4000, bin_score=5.0), True)
     # (7) pool edge cases
     case_pool_edges('pool_edges')
     case_metrics('metrics')
