@@ -26,7 +26,7 @@ SYMBOLS = [
     'imp_last_error', 'imp_version', 'imp_create', 'imp_destroy', 'imp_load_tensor', 'imp_finalize_weights',
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
-    'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_pool_select_pair', 'imp_masked_commit', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear', 'imp_op_layer_gemm',
+    'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_pool_select_pair', 'imp_masked_commit', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear', 'imp_op_layer_gemm', 'imp_op_fused_mlp',
     'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_range_events', 'imp_time_layer_gemm', 'imp_estimate_pose',
     'imp_sp_create', 'imp_sp_destroy', 'imp_sp_set_weight', 'imp_sp_finalize', 'imp_sp_detect', 'imp_sp_describe', 'imp_sp_dense', 'imp_sp_op_conv',
 ]
@@ -113,6 +113,7 @@ def lib():
     L.imp_match_pair.argtypes = [P, I, I, I, P, P, P, P, P, P, F, F, F, I, I, F, P, P, P, P, P, P]
     L.imp_op_linear.argtypes = [P, I, I, I, P, P, P, P, P]
     L.imp_op_layer_gemm.argtypes = [P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, P, I, P]
+    L.imp_op_fused_mlp.argtypes = [P, I, I, P, P, P, P, P, P, P, P, I, P, P, I, P]
     L.imp_op_attention.argtypes = [P, I, I, I, I, P, P, P, P, P, P]
     L.imp_time_attention.argtypes = [P, I, I, I, C.POINTER(C.c_float), P]
     L.imp_time_sinkhorn.argtypes = [P, I, I, I, C.POINTER(C.c_float), P]
@@ -434,6 +435,20 @@ class Context:
         self._check(self.L.imp_op_layer_gemm(self.handle, B, M, N, K, ks, _ptr(x), _ptr(x2), _ptr(W), _ptr(bias), _ptr(residual), _ptr(stats_in),
                                              _ptr(y), _ptr(so), _ptr(W2), _ptr(bias2), N2, _ptr(y2), int(pass_split), _stream(self.device)))
         return y, so, y2
+
+    def op_fused_mlp(self, x, a, W0, b0, W3, b3, W2=None, b2=None, fake=False):
+        """csrc/gemm_wf.hip's fused layer MLP on its own (include/imp_hip.h imp_op_fused_mlp): x, a [B, M, 256] -> y [B, M, 256]
+        (+ the chained projection y2 [B, M, N2])"""
+        x, a, W0, b0, W3, b3 = (_f32(t, n) for t, n in ((x, 'x'), (a, 'a'), (W0, 'W0'), (b0, 'b0'), (W3, 'W3'), (b3, 'b3')))
+        B, M, _ = x.shape
+        y = torch.empty(B, M, 256, device=x.device, dtype=torch.float32)
+        N2 = 0 if W2 is None else W2.shape[0]
+        W2 = None if W2 is None else _f32(W2, 'W2')
+        b2 = None if b2 is None else _f32(b2, 'b2')
+        y2 = None if W2 is None else torch.empty(B, M, N2, device=x.device, dtype=torch.float32)
+        self._check(self.L.imp_op_fused_mlp(self.handle, B, M, _ptr(x), _ptr(a), _ptr(W0), _ptr(b0), _ptr(W3), _ptr(b3), _ptr(W2), _ptr(b2), N2,
+                                            _ptr(y), _ptr(y2), int(bool(fake)), _stream(self.device)))
+        return y, y2
 
     def op_attention(self, qkv_q, qkv_kv, key_mask=None, want_lse=True):
         qkv_q, qkv_kv = _f32(qkv_q, 'qkv_q'), _f32(qkv_kv, 'qkv_kv')

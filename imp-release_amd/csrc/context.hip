@@ -110,6 +110,9 @@ struct imp_ctx {
     int wf_fused_fake = 0;   // TEST HOOK IMP_WF_FUSED_FAKE=1: one workgroup of every fused launch withholds its statistics (forces the time-out path)
     float *fx_rec[2] = {}, *fx_fin[2] = {};   // fused layer: statistics granules [B][tiles][512] x 16 B and (mean, rstd) granules [B][512] x 16 B per image
     unsigned fx_tag = 0;     // tag of the last fused launch (tags never repeat on fx_rec / fx_fin)
+    size_t fx_rec_floats = 0, fx_fin_floats = 0;
+    int* fx_status = nullptr;   // device word the waiters of a fused launch watch (3 = a wait timed out)
+    int ot_lane = 0;         // IMP_OT_LANE=1: resident Sinkhorn launches go through the device's lane stream (rounds 2-3) instead of the caller's stream under the spin gate
     int use_wf = 1;          // weight-fragment GEMMs (gemm_wf.hip) for the layer convolutions when f16x3, D = 256, relu + InstanceNorm; IMP_GEMM_WF=0 disables
     float* attn_split_ws = nullptr;        // key-split scratch of the attention kernel (grown on demand, allocs_x)
     unsigned* attn_split_cnt = nullptr;
@@ -293,6 +296,19 @@ int ensure_workspace(imp_ctx* c, int batch, int n) {
         if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->amass[k], B * N);
     }
     if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->stat_cnt, (B * 2 + 2) * WF_MAX_PSPLIT);
+    // fused layer MLP (gemm_wf.hip gemm_wf_fused_kernel): granule buffers of the statistics exchange, tag 0 = never written
+    c->fx_rec_floats = B * ((N + 63) / 64) * 2 * D * 4;
+    c->fx_fin_floats = B * 2 * D * 4;
+    for (int s = 0; s < 2 && !rc; ++s) {
+        rc = dev_alloc(c, c->allocs_ws, &c->fx_rec[s], c->fx_rec_floats);
+        if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->fx_fin[s], c->fx_fin_floats);
+        if (!rc) {
+            HIP_TRY(hipMemset(c->fx_rec[s], 0, c->fx_rec_floats * sizeof(float)));
+            HIP_TRY(hipMemset(c->fx_fin[s], 0, c->fx_fin_floats * sizeof(float)));
+        }
+    }
+    if (!rc) rc = dev_alloc(c, c->allocs_ws, &c->fx_status, 16);
+    if (!rc) HIP_TRY(hipMemset(c->fx_status, 0, 64));
     if (!rc) {
         HIP_TRY(hipMemset(c->stat_cnt, 0, (B * 2 + 2) * WF_MAX_PSPLIT * sizeof(unsigned)));
         HIP_TRY(hipDeviceSynchronize());              // the clear runs on the NULL stream, which the callers' streams do not wait for
@@ -436,6 +452,64 @@ int wf_pass_split(const imp_ctx* c, long tiles, int N) {
     return best;
 }
 
+struct SpinGate;
+SpinGate* spin_gate(int device);
+int spin_enter(SpinGate* g, hipStream_t st);
+int spin_leave(SpinGate* g, hipStream_t st);
+
+// tag of the next fused layer launch: unique on the context's granule buffers (cleared before the 32-bit count wraps)
+unsigned next_fused_tag(imp_ctx* c) {
+    if (c->fx_tag >= 0xFFFFFF00u) {
+        (void)hipDeviceSynchronize();
+        for (int s = 0; s < 2; ++s) {
+            (void)hipMemset(c->fx_rec[s], 0, c->fx_rec_floats * sizeof(float));
+            (void)hipMemset(c->fx_fin[s], 0, c->fx_fin_floats * sizeof(float));
+        }
+        (void)hipDeviceSynchronize();
+        c->fx_tag = 0;
+    }
+    return ++c->fx_tag;
+}
+
+// steps 4 + 5 of a layer (and the next layer's projection) as ONE launch (gemm_wf.hip gemm_wf_fused_kernel), inside a gate section of the
+// device: mlp.0 on cat[x, attention output] -> InstanceNorm statistics exchanged between the tiles of an image -> ReLU -> mlp.3 + bias +
+// residual -> `out` (-> q|k|v of layer NL into nqkv).  NL == nullptr: no chained projection
+int launch_fused_layer(imp_ctx* c, const GnnLayer& L, int batch, const int n[2], const float* const desc[2], float* const out[2],
+                       const GnnLayer* NL, float* const* nqkv, bool next_image, hipStream_t st) {
+    const int D = c->D;
+    WfParams p;
+    memset(&p, 0, sizeof p);
+    p.kv_image_col = p.kv_image_col2 = 1 << 30;
+    p.K = 2 * D; p.ksplit = D; p.N = 2 * D; p.nside = 2;
+    for (int s = 0; s < 2; ++s) {
+        WfSide& g = p.side[s];
+        g.A = desc[s]; g.A2 = c->attn_out[s]; g.C = out[s]; g.R = desc[s]; g.M = n[s];
+        g.sA_b = (long)n[s] * D; g.sA2_b = (long)n[s] * D; g.sC_b = (long)n[s] * D; g.sR_b = (long)n[s] * D;
+        if (NL) { g.C2 = NL->shared ? nqkv[s] + 2 * D : nqkv[s]; g.sC2_b = (long)n[s] * 3 * D; }
+    }
+    p.norm_eps = 1e-3f;
+    p.Wf_ = L.mlp0f_wf; p.bias = L.mlp0f.b; p.lda = D; p.lda2 = D; p.ldc = D; p.ldr = D;
+    if (NL) {
+        p.Wf2_ = NL->proj_wf; p.bias2 = NL->proj.b; p.N2 = NL->proj.out; p.ldc2 = 3 * D;
+        if (next_image) p.kv_image_col2 = NL->shared ? 0 : D;
+    }
+    p.pass_split = 1;
+    WfFused f;
+    memset(&f, 0, sizeof f);
+    f.Wf3_ = L.mlp3_wf; f.bias3 = L.mlp3.b;
+    for (int s = 0; s < 2; ++s) { f.rec[s] = c->fx_rec[s]; f.fin[s] = c->fx_fin[s]; }
+    f.tag = next_fused_tag(c);
+    f.status = c->fx_status; f.host_status = c->xstatus_hostdev;
+    f.fake = c->wf_fused_fake;
+    SpinGate* gate = spin_gate(c->device);
+    if (!gate) return fail(IMP_E_HIP, "spin gate: cannot create events");
+    if (int grc = spin_enter(gate, st)) return grc;
+    const hipError_t e = launch_gemm_wf_fused(p, f, batch, st);
+    const int lrc = spin_leave(gate, st);
+    HIP_TRY(e);
+    return lrc;
+}
+
 // One GNN layer (nets/layers.py:139-149 / :182-218) on both images.
 //   proj_done: this layer's q|k|v (or value) projection was already produced by the previous layer's chained launch
 //   chain_li:  >= 0: the caller will run layer chain_li next ON THE OUTPUT OF THIS CALL, unmodified and with no pooling in between:
@@ -532,6 +606,20 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
         if (rc) return rc;
     }
     const Linear& M0 = c->fuse_merge ? L.mlp0f : L.mlp0;
+    // 4 + 5 FUSED (round 4): one launch for mlp.0 -> InstanceNorm -> ReLU -> mlp.3 (-> the next layer's projection) when every 64-row tile of
+    // the launch gets a CU of its own (the tiles of an image wait for each other's statistics inside the kernel) and the launch is large
+    // enough to pay for the wait; not under hipGraph capture (the exchange tags are launch parameters).  IMP_WF_FUSED=0 disables
+    if (wf_mlp && c->wf_fused && D == 256 && wf_tiles >= c->wf_fused_min_tiles && wf_tiles <= (long)c->num_cus && c->fx_rec[0]) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+            const bool can_chain = chain_li >= 0 && chain_li < (int)c->layers.size() && c->wf_chain && c->layers[chain_li].proj_wf && !kmask[0] && !kmask[1];
+            const GnnLayer* NL = can_chain ? &c->layers[chain_li] : nullptr;
+            const bool nimg = NL ? (NL->shared ? c->cache[NL->cross ? 1 : 0].kv_image : img_ok) : false;      // the format the next layer will expect
+            if (int frc = launch_fused_layer(c, L, batch, n, desc, out, NL, NL ? c->qkv[NL->cross ? 1 : 0] : nullptr, nimg, st)) return frc;
+            if (chained) *chained = can_chain;
+            return IMP_OK;
+        }
+    }
     // 4. MLP conv 0 on cat([x, message]) (the concat is a K-split over two sources) + InstanceNorm statistics
     const bool in_norm = cfg.norm_fn == IMP_NORM_IN;
     const int maxn = n[0] > n[1] ? n[0] : n[1];
@@ -659,6 +747,70 @@ ResidentLane* resident_lane(int device) {
     return l;
 }
 
+// SPIN GATE (round 4).  Two kinds of kernels of this library WAIT inside the launch for other workgroups of the same launch: the chip-
+// resident Sinkhorn and the fused layer MLP (gemm_wf.hip).  Each needs all its workgroups co-resident, so two of them must never be
+// dispatched side by side (each could hold CUs the other is waiting for): every such launch runs inside a gate section of its device.
+// The gate orders the sections in the order the host enters them: a section on stream B first waits (hipStreamWaitEvent) for the event
+// the previous section left on stream A.  While all sections come from ONE stream (the common case: one context, one stream) stream
+// order already serialises them and the gate records nothing - no event, no extra packet in the stream; the first section from another
+// stream switches the gate to recording mode (one event per section) after ordering itself behind the first stream's tail.
+struct SpinGate {
+    std::mutex mu;
+    hipEvent_t ring[64] = {};
+    int head = 0, same_run = 0;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t last_event = nullptr;
+    bool has_last = false, multi = false;
+};
+SpinGate* spin_gate(int device) {
+    static std::mutex mu;
+    static std::map<int, SpinGate*> gates;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = gates.find(device);
+    if (it != gates.end()) return it->second;
+    SpinGate* g = new SpinGate();
+    for (auto& e : g->ring)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete g; return nullptr; }
+    gates[device] = g;
+    return g;
+}
+// enters a gate section on `st` (the mutex stays locked until spin_leave): everything enqueued on `st` from here on runs after the
+// previous section of the device has finished
+int spin_enter(SpinGate* g, hipStream_t st) {
+    g->mu.lock();
+    if (g->has_last && g->last_stream != st) {
+        hipError_t e = hipSuccess;
+        if (!g->multi) {
+            // the earlier sections left no event: one at the tail of their stream is late (conservative), never early
+            g->multi = true;
+            hipEvent_t ev = g->ring[g->head++ & 63];
+            e = hipEventRecord(ev, g->last_stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(st, ev, 0);
+            else e = hipDeviceSynchronize();             // (that stream no longer exists: wait for whatever is left of it)
+        } else {
+            e = hipStreamWaitEvent(st, g->last_event, 0);
+        }
+        g->same_run = 0;
+        if (e != hipSuccess) { g->mu.unlock(); return fail(IMP_E_HIP, std::string("spin gate: ") + hipGetErrorString(e)); }
+    } else if (g->multi && ++g->same_run > 512) {
+        g->multi = false;                                // one stream again for a long time: stop recording
+    }
+    return IMP_OK;
+}
+int spin_leave(SpinGate* g, hipStream_t st) {
+    hipError_t e = hipSuccess;
+    if (g->multi) {
+        hipEvent_t ev = g->ring[g->head++ & 63];
+        e = hipEventRecord(ev, st);
+        g->last_event = ev;
+    }
+    g->last_stream = st;
+    g->has_last = true;
+    g->mu.unlock();
+    if (e != hipSuccess) return fail(IMP_E_HIP, std::string("spin gate: ") + hipGetErrorString(e));
+    return IMP_OK;
+}
+
 constexpr size_t kResidentMaxLdx = 256 * 16 + 4;
 int ensure_resident_buffers(imp_ctx* c, int batch) {
     if (c->xpart && batch <= c->xcap_b) return IMP_OK;
@@ -732,8 +884,9 @@ int resident_health(imp_ctx* c) {
     if (st) {
         (void)hipSetDevice(c->device);                     // (the caller's thread may have another device current: imp_resident_health)
         (void)hipDeviceSynchronize();
-        (void)hipMemset(c->xstatus, 0, 64);
-        (void)hipMemset(c->xstatus + 17, 0, 44);           // graph launches: ticket base, done counter, tickets (their tag base [16] keeps counting)
+        if (c->xstatus) (void)hipMemset(c->xstatus, 0, 64);
+        if (c->xstatus) (void)hipMemset(c->xstatus + 17, 0, 44);           // graph launches: ticket base, done counter, tickets (their tag base [16] keeps counting)
+        if (c->fx_status) (void)hipMemset(c->fx_status, 0, 64);
         (void)hipDeviceSynchronize();
         *static_cast<volatile int*>(c->xstatus_host) = 0;
         *static_cast<volatile int*>(c->range_host) = 0;    // (raised by the match kernel that met the poisoned maxima)
@@ -793,8 +946,8 @@ int plan_resident(imp_ctx* c, int batch, int n0, int n1, int max_wgs, int* nch, 
 // one resident launch over the pairs [b0, b0 + nb) of a batch (all per-pair arrays are indexed b * stride inside the kernel)
 int run_score_resident_launch(imp_ctx* c, int batch, int b0, int nb, int n0, int n1, const float* dist, float bin, int iterations, float* scores,
                               bool want_max, bool want_uv, int nch, int rpw, int G, int local, hipStream_t st) {
-    ResidentLane* lane = resident_lane(c->device);
-    if (!lane) return 1;
+    ResidentLane* lane = c->ot_lane ? resident_lane(c->device) : nullptr;
+    if (c->ot_lane && !lane) return 1;
     OtResidentParams p;
     memset(&p, 0, sizeof p);
     p.dist = dist + (size_t)b0 * n0 * n1; p.B = nb; p.n0 = n0; p.n1 = n1; p.T = iterations; p.G = G; p.bin = bin;
@@ -811,13 +964,25 @@ int run_score_resident_launch(imp_ctx* c, int batch, int b0, int nb, int n0, int
         p.max0 = c->max0 + (size_t)b0 * n0; p.arg0 = c->arg0 + (size_t)b0 * n0;
         p.max1 = c->max1 + (size_t)b0 * n1; p.arg1 = c->arg1 + (size_t)b0 * n1;
     }
-    std::lock_guard<std::mutex> lock(lane->mu);
-    HIP_TRY(hipEventRecord(c->ev_in, st));
-    HIP_TRY(hipStreamWaitEvent(lane->stream, c->ev_in, 0));
-    HIP_TRY(launch_ot_resident(p, nch, rpw, lane->stream));
-    HIP_TRY(hipEventRecord(c->ev_out, lane->stream));
-    HIP_TRY(hipStreamWaitEvent(st, c->ev_out, 0));
-    return IMP_OK;
+    SpinGate* gate = spin_gate(c->device);
+    if (!gate) return 1;
+    if (int grc = spin_enter(gate, st)) return grc;
+    hipError_t e = hipSuccess;
+    if (c->ot_lane) {
+        // rounds 2-3: the launch on the device's lane stream, joined to `st` on both sides (two cross-stream event hops per launch)
+        std::lock_guard<std::mutex> lock(lane->mu);
+        e = hipEventRecord(c->ev_in, st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(lane->stream, c->ev_in, 0);
+        if (e == hipSuccess) e = launch_ot_resident(p, nch, rpw, lane->stream);
+        if (e == hipSuccess) e = hipEventRecord(c->ev_out, lane->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, c->ev_out, 0);
+    } else {
+        e = launch_ot_resident(p, nch, rpw, st);
+        if (e == hipSuccess && c->ot_verify) e = hipEventRecord(c->ev_out, st);      // (verify mode waits on ev_out)
+    }
+    const int lrc = spin_leave(gate, st);
+    HIP_TRY(e);
+    return lrc;
 }
 
 // A resident launch recorded into a hipGraph: on the capturing stream itself (no lane: the replay knows no host mutex), with the tag and
@@ -954,6 +1119,10 @@ int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     { const char* e = getenv("IMP_OT_FAKE_PLACEMENT"); c->ot_fake = (e && atoi(e) != 0) ? 1 : 0; }
     { const char* e = getenv("IMP_GEMM_WF"); c->use_wf = e ? atoi(e) : 1; }     // 0 off, 1 default (large launches), 2 always
     { const char* e = getenv("IMP_WF_CHAIN"); c->wf_chain = e ? atoi(e) : 1; }
+    { const char* e = getenv("IMP_WF_FUSED"); c->wf_fused = e ? atoi(e) : 1; }
+    { const char* e = getenv("IMP_WF_FUSED_MIN"); if (e) c->wf_fused_min_tiles = atol(e); }
+    { const char* e = getenv("IMP_WF_FUSED_FAKE"); c->wf_fused_fake = (e && atoi(e) != 0) ? 1 : 0; }
+    { const char* e = getenv("IMP_OT_LANE"); c->ot_lane = (e && atoi(e) != 0) ? 1 : 0; }
     { const char* e = getenv("IMP_KV_IMAGE"); c->kv_image = e ? atoi(e) : 1; }
     { const char* e = getenv("IMP_WF_CHAIN_MIN"); if (e) c->wf_chain_min_tiles = atol(e); }
     { const char* e = getenv("IMP_WF_MAX"); if (e) c->wf_max_tiles = atol(e); }
@@ -1464,6 +1633,72 @@ int imp_op_layer_gemm(imp_ctx* c, int B, int M, int N, int K, int ksplit, const 
     return IMP_OK;
 }
 
+int imp_op_fused_mlp(imp_ctx* c, int B, int M, const float* x, const float* a, const float* W0, const float* b0, const float* W3, const float* b3,
+                     const float* W2, const float* b2, int N2, float* y, float* y2, int fake, void* stream) {
+    if (!c || !x || !a || !W0 || !b0 || !W3 || !b3 || !y || B < 1 || M < 1) return fail(IMP_E_ARG, "imp_op_fused_mlp: bad argument");
+    if (W2 && (!y2 || !b2 || !gemm_wf_supported(256, N2) || N2 < 256)) return fail(IMP_E_ARG, "imp_op_fused_mlp: the chained projection needs N2 % 128 == 0, N2 >= 256");
+    const int tiles = (M + 63) / 64;
+    if ((long)B * tiles > c->num_cus) return fail(IMP_E_ARG, "imp_op_fused_mlp: more 64-row tiles than CUs (the tiles of a launch wait for each other)");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = S(stream);
+    HIP_TRY(hipStreamSynchronize(st));
+    auto pack = [&](const float* Wd, int n, int k, _Float16** out) -> int {
+        std::vector<float> h((size_t)n * k);
+        HIP_TRY(hipMemcpy(h.data(), Wd, h.size() * 4, hipMemcpyDeviceToHost));
+        std::vector<_Float16> fr((size_t)n * k * 2);
+        wf_pack(h.data(), n, k, fr.data());
+        HIP_TRY(hipMalloc(out, fr.size() * 2));
+        HIP_TRY(hipMemcpy(*out, fr.data(), fr.size() * 2, hipMemcpyHostToDevice));
+        return IMP_OK;
+    };
+    _Float16 *wf0 = nullptr, *wf3 = nullptr, *wf2 = nullptr;
+    float *rec = nullptr, *fin = nullptr;
+    int* status = nullptr;
+    int rc = pack(W0, 512, 512, &wf0);
+    if (!rc) rc = pack(W3, 256, 512, &wf3);
+    if (!rc && W2) rc = pack(W2, N2, 256, &wf2);
+    if (rc) return rc;
+    const size_t rec_b = (size_t)B * tiles * 512 * 16, fin_b = (size_t)B * 512 * 16;
+    HIP_TRY(hipMalloc(&rec, rec_b));
+    HIP_TRY(hipMalloc(&fin, fin_b));
+    HIP_TRY(hipMalloc(&status, 64));
+    HIP_TRY(hipMemset(rec, 0, rec_b));
+    HIP_TRY(hipMemset(fin, 0, fin_b));
+    HIP_TRY(hipMemset(status, 0, 64));
+    HIP_TRY(hipDeviceSynchronize());
+    WfParams p = wf_defaults();
+    p.K = 512; p.ksplit = 256; p.N = 512; p.nside = 1;
+    WfSide& g = p.side[0];
+    g.A = x; g.A2 = a; g.C = y; g.R = x; g.M = M;
+    g.sA_b = g.sA2_b = g.sC_b = g.sR_b = (long)M * 256;
+    g.C2 = y2; g.sC2_b = (long)M * N2;
+    p.norm_eps = 1e-3f;
+    p.Wf_ = wf0; p.bias = b0; p.lda = p.lda2 = 256; p.ldc = 256; p.ldr = 256;
+    p.Wf2_ = wf2; p.bias2 = b2; p.N2 = N2; p.ldc2 = N2;
+    p.pass_split = 1;
+    WfFused f;
+    memset(&f, 0, sizeof f);
+    f.Wf3_ = wf3; f.bias3 = b3; f.rec[0] = rec; f.fin[0] = fin; f.tag = 1u; f.status = status; f.fake = fake;
+    int lrc = IMP_OK;
+    hipError_t e = hipSuccess;
+    SpinGate* gate = spin_gate(c->device);
+    if (!gate) lrc = fail(IMP_E_HIP, "spin gate: cannot create events");
+    if (!lrc) lrc = spin_enter(gate, st);
+    if (!lrc) {
+        e = launch_gemm_wf_fused(p, f, B, st);
+        lrc = spin_leave(gate, st);
+    }
+    const hipError_t e2 = hipStreamSynchronize(st);
+    int hst = 0;
+    (void)hipMemcpy(&hst, status, 4, hipMemcpyDeviceToHost);
+    (void)hipFree(wf0); (void)hipFree(wf3); (void)hipFree(wf2); (void)hipFree(rec); (void)hipFree(fin); (void)hipFree(status);
+    if (lrc) return lrc;
+    HIP_TRY(e);
+    HIP_TRY(e2);
+    if (hst) return fail(IMP_E_RESIDENT, "imp_op_fused_mlp: the statistics exchange timed out (outputs are NaN)");
+    return IMP_OK;
+}
+
 int imp_op_attention(imp_ctx* c, int batch, int nq, int nk, int dim, const float* qkv_q, const float* qkv_kv,
                      const uint8_t* key_mask, float* out, float* lse, void* stream) {
     if (!c || !qkv_q || !qkv_kv || !out || (dim != 256 && dim != 128)) return fail(IMP_E_ARG, "imp_op_attention: bad argument");
@@ -1621,7 +1856,10 @@ int imp_time_sinkhorn(imp_ctx* c, int batch, int n, int iterations, float* ms, v
 int imp_time_layer_gemm(imp_ctx* c, int batch, int n, int which, int dbg, int reps, float* ms, void* stream) {
     int rc = check_ready(c, batch, n, n);
     if (rc) return rc;
-    if (!ms || reps < 1 || which < 0 || which > 3 || c->layers.empty()) return fail(IMP_E_ARG, "imp_time_layer_gemm: bad argument");
+    if (!ms || reps < 1 || which < 0 || which > 4 || c->layers.empty()) return fail(IMP_E_ARG, "imp_time_layer_gemm: bad argument");
+    if (which == 4 && (dbg != -2 || c->D != 256 || !c->layers[0].mlp0f_wf || !c->layers[0].mlp3_wf || !c->layers[0].proj_wf || !c->fx_rec[0] ||
+                       (long)batch * 2 * ((n + 63) / 64) > c->num_cus))
+        return fail(IMP_E_ARG, "imp_time_layer_gemm: which = 4 (the fused layer MLP + projection) needs dbg = -2, D = 256 and at most one 64-row tile per CU");
     if (which == 3 && dbg > -2) return fail(IMP_E_ARG, "imp_time_layer_gemm: which = 3 (MLP3 chained with the projection) exists only in gemm_wf.hip (dbg <= -2)");
     hipStream_t st = S(stream);
     const int D = c->D;
@@ -1630,6 +1868,12 @@ int imp_time_layer_gemm(imp_ctx* c, int batch, int n, int which, int dbg, int re
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     auto launch = [&]() -> hipError_t {
+        if (which == 4) {                                       // steps 4 + 5 + next projection as the one fused launch of run_layer
+            const int nn[2] = {n, n};
+            const float* de[2] = {c->descw[0], c->descw[1]};
+            float* ou[2] = {c->mdesc[0], c->mdesc[1]};
+            return launch_fused_layer(c, L, batch, nn, de, ou, &L, c->qkv[0], c->kv_image != 0, st) == IMP_OK ? hipSuccess : hipErrorUnknown;
+        }
         if (dbg <= -2) {                                        // gemm_wf.hip; -3 / -4 / -6: its probe switches 1 / 2 / 4
             WfParams p = wf_defaults();
             p.nside = 2;

@@ -246,6 +246,20 @@ __device__ __forceinline__ void wf_store_stats(float* out_stats, int b, int rtil
     }
 }
 
+// merged block statistics of one channel -> (mean, rstd): s1 = sum of the block sums, m2w = sum of the blocks' M2, sqn = sum of
+// (block sum)^2 / (block rows) - Chan's parallel-variance formula; biased variance, eps inside the root (nets/layers.py:67-68).
+// ONE function for the last-arriver merge of gemm_wf_kernel and for the slice owners of gemm_wf_fused_kernel: the two paths
+// must produce the same bits
+__device__ __forceinline__ float2 wf_finish_stats(double s1, double m2w, double sqn, int M, float eps) {
+    const double mean = s1 / (double)M;
+    double m2 = m2w + (sqn - (double)M * mean * mean);
+    m2 = m2 < 0.0 ? 0.0 : m2;
+    float2 o;
+    o.x = (float)mean;
+    o.y = (float)(1.0 / sqrt(m2 / (double)M + (double)eps));
+    return o;
+}
+
 template <int K, int PRO, int SWAP, int STATS, int CHAIN>
 __global__ __launch_bounds__(512) void gemm_wf_kernel(const WfParams p, int row_tiles) {
     constexpr int PITCH = 2 * K + 16;               // bytes per row of one half plane
@@ -503,15 +517,326 @@ __global__ __launch_bounds__(512) void gemm_wf_kernel(const WfParams p, int row_
             const double s1t = (sm[(0 * 3 + 0) * N + k] + sm[(1 * 3 + 0) * N + k]) + (sm[(2 * 3 + 0) * N + k] + sm[(3 * 3 + 0) * N + k]);
             const double m2w = (sm[(0 * 3 + 1) * N + k] + sm[(1 * 3 + 1) * N + k]) + (sm[(2 * 3 + 1) * N + k] + sm[(3 * 3 + 1) * N + k]);
             const double sqn = (sm[(0 * 3 + 2) * N + k] + sm[(1 * 3 + 2) * N + k]) + (sm[(2 * 3 + 2) * N + k] + sm[(3 * 3 + 2) * N + k]);
-            const double mean = s1t / (double)M;
-            double m2 = m2w + (sqn - (double)M * mean * mean);
-            m2 = m2 < 0.0 ? 0.0 : m2;
-            float2 o;
-            o.x = (float)mean;
-            o.y = (float)(1.0 / sqrt(m2 / (double)M + (double)p.norm_eps));   // biased variance, eps inside the root (nets/layers.py:67-68)
-            reinterpret_cast<float2*>(S.fin_stats)[(long)b * N + c0 + k] = o;
+            reinterpret_cast<float2*>(S.fin_stats)[(long)b * N + c0 + k] = wf_finish_stats(s1t, m2w, sqn, M, p.norm_eps);
         }
     }
+}
+
+// ====================================================================================================================
+// FUSED layer MLP (round 4).  Two launches per layer used to frame the InstanceNorm between mlp.0 and mlp.3:
+// MLP0 wrote the hidden tensor (33.5 MB at B = 4, N = 2048) and its statistics, MLP3 staged it again - a store drain, a launch
+// boundary and a second staging phase with the matrix pipe idle, ~15 us per layer.  Here a workgroup keeps its 64 x 512 hidden
+// tile in the accumulators of its two MLP0 column passes per group (64 VGPRs per lane) while the statistics travel:
+//   1. stage [x | attention output] -> half planes, mlp.0 K loops (2 passes per group), per-block (sum, M2) as in gemm_wf_kernel
+//   2. reduce-scatter: every workgroup publishes its 512 block records as granules {sum, tag, M2, tag}; tile j of the image OWNS
+//      the channel slice [j S, (j + 1) S), S = ceil(512 / tiles): it gathers that slice from all blocks (tagged polls, no ticket,
+//      no store acknowledgement), merges it with Chan's formula in fp64 in the order of the last-arriver merge above and publishes
+//      {mean, tag, rstd, tag}
+//   3. all-gather: every thread polls one channel's (mean, rstd) into LDS
+//   4. (acc + bias - mean) * rstd, ReLU, hi / lo split in registers; neighbouring lanes trade one value (DPP) so that every lane
+//      writes 2 consecutive channels of one row: the planes of the hidden tile replace the dead input tile in LDS
+//   5. mlp.3 + bias + residual -> new descriptors (memory and planes), then the chained projection: the CHAIN branch of gemm_wf_kernel
+// Same operands, same instruction sequences per value, same merge order: results are bit-identical to the two-launch path.
+// Exchange = two one-hop granule sweeps (handoff rows of MI355X_MICROARCH.md): writers use write-through (sc1) 16-byte stores, readers
+// poll with cache-bypassing loads until both tags of a granule pair match; tags are unique per launch on the buffers.  Polls are
+// bounded: a time-out raises *status = 3 (seen by every waiter within 256 polls) and the mapped host word, the workgroup poisons
+// its rows (NaN residual -> NaN descriptors -> NaN scores -> no matches), and the library reports IMP_E_RESIDENT at its next entry.
+constexpr int WF_SPIN_LIMIT = 1 << 21;
+constexpr int AUX_POLL = AUX_SC1 | (int)0x80000000;      // + volatile: a poll must stay inside its loop
+
+__device__ __forceinline__ void wf_poll_health(int* status, int* host, int spins, bool& dead) {
+    if (spins > WF_SPIN_LIMIT) {
+        __hip_atomic_store(status, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (host) __hip_atomic_store(host, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) dead = true;
+}
+
+// normalise one held column pass (SWAP = 0 layout: lane = column cb + lane % 32, register r of acc[i] = row 32 i + 4 half + (r & 3)
+// + 8 (r >> 2)) and write it into the K = 512 half planes as columns cb .. cb + 31 of the hidden tile.  Lanes l and l ^ 1 trade one
+// value per register pair (r, r + 4): the even lane ends up with columns (k, k + 1) of row rho, the odd lane with the same two
+// columns of row rho + 8 - 4-byte LDS writes of two halves; the 64 lanes of a write cover 4 rows x 16 dwords in distinct banks
+// (row pitch 260 dwords: rows rho, rho + 8, rho + 4, rho + 12 start at banks 0, 32, 16, 48 relative to the first)
+__device__ __forceinline__ void wf_hidden_to_planes(f32x16 (&acc)[2], const float* bias, const float* stl, unsigned char* planes, int cb, const WfLane& L) {
+    constexpr int PITCH = 2 * 512 + 16, PLANE = WF_TM * PITCH;
+    const int lane = L.lane, half = L.half;
+    const int col = cb + (lane & 31);
+    const float bv = bias ? bias[col] : 0.f;
+    const float mean = stl[2 * col], rstd = stl[2 * col + 1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = fmaxf(((acc[i][r] + bv) - mean) * rstd, 0.f);      // the stored value of MLP0 (acc + bias), then nets/layers.py:67-76 as the PRO staging does it
+    const bool odd = lane & 1;
+    unsigned char* const colbase = planes + (cb + (lane & 30)) * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int ra = (q & 3) + 8 * (q >> 2), rb = ra + 4;                  // rows rho and rho + 8
+            float xa = acc[i][ra], xb = acc[i][rb];
+            asm("" : "+v"(xa), "+v"(xb));           // (opaque copies: the compiler otherwise turns the selects below into a lane-varying INDEX into acc - a 16-way compare / select chain per value)
+            const float send = odd ? xa : xb;
+            const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]: lane ^ 1
+            const float v0 = odd ? recv : xa;
+            const float v1 = odd ? xb : recv;
+            const int row = 32 * i + 4 * half + (ra & 3) + 8 * (ra >> 2) + (odd ? 8 : 0);
+            unsigned hi, lo;
+            imp_split2(v0, v1, hi, lo);
+            *reinterpret_cast<unsigned*>(colbase + row * PITCH) = hi;
+            *reinterpret_cast<unsigned*>(colbase + row * PITCH + PLANE) = lo;
+        }
+}
+
+__global__ __launch_bounds__(512) void gemm_wf_fused_kernel(const WfParams p, const WfFused f, int row_tiles) {
+    constexpr int K = 512, N = 512;
+    constexpr int PITCH = 2 * K + 16;
+    constexpr int PLANE = WF_TM * PITCH;
+    constexpr int NS = K / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wf_smem[];
+    __shared__ int s_dead;
+    const int tid = threadIdx.x;
+    WfLane L;
+    L.lane = tid & 63; L.half = L.lane >> 5; L.w4 = (tid >> 6) & 3; L.grp = tid >> 8;
+    const int lane = L.lane, half = L.half, w4 = L.w4, grp = L.grp;
+    int z = blockIdx.x;
+    const int rtile = z % row_tiles; z /= row_tiles;
+    const int sidx = z % p.nside;
+    const int b = z / p.nside;
+    const WfSide& S = p.side[sidx];
+    const int M = S.M;
+    const int row0 = rtile * WF_TM;
+    if (row0 >= M) return;                          // uniform per workgroup, before any barrier or exchange
+    const int T = (M + WF_TM - 1) / WF_TM;          // workgroups (= statistics blocks) of this (pair, image)
+#ifdef WF_PROFILE
+    unsigned long long tp[7];
+    tp[0] = __builtin_readcyclecounter();
+#define WF_TP(i) tp[i] = __builtin_readcyclecounter()
+#else
+#define WF_TP(i)
+#endif
+    if (tid == 0) s_dead = 0;
+    unsigned char* const tbase = wf_smem + 2 * PLANE;                   // 8 wave-private transposition buffers; before: (mean, rstd) [512][2]
+    float* const stl = reinterpret_cast<float*>(tbase);
+    // ---- 1. stage the tile [x | attention output]: 64 rows x 512 fp32 -> hi / lo half planes (rows past M repeat row M - 1)
+    {
+        const float* A = S.A + b * S.sA_b;
+        const float* A2 = S.A2 ? S.A2 + b * S.sA2_b : A;
+        constexpr int F4_ROW = K / 4;
+        constexpr int PER = WF_TM * F4_ROW / 512;
+        f32x4 v[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int e = j * 512 + tid;
+            const int r = e / F4_ROW, k = (e - r * F4_ROW) * 4;
+            const int gr = min(row0 + r, M - 1);
+            const float* src = k < p.ksplit ? A + (long)gr * p.lda + k : A2 + (long)gr * p.lda2 + (k - p.ksplit);
+            v[j] = *reinterpret_cast<const f32x4*>(src);
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int e = j * 512 + tid;
+            const int r = e / F4_ROW, k = (e - r * F4_ROW) * 4;
+            u32x2 hi, lo;
+            unsigned a, c;
+            imp_split2(v[j][0], v[j][1], a, c); hi[0] = a; lo[0] = c;
+            imp_split2(v[j][2], v[j][3], a, c); hi[1] = a; lo[1] = c;
+            unsigned char* dst = wf_smem + r * PITCH + k * 2;
+            *reinterpret_cast<u32x2*>(dst) = hi;
+            *reinterpret_cast<u32x2*>(dst + PLANE) = lo;
+        }
+    }
+    __syncthreads();
+    WF_TP(1);
+
+    int aoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) aoff[i] = (32 * i + (lane & 31)) * PITCH + half * 16;
+    const u32x4* const wbase = reinterpret_cast<const u32x4*>(p.Wf_) + lane;
+    const u32x4* const wbase3 = reinterpret_cast<const u32x4*>(f.Wf3_) + lane;
+    auto wptr = [&](int pass) { return wbase + (size_t)(pass * 4 + w4) * NS * 128; };
+    auto wptr3 = [&](int pass) { return wbase3 + (size_t)(pass * 4 + w4) * NS * 128; };
+    // mlp.0: four column passes of 128, two per group (group g: passes g and g + 2; workgroups start at alternating ones)
+    const int rot = blockIdx.x & 1;
+    const int passA = grp + 2 * rot, passB = grp + 2 * (1 - rot);
+    const int cbA = passA * 128 + w4 * 32, cbB = passB * 128 + w4 * 32;
+    u32x4 bh[4], bl[4];
+    {
+        const u32x4* w0 = wptr(passA);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { bh[c] = w0[c * 128]; bl[c] = w0[c * 128 + 64]; }
+    }
+#if WF_PRIO
+    if (grp == 0) __builtin_amdgcn_s_setprio(1);
+#endif
+    f32x16 accA[2], accB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accA[i][r] = 0.f; accB[i][r] = 0.f; }
+    float sumA, m2A, sumB, m2B;
+    wf_kloop<K, 0>(accA, wf_smem, aoff, wptr(passA), wptr(passB), bh, bl);
+    wf_block_stats(accA, p.bias, row0, M, cbA, L, sumA, m2A);
+    wf_kloop<K, 0>(accB, wf_smem, aoff, wptr(passB), wptr(passB), bh, bl);      // (after the last pass: a harmless reload - mlp.3's first fragments
+    wf_block_stats(accB, p.bias, row0, M, cbB, L, sumB, m2B);                   //  are requested after the exchange: 32 registers less to hold across it)
+#if WF_PRIO
+    if (grp == 0) __builtin_amdgcn_s_setprio(0);
+#endif
+    WF_TP(2);
+    float* const Cb = S.C + b * S.sC_b;
+    const float* const Rb = S.R ? S.R + b * S.sR_b : nullptr;
+    const int cb3 = grp * 128 + w4 * 32;
+
+    // ---- 2. publish this block's records; the slice owner merges
+    const unsigned tag = f.tag;
+    bool dead = false;
+    {
+        float* rec_tile = f.rec[sidx] + (((long)b * T + rtile) * N) * 4;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)rec_tile, 0, (unsigned)(N * 16), 0x00020000);
+        if (half == 0 && !(f.fake && blockIdx.x == 0)) {
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(sumA), tag, __float_as_uint(m2A), tag}, rs, (cbA + lane) * 16, 0, AUX_SC1);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(sumB), tag, __float_as_uint(m2B), tag}, rs, (cbB + lane) * 16, 0, AUX_SC1);
+        }
+    }
+    const int SL = (N + T - 1) / T;                  // channels per owner
+    {
+        const float* rec_all = f.rec[sidx] + (long)b * T * N * 4;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)rec_all, 0, (unsigned)((size_t)T * N * 16), 0x00020000);
+        float* fin = f.fin[sidx] + (long)b * N * 4;
+        const __amdgpu_buffer_rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc((void*)fin, 0, (unsigned)(N * 16), 0x00020000);
+        const int g = tid & 3;                       // block group of the merge: blocks g, g + 4, ... (the order of the last-arriver merge)
+        for (int my = tid >> 2; my < SL; my += 128) {
+            const int chan = rtile * SL + my;
+            if (chan >= N) break;                    // (uniform over the four lanes of a channel)
+            double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            for (int t0 = g; t0 < T; t0 += 32) {
+                // all (up to) 8 records of this round in flight at once, re-read together until every one carries this launch's tag
+                // (a record never changes again inside a launch, so re-reading a good one is harmless)
+                u32x4 raw[8];
+                int spins = 0;
+                for (;;) {
+                    asm volatile("" ::: "memory");
+                    bool all = true;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int t = t0 + 4 * u;
+                        raw[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (min(t, T - 1) * N + chan) * 16, 0, AUX_POLL);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) all = all && raw[u][1] == tag && raw[u][3] == tag;      // (blocks past the last re-read block T - 1)
+                    if (all || dead) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    if ((++spins & 255) == 0) wf_poll_health(f.status, f.host_status, spins << 2, dead);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = t0 + 4 * u;
+                    if (t < T) {
+                        const int nt = min(WF_TM, M - t * WF_TM);
+                        const double vx = (double)__uint_as_float(raw[u][0]), vy = (double)__uint_as_float(raw[u][2]);
+                        a1 += vx; a2 += vy; a3 += vx * vx / (double)nt;
+                    }
+                }
+            }
+            // ((g0 + g1) + (g2 + g3)): the combination order of the last-arriver merge (additions commute: both lanes of a pair hold the same bits)
+            a1 += __shfl_xor(a1, 1); a2 += __shfl_xor(a2, 1); a3 += __shfl_xor(a3, 1);
+            a1 += __shfl_xor(a1, 2); a2 += __shfl_xor(a2, 2); a3 += __shfl_xor(a3, 2);
+            if (g == 0) {
+                const float2 o = wf_finish_stats(a1, a2, a3, M, p.norm_eps);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(o.x), tag, __float_as_uint(o.y), tag}, rsf, chan * 16, 0, AUX_SC1);
+            }
+        }
+        // ---- 3. every thread fetches one channel's (mean, rstd)
+        {
+            u32x4 r;
+            int spins = 0;
+            for (;;) {
+                asm volatile("" ::: "memory");
+                r = __builtin_amdgcn_raw_buffer_load_b128(rsf, tid * 16, 0, AUX_POLL);
+                if ((r[1] == tag && r[3] == tag) || dead) break;
+                __builtin_amdgcn_s_sleep(4);
+                if ((++spins & 255) == 0) wf_poll_health(f.status, f.host_status, spins, dead);
+            }
+            stl[2 * tid] = __uint_as_float(r[0]);
+            stl[2 * tid + 1] = __uint_as_float(r[2]);
+        }
+    }
+    if (dead) s_dead = 1;
+    __syncthreads();                                // (mean, rstd) complete; every wave is done with the input planes
+    WF_TP(3);
+    const bool dead_wg = s_dead != 0;
+    // mlp.3's first weight fragments and the residual of this wave's mlp.3 block, requested now: they arrive under step 4
+    {
+        const u32x4* w0 = wptr3(grp);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { bh[c] = w0[c * 128]; bl[c] = w0[c * 128 + 64]; }
+    }
+    f32x4 rres[2][4];
+    if (Rb) wf_load_residual(rres, Rb, p.ldr, row0, M, cb3, lane);
+    // ---- 4. the hidden tile, normalised, as half planes over the dead input tile
+    wf_hidden_to_planes(accA, p.bias, stl, wf_smem, cbA, L);
+    wf_hidden_to_planes(accB, p.bias, stl, wf_smem, cbB, L);
+    if (dead_wg) {                                  // unfinished exchange: this tile's statistics are garbage - its rows must not pass as results
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) rres[i][j][e] = __builtin_nanf("");
+    }
+    __syncthreads();
+    WF_TP(4);
+    // ---- 5. mlp.3 (N = 256: one pass per group) + bias + residual, then the chained projection (the CHAIN branch of gemm_wf_kernel)
+    unsigned char* const tbuf = tbase + (grp * 4 + w4) * WF_TBUF;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const bool has_res = Rb != nullptr || dead_wg;
+    if (!p.Wf2_) {
+        wf_kloop<K, 1>(acc, wf_smem, aoff, wptr3(grp), wptr3(grp), bh, bl);
+        wf_epilogue<1, 0>(acc, tbuf, f.bias3, rres, has_res, Cb, p.ldc, row0, M, cb3, L, 0, nullptr);
+        WF_TP(5); WF_TP(6);
+    } else {
+        constexpr int NS2 = 256 / 16;
+        const int npass2 = p.N2 >> 7;
+        const int mine2 = (npass2 + 1 - grp) >> 1;
+        const u32x4* wbase2 = reinterpret_cast<const u32x4*>(p.Wf2_) + lane;
+        auto wptr2 = [&](int ps) { return wbase2 + (size_t)(ps * 4 + w4) * NS2 * 128; };
+        wf_kloop<K, 1>(acc, wf_smem, aoff, wptr3(grp), wptr2(grp), bh, bl);
+        __syncthreads();                            // every wave is done with the K-wide planes: the new tile may overwrite them
+        wf_epilogue<1, 1>(acc, tbuf, f.bias3, rres, has_res, Cb, p.ldc, row0, M, cb3, L, 0, wf_smem);
+        __syncthreads();                            // the 64 x 256 tile X' is complete in LDS (pitch 528 bytes)
+        WF_TP(5);
+        constexpr int PITCH2 = 2 * 256 + 16;
+        int aoff2[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) aoff2[i] = (32 * i + (lane & 31)) * PITCH2 + half * 16;
+        float* const C2 = S.C2 + b * S.sC2_b;
+#if WF_PRIO
+        if (grp == 0) __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll 1
+        for (int t = 0; t < mine2; ++t) {
+            const int ps = grp + 2 * t;
+            const int pn = t + 1 < mine2 ? ps + 2 : ps;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            wf_kloop<256, 1>(acc, wf_smem, aoff2, wptr2(ps), wptr2(pn), bh, bl);
+            wf_epilogue<1, 0>(acc, tbuf, p.bias2, rres, false, C2, p.ldc2, row0, M, ps * 128 + w4 * 32, L, 0, nullptr, ps * 128 >= p.kv_image_col2);
+        }
+        WF_TP(6);
+    }
+#ifdef WF_PROFILE
+    if (f.prof && (tid & 255) == 0) {
+        unsigned long long* o = f.prof + ((size_t)blockIdx.x * 2 + grp) * 6;
+        for (int i = 0; i < 6; ++i) o[i] = tp[i + 1] - tp[i];
+    }
+#endif
+#undef WF_TP
 }
 
 template <int K, int PRO, int SWAP, int STATS, int CHAIN>
@@ -567,6 +892,21 @@ hipError_t launch_gemm_wf(const WfParams& p, int batch, hipStream_t stream) {
     }
     if (pro) return p.K == 256 ? wf_launch<256, 1, 1, 0, 0>(p, batch, stream) : wf_launch<512, 1, 1, 0, 0>(p, batch, stream);
     return p.K == 256 ? wf_launch<256, 0, 1, 0, 0>(p, batch, stream) : wf_launch<512, 0, 1, 0, 0>(p, batch, stream);
+}
+
+hipError_t launch_gemm_wf_fused(const WfParams& p, const WfFused& f, int batch, hipStream_t stream) {
+    if (p.K != 512 || p.N != 512 || !p.Wf_ || !f.Wf3_ || !f.tag || !f.status || p.pass_split > 1 || p.nside < 1 || p.nside > 2) return hipErrorInvalidValue;
+    for (int s = 0; s < p.nside; ++s)
+        if (!f.rec[s] || !f.fin[s] || !p.side[s].A || !p.side[s].C || p.side[s].M < 1) return hipErrorInvalidValue;
+    if (p.Wf2_ && (!gemm_wf_supported(256, p.N2) || !p.side[0].C2)) return hipErrorInvalidValue;
+    int maxm = p.side[0].M;
+    if (p.nside > 1 && p.side[1].M > maxm) maxm = p.side[1].M;
+    const int row_tiles = (maxm + WF_TM - 1) / WF_TM;
+    constexpr size_t lds = (size_t)2 * WF_TM * (2 * 512 + 16) + 8 * WF_TBUF;
+    static_assert(8 * WF_TBUF >= 2 * 512 * 4, "(mean, rstd) of the 512 hidden channels live in the transposition area");
+    if (hipError_t e = imp_grant_dynamic_lds((const void*)gemm_wf_fused_kernel, lds)) return e;
+    hipLaunchKernelGGL(gemm_wf_fused_kernel, dim3(batch * p.nside * row_tiles), dim3(512), lds, stream, p, f, row_tiles);
+    return hipGetLastError();
 }
 
 // W [N][K] fp32 -> MFMA fragment order [N / 32][K / 16][hi | lo][64 lanes][8 halves]: lane (col = lane % 32, k-half = lane / 32)

@@ -266,6 +266,24 @@ struct WfParams {
     int dbg;               // probe switches (tools/probe/gemm_wf_time.py): 1 no global stores, 2 no epilogue at all, 4 no residual / bias loads
 };
 hipError_t launch_gemm_wf(const WfParams& p, int batch, hipStream_t stream);
+// FUSED layer MLP (round 4): mlp.0 on cat[x, attention output] -> InstanceNorm statistics over ALL keypoints of the image (exchanged
+// between the workgroups of the launch) -> ReLU -> mlp.3 + bias + residual (-> the chained projection of WfParams::Wf2_) in ONE launch,
+// one workgroup per 64-row tile; the hidden tensor [M][512] never leaves the chip.  WfParams describes the first convolution
+// (K = 512, N = 512, side.A / A2 = x / attention output, side.C / R = new / old descriptors, side.C2 = chained output) and this
+// struct the rest.  The workgroups of one (pair, image) WAIT for each other: all of them must be co-resident (at most one tile per CU)
+// and no other waiting kernel may be dispatched beside it (context.hip SpinGate).
+struct WfFused {
+    const void* Wf3_;      // fragments of mlp.3 [256][512] (wf_pack)
+    const float* bias3;    // [256]
+    float* rec[2];         // per image: [b][tiles of the image][512] statistics granules {sum, tag, M2, tag} (16 bytes) of each 64-row block
+    float* fin[2];         // per image: [b][512] granules {mean, tag, rstd, tag}
+    unsigned tag;          // unique per launch on these buffers, never 0
+    int* status;           // device word: set to 3 when a wait timed out (every waiter of the launch then falls through and poisons its rows)
+    int* host_status;      // the context's mapped health word (context.hip resident_health), or null
+    int fake;              // TEST HOOK: workgroup 0 withholds its statistics - every wait on them times out
+    unsigned long long* prof;   // optional [grid][6] phase cycle stamps (WF_PROFILE builds), else null
+};
+hipError_t launch_gemm_wf_fused(const WfParams& p, const WfFused& f, int batch, hipStream_t stream);
 bool gemm_wf_supported(int K, int N);
 int gemm_wf_stats_rows();
 constexpr int WF_MAX_PSPLIT = 8;      // WfParams::stat_cnt holds batch x nside x WF_MAX_PSPLIT tickets (one per pass group)

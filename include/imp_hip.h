@@ -233,6 +233,14 @@ int imp_op_layer_gemm(imp_ctx* ctx, int B, int M, int N, int K, int ksplit, cons
                       const float* W2, const float* bias2, int N2, float* y2, int pass_split, void* stream);
 /* multi-head attention core on packed projections: qkv_q [B][nq][3D], qkv_kv [B][nk][3D]
  * (q | k | v, head-major), out [B][nq][D], lse [B][4][nq] (optional).  nets/layers.py:121-131 */
+/* the fused layer MLP of csrc/gemm_wf.hip on its own (tests/test_gpu_ops.py): nets/layers.py:145-149 / :210-218 after the attention,
+ *   y = x + mlp.3(relu(InstanceNorm(mlp.0(cat[x, a]))))        x, a, y: [B][M][256];  W0 [512][512], W3 [256][512]
+ *   y2 = y . W2^T + b2                                         optional (W2 [N2][256], N2 % 128 == 0): the next layer's projection
+ * in ONE launch whose B * ceil(M / 64) workgroups exchange the InstanceNorm statistics inside the kernel (must not exceed the CU
+ * count).  fake != 0: test hook, one workgroup withholds its statistics -> the exchange times out (seconds), outputs NaN, IMP_E_RESIDENT.
+ * Synchronises. */
+int imp_op_fused_mlp(imp_ctx* ctx, int B, int M, const float* x, const float* a, const float* W0, const float* b0, const float* W3,
+                     const float* b3, const float* W2, const float* b2, int N2, float* y, float* y2, int fake, void* stream);
 int imp_op_attention(imp_ctx* ctx, int batch, int nq, int nk, int dim, const float* qkv_q,
                      const float* qkv_kv, const uint8_t* key_mask, float* out, float* lse, void* stream);
 /* timing hooks for bench.py: hipEvent-bracketed repetition of one attention / one Sinkhorn pass on
@@ -243,8 +251,8 @@ int imp_time_attention(imp_ctx* ctx, int batch, int n, int reps, float* ms, void
  * *ms = average milliseconds per ITERATION */
 int imp_time_sinkhorn(imp_ctx* ctx, int batch, int n, int iterations, float* ms, void* stream);
 /* probe (tools/probe/gemm_time.py): average milliseconds of one of the three GEMMs of GNN layer 0 (which: 0 q|k|v projection,
- * 1 MLP conv 0, 2 MLP conv 3) at [batch][n] on the context's workspace; dbg == -1: gemm_f32.hip, dbg <= -2: gemm_wf.hip with
- * its probe switches -dbg - 2 */
+ * 1 MLP conv 0, 2 MLP conv 3, 3 MLP conv 3 chained with the projection, 4 the fused launch MLP conv 0 -> InstanceNorm -> MLP conv 3 ->
+ * projection) at [batch][n] on the context's workspace; dbg == -1: gemm_f32.hip, dbg <= -2: gemm_wf.hip with its probe switches -dbg - 2 */
 int imp_time_layer_gemm(imp_ctx* ctx, int batch, int n, int which, int dbg, int reps, float* ms, void* stream);
 /* Pose step of the iterative loops (eval/pose_estimation.py:92-115 estimate_pose + :13-89 decompose_essential_mat) - SURVEY §8 f-1.
  * HOST arrays in, HOST arrays out (the matched keypoints of a loop iteration live on the host, eval/matching.py:68-87):

@@ -93,6 +93,61 @@ def test_weight_fragment_layer_gemm(gm, B, M, K, ks, N, variant, psplit):
         assert err2 < 3e-6 * max(1.0, ref2.abs().max().item()) * (256 / 32) ** .5, f'chained projection: max err {err2:.3e}'
 
 
+# (B, M, N2): one 64-row tile per workgroup, B * ceil(M / 64) <= 256; ragged last tiles, tile counts that do not divide 512 (uneven
+# channel slices), a single tile, the bench geometry per image (4 x 2048) and the full chip (8 x 2048 = 256 tiles)
+FUSED_CASES = [(4, 2048, 768), (8, 2048, 768), (1, 1000, 768), (3, 77, 256), (1, 64, 768), (2, 1500, 768), (1, 5, 256), (2, 2048, 0), (1, 4100, 768),
+               (5, 333, 256)]
+
+
+@pytest.mark.parametrize('B,M,N2', FUSED_CASES)
+def test_fused_layer_mlp_is_bit_identical_to_the_two_launches(gm, B, M, N2):
+    """csrc/gemm_wf.hip gemm_wf_fused_kernel (round 4): mlp.0 -> InstanceNorm statistics exchanged between the workgroups of the launch
+    -> ReLU -> mlp.3 + residual (-> chained projection) in ONE launch.  Same operands, same per-value instruction sequences, same merge
+    order as MLP0 (statistics by the last-arriving workgroup) + MLP3 (norm prologue, chain): every output bit must agree.  Also against
+    fp64.  Inputs with |mean| >> std on some hidden channels (bias ramp), like the fixture gm_l3_bigmean."""
+    ctx = gm[2]._ensure_ctx()
+    x, a = _rand(B, M, 256, seed=11), _rand(B, M, 256, seed=12)
+    W0, b0 = _rand(512, 512, seed=13) / 512 ** .5, _rand(512, seed=14) + torch.linspace(-20, 20, 512)
+    W3, b3 = _rand(256, 512, seed=15) / 512 ** .5, _rand(256, seed=16)
+    W2 = b2 = None
+    if N2:
+        W2, b2 = (_rand(N2, 256, seed=17) / 16).to(DEV), _rand(N2, seed=18).to(DEV)
+    xd, ad, W0d, b0d, W3d, b3d = (t.to(DEV) for t in (x, a, W0, b0, W3, b3))
+    h, st, _ = ctx.op_layer_gemm(xd, W0d, b0d, x2=ad, want_stats=True)
+    y_ref, _, y2_ref = ctx.op_layer_gemm(h, W3d, b3d, residual=xd, stats_in=st, W2=W2, bias2=b2)
+    y, y2 = ctx.op_fused_mlp(xd, ad, W0d, b0d, W3d, b3d, W2, b2)
+    assert torch.isfinite(y).all()
+    nbad = int((y != y_ref).sum())
+    assert nbad == 0, f'fused vs two launches: {nbad} of {y.numel()} descriptor values differ, max {float((y - y_ref).abs().max()):.3e}'
+    if N2:
+        assert torch.equal(y2, y2_ref), f'chained projection: {int((y2 != y2_ref).sum())} values differ'
+    # fp64
+    hd = torch.cat([x, a], -1).double() @ W0.double().t() + b0.double()
+    hn = torch.relu((hd - hd.mean(1, keepdim=True)) / (hd.var(1, unbiased=False, keepdim=True) + 1e-3).sqrt())
+    ref = x.double() + hn @ W3.double().t() + b3.double()
+    err = (y.cpu().double() - ref).abs().max().item()
+    # (a hidden value is (h - mean) * rstd with |h| up to ~25 and fp32-level h: 25 * 2^-22 * rstd(~1) per value, 512 terms)
+    assert err < 2e-4, f'fused MLP vs fp64: max err {err:.3e}'
+
+
+def test_fused_layer_mlp_time_out_is_reported_and_poisons_the_outputs(gm):
+    """one workgroup withholds its statistics (test hook): every wait on them is bounded, the launch ends (seconds), the outputs are
+    NaN - never plausible numbers from an unfinished exchange - and the call reports IMP_E_RESIDENT"""
+    from imp_release_amd import _lib
+    ctx = gm[2]._ensure_ctx()
+    B, M = 2, 700
+    x, a = _rand(B, M, 256, seed=1).to(DEV), _rand(B, M, 256, seed=2).to(DEV)
+    W0, b0 = (_rand(512, 512, seed=3) / 512 ** .5).to(DEV), _rand(512, seed=4).to(DEV)
+    W3, b3 = (_rand(256, 512, seed=5) / 512 ** .5).to(DEV), _rand(256, seed=6).to(DEV)
+    W2, b2 = (_rand(768, 256, seed=7) / 16).to(DEV), _rand(768, seed=8).to(DEV)
+    y = y2 = None
+    with pytest.raises(_lib.ResidentSinkhornTimeout):
+        y, y2 = ctx.op_fused_mlp(x, a, W0, b0, W3, b3, W2, b2, fake=True)
+    # the same call without the hook works afterwards (fresh exchange buffers per call)
+    y, y2 = ctx.op_fused_mlp(x, a, W0, b0, W3, b3, W2, b2)
+    assert torch.isfinite(y).all() and torch.isfinite(y2).all()
+
+
 def _ref_attention(qkv_q, qkv_kv, D, mask=None):
     """fp64 reference of nets/layers.py:121-131 on packed head-major projections"""
     B, nq, _ = qkv_q.shape

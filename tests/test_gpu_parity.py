@@ -488,6 +488,72 @@ def test_chained_projection_is_bit_identical_to_the_separate_launches(model, n0,
     assert torch.equal(a['indices0'][-1], b['indices0'][-1]) and torch.equal(a['mscores0'][-1], b['mscores0'][-1])
 
 
+def _two_models(model, cfg, sd, env_a, env_b):
+    import os
+    out = []
+    for env in (env_a, env_b):
+        os.environ.update(env)
+        try:
+            m = make_hip_model(model, cfg, sd)
+            m._ensure_ctx()
+            out.append(m)
+        finally:
+            for k in env:
+                del os.environ[k]
+    return out
+
+
+@pytest.mark.parametrize('model,n0,n1,B', [('GM', 2048, 2048, 4), ('GM', 2048, 1990, 4), ('DGNNS', 1000, 1100, 3), ('GM', 130, 97, 2), ('AdaGMN', 420, 400, 1),
+                                           ('DGNNS', 1500, 1400, 2)])
+def test_fused_layer_launch_is_bit_identical_to_the_two_launch_path(model, n0, n1, B):
+    """round 4: a layer's MLP0 -> InstanceNorm -> MLP3 (-> next projection) as ONE launch with an in-kernel statistics exchange
+    (gemm_wf.hip gemm_wf_fused_kernel) against the round-3 path (MLP0 with last-arriver statistics, then MLP3 + chain): the same
+    arithmetic on the same operands in the same order - matches, match scores and the whole score tensor must agree bit for bit.
+    Forced on for the small shapes (IMP_WF_FUSED_MIN=1; attention-sharing layers, the masked AdaGMN loop, ragged images)."""
+    cfg = eval_config(n_layers=5 if model != 'GM' else 3, sinkhorn_iterations=20)
+    sd = synthetic.make_state_dict(cfg, model, seed=8, bin_score=5.0 if model == 'AdaGMN' else 1.0)
+    base = {'IMP_GEMM_WF': '2', 'IMP_WF_CHAIN_MIN': '1'}
+    fused, plain = _two_models(model, cfg, sd, dict(base, IMP_WF_FUSED='1', IMP_WF_FUSED_MIN='1'), dict(base, IMP_WF_FUSED='0'))
+    pair = synthetic.make_correlated_pair(n0, n1, seed=n0 + B, batch=B)
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+    kw = dict(p=0.2) if model == 'AdaGMN' else dict(p=0.2, only_last=True)
+    with torch.no_grad():
+        a = fused.produce_matches(data, **kw)
+        b = plain.produce_matches(data, **kw)
+    assert int((a['indices0'][-1] >= 0).sum()) > 0 and torch.isfinite(a['mscores0'][-1]).all()
+    assert torch.equal(a['indices0'][-1], b['indices0'][-1]) and torch.equal(a['mscores0'][-1], b['mscores0'][-1])
+    if a.get('scores'):
+        assert torch.equal(a['scores'][-1], b['scores'][-1])
+    assert fused._ensure_ctx().resident_health() == (0, 0)
+
+
+def test_fused_layer_time_out_voids_the_call_and_steps_the_context_down():
+    """IMP_WF_FUSED_FAKE=1 (test hook): one workgroup of every fused launch withholds its statistics, so every wait on them times
+    out.  The call still ends (bounded polls), the pair whose exchange failed comes back VOID (NaN descriptors -> no matches - never plausible numbers), the next
+    entry point on the context reports it (IMP_E_RESIDENT -> ResidentSinkhornTimeout), and from then on the context runs the
+    two-launch path: identical to a context that never used the fused kernel."""
+    from imp_release_amd import _lib
+    cfg = eval_config(n_layers=3, sinkhorn_iterations=20)
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=8)
+    fake, plain = _two_models('GM', cfg, sd, {'IMP_WF_FUSED_FAKE': '1'}, {'IMP_WF_FUSED': '0'})
+    pair = synthetic.make_correlated_pair(2048, 2048, seed=5, batch=4)
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+    with torch.no_grad():
+        void = fake.produce_matches(data, p=0.2, only_last=True)
+        torch.cuda.synchronize()
+        # the withheld record belongs to pair 0, image 0: that pair's descriptors are NaN from the first layer on -> no match can pass
+        # (the other pairs of the batch never waited on it)
+        assert bool((void['indices0'][-1][0] == -1).all()) and not bool((void['mscores0'][-1][0] > 0).any())
+        with pytest.raises(_lib.ResidentSinkhornTimeout):
+            fake.produce_matches(data, p=0.2, only_last=True)
+        good = fake.produce_matches(data, p=0.2, only_last=True)
+        want = plain.produce_matches(data, p=0.2, only_last=True)
+    assert torch.equal(good['indices0'][-1], want['indices0'][-1]) and torch.equal(good['mscores0'][-1], want['mscores0'][-1])
+    assert fake._ensure_ctx().resident_health()[0] == 1
+
+
 def test_weight_fragment_gemms_default_rule_agrees_with_gemm_f32():
     """B = 4, N = 2048 (the bench shape) takes the weight-fragment MLP kernels by default: same matches as with them switched off"""
     import os
@@ -562,16 +628,19 @@ def test_evaluation_tail_on_two_view_pairs_with_the_gpu_pose_step(eimp):
     assert rep['precision'] > 60.0 and rep['pose_found'] == 1.0 and rep['auc@20'] > 50.0
 
 
-def test_batch_steps_in_flight_reproduce_the_sequential_results():
+@pytest.mark.parametrize('n0,n1,B', [(1024, 1000, 2), (2048, 2048, 4)])
+def test_batch_steps_in_flight_reproduce_the_sequential_results(n0, n1, B):
     """bench.py's default mode: 3 batch-steps in flight (3 replicas, 3 streams) - every step's result must equal the
-    one-after-the-other result bit for bit"""
+    one-after-the-other result bit for bit.  At the bench geometry (4 x 2048) every layer is a fused launch whose workgroups wait for
+    each other and the Sinkhorn is the chip-resident kernel: the three streams' waiting kernels are serialised by the spin gate
+    (context.hip) - a collision would end in time-outs and NaN results"""
     from imp_release_amd import pipeline
     cfg = eval_config(n_layers=3, sinkhorn_iterations=20)
     sd = synthetic.make_state_dict(cfg, 'GM', seed=1)
     m = make_hip_model('GM', cfg, sd)
     datas = []
     for k in range(4):
-        pair = synthetic.make_correlated_pair(1024, 1000, seed=60 + k, batch=2)
+        pair = synthetic.make_correlated_pair(n0, n1, seed=60 + k, batch=B)
         d = {kk: torch.from_numpy(v).to(DEV) for kk, v in pair.items() if kk != 'image_shape'}
         d['image0'] = d['image1'] = torch.zeros(pair['image_shape'], device=DEV)
         datas.append(d)
@@ -590,7 +659,10 @@ def test_batch_steps_in_flight_reproduce_the_sequential_results():
     par = pipeline.StepPipeline([make_fn(r, i, 3) for i, r in enumerate(reps)], 2, device=DEV).run(8, keep=True)
     for s_, (a, b) in enumerate(zip(seq, par)):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), s_
+        assert torch.isfinite(a[1]).all() and int((a[0] >= 0).sum()) > 0
     assert not torch.equal(seq[0][0], seq[1][0])          # the steps really see different batches
+    for r in [m] + reps:
+        assert r._ensure_ctx().resident_health() == (0, 0)  # no waiting kernel of any replica ever timed out
 
 
 def test_prefetched_dataset_feeds_the_loop_identically(tmp_path):
