@@ -249,9 +249,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--quick-c5', action='store_true', help='configs[4] keys on 48 instead of 1000 pair evaluations (smoke runs)')
     ap.add_argument('--no-batch1', action='store_true', help='skip the extra batch-1 latency keys (profiling runs: keeps their kernels out of the trace)')
-    ap.add_argument('--in-flight', type=int, default=3,
+    ap.add_argument('--in-flight', type=int, default=0,
                     help='batch-steps in flight per GPU (model replicas, one stream + host thread each; the result '
-                         'exchange stays one ordered lane). 1 = strictly one step after the other')
+                         'exchange stays one ordered lane). 1 = strictly one step after the other; 0 (default) = the faster of 1 and 3, '
+                         'decided by a short untimed calibration (round 4: with one step in flight every layer is ONE fused launch, with '
+                         'several the two-launch layers interleave - which wins depends on the box)')
     ap.add_argument('--h2d', action='store_true',
                     help='additionally time the same steps with every batch uploaded from pinned host memory inside the '
                          'step (PCIe-inclusive rate, reported as value_with_h2d; never the headline value)')
@@ -311,14 +313,34 @@ def main():
     # a step = one pass of the matcher over this rank's batch + the exchange of its results.  --steps of them are
     # timed; up to --in-flight overlap on this GPU (independent batch-steps on replicas of the model, one stream and
     # host thread each, ONE ordered exchange lane: pipeline.StepPipeline)
-    inflight = max(1, args.in_flight)
-    replicas = eval_loop.replicate(model, inflight)
-
     def make_step(m):
         def step_fn():
             out = m.produce_matches(data, p=0.2, only_last=True)
             return out['indices0'][-1], out['mscores0'][-1]
         return step_fn
+
+    calibration = None
+    if args.in_flight <= 0:
+        # untimed calibration: the same steps with 1 and with 3 in flight, the faster setting is the one that gets timed
+        cal_steps = 12
+        rates = {}
+        for k_ in (1, 3):
+            reps_ = [model] if k_ == 1 else eval_loop.replicate(model, k_)
+            pp_ = pipeline.StepPipeline([make_step(m) for m in reps_], n_total, device=dev)
+            pp_.run(max(4, k_))
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            pp_.run(cal_steps)
+            torch.cuda.synchronize()
+            rates[k_] = cal_steps / (time.perf_counter() - t0_)
+            del pp_, reps_
+        best_ = torch.tensor([rates[1], rates[3]], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(best_, op=dist.ReduceOp.MIN)        # every rank must take the same setting
+        args.in_flight = 1 if float(best_[0]) >= float(best_[1]) else 3
+        calibration = {'steps_per_s_1_in_flight': rates[1], 'steps_per_s_3_in_flight': rates[3], 'chosen': args.in_flight}
+    inflight = max(1, args.in_flight)
+    replicas = [model] if inflight == 1 else eval_loop.replicate(model, inflight)
 
     pipe = pipeline.StepPipeline([make_step(m) for m in replicas], n_total, device=dev)
 
@@ -340,7 +362,7 @@ def main():
     res, dt = timed(pipe, args.steps)
     # the same number of steps strictly one after the other (one replica), reported next to the headline
     serial_s = None
-    if inflight > 1:
+    if True:
         pipe1 = pipeline.StepPipeline([make_step(model)], n_total, device=dev)
         pipe1.run(1)
         _, dt1 = timed(pipe1, args.steps)
@@ -426,7 +448,8 @@ def main():
                                    f'{B} pairs per GPU (BASELINE configs[2]: batch 32 over 8 GPUs), norm_fn=in, '
                                    f'seeded random weights',
                        'pairs_per_gpu': B, 'keypoints': N, 'parallelism': f'pair-sharded x{world}',
-                       'steps_in_flight_per_gpu': inflight, 'sinkhorn_storage_bytes': args.sinkhorn_storage,
+                       'steps_in_flight_per_gpu': inflight, 'steps_in_flight_calibration': calibration,
+                       'sinkhorn_storage_bytes': args.sinkhorn_storage,
                        'matched_keypoints': n_matched},
             'roofline': {'bound': 'mfma', 'kernel': kname,
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
@@ -455,7 +478,15 @@ def main():
         }
         line['one_step_in_flight'] = None if serial_s is None else {
             'value': n_total * args.steps / serial_s, 'ms_per_step': serial_s / args.steps * 1e3,
-            'note': 'same K steps strictly sequential on one model instance (no overlap between batch-steps)'}
+            'note': 'same K steps strictly sequential on one model instance (no overlap between batch-steps); since round 4 every layer of '
+                    'such a step is ONE fused launch (MLP0 -> InstanceNorm statistics exchange -> MLP3 -> next projection)'}
+        # the layer GEMMs live (HIP events, 20 launches each): the round-3 pair of launches and the fused launch that replaced it
+        try:
+            tl = {w: ctx.time_layer_gemm(B, N, w, -2) * 1e3 for w in (1, 3, 4)}
+            line['layer_gemm_us'] = {'mlp0': tl[1], 'mlp3_plus_projection': tl[3], 'two_launches': tl[1] + tl[3], 'fused_launch': tl[4],
+                                     'note': 'gemm_wf.hip, B x N of this run, back-to-back launches of one kernel (the in-pipeline durations are in profiles/)'}
+        except Exception as e_:        # (shapes the weight-fragment kernels do not take)
+            line['layer_gemm_us'] = {'error': str(e_)[:200]}
         if h2d_s is not None:
             line['value_with_h2d'] = {'value': n_total * args.steps / h2d_s,
                                       'ms_per_step': h2d_s / args.steps * 1e3,

@@ -454,6 +454,7 @@ int wf_pass_split(const imp_ctx* c, long tiles, int N) {
 
 struct SpinGate;
 SpinGate* spin_gate(int device);
+bool spin_gate_shared(int device, hipStream_t st);
 int spin_enter(SpinGate* g, hipStream_t st);
 int spin_leave(SpinGate* g, hipStream_t st);
 
@@ -475,7 +476,7 @@ unsigned next_fused_tag(imp_ctx* c) {
 // device: mlp.0 on cat[x, attention output] -> InstanceNorm statistics exchanged between the tiles of an image -> ReLU -> mlp.3 + bias +
 // residual -> `out` (-> q|k|v of layer NL into nqkv).  NL == nullptr: no chained projection
 int launch_fused_layer(imp_ctx* c, const GnnLayer& L, int batch, const int n[2], const float* const desc[2], float* const out[2],
-                       const GnnLayer* NL, float* const* nqkv, bool next_image, hipStream_t st) {
+                       const GnnLayer* NL, float* const* nqkv, bool next_image, hipStream_t st, unsigned long long* prof = nullptr) {
     const int D = c->D;
     WfParams p;
     memset(&p, 0, sizeof p);
@@ -501,6 +502,7 @@ int launch_fused_layer(imp_ctx* c, const GnnLayer& L, int batch, const int n[2],
     f.tag = next_fused_tag(c);
     f.status = c->fx_status; f.host_status = c->xstatus_hostdev;
     f.fake = c->wf_fused_fake;
+    f.prof = prof;
     SpinGate* gate = spin_gate(c->device);
     if (!gate) return fail(IMP_E_HIP, "spin gate: cannot create events");
     if (int grc = spin_enter(gate, st)) return grc;
@@ -609,7 +611,12 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
     // 4 + 5 FUSED (round 4): one launch for mlp.0 -> InstanceNorm -> ReLU -> mlp.3 (-> the next layer's projection) when every 64-row tile of
     // the launch gets a CU of its own (the tiles of an image wait for each other's statistics inside the kernel) and the launch is large
     // enough to pay for the wait; not under hipGraph capture (the exchange tags are launch parameters).  IMP_WF_FUSED=0 disables
-    if (wf_mlp && c->wf_fused && D == 256 && wf_tiles >= c->wf_fused_min_tiles && wf_tiles <= (long)c->num_cus && c->fx_rec[0]) {
+    // ... and only while this stream has the device's waiting kernels to itself: sections of several streams (batch-steps in flight on replicas)
+    // run strictly one after the other behind cross-stream events, and a waiting kernel that shares the chip with another stream's
+    // ordinary kernel spins on the CUs it got until the rest of its workgroups find room - measured: three steps in flight with fused
+    // layers 985 pairs/s, 1019 with the two-launch layers (which interleave freely), one step in flight 982 vs 957.  IMP_WF_FUSED=2: always
+    if (wf_mlp && c->wf_fused && D == 256 && wf_tiles >= c->wf_fused_min_tiles && wf_tiles <= (long)c->num_cus && c->fx_rec[0] &&
+        (c->wf_fused > 1 || !spin_gate_shared(c->device, st))) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
             const bool can_chain = chain_li >= 0 && chain_li < (int)c->layers.size() && c->wf_chain && c->layers[chain_li].proj_wf && !kmask[0] && !kmask[1];
@@ -774,6 +781,13 @@ SpinGate* spin_gate(int device) {
     gates[device] = g;
     return g;
 }
+// do sections of other streams alternate with `st`'s on this device at the moment?  (a hint for choosing kernels, not a guarantee)
+bool spin_gate_shared(int device, hipStream_t st) {
+    SpinGate* g = spin_gate(device);
+    if (!g) return false;
+    std::lock_guard<std::mutex> lock(g->mu);
+    return g->multi || (g->has_last && g->last_stream != st);
+}
 // enters a gate section on `st` (the mutex stays locked until spin_leave): everything enqueued on `st` from here on runs after the
 // previous section of the device has finished
 int spin_enter(SpinGate* g, hipStream_t st) {
@@ -792,7 +806,7 @@ int spin_enter(SpinGate* g, hipStream_t st) {
         }
         g->same_run = 0;
         if (e != hipSuccess) { g->mu.unlock(); return fail(IMP_E_HIP, std::string("spin gate: ") + hipGetErrorString(e)); }
-    } else if (g->multi && ++g->same_run > 512) {
+    } else if (g->multi && ++g->same_run > 6) {
         g->multi = false;                                // one stream again for a long time: stop recording
     }
     return IMP_OK;
@@ -1916,6 +1930,30 @@ int imp_time_layer_gemm(imp_ctx* c, int batch, int n, int which, int dbg, int re
         return hipErrorInvalidValue;                            // (dbg >= 0 selected the retired planes kernel: tools/probe/gemm_planes.hip)
     };
     HIP_TRY(launch());
+    if (which == 4 && getenv("IMP_WF_PROF")) {       // probe (a -DWF_PROFILE build of the library): phase cycle stamps of every workgroup of one fused launch
+        const int grid = batch * 2 * ((n + 63) / 64);
+        unsigned long long* dprof = nullptr;
+        HIP_TRY(hipMalloc(&dprof, (size_t)grid * 12 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(dprof, 0, (size_t)grid * 12 * sizeof(unsigned long long)));
+        const int nn[2] = {n, n};
+        const float* de[2] = {c->descw[0], c->descw[1]};
+        float* ou[2] = {c->mdesc[0], c->mdesc[1]};
+        for (int rep = 0; rep < 3; ++rep) {
+            if (int prc = launch_fused_layer(c, L, batch, nn, de, ou, &L, c->qkv[0], c->kv_image != 0, st, dprof)) return prc;
+            HIP_TRY(hipStreamSynchronize(st));
+            std::vector<unsigned long long> h((size_t)grid * 12);
+            HIP_TRY(hipMemcpy(h.data(), dprof, h.size() * 8, hipMemcpyDeviceToHost));
+            for (int g = 0; g < 2; ++g) {
+                double a[6] = {}, mx[6] = {};
+                for (int i = 0; i < grid; ++i)
+                    for (int j = 0; j < 6; ++j) { const double v = (double)h[((size_t)i * 2 + g) * 6 + j]; a[j] += v / grid; if (v > mx[j]) mx[j] = v; }
+                fprintf(stderr, "[gemm_wf_fused B=%d n=%d, %d workgroups, group %d] mean (max) cycles: staging %.0f (%.0f)  mlp.0 K loops + block stats %.0f (%.0f)  exchange %.0f (%.0f)  "
+                                "normalise -> planes %.0f (%.0f)  mlp.3 + epilogue %.0f (%.0f)  chained projection %.0f (%.0f)  total %.0f\n",
+                        batch, n, grid, g, a[0], mx[0], a[1], mx[1], a[2], mx[2], a[3], mx[3], a[4], mx[4], a[5], mx[5], a[0] + a[1] + a[2] + a[3] + a[4] + a[5]);
+            }
+        }
+        (void)hipFree(dprof);
+    }
     HIP_TRY(hipEventRecord(e0, st));
     for (int r = 0; r < reps; ++r) HIP_TRY(launch());
     HIP_TRY(hipEventRecord(e1, st));

@@ -66,10 +66,10 @@ __device__ unsigned long long wf_prof[2048][2][4];
 // K loop of one column pass: acc[i] (i = rows 32 i .. 32 i + 31 of the tile) += A . W^T over KK, A fragments from the LDS planes
 // one k-step ahead, weight fragments four k-steps ahead (bh / bl hold the first four k-steps on entry and the first four of
 // `wfollow` on exit)
-template <int KK, int SWAP>
+template <int KK, int SWAP, int KP = KK>            // KP: K extent of the planes (row pitch 2 KP + 16); KK < KP: a K loop over part of the tile's K range
 __device__ __forceinline__ void wf_kloop(f32x16 (&acc)[2], const unsigned char* planes, const int (&aoff)[2], const u32x4* wp, const u32x4* wfollow,
                                          u32x4 (&bh)[4], u32x4 (&bl)[4]) {
-    constexpr int PLANE = WF_TM * (2 * KK + 16);
+    constexpr int PLANE = WF_TM * (2 * KP + 16);
     constexpr int NS = KK / 16;
     f16x8 fah[2][2], fal[2][2];
     auto load_frag = [&](int st, int fb) {
@@ -557,11 +557,10 @@ __device__ __forceinline__ void wf_poll_health(int* status, int* host, int spins
 // value per register pair (r, r + 4): the even lane ends up with columns (k, k + 1) of row rho, the odd lane with the same two
 // columns of row rho + 8 - 4-byte LDS writes of two halves; the 64 lanes of a write cover 4 rows x 16 dwords in distinct banks
 // (row pitch 260 dwords: rows rho, rho + 8, rho + 4, rho + 12 start at banks 0, 32, 16, 48 relative to the first)
-__device__ __forceinline__ void wf_hidden_to_planes(f32x16 (&acc)[2], const float* bias, const float* stl, unsigned char* planes, int cb, const WfLane& L) {
+__device__ __forceinline__ void wf_hidden_to_planes(f32x16 (&acc)[2], float bv, const float* stl, unsigned char* planes, int cb, const WfLane& L) {
     constexpr int PITCH = 2 * 512 + 16, PLANE = WF_TM * PITCH;
     const int lane = L.lane, half = L.half;
     const int col = cb + (lane & 31);
-    const float bv = bias ? bias[col] : 0.f;
     const float mean = stl[2 * col], rstd = stl[2 * col + 1];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -618,37 +617,9 @@ __global__ __launch_bounds__(512) void gemm_wf_fused_kernel(const WfParams p, co
     if (tid == 0) s_dead = 0;
     unsigned char* const tbase = wf_smem + 2 * PLANE;                   // 8 wave-private transposition buffers; before: (mean, rstd) [512][2]
     float* const stl = reinterpret_cast<float*>(tbase);
-    // ---- 1. stage the tile [x | attention output]: 64 rows x 512 fp32 -> hi / lo half planes (rows past M repeat row M - 1)
-    {
-        const float* A = S.A + b * S.sA_b;
-        const float* A2 = S.A2 ? S.A2 + b * S.sA2_b : A;
-        constexpr int F4_ROW = K / 4;
-        constexpr int PER = WF_TM * F4_ROW / 512;
-        f32x4 v[PER];
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const int e = j * 512 + tid;
-            const int r = e / F4_ROW, k = (e - r * F4_ROW) * 4;
-            const int gr = min(row0 + r, M - 1);
-            const float* src = k < p.ksplit ? A + (long)gr * p.lda + k : A2 + (long)gr * p.lda2 + (k - p.ksplit);
-            v[j] = *reinterpret_cast<const f32x4*>(src);
-        }
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            const int e = j * 512 + tid;
-            const int r = e / F4_ROW, k = (e - r * F4_ROW) * 4;
-            u32x2 hi, lo;
-            unsigned a, c;
-            imp_split2(v[j][0], v[j][1], a, c); hi[0] = a; lo[0] = c;
-            imp_split2(v[j][2], v[j][3], a, c); hi[1] = a; lo[1] = c;
-            unsigned char* dst = wf_smem + r * PITCH + k * 2;
-            *reinterpret_cast<u32x2*>(dst) = hi;
-            *reinterpret_cast<u32x2*>(dst + PLANE) = lo;
-        }
-    }
-    __syncthreads();
-    WF_TP(1);
-
+    // ---- 1. stage the tile [x | attention output]: 64 rows x 512 fp32 -> hi / lo half planes (rows past M repeat row M - 1).  All loads
+    // are requested at once; the x half (k < 256) is converted and handed to the matrix pipe first - the first 16 k-steps of every wave's
+    // first column pass run while the attention half is still arriving (all workgroups of the launch stage together: 33.5 MB at the fabric's limit)
     int aoff[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) aoff[i] = (32 * i + (lane & 31)) * PITCH + half * 16;
@@ -660,22 +631,73 @@ __global__ __launch_bounds__(512) void gemm_wf_fused_kernel(const WfParams p, co
     const int rot = blockIdx.x & 1;
     const int passA = grp + 2 * rot, passB = grp + 2 * (1 - rot);
     const int cbA = passA * 128 + w4 * 32, cbB = passB * 128 + w4 * 32;
+    const float bvA = p.bias ? p.bias[cbA + (lane & 31)] : 0.f, bvB = p.bias ? p.bias[cbB + (lane & 31)] : 0.f;     // (held: no global load between the exchange and the planes)
     u32x4 bh[4], bl[4];
-    {
-        const u32x4* w0 = wptr(passA);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { bh[c] = w0[c * 128]; bl[c] = w0[c * 128 + 64]; }
-    }
-#if WF_PRIO
-    if (grp == 0) __builtin_amdgcn_s_setprio(1);
-#endif
     f32x16 accA[2], accB[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accA[i][r] = 0.f; accB[i][r] = 0.f; }
+    {
+        const float* A = S.A + b * S.sA_b;
+        const float* A2 = S.A2 ? S.A2 + b * S.sA2_b : A;
+        constexpr int KH = K / 2;                   // = ksplit for a layer (x | attention output), any ksplit % 4 == 0 works
+        constexpr int F4_ROW = KH / 4;              // float4 per row of a half
+        constexpr int PER = WF_TM * F4_ROW / 512;   // float4 per thread and half
+        f32x4 v[2][PER];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int e = j * 512 + tid;
+                const int r = e / F4_ROW, k = h * KH + (e - r * F4_ROW) * 4;
+                const int gr = min(row0 + r, M - 1);
+                const float* src = k < p.ksplit ? A + (long)gr * p.lda + k : A2 + (long)gr * p.lda2 + (k - p.ksplit);
+                v[h][j] = *reinterpret_cast<const f32x4*>(src);
+            }
+        {
+            const u32x4* w0 = wptr(passA);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { bh[c] = w0[c * 128]; bl[c] = w0[c * 128 + 64]; }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                const int e = j * 512 + tid;
+                const int r = e / F4_ROW, k = h * KH + (e - r * F4_ROW) * 4;
+                u32x2 hi, lo;
+                unsigned a, c;
+                imp_split2(v[h][j][0], v[h][j][1], a, c); hi[0] = a; lo[0] = c;
+                imp_split2(v[h][j][2], v[h][j][3], a, c); hi[1] = a; lo[1] = c;
+                unsigned char* dst = wf_smem + r * PITCH + k * 2;
+                *reinterpret_cast<u32x2*>(dst) = hi;
+                *reinterpret_cast<u32x2*>(dst + PLANE) = lo;
+            }
+            __syncthreads();
+            if (h == 0) {
+                WF_TP(1);
+#if WF_PRIO
+                if (grp == 0) __builtin_amdgcn_s_setprio(1);
+#endif
+                // k-steps 0 .. 15 of the first pass (weights of k-steps 16 .. follow in the fragment stream)
+                wf_kloop<KH, 0, K>(accA, wf_smem, aoff, wptr(passA), wptr(passA) + (KH / 16) * 128, bh, bl);
+#if WF_PRIO
+                if (grp == 0) __builtin_amdgcn_s_setprio(0);
+#endif
+            }
+        }
+    }
+#if WF_PRIO
+    if (grp == 0) __builtin_amdgcn_s_setprio(1);
+#endif
     float sumA, m2A, sumB, m2B;
-    wf_kloop<K, 0>(accA, wf_smem, aoff, wptr(passA), wptr(passB), bh, bl);
+    {
+        int aoff_h[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) aoff_h[i] = aoff[i] + (K / 2) * 2;       // k = 256 .. of the planes
+        wf_kloop<K / 2, 0, K>(accA, wf_smem, aoff_h, wptr(passA) + (K / 32) * 128, wptr(passB), bh, bl);
+    }
     wf_block_stats(accA, p.bias, row0, M, cbA, L, sumA, m2A);
     wf_kloop<K, 0>(accB, wf_smem, aoff, wptr(passB), wptr(passB), bh, bl);      // (after the last pass: a harmless reload - mlp.3's first fragments
     wf_block_stats(accB, p.bias, row0, M, cbB, L, sumB, m2B);                   //  are requested after the exchange: 32 registers less to hold across it)
@@ -734,7 +756,7 @@ __global__ __launch_bounds__(512) void gemm_wf_fused_kernel(const WfParams p, co
                     if (t < T) {
                         const int nt = min(WF_TM, M - t * WF_TM);
                         const double vx = (double)__uint_as_float(raw[u][0]), vy = (double)__uint_as_float(raw[u][2]);
-                        a1 += vx; a2 += vy; a3 += vx * vx / (double)nt;
+                        a1 += vx; a2 += vy; a3 += nt == WF_TM ? vx * vx * (1.0 / WF_TM) : vx * vx / (double)nt;     // (x / 64 == x * 2^-6 exactly: the bits of the division, without it)
                     }
                 }
             }
@@ -774,8 +796,8 @@ __global__ __launch_bounds__(512) void gemm_wf_fused_kernel(const WfParams p, co
     f32x4 rres[2][4];
     if (Rb) wf_load_residual(rres, Rb, p.ldr, row0, M, cb3, lane);
     // ---- 4. the hidden tile, normalised, as half planes over the dead input tile
-    wf_hidden_to_planes(accA, p.bias, stl, wf_smem, cbA, L);
-    wf_hidden_to_planes(accB, p.bias, stl, wf_smem, cbB, L);
+    wf_hidden_to_planes(accA, bvA, stl, wf_smem, cbA, L);
+    wf_hidden_to_planes(accB, bvB, stl, wf_smem, cbB, L);
     if (dead_wg) {                                  // unfinished exchange: this tile's statistics are garbage - its rows must not pass as results
 #pragma unroll
         for (int i = 0; i < 2; ++i)

@@ -628,13 +628,16 @@ def test_evaluation_tail_on_two_view_pairs_with_the_gpu_pose_step(eimp):
     assert rep['precision'] > 60.0 and rep['pose_found'] == 1.0 and rep['auc@20'] > 50.0
 
 
-@pytest.mark.parametrize('n0,n1,B', [(1024, 1000, 2), (2048, 2048, 4)])
-def test_batch_steps_in_flight_reproduce_the_sequential_results(n0, n1, B):
+@pytest.mark.parametrize('n0,n1,B,fused', [(1024, 1000, 2, '1'), (2048, 2048, 4, '1'), (2048, 2048, 4, '2')])
+def test_batch_steps_in_flight_reproduce_the_sequential_results(n0, n1, B, fused, monkeypatch):
     """bench.py's default mode: 3 batch-steps in flight (3 replicas, 3 streams) - every step's result must equal the
     one-after-the-other result bit for bit.  At the bench geometry (4 x 2048) every layer is a fused launch whose workgroups wait for
     each other and the Sinkhorn is the chip-resident kernel: the three streams' waiting kernels are serialised by the spin gate
-    (context.hip) - a collision would end in time-outs and NaN results"""
+    (context.hip) - a collision would end in time-outs and NaN results.  By default a context leaves the fused layer launch alone while
+    other streams share the gate (the two-launch layers interleave better); IMP_WF_FUSED=2 keeps it: then EVERY layer of the three
+    replicas goes through the gate"""
     from imp_release_amd import pipeline
+    monkeypatch.setenv('IMP_WF_FUSED', fused)
     cfg = eval_config(n_layers=3, sinkhorn_iterations=20)
     sd = synthetic.make_state_dict(cfg, 'GM', seed=1)
     m = make_hip_model('GM', cfg, sd)

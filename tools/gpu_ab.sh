@@ -2,7 +2,7 @@
 # same-box A/B of bench.py under environment switches:  gpurun -- bash tools/gpu_ab.sh TAG "ENV1=.. ENV2=.." "ENV..." ...   ("-" = no switch)
 TAG=$1; shift
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
   for E in "$@"; do
     [ "$E" = "-" ] && E=""
     (env $E timeout 300 python bench.py --steps ${STEPS:-60} --warmup 10 --no-cpu-baseline --no-batch1 2>&1 | tail -1 | python -c "
