@@ -493,6 +493,51 @@ def main():
                                       'note': 'every step uploads its batch (keypoints, scores, descriptors of '
                                               'both images) from pinned host memory on the step stream'}
         if world == 1 and not args.no_batch1:
+            # ragged batch (round 4): 4 pairs with N ~ U(1200, 2048) keypoints per image in ONE padded batch under per-pair counts
+            # (include/imp_hip.h imp_set_counts) - what real SuperPoint output looks like; the reference runs such pairs one at a time
+            try:
+                rg = np.random.default_rng(5)
+                sizes = [(int(rg.integers(1200, 2049)), int(rg.integers(1200, 2049))) for _ in range(B)]
+                N0, N1 = max(s_[0] for s_ in sizes), max(s_[1] for s_ in sizes)
+                rd = {}
+                singles = [synthetic.make_correlated_pair(a_, b_, seed=300 + i_) for i_, (a_, b_) in enumerate(sizes)]
+                for key, n_ in (('keypoints0', N0), ('keypoints1', N1), ('scores0', N0), ('scores1', N1), ('descriptors0', N0), ('descriptors1', N1)):
+                    arr = np.zeros((B, n_) + singles[0][key].shape[2:], np.float32)
+                    for i_, sg in enumerate(singles):
+                        arr[i_, :sg[key].shape[1]] = sg[key][0]
+                    rd[key] = torch.from_numpy(arr).to(dev)
+                rd['image0'] = rd['image1'] = data['image0']
+                rd['num_keypoints0'] = [s_[0] for s_ in sizes]; rd['num_keypoints1'] = [s_[1] for s_ in sizes]
+                for _ in range(4):
+                    model.produce_matches(rd, p=0.2, only_last=True)
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for _ in range(30):
+                    ro = model.produce_matches(rd, p=0.2, only_last=True)
+                torch.cuda.synchronize()
+                dtr = time.perf_counter() - t0_
+                # the same pairs one call each (what a batch-1 user pays)
+                sdata = []
+                for sg in singles:
+                    d1 = {k: torch.from_numpy(v).to(dev) for k, v in sg.items() if k != 'image_shape'}
+                    d1['image0'] = d1['image1'] = data['image0']
+                    sdata.append(d1)
+                for d1 in sdata:
+                    model.produce_matches(d1, p=0.2, only_last=True)
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for _ in range(10):
+                    for d1 in sdata:
+                        model.produce_matches(d1, p=0.2, only_last=True)
+                torch.cuda.synchronize()
+                dts = time.perf_counter() - t0_
+                line['ragged_b4_pairs_per_s'] = B * 30 / dtr
+                line['ragged_b4_note'] = {'sizes': sizes, 'matched_keypoints': int((ro['indices0'][-1] >= 0).sum()),
+                                          'same_pairs_one_call_each_pairs_per_s': B * 10 / dts,
+                                          'note': 'GM L=9 T=100, one step in flight; pairs padded to the largest, per-pair counts by imp_set_counts'}
+            except Exception as e_:
+                line['ragged_b4_pairs_per_s'] = None
+                line['ragged_b4_note'] = {'error': str(e_)[:300]}
             # the batch-1 configurations of BASELINE.json on the same GPU (not the metric; recorded so that every round
             # shows them): configs[1] GM N=1024 L=9 T=100 batch 1, and configs[3] the EIMP sliced loop from N=4096
             line.update(batch1_latencies(dev, args))

@@ -26,7 +26,7 @@ SYMBOLS = [
     'imp_last_error', 'imp_version', 'imp_create', 'imp_destroy', 'imp_load_tensor', 'imp_finalize_weights',
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
-    'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_pool_select_pair', 'imp_masked_commit', 'imp_gather_rows', 'imp_match_pair', 'imp_op_linear', 'imp_op_layer_gemm', 'imp_op_fused_mlp',
+    'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_pool_select_pair', 'imp_masked_commit', 'imp_gather_rows', 'imp_match_pair', 'imp_set_counts', 'imp_match_tail', 'imp_op_linear', 'imp_op_layer_gemm', 'imp_op_fused_mlp',
     'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_range_events', 'imp_time_layer_gemm', 'imp_estimate_pose',
     'imp_sp_create', 'imp_sp_destroy', 'imp_sp_set_weight', 'imp_sp_finalize', 'imp_sp_detect', 'imp_sp_describe', 'imp_sp_dense', 'imp_sp_op_conv',
 ]
@@ -111,6 +111,8 @@ def lib():
     L.imp_gather_rows.argtypes = [P, I, I, I, I, P, P, P, P]
     L.imp_masked_commit.argtypes = [P, I, P, P, P, P, P, P, P, I, P, I, P, P, P, P, P]
     L.imp_match_pair.argtypes = [P, I, I, I, P, P, P, P, P, P, F, F, F, I, I, F, P, P, P, P, P, P]
+    L.imp_set_counts.argtypes = [P, I, P, P]
+    L.imp_match_tail.argtypes = [P, I, I, I, I, P, P, F, I, I, F, P, P, P, P, P]
     L.imp_op_linear.argtypes = [P, I, I, I, P, P, P, P, P]
     L.imp_op_layer_gemm.argtypes = [P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, P, I, P]
     L.imp_op_fused_mlp.argtypes = [P, I, I, P, P, P, P, P, P, P, P, I, P, P, I, P]
@@ -408,6 +410,33 @@ class Context:
             float(width), float(height), float(bin_score), int(iterations), 1 if with_sinkhorn else 0, float(p),
             _ptr(out['indices0']), _ptr(out['mscores0']), _ptr(out.get('indices1')), _ptr(out.get('mscores1')),
             _ptr(out.get('scores')), _stream(self.device)))
+        return out
+
+    def set_counts(self, n0=None, n1=None):
+        """ragged batches (include/imp_hip.h imp_set_counts): per-pair keypoint counts (host sequences) that the NEXT calls on this
+        context obey - tensors stay padded to the largest pair; ``set_counts()`` returns to uniform batches"""
+        if n0 is None and n1 is None:
+            self._check(self.L.imp_set_counts(self.handle, 0, None, None))
+            return
+        a0 = (C.c_int32 * len(n0))(*[int(v) for v in n0])
+        a1 = (C.c_int32 * len(n1))(*[int(v) for v in n1])
+        if len(n0) != len(n1):
+            raise ValueError('set_counts: one count per pair and image')
+        self._check(self.L.imp_set_counts(self.handle, len(n0), a0, a1))
+
+    def match_tail(self, layer_id, desc0, desc1, bin_score, iterations, with_sinkhorn, p, want_side1=False):
+        """final projection of iteration `layer_id` -> distance -> Sinkhorn -> mutual matches without a score tensor
+        (include/imp_hip.h imp_match_tail); obeys set_counts"""
+        desc0, desc1 = _f32(desc0, 'desc0'), _f32(desc1, 'desc1')
+        B, n0, n1 = desc0.shape[0], desc0.shape[1], desc1.shape[1]
+        dev = desc0.device
+        out = {'indices0': torch.empty(B, n0, device=dev, dtype=torch.int64), 'mscores0': torch.empty(B, n0, device=dev, dtype=torch.float32)}
+        if want_side1:
+            out['indices1'] = torch.empty(B, n1, device=dev, dtype=torch.int64)
+            out['mscores1'] = torch.empty(B, n1, device=dev, dtype=torch.float32)
+        self._check(self.L.imp_match_tail(self.handle, int(layer_id), B, n0, n1, _ptr(desc0), _ptr(desc1), float(bin_score), int(iterations),
+                                          1 if with_sinkhorn else 0, float(p), _ptr(out['indices0']), _ptr(out['mscores0']),
+                                          _ptr(out.get('indices1')), _ptr(out.get('mscores1')), _stream(self.device)))
         return out
 
     def op_linear(self, x, W, bias=None):

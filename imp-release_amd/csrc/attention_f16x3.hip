@@ -86,14 +86,14 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_f16x3_kernel(const AttnPa
     const int sidx = id % p.nside;
     const int b = id / p.nside;
     const AttnSide& S = p.side[sidx];
-    const int nq = S.nq, nk = S.nk;
+    const int nq = imp_count(p.rc, S.qimg, b, S.nq), nk = imp_count(p.rc, S.kimg, b, S.nk);      // ragged batches: this pair's own counts; S.nq / S.nk = the padded layout
     const int q0 = qt * (NWAVES * 32);
-    if (q0 >= nq) return;
+    if (q0 >= nq || nk <= 0) return;
 
     const float* Qg = S.q + b * S.sq_b + h * DH;
     const float* Kg = S.k + b * S.sk_b + h * DH;
     const float* Vg = S.v + b * S.sk_b + h * DH;
-    const uint8_t* mk = S.kmask ? S.kmask + (long)b * nk : nullptr;
+    const uint8_t* mk = S.kmask ? S.kmask + (long)b * S.nk : nullptr;
 
     // Q fragments: lane (query l31, half) holds d = 16 s + 8 half .. + 7 for k-step s, as hi / lo halves
     f16x8 qh[KS], ql[KS];
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_f16x3_kernel(const AttnPa
             ot[l31 * LDO + d * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = oacc[d][r] / l_tot;
     if (S.lse && half == 0) {
         const int qrow = q0 + wave * 32 + l31;
-        if (qrow < nq) S.lse[((long)b * IMP_NUM_HEADS + h) * nq + qrow] = m_run + logf(l_tot);
+        if (qrow < nq) S.lse[((long)b * IMP_NUM_HEADS + h) * S.nq + qrow] = m_run + logf(l_tot);
     }
     __syncthreads();
     store_attention_rows<DH>(p, S, b, h, q0 + wave * 32, nq, ot, LDO, lane);
@@ -393,9 +393,9 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     const int sidx = id % p.nside;
     const int b = id / p.nside;
     const AttnSide& S = p.side[sidx];
-    const int nq = S.nq, nk = S.nk;
+    const int nq = imp_count(p.rc, S.qimg, b, S.nq), nk = imp_count(p.rc, S.kimg, b, S.nk);      // ragged batches: this pair's own counts; S.nq / S.nk = the padded layout
     const int q0 = qt * 256;
-    if (q0 >= nq) return;
+    if (q0 >= nq || nk <= 0) return;
 
     const int nt_all = (nk + KT - 1) / KT, t_per = (nt_all + nsplit - 1) / nsplit;
     const int t0 = sp * t_per;
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     const float* Qg = S.q + b * S.sq_b + h * DH;
     const float* Kg = S.k + b * S.sk_b + h * DH;
     const float* Vg = S.v + b * S.sk_b + h * DH;
-    const uint8_t* mk = S.kmask ? S.kmask + (long)b * nk : nullptr;
+    const uint8_t* mk = S.kmask ? S.kmask + (long)b * S.nk : nullptr;
 
     f16x8 qh[KS], ql[KS];
     {
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
             if (half == 0) {
                 wq[l31 * 8 + 7] = L;                          // (nsplit <= 7)
                 const int qrow = q0 + wave * 32 + l31;
-                if (S.lse && qrow < nq) S.lse[((long)b * IMP_NUM_HEADS + h) * nq + qrow] = mmax * (1.0f / LOG2E) + logf(L);
+                if (S.lse && qrow < nq) S.lse[((long)b * IMP_NUM_HEADS + h) * S.nq + qrow] = mmax * (1.0f / LOG2E) + logf(L);
             }
         }
         __syncthreads();
@@ -790,7 +790,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
             ot[l31 * LDO + d * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = oacc[d][r] / l_tot;
     if (S.lse && half == 0) {
         const int qrow = q0 + wave * 32 + l31;
-        if (qrow < nq) S.lse[((long)b * IMP_NUM_HEADS + h) * nq + qrow] = m_ref * (1.0f / LOG2E) + logf(l_tot);
+        if (qrow < nq) S.lse[((long)b * IMP_NUM_HEADS + h) * S.nq + qrow] = m_ref * (1.0f / LOG2E) + logf(l_tot);
     }
     __syncthreads();
     store_attention_rows<DH>(p, S, b, h, q0 + wave * 32, nq, ot, LDO, lane);
@@ -832,7 +832,7 @@ int attention_f16x3_splits(const AttnParams& p, int batch) {
     static const int force = [] { const char* e = getenv("IMP_ATTN_SPLIT"); return e ? atoi(e) : 0; }();
     int maxq = p.side[0].nq, mink = p.side[0].nk;
     if (p.nside == 2) { if (p.side[1].nq > maxq) maxq = p.side[1].nq; if (p.side[1].nk < mink) mink = p.side[1].nk; }
-    if (!p.split_ws || !p.split_cnt || maxq <= 192 || force == 1) return 1;
+    if (!p.split_ws || !p.split_cnt || maxq <= 192 || force == 1 || p.rc.on) return 1;       // (ragged batches: a pair's key range may be shorter than a split's share)
     const long wg = (long)((maxq + 255) / 256) * IMP_NUM_HEADS * p.nside * batch;
     const int tiles = (mink + KT - 1) / KT;
     int s = 1;

@@ -55,14 +55,14 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES == 4 ? 2 : 1)) void attn_f32_k
     const int sidx = id % p.nside;
     const int b = id / p.nside;
     const AttnSide& S = p.side[sidx];
-    const int nq = S.nq, nk = S.nk;
+    const int nq = imp_count(p.rc, S.qimg, b, S.nq), nk = imp_count(p.rc, S.kimg, b, S.nk);      // ragged batches: this pair's own counts; S.nq / S.nk = the padded layout
     const int q0 = qt * (NWAVES * 32);
-    if (q0 >= nq) return;
+    if (q0 >= nq || nk <= 0) return;
 
     const float* Qg = S.q + b * S.sq_b + h * DH;
     const float* Kg = S.k + b * S.sk_b + h * DH;
     const float* Vg = S.v + b * S.sk_b + h * DH;
-    const uint8_t* mk = S.kmask ? S.kmask + (long)b * nk : nullptr;
+    const uint8_t* mk = S.kmask ? S.kmask + (long)b * S.nk : nullptr;
 
     // Q fragment: lane (query l31, half) holds Q[q][half*QS + s], s = 0..QS-1
     float qreg[QS];
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES == 4 ? 2 : 1)) void attn_f32_k
             ot[l31 * LDO + d * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = oacc[d][r] / l_tot;
     if (S.lse && half == 0) {
         const int qrow = q0 + wave * 32 + l31;
-        if (qrow < nq) S.lse[((long)b * IMP_NUM_HEADS + h) * nq + qrow] = m_run + logf(l_tot);
+        if (qrow < nq) S.lse[((long)b * IMP_NUM_HEADS + h) * S.nq + qrow] = m_run + logf(l_tot);
     }
     __syncthreads();
     float* Og = S.out + b * S.so_b + h * DH;

@@ -112,6 +112,8 @@ struct imp_ctx {
     unsigned fx_tag = 0;     // tag of the last fused launch (tags never repeat on fx_rec / fx_fin)
     size_t fx_rec_floats = 0, fx_fin_floats = 0;
     int* fx_status = nullptr;   // device word the waiters of a fused launch watch (3 = a wait timed out)
+    RaggedCounts rc{};       // imp_set_counts: per-pair keypoint counts of the NEXT calls (rc.on = 0: uniform batches); rc_batch pairs
+    int rc_batch = 0;
     int ot_lane = 0;         // IMP_OT_LANE=1: resident Sinkhorn launches go through the device's lane stream (rounds 2-3) instead of the caller's stream under the spin gate
     int use_wf = 1;          // weight-fragment GEMMs (gemm_wf.hip) for the layer convolutions when f16x3, D = 256, relu + InstanceNorm; IMP_GEMM_WF=0 disables
     float* attn_split_ws = nullptr;        // key-split scratch of the attention kernel (grown on demand, allocs_x)
@@ -328,7 +330,17 @@ int check_ready(imp_ctx* c, int batch, int n0, int n1) {
     if (batch < 1 || n0 < 1 || n1 < 1) return fail(IMP_E_ARG, "batch, n0, n1 must be >= 1");
     HIP_TRY(hipSetDevice(c->device));
     if (int hrc = resident_health(c)) return hrc;
+    if (c->rc.on) {
+        if (batch != c->rc_batch) return fail(IMP_E_ARG, "per-pair keypoint counts are set for " + std::to_string(c->rc_batch) + " pairs (imp_set_counts), the call has " + std::to_string(batch));
+        for (int b = 0; b < batch; ++b)
+            if (c->rc.n[0][b] > n0 || c->rc.n[1][b] > n1) return fail(IMP_E_ARG, "a per-pair keypoint count (imp_set_counts) exceeds the padded size of the call");
+    }
     return ensure_workspace(c, batch, n0 > n1 ? n0 : n1);
+}
+// the per-pair counts of a ragged batch into a launch's parameter block (side s = image s unless the launch says otherwise)
+template <typename P> void apply_ragged(const imp_ctx* c, P& p) {
+    p.rc = c->rc;
+    p.side[0].img = 0; p.side[1].img = 1;
 }
 
 // attention launch; in f16x3 mode the context lends its key-split scratch (grown on demand) for launches too small to fill the chip
@@ -379,6 +391,7 @@ int linear_both(imp_ctx* c, const Linear& L, int batch, const int n[2], const fl
         g.sA_b = (long)n[s] * ldx; g.sC_b = (long)n[s] * ldy;
     }
     p.bias = L.b; p.lda = ldx; p.ldw = L.in; p.ldc = ldy;
+    apply_ragged(c, p);
     HIP_TRY(launch_gemm_f32(p, batch, st));
     return IMP_OK;
 }
@@ -399,7 +412,7 @@ int run_kenc(imp_ctx* c, int batch, const int n[2], const float* const kpts[2], 
                         c->stats[1] + (size_t)c->cap_b * tiles_cap * 2 * D * 2};
     Kenc0Side ks[2];
     for (int s = 0; s < 2; ++s) ks[s] = Kenc0Side{kpts[s], scores[s], c->kbuf[s][0], in_norm ? kstats[s] : nullptr, n[s]};
-    HIP_TRY(launch_kenc_first(ks, batch, c->kenc[0].out, c->kenc[0].W, c->kenc[0].b, width, height, st));
+    HIP_TRY(launch_kenc_first(ks, batch, c->kenc[0].out, c->kenc[0].W, c->kenc[0].b, width, height, st, &c->rc));
     int in_rows = 64;                                            // kenc_first: 64-token statistics blocks
     const int maxn = n[0] > n[1] ? n[0] : n[1];
     int cur = 0;
@@ -419,7 +432,7 @@ int run_kenc(imp_ctx* c, int batch, const int n[2], const float* const kpts[2], 
         if (in_norm) {
             StatsSide ss[2];
             for (int s = 0; s < 2; ++s) ss[s] = StatsSide{kstats[s] + ((i - 1) & 1) * slot, c->nstat[s], (n[s] + in_rows - 1) / in_rows, n[s], in_rows};
-            HIP_TRY(launch_stats_finalize(ss, 2, batch, L.in, 1e-3f, st));
+            HIP_TRY(launch_stats_finalize(ss, 2, batch, L.in, 1e-3f, st, &c->rc));
         }
         for (int s = 0; s < 2; ++s) {
             GemmSide& g = p.side[s];
@@ -435,6 +448,7 @@ int run_kenc(imp_ctx* c, int batch, const int n[2], const float* const kpts[2], 
             }
         }
         p.bias = L.b; p.lda = L.in; p.ldw = L.in; p.ldc = last ? D : L.out; p.ldr = D;
+        apply_ragged(c, p);
         HIP_TRY(launch_gemm_f32(p, batch, st));
         in_rows = srows;
         cur ^= 1;
@@ -495,6 +509,7 @@ int launch_fused_layer(imp_ctx* c, const GnnLayer& L, int batch, const int n[2],
         if (next_image) p.kv_image_col2 = NL->shared ? 0 : D;
     }
     p.pass_split = 1;
+    apply_ragged(c, p);
     WfFused f;
     memset(&f, 0, sizeof f);
     f.Wf3_ = L.mlp3_wf; f.bias3 = L.mlp3.b;
@@ -562,6 +577,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
         p.Wf_ = L.proj_wf; p.bias = L.proj.b; p.lda = D; p.ldc = 3 * D;
         if (kv_image) p.kv_image_col = L.shared ? 0 : D;     // (a sharing layer's launch writes the value slot only)
         p.pass_split = wf_pass_split(c, wf_tiles, p.N);
+        apply_ragged(c, p);
         HIP_TRY(launch_gemm_wf(p, batch, st));
     } else {
         GemmParams p = gemm_defaults(c, D);
@@ -572,8 +588,10 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
             g.sA_b = (long)n[s] * D; g.sC_b = (long)n[s] * 3 * D;
         }
         p.bias = L.proj.b; p.lda = D; p.ldw = D; p.ldc = 3 * D;
+        apply_ragged(c, p);
         HIP_TRY(launch_gemm_f32(p, batch, st));
     }
+    if (c->rc.on && (kmask[0] || kmask[1])) return fail(IMP_E_ARG, "key masks and per-pair keypoint counts (imp_set_counts) exclude each other");
     if (!L.shared) {
         for (int img = 0; img < 2; ++img) {
             cache.masked[img] = kmask[img] != nullptr;
@@ -597,7 +615,9 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
             g.kmask = cache.masked[src] ? c->cmask[kind][src] : nullptr;
             g.sq_b = (long)n[s] * 3 * D; g.sk_b = (long)n[src] * 3 * D; g.so_b = (long)n[s] * D;
             g.nq = n[s]; g.nk = n[src];
+            g.qimg = s; g.kimg = src;
         }
+        a.rc = c->rc;
         a.kv_planes = kv_image ? 1 : 0;
         if (int arc = launch_attention(c, a, batch, st)) return arc;
     }
@@ -644,6 +664,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
         p.stat_cnt = c->stat_cnt; p.norm_eps = 1e-3f;
         p.Wf_ = L.mlp0f_wf; p.bias = M0.b; p.lda = D; p.lda2 = D; p.ldc = 2 * D;
         p.pass_split = wf_pass_split(c, wf_tiles, p.N);
+        apply_ragged(c, p);
         HIP_TRY(launch_gemm_wf(p, batch, st));
     } else {
         GemmParams p = gemm_defaults(c, 2 * D);
@@ -656,11 +677,12 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
         }
         if (in_norm) p.flags |= GEMM_EPI_STATS;
         p.bias = M0.b; p.lda = D; p.lda2 = D; p.ldw = 2 * D; p.ldc = 2 * D;
+        apply_ragged(c, p);
         HIP_TRY(launch_gemm_f32(p, batch, st));
         if (in_norm) {
             StatsSide ss[2];
             for (int s = 0; s < 2; ++s) ss[s] = StatsSide{c->stats[s], c->nstat[s], (n[s] + bm0 - 1) / bm0, n[s], bm0};
-            HIP_TRY(launch_stats_finalize(ss, 2, batch, 2 * D, 1e-3f, st));
+            HIP_TRY(launch_stats_finalize(ss, 2, batch, 2 * D, 1e-3f, st, &c->rc));
         }
     }
     // 5. norm + activation while staging, conv 3, bias, residual add -> new descriptors; CHAIN: + the next layer's projection
@@ -691,6 +713,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
             p.pass_split = 1;
             if (chained) *chained = true;
         }
+        apply_ragged(c, p);
         HIP_TRY(launch_gemm_wf(p, batch, st));
     } else {
         GemmParams p = gemm_defaults(c, 2 * D);
@@ -707,6 +730,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
             g.in_stats = in_norm ? c->nstat[s] : nullptr;
         }
         p.bias = L.mlp3.b; p.lda = 2 * D; p.ldw = 2 * D; p.ldc = D; p.ldr = D;
+        apply_ragged(c, p);
         HIP_TRY(launch_gemm_f32(p, batch, st));
     }
     return IMP_OK;
@@ -727,6 +751,7 @@ int run_distance(imp_ctx* c, int layer_id, int batch, const int n[2], const floa
     p.lda = D; p.ldw = D; p.ldc = n[1];
     p.flags = GEMM_EPI_DIV;
     p.div = (float)std::sqrt((double)D);      // dist / descriptor_dim ** .5   nets/gm.py:294
+    p.rc = c->rc; p.side[0].img = 0;          // (ragged batches: rows past a pair's own n0 are skipped; columns are computed to the padded n1 and never read)
     HIP_TRY(launch_gemm_f32(p, batch, st));
     return IMP_OK;
 }
@@ -967,6 +992,7 @@ int run_score_resident_launch(imp_ctx* c, int batch, int b0, int nb, int n0, int
     p.dist = dist + (size_t)b0 * n0 * n1; p.B = nb; p.n0 = n0; p.n1 = n1; p.T = iterations; p.G = G; p.bin = bin;
     p.xpart = c->xpart; p.xv = c->xv; p.xmax = c->xmax; p.status = c->xstatus;
     p.local = local; p.xhalf = c->xhalf;
+    p.rc = c->rc;
     p.tag_base = resident_tags(c, iterations);
     resident_health_params(c, &p);
     if (want_uv) {
@@ -1014,6 +1040,7 @@ int run_score_resident_graph(imp_ctx* c, int batch, int n0, int n1, const float*
     p.dist = dist; p.B = batch; p.n0 = n0; p.n1 = n1; p.T = iterations; p.G = G; p.bin = bin;
     p.xpart = c->xpart; p.xv = c->xv; p.xmax = c->xmax; p.status = c->xstatus;
     p.local = local; p.xhalf = c->xhalf;
+    p.rc = c->rc;
     p.host_status = c->xstatus_hostdev;
     p.dev_base = reinterpret_cast<unsigned*>(c->xstatus) + 16;
     p.xcc_tickets = reinterpret_cast<unsigned*>(c->xstatus) + 20;
@@ -1054,6 +1081,8 @@ int run_score(imp_ctx* c, int batch, int n0, int n1, const float* dist, float bi
     ot_layout(c, n0, n1, &o);
     const int dual = with_sinkhorn ? 0 : 1;
     if (max_done) *max_done = false;
+    if (c->rc.on && (dual || scores || !max_done))
+        return fail(IMP_E_ARG, "ragged batches (imp_set_counts) take the fused score + matches path only: Sinkhorn scorer, no score tensor (imp_match_pair / imp_match_tail)");
     if (!dual && (scores || max_done)) {
         const int rr = run_score_resident(c, batch, n0, n1, dist, bin, iterations, scores, max_done != nullptr, true, st);
         if (rr < 0) return rr;
@@ -1063,6 +1092,8 @@ int run_score(imp_ctx* c, int batch, int n0, int n1, const float* dist, float bi
             return IMP_OK;
         }
     }
+    if (c->rc.on)
+        return fail(IMP_E_ARG, "ragged batch beyond the chip-resident Sinkhorn kernel (sizes, or the context fell back to the streaming kernels): run these pairs one call each");
     HIP_TRY(launch_ot_init(dist, batch, n0, n1, bin, dual, o, st));
     if (dual) HIP_TRY(launch_ot_dual_lse(batch, n0, n1, o, st));
     else HIP_TRY(launch_ot_iterations(batch, n0, n1, iterations, o, st));
@@ -1556,6 +1587,7 @@ int imp_match_pair(imp_ctx* c, int batch, int n0, int n1, const float* kpts0, co
     int rc = check_ready(c, batch, n0, n1);
     if (rc) return rc;
     if (!kpts0 || !kpts1 || !scores0 || !scores1 || !desc0 || !desc1) return fail(IMP_E_ARG, "imp_match_pair: null input");
+    if (c->rc.on && scores) return fail(IMP_E_ARG, "imp_match_pair: no score tensor for a ragged batch (imp_set_counts): every pair's dustbin row / column sits elsewhere");
     hipStream_t st = S(stream);
     const int n[2] = {n0, n1};
     const float* kp[2] = {kpts0, kpts1};
@@ -1578,7 +1610,42 @@ int imp_match_pair(imp_ctx* c, int batch, int n0, int n1, const float* kpts0, co
     if ((rc = run_score(c, batch, n0, n1, c->dist, bin_score, sinkhorn_iterations, with_sinkhorn, scores, &o, st, &max_done))) return rc;
     if (!max_done) HIP_TRY(launch_ot_maxima(batch, n0, n1, with_sinkhorn ? 0 : 1, o, c->max0, c->arg0, c->max1, c->arg1, st));
     HIP_TRY(launch_mutual_matches(batch, n0, n1, c->max0, c->arg0, c->max1, c->arg1, p, indices0, indices1, mscores0,
-                                  mscores1, c->range_hostdev, st));
+                                  mscores1, c->range_hostdev, st, &c->rc));
+    return IMP_OK;
+}
+
+int imp_match_tail(imp_ctx* c, int layer_id, int batch, int n0, int n1, const float* desc0, const float* desc1, float bin_score,
+                   int sinkhorn_iterations, int with_sinkhorn, float p, int64_t* indices0, float* mscores0, int64_t* indices1,
+                   float* mscores1, void* stream) {
+    int rc = check_ready(c, batch, n0, n1);
+    if (rc) return rc;
+    if (!desc0 || !desc1) return fail(IMP_E_ARG, "imp_match_tail: null descriptors");
+    hipStream_t st = S(stream);
+    const int n[2] = {n0, n1};
+    const float* de[2] = {desc0, desc1};
+    if ((rc = run_distance(c, layer_id, batch, n, de, c->dist, st))) return rc;
+    OtBuffers o;
+    bool max_done = false;
+    if ((rc = run_score(c, batch, n0, n1, c->dist, bin_score, sinkhorn_iterations, with_sinkhorn, nullptr, &o, st, &max_done))) return rc;
+    if (!max_done) HIP_TRY(launch_ot_maxima(batch, n0, n1, with_sinkhorn ? 0 : 1, o, c->max0, c->arg0, c->max1, c->arg1, st));
+    HIP_TRY(launch_mutual_matches(batch, n0, n1, c->max0, c->arg0, c->max1, c->arg1, p, indices0, indices1, mscores0,
+                                  mscores1, c->range_hostdev, st, &c->rc));
+    return IMP_OK;
+}
+
+int imp_set_counts(imp_ctx* c, int batch, const int32_t* n0, const int32_t* n1) {
+    if (!c) return fail(IMP_E_ARG, "null context");
+    if (!n0 && !n1) { c->rc.on = 0; c->rc_batch = 0; return IMP_OK; }
+    if (!n0 || !n1 || batch < 1 || batch > IMP_RAGGED_MAX)
+        return fail(IMP_E_ARG, "imp_set_counts: 1 .. " + std::to_string(IMP_RAGGED_MAX) + " pairs, both count arrays (or both null to clear)");
+    for (int b = 0; b < batch; ++b) {
+        if (n0[b] < 0 || n1[b] < 0 || ((n0[b] == 0) != (n1[b] == 0)))
+            return fail(IMP_E_ARG, "imp_set_counts: counts must be positive, or 0 for BOTH images of a retired pair");
+        c->rc.n[0][b] = n0[b]; c->rc.n[1][b] = n1[b];
+    }
+    for (int b = batch; b < IMP_RAGGED_MAX; ++b) c->rc.n[0][b] = c->rc.n[1][b] = 0;
+    c->rc.on = 1;
+    c->rc_batch = batch;
     return IMP_OK;
 }
 

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 3) void gemm_f32_kernel(const GemmP
     const int sub = z % p.nsub;
     const int b = z / p.nsub;
     const GemmSide& S = p.side[sidx];
-    const int M = S.M, N = S.N, K = p.K;
+    const int Mpad = S.M;                                   // strides and the statistics layout follow the padded size
+    const int M = imp_count(p.rc, S.img, b, Mpad), N = S.N, K = p.K;      // (ragged batches: this pair's own row count; 0 = retired pair)
     const int row0 = rtile * BM, col0 = ctile * BN;
     if (row0 >= M || col0 >= N) return;     // uniform per workgroup, before any barrier
 
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 3) void gemm_f32_kernel(const GemmP
         const int blk_row0 = row0 + wm * WM;
         const int cnt = min(WM, M - blk_row0);                    // valid rows of this block (<= 0: nothing to report)
         if (cnt > 0) {
-            const int tiles_side = (M + WM - 1) / WM;             // dense per side: [b][block][N][2]
+            const int tiles_side = (Mpad + WM - 1) / WM;          // dense per side: [b][block][N][2]
             float* os = S.out_stats + ((long)b * tiles_side + (rtile * 2 + wm)) * N * 2;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
@@ -428,29 +429,32 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 3) void gemm_f32_kernel(const GemmP
 // (the last two terms are the between-block part sum_t n_t (mean_t - mean)^2; in fp64 their cancellation costs
 // (mean / std)^2 x 2^-53 relative - nothing for any fp32-representable channel).  Workgroup = 64 channels x 4 block groups
 // (group g takes blocks g, g + 4, ...; 4 independent loads in flight), combined through LDS in a fixed order.
-__global__ __launch_bounds__(256) void stats_finalize_kernel(StatsSide s0, StatsSide s1, int K, float eps) {
+__global__ __launch_bounds__(256) void stats_finalize_kernel(StatsSide s0, StatsSide s1, int K, float eps, RaggedCounts rc) {
     __shared__ double sm[4][3][64];
     const StatsSide& S = blockIdx.y == 0 ? s0 : s1;
     const int b = blockIdx.z;
+    const int M = imp_count(rc, blockIdx.y, b, S.M);                          // ragged batches: this pair's own row count (the sides are image 0, image 1)
+    if (M <= 0) return;                                                       // retired pair
+    const int tiles = rc.on ? (M + S.tile_rows - 1) / S.tile_rows : S.tiles;  // blocks that were written; the layout keeps S.tiles per pair
     const int cx = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + cx;
     double a1 = 0.0, a2 = 0.0, a3 = 0.0;
     if (k < K) {
         const float2* st = reinterpret_cast<const float2*>(S.part) + (long)b * S.tiles * K + k;
         int t = g;
-        for (; t + 12 < S.tiles; t += 16) {
+        for (; t + 12 < tiles; t += 16) {
             float2 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) v[u] = st[(long)(t + 4 * u) * K];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int nt = min(S.tile_rows, S.M - (t + 4 * u) * S.tile_rows);
+                const int nt = min(S.tile_rows, M - (t + 4 * u) * S.tile_rows);
                 a1 += (double)v[u].x; a2 += (double)v[u].y; a3 += (double)v[u].x * (double)v[u].x / (double)nt;
             }
         }
-        for (; t < S.tiles; t += 4) {
+        for (; t < tiles; t += 4) {
             const float2 v = st[(long)t * K];
-            const int nt = min(S.tile_rows, S.M - t * S.tile_rows);
+            const int nt = min(S.tile_rows, M - t * S.tile_rows);
             a1 += (double)v.x; a2 += (double)v.y; a3 += (double)v.x * (double)v.x / (double)nt;
         }
     }
@@ -460,12 +464,12 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(StatsSide s0, Stats
         const double s1t = (sm[0][0][cx] + sm[1][0][cx]) + (sm[2][0][cx] + sm[3][0][cx]);
         const double m2w = (sm[0][1][cx] + sm[1][1][cx]) + (sm[2][1][cx] + sm[3][1][cx]);
         const double sqn = (sm[0][2][cx] + sm[1][2][cx]) + (sm[2][2][cx] + sm[3][2][cx]);
-        const double mean = s1t / (double)S.M;
-        double m2 = m2w + (sqn - (double)S.M * mean * mean);
+        const double mean = s1t / (double)M;
+        double m2 = m2w + (sqn - (double)M * mean * mean);
         m2 = m2 < 0.0 ? 0.0 : m2;
         float2 o;
         o.x = (float)mean;
-        o.y = (float)(1.0 / sqrt(m2 / (double)S.M + (double)eps));       // biased variance, eps inside the root (nets/layers.py:67-68)
+        o.y = (float)(1.0 / sqrt(m2 / (double)M + (double)eps));       // biased variance, eps inside the root (nets/layers.py:67-68)
         reinterpret_cast<float2*>(S.out)[(long)b * K + k] = o;
     }
 }
@@ -542,8 +546,10 @@ hipError_t launch_gemm_f32(const GemmParams& p, int batch, hipStream_t stream) {
     return gemm_launch_pro<64, 64>(p, pro, grid, stream);
 }
 
-hipError_t launch_stats_finalize(const StatsSide sides[2], int nside, int batch, int K, float eps, hipStream_t stream) {
+hipError_t launch_stats_finalize(const StatsSide sides[2], int nside, int batch, int K, float eps, hipStream_t stream, const RaggedCounts* rc) {
+    RaggedCounts r;
+    if (rc) r = *rc; else r.on = 0;
     hipLaunchKernelGGL(stats_finalize_kernel, dim3((K + 63) / 64, nside, batch), dim3(256), 0, stream, sides[0],
-                       sides[nside - 1], K, eps);
+                       sides[nside - 1], K, eps, r);
     return hipGetLastError();
 }

@@ -237,9 +237,9 @@ __device__ __forceinline__ void wf_block_stats(const f32x16 (&acc)[2], const flo
 // ... written through to memory (the finalizing workgroup may sit on another XCD).  Called ONCE per wave, after its last pass: a
 // write-through store is acknowledged only by the memory side (microseconds), and a wave's loads and stores retire in order - a
 // statistics store between two passes stalled the next pass's first wait for weights (measured: +10 us per launch)
-__device__ __forceinline__ void wf_store_stats(float* out_stats, int b, int rtile, int M, int N, int cb, const WfLane& L, float sum, float m2) {
+__device__ __forceinline__ void wf_store_stats(float* out_stats, int b, int rtile, int Mpad, int N, int cb, const WfLane& L, float sum, float m2) {
     if (L.half == 0) {
-        const int tiles_side = (M + WF_TM - 1) / WF_TM;            // the buffer is [b][this side's blocks][N][2]
+        const int tiles_side = (Mpad + WF_TM - 1) / WF_TM;         // the buffer is [b][this side's blocks (of the padded size)][N][2]
         float* o = out_stats + (((long)b * tiles_side + rtile) * N + cb) * 2;      // wave-uniform base, lane = column
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)o, 0, 32u * 8u, 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(sum), __float_as_uint(m2)}, rs, (L.lane & 31) * 8, 0, AUX_SC1);
@@ -278,7 +278,8 @@ __global__ __launch_bounds__(512) void gemm_wf_kernel(const WfParams p, int row_
     const int sidx = z % p.nside;
     const int b = z / p.nside;
     const WfSide& S = p.side[sidx];
-    const int M = S.M, N = p.N;
+    const int Mpad = S.M;                           // strides and the statistics layout follow the padded size
+    const int M = imp_count(p.rc, S.img, b, Mpad), N = p.N;     // ragged batches: this pair's own row count (0 = retired pair)
     const int row0 = rtile * WF_TM;
     if (row0 >= M) return;                          // uniform per workgroup, before any barrier
     WF_T(t_begin);
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(512) void gemm_wf_kernel(const WfParams p, int row_
             // stall nothing): their acknowledgement - which the ticket below has to wait for - travels under the epilogue's stores
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if (q < mine) wf_store_stats(S.out_stats, b, rtile, M, N, st_cb[q], L, st_sum[q], st_m2[q]);
+                if (q < mine) wf_store_stats(S.out_stats, b, rtile, Mpad, N, st_cb[q], L, st_sum[q], st_m2[q]);
         }
         wf_epilogue<SWAP, 0>(acc, tbuf, p.bias, rres, Rb != nullptr, Cb, p.ldc, row0, M, cb, L, p.dbg, nullptr, SWAP && pass * 128 >= p.kv_image_col);
 #ifdef WF_PROFILE
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(512) void gemm_wf_kernel(const WfParams p, int row_
         // Chan's parallel-variance merge in fp64 in the arithmetic and order of stats_finalize_kernel: 4 block groups (group g takes
         // blocks g, g + 4, ...), combined ((g0 + g1) + (g2 + g3)) through LDS.  Thread = (group, column mod 128); all loads of a
         // round (up to 8 blocks x the pass group's columns / 128) are issued before any is used - they are cache-bypassing and ~2 us each
-        const float* part = S.out_stats + (long)b * tiles_side * N * 2;
+        const float* part = S.out_stats + (long)b * ((Mpad + WF_TM - 1) / WF_TM) * N * 2;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, (unsigned)((size_t)tiles_side * N * 8), 0x00020000);
         double* sm = reinterpret_cast<double*>(wf_smem);              // [4 groups][3][N]: the planes are no longer needed
         const int g = tid >> 7, kk = tid & 127;
@@ -603,10 +604,12 @@ __global__ __launch_bounds__(512) void gemm_wf_fused_kernel(const WfParams p, co
     const int sidx = z % p.nside;
     const int b = z / p.nside;
     const WfSide& S = p.side[sidx];
-    const int M = S.M;
+    const int Mpad = S.M;                           // strides and the layout of the exchange buffers follow the padded size
+    const int M = imp_count(p.rc, S.img, b, Mpad);  // ragged batches: this pair's own row count (0 = retired pair)
     const int row0 = rtile * WF_TM;
     if (row0 >= M) return;                          // uniform per workgroup, before any barrier or exchange
     const int T = (M + WF_TM - 1) / WF_TM;          // workgroups (= statistics blocks) of this (pair, image)
+    const int Tpad = (Mpad + WF_TM - 1) / WF_TM;
 #ifdef WF_PROFILE
     unsigned long long tp[7];
     tp[0] = __builtin_readcyclecounter();
@@ -713,7 +716,7 @@ __global__ __launch_bounds__(512) void gemm_wf_fused_kernel(const WfParams p, co
     const unsigned tag = f.tag;
     bool dead = false;
     {
-        float* rec_tile = f.rec[sidx] + (((long)b * T + rtile) * N) * 4;
+        float* rec_tile = f.rec[sidx] + (((long)b * Tpad + rtile) * N) * 4;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)rec_tile, 0, (unsigned)(N * 16), 0x00020000);
         if (half == 0 && !(f.fake && blockIdx.x == 0)) {
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(sumA), tag, __float_as_uint(m2A), tag}, rs, (cbA + lane) * 16, 0, AUX_SC1);
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(512) void gemm_wf_fused_kernel(const WfParams p, co
     }
     const int SL = (N + T - 1) / T;                  // channels per owner
     {
-        const float* rec_all = f.rec[sidx] + (long)b * T * N * 4;
+        const float* rec_all = f.rec[sidx] + (long)b * Tpad * N * 4;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)rec_all, 0, (unsigned)((size_t)T * N * 16), 0x00020000);
         float* fin = f.fin[sidx] + (long)b * N * 4;
         const __amdgpu_buffer_rsrc_t rsf = __builtin_amdgcn_make_buffer_rsrc((void*)fin, 0, (unsigned)(N * 16), 0x00020000);

@@ -6,6 +6,20 @@
 
 #define IMP_NUM_HEADS 4          // hard-coded in nets/layers.py:157,230
 
+// RAGGED BATCHES (round 4): the pairs of a batch may hold different numbers of keypoints (real SuperPoint output, nets/superpoint.py:204-216;
+// the reference therefore runs batch 1, eval/eval_imp.py:60-70).  Tensors stay rectangular - padded to the largest pair, all strides from
+// the padded sizes - and every kernel takes the per-pair counts BY VALUE in its parameter block (scalar loads from the kernarg segment: no
+// device buffer, nothing to keep alive across asynchronous launches): rows / keys / statistics beyond a pair's own count do not exist for
+// it.  A count of 0 retires a pair (every workgroup of it leaves at once): the lock-step loops park finished pairs that way.
+#define IMP_RAGGED_MAX 16        // pairs per ragged call (larger batches: several calls)
+struct RaggedCounts {
+    int on;                      // 0: every pair has the launch's uniform sizes
+    int n[2][IMP_RAGGED_MAX];    // [image][pair]
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ int imp_count(const RaggedCounts& rc, int img, int b, int uniform) { return rc.on ? rc.n[img][b] : uniform; }
+#endif
+
 // opt-in to more than 48 KB of dynamic LDS for `kernel`: the attribute is per device, so the largest size already granted is
 // tracked per (device, kernel) under a mutex (worker threads launch concurrently; a process may drive several GPUs)
 hipError_t imp_grant_dynamic_lds(const void* kernel, size_t bytes);
@@ -52,7 +66,8 @@ struct GemmSide {
     const float* in_stats; // [b][K][2] finalised (mean, rstd) of the producer (launch_stats_finalize), or null
     float* out_stats;      // [b][row_tiles][N][2]
     long sA_b, sA_s, sW_b, sW_s, sC_b, sC_s, sR_b, sRV_b, sRV_s;
-    int M, N;
+    int M, N;              // ragged launches (GemmParams::rc): M is the PADDED row count (strides, statistics layout), a pair's own count comes from rc.n[img][b]
+    int img;               // image index of this side in GemmParams::rc
 };
 
 struct GemmParams {
@@ -68,14 +83,15 @@ struct GemmParams {
     int flags, act;
     int prec;              // 0: fp32 MFMA, 1: f16x3 split (hi/lo halves, 3 f16 MFMAs per fp32 product)
     float div, norm_eps;
+    RaggedCounts rc;       // per-pair row counts (rows of A / C; the N dimension is never ragged here)
 };
 
 hipError_t launch_gemm_f32(const GemmParams& p, int batch, hipStream_t stream);
 // InstanceNorm statistics: per-block (sum, M2 about the block mean) [b][tiles][K][2] of a producer -> (mean, rstd) [b][K][2];
 // block t = rows [t * tile_rows, min(M, (t + 1) * tile_rows)); merged with Chan's formula in fp64 in a fixed order, once
 // per (batch, side) instead of once per consumer workgroup
-struct StatsSide { const float* part; float* out; int tiles; int M; int tile_rows; };
-hipError_t launch_stats_finalize(const StatsSide sides[2], int nside, int batch, int K, float eps, hipStream_t stream);
+struct StatsSide { const float* part; float* out; int tiles; int M; int tile_rows; };      // ragged: tiles / M of the PADDED size (the layout), counts from rc
+hipError_t launch_stats_finalize(const StatsSide sides[2], int nside, int batch, int K, float eps, hipStream_t stream, const RaggedCounts* rc = nullptr);
 // rows per statistics block of the launch these sizes will get (half the tile height: one wave's rows)
 int gemm_stats_rows(int M, int N, int total_z);
 int gemm_tile_m(int M, int N, int total_z);
@@ -91,7 +107,8 @@ struct AttnSide {
     float* lse;            // [b][H][nq] or null
     const uint8_t* kmask;  // [b][nk] or null (1 = key kept)
     long sq_b, sk_b, so_b;
-    int nq, nk;
+    int nq, nk;            // ragged launches (AttnParams::rc): the padded sizes (lse / mask strides); a pair's own counts come from rc.n[qimg / kimg][b]
+    int qimg, kimg;        // image index of the queries / keys in AttnParams::rc
 };
 struct AttnParams {
     AttnSide side[2];
@@ -102,6 +119,7 @@ struct AttnParams {
     unsigned* split_cnt;
     int kv_planes;         // EXPERIMENT (ping-pong kernel only): k / v rows hold, per head, [dh hi halves | dh lo halves] (the split-half image the
                            // kernel otherwise builds while staging) in the bytes of the head's dh floats: staged by plain copy
+    RaggedCounts rc;       // per-pair query / key counts (no key split, no key mask with it)
 };
 // in place: the dh-float head segments of columns [col0, col0 + 4 dh) of `rows` rows -> [dh hi halves | dh lo halves]
 hipError_t launch_attn_kv_planes(float* base, long rows, int ld, int col0, int dh, hipStream_t stream);
@@ -131,9 +149,9 @@ hipError_t launch_normalize_kpts(const float* kpts, long count, float width, flo
                                  hipStream_t stream);
 // y[b][n][C0] = W0[C0][3] . (x, y, score) + b0 ; optional fused normalisation (width > 0)
 // plus per-channel partial statistics (tiles of 128 tokens) for the following InstanceNorm
-struct Kenc0Side { const float* kpts; const float* scores; float* y; float* stats; int n; };
+struct Kenc0Side { const float* kpts; const float* scores; float* y; float* stats; int n; };      // ragged: n = the padded count
 hipError_t launch_kenc_first(const Kenc0Side sides[2], int batch, int c0, const float* W0, const float* b0,
-                             float width, float height, hipStream_t stream);
+                             float width, float height, hipStream_t stream, const RaggedCounts* rc = nullptr);
 
 // ------------------------------------------------------------------------------------------------
 // optimal transport (probability-domain Sinkhorn, nets/layers.py:27-46) + matches
@@ -166,7 +184,8 @@ hipError_t launch_score_maxima(const float* scores, int batch, int n0, int n1, f
 int score_maxima_chunks(int n0);
 hipError_t launch_mutual_matches(int batch, int n0, int n1, const float* max0, const int* arg0, const float* max1,
                                  const int* arg1, float p, int64_t* indices0, int64_t* indices1, float* ms0,
-                                 float* ms1, int* range_flag, hipStream_t stream);   // range_flag (mapped host word or null): set when a maximum is not finite
+                                 float* ms1, int* range_flag, hipStream_t stream,    // range_flag (mapped host word or null): set when a maximum is not finite
+                                 const RaggedCounts* rc = nullptr);                  // ragged: n0 / n1 = padded sizes; keypoints past a pair's own count get -1 / 0
 
 // ------------------------------------------------------------------------------------------------
 // adaptive pooling (nets/adgm.py:552-605) + ragged compaction
@@ -224,6 +243,8 @@ struct OtResidentParams {
     float* scores;            // optional [B][n0+1][n1+1]
     float* max0; int* arg0;   // optional row / column maxima of the inner block (all four or none)
     float* max1; int* arg1;
+    RaggedCounts rc;          // ragged: n0 / n1 above are the PADDED sizes (strides of dist, max0 / max1, u / v); pair b's matrix is rc.n[0][b] x rc.n[1][b];
+                              //   no score tensor with it
 };
 int ot_resident_plan(int batch, int n0, int n1, int max_wgs, int* nch, int* rpw, int* G);
 size_t ot_resident_ldx(int nch);
@@ -244,7 +265,8 @@ struct WfSide {
                            //   (WfParams::stat_cnt ticket; replaces the stats_finalize launch), or null
     float* C2;             // chained projection output [b][M][ldc2] (WfParams::Wf2_), or null
     long sA_b, sA2_b, sC_b, sR_b, sC2_b;
-    int M;
+    int M;                 // ragged launches (WfParams::rc): the PADDED row count (strides, statistics layout); a pair's own count comes from rc.n[img][b]
+    int img;               // image index of this side in WfParams::rc
 };
 struct WfParams {
     WfSide side[2];
@@ -264,6 +286,7 @@ struct WfParams {
                            // attention kernel stages by plain copy: per 64-channel head segment [64 hi halves | 64 lo halves] (AttnParams::kv_planes)
     int pass_split;        // > 1: the N / 128 column passes of a row tile are dealt to this many workgroups (must divide N / 128; not with Wf2_)
     int dbg;               // probe switches (tools/probe/gemm_wf_time.py): 1 no global stores, 2 no epilogue at all, 4 no residual / bias loads
+    RaggedCounts rc;       // per-pair row counts
 };
 hipError_t launch_gemm_wf(const WfParams& p, int batch, hipStream_t stream);
 // FUSED layer MLP (round 4): mlp.0 on cat[x, attention output] -> InstanceNorm statistics over ALL keypoints of the image (exchanged

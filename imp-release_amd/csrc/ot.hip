@@ -489,16 +489,22 @@ __global__ __launch_bounds__(256) void colmax_combine_kernel(const float* __rest
 }
 
 // ---- mutual nearest neighbours + threshold (nets/gm.py:308-318) ---------------------------------------------
-__global__ __launch_bounds__(256) void mutual_kernel(int n0, int n1, const float* __restrict__ max0,
+__global__ __launch_bounds__(256) void mutual_kernel(int ld0, int ld1, const float* __restrict__ max0,
                                                      const int* __restrict__ arg0, const float* __restrict__ max1,
                                                      const int* __restrict__ arg1, float p,
                                                      int64_t* __restrict__ ind0, int64_t* __restrict__ ind1,
-                                                     float* __restrict__ ms0, float* __restrict__ ms1, int* __restrict__ range_flag) {
+                                                     float* __restrict__ ms0, float* __restrict__ ms1, int* __restrict__ range_flag, RaggedCounts rc) {
     const int b = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
-    const float* m0 = max0 + (long)b * n0;
-    const int* a0 = arg0 + (long)b * n0;
-    const int* a1 = arg1 + (long)b * n1;
+    // ragged batches: pair b has n0 x n1 keypoints inside arrays padded to ld0 / ld1; keypoints past its own count are "unmatched"
+    const int n0 = imp_count(rc, 0, b, ld0), n1 = imp_count(rc, 1, b, ld1);
+    if (rc.on) {
+        if (t >= n0 && t < ld0) { if (ms0) ms0[(long)b * ld0 + t] = 0.f; if (ind0) ind0[(long)b * ld0 + t] = -1; }
+        if (t >= n1 && t < ld1) { if (ms1) ms1[(long)b * ld1 + t] = 0.f; if (ind1) ind1[(long)b * ld1 + t] = -1; }
+    }
+    const float* m0 = max0 + (long)b * ld0;
+    const int* a0 = arg0 + (long)b * ld0;
+    const int* a1 = arg1 + (long)b * ld1;
     // an argmax of 0x7fffffff means "no maximum found" (a row of NaNs: |operand| >= 65504 in f16x3 mode, or NaN inputs):
     // such a keypoint has no match - never an out-of-range read
     // a row / column maximum of -inf: every score of that row was NaN (an MFMA operand beyond the fp16 range in f16x3 mode, or
@@ -511,8 +517,8 @@ __global__ __launch_bounds__(256) void mutual_kernel(int n0, int n1, const float
         const bool mutual = (unsigned)j < (unsigned)n1 && a1[j] == t;
         float s = mutual ? m0[t] : 0.f;
         if (j == 0x7fffffff && m0[t] != m0[t]) s = m0[t];       // voided by the resident Sinkhorn kernel (time-out): NaN, never a plausible 0
-        if (ms0) ms0[(long)b * n0 + t] = s;
-        if (ind0) ind0[(long)b * n0 + t] = (mutual && s > p) ? (int64_t)j : (int64_t)-1;
+        if (ms0) ms0[(long)b * ld0 + t] = s;
+        if (ind0) ind0[(long)b * ld0 + t] = (mutual && s > p) ? (int64_t)j : (int64_t)-1;
     }
     if (t < n1) {
         const int i = a1[t];
@@ -522,9 +528,9 @@ __global__ __launch_bounds__(256) void mutual_kernel(int n0, int n1, const float
         const bool mutual0_i = ok_i && (unsigned)ji < (unsigned)n1 && a1[ji] == i;
         const float s0_i = mutual0_i ? m0[i] : 0.f;
         const bool valid0_i = mutual0_i && s0_i > p;
-        const bool voided = i == 0x7fffffff && max1[(long)b * n1 + t] != max1[(long)b * n1 + t];
-        if (ms1) ms1[(long)b * n1 + t] = voided ? max1[(long)b * n1 + t] : (mutual1 ? s0_i : 0.f);
-        if (ind1) ind1[(long)b * n1 + t] = (mutual1 && valid0_i) ? (int64_t)i : (int64_t)-1;
+        const bool voided = i == 0x7fffffff && max1[(long)b * ld1 + t] != max1[(long)b * ld1 + t];
+        if (ms1) ms1[(long)b * ld1 + t] = voided ? max1[(long)b * ld1 + t] : (mutual1 ? s0_i : 0.f);
+        if (ind1) ind1[(long)b * ld1 + t] = (mutual1 && valid0_i) ? (int64_t)i : (int64_t)-1;
     }
 }
 
@@ -665,10 +671,12 @@ hipError_t launch_score_maxima(const float* scores, int batch, int n0, int n1, f
 
 hipError_t launch_mutual_matches(int batch, int n0, int n1, const float* max0, const int* arg0, const float* max1,
                                  const int* arg1, float p, int64_t* indices0, int64_t* indices1, float* ms0,
-                                 float* ms1, int* range_flag, hipStream_t stream) {
+                                 float* ms1, int* range_flag, hipStream_t stream, const RaggedCounts* rc) {
     const int n = n0 > n1 ? n0 : n1;
+    RaggedCounts r;
+    if (rc) r = *rc; else r.on = 0;
     hipLaunchKernelGGL(mutual_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, stream, n0, n1, max0, arg0, max1, arg1,
-                       p, indices0, indices1, ms0, ms1, range_flag);
+                       p, indices0, indices1, ms0, ms1, range_flag, r);
     return hipGetLastError();
 }
 

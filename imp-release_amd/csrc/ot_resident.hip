@@ -229,7 +229,10 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         b = blockIdx.x / G;
         g = blockIdx.x % G;
     }
-    const int n0 = p.n0, n1 = p.n1;
+    // ragged batches: this pair's own matrix is n0 x n1; p.n0 / p.n1 are the padded sizes (strides of dist, of the maxima and of u / v)
+    const int ld0 = p.n0, ld1 = p.n1;
+    const int n0 = imp_count(p.rc, 0, b, ld0), n1 = imp_count(p.rc, 1, b, ld1);
+    if (n0 <= 0 || n1 <= 0) { leave(); return; }       // retired pair: all its workgroups leave here, before any exchange
     const int r0 = g * ROWS + wave * RPW;
     bool dead = false;
     const Health health{p.status, p.host_status};
@@ -249,13 +252,13 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
     for (int k = 0; k < RPW; ++k) {
         const int r = r0 + k;
         const bool rv = r < n0;
-        const float* drow = p.dist + ((size_t)b * n0 + (rv ? r : 0)) * n1;
+        const float* drow = p.dist + ((size_t)b * ld0 + (rv ? r : 0)) * ld1;
         float mx = bin;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int j = 4 * (lane + 64 * c);
             f32x4 x;
-            if (rv && j + 3 < n1 && (n1 & 3) == 0) {
+            if (rv && j + 3 < n1 && (ld1 & 3) == 0) {
                 x = *reinterpret_cast<const f32x4*>(drow + j);
             } else {
 #pragma unroll
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         }
         if (want_max) {
             wave_argmax(best, bi);
-            if (lane == 0) { p.max0[(size_t)b * n0 + r] = best; p.arg0[(size_t)b * n0 + r] = bi; }
+            if (lane == 0) { p.max0[(size_t)b * ld0 + r] = best; p.arg0[(size_t)b * ld0 + r] = bi; }
         }
         if (p.scores) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -523,8 +526,8 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
                     const int oi = __float_as_int(red[(size_t)((G + w) * ncq + qq) * 4 + e]);
                     if (ov > best) { best = ov; bi = oi; }
                 }
-                p.max1[(size_t)b * n1 + j] = best;
-                p.arg1[(size_t)b * n1 + j] = bi;
+                p.max1[(size_t)b * ld1 + j] = best;
+                p.arg1[(size_t)b * ld1 + j] = bi;
             }
         }
     }
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         const float nanv = __builtin_nanf("");
         const int rend = min(n0, (g + 1) * ROWS);
         for (int r = g * ROWS + tid; r < rend; r += 512)
-            if (want_max) { p.max0[(size_t)b * n0 + r] = nanv; p.arg0[(size_t)b * n0 + r] = 0x7fffffff; }
+            if (want_max) { p.max0[(size_t)b * ld0 + r] = nanv; p.arg0[(size_t)b * ld0 + r] = 0x7fffffff; }
         // the WHOLE own rows of the score tensor (with only the first score of a row poisoned, maxima recomputed from the
         // tensor - imp_compute_matches after imp_compute_score - skipped the NaN and returned plausible matches from garbage)
         if (p.scores)
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             const int ncq = (DCOL / 4 + G - 1) / G;
             for (int cl = tid; cl < 4 * ncq; cl += 512) {
                 const int j = 4 * (g * ncq) + cl;
-                if (j < n1) { p.max1[(size_t)b * n1 + j] = nanv; p.arg1[(size_t)b * n1 + j] = 0x7fffffff; }
+                if (j < n1) { p.max1[(size_t)b * ld1 + j] = nanv; p.arg1[(size_t)b * ld1 + j] = 0x7fffffff; }
             }
         }
     }

@@ -53,25 +53,26 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict_
 // InstanceNorm: (sum, M2 about the block mean) per channel, merged by launch_stats_finalize (Chan's formula)
 __global__ __launch_bounds__(128) void kenc_first_kernel(Kenc0Side s0, Kenc0Side s1, int c0,
                                                          const float* __restrict__ W0, const float* __restrict__ b0,
-                                                         float cx, float cy, float scaling) {
+                                                         float cx, float cy, float scaling, RaggedCounts rc) {
     const Kenc0Side& S = blockIdx.y == 0 ? s0 : s1;
-    const int b = blockIdx.z, n = S.n;
+    const int b = blockIdx.z, npad = S.n;                       // strides and the statistics layout follow the padded count
+    const int n = imp_count(rc, blockIdx.y, b, npad);           // ragged batches: this pair's own keypoint count
     if ((int)blockIdx.x * 128 >= n) return;
     const int tok = blockIdx.x * 128 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool ok = tok < n;
     float x = 0.f, y = 0.f, sc = 0.f;
     if (ok) {
-        x = S.kpts[((long)b * n + tok) * 2];
-        y = S.kpts[((long)b * n + tok) * 2 + 1];
-        sc = S.scores[(long)b * n + tok];
+        x = S.kpts[((long)b * npad + tok) * 2];
+        y = S.kpts[((long)b * npad + tok) * 2 + 1];
+        sc = S.scores[(long)b * npad + tok];
         if (scaling > 0.f) { x = (x - cx) / scaling; y = (y - cy) / scaling; }
     }
-    const int blk = blockIdx.x * 2 + wave, nblk = (n + 63) / 64;
+    const int blk = blockIdx.x * 2 + wave, nblk = (npad + 63) / 64;
     const int cnt = min(64, n - blk * 64);                      // valid keypoints of this wave's block
     for (int c = 0; c < c0; ++c) {
         float v = fmaf(W0[c * 3 + 2], sc, fmaf(W0[c * 3 + 1], y, W0[c * 3] * x)) + b0[c];
-        if (ok) S.y[((long)b * n + tok) * c0 + c] = v; else v = 0.f;
+        if (ok) S.y[((long)b * npad + tok) * c0 + c] = v; else v = 0.f;
         if (S.stats && cnt > 0) {                               // wave-uniform
             const float s = wave_sum(v);
             const float d = v - s / (float)cnt;
@@ -485,13 +486,15 @@ hipError_t launch_normalize_kpts(const float* kpts, long count, float width, flo
 }
 
 hipError_t launch_kenc_first(const Kenc0Side sides[2], int batch, int c0, const float* W0, const float* b0,
-                             float width, float height, hipStream_t stream) {
+                             float width, float height, hipStream_t stream, const RaggedCounts* rc) {
     const int nmax = sides[0].n > sides[1].n ? sides[0].n : sides[1].n;
     if (nmax <= 0 || c0 > 64) return c0 > 64 ? hipErrorInvalidValue : hipSuccess;
     float scaling = 0.f;
     if (width > 0.f) scaling = (width > height ? width : height) * 0.7f;
+    RaggedCounts r;
+    if (rc) r = *rc; else r.on = 0;
     hipLaunchKernelGGL(kenc_first_kernel, dim3((nmax + 127) / 128, 2, batch), dim3(128), 0, stream, sides[0], sides[1], c0,
-                       W0, b0, width / 2.f, height / 2.f, scaling);
+                       W0, b0, width / 2.f, height / 2.f, scaling, r);
     return hipGetLastError();
 }
 

@@ -323,9 +323,54 @@ class GM(nn.Module):
             cache[key] = torch.tensor([0., 0., 1., 1.], device=dev)
         return cache[key].clone().unbind(0)
 
+    RAGGED_MAX = 16          # pairs per ragged call of the library (include/imp_hip.h imp_set_counts); larger batches are chunked here
+
+    @staticmethod
+    def _counts(data, B, n0, n1):
+        """per-pair keypoint counts of a RAGGED batch, or None.  An extension of the reference's rectangular interface (its drivers
+        run batch 1 because real SuperPoint output is ragged, eval/eval_imp.py:60-70): ``data['num_keypoints0' / 'num_keypoints1']`` =
+        one count per pair (sequence or 1-D tensor); the tensors are padded to the largest pair, outputs past a pair's count are -1 / 0"""
+        c0, c1 = data.get('num_keypoints0'), data.get('num_keypoints1')
+        if c0 is None and c1 is None:
+            return None
+        if c0 is None or c1 is None:
+            raise ValueError('num_keypoints0 and num_keypoints1 go together')
+        c0 = [int(v) for v in (c0.tolist() if torch.is_tensor(c0) else c0)]
+        c1 = [int(v) for v in (c1.tolist() if torch.is_tensor(c1) else c1)]
+        if len(c0) != B or len(c1) != B:
+            raise ValueError(f'num_keypoints0/1: one count per pair ({B}), got {len(c0)} / {len(c1)}')
+        if min(c0) < 1 or min(c1) < 1 or max(c0) > n0 or max(c1) > n1:
+            raise ValueError('num_keypoints0/1 must lie in 1 .. the padded size')
+        return c0, c1
+
     def _run_iterations(self, data, p, only_last, want_scores):
         """shared body of GM / DGNNS produce_matches: returns per-emitted-iteration lists"""
+        B = data['keypoints0'].shape[0]
+        counts = self._counts(data, B, data['keypoints0'].shape[1], data['keypoints1'].shape[1])
+        if counts is None:
+            return self._run_iterations_chunk(data, p, only_last, want_scores, None)
+        # ragged batch: chunks of at most RAGGED_MAX pairs, each under its own counts; no score tensors (every pair's dustbin row /
+        # column would sit elsewhere inside the padded tensor)
+        outs = []
+        for s0 in range(0, B, self.RAGGED_MAX):
+            sl = slice(s0, min(B, s0 + self.RAGGED_MAX))
+            chunk = {k: (v[sl] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B and k not in ('image0', 'image1') else v)
+                     for k, v in data.items() if k not in ('num_keypoints0', 'num_keypoints1')}
+            outs.append(self._run_iterations_chunk(chunk, p, only_last, False, (counts[0][sl], counts[1][sl])))
+        out = {k: [torch.cat([o[k][i] for o in outs], 0) for i in range(len(outs[0][k]))] for k in outs[0]}
+        return out
+
+    def _run_iterations_chunk(self, data, p, only_last, want_scores, counts):
         ctx = self._ensure_ctx(check=True)
+        if counts is not None:
+            ctx.set_counts(*counts)
+        try:
+            return self._run_iterations_body(ctx, data, p, only_last, want_scores, counts is not None)
+        finally:
+            if counts is not None:
+                ctx.set_counts()
+
+    def _run_iterations_body(self, ctx, data, p, only_last, want_scores, ragged):
         k0, k1, w, h = self._inputs(data)
         nI = self.n_layers
         out = {'scores': [], 'indices0': [], 'indices1': [], 'mscores0': [], 'mscores1': []}
@@ -349,6 +394,11 @@ class GM(nn.Module):
                 d0, d1 = ctx.forward_layer(li, d0, d1, inplace=True)
                 self._note_layer(li, B, n0, n1)
             if only_last and it != nI - 1:
+                continue
+            if ragged:
+                r = ctx.match_tail(it, d0, d1, self._bin(None), self.sinkhorn_iterations, self.with_sinkhorn, p, want_side1=True)
+                for k in ('indices0', 'indices1', 'mscores0', 'mscores1'):
+                    out[k].append(r[k])
                 continue
             dist = ctx.compute_distance(it, d0, d1)
             score = ctx.compute_score(dist, self._bin(None), self.sinkhorn_iterations, self.with_sinkhorn)

@@ -233,6 +233,22 @@ int imp_op_layer_gemm(imp_ctx* ctx, int B, int M, int N, int K, int ksplit, cons
                       const float* W2, const float* bias2, int N2, float* y2, int pass_split, void* stream);
 /* multi-head attention core on packed projections: qkv_q [B][nq][3D], qkv_kv [B][nk][3D]
  * (q | k | v, head-major), out [B][nq][D], lse [B][4][nq] (optional).  nets/layers.py:121-131 */
+/* RAGGED BATCHES (round 4).  Real SuperPoint output holds a different number of keypoints per image (nets/superpoint.py:204-216:
+ * threshold, border filter, top-k), which is why the reference's drivers run one pair at a time (eval/eval_imp.py:60-70).  Here a batch
+ * may be ragged: the tensors stay rectangular, padded to the largest pair of the batch (every n0 / n1 argument below = the padded size),
+ * and imp_set_counts gives the per-pair counts that the NEXT calls on this context obey - imp_encode_keypoints, imp_forward_layer,
+ * imp_compute_distance, imp_match_pair, imp_match_tail: keypoints / keys / InstanceNorm statistics past a pair's own count do not
+ * exist for it, its result equals the pair run alone; outputs past the count are -1 (indices) / 0 (scores) or unspecified
+ * (descriptors).  Not with key masks, a score tensor or the dual-softmax scorer.  A count of 0 for BOTH images retires a pair: its
+ * workgroups leave at once (the lock-step loops of imp_release_amd.eval_loop park finished pairs that way).  batch <= 16; the counts
+ * are HOST arrays, copied; n0 = n1 = NULL returns the context to uniform batches. */
+int imp_set_counts(imp_ctx* ctx, int batch, const int32_t* n0, const int32_t* n1);
+/* the tail of imp_match_pair on its own, for loops that score at several iterations (eval/matching.py:55-61: compute_distance
+ * (final_proj[layer_id], nets/gm.py:290-295) -> compute_score -> compute_matches) without materialising the score tensor; obeys
+ * imp_set_counts */
+int imp_match_tail(imp_ctx* ctx, int layer_id, int batch, int n0, int n1, const float* desc0, const float* desc1, float bin_score,
+                   int sinkhorn_iterations, int with_sinkhorn, float p, int64_t* indices0, float* mscores0, int64_t* indices1,
+                   float* mscores1, void* stream);
 /* the fused layer MLP of csrc/gemm_wf.hip on its own (tests/test_gpu_ops.py): nets/layers.py:145-149 / :210-218 after the attention,
  *   y = x + mlp.3(relu(InstanceNorm(mlp.0(cat[x, a]))))        x, a, y: [B][M][256];  W0 [512][512], W3 [256][512]
  *   y2 = y . W2^T + b2                                         optional (W2 [N2][256], N2 % 128 == 0): the next layer's projection

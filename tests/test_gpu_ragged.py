@@ -1,0 +1,160 @@
+"""GPU: RAGGED batches (round 4) - pairs with different keypoint counts in one padded batch (include/imp_hip.h imp_set_counts).
+
+The reference's interface is rectangular and its drivers run one pair at a time because real SuperPoint output is ragged
+(eval/eval_imp.py:60-70, nets/superpoint.py:204-216).  The bar: every pair of a ragged batch reproduces (a) the fixture captured from the
+imported reference on that pair ALONE at its own size, and (b) this library's own batch-1 result on the unpadded pair - match indices
+identical, scores within 1e-4 - whatever garbage sits in the padding."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import compare_matches, eval_config, load_golden, make_hip_model
+from imp_release_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+TOL = 1e-4
+
+
+def _padded_batch(pairs, desc_dim=256, fill='noise'):
+    """pairs: [(n0, n1, dseed)] -> (padded data dict on the GPU, list of the unpadded per-pair dicts).  The padding is filled with
+    large finite noise: nothing past a pair's own count may leak into its result"""
+    singles = []
+    for n0, n1, dseed in pairs:
+        p = synthetic.make_correlated_pair(n0, n1, desc_dim=desc_dim, seed=dseed)
+        singles.append(p)
+    N0, N1 = max(p[0] for p in pairs), max(p[1] for p in pairs)
+    B = len(pairs)
+    g = np.random.default_rng(7)
+    out = {}
+    for key, n_, width in (('keypoints0', N0, 2), ('keypoints1', N1, 2), ('scores0', N0, 0), ('scores1', N1, 0), ('descriptors0', N0, desc_dim),
+                           ('descriptors1', N1, desc_dim)):
+        shape = (B, n_) + ((width,) if width else ())
+        arr = (g.standard_normal(shape) * 50.0).astype(np.float32) if fill == 'noise' else np.zeros(shape, np.float32)
+        for b, s in enumerate(singles):
+            v = s[key][0]
+            arr[b, :v.shape[0]] = v
+        out[key] = torch.from_numpy(arr).to(DEV)
+    out['image0'] = out['image1'] = torch.zeros(singles[0]['image_shape'], device=DEV)
+    out['num_keypoints0'] = [p[0] for p in pairs]
+    out['num_keypoints1'] = [p[1] for p in pairs]
+    return out, singles
+
+
+def _single(p):
+    d = {k: torch.from_numpy(v).to(DEV) for k, v in p.items() if k != 'image_shape'}
+    d['image0'] = d['image1'] = torch.zeros(p['image_shape'], device=DEV)
+    return d
+
+
+@pytest.mark.parametrize('precision', ['f16x3', 'f32'])
+@pytest.mark.parametrize('name', ['ragged_gm_l9_t100_b4', 'ragged_dgnns_l15_b4', 'ragged_gm_l3_b5_tiny'])
+def test_ragged_batch_vs_the_reference_on_each_pair_alone(name, precision):
+    spec, z = load_golden(name)
+    cfg = eval_config(**spec['config'])
+    sd = synthetic.make_state_dict(cfg, model=spec['model'], seed=spec['wseed'])
+    m = make_hip_model(spec['model'], cfg, sd, precision=precision)
+    data, singles = _padded_batch([tuple(p) for p in spec['pairs']])
+    with torch.no_grad():
+        out = m.produce_matches(data, **spec['call'])
+    i0, ms0 = out['indices0'][-1].cpu(), out['mscores0'][-1].cpu()
+    for b, (n0, n1, _) in enumerate(spec['pairs']):
+        print(compare_matches(i0[b:b + 1, :n0], ms0[b:b + 1, :n0], z[f'indices0_b{b}'][None], z[f'mscores0_b{b}'][None], 0.2, TOL,
+                              f'{name} pair {b} ({n0} x {n1}) inside the ragged batch vs the reference on the pair alone'))
+        assert bool((i0[b, n0:] == -1).all()) and bool((ms0[b, n0:] == 0).all()), 'outputs past a pair\'s own count must read "unmatched"'
+        assert int(i0[b, :n0].max()) < n1
+    # ... and the library's own batch-1 path on the unpadded pairs
+    for b, s in enumerate(singles):
+        with torch.no_grad():
+            o1 = m.produce_matches(_single(s), **spec['call'])
+        n0 = spec['pairs'][b][0]
+        print(compare_matches(i0[b:b + 1, :n0], ms0[b:b + 1, :n0], o1['indices0'][-1].cpu().numpy(), o1['mscores0'][-1].cpu().numpy(), 0.2, TOL,
+                              f'{name} pair {b}: ragged batch vs batch 1'))
+
+
+def test_ragged_all_iterations_and_zero_padding():
+    """only_last=False on a ragged batch: every emitted iteration goes through imp_match_tail (no score tensor); zero padding"""
+    cfg = eval_config(n_layers=3)
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=2)
+    m = make_hip_model('GM', cfg, sd)
+    pairs = [(300, 280, 31), (130, 97, 32), (280, 300, 33)]
+    data, singles = _padded_batch(pairs, fill='zeros')
+    with torch.no_grad():
+        out = m.produce_matches(data, p=0.2, only_last=False)
+    assert len(out['indices0']) == 3 and out['scores'] == []
+    for b, s in enumerate(singles):
+        with torch.no_grad():
+            o1 = m.produce_matches(_single(s), p=0.2, only_last=False)
+        for it in range(3):
+            n0 = pairs[b][0]
+            compare_matches(out['indices0'][it][b:b + 1, :n0].cpu(), out['mscores0'][it][b:b + 1, :n0].cpu(), o1['indices0'][it].cpu().numpy(),
+                            o1['mscores0'][it].cpu().numpy(), 0.2, TOL, f'pair {b} iteration {it}')
+
+
+def test_retired_pairs_cost_nothing_and_change_nothing():
+    """a count of 0 for both images retires a pair (the lock-step loops park finished pairs that way): its outputs read "unmatched",
+    the other pairs' results are bit-identical to the batch without retirements"""
+    cfg = eval_config(n_layers=5)
+    sd = synthetic.make_state_dict(cfg, 'DGNNS', seed=4)
+    m = make_hip_model('DGNNS', cfg, sd)
+    ctx = m._ensure_ctx()
+    pairs = [(512, 519, 41), (700, 333, 42), (333, 700, 43), (640, 640, 44)]
+    data, _ = _padded_batch(pairs)
+    k0, k1 = data['keypoints0'], data['keypoints1']
+
+    def run(c0, c1):
+        ctx.set_counts(c0, c1)
+        try:
+            r = ctx.match_pair(k0, data['scores0'], data['descriptors0'], k1, data['scores1'], data['descriptors1'], 640.0, 480.0, 1.0, 20, True, 0.2)
+        finally:
+            ctx.set_counts()
+        torch.cuda.synchronize()
+        return r['indices0'].clone(), r['mscores0'].clone()
+
+    full = run([p[0] for p in pairs], [p[1] for p in pairs])
+    part = run([512, 0, 333, 0], [519, 0, 700, 0])
+    for b in (0, 2):
+        assert torch.equal(full[0][b], part[0][b]) and torch.equal(full[1][b], part[1][b])
+    for b in (1, 3):
+        assert bool((part[0][b] == -1).all()) and bool((part[1][b] == 0).all())
+    assert int((full[0][1] >= 0).sum()) > 0
+    assert ctx.resident_health() == (0, 0)
+
+
+def test_more_pairs_than_one_ragged_call_takes():
+    """18 pairs: chunks of 16 + 2 behind the module interface"""
+    cfg = eval_config(n_layers=2)
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=3)
+    m = make_hip_model('GM', cfg, sd)
+    pairs = [(40 + 7 * k, 90 - 3 * k, 50 + k) for k in range(18)]
+    data, singles = _padded_batch(pairs)
+    with torch.no_grad():
+        out = m.produce_matches(data, p=0.2, only_last=True)
+    assert out['indices0'][-1].shape == (18, 40 + 7 * 17)
+    for b in (0, 9, 16, 17):
+        with torch.no_grad():
+            o1 = m.produce_matches(_single(singles[b]), p=0.2, only_last=True)
+        n0 = pairs[b][0]
+        compare_matches(out['indices0'][-1][b:b + 1, :n0].cpu(), out['mscores0'][-1][b:b + 1, :n0].cpu(), o1['indices0'][-1].cpu().numpy(),
+                        o1['mscores0'][-1].cpu().numpy(), 0.2, TOL, f'pair {b} of 18')
+
+
+def test_ragged_argument_errors():
+    from imp_release_amd import _lib
+    cfg = eval_config(n_layers=2)
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=3)
+    m = make_hip_model('GM', cfg, sd)
+    ctx = m._ensure_ctx()
+    data, _ = _padded_batch([(64, 70, 1), (50, 80, 2)])
+    with pytest.raises(_lib.ImpError):
+        ctx.set_counts([64, 0], [70, 5])            # a pair retires as a whole
+    with pytest.raises(_lib.ImpError):
+        ctx.set_counts(list(range(1, 18)), list(range(1, 18)))
+    ctx.set_counts([64, 50, 3], [70, 80, 3])
+    with pytest.raises(_lib.ImpError):              # counts for 3 pairs, a call with 2
+        ctx.match_pair(data['keypoints0'], data['scores0'], data['descriptors0'], data['keypoints1'], data['scores1'], data['descriptors1'],
+                       640.0, 480.0, 1.0, 20, True, 0.2)
+    ctx.set_counts()
+    bad = dict(data, num_keypoints0=[64, 99])
+    with pytest.raises(ValueError):
+        m.produce_matches(bad, p=0.2, only_last=True)

@@ -37,6 +37,24 @@ def test_produce_matches_vs_reference(name):
         np.testing.assert_allclose(s[:8, :8].numpy(), z['score_corner'], atol=2e-5 * tol, rtol=0)
 
 
+@pytest.mark.parametrize('name', golden_names(['ragged_']))
+def test_ragged_fixtures_vs_reference(name):
+    """the ragged-batch fixtures hold the reference on every pair ALONE (tools/make_golden.py case_ragged): the oracle reproduces them"""
+    spec, z = load_golden(name)
+    from helpers import eval_config
+    cfg = eval_config(**spec['config'])
+    sd = synthetic.make_state_dict(cfg, model=spec['model'], seed=spec['wseed'])
+    o = orc.MatcherOracle(cfg, sd, model=spec['model'])
+    for b, (n0, n1, dseed) in enumerate(spec['pairs']):
+        pair = synthetic.make_correlated_pair(n0, n1, seed=dseed)
+        data = {k: torch.from_numpy(v) for k, v in pair.items() if k != 'image_shape'}
+        data['image0'] = data['image1'] = torch.zeros(pair['image_shape'])
+        with torch.no_grad():
+            out = o.produce_matches(data, **spec['call'])
+        assert np.array_equal(out['indices0'][-1][0].numpy(), z[f'indices0_b{b}']), f'{name} pair {b}'
+        np.testing.assert_allclose(out['mscores0'][-1][0].numpy(), z[f'mscores0_b{b}'], atol=2e-5, rtol=0)
+
+
 @pytest.mark.parametrize('name', golden_names(['gm_run', 'adagmn_run']))
 def test_run_vs_reference(name):
     spec, z = load_golden(name)

@@ -132,6 +132,34 @@ def case_produce(name, spec):
     assert ok, f'oracle index mismatch in {name}'
 
 
+def case_ragged(name, spec):
+    """round 4: a RAGGED batch - every pair with its own keypoint counts.  The reference's interface is rectangular and its drivers
+    run one pair at a time (eval/eval_imp.py:60-70), so the fixture is the reference run on each pair ALONE at its own size; the
+    library must reproduce every one of them from a single padded batch (imp_set_counts)."""
+    if not wanted(name):
+        return
+    cfg = eval_config(**spec['config'])
+    sd_np = synthetic.make_state_dict(cfg, model=spec['model'], seed=spec['wseed'], style=spec.get('style', 'uniform'))
+    ref = REF_CLS[spec['model']](cfg).eval()
+    ref.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=True)
+    oracle = orc.MatcherOracle(cfg, sd_np, model=spec['model'])
+    arrays, rep = {}, []
+    for k, (n0, n1, dseed) in enumerate(spec['pairs']):
+        pair = synthetic.make_correlated_pair(n0, n1, desc_dim=cfg['descriptor_dim'], seed=dseed)
+        data = {kk: torch.from_numpy(v) for kk, v in pair.items() if kk != 'image_shape'}
+        data['image0'] = torch.zeros(pair['image_shape']); data['image1'] = torch.zeros(pair['image_shape'])
+        with torch.no_grad():
+            r = ref.produce_matches(data, **spec['call'])
+            o = oracle.produce_matches(data, **spec['call'])
+        arrays[f'indices0_b{k}'] = r['indices0'][-1][0].numpy()
+        arrays[f'mscores0_b{k}'] = r['mscores0'][-1][0].numpy()
+        same = bool((r['indices0'][-1] == o['indices0'][-1]).all())
+        rep.append((same, maxdiff(r['mscores0'][-1], o['mscores0'][-1]), int((r['indices0'][-1] >= 0).sum())))
+    ok = all(x[0] for x in rep)
+    save(name, spec, arrays, f'pairs={len(rep)} matches={[x[2] for x in rep]} oracle_idx_equal={ok} max|dms|={max(x[1] for x in rep):.2e}')
+    assert ok, name
+
+
 def case_run(name, spec):
     if not wanted(name):
         return
@@ -465,6 +493,14 @@ def main():
     case_produce('gm_trained_l9_n2048', dict(model='GM', config=dict(n_layers=9, sinkhorn_iterations=100), wseed=21, dseed=34,
                                              n0=2048, n1=2048, style='trained', call=dict(p=0.2, only_last=True)))
     case_loop('eimp_loop_sliced_n4096', dict(model='AdaGMN', config=dict(), wseed=9, dseed=41, n0=4096, n1=4000, bin_score=5.0), True)
+    # (6d) round 4: ragged batches (the reference on every pair alone, at four sizes each): the bench-like GM shape with N ~ U(1200, 2048),
+    # the attention-sharing IMP model, and a batch with a tiny pair
+    case_ragged('ragged_gm_l9_t100_b4', dict(model='GM', config=dict(n_layers=9, sinkhorn_iterations=100), wseed=1, call=dict(p=0.2, only_last=True),
+                                            pairs=[(2048, 1811, 201), (1693, 2048, 202), (1250, 1333, 203), (1920, 1477, 204)]))
+    case_ragged('ragged_dgnns_l15_b4', dict(model='DGNNS', config=dict(), wseed=4, call=dict(p=0.2, only_last=True),
+                                           pairs=[(512, 519, 211), (700, 333, 212), (64, 70, 213), (1000, 901, 214)]))
+    case_ragged('ragged_gm_l3_b5_tiny', dict(model='GM', config=dict(n_layers=3), wseed=2, call=dict(p=0.2, only_last=True),
+                                            pairs=[(130, 97, 221), (5, 7, 222), (300, 64, 223), (65, 300, 224), (256, 256, 225)]))
     # (7) pool edge cases
     case_pool_edges('pool_edges')
     case_metrics('metrics')
