@@ -57,3 +57,73 @@ def all_gather_matches(indices0: torch.Tensor, mscores0: torch.Tensor, n_total: 
         s, e = shard_range(n_total, r, world)
         rows.append(out[r * per: r * per + (e - s)])
     return unpack_matches(torch.cat(rows, dim=0), n)
+
+
+def lpt_assignment(costs, world: int):
+    """Rank-level schedule for pairs of UNEQUAL cost (the iterative loops: cost grows with the keypoint counts, shrinks with pruning and
+    early exit - SURVEY.md section 8(e) asks for "dynamic work-stealing or longest-first"): longest processing time first - pairs in
+    order of decreasing cost, each to the rank with the least work so far (ties: lower pair id, lower rank).  Deterministic, computed
+    identically on every rank from the same costs, no communication.  -> [[pair ids of rank 0], [rank 1], ...], each list ascending."""
+    order = sorted(range(len(costs)), key=lambda i: (-float(costs[i]), i))
+    load = [0.0] * world
+    out = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += float(costs[i])
+    return [sorted(x) for x in out]
+
+
+def gpu_numa_cpus(local_rank: int, sysfs: str = '/sys'):
+    """CPUs of the NUMA node the GPU `local_rank` hangs off (its PCI device's ``numa_node``), or None when the topology cannot be read
+    (no such file, node -1: single-node hosts).  Looks the device up by PCI address through ``torch.cuda.get_device_properties`` when a
+    GPU is visible, else by position among /sys/class/drm/card*/device entries that have a ``numa_node``."""
+    import glob
+    node = None
+    try:
+        if torch.cuda.is_available() and local_rank < torch.cuda.device_count():
+            pr = torch.cuda.get_device_properties(local_rank)
+            bdf = f'{getattr(pr, "pci_domain_id", 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0'
+            with open(os.path.join(sysfs, 'bus', 'pci', 'devices', bdf, 'numa_node')) as f:
+                node = int(f.read().strip())
+    except Exception:
+        node = None
+    if node is None:
+        cards = sorted(glob.glob(os.path.join(sysfs, 'class', 'drm', 'card[0-9]*', 'device', 'numa_node')))
+        if local_rank < len(cards):
+            try:
+                with open(cards[local_rank]) as f:
+                    node = int(f.read().strip())
+            except Exception:
+                node = None
+    if node is None or node < 0:
+        return None
+    try:
+        with open(os.path.join(sysfs, 'devices', 'system', 'node', f'node{node}', 'cpulist')) as f:
+            txt = f.read().strip()
+    except Exception:
+        return None
+    cpus = set()
+    for part in txt.split(','):
+        if '-' in part:
+            a, b = part.split('-')
+            cpus.update(range(int(a), int(b) + 1))
+        elif part:
+            cpus.add(int(part))
+    return sorted(cpus) or None
+
+
+def pin_to_gpu_numa(local_rank: int, sysfs: str = '/sys'):
+    """One process per GPU: keep this rank's threads (the step workers, the exchange lane, the pose workers, the pinned-memory prefetcher)
+    on the CPUs next to its GPU.  IMP_NUMA_AFFINITY=0 disables; a no-op when the topology cannot be read or the mask would be empty.
+    -> the CPU list applied, or None."""
+    if os.environ.get('IMP_NUMA_AFFINITY', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
+        return None
+    cpus = gpu_numa_cpus(local_rank, sysfs)
+    if not cpus:
+        return None
+    allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+    if not allowed:
+        return None
+    os.sched_setaffinity(0, allowed)
+    return allowed

@@ -27,7 +27,7 @@ import torch
 import torch.distributed as dist
 
 from . import matching
-from .dist import shard_range
+from .dist import lpt_assignment, shard_range
 
 # one row per pair = what eval/eval_imp.py:112-141,190-225 accumulates for its report: pose errors (degrees; inf = no pose),
 # precision and matching score of the final matches against the ground-truth essential matrix, plus the loop statistics
@@ -112,29 +112,65 @@ def replicate(model, n: int) -> list:
 def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int, eimp: bool = False, nI: int = 15,
                       match_ratio: float = 0.1, min_kpts: int = 25, error_th: float = 1.0,
                       stop_criteria: Optional[dict] = None, estimate_pose=None, group=None, workers: int = 1,
-                      replicas: Optional[Sequence] = None) -> np.ndarray:
+                      replicas: Optional[Sequence] = None, lockstep: int = 1, schedule: str = 'block',
+                      pair_cost: Optional[Callable[[int], float]] = None) -> np.ndarray:
     """-> [n_pairs, len(SUMMARY_COLUMNS)] summary table, identical on every rank.  ``pair_provider(pair_id)`` returns the reference's
     per-pair ``data`` dict (GPU tensors + pts*_cpu / K*), exactly what eval/matching.py consumes.
     ``workers`` > 1: that many pairs in flight on this rank (see module docstring); ``replicas`` may pass pre-built
-    model instances (else they are created with :func:`replicate`)."""
+    model instances (else they are created with :func:`replicate`).
+    ``lockstep`` > 1 (IMP loop only, round 4): that many pairs advance TOGETHER through ``matching.matching_iterative_lockstep`` - one
+    ragged batch, one kernel launch per layer for all of them, per-pair early exit (at most 4 pairs of ~2048 keypoints, 8 of <= 1024:
+    the batch must fit the chip-resident Sinkhorn); with ``workers`` > 1 several such groups are in flight.  Rows do not depend on it.
+    ``schedule``: how pairs map to ranks - 'block' (contiguous blocks, :func:`imp_release_amd.dist.shard_range`) or 'lpt' (longest
+    processing time first over ``pair_cost(pid)``: see :func:`imp_release_amd.dist.lpt_assignment`)."""
     stop_criteria = {'pose': 1.5} if stop_criteria is None else stop_criteria
     ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     rank = dist.get_rank(group) if ddp else 0
     world = dist.get_world_size(group) if ddp else 1
-    s, e = shard_range(n_pairs, rank, world)
-    rows = np.zeros((e - s, len(SUMMARY_COLUMNS)), dtype=np.float64)
+    if schedule == 'lpt':
+        if pair_cost is None:
+            raise ValueError("schedule='lpt' needs pair_cost(pair_id) -> relative cost (e.g. n0 * n1)")
+        mine = lpt_assignment([pair_cost(i) for i in range(n_pairs)], world)[rank]
+    elif schedule == 'block':
+        mine = list(range(*shard_range(n_pairs, rank, world)))
+    else:
+        raise ValueError("schedule: 'block' or 'lpt'")
+    pos = {pid: i for i, pid in enumerate(mine)}
+
+    class _Rows:                                  # rows[pid - s] of the block schedule, for any id list
+        def __init__(self):
+            self.a = np.zeros((len(mine), len(SUMMARY_COLUMNS)), dtype=np.float64)
+
+        def __setitem__(self, k, v):
+            self.a[pos[k]] = v
+    s = 0
+    rows = _Rows()
     loop = matching.matching_iterative_uncertainty if eimp else matching.matching_iterative
+    lockstep = 1 if eimp else max(1, int(lockstep))
+    # units of work: single pairs, or groups of `lockstep` pairs that advance together (pairs of similar cost side by side under 'lpt':
+    # the list is ascending in pair id, the provider's order)
+    units = [mine[a:a + lockstep] for a in range(0, len(mine), lockstep)]
 
-    def run_one(m, pid):
-        data = pair_provider(pid)
-        out = loop(data, m, nI, match_ratio, min_kpts, error_th, stop_criteria, estimate_pose=estimate_pose)
-        return summarize(out, eimp, data, estimate_pose, error_th)
+    def run_unit(m, pids):
+        if len(pids) == 1 and lockstep == 1:
+            data = pair_provider(pids[0])
+            out = loop(data, m, nI, match_ratio, min_kpts, error_th, stop_criteria, estimate_pose=estimate_pose)
+            rows[pids[0] - s] = summarize(out, eimp, data, estimate_pose, error_th)
+            return
+        datas = [pair_provider(pid) for pid in pids]
+        from . import _lib
+        try:
+            outs = matching.matching_iterative_lockstep(datas, m, nI, match_ratio, min_kpts, error_th, stop_criteria, estimate_pose=estimate_pose)
+        except _lib.ResidentSinkhornTimeout:          # a voided launch inside the pipelined group: once more, on the protocol the context stepped down to
+            outs = matching.matching_iterative_lockstep(datas, m, nI, match_ratio, min_kpts, error_th, stop_criteria, estimate_pose=estimate_pose)
+        for pid, data, out in zip(pids, datas, outs):
+            rows[pid - s] = summarize(out, False, data, estimate_pose, error_th)
 
-    workers = max(1, min(int(workers), e - s))
+    workers = max(1, min(int(workers), len(units)))
     if workers == 1:
         with torch.no_grad():
-            for i, pid in enumerate(range(s, e)):
-                rows[i] = run_one(model, pid)
+            for u in units:
+                run_unit(model, u)
     else:
         models = list(replicas) if replicas is not None else replicate(model, workers)
         if len(models) < workers:
@@ -142,7 +178,7 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
         device = model._device()
         if device.type == 'cuda' and device.index is None:
             device = torch.device('cuda', torch.cuda.current_device())
-        todo = iter(range(s, e))
+        todo = iter(units)
         lock = threading.Lock()
         errors = []
 
@@ -154,15 +190,15 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
                 with torch.no_grad():
                     while not errors:
                         with lock:
-                            pid = next(todo, None)
-                        if pid is None:
+                            unit = next(todo, None)
+                        if unit is None:
                             return
                         if stream is not None:
                             with torch.cuda.stream(stream):
-                                rows[pid - s] = run_one(m, pid)
+                                run_unit(m, unit)
                             stream.synchronize()
                         else:
-                            rows[pid - s] = run_one(m, pid)
+                            run_unit(m, unit)
             except BaseException as ex:                  # surfaced on the calling thread
                 errors.append(ex)
 
@@ -174,9 +210,29 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
         if errors:
             raise errors[0]
     if not ddp:
-        return rows
-    return gather_rows_across_ranks(rows, n_pairs, device=model._device() if hasattr(model, '_device') else 'cpu',
-                                    group=group)
+        return rows.a
+    return gather_rows_by_id(rows.a, mine, n_pairs, device=model._device() if hasattr(model, '_device') else 'cpu', group=group)
+
+
+def gather_rows_by_id(rows: np.ndarray, ids, n_total: int, device='cpu', group=None) -> np.ndarray:
+    """one equal-size all-gather of (pair id, row) blocks padded to the largest rank's count -> the full table in pair order (any
+    assignment of pairs to ranks: contiguous blocks or dist.lpt_assignment)"""
+    world, width = dist.get_world_size(group), rows.shape[1]
+    cnt = torch.tensor([len(ids)], dtype=torch.int64, device=device)
+    cnts = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(cnts, cnt, group=group)
+    per = int(cnts.max().item())
+    pad = torch.full((per, width + 1), -1.0, dtype=torch.float64, device=device)
+    if len(ids):
+        pad[:len(ids), 0] = torch.tensor(list(ids), dtype=torch.float64, device=device)
+        pad[:len(ids), 1:] = torch.from_numpy(rows).to(device)
+    out = torch.empty(world * per, width + 1, dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    out = out.cpu().numpy()
+    table = np.full((n_total, width), np.nan)
+    valid = out[:, 0] >= 0
+    table[out[valid, 0].astype(np.int64)] = out[valid, 1:]
+    return table
 
 
 def gather_rows_across_ranks(rows: np.ndarray, n_total: int, device='cpu', group=None) -> np.ndarray:

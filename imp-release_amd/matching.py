@@ -4,6 +4,8 @@ Same signatures, schedule and return tuples as the reference:
 
 * ``matching_iterative``             eval/matching.py:16-123   (IMP)
 * ``matching_iterative_uncertainty`` eval/matching.py:126-276  (EIMP: adaptive pooling + real ragged slicing)
+* ``matching_iterative_lockstep``    round 4: B pairs of DIFFERENT sizes through ``matching_iterative`` together - one kernel launch per
+  layer for the whole (ragged) batch, every pair keeping its own early exit; per-pair results equal ``matching_iterative``'s
 
 The GPU work goes through the step API of :mod:`imp_release_amd.modules` (HIP kernels).  The pose step
 of the reference (``cv2.findEssentialMat(USAC_MAGSAC)``, eval/pose_estimation.py:92-115) is a CPU
@@ -162,3 +164,194 @@ def matching_iterative_uncertainty(data, model, nI, match_ratio, min_kpts, error
     r = _loop(data, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method, estimate_pose, True,
               with_uncertainty, trace)
     return (r[0], r[1], r[2][0].cpu().numpy(), r[3][0].cpu().numpy(), r[4], r[5], r[6], r[7], r[8])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# lock-step batches (round 4)
+# ----------------------------------------------------------------------------------------------------------------------
+class _PoseWorkers:
+    """a few host threads, each with its own stream, for the pose estimates of one scored iteration: the calls of different pairs are
+    independent, latency-bound (a fraction of a millisecond of small kernels + one read-back each) and overlap on the GPU"""
+
+    def __init__(self, n, device):
+        from concurrent.futures import ThreadPoolExecutor
+        import threading
+        self.device = device
+        self.local = threading.local()
+        self.pool = ThreadPoolExecutor(max_workers=max(1, n))
+
+    def _call(self, fn, kw):
+        if self.device.type == 'cuda':
+            if not hasattr(self.local, 'stream'):
+                torch.cuda.set_device(self.device)           # a new thread starts with device 0 current
+                self.local.stream = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(self.local.stream):
+                return fn(**kw)
+        return fn(**kw)
+
+    def map(self, fn, kws):
+        futs = [self.pool.submit(self._call, fn, kw) for kw in kws]
+        return [f.result() for f in futs]
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+
+
+_POSE_POOLS = {}
+
+
+def _pose_workers(n, device):
+    """one pool per (calling thread, device, size), kept for the life of the process: creating and joining 4 threads cost 8 ms per group"""
+    import threading
+    key = (threading.get_ident(), str(device), n)
+    pool = _POSE_POOLS.get(key)
+    if pool is None:
+        pool = _POSE_POOLS[key] = _PoseWorkers(n, device)
+    return pool
+
+
+def matching_iterative_lockstep(datas, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method=None, estimate_pose=None,
+                                pose_threads=4, traces=None):
+    """eval/matching.py:16-123 on SEVERAL pairs at once -> [(indices0, mscores0, R, t, n_iterations)] - per pair exactly what
+    :func:`matching_iterative` returns for it.
+
+    The reference advances one pair at a time because SuperPoint keypoint counts differ per image (eval/eval_imp.py:60-70); at batch 1
+    every kernel of the loop is a few workgroups on a 256-CU chip.  Here the pairs form ONE ragged batch (tensors padded to the largest
+    pair, per-pair counts through ``imp_set_counts``): a layer is one launch for all of them, a scored iteration one
+    ``imp_match_tail`` + one device->host copy, then every live pair runs its own host-side step of the reference loop (matched-count
+    gate, pose estimate, pose-change test).  A pair that exits early is RETIRED - its counts become 0 and its workgroups leave at once -
+    while the others go on.  The final ``compute_matches(pred_score, 0.2)`` of pairs that never exit (eval/matching.py:119) needs no
+    second Sinkhorn: mscores0 do not depend on the threshold and indices0 at 0.2 are the indices at ``match_ratio`` <= 0.2 with
+    scores <= 0.2 cleared (nets/gm.py:312-318).  IMP / GM loop only (the EIMP loop re-slices every pair after each pool)."""
+    B = len(datas)
+    if B == 0:
+        return []
+    if match_ratio > 0.2:
+        raise ValueError('the lock-step loop derives the final p = 0.2 matches from the scored ones: match_ratio must be <= 0.2')
+    ctx = model._ensure_ctx(check=True)
+    dev = model._device()
+    n0s = [int(d['keypoints0'].shape[1]) for d in datas]
+    n1s = [int(d['keypoints1'].shape[1]) for d in datas]
+    N0, N1 = max(n0s), max(n1s)
+    D = int(datas[0]['descriptors0'].shape[-1])
+
+    def padded(key, n, width):
+        out = torch.zeros((B, n) + ((width,) if width else ()), device=dev, dtype=torch.float32)
+        for b, d in enumerate(datas):
+            v = d[key][0] if key in d else None
+            out[b, :v.shape[0]] = v
+        return out
+
+    nk = [_normalize(model, d) for d in datas]                                  # (image-size normalisation per pair: eval/matching.py:20-26)
+    nk0 = torch.zeros(B, N0, 2, device=dev); nk1 = torch.zeros(B, N1, 2, device=dev)
+    for b in range(B):
+        nk0[b, :n0s[b]] = nk[b][0][0]; nk1[b, :n1s[b]] = nk[b][1][0]
+    sc0, sc1 = padded('scores0', N0, 0), padded('scores1', N1, 0)
+    de0, de1 = padded('descriptors0', N0, D), padded('descriptors1', N1, D)
+    live = [True] * B
+    c0, c1 = list(n0s), list(n1s)
+    results = [None] * B
+    last_R = [None] * B; last_t = [None] * B
+    last_scored = [None] * B                                                     # (indices0, mscores0) of the newest scored iteration
+    pose_pool = _pose_workers(pose_threads, dev) if estimate_pose is not None and pose_threads > 1 and B > 1 else None
+    try:
+        ctx.set_counts(c0, c1)
+        desc0, desc1 = ctx.encode_keypoints(nk0, sc0, nk1, sc1, de0, de1)
+        layers_done = -1                                                         # last iteration whose two layers are enqueued
+        pinned = torch.empty((B, N0 * 12), dtype=torch.uint8).pin_memory() if dev.type == 'cuda' else None
+        for it in range(nI):
+            if layers_done < it:
+                for li in (2 * it, 2 * it + 1):
+                    desc0, desc1 = ctx.forward_layer(li, desc0, desc1, inplace=True)
+                    model._note_layer(li, B, N0, N1)
+                layers_done = it
+            if it not in VALID_ITS:
+                continue
+            pipelined = False
+            for attempt in range(3):
+                try:
+                    r = ctx.match_tail(it, desc0, desc1, model._bin(None), model.sinkhorn_iterations, model.with_sinkhorn, match_ratio)
+                except _lib.ResidentSinkhornTimeout:
+                    continue                                                       # (an EARLIER call's void noticed at this entry: nothing of this iteration ran yet)
+                pk = pack_matches(r['indices0'], r['mscores0'])
+                if pinned is not None and attempt == 0 and it + 1 < nI:
+                    # software pipeline: the copy of this iteration's matches and the NEXT iteration's two layers are enqueued before
+                    # the host turns to the pose estimates, so the GPU keeps working through them.  A pair that exits now has those
+                    # layers computed for nothing (its result is already taken; it is retired before the iteration after)
+                    pinned.copy_(pk, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    for li in (2 * it + 2, 2 * it + 3):
+                        desc0, desc1 = ctx.forward_layer(li, desc0, desc1, inplace=True)
+                        model._note_layer(li, B, N0, N1)
+                    layers_done = it + 1
+                    pipelined = True
+                    ev.synchronize()
+                    packed = pinned
+                else:
+                    packed = pk.cpu()                                              # the one sync of this iteration, all pairs
+                if ctx.resident_health(raise_on_timeout=False) is not False:
+                    break
+                if pipelined:
+                    # a voided Sinkhorn launch, and the descriptors it would have to be recomputed from are already two layers further:
+                    # the group has to start over (eval_loop does; the context has stepped down to a safer protocol meanwhile)
+                    raise _lib.ResidentSinkhornTimeout(_lib.IMP_E_RESIDENT, 'a score of this lock-step group was voided after the next layers were enqueued: re-run the group')
+            else:
+                raise _lib.ResidentSinkhornTimeout(_lib.IMP_E_RESIDENT, 'the Sinkhorn score stayed void on every protocol')
+            # (numpy views of the one host buffer: torch's strided CPU copies of a [B, 12 N] byte tensor cost milliseconds on a many-core host)
+            buf = packed.numpy()
+            idx_h = np.ascontiguousarray(buf[:, :N0 * 8]).view(np.int64)
+            ms_h = np.ascontiguousarray(buf[:, N0 * 8:]).view(np.float32)
+            todo = []
+            for b in range(B):
+                if not live[b]:
+                    continue
+                i_cpu, m_cpu = idx_h[b, :n0s[b]].copy(), ms_h[b, :n0s[b]].copy()
+                last_scored[b] = (i_cpu, m_cpu)
+                if traces is not None:
+                    traces[b].append({'it': it, 'indices0': i_cpu.copy(), 'mscores0': m_cpu.copy()})
+                matched0 = np.nonzero(i_cpu > -1)[0]
+                if matched0.shape[0] < min_kpts:                                   # eval/matching.py:63-66
+                    last_R[b] = last_t[b] = None
+                    continue
+                pm = np.stack([matched0, i_cpu[matched0]], axis=1)
+                todo.append((b, pm))
+            rets = {}
+            if estimate_pose is not None and todo:
+                kws = [dict(kpts0=datas[b]['pts0_cpu'][pm[:, 0]], kpts1=datas[b]['pts1_cpu'][pm[:, 1]], K0=datas[b].get('K0'), K1=datas[b].get('K1'),
+                            norm_thresh=error_th, method=method) for b, pm in todo]
+                got = pose_pool.map(estimate_pose, kws) if pose_pool is not None else [estimate_pose(**kw) for kw in kws]
+                rets = {b: g for (b, _), g in zip(todo, got)}
+            retired = False
+            for b, pm in todo:
+                ret = rets.get(b)
+                if ret is not None:
+                    E, R, t, inl = ret
+                else:
+                    R = t = None
+                    inl = np.zeros(pm.shape[0], dtype=bool)
+                if it >= 1:
+                    diff_R = angle_error_mat(last_R[b], R) if last_R[b] is not None and R is not None else np.inf
+                    diff_t = angle_error_vec(last_t[b], t) if last_t[b] is not None and t is not None else np.inf
+                else:
+                    diff_R, diff_t = np.inf, np.inf
+                last_R[b], last_t[b] = R, t
+                if 'pose' in stop_criteria.keys() and np.max([diff_R, diff_t]) <= stop_criteria['pose']:      # eval/matching.py:110-117
+                    i_cpu, m_cpu = last_scored[b]
+                    o = np.zeros_like(i_cpu) - 1
+                    o[pm[inl, 0]] = pm[inl, 1]
+                    results[b] = (o, m_cpu, R, t, it + 1)
+                    live[b] = False
+                    c0[b] = c1[b] = 0
+                    retired = True
+            if not any(live):
+                break
+            if retired:
+                ctx.set_counts(c0, c1)
+    finally:
+        ctx.set_counts()
+    for b in range(B):
+        if results[b] is None:                                                     # never exited: compute_matches(pred_score, 0.2)
+            i_cpu, m_cpu = last_scored[b]
+            results[b] = (np.where(m_cpu > 0.2, i_cpu, -1), m_cpu, None, None, nI)
+    return results

@@ -181,7 +181,12 @@ class GM(nn.Module):
 
     def _weights_version(self):
         # _version catches in-place updates (load_state_dict, optimiser steps), data_ptr catches `p.data = new_tensor`
-        ps = list(self.parameters()) + list(self.buffers())
+        # (the module tree is walked once: nn.Module.parameters() costs ~1.5 ms per call for the ~350 tensors - more than a batch-1 pair's
+        # whole host time; `.to()` / load_state_dict, which may replace Parameter objects, drop the list through _apply / load_state_dict)
+        ps = self.__dict__.get('_ps_cache')
+        if ps is None:
+            ps = list(self.parameters()) + list(self.buffers())
+            self.__dict__['_ps_cache'] = ps
         return (str(self._device()), tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
 
     def refresh_weights(self):
@@ -191,11 +196,17 @@ class GM(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._ctx_key = None
-        return super()._apply(fn, *a, **k)
+        self.__dict__.pop('_ps_cache', None)
+        r = super()._apply(fn, *a, **k)
+        self.__dict__.pop('_ps_cache', None)
+        return r
 
     def load_state_dict(self, *a, **k):
         self._ctx_key = None
-        return super().load_state_dict(*a, **k)
+        self.__dict__.pop('_ps_cache', None)
+        r = super().load_state_dict(*a, **k)
+        self.__dict__.pop('_ps_cache', None)
+        return r
 
     def _ensure_ctx(self, check: bool = False) -> _lib.Context:
         """check=True (entry points of a pair: produce_matches / run / encode_keypoint / the loops) walks the ~350

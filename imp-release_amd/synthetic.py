@@ -208,7 +208,7 @@ def make_correlated_pair(n0: int, n1: int, desc_dim: int = 256, seed: int = 0, b
 
 
 def make_two_view_pair(n0: int, n1: int, desc_dim: int = 256, seed: int = 0, overlap: float = 0.6, noise_px: float = 0.5,
-                       desc_noise: float = 0.25, angle_deg: float = 12.0, width: int = 640, height: int = 480):
+                       desc_noise: float = 0.25, angle_deg: float = 12.0, width: int = 640, height: int = 480, outlier_ratio: float = 0.0):
     """A pair with GEOMETRY: image 0 sees random 3D points, image 1 re-observes a fraction ``overlap`` of them from a second camera
     (rotation ``angle_deg`` about a random axis, unit baseline, pixel noise ``noise_px``, descriptors perturbed like
     :func:`make_correlated_pair`); every other keypoint of either image is an unrelated distractor.  On such pairs the pose step and
@@ -240,10 +240,34 @@ def make_two_view_pair(n0: int, n1: int, desc_dim: int = 256, seed: int = 0, ove
     out['descriptors1'][0, dst] = d.astype(np.float32)
     out['keypoints1'][0, dst] = x1.astype(np.float32)
     out['scores1'][0, dst] = np.clip(out['scores0'][0, src] + 0.05 * g.standard_normal(size=len(src)), 0.01, 0.99).astype(np.float32)
+    if outlier_ratio > 0.0:
+        # look-alikes (round 4: the evaluation set must not be a best case): further keypoints of image 0 get a descriptor twin at an
+        # UNRELATED position of image 1 - a descriptor-driven matcher pairs them up, the geometry says no.  `outlier_ratio` = their share
+        # of all planted correspondences
+        used0, used1 = np.zeros(n0, bool), np.zeros(n1, bool)
+        used0[src] = True; used1[dst] = True
+        free0, free1 = np.nonzero(~used0)[0], np.nonzero(~used1)[0]
+        m = int(round(len(src) * outlier_ratio / max(1e-9, 1.0 - outlier_ratio)))
+        m = min(m, len(free0), len(free1))
+        a = g.permutation(free0)[:m]
+        b = g.permutation(free1)[:m]
+        dd = out['descriptors0'][0, a] + desc_noise * g.standard_normal(size=(m, desc_dim)).astype(np.float32) / np.sqrt(desc_dim)
+        dd /= np.maximum(np.linalg.norm(dd, axis=-1, keepdims=True), 1e-12)
+        out['descriptors1'][0, b] = dd.astype(np.float32)
     tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
     out.update({'K0': K.copy(), 'K1': K.copy(), 'T_0to1': np.hstack([R, t.reshape(3, 1)]), 'E': tx @ R,
                 'true_matches': np.stack([src, dst], 1)})
     return out
+
+
+def make_hard_two_view_pair(seed: int, n_lo: int = 1000, n_hi: int = 2048, **kw):
+    """one pair of the HARDER evaluation set of round 4 (the 64 scenes of round 3 all left the loop at the earliest
+    possible iteration): keypoint counts ~ U(n_lo, n_hi) per image, overlap ~ U(0.2, 0.8), pixel noise ~ U(0.5, 2), look-alike
+    outliers ~ U(0.3, 0.7) of the planted correspondences, rotation ~ U(5, 25) degrees - all drawn from the pair's seed"""
+    g = _rng_for(seed, 'pair.hard')
+    n0, n1 = int(g.integers(n_lo, n_hi + 1)), int(g.integers(n_lo, n_hi + 1))
+    return make_two_view_pair(n0, n1, seed=seed, overlap=float(g.uniform(0.2, 0.8)), noise_px=float(g.uniform(0.5, 2.0)),
+                              outlier_ratio=float(g.uniform(0.3, 0.7)), angle_deg=float(g.uniform(5.0, 25.0)), **kw)
 
 
 class PoseStub:

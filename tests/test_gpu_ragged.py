@@ -158,3 +158,89 @@ def test_ragged_argument_errors():
     bad = dict(data, num_keypoints0=[64, 99])
     with pytest.raises(ValueError):
         m.produce_matches(bad, p=0.2, only_last=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------- lock-step loops
+def _loop_dict(p):
+    d = _single(p)
+    d['pts0_cpu'], d['pts1_cpu'] = p['keypoints0'][0], p['keypoints1'][0]
+    for k in ('K0', 'K1', 'T_0to1', 'E'):
+        if k in p:
+            d[k] = p[k]
+    if 'K0' not in d:
+        d['K0'] = d['K1'] = np.eye(3)
+    return d
+
+
+@pytest.mark.parametrize('name', ['imp_loop_n400', 'imp_loop_exit_n400'])
+def test_lockstep_loop_of_one_pair_vs_the_reference_fixture(name):
+    """the host logic of the lock-step loop (matching_iterative_lockstep) pinned to the reference-captured IMP loop fixtures: all 15
+    iterations with the final p = 0.2 matches DERIVED from the last scored iteration (no second Sinkhorn), and the pose-change early
+    exit with inlier-filtered indices"""
+    from helpers import build_case
+    from imp_release_amd import matching as hip_matching
+    spec, z = load_golden(name)
+    cfg, sd, data = build_case(spec, DEV)
+    m = make_hip_model(spec, cfg, sd)
+    sched = spec.get('pose_schedule')
+    stub = synthetic.PoseStub(sched) if sched is not None else None
+    d = dict(data)
+    d['pts0_cpu'] = data['keypoints0'][0].cpu().numpy(); d['pts1_cpu'] = data['keypoints1'][0].cpu().numpy()
+    d['K0'] = d['K1'] = np.eye(3)
+    with torch.no_grad():
+        (i0, ms0, R, t, nit), = hip_matching.matching_iterative_lockstep([d], m, 15, 0.1, 25, 1.0, {'pose': 1.5}, method=38, estimate_pose=stub,
+                                                                        pose_threads=1)
+    assert nit == int(z['n_iter'])
+    assert np.array_equal(i0, z['indices0']), f'{name}: {(i0 != z["indices0"]).sum()} indices differ'
+    assert np.abs(ms0.astype(np.float64) - z['mscores0']).max() <= TOL
+    if 'R' in z.files:
+        assert np.allclose(R, z['R']) and np.allclose(t, z['t'])
+    else:
+        assert R is None and t is None
+
+
+@pytest.mark.parametrize('pose_threads', [1, 4])
+def test_lockstep_loop_equals_the_pairs_one_at_a_time(pose_threads):
+    """4 pairs of different sizes and difficulty through the IMP loop TOGETHER (one ragged batch, per-pair early exit, the GPU pose step
+    in its estimate_pose slot) = each pair through matching_iterative alone: same exit iteration, same matches, same pose"""
+    from imp_release_amd import matching as hip_matching, pose as gpose
+    cfg = eval_config()
+    sd = synthetic.make_state_dict(cfg, 'DGNNS', seed=0, bin_score=synthetic.MATCHING_BIN_SCORE, style='matching')
+    m = make_hip_model('DGNNS', cfg, sd)
+    pairs = [synthetic.make_hard_two_view_pair(seed=9100 + k, n_lo=500, n_hi=1400) for k in range(3)] + [synthetic.make_two_view_pair(900, 860, seed=9200)]
+    datas = [_loop_dict(p) for p in pairs]
+    with torch.no_grad():
+        solo = [hip_matching.matching_iterative(d, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, estimate_pose=gpose.estimate_pose) for d in datas]
+        together = hip_matching.matching_iterative_lockstep(datas, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, estimate_pose=gpose.estimate_pose,
+                                                            pose_threads=pose_threads)
+    iters = [s_[4] for s_ in solo]
+    print('exit iterations:', iters)
+    for b, (a, c) in enumerate(zip(solo, together)):
+        assert a[4] == c[4], f'pair {b}: n_iterations {a[4]} alone, {c[4]} in the batch'
+        assert np.array_equal(a[0], c[0]), f'pair {b}: {(a[0] != c[0]).sum()} indices differ'
+        assert np.abs(a[1].astype(np.float64) - c[1]).max() <= TOL
+        assert (a[2] is None) == (c[2] is None)
+        if a[2] is not None:
+            assert np.allclose(a[2], c[2], atol=1e-6) and np.allclose(a[3], c[3], atol=1e-6)
+    assert m._ensure_ctx().resident_health() == (0, 0)
+
+
+def test_eval_loop_lockstep_rows_equal_the_sequential_rows():
+    from imp_release_amd import eval_loop, pose as gpose
+    cfg = eval_config()
+    sd = synthetic.make_state_dict(cfg, 'DGNNS', seed=0, bin_score=synthetic.MATCHING_BIN_SCORE, style='matching')
+    m = make_hip_model('DGNNS', cfg, sd)
+    pairs = [synthetic.make_hard_two_view_pair(seed=9300 + k, n_lo=400, n_hi=1000) for k in range(7)]
+
+    def provider(pid):
+        return _loop_dict(pairs[pid])
+
+    kw = dict(estimate_pose=gpose.estimate_pose)
+    seq = eval_loop.run_pairs_sharded(m, provider, 7, **kw)
+    lock = eval_loop.run_pairs_sharded(m, provider, 7, lockstep=3, **kw)
+    both = eval_loop.run_pairs_sharded(m, provider, 7, lockstep=2, workers=2, **kw)
+    cols = [eval_loop.SUMMARY_COLUMNS.index(c) for c in ('n_iterations', 'n_matches', 'precision', 'matching_score')]
+    for other in (lock, both):
+        assert np.array_equal(seq[:, cols], other[:, cols])
+        assert np.allclose(seq, other, atol=1e-4, equal_nan=True)
+    print(eval_loop.aggregate(seq))
