@@ -189,6 +189,9 @@ class _PoseWorkers:
                 return fn(**kw)
         return fn(**kw)
 
+    def submit(self, fn, kw):
+        return self.pool.submit(self._call, fn, kw)
+
     def map(self, fn, kws):
         futs = [self.pool.submit(self._call, fn, kw) for kw in kws]
         return [f.result() for f in futs]
@@ -197,7 +200,26 @@ class _PoseWorkers:
         self.pool.shutdown(wait=True)
 
 
+class _Done:
+    def __init__(self, v):
+        self.v = v
+
+    def result(self):
+        return self.v
+
+
 _POSE_POOLS = {}
+_PINNED = {}
+
+
+def _pinned_bytes(n):
+    """a page-locked staging buffer of >= n bytes per calling thread, kept (allocating page-locked memory costs milliseconds)"""
+    import threading
+    key = threading.get_ident()
+    buf = _PINNED.get(key)
+    if buf is None or buf.numel() < n:
+        buf = _PINNED[key] = torch.empty(max(n, 1 << 18), dtype=torch.uint8).pin_memory()
+    return buf[:n]
 
 
 def _pose_workers(n, device):
@@ -253,12 +275,41 @@ def matching_iterative_lockstep(datas, model, nI, match_ratio, min_kpts, error_t
     results = [None] * B
     last_R = [None] * B; last_t = [None] * B
     last_scored = [None] * B                                                     # (indices0, mscores0) of the newest scored iteration
-    pose_pool = _pose_workers(pose_threads, dev) if estimate_pose is not None and pose_threads > 1 and B > 1 else None
+    pose_pool = _pose_workers(max(pose_threads, B), dev) if estimate_pose is not None and pose_threads > 1 else None
+    pending = [None] * B                                                         # (future, iteration, matches handed to the pose step, indices0, mscores0)
+
+    def resolve(b):
+        """finish pair b's outstanding pose estimate and take its exit test (eval/matching.py:84-117); True when the pair exits"""
+        pend, pending[b] = pending[b], None
+        if pend is None:
+            return False
+        fut, it_k, pm, i_cpu, m_cpu = pend
+        ret = fut.result() if fut is not None else None
+        if ret is not None:
+            E, R, t, inl = ret
+        else:
+            R = t = None
+            inl = np.zeros(pm.shape[0], dtype=bool)
+        if it_k >= 1:
+            diff_R = angle_error_mat(last_R[b], R) if last_R[b] is not None and R is not None else np.inf
+            diff_t = angle_error_vec(last_t[b], t) if last_t[b] is not None and t is not None else np.inf
+        else:
+            diff_R, diff_t = np.inf, np.inf
+        last_R[b], last_t[b] = R, t
+        if 'pose' in stop_criteria.keys() and np.max([diff_R, diff_t]) <= stop_criteria['pose']:      # eval/matching.py:110-117
+            o = np.zeros_like(i_cpu) - 1
+            o[pm[inl, 0]] = pm[inl, 1]
+            results[b] = (o, m_cpu, R, t, it_k + 1)
+            live[b] = False
+            c0[b] = c1[b] = 0
+            return True
+        return False
+
     try:
         ctx.set_counts(c0, c1)
         desc0, desc1 = ctx.encode_keypoints(nk0, sc0, nk1, sc1, de0, de1)
         layers_done = -1                                                         # last iteration whose two layers are enqueued
-        pinned = torch.empty((B, N0 * 12), dtype=torch.uint8).pin_memory() if dev.type == 'cuda' else None
+        pinned = _pinned_bytes(B * N0 * 12).view(B, N0 * 12) if dev.type == 'cuda' else None
         for it in range(nI):
             if layers_done < it:
                 for li in (2 * it, 2 * it + 1):
@@ -302,9 +353,16 @@ def matching_iterative_lockstep(datas, model, nI, match_ratio, min_kpts, error_t
             buf = packed.numpy()
             idx_h = np.ascontiguousarray(buf[:, :N0 * 8]).view(np.int64)
             ms_h = np.ascontiguousarray(buf[:, N0 * 8:]).view(np.float32)
-            todo = []
+            retired = False
             for b in range(B):
                 if not live[b]:
+                    continue
+                # the pose estimate this pair started at its PREVIOUS scored iteration ran beside the two iterations since (deferred
+                # decision: the pose step is latency, not GPU load, so the exit test of iteration k is taken at the next scored
+                # iteration - a pair that exits is returned with the matches, the pose and the count of iteration k all the same; what it
+                # computed since is dropped)
+                if resolve(b):
+                    retired = True
                     continue
                 i_cpu, m_cpu = idx_h[b, :n0s[b]].copy(), ms_h[b, :n0s[b]].copy()
                 last_scored[b] = (i_cpu, m_cpu)
@@ -315,39 +373,24 @@ def matching_iterative_lockstep(datas, model, nI, match_ratio, min_kpts, error_t
                     last_R[b] = last_t[b] = None
                     continue
                 pm = np.stack([matched0, i_cpu[matched0]], axis=1)
-                todo.append((b, pm))
-            rets = {}
-            if estimate_pose is not None and todo:
-                kws = [dict(kpts0=datas[b]['pts0_cpu'][pm[:, 0]], kpts1=datas[b]['pts1_cpu'][pm[:, 1]], K0=datas[b].get('K0'), K1=datas[b].get('K1'),
-                            norm_thresh=error_th, method=method) for b, pm in todo]
-                got = pose_pool.map(estimate_pose, kws) if pose_pool is not None else [estimate_pose(**kw) for kw in kws]
-                rets = {b: g for (b, _), g in zip(todo, got)}
-            retired = False
-            for b, pm in todo:
-                ret = rets.get(b)
-                if ret is not None:
-                    E, R, t, inl = ret
+                kw = dict(kpts0=datas[b]['pts0_cpu'][pm[:, 0]], kpts1=datas[b]['pts1_cpu'][pm[:, 1]], K0=datas[b].get('K0'), K1=datas[b].get('K1'),
+                          norm_thresh=error_th, method=method)
+                if estimate_pose is None:
+                    fut = None
+                elif pose_pool is not None:
+                    fut = pose_pool.submit(estimate_pose, kw)
                 else:
-                    R = t = None
-                    inl = np.zeros(pm.shape[0], dtype=bool)
-                if it >= 1:
-                    diff_R = angle_error_mat(last_R[b], R) if last_R[b] is not None and R is not None else np.inf
-                    diff_t = angle_error_vec(last_t[b], t) if last_t[b] is not None and t is not None else np.inf
-                else:
-                    diff_R, diff_t = np.inf, np.inf
-                last_R[b], last_t[b] = R, t
-                if 'pose' in stop_criteria.keys() and np.max([diff_R, diff_t]) <= stop_criteria['pose']:      # eval/matching.py:110-117
-                    i_cpu, m_cpu = last_scored[b]
-                    o = np.zeros_like(i_cpu) - 1
-                    o[pm[inl, 0]] = pm[inl, 1]
-                    results[b] = (o, m_cpu, R, t, it + 1)
-                    live[b] = False
-                    c0[b] = c1[b] = 0
+                    fut = _Done(estimate_pose(**kw))
+                pending[b] = (fut, it, pm, i_cpu, m_cpu)
+                if pose_pool is None and resolve(b):                               # (no worker threads: nothing to overlap, decide at once)
                     retired = True
             if not any(live):
                 break
             if retired:
                 ctx.set_counts(c0, c1)
+        for b in range(B):                                                         # the estimates of the last scored iteration
+            if live[b]:
+                resolve(b)
     finally:
         ctx.set_counts()
     for b in range(B):
