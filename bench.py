@@ -309,6 +309,11 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    numa_cpus = None
+    if world > 1:
+        # one process per GPU: this rank's host threads (step workers, exchange lane, pose workers, prefetcher) next to its GPU's NUMA node
+        from imp_release_amd import dist as _pd
+        numa_cpus = _pd.pin_to_gpu_numa(local_rank)
     import torch.distributed as dist
     use_pg = world > 1 or bool(os.environ.get('IMP_FORCE_COLLECTIVES'))     # the latter: one-rank check of the RCCL path
     if use_pg:
@@ -472,6 +477,7 @@ def main():
                                    f'seeded random weights',
                        'pairs_per_gpu': B, 'keypoints': N, 'parallelism': f'pair-sharded x{world}',
                        'steps_in_flight_per_gpu': inflight, 'steps_in_flight_calibration': calibration,
+                       'rank0_numa_cpus': None if numa_cpus is None else len(numa_cpus),
                        'sinkhorn_storage_bytes': args.sinkhorn_storage,
                        'matched_keypoints': n_matched},
             'roofline': {'bound': 'mfma', 'kernel': kname,

@@ -47,10 +47,39 @@ def main():
     par = pipeline.StepPipeline([make_fn(r, i, 3) for i, r in enumerate(reps)], 2, device=dev).run(7, keep=True)
     same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(seq, par))
     distinct = not torch.equal(seq[0][0], seq[1][0])
+    # round 4: a SECOND communicator alive and busy in the same process (another process group, its own stream and host
+    # thread) beside the ordered exchange lane and the spin gate of the waiting kernels: the steps must still come out identical
+    import threading
+    g2 = dist.new_group(ranks=[0], backend='nccl')
+    stop, counts = threading.Event(), []
+
+    def noise():
+        torch.cuda.set_device(dev)
+        s2 = torch.cuda.Stream(dev)
+        x, out = torch.ones(4096, device=dev), torch.empty(4096, device=dev)
+        n = 0
+        with torch.cuda.stream(s2):
+            while not stop.is_set():
+                dist.all_gather_into_tensor(out, x, group=g2)
+                n += 1
+                if n % 16 == 0:
+                    s2.synchronize()
+            s2.synchronize()
+        counts.append((n, bool((out == 1).all())))
+
+    th = threading.Thread(target=noise, daemon=True)
+    th.start()
+    par2 = pipeline.StepPipeline([make_fn(r, i, 3) for i, r in enumerate(reps)], 2, device=dev).run(7, keep=True)
+    stop.set()
+    th.join(timeout=60)
+    same2 = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(seq, par2))
+    healthy = all(r._ensure_ctx().resident_health() == (0, 0) for r in reps)
     dist.barrier()
     dist.destroy_process_group()
     print(json.dumps({'steps': len(par), 'same': bool(same), 'distinct_batches': bool(distinct),
-                      'backend': 'nccl', 'matched': int((par[-1][0] >= 0).sum())}), flush=True)
+                      'backend': 'nccl', 'matched': int((par[-1][0] >= 0).sum()), 'same_beside_a_second_process_group': bool(same2),
+                      'second_group_collectives': counts[0][0] if counts else -1, 'second_group_ok': bool(counts and counts[0][1]),
+                      'no_waiting_kernel_timed_out': bool(healthy)}), flush=True)
 
 
 if __name__ == '__main__':

@@ -30,6 +30,8 @@ def test_rccl_lane_single_rank_three_replicas_in_flight():
     assert r.returncode == 0, r.stderr[-3000:]
     j = _last_json(r.stdout)
     assert j['same'] and j['distinct_batches'] and j['steps'] == 7 and j['matched'] > 0, j
+    # ... and again with a second process group (its own communicator, stream and host thread) busy in the same process
+    assert j['same_beside_a_second_process_group'] and j['second_group_collectives'] > 0 and j['second_group_ok'] and j['no_waiting_kernel_timed_out'], j
 
 
 def test_bench_under_torch_distributed_run_with_the_collective_lane():

@@ -29,6 +29,10 @@ def main():
     ap.add_argument('--pose', choices=['none', 'gpu'], default='gpu')
     ap.add_argument('--overlap', type=float, default=0.6)
     ap.add_argument('--noise-px', type=float, default=0.5)
+    ap.add_argument('--hard', action='store_true', help='the harder evaluation set of round 4 (synthetic.make_hard_two_view_pair: N ~ U(1000, 2048), '
+                                                        'overlap 0.2-0.8, noise 0.5-2 px, 30-70 %% look-alike outliers) instead of fixed-size easy pairs')
+    ap.add_argument('--lockstep', type=int, default=1, help='IMP only: that many pairs advance together as one ragged batch (matching_iterative_lockstep)')
+    ap.add_argument('--schedule', choices=['block', 'lpt'], default='block', help="pairs -> ranks: contiguous blocks or longest-first by n0 * n1")
     a = ap.parse_args()
     rank, world, lr = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(lr)
@@ -51,7 +55,8 @@ def main():
 
     def host_pair(pid):
         if pid not in cache:
-            cache[pid] = synthetic.make_two_view_pair(a.kpts, a.kpts - 37, seed=1000 + pid, overlap=a.overlap, noise_px=a.noise_px)
+            cache[pid] = (synthetic.make_hard_two_view_pair(seed=1000 + pid) if a.hard else
+                          synthetic.make_two_view_pair(a.kpts, a.kpts - 37, seed=1000 + pid, overlap=a.overlap, noise_px=a.noise_px))
             pinned[pid] = {k: torch.from_numpy(cache[pid][k]).pin_memory() for k in UP}
         return cache[pid]
 
@@ -63,11 +68,11 @@ def main():
         d.update({k: pair[k] for k in ('K0', 'K1', 'T_0to1', 'E')})
         return d
 
-    s0, e0 = __import__('imp_release_amd').dist.shard_range(a.pairs, rank, world)
-    for pid in range(s0, e0):
+    for pid in range(a.pairs):                   # (every rank generates all pairs: the longest-first schedule needs every pair's size)
         host_pair(pid)
     reps = eval_loop.replicate(m, a.workers)
-    kw = dict(eimp=a.model == 'EIMP', workers=a.workers, replicas=reps)
+    kw = dict(eimp=a.model == 'EIMP', workers=a.workers, replicas=reps, lockstep=a.lockstep, schedule=a.schedule,
+              pair_cost=lambda pid: cache[pid]['keypoints0'].shape[1] * cache[pid]['keypoints1'].shape[1])
     if a.pose == 'gpu':
         from imp_release_amd import pose as gpose
         kw['estimate_pose'] = gpose.estimate_pose
