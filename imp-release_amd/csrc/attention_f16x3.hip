@@ -405,17 +405,18 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     const float* Vg = S.v + b * S.sk_b + h * DH;
     const uint8_t* mk = S.kmask ? S.kmask + (long)b * S.nk : nullptr;
 
+    // (round 4: the Q rows are only REQUESTED here; the first two K / V tiles are requested right behind them and the Q split waits
+    // for its own loads alone - the prologue used to pay two dependent memory round trips with the matrix pipe idle, Q then K / V, while
+    // all 256 workgroups of the launch pull their 64-KB Q tile and first tiles at once)
     f16x8 qh[KS], ql[KS];
+    f32x4 qraw[KS][2];
     {
         const int qrow = q0 + wave * 32 + l31;
         const float* src = Qg + (long)(qrow < nq ? qrow : nq - 1) * p.ldq + 8 * half;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(src + 16 * s);
-            const f32x4 c = *reinterpret_cast<const f32x4*>(src + 16 * s + 4);
-            const float x[8] = {a[0] * SL2E, a[1] * SL2E, a[2] * SL2E, a[3] * SL2E,
-                                c[0] * SL2E, c[1] * SL2E, c[2] * SL2E, c[3] * SL2E};
-            split8(x, qh[s], ql[s]);
+            qraw[s][0] = *reinterpret_cast<const f32x4*>(src + 16 * s);
+            qraw[s][1] = *reinterpret_cast<const f32x4*>(src + 16 * s + 4);
         }
     }
 
@@ -487,6 +488,13 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     bool need_slow = true;        // wave-uniform: some query of the wave has not seen an unmasked key yet
     load_tile(0, rkA, rvA, rbA);
     if (nt > 1) load_tile(1, rkB, rvB, rbB);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const f32x4 a = qraw[s][0], c = qraw[s][1];
+        const float x[8] = {a[0] * SL2E, a[1] * SL2E, a[2] * SL2E, a[3] * SL2E,
+                            c[0] * SL2E, c[1] * SL2E, c[2] * SL2E, c[3] * SL2E};
+        split8(x, qh[s], ql[s]);
+    }
     store_tile(0, rkA, rvA, rbA);
     if (nt > 2) load_tile(2, rkA, rvA, rbA);
     if (nt > 1) store_tile(1, rkB, rvB, rbB);
@@ -783,17 +791,31 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
         store_attention_rows<DH>(p, S, b, h, q0 + wave * 32, nq, ot, LDO, lane);
         return;
     }
+    {
+        // round 4: the wave's 32 output rows leave as 16-byte stores of full 256-byte rows (4 rows per instruction; 4-byte stores, one row
+        // per instruction, before): all 256 workgroups write their 64-KB tile at the same moment with the matrix pipe idle
+        constexpr int LDP = DH + 4, LPR = DH / 4, RPI = 64 / LPR;
+        float* otp = smem + wave * 32 * LDP;
 #pragma unroll
-    for (int d = 0; d < DT; ++d)
+        for (int d = 0; d < DT; ++d)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            ot[l31 * LDO + d * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = oacc[d][r] / l_tot;
-    if (S.lse && half == 0) {
-        const int qrow = q0 + wave * 32 + l31;
-        if (qrow < nq) S.lse[((long)b * IMP_NUM_HEADS + h) * S.nq + qrow] = m_ref * (1.0f / LOG2E) + logf(l_tot);
+            for (int r = 0; r < 16; ++r)
+                otp[l31 * LDP + d * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = oacc[d][r] / l_tot;
+        if (S.lse && half == 0) {
+            const int qrow = q0 + wave * 32 + l31;
+            if (qrow < nq) S.lse[((long)b * IMP_NUM_HEADS + h) * S.nq + qrow] = m_ref * (1.0f / LOG2E) + logf(l_tot);
+        }
+        __syncthreads();
+        const int prow = lane / LPR, pc4 = (lane % LPR) * 4;
+        float* Og = S.out + b * S.so_b + h * DH;
+#pragma unroll
+        for (int j = 0; j < 32 / RPI; ++j) {
+            const int qi = j * RPI + prow;
+            const int qrow = q0 + wave * 32 + qi;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(otp + qi * LDP + pc4);
+            if (qrow < nq) *reinterpret_cast<f32x4*>(Og + (long)qrow * p.ldo + pc4) = v;
+        }
     }
-    __syncthreads();
-    store_attention_rows<DH>(p, S, b, h, q0 + wave * 32, nq, ot, LDO, lane);
 #ifdef PP_PROFILE
     __builtin_amdgcn_s_waitcnt(0);              // the stores of this wave are out
     if (blockIdx.x == 0 && lane == 0) {
