@@ -26,7 +26,7 @@ SYMBOLS = [
     'imp_last_error', 'imp_version', 'imp_create', 'imp_destroy', 'imp_load_tensor', 'imp_finalize_weights',
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
-    'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_pool_select_pair', 'imp_masked_commit', 'imp_gather_rows', 'imp_match_pair', 'imp_set_counts', 'imp_match_tail', 'imp_op_linear', 'imp_op_layer_gemm', 'imp_op_fused_mlp',
+    'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_pool_select_pair', 'imp_masked_commit', 'imp_gather_rows', 'imp_match_pair', 'imp_set_counts', 'imp_match_tail', 'imp_loop_lockstep', 'imp_op_linear', 'imp_op_layer_gemm', 'imp_op_fused_mlp',
     'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_range_events', 'imp_time_layer_gemm', 'imp_estimate_pose',
     'imp_sp_create', 'imp_sp_destroy', 'imp_sp_set_weight', 'imp_sp_finalize', 'imp_sp_detect', 'imp_sp_describe', 'imp_sp_dense', 'imp_sp_op_conv',
 ]
@@ -55,6 +55,12 @@ class OperandRangeError(ImpError):
 
 IMP_E_RESIDENT = -6
 IMP_E_RANGE = -7
+
+
+class ImpLoopPair(C.Structure):
+    """include/imp_hip.h imp_loop_pair"""
+    _fields_ = [('pts0', C.c_void_p), ('pts1', C.c_void_p), ('K0', C.c_void_p), ('K1', C.c_void_p), ('indices0', C.c_void_p), ('mscores0', C.c_void_p),
+                ('R', C.c_double * 9), ('t', C.c_double * 3), ('found', C.c_int32), ('n_iterations', C.c_int32)]
 
 
 class ImpConfig(C.Structure):
@@ -113,6 +119,7 @@ def lib():
     L.imp_match_pair.argtypes = [P, I, I, I, P, P, P, P, P, P, F, F, F, I, I, F, P, P, P, P, P, P]
     L.imp_set_counts.argtypes = [P, I, P, P]
     L.imp_match_tail.argtypes = [P, I, I, I, I, P, P, F, I, I, F, P, P, P, P, P]
+    L.imp_loop_lockstep.argtypes = [P, I, P, P, I, I, P, P, P, P, P, P, F, I, I, C.c_uint, F, I, C.c_double, C.c_double, I, I, C.c_uint, I, P, P]
     L.imp_op_linear.argtypes = [P, I, I, I, P, P, P, P, P]
     L.imp_op_layer_gemm.argtypes = [P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, P, I, P]
     L.imp_op_fused_mlp.argtypes = [P, I, I, P, P, P, P, P, P, P, P, I, P, P, I, P]
@@ -437,6 +444,41 @@ class Context:
         self._check(self.L.imp_match_tail(self.handle, int(layer_id), B, n0, n1, _ptr(desc0), _ptr(desc1), float(bin_score), int(iterations),
                                           1 if with_sinkhorn else 0, float(p), _ptr(out['indices0']), _ptr(out['mscores0']),
                                           _ptr(out.get('indices1')), _ptr(out.get('mscores1')), _stream(self.device)))
+        return out
+
+    def loop_lockstep(self, n0, n1, nk0, sc0, de0, nk1, sc1, de1, pts0, pts1, K0, K1, bin_score, sinkhorn_iterations, n_iterations, valid_its,
+                      match_ratio, min_kpts, error_th, stop_pose_deg, pose_threads=4, pose_iterations=1024, pose_seed=1, pose_flags=1):
+        """the native lock-step IMP loop (include/imp_hip.h imp_loop_lockstep): padded device tensors + per-pair host arrays in,
+        [(indices0, mscores0, R | None, t | None, n_iterations)] out"""
+        import numpy as np
+        B = len(n0)
+        nk0, sc0, de0, nk1, sc1, de1 = (_f32(t, 'input') for t in (nk0, sc0, de0, nk1, sc1, de1))
+        N0, N1 = nk0.shape[1], nk1.shape[1]
+        recs = (ImpLoopPair * B)()
+        keep = []
+        for b in range(B):
+            p0 = np.ascontiguousarray(pts0[b], dtype=np.float32); p1 = np.ascontiguousarray(pts1[b], dtype=np.float32)
+            k0 = np.ascontiguousarray(np.eye(3) if K0[b] is None else K0[b], dtype=np.float64).reshape(3, 3)
+            k1 = np.ascontiguousarray(np.eye(3) if K1[b] is None else K1[b], dtype=np.float64).reshape(3, 3)
+            oi = np.empty(n0[b], dtype=np.int64); om = np.empty(n0[b], dtype=np.float32)
+            keep.append((p0, p1, k0, k1, oi, om))
+            recs[b].pts0, recs[b].pts1 = p0.ctypes.data, p1.ctypes.data
+            recs[b].K0, recs[b].K1 = k0.ctypes.data, k1.ctypes.data
+            recs[b].indices0, recs[b].mscores0 = oi.ctypes.data, om.ctypes.data
+        a0 = (C.c_int32 * B)(*[int(v) for v in n0]); a1 = (C.c_int32 * B)(*[int(v) for v in n1])
+        mask = 0
+        for it in valid_its:
+            mask |= 1 << int(it)
+        self._check(self.L.imp_loop_lockstep(self.handle, B, a0, a1, N0, N1, _ptr(nk0), _ptr(sc0), _ptr(de0), _ptr(nk1), _ptr(sc1), _ptr(de1),
+                                             float(bin_score), int(sinkhorn_iterations), int(n_iterations), C.c_uint(mask), float(match_ratio), int(min_kpts),
+                                             C.c_double(float(error_th)), C.c_double(float(stop_pose_deg)), int(pose_threads), int(pose_iterations),
+                                             C.c_uint(pose_seed), int(pose_flags), recs, _stream(self.device)))
+        out = []
+        for b in range(B):
+            found = bool(recs[b].found)
+            R = np.array(recs[b].R, dtype=np.float64).reshape(3, 3) if found else None
+            t = np.array(recs[b].t, dtype=np.float64) if found else None
+            out.append((keep[b][4], keep[b][5], R, t, int(recs[b].n_iterations)))
         return out
 
     def op_linear(self, x, W, bias=None):

@@ -8,8 +8,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <future>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -106,12 +112,16 @@ struct imp_ctx {
     int wf_chain = 1;        // IMP_WF_CHAIN=0: never compute the next layer's projection inside the MLP3 launch
     long wf_chain_min_tiles = 160, wf_max_tiles = 640, wf_proj_max_tiles = 40;     // IMP_WF_CHAIN_MIN / IMP_WF_MAX / IMP_WF_PROJ_MAX
     int wf_fused = 1;        // IMP_WF_FUSED=0: never run a layer's MLP0 -> InstanceNorm -> MLP3 (-> next projection) as ONE launch (gemm_wf.hip fused kernel)
-    long wf_fused_min_tiles = 160;   // IMP_WF_FUSED_MIN
+    long wf_fused_min_tiles = 100;   // IMP_WF_FUSED_MIN (measured: the fused launch wins from ~64 tiles up - 128 tiles: -7..-9 %, 64: +-1 % - and loses 12-18 % at 16-32)
     int wf_fused_fake = 0;   // TEST HOOK IMP_WF_FUSED_FAKE=1: one workgroup of every fused launch withholds its statistics (forces the time-out path)
     float *fx_rec[2] = {}, *fx_fin[2] = {};   // fused layer: statistics granules [B][tiles][512] x 16 B and (mean, rstd) granules [B][512] x 16 B per image
     unsigned fx_tag = 0;     // tag of the last fused launch (tags never repeat on fx_rec / fx_fin)
     size_t fx_rec_floats = 0, fx_fin_floats = 0;
     int* fx_status = nullptr;   // device word the waiters of a fused launch watch (3 = a wait timed out)
+    // native lock-step loop (imp_loop_lockstep): device outputs of a scored iteration, their pinned mirror, the pose workers
+    int64_t* lp_idx = nullptr; float* lp_ms = nullptr; unsigned char* lp_pin = nullptr; size_t lp_cap = 0;
+    hipEvent_t lp_ev = nullptr;
+    struct PoseWorkers* lp_workers = nullptr;
     RaggedCounts rc{};       // imp_set_counts: per-pair keypoint counts of the NEXT calls (rc.on = 0: uniform batches); rc_batch pairs
     int rc_batch = 0;
     int ot_lane = 0;         // IMP_OT_LANE=1: resident Sinkhorn launches go through the device's lane stream (rounds 2-3) instead of the caller's stream under the spin gate
@@ -1129,6 +1139,90 @@ __global__ void zero_masked_columns_kernel(float* prob, const uint8_t* mask, int
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Host threads for the pose estimates of the native lock-step loop: imp_estimate_pose keeps a per-THREAD workspace (device buffers, a
+// pinned staging page, the MAGSAC++ weight table), so the workers live as long as the context; each owns a stream.
+struct PoseWorkers {
+    std::vector<std::thread> threads;
+    std::deque<std::function<void(hipStream_t)>> jobs;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool stop = false;
+    int device = 0;
+    explicit PoseWorkers(int n, int dev) : device(dev) {
+        for (int i = 0; i < n; ++i)
+            threads.emplace_back([this] {
+                (void)hipSetDevice(device);
+                hipStream_t st = nullptr;
+                (void)hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+                for (;;) {
+                    std::function<void(hipStream_t)> job;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [this] { return stop || !jobs.empty(); });
+                        if (stop && jobs.empty()) break;
+                        job = std::move(jobs.front());
+                        jobs.pop_front();
+                    }
+                    job(st);
+                }
+                if (st) (void)hipStreamDestroy(st);
+            });
+    }
+    void submit(std::function<void(hipStream_t)> f) {
+        { std::lock_guard<std::mutex> lk(mu); jobs.push_back(std::move(f)); }
+        cv.notify_one();
+    }
+    ~PoseWorkers() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto& t : threads) t.join();
+    }
+};
+
+namespace {
+void loop_release(imp_ctx* c) {
+    delete c->lp_workers; c->lp_workers = nullptr;
+    if (c->lp_idx) (void)hipFree(c->lp_idx);
+    if (c->lp_ms) (void)hipFree(c->lp_ms);
+    if (c->lp_pin) (void)hipHostFree(c->lp_pin);
+    if (c->lp_ev) (void)hipEventDestroy(c->lp_ev);
+    c->lp_idx = nullptr; c->lp_ms = nullptr; c->lp_pin = nullptr; c->lp_ev = nullptr; c->lp_cap = 0;
+}
+// rotation angle between two rotation matrices / angle between two vectors, degrees (imp_release_amd/matching.py angle_error_mat / _vec,
+// the semantics of tools/utils.py:425-431)
+double loop_angle_mat(const double* R1, const double* R2) {
+    double tr = 0.0;                                    // trace(R1^T R2) = sum_ij R1[i][j] R2[i][j]
+    for (int i = 0; i < 9; ++i) tr += R1[i] * R2[i];
+    double cs = (tr - 1.0) / 2.0;
+    cs = cs < -1.0 ? -1.0 : (cs > 1.0 ? 1.0 : cs);
+    return std::fabs(std::acos(cs)) * 180.0 / M_PI;
+}
+double loop_angle_vec(const double* a, const double* b) {
+    const double n = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) * std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+    double cs = (a[0] * b[0] + a[1] * b[1] + a[2] * b[2]) / n;
+    cs = cs < -1.0 ? -1.0 : (cs > 1.0 ? 1.0 : cs);
+    return std::acos(cs) * 180.0 / M_PI;
+}
+struct LoopPose {                                       // one pose estimate in flight
+    std::vector<float> k0, k1;
+    std::vector<unsigned char> mask;
+    double E[9], R[9], t[3];
+    int n = 0, rc = 1, ninl = 0;
+    std::promise<void> done;
+    std::future<void> fut;
+};
+struct LoopPair {
+    bool live = true, has_last = false, scored = false;
+    double lastR[9], lastT[3];
+    std::shared_ptr<LoopPose> pend;
+    int pend_it = -1;
+    std::vector<int> pm0, pm1;                          // matches handed to the pose step of the pending iteration
+    std::vector<int64_t> pend_idx, last_idx;
+    std::vector<float> pend_ms, last_ms;
+};
+}  // namespace
+
 // ================================================================================================
 int imp_fail(int code, const char* msg) { return fail(code, msg); }   // for the other translation units (superpoint.hip)
 
@@ -1211,6 +1305,7 @@ int imp_destroy(imp_ctx* c) {
     free_pool(c->allocs_ws);
     free_pool(c->allocs_x);
     if (c->xstatus_host) (void)hipHostFree(c->xstatus_host);
+    loop_release(c);
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     if (c->ev_out) (void)hipEventDestroy(c->ev_out);
     delete c;
@@ -1630,6 +1725,174 @@ int imp_match_tail(imp_ctx* c, int layer_id, int batch, int n0, int n1, const fl
     if (!max_done) HIP_TRY(launch_ot_maxima(batch, n0, n1, with_sinkhorn ? 0 : 1, o, c->max0, c->arg0, c->max1, c->arg1, st));
     HIP_TRY(launch_mutual_matches(batch, n0, n1, c->max0, c->arg0, c->max1, c->arg1, p, indices0, indices1, mscores0,
                                   mscores1, c->range_hostdev, st, &c->rc));
+    return IMP_OK;
+}
+
+int imp_loop_lockstep(imp_ctx* c, int B, const int32_t* n0v, const int32_t* n1v, int n0, int n1, const float* nkpts0, const float* scores0,
+                      const float* desc0, const float* nkpts1, const float* scores1, const float* desc1, float bin_score, int sinkhorn_iterations,
+                      int n_iterations, unsigned valid_mask, float match_ratio, int min_kpts, double error_th, double stop_pose_deg,
+                      int pose_threads, int pose_iterations, unsigned pose_seed, int pose_flags, imp_loop_pair* pairs, void* stream) {
+    if (!c || !n0v || !n1v || !pairs || B < 1 || B > IMP_RAGGED_MAX) return fail(IMP_E_ARG, "imp_loop_lockstep: 1 .. 16 pairs, counts and pair records");
+    if (!nkpts0 || !nkpts1 || !scores0 || !scores1 || !desc0 || !desc1) return fail(IMP_E_ARG, "imp_loop_lockstep: null input");
+    if (match_ratio > 0.2f) return fail(IMP_E_ARG, "imp_loop_lockstep: match_ratio must be <= 0.2 (the final p = 0.2 matches are derived from the scored ones)");
+    if (n_iterations < 1 || 2 * n_iterations > c->cfg.n_gnn_layers) return fail(IMP_E_ARG, "imp_loop_lockstep: more iterations than the model has layer pairs");
+    int rc = imp_set_counts(c, B, n0v, n1v);
+    if (rc) return rc;
+    struct Restore { imp_ctx* c; ~Restore() { c->rc.on = 0; c->rc_batch = 0; } } restore{c};
+    if ((rc = check_ready(c, B, n0, n1))) return rc;
+    hipStream_t st = S(stream);
+    const int n[2] = {n0, n1};
+    // buffers of a scored iteration: device outputs + one pinned mirror (int64 indices | float scores)
+    const size_t need = (size_t)B * n0;
+    if (need > c->lp_cap) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (c->lp_idx) (void)hipFree(c->lp_idx);
+        if (c->lp_ms) (void)hipFree(c->lp_ms);
+        if (c->lp_pin) (void)hipHostFree(c->lp_pin);
+        c->lp_idx = nullptr; c->lp_ms = nullptr; c->lp_pin = nullptr; c->lp_cap = 0;
+        const size_t cap = need < 16384 ? 16384 : need;
+        HIP_TRY(hipMalloc(&c->lp_idx, cap * sizeof(int64_t)));
+        HIP_TRY(hipMalloc(&c->lp_ms, cap * sizeof(float)));
+        HIP_TRY(hipHostMalloc(&c->lp_pin, cap * 12));
+        c->lp_cap = cap;
+    }
+    if (!c->lp_ev) HIP_TRY(hipEventCreateWithFlags(&c->lp_ev, hipEventDisableTiming));
+    const bool with_pose = pose_threads > 0;
+    if (with_pose && !c->lp_workers) c->lp_workers = new PoseWorkers(pose_threads < B ? B : pose_threads, c->device);
+    int64_t* const h_idx = reinterpret_cast<int64_t*>(c->lp_pin);
+    float* const h_ms = reinterpret_cast<float*>(c->lp_pin + c->lp_cap * sizeof(int64_t));
+
+    std::vector<LoopPair> P(B);
+    struct WaitAll {                                    // no return path may leave a pose worker behind that still reads the caller's arrays
+        std::vector<LoopPair>& P;
+        ~WaitAll() { for (auto& q : P) if (q.pend) q.pend->fut.wait(); }
+    } wait_all{P};
+    for (int b = 0; b < B; ++b) { pairs[b].found = 0; pairs[b].n_iterations = n_iterations; }
+    auto retire = [&](int b) { P[b].live = false; c->rc.n[0][b] = 0; c->rc.n[1][b] = 0; };
+    // finish pair b's outstanding pose estimate and take its exit test (eval/matching.py:84-117); true when the pair exits
+    auto resolve = [&](int b) -> bool {
+        LoopPair& q = P[b];
+        if (q.pend_it < 0) return false;
+        const int it_k = q.pend_it;
+        q.pend_it = -1;
+        std::shared_ptr<LoopPose> job = q.pend;
+        q.pend.reset();
+        bool have = false;
+        if (job) { job->fut.wait(); have = job->rc == 0; }
+        double diff_R = INFINITY, diff_t = INFINITY;
+        if (it_k >= 1 && have && q.has_last) { diff_R = loop_angle_mat(q.lastR, job->R); diff_t = loop_angle_vec(q.lastT, job->t); }
+        q.has_last = have;
+        if (have) { memcpy(q.lastR, job->R, sizeof q.lastR); memcpy(q.lastT, job->t, sizeof q.lastT); }
+        const double pose_diff = diff_R > diff_t ? diff_R : diff_t;
+        if (stop_pose_deg >= 0.0 && pose_diff <= stop_pose_deg) {                  // eval/matching.py:110-117
+            imp_loop_pair& o = pairs[b];
+            const int nb = n0v[b];
+            for (int i = 0; i < nb; ++i) { o.indices0[i] = -1; o.mscores0[i] = q.pend_ms[i]; }
+            for (size_t m = 0; m < q.pm0.size(); ++m)
+                if (job->mask[m]) o.indices0[q.pm0[m]] = q.pm1[m];
+            memcpy(o.R, job->R, sizeof o.R); memcpy(o.t, job->t, sizeof o.t);
+            o.found = 1; o.n_iterations = it_k + 1;
+            retire(b);
+            return true;
+        }
+        return false;
+    };
+
+    const float* kp[2] = {nkpts0, nkpts1};
+    const float* sc[2] = {scores0, scores1};
+    const float* de[2] = {desc0, desc1};
+    float* dw[2] = {c->descw[0], c->descw[1]};
+    if ((rc = run_kenc(c, B, n, kp, sc, 0.f, 0.f, de, dw, st))) return rc;       // desc + enc (eval/matching.py:47-50)
+    const uint8_t* nomask[2] = {nullptr, nullptr};
+    const float* dr[2] = {c->descw[0], c->descw[1]};
+    bool proj_done = false;
+    int layers_done = -1;
+    auto run_two_layers = [&](int it) -> int {
+        for (int li = 2 * it; li <= 2 * it + 1; ++li) {
+            bool chained = false;
+            const int r2 = run_layer(c, li, B, n, dr, dw, nomask, st, proj_done, li + 1 < c->cfg.n_gnn_layers ? li + 1 : -1, &chained);
+            if (r2) return r2;
+            proj_done = chained;
+        }
+        layers_done = it;
+        return IMP_OK;
+    };
+    for (int it = 0; it < n_iterations; ++it) {
+        if (layers_done < it && (rc = run_two_layers(it))) return rc;
+        if (!((valid_mask >> it) & 1u)) continue;
+        // score + matches of this iteration for the whole (ragged) batch, one copy, and - before the host looks at it - the next
+        // iteration's layers, so that the GPU works through the pose estimates
+        if ((rc = run_distance(c, it, B, n, dr, c->dist, st))) return rc;
+        OtBuffers o;
+        bool max_done = false;
+        if ((rc = run_score(c, B, n0, n1, c->dist, bin_score, sinkhorn_iterations, 1, nullptr, &o, st, &max_done))) return rc;
+        HIP_TRY(launch_mutual_matches(B, n0, n1, c->max0, c->arg0, c->max1, c->arg1, match_ratio, c->lp_idx, nullptr, c->lp_ms, nullptr,
+                                      c->range_hostdev, st, &c->rc));
+        HIP_TRY(hipMemcpyAsync(h_idx, c->lp_idx, need * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_ms, c->lp_ms, need * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(c->lp_ev, st));
+        if (it + 1 < n_iterations && (rc = run_two_layers(it + 1))) return rc;
+        HIP_TRY(hipEventSynchronize(c->lp_ev));
+        if ((rc = resident_health(c))) return rc;                                  // a voided launch: the caller runs the group again
+        bool retired = false;
+        for (int b = 0; b < B; ++b) {
+            LoopPair& q = P[b];
+            if (!q.live) continue;
+            if (resolve(b)) { retired = true; continue; }
+            const int nb = n0v[b];
+            const int64_t* ib = h_idx + (size_t)b * n0;
+            const float* mb = h_ms + (size_t)b * n0;
+            q.last_idx.assign(ib, ib + nb);
+            q.last_ms.assign(mb, mb + nb);
+            q.scored = true;
+            q.pm0.clear(); q.pm1.clear();
+            for (int i = 0; i < nb; ++i)
+                if (ib[i] > -1) { q.pm0.push_back(i); q.pm1.push_back((int)ib[i]); }
+            if ((int)q.pm0.size() < min_kpts) { q.has_last = false; continue; }   // eval/matching.py:63-66
+            q.pend_it = it;
+            q.pend_idx = q.last_idx; q.pend_ms = q.last_ms;
+            q.pend.reset();
+            if (with_pose) {
+                auto job = std::make_shared<LoopPose>();
+                const int m = (int)q.pm0.size();
+                job->n = m;
+                job->k0.resize(2 * (size_t)m); job->k1.resize(2 * (size_t)m); job->mask.assign(m, 0);
+                for (int j = 0; j < m; ++j) {
+                    job->k0[2 * j] = pairs[b].pts0[2 * q.pm0[j]]; job->k0[2 * j + 1] = pairs[b].pts0[2 * q.pm0[j] + 1];
+                    job->k1[2 * j] = pairs[b].pts1[2 * q.pm1[j]]; job->k1[2 * j + 1] = pairs[b].pts1[2 * q.pm1[j] + 1];
+                }
+                job->fut = job->done.get_future();
+                const double* K0 = pairs[b].K0; const double* K1 = pairs[b].K1;
+                const int dev = c->device;
+                c->lp_workers->submit([job, K0, K1, error_th, pose_iterations, pose_seed, pose_flags, dev](hipStream_t ps) {
+                    job->rc = imp_estimate_pose(job->k0.data(), job->k1.data(), job->n, K0, K1, error_th, pose_iterations, pose_seed, dev, job->E, job->R,
+                                                job->t, job->mask.data(), nullptr, &job->ninl, pose_flags, ps);
+                    job->done.set_value();
+                });
+                q.pend = job;
+            }
+        }
+        bool any = false;
+        for (int b = 0; b < B; ++b) any = any || P[b].live;
+        if (!any) break;
+        (void)retired;                                                             // (the counts live in c->rc: the next launches see them)
+    }
+    for (int b = 0; b < B; ++b)
+        if (P[b].live) resolve(b);                                                 // the estimates of the last scored iteration
+    // wait for estimates nobody looked at any more (a worker must not outlive its job's buffers)
+    for (int b = 0; b < B; ++b)
+        if (P[b].pend) P[b].pend->fut.wait();
+    for (int b = 0; b < B; ++b) {
+        if (!P[b].live) continue;                                                  // never exited: compute_matches(pred_score, 0.2) (eval/matching.py:119)
+        imp_loop_pair& o = pairs[b];
+        const int nb = n0v[b];
+        for (int i = 0; i < nb; ++i) {
+            const float ms = P[b].scored ? P[b].last_ms[i] : 0.f;
+            o.mscores0[i] = ms;
+            o.indices0[i] = (P[b].scored && ms > 0.2f) ? P[b].last_idx[i] : -1;
+        }
+        o.found = 0; o.n_iterations = n_iterations;
+    }
     return IMP_OK;
 }
 

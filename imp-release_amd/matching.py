@@ -233,7 +233,7 @@ def _pose_workers(n, device):
 
 
 def matching_iterative_lockstep(datas, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method=None, estimate_pose=None,
-                                pose_threads=4, traces=None):
+                                pose_threads=4, traces=None, native='auto'):
     """eval/matching.py:16-123 on SEVERAL pairs at once -> [(indices0, mscores0, R, t, n_iterations)] - per pair exactly what
     :func:`matching_iterative` returns for it.
 
@@ -244,7 +244,12 @@ def matching_iterative_lockstep(datas, model, nI, match_ratio, min_kpts, error_t
     gate, pose estimate, pose-change test).  A pair that exits early is RETIRED - its counts become 0 and its workgroups leave at once -
     while the others go on.  The final ``compute_matches(pred_score, 0.2)`` of pairs that never exit (eval/matching.py:119) needs no
     second Sinkhorn: mscores0 do not depend on the threshold and indices0 at 0.2 are the indices at ``match_ratio`` <= 0.2 with
-    scores <= 0.2 cleared (nets/gm.py:312-318).  IMP / GM loop only (the EIMP loop re-slices every pair after each pool)."""
+    scores <= 0.2 cleared (nets/gm.py:312-318).  IMP / GM loop only (the EIMP loop re-slices every pair after each pool).
+
+    ``native``: the whole loop in the library (``imp_loop_lockstep``: C++ host logic, pose workers of the context) instead of this Python
+    body - same results, a fraction of the host time (a group's 9 ms were 3.5 ms of GPU time and 5.5 ms of Python).  'auto' (default): native
+    when the pose step is the library's own (``imp_release_amd.pose.estimate_pose``) or absent and no trace is requested; the Python body
+    takes any ``estimate_pose`` callable."""
     B = len(datas)
     if B == 0:
         return []
@@ -270,6 +275,19 @@ def matching_iterative_lockstep(datas, model, nI, match_ratio, min_kpts, error_t
         nk0[b, :n0s[b]] = nk[b][0][0]; nk1[b, :n1s[b]] = nk[b][1][0]
     sc0, sc1 = padded('scores0', N0, 0), padded('scores1', N1, 0)
     de0, de1 = padded('descriptors0', N0, D), padded('descriptors1', N1, D)
+    from . import pose as _gpose
+    own_pose = estimate_pose is None or estimate_pose is _gpose.estimate_pose
+    if native is True or (native == 'auto' and own_pose and traces is None and model.with_sinkhorn and 2 * nI <= len(model.gnn.names)):
+        if not own_pose:
+            raise ValueError("native=True runs the library's own pose step: pass imp_release_amd.pose.estimate_pose or None")
+        stop = float(stop_criteria['pose']) if 'pose' in stop_criteria.keys() else -1.0
+        res = ctx.loop_lockstep(n0s, n1s, nk0, sc0, de0, nk1, sc1, de1, [d['pts0_cpu'] for d in datas], [d['pts1_cpu'] for d in datas],
+                                [d.get('K0') for d in datas], [d.get('K1') for d in datas], model._bin(None), model.sinkhorn_iterations, nI,
+                                [i for i in VALID_ITS if i < nI], match_ratio, min_kpts, error_th, stop,
+                                pose_threads=max(pose_threads, 1) if estimate_pose is not None else 0)
+        for li in range(2 * nI):
+            model._note_layer(li, B, N0, N1)
+        return res
     live = [True] * B
     c0, c1 = list(n0s), list(n1s)
     results = [None] * B

@@ -249,6 +249,35 @@ int imp_set_counts(imp_ctx* ctx, int batch, const int32_t* n0, const int32_t* n1
 int imp_match_tail(imp_ctx* ctx, int layer_id, int batch, int n0, int n1, const float* desc0, const float* desc1, float bin_score,
                    int sinkhorn_iterations, int with_sinkhorn, float p, int64_t* indices0, float* mscores0, int64_t* indices1,
                    float* mscores1, void* stream);
+/* The lock-step IMP loop (eval/matching.py:16-123 `matching_iterative` on B pairs of different sizes at once) driven natively: encoder, per iteration
+ * the two layers (chained projections), at the iterations of `valid_mask` (bit it: eval/matching.py:43 = {3,5,7,9,11,13,14}) final projection
+ * -> distance -> Sinkhorn -> mutual matches at `match_ratio` for the whole ragged batch, one device->host copy, and per live pair the
+ * reference's host step: matched-count gate (`min_kpts`), pose estimate (imp_estimate_pose on `pose_threads` worker threads of the context, each
+ * with its own stream; 0 = no pose step: no pair ever exits), pose-change test against `stop_pose_deg` (< 0: never stop).  The next iteration's
+ * layers are enqueued BEFORE the host turns to the pose step and the exit decision of a scored iteration is taken at the next scored one - the
+ * pose step is latency, not GPU load; a pair that exits is returned with the matches (inlier-filtered, :112-113), pose and iteration count of
+ * the iteration it exited at, exactly as the sequential loop returns them, and is then RETIRED (count 0).  Pairs that never exit get the
+ * p = 0.2 matches of the last scored iteration (:119; derived from the scored matches: mscores0 do not depend on the threshold).
+ * Inputs as for imp_encode_keypoints (normalised keypoints, device tensors padded to n0 / n1) + per-pair host records.  Synchronises.
+ * IMP_E_RESIDENT: a waiting kernel of the group was voided - run the group again.  (The Python twin, with any estimate_pose callable:
+ * imp_release_amd.matching.matching_iterative_lockstep.) */
+typedef struct imp_loop_pair {
+    const float* pts0;      /* [n0[b]][2] pixel keypoints of image 0 (host): what the pose step sees (eval/matching.py:84-87) */
+    const float* pts1;      /* [n1[b]][2] */
+    const double* K0;       /* 3x3 row-major intrinsics (host) */
+    const double* K1;
+    int64_t* indices0;      /* out [n0[b]] (host) */
+    float* mscores0;        /* out [n0[b]] (host) */
+    double R[9];            /* out: pose of the exit iteration (found = 1) */
+    double t[3];
+    int32_t found;          /* out: 1 = the pair left the loop on pose convergence */
+    int32_t n_iterations;   /* out: eval/matching.py's n_iter */
+} imp_loop_pair;
+int imp_loop_lockstep(imp_ctx* ctx, int batch, const int32_t* n0_counts, const int32_t* n1_counts, int n0, int n1, const float* nkpts0,
+                      const float* scores0, const float* desc0, const float* nkpts1, const float* scores1, const float* desc1, float bin_score,
+                      int sinkhorn_iterations, int n_iterations, unsigned valid_mask, float match_ratio, int min_kpts, double error_th,
+                      double stop_pose_deg, int pose_threads, int pose_iterations, unsigned pose_seed, int pose_flags, imp_loop_pair* pairs,
+                      void* stream);
 /* the fused layer MLP of csrc/gemm_wf.hip on its own (tests/test_gpu_ops.py): nets/layers.py:145-149 / :210-218 after the attention,
  *   y = x + mlp.3(relu(InstanceNorm(mlp.0(cat[x, a]))))        x, a, y: [B][M][256];  W0 [512][512], W3 [256][512]
  *   y2 = y . W2^T + b2                                         optional (W2 [N2][256], N2 % 128 == 0): the next layer's projection

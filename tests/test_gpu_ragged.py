@@ -199,8 +199,8 @@ def test_lockstep_loop_of_one_pair_vs_the_reference_fixture(name):
         assert R is None and t is None
 
 
-@pytest.mark.parametrize('pose_threads', [1, 4])
-def test_lockstep_loop_equals_the_pairs_one_at_a_time(pose_threads):
+@pytest.mark.parametrize('pose_threads,native', [(1, False), (4, False), (4, True), (1, True)])
+def test_lockstep_loop_equals_the_pairs_one_at_a_time(pose_threads, native):
     """4 pairs of different sizes and difficulty through the IMP loop TOGETHER (one ragged batch, per-pair early exit, the GPU pose step
     in its estimate_pose slot) = each pair through matching_iterative alone: same exit iteration, same matches, same pose"""
     from imp_release_amd import matching as hip_matching, pose as gpose
@@ -212,7 +212,7 @@ def test_lockstep_loop_equals_the_pairs_one_at_a_time(pose_threads):
     with torch.no_grad():
         solo = [hip_matching.matching_iterative(d, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, estimate_pose=gpose.estimate_pose) for d in datas]
         together = hip_matching.matching_iterative_lockstep(datas, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, estimate_pose=gpose.estimate_pose,
-                                                            pose_threads=pose_threads)
+                                                            pose_threads=pose_threads, native=native)     # native: imp_loop_lockstep (C++ host logic)
     iters = [s_[4] for s_ in solo]
     print('exit iterations:', iters)
     for b, (a, c) in enumerate(zip(solo, together)):
@@ -244,3 +244,21 @@ def test_eval_loop_lockstep_rows_equal_the_sequential_rows():
         assert np.array_equal(seq[:, cols], other[:, cols])
         assert np.allclose(seq, other, atol=1e-4, equal_nan=True)
     print(eval_loop.aggregate(seq))
+
+
+def test_native_lockstep_loop_without_a_pose_step_runs_every_iteration():
+    """estimate_pose=None: no pair ever exits; the final matches are the last scored iteration's at p = 0.2 - native and Python bodies agree"""
+    from imp_release_amd import matching as hip_matching
+    cfg = eval_config()
+    sd = synthetic.make_state_dict(cfg, 'DGNNS', seed=4)
+    m = make_hip_model('DGNNS', cfg, sd)
+    pairs = [synthetic.make_correlated_pair(400, 380, seed=23), synthetic.make_correlated_pair(300, 420, seed=24)]
+    datas = [_loop_dict(p) for p in pairs]
+    with torch.no_grad():
+        a = hip_matching.matching_iterative_lockstep(datas, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, native=False)
+        b = hip_matching.matching_iterative_lockstep(datas, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, native=True)
+        solo = hip_matching.matching_iterative(datas[0], m, 15, 0.1, 25, 1.0, {'pose': 1.5})
+    for x, y in zip(a, b):
+        assert x[4] == y[4] == 15 and x[2] is None and y[2] is None
+        assert np.array_equal(x[0], y[0]) and np.abs(x[1].astype(np.float64) - y[1]).max() <= TOL
+    assert np.array_equal(a[0][0], solo[0])

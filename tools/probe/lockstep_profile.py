@@ -41,7 +41,7 @@ eval_loop.run_pairs_sharded(m, provider, 96, lockstep=4, **kw)
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr, stream=sys.stdout)
-st.sort_stats('cumulative').print_stats(28)
+st.sort_stats('tottime').print_stats(32)
 for ls, wk in ((1, 1), (1, 3), (4, 1), (4, 2), (4, 3), (2, 3), (8, 1)):
     reps = eval_loop.replicate(m, wk)
     try:
