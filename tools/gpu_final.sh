@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 (timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/final_${T}_c2 -o c2 -- python $R/tools/probe/c2_run.py 1024 1 2>&1 | tail -1) > $O/final_${T}_c2.log 2>&1
 cd $R
 (timeout 200 python tools/gpu_configs.py 2>&1 | tail -7) > $O/final_${T}_configs.log 2>&1
-(timeout 300 python tools/eval_synthetic.py --pairs 2000 --model IMP --hard --workers 2 --lockstep 4 --pose gpu 2>&1 | tail -1; timeout 300 python tools/eval_synthetic.py --pairs 1000 --model IMP --hard --workers 3 --pose gpu 2>&1 | tail -1; timeout 300 python tools/eval_synthetic.py --pairs 2000 --model EIMP --hard --workers 3 --pose gpu 2>&1 | tail -1; for M in IMP EIMP; do timeout 300 python tools/eval_synthetic.py --pairs 1000 --model $M --kpts 2048 --workers 3 --pose gpu 2>&1 | tail -1; done; timeout 200 python tools/eval_synthetic.py --pairs 200 --model EIMP --kpts 2048 --workers 3 --pose none --weights uniform 2>&1 | tail -1) > $O/final_${T}_loop.log 2>&1
+(timeout 300 python tools/eval_synthetic.py --pairs 2000 --model IMP --hard --workers 3 --lockstep 4 --pose gpu 2>&1 | tail -1; timeout 300 python tools/eval_synthetic.py --pairs 1000 --model IMP --hard --workers 3 --pose gpu 2>&1 | tail -1; timeout 300 python tools/eval_synthetic.py --pairs 2000 --model EIMP --hard --workers 3 --pose gpu 2>&1 | tail -1; for M in IMP EIMP; do timeout 300 python tools/eval_synthetic.py --pairs 1000 --model $M --kpts 2048 --workers 3 --pose gpu 2>&1 | tail -1; done; timeout 200 python tools/eval_synthetic.py --pairs 200 --model EIMP --kpts 2048 --workers 3 --pose none --weights uniform 2>&1 | tail -1) > $O/final_${T}_loop.log 2>&1
 # round 4: the fused layer launch - phase cycles (-DWF_PROFILE variant, if built), same-box A/B against the two-launch layers, lock-step rates
 ([ -f imp-release_amd/csrc/variants/libimp_hip_wfprof.so ] && IMP_WF_PROF=1 IMP_HIP_LIB=$R/imp-release_amd/csrc/variants/libimp_hip_wfprof.so timeout 200 python tools/probe/fused_time.py 2>&1 | grep -v amdgpu.ids | tail -9; timeout 200 python tools/probe/fused_time.py 2>&1 | grep -v amdgpu.ids | tail -3) > $O/final_${T}_fused.log 2>&1
 REPS=2 STEPS=60 bash tools/gpu_ab.sh final_$T "-" "IMP_WF_FUSED=0" "IMP_WF_FUSED=0 IMP_OT_LANE=1" > /dev/null 2>&1
