@@ -234,6 +234,21 @@ def _pose_workers(n, device):
 
 def matching_iterative_lockstep(datas, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method=None, estimate_pose=None,
                                 pose_threads=4, traces=None, native='auto'):
+    """:func:`_lockstep_group` on all of ``datas``; a group the chip-resident Sinkhorn cannot hold as one ragged batch (more than 4 pairs of
+    ~2048 keypoints, 8 of <= 1024) is split in halves (a single pair always fits)"""
+    try:
+        return _lockstep_group(datas, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method, estimate_pose, pose_threads, traces, native)
+    except _lib.ImpError as e:
+        if 'chip-resident' not in str(e) or len(datas) < 2:
+            raise
+    mid = len(datas) // 2
+    tr = (None, None) if traces is None else (traces[:mid], traces[mid:])
+    return (matching_iterative_lockstep(datas[:mid], model, nI, match_ratio, min_kpts, error_th, stop_criteria, method, estimate_pose, pose_threads, tr[0], native) +
+            matching_iterative_lockstep(datas[mid:], model, nI, match_ratio, min_kpts, error_th, stop_criteria, method, estimate_pose, pose_threads, tr[1], native))
+
+
+def _lockstep_group(datas, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method=None, estimate_pose=None,
+                    pose_threads=4, traces=None, native='auto'):
     """eval/matching.py:16-123 on SEVERAL pairs at once -> [(indices0, mscores0, R, t, n_iterations)] - per pair exactly what
     :func:`matching_iterative` returns for it.
 

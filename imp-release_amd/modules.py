@@ -362,13 +362,39 @@ class GM(nn.Module):
             return self._run_iterations_chunk(data, p, only_last, want_scores, None)
         # ragged batch: chunks of at most RAGGED_MAX pairs, each under its own counts; no score tensors (every pair's dustbin row /
         # column would sit elsewhere inside the padded tensor)
+        N0, N1 = data['keypoints0'].shape[1], data['keypoints1'].shape[1]
+        per_pair = ('keypoints0', 'keypoints1', 'scores0', 'scores1', 'descriptors0', 'descriptors1', 'norm_keypoints0', 'norm_keypoints1')
+
+        def run(lo, hi):
+            """pairs [lo, hi) as one ragged call; a batch the chip-resident Sinkhorn cannot hold (more than 4 pairs of ~2048 keypoints, 8 of
+            <= 1024) is split in halves, down to single pairs, which run unpadded through the uniform path"""
+            sl = slice(lo, hi)
+            chunk = {k: (v[sl] if torch.is_tensor(v) and k in per_pair else v) for k, v in data.items() if k not in ('num_keypoints0', 'num_keypoints1')}
+            if hi - lo == 1:
+                a, b_ = counts[0][lo], counts[1][lo]
+                for k in per_pair:
+                    if k in chunk:
+                        chunk[k] = chunk[k][:, :(a if k.endswith('0') else b_)]
+                r = self._run_iterations_chunk(chunk, p, only_last, False, None)
+                r.pop('scores', None)
+                pad = {'indices0': (N0, -1), 'mscores0': (N0, 0.0), 'indices1': (N1, -1), 'mscores1': (N1, 0.0)}
+                for k, (n_, fill) in pad.items():
+                    r[k] = [torch.nn.functional.pad(t, (0, n_ - t.shape[1]), value=fill) for t in r[k]]
+                return [r]
+            try:
+                return [self._run_iterations_chunk(chunk, p, only_last, False, (counts[0][sl], counts[1][sl]))]
+            except _lib.ImpError as e:
+                if 'chip-resident' not in str(e):
+                    raise
+                mid = (lo + hi) // 2
+                return run(lo, mid) + run(mid, hi)
+
         outs = []
         for s0 in range(0, B, self.RAGGED_MAX):
-            sl = slice(s0, min(B, s0 + self.RAGGED_MAX))
-            chunk = {k: (v[sl] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == B and k not in ('image0', 'image1') else v)
-                     for k, v in data.items() if k not in ('num_keypoints0', 'num_keypoints1')}
-            outs.append(self._run_iterations_chunk(chunk, p, only_last, False, (counts[0][sl], counts[1][sl])))
-        out = {k: [torch.cat([o[k][i] for o in outs], 0) for i in range(len(outs[0][k]))] for k in outs[0]}
+            outs += run(s0, min(B, s0 + self.RAGGED_MAX))
+        keys = [k for k in outs[0] if k != 'scores']
+        out = {k: [torch.cat([o[k][i] for o in outs], 0) for i in range(len(outs[0][k]))] for k in keys}
+        out['scores'] = []
         return out
 
     def _run_iterations_chunk(self, data, p, only_last, want_scores, counts):

@@ -139,6 +139,26 @@ def test_more_pairs_than_one_ragged_call_takes():
                         o1['mscores0'][-1].cpu().numpy(), 0.2, TOL, f'pair {b} of 18')
 
 
+def test_ragged_batch_beyond_the_resident_sinkhorn_is_split_not_refused():
+    """6 pairs of up to 2048 keypoints do not fit the chip-resident Sinkhorn as ONE ragged batch (4 at that size): the module splits the batch
+    (3 + 3 here) instead of failing; a single left-over pair runs unpadded through the uniform path.  Results per pair as always."""
+    cfg = eval_config(n_layers=2)
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=3)
+    m = make_hip_model('GM', cfg, sd)
+    pairs = [(2048, 1500, 70), (1200, 2048, 71), (1800, 1700, 72), (300, 280, 73), (2048, 2048, 74), (1100, 900, 75)]
+    data, singles = _padded_batch(pairs)
+    with torch.no_grad():
+        out = m.produce_matches(data, p=0.2, only_last=True)
+    assert out['indices0'][-1].shape == (6, 2048)
+    for b in (0, 3, 4, 5):
+        with torch.no_grad():
+            o1 = m.produce_matches(_single(singles[b]), p=0.2, only_last=True)
+        n0 = pairs[b][0]
+        compare_matches(out['indices0'][-1][b:b + 1, :n0].cpu(), out['mscores0'][-1][b:b + 1, :n0].cpu(), o1['indices0'][-1].cpu().numpy(),
+                        o1['mscores0'][-1].cpu().numpy(), 0.2, TOL, f'pair {b} of 6')
+        assert bool((out['indices0'][-1][b, n0:] == -1).all())
+
+
 def test_ragged_argument_errors():
     from imp_release_amd import _lib
     cfg = eval_config(n_layers=2)
