@@ -1492,6 +1492,7 @@ int imp_forward_layer(imp_ctx* c, int layer_i, int batch, int n0, int n1, const 
 }
 
 int imp_attention_prob(imp_ctx* c, int which, float* prob, void* stream) {
+    if (c && c->rc.on) return fail(IMP_E_ARG, "imp_attention_prob: not with per-pair keypoint counts (imp_set_counts) - the cached attention of a ragged batch has per-pair shapes");
     if (!c || !prob || which < 0 || which > 3) return fail(IMP_E_ARG, "imp_attention_prob: bad argument");
     const ProbSpec ps = kProb[which];
     const AttnCache& cache = c->cache[ps.kind];
@@ -1525,6 +1526,7 @@ int imp_attention_prob(imp_ctx* c, int which, float* prob, void* stream) {
 }
 
 int imp_attention_received(imp_ctx* c, int which, float* out, void* stream) {
+    if (c && c->rc.on) return fail(IMP_E_ARG, "imp_attention_received: not with per-pair keypoint counts (imp_set_counts) - the cached attention of a ragged batch has per-pair shapes");
     if (!c || !out || which < 0 || which > 3) return fail(IMP_E_ARG, "imp_attention_received: bad argument");
     const ProbSpec ps = kProb[which];
     const AttnCache& cache = c->cache[ps.kind];
@@ -1605,6 +1607,7 @@ int imp_compute_matches(imp_ctx* c, int batch, int n0, int n1, const float* scor
     int rc = check_ready(c, batch, n0, n1);
     if (rc) return rc;
     if (!scores) return fail(IMP_E_ARG, "imp_compute_matches: null scores");
+    if (c->rc.on) return fail(IMP_E_ARG, "imp_compute_matches: no score tensors with per-pair keypoint counts (imp_set_counts): use imp_match_tail");
     HIP_TRY(launch_score_maxima(scores, batch, n0, n1, c->max0, c->arg0, c->max1, c->arg1, c->colpart_v, c->colpart_i,
                                 S(stream)));
     HIP_TRY(launch_mutual_matches(batch, n0, n1, c->max0, c->arg0, c->max1, c->arg1, p, indices0, indices1, mscores0,
@@ -1617,6 +1620,7 @@ int imp_pool(imp_ctx* c, int n0, int n1, const float* scores, float mscore_th, f
     int rc = check_ready(c, 1, n0, n1);
     if (rc) return rc;
     if (!scores || !ids0 || !ids1 || !counts) return fail(IMP_E_ARG, "imp_pool: null argument");
+    if (c->rc.on) return fail(IMP_E_ARG, "imp_pool: not with per-pair keypoint counts (imp_set_counts)");
     for (int k = 0; k < 2; ++k)
         if (!c->cache[k].valid || c->cache[k].n[0] != n0 || c->cache[k].n[1] != n1)
             return fail(IMP_E_STATE, "imp_pool: cached self/cross attention does not match (n0, n1)");
