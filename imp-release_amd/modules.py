@@ -452,7 +452,7 @@ class GM(nn.Module):
         r = self._run_iterations(data, p, only_last, want_scores=True)
         nB = kpts0.shape[0]
         nI = len(r['indices0'])
-        acc = self._acc_stats(data, torch.cat(r['indices0'], 0), nB, nI, kpts0.device)
+        acc = self._acc_stats(data, r['indices0'][0] if nI == 1 else torch.cat(r['indices0'], 0), nB, nI, kpts0.device)      # (no copy kernel for the one-shot call)
         return {'scores': r['scores'], 'indices0': r['indices0'], 'mscores0': r['mscores0'],
                 'acc_corr': [acc[0]], 'acc_incorr': [acc[1]], 'total_acc_corr': [acc[2]],
                 'total_acc_incorr': [acc[3]]}
