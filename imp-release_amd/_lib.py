@@ -27,7 +27,7 @@ SYMBOLS = [
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
     'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_pool_select_pair', 'imp_masked_commit', 'imp_gather_rows', 'imp_match_pair', 'imp_set_counts', 'imp_match_tail', 'imp_loop_lockstep', 'imp_op_linear', 'imp_op_layer_gemm', 'imp_op_fused_mlp',
-    'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_range_events', 'imp_time_layer_gemm', 'imp_estimate_pose',
+    'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_range_events', 'imp_tag_wraps', 'imp_time_layer_gemm', 'imp_estimate_pose',
     'imp_sp_create', 'imp_sp_destroy', 'imp_sp_set_weight', 'imp_sp_finalize', 'imp_sp_detect', 'imp_sp_describe', 'imp_sp_dense', 'imp_sp_op_conv',
 ]
 
@@ -130,6 +130,7 @@ def lib():
     L.imp_resident_health.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.imp_set_resident_verify.argtypes = [P, I]
     L.imp_range_events.argtypes = [P]
+    L.imp_tag_wraps.argtypes = [P]
     L.imp_time_layer_gemm.argtypes = [P, I, I, I, I, I, C.POINTER(C.c_float), P]
     L.imp_estimate_pose.argtypes = [P, P, I, P, P, C.c_double, I, C.c_uint, I, P, P, P, P, P, C.POINTER(C.c_int), I, P]
     L.imp_sp_create.argtypes = [C.POINTER(C.c_void_p), I, I]
@@ -558,6 +559,10 @@ class Context:
             return False
         self._check(rc)
         return n.value, lvl.value
+
+    def tag_wraps(self):
+        """how often the tag counter of hipGraph-replayed resident launches wrapped (the library then cleared the exchange buffers)"""
+        return int(self.L.imp_tag_wraps(self.handle))
 
     def set_resident_verify(self, on: bool):
         """every chip-resident Sinkhorn launch is awaited inside the call and a voided one is re-run there (one host

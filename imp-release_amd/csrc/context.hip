@@ -90,6 +90,8 @@ struct imp_ctx {
     int* xstatus_hostdev = nullptr;                //   its device address
     int* range_host = nullptr;                     // word 1 of the same page: a match kernel saw non-finite scores (IMP_E_RANGE)
     int* range_hostdev = nullptr;
+    unsigned graph_tag0 = 0x80000000u;             // first tag of the graph launches (IMP_OT_GRAPH_TAG0: a test starts close to the wrap)
+    int tag_wraps = 0;                             // word 2 of the page: the graph launches' tag counter wrapped (resident_health clears the buffers)
     unsigned ticket_base = 0;                      // value of the per-XCC ticket counters before the next LOCAL launch
     int num_xccs = 0;
     int ot_degrade = 0;      // raised by a time-out: 1 = no XCD-local launches any more (chip-wide exchange only), 2 = streaming kernels only
@@ -873,7 +875,7 @@ int ensure_resident_buffers(imp_ctx* c, int batch) {
         if (!rc) HIP_TRY(hipMemset(c->xmax, 0, 4 * wgs * kResidentMaxLdx * sizeof(float)));
         if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xstatus, 32);
         if (!rc) HIP_TRY(hipMemset(c->xstatus, 0, 128));
-        if (!rc) { const unsigned graph_tags = 0x80000000u; HIP_TRY(hipMemcpy(c->xstatus + 16, &graph_tags, 4, hipMemcpyHostToDevice)); }   // graph launches tag in the upper half
+        if (!rc) { const unsigned graph_tags = c->graph_tag0; HIP_TRY(hipMemcpy(c->xstatus + 16, &graph_tags, 4, hipMemcpyHostToDevice)); }   // graph launches tag in the upper half
         c->ticket_base = 0;
         if (!rc) HIP_TRY(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
         if (!rc) HIP_TRY(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
@@ -930,6 +932,22 @@ int resident_health(imp_ctx* c) {
     // the resident word first: a voided launch leaves NaN maxima behind, which the match kernel also reports through the range word -
     // that is one event (IMP_E_RESIDENT), not two
     const int st = *static_cast<volatile int*>(c->xstatus_host);
+    if (st == 0 && static_cast<volatile int*>(c->xstatus_host)[2]) {
+        // not a failure: the device-side tag counter of hipGraph-replayed resident launches wrapped (ot_resident.hip leave()).  Their tags
+        // start over, so the exchange buffers must not hold old ones: wait for the device and clear them
+        (void)hipSetDevice(c->device);
+        if (hipDeviceSynchronize() != hipSuccess) { (void)hipGetLastError(); return IMP_OK; }      // (e.g. a capture in progress: at the next entry point)
+        const size_t wgs = (size_t)c->num_cus;
+        if (c->xpart) (void)hipMemset(c->xpart, 0, 2 * wgs * kResidentMaxLdx * sizeof(float));
+        if (c->xmax) (void)hipMemset(c->xmax, 0, 4 * wgs * kResidentMaxLdx * sizeof(float));
+        if (c->xv) (void)hipMemset(c->xv, 0, 2 * (size_t)c->xcap_b * kResidentMaxLdx * sizeof(float));
+        if (c->xhalf) (void)hipMemset(c->xhalf, 0, 2 * (size_t)c->xcap_b * kResidentMaxLdx * sizeof(float));
+        c->xtag = 0;                                       // (the eager launches' tags may start over as well: the buffers are clean)
+        (void)hipDeviceSynchronize();
+        static_cast<volatile int*>(c->xstatus_host)[2] = 0;
+        c->tag_wraps += 1;
+        return IMP_OK;
+    }
     if (st) {
         (void)hipSetDevice(c->device);                     // (the caller's thread may have another device current: imp_resident_health)
         (void)hipDeviceSynchronize();
@@ -1256,6 +1274,7 @@ int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     { const char* e = getenv("IMP_OT_VERIFY"); c->ot_verify = (e && atoi(e) != 0) ? 1 : 0; }
     { const char* e = getenv("IMP_OT_GRAPH"); c->ot_graph = (e && atoi(e) == 0) ? 0 : 1; }      // 0: hipGraph captures record the streaming Sinkhorn (round 2 / 3)
     { const char* e = getenv("IMP_OT_FAKE_PLACEMENT"); c->ot_fake = (e && atoi(e) != 0) ? 1 : 0; }
+    { const char* e = getenv("IMP_OT_GRAPH_TAG0"); if (e) { const unsigned long v = strtoul(e, nullptr, 0); if (v >= 0x80000000ul && v <= 0xFFFFF000ul) c->graph_tag0 = (unsigned)v; } }   // TEST HOOK
     { const char* e = getenv("IMP_GEMM_WF"); c->use_wf = e ? atoi(e) : 1; }     // 0 off, 1 default (large launches), 2 always
     { const char* e = getenv("IMP_WF_CHAIN"); c->wf_chain = e ? atoi(e) : 1; }
     { const char* e = getenv("IMP_WF_FUSED"); c->wf_fused = e ? atoi(e) : 1; }
@@ -2322,6 +2341,8 @@ int imp_resident_health(imp_ctx* c, int* timeouts, int* level) {
 }
 
 int imp_range_events(imp_ctx* c) { return c ? c->range_events : -1; }
+
+int imp_tag_wraps(imp_ctx* c) { return c ? c->tag_wraps : -1; }
 
 int imp_set_resident_verify(imp_ctx* c, int on) {
     if (!c) return fail(IMP_E_ARG, "imp_set_resident_verify: null context");

@@ -185,7 +185,13 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             const unsigned done = __hip_atomic_fetch_add(p.dev_base + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (done == gridDim.x - 1) {
                 unsigned nb = tag_base + 3u * (unsigned)p.T + 4u;
-                if (nb > 0xFFFFF000u) nb = 0x80000000u;                    // graph launches tag in the upper half of the 32-bit space
+                if (nb > 0xFFFFF000u) {                                    // graph launches tag in the upper half of the 32-bit space
+                    nb = 0x80000000u;
+                    // ~7 million replays at T = 100: the tag space of the replayed launches starts over.  Tags must not repeat on buffers that
+                    // may still hold them, so the library is told (word 2 of the mapped health page: "clear the exchange buffers", not an
+                    // error) and does so at its next entry point (context.hip resident_health)
+                    if (p.host_status) __hip_atomic_store(p.host_status + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
                 const unsigned share = LOCAL == 1 ? (unsigned)(G * ((p.B + 7) >> 3)) : (LOCAL == 2 ? (unsigned)(G >> 1) : 0u);
                 __hip_atomic_store(p.dev_base, nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(p.dev_base + 1, ticket_base + share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

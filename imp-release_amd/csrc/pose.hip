@@ -280,8 +280,13 @@ __global__ __launch_bounds__(64) void pose_hypotheses5_kernel(const double2* __r
         unsigned long long prof[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         nsol = fivept::five_point<FP_L>(Eh + (long)h * 90, w, lane, prof);
         if (lane == 0 && (h & 255) == 0)      // 100 MHz counter: x 10 ns
+#ifdef FP_EIG_QR
             printf("fivept h=%d nsol=%d: null space %llu  cubics %llu  gauss-jordan %llu  eigenvalues %llu (hessenberg %llu, %llu QR sweeps, %llu bulge steps)  eigenvectors %llu  (x 10 ns)\n", h, nsol,
                    prof[1] - prof[0], prof[2] - prof[1], prof[3] - prof[2], prof[4] - prof[3], prof[6] - prof[3], prof[7], prof[8], prof[5] - prof[4]);
+#else
+            printf("fivept h=%d nsol=%d: null space %llu  cubics %llu  gauss-jordan %llu  eigenvalues %llu (hessenberg %llu, characteristic polynomial %llu, roots + polish %llu)  eigenvectors %llu  (x 10 ns)\n", h, nsol,
+                   prof[1] - prof[0], prof[2] - prof[1], prof[3] - prof[2], prof[4] - prof[3], prof[6] - prof[3], prof[7] - prof[6], prof[4] - prof[7], prof[5] - prof[4]);
+#endif
 #else
         nsol = fivept::five_point<FP_L>(Eh + (long)h * 90, w, lane);
 #endif
@@ -487,14 +492,18 @@ __global__ __launch_bounds__(CT) void pose_consensus_kernel(const double2* __res
         const double r2 = sampson_sq(E, ax, ay, bx, by);
         return magsac ? magsac_weight_lut(r2, inv_k2s2, wlut) : (r2 < thr2 ? 1.0 : 0.0);
     };
-    // the first CPT points of a thread stay in registers with their weight under the current model; the rest (n > 4096) is recomputed
-    double pax[CPT], pay[CPT], pbx[CPT], pby[CPT], pw[CPT], pn[CPT];
+    // the first CPT points of a thread stay on chip - their coordinates in LDS (128 KB: this is the only workgroup of the launch; in
+    // registers they made the kernel spill), their weight under the current model in registers; the rest (n > 4096) is recomputed
+    extern __shared__ __attribute__((aligned(16))) double2 cpts[];
+    double2* const sa = cpts + tid;                              // point u of this thread: sa[u * CT], sb[u * CT] (16-byte stride over the lanes)
+    double2* const sb = cpts + CPT * CT + tid;
+    double pw[CPT];
 #pragma unroll
     for (int u = 0; u < CPT; ++u) {
         const int i = tid + u * CT;
         const bool in = i < n;
         const double2 a = x0[in ? i : 0], b = x1[in ? i : 0];
-        pax[u] = a.x; pay[u] = a.y; pbx[u] = b.x; pby[u] = b.y;
+        sa[u * CT] = a; sb[u * CT] = b;                          // (read back by this thread only: no barrier)
         pw[u] = in ? weight_of(Es, a.x, a.y, b.x, b.y) : 0.0;
         if (in) inl[i] = sampson_sq(Es, a.x, a.y, b.x, b.y) < thr2;
     }
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(CT) void pose_consensus_kernel(const double2* __res
     // f(ax, ay, bx, by, w) over all points with their weight under Es
     auto for_points = [&](auto&& f) {
 #pragma unroll
-        for (int u = 0; u < CPT; ++u) if (pw[u] > 0) f(pax[u], pay[u], pbx[u], pby[u], pw[u]);
+        for (int u = 0; u < CPT; ++u) if (pw[u] > 0) { const double2 a = sa[u * CT], b = sb[u * CT]; f(a.x, a.y, b.x, b.y, pw[u]); }
         for (int i = tid + CPT * CT; i < n; i += CT) {
             const double w = weight_of(Es, x0[i].x, x0[i].y, x1[i].x, x1[i].y);
             if (w > 0) f(x0[i].x, x0[i].y, x1[i].x, x1[i].y, w);
@@ -521,24 +530,26 @@ __global__ __launch_bounds__(CT) void pose_consensus_kernel(const double2* __res
         });
         block_sums<2>(d2, part, red);
         const double s0 = 1.4142135623730951 / fmax(red[0] / cnt, 1e-12), s1 = 1.4142135623730951 / fmax(red[1] / cnt, 1e-12);
-        double acc[45];
+        // the normal matrix sum_i w_i r_i r_i^T of the rows r = (bx, by, 1) (x) (ax, ay, 1) is sum_i w_i (b b^T) (x) (a a^T): 6 x 6 = 36
+        // distinct sums instead of the 45 of a general symmetric 9 x 9 matrix (fewer live registers: the kernel used to spill)
+        double acc[36];
 #pragma unroll
-        for (int k = 0; k < 45; ++k) acc[k] = 0.0;
+        for (int k = 0; k < 36; ++k) acc[k] = 0.0;
         for_points([&](double ax0, double ay0, double bx0, double by0, double w) {
             const double ax = (ax0 - cx0) * s0, ay = (ay0 - cy0) * s0, bx = (bx0 - cx1) * s1, by = (by0 - cy1) * s1;
-            const double r[9] = {bx * ax, bx * ay, bx, by * ax, by * ay, by, ax, ay, 1.0};
-            int k = 0;
+            const double qa[6] = {ax * ax, ax * ay, ax, ay * ay, ay, 1.0};                      // a a^T: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+            const double qb[6] = {w * bx * bx, w * bx * by, w * bx, w * by * by, w * by, w};    // w b b^T, same order
 #pragma unroll
-            for (int a = 0; a < 9; ++a)
+            for (int u = 0; u < 6; ++u)
 #pragma unroll
-                for (int b2 = a; b2 < 9; ++b2) acc[k++] += w * r[a] * r[b2];
+                for (int v = 0; v < 6; ++v) acc[u * 6 + v] += qb[u] * qa[v];
         });
-        block_sums<45>(acc, part, red);
-        if (tid < 45) {                                            // the symmetric normal matrix
-            int a = 0, rem = tid;
-            while (rem >= 9 - a) { rem -= 9 - a; ++a; }
-            const int b2 = a + rem;
-            JA[a * 9 + b2] = JA[b2 * 9 + a] = red[tid];
+        block_sums<36>(acc, part, red);
+        if (tid < 81) {                                            // entry (3 i + k, 3 j + l) = (b b^T)_ij (a a^T)_kl
+            const int r = tid / 9, c = tid - 9 * r;
+            const int i = r / 3, k = r - 3 * i, j = c / 3, l = c - 3 * j;
+            const int sym[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}};
+            JA[tid] = red[sym[i][j] * 6 + sym[k][l]];
         }
         if (tid == 64) {                                           // the current model in conditioned coordinates: F0 = T1^-T Es T0^-1
             // T^-1 = [[1/s, 0, cx], [0, 1/s, cy], [0, 0, 1]]
@@ -567,7 +578,7 @@ __global__ __launch_bounds__(CT) void pose_consensus_kernel(const double2* __res
         if (!s_ok) break;
         double c2[1] = {0};
 #pragma unroll
-        for (int u = 0; u < CPT; ++u) { pn[u] = tid + u * CT < n ? weight_of(Et, pax[u], pay[u], pbx[u], pby[u]) : 0.0; c2[0] += pn[u]; }
+        for (int u = 0; u < CPT; ++u) { const double2 a = sa[u * CT], b = sb[u * CT]; c2[0] += tid + u * CT < n ? weight_of(Et, a.x, a.y, b.x, b.y) : 0.0; }
         for (int i = tid + CPT * CT; i < n; i += CT) c2[0] += weight_of(Et, x0[i].x, x0[i].y, x1[i].x, x1[i].y);
         block_sums<1>(c2, part, red);
         const int cnt2 = magsac ? (int)floor(red[0] * QUALITY_SCALE) : (int)red[0];
@@ -578,9 +589,10 @@ __global__ __launch_bounds__(CT) void pose_consensus_kernel(const double2* __res
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
-            pw[u] = pn[u];
             const int i = tid + u * CT;
-            if (i < n) inl[i] = sampson_sq(Es, pax[u], pay[u], pbx[u], pby[u]) < thr2;
+            const double2 a = sa[u * CT], b = sb[u * CT];
+            pw[u] = i < n ? weight_of(Es, a.x, a.y, b.x, b.y) : 0.0;                             // (recomputed rather than held)
+            if (i < n) inl[i] = sampson_sq(Es, a.x, a.y, b.x, b.y) < thr2;
         }
         for (int i = tid + CPT * CT; i < n; i += CT) inl[i] = sampson_sq(Es, x0[i].x, x0[i].y, x1[i].x, x1[i].y) < thr2;
         if (same && round > 0) break;
@@ -755,7 +767,9 @@ extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, 
     hipLaunchKernelGGL(pose_score_kernel, dim3((ncand + SCORE_C - 1) / SCORE_C), dim3(256), 0, st, x0, x1, n, ncand, ws.Eh, ws.valid, thr * thr, (flags & 1) ? ws.wlut : nullptr, ws.counts);
     // the cheirality step of the reference normalises with K = (K0 + K1) / 2 (eval/pose_estimation.py:29-33): with K0 == K1 (every
     // caller in the repo) these are the coordinates above; a caller with two different cameras gets per-camera normalisation
-    hipLaunchKernelGGL(pose_consensus_kernel, dim3(1), dim3(CT), 0, st, x0, x1, n, ncand, ws.Eh, ws.counts, thr * thr, (flags & 1) ? ws.wlut : nullptr, eight ? 8 : 5, inl, dout, ws.good);
+    constexpr size_t consensus_lds = 2 * (size_t)CPT * CT * sizeof(double2);
+    if (imp_grant_dynamic_lds(reinterpret_cast<const void*>(&pose_consensus_kernel), consensus_lds) != hipSuccess) return IMP_E_HIP;
+    hipLaunchKernelGGL(pose_consensus_kernel, dim3(1), dim3(CT), consensus_lds, st, x0, x1, n, ncand, ws.Eh, ws.counts, thr * thr, (flags & 1) ? ws.wlut : nullptr, eight ? 8 : 5, inl, dout, ws.good);
     hipLaunchKernelGGL(pose_cheirality_kernel, dim3((4 * n + 255) / 256), dim3(256), 0, st, x0, x1, n, dout, inl, 1000.0, ws.bits, ws.good);
     hipLaunchKernelGGL(pose_vote_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, ws.good, ws.bits, inl, refmask, dout);
     // one read-back: the 24 result doubles, the reference-semantics mask and the geometric mask

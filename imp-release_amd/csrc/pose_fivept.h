@@ -43,6 +43,15 @@
 
 namespace fivept {
 
+// scratch of the root finder (aliases Work::G, which is only needed once the eigenvalues are known)
+struct RootScratch {
+    double P[11][12];          // P[k]: characteristic polynomial of the leading k x k block of the Hessenberg matrix (lambda^0 .. lambda^k, zero above)
+    double Q[10][12];          // Q[m] = p^(m) / m!: Q[m][j] = C(j + m, m) c[j + m] (zero above degree 10 - m)
+    double rt[2][12];          // the real roots of two consecutive derivative levels, ascending
+    double cand[12];           // level being processed: the root of interval i ...
+    int found[12];             // ... if it holds one
+};
+
 // Scratch of one solve (LDS on the GPU): 8240 bytes
 struct Work {
     double pts[5][4];          // the sample: x0, y0, x1, y1 (normalised coordinates)
@@ -54,7 +63,10 @@ struct Work {
     double A[10][20];          // the ten cubics [degree-3 monomials | quotient basis] -> A1^-1 A2
     double H[11][11];          // action matrix, 1-based (EISPACK)
     double wr[11], wi[11];     // eigenvalues; wr is reused for the sorted real ones
-    double G[10][6][6];        // eigenvector system of each real eigenvalue
+    union {
+        double G[10][6][6];    // eigenvector system of each real eigenvalue
+        RootScratch rs;        // (before that: the root finder's tables)
+    };
     double Es[10][9];          // candidate essential matrices
     int ok[10];
     int pad[2];
@@ -207,8 +219,7 @@ FP_HD bool gauss_jordan_10x20(double (&A)[10][20], int lane) {
 // eigenvalue needs more than 60 iterations.  The arithmetic is the published one, element for element; the row / column loops are
 // dealt to the lanes, everything else is computed by every lane of the group (identical values).
 template <int L>
-FP_HD bool eig_real_nonsym(double (&a)[11][11], double* wr, double* wi, int lane, unsigned long long* prof = nullptr) {
-    (void)prof;
+FP_HD void hessenberg_10(double (&a)[11][11], int lane) {
     constexpr int n = 10;
     FP_LOOP for (int m = 2; m < n; ++m) {
         double best = 0.0;
@@ -226,22 +237,37 @@ FP_HD bool eig_real_nonsym(double (&a)[11][11], double* wr, double* wi, int lane
             FP_LOOP for (int j = 1 + lane; j <= n; j += L) { const double t = a[j][i]; a[j][i] = a[j][m]; a[j][m] = t; }
             group_fence<L>();
         }
-        if (x != 0.0)
-            FP_LOOP for (int ii = m + 1; ii <= n; ++ii) {
-                double y = a[ii][m - 1];
-                if (y != 0.0) {
-                    y /= x;
-                    a[ii][m - 1] = y;                                      // every lane: the same value
-                    FP_LOOP for (int j = m + lane; j <= n; j += L) a[ii][j] -= y * a[m][j];
-                    group_fence<L>();
-                    FP_LOOP for (int j = 1 + lane; j <= n; j += L) a[j][m] += y * a[j][ii];
-                    group_fence<L>();
-                }
+        if (x != 0.0) {
+            // The published loop treats the rows ii = m + 1 .. n one after the other (row operation, then column operation: two dependent
+            // LDS round trips per row).  The elementary matrices L_ii = I - y_ii e_ii e_m^T of one step act on different rows and share
+            // the column, so A <- (L_n .. L_m+1) A (L_m+1^-1 .. L_n^-1) can be applied as ALL row operations, then ALL column operations
+            // (the same similarity transformation; only the order of a few roundings differs): three round trips per step.
+            FP_LOOP for (int ii = m + 1 + lane; ii <= n; ii += L) a[ii][m - 1] = a[ii][m - 1] / x;      // the multipliers y_ii (stored as published)
+            group_fence<L>();
+            const int w = n - m + 1;                                       // columns m .. n
+            FP_LOOP for (int t = lane; t < (n - m) * w; t += L) {
+                const int r = t / w, ii = m + 1 + r, j = m + (t - r * w);
+                a[ii][j] -= a[ii][m - 1] * a[m][j];
             }
+            group_fence<L>();
+            FP_LOOP for (int j = 1 + lane; j <= n; j += L) {
+                double acc = a[j][m];
+                FP_UNROLL for (int ii = 3; ii <= n; ++ii) acc += (ii > m ? a[ii][m - 1] : 0.0) * a[j][ii];      // (fixed trip count: the loads overlap)
+                a[j][m] = acc;
+            }
+            group_fence<L>();
+        }
     }
     FP_LOOP for (int i = 3 + lane; i <= n; i += L)
         for (int j = 1; j <= i - 2; ++j) a[i][j] = 0.0;
     group_fence<L>();
+}
+
+template <int L>
+FP_HD bool eig_real_nonsym(double (&a)[11][11], double* wr, double* wi, int lane, unsigned long long* prof = nullptr) {
+    (void)prof;
+    constexpr int n = 10;
+    hessenberg_10<L>(a, lane);
     double anorm = 0.0;
     for (int i = 1; i <= n; ++i)
         for (int j = (i - 1 > 1 ? i - 1 : 1); j <= n; ++j) anorm += fabs(a[i][j]);
@@ -393,6 +419,204 @@ FP_HD bool eig_real_nonsym(double (&a)[11][11], double* wr, double* wi, int lane
     return true;
 }
 
+// ---- the real eigenvalues as the real roots of the characteristic polynomial (round 4) ------------------------------------
+// The shifted-QR iteration above is a chain of ~100 dependent bulge steps (2 700 cycles each on gfx950) however many lanes help.  Only the
+// REAL eigenvalues are wanted, so: Hessenberg form (as before), its characteristic polynomial by the leading-block recurrence
+//   p_k(l) = (l - h_kk) p_{k-1}(l) - sum_{i<k} h_ik (h_{i+1,i} ... h_{k,k-1}) p_{i-1}(l)          (coefficient j on lane j),
+// and the real roots of the monic degree-10 polynomial by the derivative cascade: the roots of p^(m+1) cut the line into intervals on
+// which p^(m) is monotonic, so each holds at most one root of p^(m), decided by the signs at its ends and found by a bracketed Newton
+// iteration - one interval per lane, ten levels from the linear p^(9) down to p.  No deflation, no complex arithmetic, nothing that
+// can fail to converge; close root pairs are found as long as fp64 still separates the signs (Nister's original solver isolates the
+// roots of the same polynomial with Sturm sequences).  The scaled derivatives p^(m) / m! keep the coefficients within a factor 252.
+
+// f = q(x), df = q'(x) for q = c[0] + c[1] x + ... + c[D] x^D
+template <int D>
+FP_HD void poly_eval(const double (&c)[11], double x, double& f, double& df) {
+    double p = c[D], d = 0.0;
+    FP_UNROLL for (int j = D - 1; j >= 0; --j) { d = d * x + p; p = p * x + c[j]; }
+    f = p; df = d;
+}
+
+// 1 / x for a Newton step (the iteration corrects itself: the hardware estimate is enough on the GPU)
+FP_HD double step_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(x);
+#else
+    return 1.0 / x;
+#endif
+}
+
+// the root of q in [a, b], q monotonic there, q(a) < 0 iff neg_a and the opposite sign at b: Newton steps, a bisection whenever a step
+// would leave the bracket or stops halving the interval (the classic safeguarded iteration).  Relative accuracy 1e-11: these roots are
+// separators for the next level or, at the last level, starting points of the correction on the matrix (hyman_polish)
+template <int D>
+FP_HD double root_in_bracket(const double (&c)[11], double a, double b, bool neg_a) {
+    double lo = neg_a ? a : b, hi = neg_a ? b : a;        // q(lo) < 0 <= q(hi)
+    double x = 0.5 * (a + b), dxold = fabs(b - a), dx = dxold, f, df;
+    poly_eval<D>(c, x, f, df);
+    if (f < 0.0) lo = x; else hi = x;
+    FP_LOOP for (int it = 0; it < 200; ++it) {
+        if (f == 0.0) return x;
+        const bool bisect = !(((x - hi) * df - f) * ((x - lo) * df - f) < 0.0) || !(fabs(2.0 * f) <= fabs(dxold * df));
+        dxold = dx;
+        double xn;
+        if (bisect) { dx = 0.5 * (hi - lo); xn = lo + dx; }
+        else { dx = f * step_rcp(df); xn = x - dx; }
+        if (xn == x) return x;
+        x = xn;
+        if (fabs(dx) <= 1e-11 * fabs(x)) return x;
+        poly_eval<D>(c, x, f, df);
+        if (f < 0.0) lo = x; else hi = x;
+    }
+    return x;
+}
+
+// characteristic polynomial of the upper Hessenberg matrix a (1-based, n = 10) -> P[10][0 .. 10] (monic)
+template <int L>
+FP_HD void charpoly_hessenberg(const double (&a)[11][11], double (&P)[11][12], int lane) {
+    FP_LOOP for (int t = lane; t < 11 * 12; t += L) (&P[0][0])[t] = t == 0 ? 1.0 : 0.0;
+    group_fence<L>();
+    FP_UNROLL for (int k = 1; k <= 10; ++k) {
+        FP_LOOP for (int j = lane; j <= k; j += L) {
+            double acc = (j > 0 ? P[k - 1][j - 1] : 0.0) - a[k][k] * P[k - 1][j];
+            double prod = 1.0;
+            FP_UNROLL for (int i = k - 1; i >= 1; --i) {
+                prod *= a[i + 1][i];
+                acc -= a[i][k] * prod * P[i - 1][j];
+            }
+            P[k][j] = acc;
+        }
+        group_fence<L>();
+    }
+}
+
+// Newton correction of an eigenvalue estimate on the MATRIX (Hyman's method: det(H - l I) of an upper Hessenberg matrix by back
+// substitution of (H - l I) x = alpha e_1 with x_n = 1; the value is alpha times the subdiagonal product, which cancels in p / p').
+// The coefficients of the characteristic polynomial carry the rounding of ~200 operations; its roots can be off by 1e-4 of an
+// ill-conditioned solution, Hyman's evaluation is backward stable.  Steps larger than 1e-3 (1 + |l|) are refused (a root pair about to
+// merge: the estimate stays).  a is 1-based, n = 10.
+FP_HD double hyman_polish(const double (&a)[11][11], double lam) {
+    constexpr int n = 10;
+    FP_LOOP for (int it = 0; it < 2; ++it) {
+        double x[n + 1], dx[n + 1];
+        x[n] = 1.0; dx[n] = 0.0;
+        bool ok = true;
+        FP_UNROLL for (int i = n; i >= 2; --i) {
+            double sx = 0.0, sd = 0.0;
+            FP_UNROLL for (int j = n; j >= i; --j) {
+                const double hij = j == i ? a[i][j] - lam : a[i][j];
+                sx += hij * x[j]; sd += hij * dx[j];
+            }
+            sd -= x[i];
+            const double sub = a[i][i - 1];
+            ok = ok && sub != 0.0;
+            const double inv = 1.0 / sub;
+            x[i - 1] = -sx * inv; dx[i - 1] = -sd * inv;
+        }
+        double pv = 0.0, pd = 0.0;
+        FP_UNROLL for (int j = n; j >= 1; --j) {
+            const double hij = j == 1 ? a[1][j] - lam : a[1][j];
+            pv += hij * x[j]; pd += hij * dx[j];
+        }
+        pd -= x[1];
+        const double step = pv / pd;
+        if (!ok || !isfinite(step) || !(fabs(step) <= 1e-3 * (1.0 + fabs(lam)))) break;
+        lam -= step;
+    }
+    return lam;
+}
+
+// one level of the cascade: the real roots of q_m = p^(m) / m! (degree D = 10 - m) between the np separators in s.rt[(m + 1) & 1] (the
+// real roots of q_(m+1)), ascending into s.rt[m & 1]; returns their number.  Interval i = (sep[i - 1], sep[i]) on lane i, the outer two open.
+template <int L, int D>
+FP_HD int root_level(RootScratch& s, int np, int lane) {
+    constexpr int m = 10 - D;
+    double c[11];
+    FP_UNROLL for (int j = 0; j <= D; ++j) c[j] = s.Q[m][j];
+    const double* sep = s.rt[(m + 1) & 1];
+    FP_LOOP for (int i = lane; i <= np; i += L) {
+        const bool open_a = i == 0, open_b = i == np;
+        double a = open_a ? 0.0 : sep[i - 1], b = open_b ? 0.0 : sep[i];
+        double fa = 0.0, fb = 0.0, dd;
+        if (!open_a) poly_eval<D>(c, a, fa, dd);
+        if (!open_b) poly_eval<D>(c, b, fb, dd);
+        const bool neg_a = open_a ? (D & 1) != 0 : fa < 0.0;          // the leading coefficient C(10, m) is positive
+        const bool neg_b = open_b ? false : fb < 0.0;
+        bool has = neg_a != neg_b;
+        double root = 0.0;
+        if (has) {
+            // an open end: walk outwards in doubling steps until the sign of the far side shows (the Cauchy bound guarantees it does)
+            if (open_a) {
+                const double from = open_b ? 0.0 : b;
+                double step = fabs(from) > 1.0 ? fabs(from) : 1.0;
+                int tries = 0;
+                FP_LOOP for (;; ++tries) {
+                    a = from - step;
+                    poly_eval<D>(c, a, fa, dd);
+                    if ((fa < 0.0) == neg_a || tries >= 400) break;
+                    step *= 2.0;
+                }
+                has = has && tries < 400;
+            }
+            if (open_b) {
+                const double from = open_a ? 0.0 : a;
+                double step = fabs(from) > 1.0 ? fabs(from) : 1.0;
+                int tries = 0;
+                FP_LOOP for (;; ++tries) {
+                    b = from + step;
+                    poly_eval<D>(c, b, fb, dd);
+                    if (!(fb < 0.0) || tries >= 400) break;
+                    step *= 2.0;
+                }
+                has = has && tries < 400;
+            }
+            if (has) root = root_in_bracket<D>(c, a, b, neg_a);
+            has = has && isfinite(root);
+        }
+        s.cand[i] = root;
+        s.found[i] = has ? 1 : 0;
+    }
+    group_fence<L>();
+    double* dst = s.rt[m & 1];
+    int cnt = 0;
+    FP_LOOP for (int i = 0; i <= np; ++i) {                // every lane: the same values to the same places
+        if (s.found[i]) { dst[cnt] = s.cand[i]; ++cnt; }
+    }
+    group_fence<L>();
+    return cnt;
+}
+
+// real roots of the monic polynomial c[0 .. 10] (c = s.P[10]), ascending, into out[]; returns their number (every lane: the same)
+template <int L>
+FP_HD int real_roots_monic10(RootScratch& s, double* out, int lane) {
+    FP_LOOP for (int t = lane; t < 10 * 12; t += L) {
+        const int m = t / 12, j = t - 12 * m;
+        double v = 0.0;
+        if (j + m <= 10) {
+            double b = 1.0;                                // C(j + m, m), exact
+            FP_LOOP for (int u = 1; u <= m; ++u) b = b * (double)(j + u) / (double)u;
+            v = b * s.P[10][j + m];
+        }
+        s.Q[m][j] = v;
+    }
+    group_fence<L>();
+    s.rt[1][0] = -s.Q[9][0] / s.Q[9][1];                   // level 9 is linear (every lane writes the same value)
+    group_fence<L>();
+    int np = 1;                                            // number of separators = real roots of the level above
+    np = root_level<L, 2>(s, np, lane);
+    np = root_level<L, 3>(s, np, lane);
+    np = root_level<L, 4>(s, np, lane);
+    np = root_level<L, 5>(s, np, lane);
+    np = root_level<L, 6>(s, np, lane);
+    np = root_level<L, 7>(s, np, lane);
+    np = root_level<L, 8>(s, np, lane);
+    np = root_level<L, 9>(s, np, lane);
+    np = root_level<L, 10>(s, np, lane);
+    FP_LOOP for (int i = lane; i < np; i += L) out[i] = s.rt[0][i];
+    group_fence<L>();
+    return np;
+}
+
 // Eigenvector of the action matrix M for a real eigenvalue lambda, i.e. the basis monomials b = [x^2, xy, xz, y^2, yz, z^2, x, y, z, 1]
 // at a solution: rows 6..9 of M are unit rows (x.x = x^2, x.y = xy, x.z = xz, x.1 = x), so with b9 = 1: b6 = lambda, b0 = lambda^2,
 // b1 = lambda b7, b2 = lambda b8, and rows 0..5 of (M - lambda I) b = 0 are six linear equations in the five unknowns
@@ -519,10 +743,11 @@ FP_HD int five_point(double* Eout, Work& w, int lane, unsigned long long* prof =
         w.H[i + 1][j + 1] = i < 6 ? -w.A[i][10 + j] : (unit ? 1.0 : 0.0);
     }
     group_fence<L>();
+    int nl = 0;
+#ifdef FP_EIG_QR                                           // rounds 2-3: every eigenvalue by the shifted QR iteration (kept for A/B runs)
     if (!eig_real_nonsym<L>(w.H, w.wr, w.wi, lane, prof)) return 0;
     FP_STAMP(4);
     // the real eigenvalues in ascending order, in place: wr[0 .. nl) (step i writes below index i and reads index i and above); every lane
-    int nl = 0;
     FP_LOOP for (int i = 1; i <= 10; ++i) {
         const double re = w.wr[i], im = w.wi[i];
         if (im == 0.0 && isfinite(re)) {
@@ -532,6 +757,23 @@ FP_HD int five_point(double* Eout, Work& w, int lane, unsigned long long* prof =
         }
     }
     group_fence<L>();
+#else
+    hessenberg_10<L>(w.H, lane);
+    FP_STAMP(6);
+    charpoly_hessenberg<L>(w.H, w.rs.P, lane);
+    FP_STAMP(7);
+    nl = real_roots_monic10<L>(w.rs, w.wr, lane);
+    FP_LOOP for (int e = lane; e < nl; e += L) w.wr[e] = hyman_polish(w.H, w.wr[e]);
+    group_fence<L>();
+    FP_LOOP for (int i = 1; i < nl; ++i) {                 // ascending order again, should two close roots have crossed (every lane, same values)
+        const double v = w.wr[i];
+        int k = i;
+        while (k > 0 && w.wr[k - 1] > v) { w.wr[k] = w.wr[k - 1]; --k; }
+        w.wr[k] = v;
+    }
+    group_fence<L>();
+    FP_STAMP(4);
+#endif
     FP_LOOP for (int e = lane; e < nl; e += L) {          // an eigenvalue per lane
         const double x = w.wr[e];
         double y, z;

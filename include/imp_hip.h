@@ -340,6 +340,9 @@ int imp_resident_health(imp_ctx* ctx, int* timeouts, int* level);
 int imp_set_resident_verify(imp_ctx* ctx, int on);
 /* how many calls on this context were reported with IMP_E_RANGE so far */
 int imp_range_events(imp_ctx* ctx);
+/* how many times the tag counter of hipGraph-REPLAYED resident launches wrapped (about every 7 million replays at 100 Sinkhorn iterations;
+ * the library clears the exchange buffers at the next entry point - not an error).  Test hook: IMP_OT_GRAPH_TAG0=<first tag>. */
+int imp_tag_wraps(imp_ctx* ctx);
 
 /* ---------------------------------------------------------------------------------------------------------------------------
  * SuperPoint front-end: nets/superpoint.py:97-232.  Its own handle (independent of imp_ctx);

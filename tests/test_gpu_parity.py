@@ -433,6 +433,47 @@ def test_fused_call_is_hip_graph_capturable():
                         _cpu(eager_stream['mscores0']).numpy(), 0.2, 1e-5, f'graph replay ({what}) vs eager streaming')
 
 
+def test_graph_replays_survive_the_tag_wrap():
+    """the replayed resident launches take their exchange tags from a device-side counter in the upper half of the 32-bit
+    space; after ~7 million replays it starts over.  The launch that wraps it tells the library (word 2 of the mapped health page), and
+    the next entry point clears the exchange buffers so that no old tag can be met again.  IMP_OT_GRAPH_TAG0 (test hook) starts the
+    counter two launches short of the wrap: replays before, across and after it - and eager calls in between - stay bitwise equal."""
+    import os
+    cfg = eval_config(n_layers=3)
+    sd = synthetic.make_state_dict(cfg, 'DGNNS', seed=2)
+    os.environ['IMP_OT_GRAPH_TAG0'] = hex(0xFFFFF000 - 2 * (3 * 20 + 4) - 8)
+    try:
+        m = make_hip_model('DGNNS', cfg, sd)
+        ctx = m._ensure_ctx()
+    finally:
+        del os.environ['IMP_OT_GRAPH_TAG0']
+    pair = synthetic.make_correlated_pair(300, 280, seed=9, batch=2)
+    d = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+    args = (d['keypoints0'], d['scores0'], d['descriptors0'], d['keypoints1'], d['scores1'], d['descriptors1'],
+            640., 480., 1.0, 20, True, 0.2)
+    eager = ctx.match_pair(*args, want_side1=True)
+    out = {k: torch.zeros_like(v) for k, v in eager.items()}
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ctx.match_pair(*args, out=out)
+    assert ctx.tag_wraps() == 0
+    for i in range(8):
+        for v in out.values():
+            v.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for k in eager:
+            assert torch.equal(out[k], eager[k]), (i, k)
+        if i % 3 == 2:
+            again = ctx.match_pair(*args, want_side1=True)              # an entry point: notices the wrap, clears the buffers
+            torch.cuda.synchronize()
+            for k in eager:
+                assert torch.equal(again[k], eager[k]), (i, k)
+    assert ctx.resident_health() == (0, 0)
+    assert ctx.tag_wraps() == 1, ctx.tag_wraps()
+
+
 WF_FIXTURES = ['gm_l3_alliters_b2', 'gm_l3_bigmean', 'gm_l9_t100_ragged', 'dgnns_l5_alliters', 'adagmn_masked_l9']
 
 

@@ -115,6 +115,39 @@ def test_five_point_header_of_the_gpu_kernel_equals_the_twin(tmp_path):
             assert np.abs(a - b).max() < 1e-7
 
 
+def test_five_point_root_finder_against_lapack_on_random_samples(tmp_path):
+    """round 4: the header finds the real eigenvalues of the action matrix as the real roots of its characteristic polynomial
+    (derivative cascade + a Newton correction on the Hessenberg matrix), the twin asks LAPACK for all eigenvalues.  600 minimal samples
+    drawn from scenes with outliers and noise (the samples RANSAC really meets: most are not all-inlier): the same number of real
+    solutions for every sample, each solution within 5e-6 (the shifted-QR iteration of rounds 2-3 had the same worst case, 6e-7, on
+    this set: what is left is the conditioning of the sample, not the solver)"""
+    import os, shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which('g++') is None:
+        pytest.skip('no g++')
+    exe = str(tmp_path / 'fivept_host')
+    subprocess.run(['g++', '-O2', '-std=c++17', os.path.join(root, 'tools', 'probe', 'fivept_host.cpp'), '-o', exe], check=True)
+    g = np.random.default_rng(5)
+    scenes, lines = [], []
+    for s in range(600):
+        k0, k1, K, *_ = po.synthetic_scene(40, outliers=0.4 if s % 3 else 0.0, noise=[0.0, 0.3, 1.0][s % 3], seed=1000 + s)
+        ids = g.choice(40, 5, replace=False)
+        x0, x1 = po.normalise(k0[ids], K), po.normalise(k1[ids], K)
+        scenes.append((x0, x1))
+        lines += ['%.17g %.17g %.17g %.17g' % (a[0], a[1], b[0], b[1]) for a, b in zip(x0, x1)]
+    out = subprocess.run([exe], input='\n'.join(lines) + '\n', capture_output=True, text=True, check=True).stdout.split('\n')
+    pos, total, worst = 0, 0, 0.0
+    for x0, x1 in scenes:
+        n = int(out[pos]); pos += 1
+        got = [np.array(out[pos + k].split(), dtype=float).reshape(3, 3) for k in range(n)]; pos += n
+        ref = po.five_point(x0, x1)
+        assert len(ref) == n
+        total += n
+        for a, b in zip(got, ref):
+            worst = max(worst, np.abs(a - b).max())
+    assert total > 2000 and worst < 5e-6, (total, worst)
+
+
 @pytest.mark.parametrize('sampler,scoring', [('5pt', 'magsac'), ('5pt', 'count'), ('8pt', 'magsac'), ('8pt', 'count')])
 @pytest.mark.parametrize('seed,outliers', [(0, 0.2), (1, 0.3), (2, 0.35)])
 def test_ransac_twin_recovers_a_known_pose(seed, outliers, scoring, sampler):
