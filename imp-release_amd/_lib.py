@@ -26,7 +26,7 @@ SYMBOLS = [
     'imp_last_error', 'imp_version', 'imp_create', 'imp_destroy', 'imp_load_tensor', 'imp_finalize_weights',
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
-    'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_pool_select_pair', 'imp_masked_commit', 'imp_gather_rows', 'imp_match_pair', 'imp_set_counts', 'imp_match_tail', 'imp_loop_lockstep', 'imp_op_linear', 'imp_op_layer_gemm', 'imp_op_fused_mlp',
+    'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_pool_select_pair', 'imp_masked_commit', 'imp_gather_rows', 'imp_match_pair', 'imp_set_counts', 'imp_match_tail', 'imp_match_tail_scores', 'imp_pool_pair', 'imp_loop_lockstep', 'imp_op_linear', 'imp_op_layer_gemm', 'imp_op_fused_mlp',
     'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_range_events', 'imp_tag_wraps', 'imp_time_layer_gemm', 'imp_estimate_pose',
     'imp_sp_create', 'imp_sp_destroy', 'imp_sp_set_weight', 'imp_sp_finalize', 'imp_sp_detect', 'imp_sp_describe', 'imp_sp_dense', 'imp_sp_op_conv',
 ]
@@ -119,6 +119,8 @@ def lib():
     L.imp_match_pair.argtypes = [P, I, I, I, P, P, P, P, P, P, F, F, F, I, I, F, P, P, P, P, P, P]
     L.imp_set_counts.argtypes = [P, I, P, P]
     L.imp_match_tail.argtypes = [P, I, I, I, I, P, P, F, I, I, F, P, P, P, P, P]
+    L.imp_match_tail_scores.argtypes = [P, I, I, I, I, P, P, F, I, I, F, P, P, P, P, P, P]
+    L.imp_pool_pair.argtypes = [P, I, I, I, I, P, F, F, I, P, P, P, P]
     L.imp_loop_lockstep.argtypes = [P, I, P, P, I, I, P, P, P, P, P, P, F, I, I, C.c_uint, F, I, C.c_double, C.c_double, I, I, C.c_uint, I, P, P]
     L.imp_op_linear.argtypes = [P, I, I, I, P, P, P, P, P]
     L.imp_op_layer_gemm.argtypes = [P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, P, I, P]
@@ -390,11 +392,16 @@ class Context:
                                              N(mask1_row if update else None), _stream(self.device)))
         return ng0, ng1
 
-    def gather_rows(self, x, ids):
+    def gather_rows(self, x, ids, out=None):
+        """x [B, n_in, dim], ids [n_out] -> [B, n_out, dim]; ``out``: a contiguous float32 tensor whose first B * n_out * dim elements
+        receive the rows (a pair's slot of a padded batch) instead of a new tensor"""
         x = _f32(x, 'x')
         ids = ids.to(torch.int64).contiguous()
         B, n_in, dim = x.shape
-        out = torch.empty(B, ids.numel(), dim, device=x.device, dtype=torch.float32)
+        if out is None:
+            out = torch.empty(B, ids.numel(), dim, device=x.device, dtype=torch.float32)
+        elif out.dtype != torch.float32 or not out.is_contiguous() or out.numel() < B * ids.numel() * dim:
+            raise ValueError('gather_rows: out must be a contiguous float32 tensor with room for the gathered rows')
         self._check(self.L.imp_gather_rows(self.handle, B, n_in, ids.numel(), dim, _ptr(x), _ptr(ids), _ptr(out),
                                            _stream(self.device)))
         return out
@@ -432,9 +439,10 @@ class Context:
             raise ValueError('set_counts: one count per pair and image')
         self._check(self.L.imp_set_counts(self.handle, len(n0), a0, a1))
 
-    def match_tail(self, layer_id, desc0, desc1, bin_score, iterations, with_sinkhorn, p, want_side1=False):
+    def match_tail(self, layer_id, desc0, desc1, bin_score, iterations, with_sinkhorn, p, want_side1=False, want_scores=False):
         """final projection of iteration `layer_id` -> distance -> Sinkhorn -> mutual matches without a score tensor
-        (include/imp_hip.h imp_match_tail); obeys set_counts"""
+        (include/imp_hip.h imp_match_tail); obeys set_counts.  ``want_scores``: additionally ``out['scores']``, [B, (n0 + 1) * (n1 + 1)]
+        - slot b starts with pair b's DENSE score tensor of its own shape (imp_match_tail_scores; what the pool consumes)"""
         desc0, desc1 = _f32(desc0, 'desc0'), _f32(desc1, 'desc1')
         B, n0, n1 = desc0.shape[0], desc0.shape[1], desc1.shape[1]
         dev = desc0.device
@@ -442,9 +450,32 @@ class Context:
         if want_side1:
             out['indices1'] = torch.empty(B, n1, device=dev, dtype=torch.int64)
             out['mscores1'] = torch.empty(B, n1, device=dev, dtype=torch.float32)
-        self._check(self.L.imp_match_tail(self.handle, int(layer_id), B, n0, n1, _ptr(desc0), _ptr(desc1), float(bin_score), int(iterations),
-                                          1 if with_sinkhorn else 0, float(p), _ptr(out['indices0']), _ptr(out['mscores0']),
-                                          _ptr(out.get('indices1')), _ptr(out.get('mscores1')), _stream(self.device)))
+        if want_scores:
+            out['scores'] = torch.empty(B, (n0 + 1) * (n1 + 1), device=dev, dtype=torch.float32)
+        self._check(self.L.imp_match_tail_scores(self.handle, int(layer_id), B, n0, n1, _ptr(desc0), _ptr(desc1), float(bin_score), int(iterations),
+                                                 1 if with_sinkhorn else 0, float(p), _ptr(out['indices0']), _ptr(out['mscores0']),
+                                                 _ptr(out.get('indices1')), _ptr(out.get('mscores1')), _ptr(out.get('scores')), _stream(self.device)))
+        return out
+
+    def pool_pairs(self, jobs, batch, n0, n1, scores, uncertainty_ratio, n_min_tokens):
+        """AdaGMN.pool of several pairs of the batch whose attention is cached (include/imp_hip.h imp_pool_pair), ONE host sync for all:
+        ``jobs`` = [(pair, (m0, m1), mscore_th)]; ``scores`` = the [batch, (n0 + 1) * (n1 + 1)] tensor of match_tail(want_scores=True).
+        -> {pair: (ids0 | None, ids1 | None, host ids0 | None, host ids1 | None)} like ``pool(..., return_host=True)``"""
+        if not jobs:
+            return {}
+        dev = scores.device
+        w = n0 + n1 + 2
+        buf = torch.empty(len(jobs), w, device=dev, dtype=torch.int64)          # per pair: ids0 | ids1 | 4 int32 counts
+        for k, (b, (m0, m1), th) in enumerate(jobs):
+            row = buf[k]
+            self._check(self.L.imp_pool_pair(self.handle, int(b), int(batch), int(n0), int(n1), _ptr(scores[b]), float(th), float(uncertainty_ratio),
+                                             int(n_min_tokens), _ptr(row[:n0]), _ptr(row[n0:n0 + n1]), _ptr(row[n0 + n1:]), _stream(self.device)))
+        host = buf.cpu()
+        out = {}
+        for k, (b, _, _) in enumerate(jobs):
+            c = host[k, n0 + n1:].view(torch.int32).tolist()
+            out[b] = (buf[k, :c[0]] if c[0] >= 0 else None, buf[k, n0:n0 + c[2]] if c[2] >= 0 else None,
+                      host[k, :c[0]].numpy() if c[0] >= 0 else None, host[k, n0:n0 + c[2]].numpy() if c[2] >= 0 else None)
         return out
 
     def loop_lockstep(self, n0, n1, nk0, sc0, de0, nk1, sc1, de1, pts0, pts1, K0, K1, bin_score, sinkhorn_iterations, n_iterations, valid_its,

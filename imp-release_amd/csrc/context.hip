@@ -1109,8 +1109,8 @@ int run_score(imp_ctx* c, int batch, int n0, int n1, const float* dist, float bi
     ot_layout(c, n0, n1, &o);
     const int dual = with_sinkhorn ? 0 : 1;
     if (max_done) *max_done = false;
-    if (c->rc.on && (dual || scores || !max_done))
-        return fail(IMP_E_ARG, "ragged batches (imp_set_counts) take the fused score + matches path only: Sinkhorn scorer, no score tensor (imp_match_pair / imp_match_tail)");
+    if (c->rc.on && (dual || !max_done))
+        return fail(IMP_E_ARG, "ragged batches (imp_set_counts) take the fused score + matches path only: Sinkhorn scorer (imp_match_pair / imp_match_tail)");
     if (!dual && (scores || max_done)) {
         const int rr = run_score_resident(c, batch, n0, n1, dist, bin, iterations, scores, max_done != nullptr, true, st);
         if (rr < 0) return rr;
@@ -1634,16 +1634,11 @@ int imp_compute_matches(imp_ctx* c, int batch, int n0, int n1, const float* scor
     return IMP_OK;
 }
 
-int imp_pool(imp_ctx* c, int n0, int n1, const float* scores, float mscore_th, float uncertainty_ratio, int n_min_tokens,
-             int64_t* ids0, int64_t* ids1, int32_t* counts, void* stream) {
-    int rc = check_ready(c, 1, n0, n1);
-    if (rc) return rc;
-    if (!scores || !ids0 || !ids1 || !counts) return fail(IMP_E_ARG, "imp_pool: null argument");
-    if (c->rc.on) return fail(IMP_E_ARG, "imp_pool: not with per-pair keypoint counts (imp_set_counts)");
-    for (int k = 0; k < 2; ++k)
-        if (!c->cache[k].valid || c->cache[k].n[0] != n0 || c->cache[k].n[1] != n1)
-            return fail(IMP_E_STATE, "imp_pool: cached self/cross attention does not match (n0, n1)");
-    hipStream_t st = S(stream);
+// AdaGMN.pool for pair b of the cached batch: the pair's own sizes m[0], m[1] inside a batch whose tensors are padded to pad[0], pad[1]
+// (b = 0 and m == pad: the single pair imp_pool has always served).  Every kernel runs on the pair's slice with the pair's sizes, so
+// the result is the one of the pair pooled alone.
+static int pool_pair_impl(imp_ctx* c, int b, const int m[2], const int pad[2], const float* scores, float thr, int n_min_tokens,
+                          int64_t* ids0, int64_t* ids1, int32_t* counts, hipStream_t st) {
     const int D = c->D;
     // attention mass received per key: a00, a11 (self) and a01 (img1 queries -> img0 keys), a10 (nets/adgm.py:557-565)
     for (int kind = 0; kind < 2; ++kind) {
@@ -1655,26 +1650,57 @@ int imp_pool(imp_ctx* c, int n0, int n1, const float* scores, float mscore_th, f
             const int qside = kind == 0 ? keyside : 1 - keyside;
             ColsumSide& g = p.side[keyside];
             hipError_t kerr;
-            g.q = c->qkv[kind][qside]; g.k = cached_k_fp32(c, kind, keyside, &ldk, st, &kerr); g.lse = c->lse[kind][qside];
+            const float* kf = cached_k_fp32(c, kind, keyside, &ldk, st, &kerr);       // (the whole batch: one small launch per call)
             HIP_TRY(kerr);
+            g.q = c->qkv[kind][qside] + (size_t)b * pad[qside] * 3 * D;
+            g.k = kf + (size_t)b * pad[keyside] * ldk;
+            g.lse = c->lse[kind][qside] + (size_t)b * IMP_NUM_HEADS * pad[qside];
+            g.lq = pad[qside];
             p.ldk = (int)ldk;
             g.out = c->colsum[kind * 2 + keyside];
-            g.kmask = c->cache[kind].masked[keyside] ? c->cmask[kind][keyside] : nullptr;   // masked keys received exactly 0
-            g.nq = kind == 0 ? (keyside ? n1 : n0) : (qside ? n1 : n0);
-            g.nk = keyside ? n1 : n0;
-            g.sq_b = (long)g.nq * 3 * D; g.sk_b = (long)g.nk * ldk;
+            g.kmask = c->cache[kind].masked[keyside] ? c->cmask[kind][keyside] + (size_t)b * pad[keyside] : nullptr;   // masked keys received exactly 0
+            g.nq = m[qside];
+            g.nk = m[keyside];
+            g.sq_b = 0; g.sk_b = 0;
         }
         HIP_TRY(launch_attn_colsum(p, 1, c->prec, st));
         for (int keyside = 0; keyside < 2; ++keyside)
-            HIP_TRY(launch_attn_mass_normalize(c->colsum[kind * 2 + keyside], keyside ? n1 : n0, c->amass[kind * 2 + keyside], st));
+            HIP_TRY(launch_attn_mass_normalize(c->colsum[kind * 2 + keyside], m[keyside], c->amass[kind * 2 + keyside], st));
     }
-    HIP_TRY(launch_score_mass(scores, n0, n1, c->mass[0], c->mass[1], c->colpart_v, st));
+    HIP_TRY(launch_score_mass(scores, m[0], m[1], c->mass[0], c->mass[1], c->colpart_v, st));
     PoolSide ps[2];
     // image 0: a_self = a00 (colsum[0]), a_cross = a01 (colsum[2]); image 1: a_self = a11 (colsum[1]), a_cross = a10 (colsum[3])
-    ps[0] = PoolSide{c->mass[0], c->amass[0], c->amass[2], ids0, n0, (n_min_tokens > 0 && n0 + 1 <= n_min_tokens) ? 1 : 0};
-    ps[1] = PoolSide{c->mass[1], c->amass[1], c->amass[3], ids1, n1, (n_min_tokens > 0 && n1 + 1 <= n_min_tokens) ? 1 : 0};
-    HIP_TRY(launch_pool_select(ps, 2, mscore_th * uncertainty_ratio, counts, st));
+    ps[0] = PoolSide{c->mass[0], c->amass[0], c->amass[2], ids0, m[0], (n_min_tokens > 0 && m[0] + 1 <= n_min_tokens) ? 1 : 0};
+    ps[1] = PoolSide{c->mass[1], c->amass[1], c->amass[3], ids1, m[1], (n_min_tokens > 0 && m[1] + 1 <= n_min_tokens) ? 1 : 0};
+    HIP_TRY(launch_pool_select(ps, 2, thr, counts, st));
     return IMP_OK;
+}
+
+int imp_pool(imp_ctx* c, int n0, int n1, const float* scores, float mscore_th, float uncertainty_ratio, int n_min_tokens,
+             int64_t* ids0, int64_t* ids1, int32_t* counts, void* stream) {
+    int rc = check_ready(c, 1, n0, n1);
+    if (rc) return rc;
+    if (!scores || !ids0 || !ids1 || !counts) return fail(IMP_E_ARG, "imp_pool: null argument");
+    if (c->rc.on) return fail(IMP_E_ARG, "imp_pool: not with per-pair keypoint counts (imp_set_counts): imp_pool_pair");
+    for (int k = 0; k < 2; ++k)
+        if (!c->cache[k].valid || c->cache[k].n[0] != n0 || c->cache[k].n[1] != n1)
+            return fail(IMP_E_STATE, "imp_pool: cached self/cross attention does not match (n0, n1)");
+    const int m[2] = {n0, n1};
+    return pool_pair_impl(c, 0, m, m, scores, mscore_th * uncertainty_ratio, n_min_tokens, ids0, ids1, counts, S(stream));
+}
+
+int imp_pool_pair(imp_ctx* c, int pair, int batch, int n0, int n1, const float* scores, float mscore_th, float uncertainty_ratio,
+                  int n_min_tokens, int64_t* ids0, int64_t* ids1, int32_t* counts, void* stream) {
+    int rc = check_ready(c, batch, n0, n1);
+    if (rc) return rc;
+    if (!scores || !ids0 || !ids1 || !counts || pair < 0 || pair >= batch) return fail(IMP_E_ARG, "imp_pool_pair: bad argument");
+    for (int k = 0; k < 2; ++k)
+        if (!c->cache[k].valid || c->cache[k].batch != batch || c->cache[k].n[0] != n0 || c->cache[k].n[1] != n1)
+            return fail(IMP_E_STATE, "imp_pool_pair: cached self/cross attention does not match (batch, n0, n1)");
+    const int pad[2] = {n0, n1};
+    const int m[2] = {c->rc.on ? c->rc.n[0][pair] : n0, c->rc.on ? c->rc.n[1][pair] : n1};
+    if (m[0] < 1 || m[1] < 1) return fail(IMP_E_ARG, "imp_pool_pair: the pair is retired (count 0)");
+    return pool_pair_impl(c, pair, m, pad, scores, mscore_th * uncertainty_ratio, n_min_tokens, ids0, ids1, counts, S(stream));
 }
 
 int imp_gather_rows(imp_ctx* c, int batch, int n_in, int n_out, int dim, const float* in, const int64_t* ids, float* out,
@@ -1735,16 +1761,24 @@ int imp_match_pair(imp_ctx* c, int batch, int n0, int n1, const float* kpts0, co
 int imp_match_tail(imp_ctx* c, int layer_id, int batch, int n0, int n1, const float* desc0, const float* desc1, float bin_score,
                    int sinkhorn_iterations, int with_sinkhorn, float p, int64_t* indices0, float* mscores0, int64_t* indices1,
                    float* mscores1, void* stream) {
+    return imp_match_tail_scores(c, layer_id, batch, n0, n1, desc0, desc1, bin_score, sinkhorn_iterations, with_sinkhorn, p, indices0, mscores0,
+                                 indices1, mscores1, nullptr, stream);
+}
+
+int imp_match_tail_scores(imp_ctx* c, int layer_id, int batch, int n0, int n1, const float* desc0, const float* desc1, float bin_score,
+                          int sinkhorn_iterations, int with_sinkhorn, float p, int64_t* indices0, float* mscores0, int64_t* indices1,
+                          float* mscores1, float* scores, void* stream) {
     int rc = check_ready(c, batch, n0, n1);
     if (rc) return rc;
     if (!desc0 || !desc1) return fail(IMP_E_ARG, "imp_match_tail: null descriptors");
+    if (scores && !with_sinkhorn) return fail(IMP_E_ARG, "imp_match_tail_scores: the score tensor comes with the Sinkhorn scorer only");
     hipStream_t st = S(stream);
     const int n[2] = {n0, n1};
     const float* de[2] = {desc0, desc1};
     if ((rc = run_distance(c, layer_id, batch, n, de, c->dist, st))) return rc;
     OtBuffers o;
     bool max_done = false;
-    if ((rc = run_score(c, batch, n0, n1, c->dist, bin_score, sinkhorn_iterations, with_sinkhorn, nullptr, &o, st, &max_done))) return rc;
+    if ((rc = run_score(c, batch, n0, n1, c->dist, bin_score, sinkhorn_iterations, with_sinkhorn, scores, &o, st, &max_done))) return rc;
     if (!max_done) HIP_TRY(launch_ot_maxima(batch, n0, n1, with_sinkhorn ? 0 : 1, o, c->max0, c->arg0, c->max1, c->arg1, st));
     HIP_TRY(launch_mutual_matches(batch, n0, n1, c->max0, c->arg0, c->max1, c->arg1, p, indices0, indices1, mscores0,
                                   mscores1, c->range_hostdev, st, &c->rc));

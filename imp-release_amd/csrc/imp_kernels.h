@@ -138,6 +138,7 @@ struct ColsumSide {
     const uint8_t* kmask;                                            // [b][nk] or null: masked keys receive 0
     long sq_b, sk_b;
     int nq, nk;
+    int lq;                                                          // stride between the heads of lse (0: nq) - a pair of a padded ragged batch
 };
 struct ColsumParams { ColsumSide side[2]; int nside, ldq, ldk, dh; };
 hipError_t launch_attn_colsum(const ColsumParams& p, int batch, int prec, hipStream_t stream);   // prec: GemmParams::prec

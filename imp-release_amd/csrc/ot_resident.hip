@@ -457,7 +457,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         if (p.scores) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            float* srow = p.scores + ((size_t)b * (n0 + 1) + r) * (n1 + 1);
+            float* srow = p.scores + (size_t)b * (ld0 + 1) * (ld1 + 1) + (size_t)r * (n1 + 1);
             for (int j = lane; j < n1; j += 64) srow[j] = rowbuf[j];       // lane-linear dword stores
             if (lane == 0) srow[n1] = (Pd[k] * u[k]) * vd;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         }
     }
     if (p.scores && g == 0) {                          // dustbin row of the score tensor
-        float* srow = p.scores + ((size_t)b * (n0 + 1) + n0) * (n1 + 1);
+        float* srow = p.scores + (size_t)b * (ld0 + 1) * (ld1 + 1) + (size_t)n0 * (n1 + 1);
         for (int j = tid; j < n1; j += 512) srow[j] = (c0 * u_last) * vs[j];
         if (tid == 0) srow[n1] = (c0 * u_last) * vd;
     }
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         // tensor - imp_compute_matches after imp_compute_score - skipped the NaN and returned plausible matches from garbage)
         if (p.scores)
             for (int r = g * ROWS + wave; r < rend; r += 8) {
-                float* srow = p.scores + ((size_t)b * (n0 + 1) + r) * (n1 + 1);
+                float* srow = p.scores + (size_t)b * (ld0 + 1) * (ld1 + 1) + (size_t)r * (n1 + 1);
                 for (int j = lane; j <= n1; j += 64) srow[j] = nanv;
             }
         if (want_max) {

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void attn_colsum_kernel(const ColsumParams 
     if (k0 >= nk) return;
     const float* Qg = S.q + b * S.sq_b + h * DH;
     const float* Kg = S.k + b * S.sk_b + h * DH;
-    const float* Lg = S.lse + ((long)b * IMP_NUM_HEADS + h) * nq;
+    const float* Lg = S.lse + ((long)b * IMP_NUM_HEADS + h) * (S.lq ? S.lq : nq);
 
     float kreg[QS];
     {
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void attn_colsum_f16x3_kernel(const ColsumP
     if (k0 >= nk) return;
     const float* Qg = S.q + b * S.sq_b + h * DH;
     const float* Kg = S.k + b * S.sk_b + h * DH;
-    const float* Lg = S.lse + ((long)b * IMP_NUM_HEADS + h) * nq;
+    const float* Lg = S.lse + ((long)b * IMP_NUM_HEADS + h) * (S.lq ? S.lq : nq);
 
     f16x8 kh[KS], kl[KS];                       // lane (key l31, half) holds d = 16 s + 8 half .. + 7 of k-step s
     {

@@ -113,14 +113,20 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
                       match_ratio: float = 0.1, min_kpts: int = 25, error_th: float = 1.0,
                       stop_criteria: Optional[dict] = None, estimate_pose=None, group=None, workers: int = 1,
                       replicas: Optional[Sequence] = None, lockstep: int = 1, schedule: str = 'block',
-                      pair_cost: Optional[Callable[[int], float]] = None) -> np.ndarray:
+                      pair_cost: Optional[Callable[[int], float]] = None, with_uncertainty: Optional[bool] = None) -> np.ndarray:
     """-> [n_pairs, len(SUMMARY_COLUMNS)] summary table, identical on every rank.  ``pair_provider(pair_id)`` returns the reference's
     per-pair ``data`` dict (GPU tensors + pts*_cpu / K*), exactly what eval/matching.py consumes.
     ``workers`` > 1: that many pairs in flight on this rank (see module docstring); ``replicas`` may pass pre-built
     model instances (else they are created with :func:`replicate`).
-    ``lockstep`` > 1 (IMP loop only, round 4): that many pairs advance TOGETHER through ``matching.matching_iterative_lockstep`` - one
-    ragged batch, one kernel launch per layer for all of them, per-pair early exit (at most 4 pairs of ~2048 keypoints, 8 of <= 1024:
-    the batch must fit the chip-resident Sinkhorn); with ``workers`` > 1 several such groups are in flight.  Rows do not depend on it.
+    ``lockstep`` > 1 (round 4): that many pairs advance TOGETHER through ``matching.matching_iterative_lockstep`` (IMP) /
+    ``matching.matching_iterative_uncertainty_lockstep`` (EIMP: per-pair pooling inside the ragged batch) - one ragged batch, one kernel
+    launch per layer for all of them, per-pair early exit (at most 4 pairs of ~2048 keypoints, 8 of <= 1024: the batch must fit the
+    chip-resident Sinkhorn); with ``workers`` > 1 several such groups are in flight.  A pair's row is the row of the pair run alone up to
+    fp32 summation order: a batch takes other kernel decompositions than a single pair (scores agree to ~2e-6), and where the EIMP pool
+    meets a keypoint exactly on a threshold / lower-median boundary the kept set can differ by that keypoint (11 of 96 pairs of the
+    harder synthetic set, report unchanged to 0.03 AUC points: tools/probe/eimp_lockstep_diff.py; the IMP loop has no such decision).
+    ``with_uncertainty`` (EIMP): pool threshold 0.2 x the pose estimate's inlier ratio (eval/matching.py:243-247); default = ``eimp``,
+    as eval/eval_imp.py:95-105 passes its one ``use_uncertainty`` switch to both.
     ``schedule``: how pairs map to ranks - 'block' (contiguous blocks, :func:`imp_release_amd.dist.shard_range`) or 'lpt' (longest
     processing time first over ``pair_cost(pid)``: see :func:`imp_release_amd.dist.lpt_assignment`)."""
     stop_criteria = {'pose': 1.5} if stop_criteria is None else stop_criteria
@@ -146,7 +152,9 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
     s = 0
     rows = _Rows()
     loop = matching.matching_iterative_uncertainty if eimp else matching.matching_iterative
-    lockstep = 1 if eimp else max(1, int(lockstep))
+    unc = dict(with_uncertainty=bool(eimp if with_uncertainty is None else with_uncertainty)) if eimp else {}
+    lockstep = max(1, int(lockstep))
+    group_loop = matching.matching_iterative_uncertainty_lockstep if eimp else matching.matching_iterative_lockstep
     # units of work: single pairs, or groups of `lockstep` pairs that advance together (pairs of similar cost side by side under 'lpt':
     # the list is ascending in pair id, the provider's order)
     units = [mine[a:a + lockstep] for a in range(0, len(mine), lockstep)]
@@ -154,17 +162,17 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
     def run_unit(m, pids):
         if len(pids) == 1 and lockstep == 1:
             data = pair_provider(pids[0])
-            out = loop(data, m, nI, match_ratio, min_kpts, error_th, stop_criteria, estimate_pose=estimate_pose)
+            out = loop(data, m, nI, match_ratio, min_kpts, error_th, stop_criteria, estimate_pose=estimate_pose, **unc)
             rows[pids[0] - s] = summarize(out, eimp, data, estimate_pose, error_th)
             return
         datas = [pair_provider(pid) for pid in pids]
         from . import _lib
         try:
-            outs = matching.matching_iterative_lockstep(datas, m, nI, match_ratio, min_kpts, error_th, stop_criteria, estimate_pose=estimate_pose)
+            outs = group_loop(datas, m, nI, match_ratio, min_kpts, error_th, stop_criteria, estimate_pose=estimate_pose, **unc)
         except _lib.ResidentSinkhornTimeout:          # a voided launch inside the pipelined group: once more, on the protocol the context stepped down to
-            outs = matching.matching_iterative_lockstep(datas, m, nI, match_ratio, min_kpts, error_th, stop_criteria, estimate_pose=estimate_pose)
+            outs = group_loop(datas, m, nI, match_ratio, min_kpts, error_th, stop_criteria, estimate_pose=estimate_pose, **unc)
         for pid, data, out in zip(pids, datas, outs):
-            rows[pid - s] = summarize(out, False, data, estimate_pose, error_th)
+            rows[pid - s] = summarize(out, eimp, data, estimate_pose, error_th)
 
     workers = max(1, min(int(workers), len(units)))
     if workers == 1:

@@ -431,3 +431,185 @@ def _lockstep_group(datas, model, nI, match_ratio, min_kpts, error_th, stop_crit
             i_cpu, m_cpu = last_scored[b]
             results[b] = (np.where(m_cpu > 0.2, i_cpu, -1), m_cpu, None, None, nI)
     return results
+
+
+def matching_iterative_uncertainty_lockstep(datas, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method=None,
+                                            with_uncertainty=False, estimate_pose=None, pose_threads=4, traces=None):
+    """:func:`_lockstep_group_uncertainty` on all of ``datas``; a group the chip-resident Sinkhorn cannot hold as one ragged batch is
+    split in halves (a single pair always fits)"""
+    try:
+        return _lockstep_group_uncertainty(datas, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method, with_uncertainty,
+                                           estimate_pose, pose_threads, traces)
+    except _lib.ImpError as e:
+        if 'chip-resident' not in str(e) or len(datas) < 2:
+            raise
+    mid = len(datas) // 2
+    tr = (None, None) if traces is None else (traces[:mid], traces[mid:])
+    a = (datas[:mid], model, nI, match_ratio, min_kpts, error_th, stop_criteria, method, with_uncertainty, estimate_pose, pose_threads)
+    b = (datas[mid:],) + a[1:]
+    return matching_iterative_uncertainty_lockstep(*a, tr[0]) + matching_iterative_uncertainty_lockstep(*b, tr[1])
+
+
+def _lockstep_group_uncertainty(datas, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method=None, with_uncertainty=False,
+                                estimate_pose=None, pose_threads=4, traces=None):
+    """eval/matching.py:126-276 (the EIMP loop: adaptive pooling between the iterations) on SEVERAL pairs at once ->
+    [(pts0, pts1, norm_kpts0, norm_kpts1, indices0, mscores0, R, t, n_iterations)] - per pair exactly what
+    :func:`matching_iterative_uncertainty` returns for it.
+
+    The pairs form one ragged batch (``imp_set_counts``) whose per-pair counts SHRINK: after every scored iteration each live pair is
+    pooled on its own slice of the batch (``imp_pool_pair``: cached attention + the pair's dense score tensor from
+    ``imp_match_tail_scores``; all pairs' id lists come back in one copy), and the next iteration starts by gathering every pair's kept
+    rows into a batch padded to the new largest pair.  The pool threshold of a pair depends on the inlier ratio of its pose estimate
+    (eval/matching.py:243-247), so - unlike the IMP loop - the estimates of an iteration cannot be deferred: they run side by side on
+    the worker threads and the group waits for the slowest."""
+    B = len(datas)
+    if B == 0:
+        return []
+    if match_ratio > 0.2:
+        raise ValueError('the lock-step loop derives the final p = 0.2 matches from the scored ones: match_ratio must be <= 0.2')
+    if not model.with_sinkhorn:
+        raise ValueError('the lock-step EIMP loop needs the Sinkhorn scorer (the pool consumes its score tensor)')
+    ctx = model._ensure_ctx(check=True)
+    dev = model._device()
+    c0 = [int(d['keypoints0'].shape[1]) for d in datas]
+    c1 = [int(d['keypoints1'].shape[1]) for d in datas]
+    N0, N1 = max(c0), max(c1)
+    D = int(datas[0]['descriptors0'].shape[-1])
+    nk = [_normalize(model, d) for d in datas]                                  # (image-size normalisation per pair: eval/matching.py:131-137)
+    nk0 = torch.zeros(B, N0, 2, device=dev); nk1 = torch.zeros(B, N1, 2, device=dev)
+    sc0 = torch.zeros(B, N0, device=dev); sc1 = torch.zeros(B, N1, device=dev)
+    de0 = torch.zeros(B, N0, D, device=dev); de1 = torch.zeros(B, N1, D, device=dev)
+    for b, d in enumerate(datas):
+        nk0[b, :c0[b]] = nk[b][0][0]; nk1[b, :c1[b]] = nk[b][1][0]
+        sc0[b, :c0[b]] = d['scores0'][0]; sc1[b, :c1[b]] = d['scores1'][0]
+        de0[b, :c0[b]] = d['descriptors0'][0]; de1[b, :c1[b]] = d['descriptors1'][0]
+    pts0 = [d['pts0_cpu'] for d in datas]; pts1 = [d['pts1_cpu'] for d in datas]
+    kept0 = [None] * B; kept1 = [None] * B                                       # ids of the surviving keypoints in the pair's original numbering (None: all)
+    sel = [None] * B                                                             # pool result waiting for the next iteration: (ids0, ids1, host0, host1)
+    live = [True] * B
+    results = [None] * B
+    last_R = [None] * B; last_t = [None] * B
+    last_scored = [None] * B
+    pose_pool = _pose_workers(max(pose_threads, B), dev) if estimate_pose is not None and pose_threads > 1 and B > 1 else None
+
+    def norm_of(b):
+        n0, n1 = nk[b]
+        a = n0[0].cpu().numpy(); c = n1[0].cpu().numpy()
+        return (a if kept0[b] is None else a[kept0[b]]), (c if kept1[b] is None else c[kept1[b]])
+
+    try:
+        ctx.set_counts(c0, c1)
+        desc0, desc1 = ctx.encode_keypoints(nk0, sc0, nk1, sc1, de0, de1)
+        for it in range(nI):
+            if any(s is not None for s in sel):                                  # eval/matching.py:166-174, every pair on its own rows
+                m0 = [0 if not live[b] else (c0[b] if sel[b] is None or sel[b][0] is None else int(sel[b][0].numel())) for b in range(B)]
+                m1 = [0 if not live[b] else (c1[b] if sel[b] is None or sel[b][1] is None else int(sel[b][1].numel())) for b in range(B)]
+                M0, M1 = max(max(m0), 1), max(max(m1), 1)
+                nd0 = torch.zeros(B, M0, D, device=dev); nd1 = torch.zeros(B, M1, D, device=dev)
+                for b in range(B):
+                    if not live[b]:
+                        continue
+                    s = sel[b] or (None, None, None, None)
+                    for side, (old, new, ids, hid, cnt) in enumerate(((desc0, nd0, s[0], s[2], c0[b]), (desc1, nd1, s[1], s[3], c1[b]))):
+                        if ids is None:
+                            new[b, :cnt] = old[b, :cnt]
+                            continue
+                        ctx.gather_rows(old[b:b + 1], ids, out=new[b])
+                        if side == 0:
+                            pts0[b] = pts0[b][hid]; kept0[b] = hid if kept0[b] is None else kept0[b][hid]
+                        else:
+                            pts1[b] = pts1[b][hid]; kept1[b] = hid if kept1[b] is None else kept1[b][hid]
+                    sel[b] = None
+                desc0, desc1, c0, c1, N0, N1 = nd0, nd1, m0, m1, M0, M1
+                ctx.set_counts(c0, c1)
+            for li in (2 * it, 2 * it + 1):
+                desc0, desc1 = ctx.forward_layer(li, desc0, desc1, inplace=True)
+                model._note_layer(li, B, N0, N1)
+            if it not in VALID_ITS:
+                continue
+            for attempt in range(3):
+                try:
+                    r = ctx.match_tail(it, desc0, desc1, model._bin(None), model.sinkhorn_iterations, True, match_ratio, want_scores=True)
+                    packed = pack_matches(r['indices0'], r['mscores0']).cpu()     # the one sync of the scores, all pairs
+                except _lib.ResidentSinkhornTimeout:
+                    continue
+                if ctx.resident_health(raise_on_timeout=False) is not False:
+                    break
+            else:
+                raise _lib.ResidentSinkhornTimeout(_lib.IMP_E_RESIDENT, 'the Sinkhorn score stayed void on every protocol')
+            buf = packed.numpy()
+            idx_h = np.ascontiguousarray(buf[:, :N0 * 8]).view(np.int64)
+            ms_h = np.ascontiguousarray(buf[:, N0 * 8:]).view(np.float32)
+            work = []                                                              # (pair, matches, indices, scores, future)
+            for b in range(B):
+                if not live[b]:
+                    continue
+                i_cpu, m_cpu = idx_h[b, :c0[b]].copy(), ms_h[b, :c0[b]].copy()
+                last_scored[b] = (i_cpu, m_cpu)
+                if traces is not None:
+                    traces[b].append({'it': it, 'n0': c0[b], 'n1': c1[b], 'indices0': i_cpu.copy(), 'mscores0': m_cpu.copy(),
+                                      'pts0': pts0[b].copy(), 'pts1': pts1[b].copy()})
+                matched0 = np.nonzero(i_cpu > -1)[0]
+                if matched0.shape[0] < min_kpts:                                   # eval/matching.py:191-194
+                    last_R[b] = last_t[b] = None
+                    continue
+                if matched0.shape[0] == 0:
+                    continue
+                pm = np.stack([matched0, i_cpu[matched0]], axis=1)
+                kw = dict(kpts0=pts0[b][pm[:, 0]], kpts1=pts1[b][pm[:, 1]], K0=datas[b].get('K0'), K1=datas[b].get('K1'),
+                          norm_thresh=error_th, method=method)
+                if estimate_pose is None:
+                    fut = None
+                elif pose_pool is not None:
+                    fut = pose_pool.submit(estimate_pose, kw)
+                else:
+                    fut = _Done(estimate_pose(**kw))
+                work.append((b, pm, i_cpu, m_cpu, fut))
+            jobs = []
+            retired = False
+            for b, pm, i_cpu, m_cpu, fut in work:
+                ret = fut.result() if fut is not None else None
+                if ret is not None:
+                    E, R, t, inl = ret
+                    inlier_ratio = np.sum(inl) / pm.shape[0]
+                else:
+                    R = t = None
+                    inl = np.zeros(pm.shape[0], dtype=bool)
+                    inlier_ratio = 0
+                if it >= 1:
+                    diff_R = angle_error_mat(last_R[b], R) if last_R[b] is not None and R is not None else np.inf
+                    diff_t = angle_error_vec(last_t[b], t) if last_t[b] is not None and t is not None else np.inf
+                else:
+                    diff_R, diff_t = np.inf, np.inf
+                last_R[b], last_t[b] = R, t
+                if 'pose' in stop_criteria.keys() and np.max([diff_R, diff_t]) <= stop_criteria['pose']:      # eval/matching.py:259-269
+                    o = np.zeros_like(i_cpu) - 1
+                    o[pm[inl, 0]] = pm[inl, 1]
+                    na, nb = norm_of(b)
+                    results[b] = (pts0[b], pts1[b], na, nb, o, m_cpu, R, t, it + 1)
+                    live[b] = False
+                    retired = True
+                    continue
+                # (the reference pools before it takes the exit test; a pair that exits never uses the result)
+                th = 0.2 * inlier_ratio if (with_uncertainty and inlier_ratio != 0) else 0.2                  # eval/matching.py:243-247
+                jobs.append((b, (c0[b], c1[b]), th))
+            if not any(live):
+                break
+            if jobs and it + 1 < nI:
+                pooled = ctx.pool_pairs(jobs, B, N0, N1, r["scores"], 1.0, 256)          # (n_min_tokens: the default of AdaGMN.pool, as the reference loop calls it)
+                for b, v in pooled.items():
+                    if v[0] is not None or v[1] is not None:
+                        sel[b] = v
+            if retired:
+                for b in range(B):
+                    if not live[b]:
+                        c0[b] = c1[b] = 0
+                ctx.set_counts(c0, c1)
+    finally:
+        ctx.set_counts()
+    for b in range(B):
+        if results[b] is None:                                                     # never exited: compute_matches(pred_score, 0.2), eval/matching.py:271
+            i_cpu, m_cpu = last_scored[b]
+            na, nb = norm_of(b)
+            results[b] = (pts0[b], pts1[b], na, nb, np.where(m_cpu > 0.2, i_cpu, -1), m_cpu, None, None, nI)
+    return results

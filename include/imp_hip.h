@@ -249,6 +249,18 @@ int imp_set_counts(imp_ctx* ctx, int batch, const int32_t* n0, const int32_t* n1
 int imp_match_tail(imp_ctx* ctx, int layer_id, int batch, int n0, int n1, const float* desc0, const float* desc1, float bin_score,
                    int sinkhorn_iterations, int with_sinkhorn, float p, int64_t* indices0, float* mscores0, int64_t* indices1,
                    float* mscores1, void* stream);
+/* the same with the score tensor of the Sinkhorn scorer as a by-product (what AdaGMN.pool consumes, nets/adgm.py:552-605): scores holds
+ * batch slots of (n0 + 1) * (n1 + 1) floats (n0, n1 = the padded sizes); pair b's tensor lies at the start of slot b, DENSE with the pair's
+ * own shape [m0 + 1][m1 + 1] (m = its counts, imp_set_counts; uniform batches: m = n) - the tensor the pair run alone returns from
+ * imp_compute_score.  scores = NULL: imp_match_tail. */
+int imp_match_tail_scores(imp_ctx* ctx, int layer_id, int batch, int n0, int n1, const float* desc0, const float* desc1, float bin_score,
+                          int sinkhorn_iterations, int with_sinkhorn, float p, int64_t* indices0, float* mscores0, int64_t* indices1,
+                          float* mscores1, float* scores, void* stream);
+/* imp_pool for pair `pair` of the batch whose attention is cached (batch, n0, n1 = its padded shape; the pair's own sizes from
+ * imp_set_counts): scores = that pair's dense score tensor (slot `pair` of imp_match_tail_scores); ids0 / ids1 / counts as imp_pool.  The
+ * result equals imp_pool of the pair run alone (round 4: EIMP pairs of different sizes advance in lock step, eval/matching.py:126-276). */
+int imp_pool_pair(imp_ctx* ctx, int pair, int batch, int n0, int n1, const float* scores, float mscore_th, float uncertainty_ratio,
+                  int n_min_tokens, int64_t* ids0, int64_t* ids1, int32_t* counts, void* stream);
 /* The lock-step IMP loop (eval/matching.py:16-123 `matching_iterative` on B pairs of different sizes at once) driven natively: encoder, per iteration
  * the two layers (chained projections), at the iterations of `valid_mask` (bit it: eval/matching.py:43 = {3,5,7,9,11,13,14}) final projection
  * -> distance -> Sinkhorn -> mutual matches at `match_ratio` for the whole ragged batch, one device->host copy, and per live pair the

@@ -282,3 +282,105 @@ def test_native_lockstep_loop_without_a_pose_step_runs_every_iteration():
         assert x[4] == y[4] == 15 and x[2] is None and y[2] is None
         assert np.array_equal(x[0], y[0]) and np.abs(x[1].astype(np.float64) - y[1]).max() <= TOL
     assert np.array_equal(a[0][0], solo[0])
+
+
+# ---- the EIMP loop in lock step (round 4): per-pair adaptive pooling inside the ragged batch ----------------------------------------
+def _eimp_model(style='matching', seed=0):
+    cfg = eval_config()
+    sd = synthetic.make_state_dict(cfg, 'AdaGMN', seed=seed, bin_score=synthetic.MATCHING_BIN_SCORE, style=style)
+    return make_hip_model('AdaGMN', cfg, sd)
+
+
+def _same_eimp_result(a, c, what):
+    """two 9-tuples of matching_iterative_uncertainty: same exit iteration, kept keypoint sets, matches, pose"""
+    assert a[8] == c[8], f'{what}: n_iterations {a[8]} vs {c[8]}'
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1]), f'{what}: surviving keypoint sets differ'
+    assert np.array_equal(a[2], c[2]) and np.array_equal(a[3], c[3]), f'{what}: normalised keypoints differ'
+    assert np.array_equal(a[4], c[4]), f'{what}: {(a[4] != c[4]).sum()} indices differ'
+    assert np.abs(a[5].astype(np.float64) - c[5]).max() <= TOL
+    assert (a[6] is None) == (c[6] is None)
+    if a[6] is not None:
+        assert np.allclose(a[6], c[6], atol=1e-6) and np.allclose(a[7], c[7], atol=1e-6)
+
+
+@pytest.mark.parametrize('name', ['eimp_loop_sliced_n1024', 'eimp_loop_uncert_exit_n1024', 'eimp_loop_uncert_full_n700'])
+def test_eimp_lockstep_loop_of_one_pair_vs_the_reference_fixture(name):
+    """the host logic of the lock-step EIMP loop (matching_iterative_uncertainty_lockstep) and the per-pair pool entry points
+    (imp_match_tail_scores, imp_pool_pair) pinned to the loop fixtures captured from the reference: pruning trajectory, kept sets,
+    matches of every scored iteration, the pose-driven exit and the with_uncertainty thresholds"""
+    from helpers import build_case
+    from imp_release_amd import matching as hip_matching
+    from test_gpu_parity import _check_loop_against_golden, _loop_data
+    spec, z = load_golden(name)
+    cfg, sd, data = build_case(spec, DEV)
+    m = make_hip_model(spec, cfg, sd)
+    sched = spec.get('pose_schedule')
+    stub = synthetic.PoseStub(sched) if sched is not None else None
+    traces = [[]]
+    with torch.no_grad():
+        (p0, p1, nk0, nk1, i0, ms0, R, t, nit), = hip_matching.matching_iterative_uncertainty_lockstep(
+            [_loop_data(data)], m, 15, 0.1, 25, 1.0, {'pose': 1.5}, method=38, with_uncertainty=bool(spec.get('with_uncertainty', False)),
+            estimate_pose=stub, pose_threads=1, traces=traces)
+    assert nk0.shape == (p0.shape[0], 2) and nk1.shape == (p1.shape[0], 2)
+    _check_loop_against_golden(name, z, data, (p0, p1, i0, ms0, R, t, nit), traces[0], stub)
+
+
+def test_eimp_lockstep_reference_pair_inside_a_ragged_group():
+    """the reference-captured pair (N = 1024 / 1000, no pose: all 15 iterations, pooled after every scored one) advances TOGETHER with two
+    pairs of other sizes: its trajectory, kept sets and matches are still the reference's, strictly; the other two equal their own runs alone"""
+    from helpers import build_case
+    from imp_release_amd import matching as hip_matching
+    from test_gpu_parity import _check_loop_against_golden, _loop_data
+    name = 'eimp_loop_sliced_n1024'
+    spec, z = load_golden(name)
+    cfg, sd, data = build_case(spec, DEV)
+    m = make_hip_model(spec, cfg, sd)
+    others = [_loop_dict(synthetic.make_correlated_pair(700, 640, seed=71)), _loop_dict(synthetic.make_correlated_pair(1300, 1210, seed=72))]
+    datas = [others[0], _loop_data(data), others[1]]
+    traces = [[], [], []]
+    with torch.no_grad():
+        solo = [hip_matching.matching_iterative_uncertainty(d, m, 15, 0.1, 25, 1.0, {'pose': 1.5}) for d in others]
+        out = hip_matching.matching_iterative_uncertainty_lockstep(datas, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, traces=traces)
+    p0, p1, nk0, nk1, i0, ms0, R, t, nit = out[1]
+    _check_loop_against_golden(name, z, data, (p0, p1, i0, ms0, R, t, nit), traces[1], None)
+    _same_eimp_result(solo[0], out[0], 'pair 0')
+    _same_eimp_result(solo[1], out[2], 'pair 2')
+    print('kept sizes:', [(o[0].shape[0], o[1].shape[0]) for o in out])
+    assert m._ensure_ctx().resident_health() == (0, 0)
+
+
+@pytest.mark.parametrize('pose_threads', [1, 4])
+def test_eimp_lockstep_loop_equals_the_pairs_one_at_a_time(pose_threads):
+    """4 two-view pairs of different sizes and difficulty through the EIMP loop together (GPU pose step, with_uncertainty: the pool
+    threshold of a pair follows its own inlier ratio) = each pair through matching_iterative_uncertainty alone"""
+    from imp_release_amd import matching as hip_matching, pose as gpose
+    m = _eimp_model()
+    pairs = [synthetic.make_hard_two_view_pair(seed=9400 + k, n_lo=600, n_hi=1500) for k in range(3)] + [synthetic.make_two_view_pair(1000, 940, seed=9500)]
+    datas = [_loop_dict(p) for p in pairs]
+    kw = dict(with_uncertainty=True, estimate_pose=gpose.estimate_pose)
+    with torch.no_grad():
+        solo = [hip_matching.matching_iterative_uncertainty(d, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, **kw) for d in datas]
+        together = hip_matching.matching_iterative_uncertainty_lockstep(datas, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, pose_threads=pose_threads, **kw)
+    print('exit iterations:', [s_[8] for s_ in solo], 'kept:', [(s_[0].shape[0], s_[1].shape[0]) for s_ in solo])
+    for b, (a, c) in enumerate(zip(solo, together)):
+        _same_eimp_result(a, c, f'pair {b}')
+    assert m._ensure_ctx().resident_health() == (0, 0)
+
+
+def test_eval_loop_eimp_lockstep_rows_equal_the_sequential_rows():
+    from imp_release_amd import eval_loop, pose as gpose
+    m = _eimp_model()
+    pairs = [synthetic.make_hard_two_view_pair(seed=9600 + k, n_lo=500, n_hi=1100) for k in range(7)]
+
+    def provider(pid):
+        return _loop_dict(pairs[pid])
+
+    kw = dict(estimate_pose=gpose.estimate_pose, eimp=True)
+    seq = eval_loop.run_pairs_sharded(m, provider, 7, **kw)
+    lock = eval_loop.run_pairs_sharded(m, provider, 7, lockstep=3, **kw)
+    both = eval_loop.run_pairs_sharded(m, provider, 7, lockstep=2, workers=2, **kw)
+    cols = [eval_loop.SUMMARY_COLUMNS.index(c) for c in ('n_iterations', 'n_matches', 'precision', 'matching_score')]
+    for other in (lock, both):
+        assert np.array_equal(seq[:, cols], other[:, cols])
+        assert np.allclose(seq, other, atol=1e-4, equal_nan=True)
+    print(eval_loop.aggregate(seq))

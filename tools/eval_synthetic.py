@@ -31,7 +31,7 @@ def main():
     ap.add_argument('--noise-px', type=float, default=0.5)
     ap.add_argument('--hard', action='store_true', help='the harder evaluation set of round 4 (synthetic.make_hard_two_view_pair: N ~ U(1000, 2048), '
                                                         'overlap 0.2-0.8, noise 0.5-2 px, 30-70 %% look-alike outliers) instead of fixed-size easy pairs')
-    ap.add_argument('--lockstep', type=int, default=1, help='IMP only: that many pairs advance together as one ragged batch (matching_iterative_lockstep)')
+    ap.add_argument('--lockstep', type=int, default=1, help='that many pairs advance together as one ragged batch (matching_iterative_lockstep / matching_iterative_uncertainty_lockstep)')
     ap.add_argument('--schedule', choices=['block', 'lpt'], default='block', help="pairs -> ranks: contiguous blocks or longest-first by n0 * n1")
     a = ap.parse_args()
     rank, world, lr = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
