@@ -211,10 +211,9 @@ def batch1_latencies(dev, args):
         del m, sp
         for tag, name in (('imp', 'DGNNS'), ('eimp', 'AdaGMN')):
             mm = model_of(name, eval_config(15, 20), bin_score=synthetic.MATCHING_BIN_SCORE, style='matching')
-            # IMP: 4 pairs advance in lock step as one ragged batch (the native driver imp_loop_lockstep: one launch per layer for all of them,
-            # per-pair early exit), 3 such groups in flight; EIMP (every pair re-sliced after each pool): 3 single pairs in flight as in round 3
-            kw = dict(eimp=name == 'AdaGMN', estimate_pose=gpose.estimate_pose)
-            kw.update(dict(workers=3) if name == 'AdaGMN' else dict(workers=3, lockstep=4))
+            # 4 pairs advance in lock step as one ragged batch (the native drivers imp_loop_lockstep / imp_loop_lockstep_uncertainty: one launch
+            # per layer for all of them, per-pair early exit; EIMP: per-pair pooling inside the batch), 3 such groups in flight
+            kw = dict(eimp=name == 'AdaGMN', estimate_pose=gpose.estimate_pose, workers=3, lockstep=4)
             reps = eval_loop.replicate(mm, kw['workers'])
             kw['replicas'] = reps
             eval_loop.run_pairs_sharded(mm, provider, 24, **kw)                                     # warm-up (workspaces)
@@ -231,17 +230,19 @@ def batch1_latencies(dev, args):
             nit = table[:, eval_loop.SUMMARY_COLUMNS.index('n_iterations')].astype(int)
             rep['n_iterations_histogram'] = {int(k_): int(v_) for k_, v_ in zip(*np.unique(nit, return_counts=True))}
             out[f'c5_{tag}_report'] = rep
-            if name == 'DGNNS':                                                                     # the round-3 schedule on the same set, for the record
-                kw3 = dict(eimp=False, estimate_pose=gpose.estimate_pose, workers=3, replicas=eval_loop.replicate(mm, 3))
-                eval_loop.run_pairs_sharded(mm, provider, 12, **kw3)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                eval_loop.run_pairs_sharded(mm, provider, n_eval // 4, **kw3)
-                torch.cuda.synchronize()
-                out['c5_imp_single_pairs_3_in_flight_pairs_per_s'] = (n_eval // 4) / (time.perf_counter() - t0)
+            # the round-3 schedule (single pairs, 3 in flight) on the same set, for the record
+            kw3 = dict(eimp=name == 'AdaGMN', estimate_pose=gpose.estimate_pose, workers=3, replicas=reps)
+            eval_loop.run_pairs_sharded(mm, provider, 12, **kw3)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            t3 = eval_loop.run_pairs_sharded(mm, provider, n_eval // 4, **kw3)
+            torch.cuda.synchronize()
+            out[f'c5_{tag}_single_pairs_3_in_flight_pairs_per_s'] = (n_eval // 4) / (time.perf_counter() - t0)
+            out[f'c5_{tag}_single_pairs_auc5'] = eval_loop.aggregate(t3)['auc@5']
             del mm, reps
-        out['c5_note'] = (f'BASELINE configs[4] on ONE GPU: {n_eval} evaluations of matching_iterative (imp: DGNNS; 4 pairs in lock step as one ragged batch - imp_loop_lockstep -, '
-                          f'3 groups in flight) / matching_iterative_uncertainty (eimp: AdaGMN, adaptive pooling; 3 single pairs in flight) over {n_distinct} '
+        out['c5_note'] = (f'BASELINE configs[4] on ONE GPU: {n_eval} evaluations of matching_iterative (imp: DGNNS) / matching_iterative_uncertainty (eimp: AdaGMN, adaptive '
+                          f'pooling, with_uncertainty as eval/eval_imp.py:95-105), 4 pairs in lock step as one ragged batch (imp_loop_lockstep / imp_loop_lockstep_uncertainty), '
+                          f'3 groups in flight; *_single_pairs_3_in_flight_* = one pair per call, 3 in flight ({n_eval // 4} evaluations); over {n_distinct} '
                           'distinct two-view synthetic scenes (N ~ U(1000, 2048) keypoints per image, overlap 0.2-0.8, pixel noise 0.5-2, 30-70 % look-alike '
                           'outliers, known relative pose), 15 iterations, early exit on pose convergence, pose step = csrc/pose.hip in the estimate_pose slot (NOT '
                           "OpenCV MAGSAC), H2D upload of every pair included; report = eval/eval_imp.py:213-227's numbers with the "

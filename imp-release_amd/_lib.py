@@ -26,7 +26,7 @@ SYMBOLS = [
     'imp_last_error', 'imp_version', 'imp_create', 'imp_destroy', 'imp_load_tensor', 'imp_finalize_weights',
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
-    'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_pool_select_pair', 'imp_masked_commit', 'imp_gather_rows', 'imp_match_pair', 'imp_set_counts', 'imp_match_tail', 'imp_match_tail_scores', 'imp_pool_pair', 'imp_loop_lockstep', 'imp_op_linear', 'imp_op_layer_gemm', 'imp_op_fused_mlp',
+    'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_pool_select_pair', 'imp_masked_commit', 'imp_gather_rows', 'imp_match_pair', 'imp_set_counts', 'imp_match_tail', 'imp_match_tail_scores', 'imp_pool_pair', 'imp_loop_lockstep', 'imp_loop_lockstep_uncertainty', 'imp_op_linear', 'imp_op_layer_gemm', 'imp_op_fused_mlp',
     'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_range_events', 'imp_tag_wraps', 'imp_time_layer_gemm', 'imp_estimate_pose',
     'imp_sp_create', 'imp_sp_destroy', 'imp_sp_set_weight', 'imp_sp_finalize', 'imp_sp_detect', 'imp_sp_describe', 'imp_sp_dense', 'imp_sp_op_conv',
 ]
@@ -61,6 +61,13 @@ class ImpLoopPair(C.Structure):
     """include/imp_hip.h imp_loop_pair"""
     _fields_ = [('pts0', C.c_void_p), ('pts1', C.c_void_p), ('K0', C.c_void_p), ('K1', C.c_void_p), ('indices0', C.c_void_p), ('mscores0', C.c_void_p),
                 ('R', C.c_double * 9), ('t', C.c_double * 3), ('found', C.c_int32), ('n_iterations', C.c_int32)]
+
+
+class ImpLoopPairU(C.Structure):
+    """include/imp_hip.h imp_loop_pair_u"""
+    _fields_ = [('pts0', C.c_void_p), ('pts1', C.c_void_p), ('K0', C.c_void_p), ('K1', C.c_void_p), ('indices0', C.c_void_p), ('mscores0', C.c_void_p),
+                ('kept0', C.c_void_p), ('kept1', C.c_void_p), ('R', C.c_double * 9), ('t', C.c_double * 3), ('found', C.c_int32),
+                ('n_iterations', C.c_int32), ('n_kept0', C.c_int32), ('n_kept1', C.c_int32), ('n_indices', C.c_int32), ('reserved', C.c_int32)]
 
 
 class ImpConfig(C.Structure):
@@ -122,6 +129,7 @@ def lib():
     L.imp_match_tail_scores.argtypes = [P, I, I, I, I, P, P, F, I, I, F, P, P, P, P, P, P]
     L.imp_pool_pair.argtypes = [P, I, I, I, I, P, F, F, I, P, P, P, P]
     L.imp_loop_lockstep.argtypes = [P, I, P, P, I, I, P, P, P, P, P, P, F, I, I, C.c_uint, F, I, C.c_double, C.c_double, I, I, C.c_uint, I, P, P]
+    L.imp_loop_lockstep_uncertainty.argtypes = [P, I, P, P, I, I, P, P, P, P, P, P, F, I, I, C.c_uint, F, I, C.c_double, C.c_double, I, I, I, I, C.c_uint, I, P, P]
     L.imp_op_linear.argtypes = [P, I, I, I, P, P, P, P, P]
     L.imp_op_layer_gemm.argtypes = [P, I, I, I, I, I, P, P, P, P, P, P, P, P, P, P, I, P, I, P]
     L.imp_op_fused_mlp.argtypes = [P, I, I, P, P, P, P, P, P, P, P, I, P, P, I, P]
@@ -511,6 +519,48 @@ class Context:
             R = np.array(recs[b].R, dtype=np.float64).reshape(3, 3) if found else None
             t = np.array(recs[b].t, dtype=np.float64) if found else None
             out.append((keep[b][4], keep[b][5], R, t, int(recs[b].n_iterations)))
+        return out
+
+    def loop_lockstep_uncertainty(self, n0, n1, nk0, sc0, de0, nk1, sc1, de1, pts0, pts1, K0, K1, bin_score, sinkhorn_iterations, n_iterations,
+                                  valid_its, match_ratio, min_kpts, error_th, stop_pose_deg, with_uncertainty, n_min_tokens=256, pose_threads=4,
+                                  pose_iterations=1024, pose_seed=1, pose_flags=1):
+        """the native lock-step EIMP loop (include/imp_hip.h imp_loop_lockstep_uncertainty): padded device tensors + per-pair host arrays
+        in, [(kept0, kept1, indices0, mscores0, R | None, t | None, n_iterations)] out (kept: indices of the surviving keypoints)"""
+        import numpy as np
+        B = len(n0)
+        nk0, sc0, de0, nk1, sc1, de1 = (_f32(t, 'input') for t in (nk0, sc0, de0, nk1, sc1, de1))
+        N0, N1 = nk0.shape[1], nk1.shape[1]
+        recs = (ImpLoopPairU * B)()
+        keep = []
+        for b in range(B):
+            p0 = np.ascontiguousarray(pts0[b], dtype=np.float32); p1 = np.ascontiguousarray(pts1[b], dtype=np.float32)
+            k0 = np.ascontiguousarray(np.eye(3) if K0[b] is None else K0[b], dtype=np.float64).reshape(3, 3)
+            k1 = np.ascontiguousarray(np.eye(3) if K1[b] is None else K1[b], dtype=np.float64).reshape(3, 3)
+            oi = np.empty(n0[b], dtype=np.int64); om = np.empty(n0[b], dtype=np.float32)
+            q0 = np.empty(n0[b], dtype=np.int32); q1 = np.empty(n1[b], dtype=np.int32)
+            keep.append((p0, p1, k0, k1, oi, om, q0, q1))
+            recs[b].pts0, recs[b].pts1 = p0.ctypes.data, p1.ctypes.data
+            recs[b].K0, recs[b].K1 = k0.ctypes.data, k1.ctypes.data
+            recs[b].indices0, recs[b].mscores0 = oi.ctypes.data, om.ctypes.data
+            recs[b].kept0, recs[b].kept1 = q0.ctypes.data, q1.ctypes.data
+        a0 = (C.c_int32 * B)(*[int(v) for v in n0]); a1 = (C.c_int32 * B)(*[int(v) for v in n1])
+        mask = 0
+        for it in valid_its:
+            mask |= 1 << int(it)
+        self._check(self.L.imp_loop_lockstep_uncertainty(
+            self.handle, B, a0, a1, N0, N1, _ptr(nk0), _ptr(sc0), _ptr(de0), _ptr(nk1), _ptr(sc1), _ptr(de1), float(bin_score), int(sinkhorn_iterations),
+            int(n_iterations), C.c_uint(mask), float(match_ratio), int(min_kpts), C.c_double(float(error_th)), C.c_double(float(stop_pose_deg)),
+            1 if with_uncertainty else 0, int(n_min_tokens), int(pose_threads), int(pose_iterations), C.c_uint(pose_seed), int(pose_flags), recs,
+            _stream(self.device)))
+        out = []
+        for b in range(B):
+            r = recs[b]
+            found = bool(r.found)
+            R = np.array(r.R, dtype=np.float64).reshape(3, 3) if found else None
+            t = np.array(r.t, dtype=np.float64) if found else None
+            ni = int(r.n_indices)
+            out.append((keep[b][6][:int(r.n_kept0)].astype(np.int64), keep[b][7][:int(r.n_kept1)].astype(np.int64), keep[b][4][:ni], keep[b][5][:ni], R, t,
+                        int(r.n_iterations)))
         return out
 
     def op_linear(self, x, W, bias=None):

@@ -124,6 +124,11 @@ struct imp_ctx {
     int64_t* lp_idx = nullptr; float* lp_ms = nullptr; unsigned char* lp_pin = nullptr; size_t lp_cap = 0;
     hipEvent_t lp_ev = nullptr;
     struct PoseWorkers* lp_workers = nullptr;
+    // native EIMP loop (imp_loop_lockstep_uncertainty): score tensors of a scored iteration, the pool's id lists + counts (device and pinned
+    // mirror), the second descriptor buffers the kept rows are gathered into
+    float* lu_scores = nullptr; size_t lu_scores_cap = 0;
+    int64_t* lu_pool = nullptr; int64_t* lu_pool_pin = nullptr; size_t lu_pool_cap = 0;
+    float* lu_alt[2] = {nullptr, nullptr}; size_t lu_alt_cap[2] = {0, 0};
     RaggedCounts rc{};       // imp_set_counts: per-pair keypoint counts of the NEXT calls (rc.on = 0: uniform batches); rc_batch pairs
     int rc_batch = 0;
     int ot_lane = 0;         // IMP_OT_LANE=1: resident Sinkhorn launches go through the device's lane stream (rounds 2-3) instead of the caller's stream under the spin gate
@@ -1206,6 +1211,11 @@ void loop_release(imp_ctx* c) {
     if (c->lp_pin) (void)hipHostFree(c->lp_pin);
     if (c->lp_ev) (void)hipEventDestroy(c->lp_ev);
     c->lp_idx = nullptr; c->lp_ms = nullptr; c->lp_pin = nullptr; c->lp_ev = nullptr; c->lp_cap = 0;
+    if (c->lu_scores) (void)hipFree(c->lu_scores);
+    if (c->lu_pool) (void)hipFree(c->lu_pool);
+    if (c->lu_pool_pin) (void)hipHostFree(c->lu_pool_pin);
+    for (int s = 0; s < 2; ++s) { if (c->lu_alt[s]) (void)hipFree(c->lu_alt[s]); c->lu_alt[s] = nullptr; c->lu_alt_cap[s] = 0; }
+    c->lu_scores = nullptr; c->lu_pool = nullptr; c->lu_pool_pin = nullptr; c->lu_scores_cap = 0; c->lu_pool_cap = 0;
 }
 // rotation angle between two rotation matrices / angle between two vectors, degrees (imp_release_amd/matching.py angle_error_mat / _vec,
 // the semantics of tools/utils.py:425-431)
@@ -1950,6 +1960,301 @@ int imp_loop_lockstep(imp_ctx* c, int B, const int32_t* n0v, const int32_t* n1v,
         }
         o.found = 0; o.n_iterations = n_iterations;
     }
+    return IMP_OK;
+}
+
+// The EIMP loop (eval/matching.py:126-276) on B pairs in lock step, host logic included: the twin of
+// imp_release_amd.matching._lockstep_group_uncertainty.  Unlike the IMP loop the pose estimates of a scored iteration cannot be deferred -
+// with_uncertainty makes a pair's pool threshold 0.2 x the inlier ratio of ITS estimate (:243-247) - so they run side by side on the
+// context's pose workers and the group waits for the slowest; then every live pair is pooled on its slice (pool_pair_impl), all id
+// lists come back in one copy, and the kept rows are gathered into the second descriptor buffers, padded to the new largest pair.
+int imp_loop_lockstep_uncertainty(imp_ctx* c, int B, const int32_t* n0v, const int32_t* n1v, int n0, int n1, const float* nkpts0,
+                                  const float* scores0, const float* desc0, const float* nkpts1, const float* scores1, const float* desc1,
+                                  float bin_score, int sinkhorn_iterations, int n_iterations, unsigned valid_mask, float match_ratio, int min_kpts,
+                                  double error_th, double stop_pose_deg, int with_uncertainty, int n_min_tokens, int pose_threads,
+                                  int pose_iterations, unsigned pose_seed, int pose_flags, imp_loop_pair_u* pairs, void* stream) {
+    if (!c || !n0v || !n1v || !pairs || B < 1 || B > IMP_RAGGED_MAX) return fail(IMP_E_ARG, "imp_loop_lockstep_uncertainty: 1 .. 16 pairs, counts and pair records");
+    if (!nkpts0 || !nkpts1 || !scores0 || !scores1 || !desc0 || !desc1) return fail(IMP_E_ARG, "imp_loop_lockstep_uncertainty: null input");
+    if (match_ratio > 0.2f) return fail(IMP_E_ARG, "imp_loop_lockstep_uncertainty: match_ratio must be <= 0.2 (the final p = 0.2 matches are derived from the scored ones)");
+    if (n_iterations < 1 || 2 * n_iterations > c->cfg.n_gnn_layers) return fail(IMP_E_ARG, "imp_loop_lockstep_uncertainty: more iterations than the model has layer pairs");
+    for (int b = 0; b < B; ++b)
+        if (!pairs[b].pts0 || !pairs[b].pts1 || !pairs[b].K0 || !pairs[b].K1 || !pairs[b].indices0 || !pairs[b].mscores0 || !pairs[b].kept0 || !pairs[b].kept1)
+            return fail(IMP_E_ARG, "imp_loop_lockstep_uncertainty: a pair record with a null array");
+    int rc = imp_set_counts(c, B, n0v, n1v);
+    if (rc) return rc;
+    struct Restore { imp_ctx* c; ~Restore() { c->rc.on = 0; c->rc_batch = 0; } } restore{c};
+    if ((rc = check_ready(c, B, n0, n1))) return rc;
+    hipStream_t st = S(stream);
+    const int D = c->D;
+    {   // buffers, sized for the first (largest) shape of the group
+        const size_t need = (size_t)B * n0;
+        if (need > c->lp_cap) {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (c->lp_idx) (void)hipFree(c->lp_idx);
+            if (c->lp_ms) (void)hipFree(c->lp_ms);
+            if (c->lp_pin) (void)hipHostFree(c->lp_pin);
+            c->lp_idx = nullptr; c->lp_ms = nullptr; c->lp_pin = nullptr; c->lp_cap = 0;
+            const size_t cap = need < 16384 ? 16384 : need;
+            HIP_TRY(hipMalloc(&c->lp_idx, cap * sizeof(int64_t)));
+            HIP_TRY(hipMalloc(&c->lp_ms, cap * sizeof(float)));
+            HIP_TRY(hipHostMalloc(&c->lp_pin, cap * 12));
+            c->lp_cap = cap;
+        }
+        const size_t sneed = (size_t)B * (n0 + 1) * (n1 + 1);
+        if (sneed > c->lu_scores_cap) {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (c->lu_scores) (void)hipFree(c->lu_scores);
+            c->lu_scores = nullptr; c->lu_scores_cap = 0;
+            HIP_TRY(hipMalloc(&c->lu_scores, sneed * sizeof(float)));
+            c->lu_scores_cap = sneed;
+        }
+        const size_t pneed = (size_t)B * (n0 + n1 + 2);
+        if (pneed > c->lu_pool_cap) {
+            HIP_TRY(hipStreamSynchronize(st));
+            if (c->lu_pool) (void)hipFree(c->lu_pool);
+            if (c->lu_pool_pin) (void)hipHostFree(c->lu_pool_pin);
+            c->lu_pool = nullptr; c->lu_pool_pin = nullptr; c->lu_pool_cap = 0;
+            HIP_TRY(hipMalloc(&c->lu_pool, pneed * sizeof(int64_t)));
+            HIP_TRY(hipHostMalloc(&c->lu_pool_pin, pneed * sizeof(int64_t)));
+            c->lu_pool_cap = pneed;
+        }
+        const int nn[2] = {n0, n1};
+        for (int s = 0; s < 2; ++s) {
+            const size_t aneed = (size_t)B * nn[s] * D;
+            if (aneed > c->lu_alt_cap[s]) {
+                HIP_TRY(hipStreamSynchronize(st));
+                if (c->lu_alt[s]) (void)hipFree(c->lu_alt[s]);
+                c->lu_alt[s] = nullptr; c->lu_alt_cap[s] = 0;
+                HIP_TRY(hipMalloc(&c->lu_alt[s], aneed * sizeof(float)));
+                c->lu_alt_cap[s] = aneed;
+            }
+        }
+    }
+    if (!c->lp_ev) HIP_TRY(hipEventCreateWithFlags(&c->lp_ev, hipEventDisableTiming));
+    const bool with_pose = pose_threads > 0;
+    if (with_pose && !c->lp_workers) c->lp_workers = new PoseWorkers(pose_threads < B ? B : pose_threads, c->device);
+    int64_t* const h_idx = reinterpret_cast<int64_t*>(c->lp_pin);
+    float* const h_ms = reinterpret_cast<float*>(c->lp_pin + c->lp_cap * sizeof(int64_t));
+
+    struct PairU {
+        bool live = true, has_last = false, scored = false, sel = false;
+        double lastR[9], lastT[3];
+        std::vector<float> pts[2];                      // the surviving pixel keypoints (eval/matching.py:166-174 slices them every iteration)
+        std::vector<int32_t> kept[2];                   // their indices in the pair's original numbering
+        int sel_n[2] = {-1, -1};                        // pool result waiting for the next iteration: kept counts (-1: side unchanged)
+        std::vector<int64_t> last_idx;
+        std::vector<float> last_ms;
+        std::shared_ptr<LoopPose> job;
+        std::vector<int> pm0, pm1;
+    };
+    std::vector<PairU> P(B);
+    struct WaitAll {                                    // no return path may leave a pose worker behind
+        std::vector<PairU>& P;
+        ~WaitAll() { for (auto& q : P) if (q.job) q.job->fut.wait(); }
+    } wait_all{P};
+    int pad[2] = {n0, n1};
+    std::vector<int> cnt[2] = {std::vector<int>(n0v, n0v + B), std::vector<int>(n1v, n1v + B)};
+    for (int b = 0; b < B; ++b) {
+        pairs[b].found = 0; pairs[b].n_iterations = n_iterations; pairs[b].n_kept0 = n0v[b]; pairs[b].n_kept1 = n1v[b];
+        P[b].pts[0].assign(pairs[b].pts0, pairs[b].pts0 + 2 * (size_t)n0v[b]);
+        P[b].pts[1].assign(pairs[b].pts1, pairs[b].pts1 + 2 * (size_t)n1v[b]);
+        for (int s = 0; s < 2; ++s) { P[b].kept[s].resize(cnt[s][b]); for (int i = 0; i < cnt[s][b]; ++i) P[b].kept[s][i] = i; }
+    }
+    auto finish = [&](int b, const int64_t* idx, const float* ms, const unsigned char* inl, const double* R, const double* t, int n_iter) {
+        imp_loop_pair_u& o = pairs[b];
+        PairU& q = P[b];
+        const int nb = (int)q.kept[0].size();
+        if (inl) {                                      // pose exit: the inlier-filtered matches (eval/matching.py:259-269)
+            for (int i = 0; i < nb; ++i) { o.indices0[i] = -1; o.mscores0[i] = ms[i]; }
+            for (size_t m = 0; m < q.pm0.size(); ++m)
+                if (inl[m]) o.indices0[q.pm0[m]] = q.pm1[m];
+            memcpy(o.R, R, sizeof o.R); memcpy(o.t, t, sizeof o.t);
+            o.found = 1;
+        } else {                                        // never exited: compute_matches(pred_score, 0.2) (eval/matching.py:271)
+            // (sized by the LAST SCORED iteration: if the loop ends on an unscored one after a pool, the reference returns the sliced
+            // keypoints beside the older, longer match vector - so does this)
+            const int ns = idx ? (int)q.last_idx.size() : nb;
+            for (int i = 0; i < ns; ++i) {
+                const float v = idx ? ms[i] : 0.f;
+                o.mscores0[i] = v;
+                o.indices0[i] = (idx && v > 0.2f) ? idx[i] : -1;
+            }
+            o.found = 0;
+        }
+        o.n_iterations = n_iter;
+        o.n_indices = (!inl && idx) ? (int)q.last_idx.size() : nb;
+        o.n_kept0 = nb; o.n_kept1 = (int)q.kept[1].size();
+        memcpy(o.kept0, q.kept[0].data(), q.kept[0].size() * sizeof(int32_t));
+        memcpy(o.kept1, q.kept[1].data(), q.kept[1].size() * sizeof(int32_t));
+    };
+
+    const float* kp[2] = {nkpts0, nkpts1};
+    const float* sc[2] = {scores0, scores1};
+    const float* de[2] = {desc0, desc1};
+    float* cur[2] = {c->descw[0], c->descw[1]};
+    float* alt[2] = {c->lu_alt[0], c->lu_alt[1]};
+    if ((rc = run_kenc(c, B, pad, kp, sc, 0.f, 0.f, de, cur, st))) return rc;     // desc + enc (eval/matching.py:158-160)
+    const uint8_t* nomask[2] = {nullptr, nullptr};
+    bool proj_done = false;
+    const size_t pool_w = (size_t)n0 + n1 + 2;                                     // int64 words of a pair's pool record: ids0 | ids1 | 4 int32 counts
+    for (int it = 0; it < n_iterations; ++it) {
+        bool any_sel = false;
+        for (int b = 0; b < B; ++b) any_sel = any_sel || (P[b].live && P[b].sel);
+        if (any_sel) {                                                             // eval/matching.py:166-174, every pair on its own rows
+            int npad[2] = {1, 1};
+            std::vector<int> ncnt[2] = {cnt[0], cnt[1]};
+            for (int b = 0; b < B; ++b)
+                for (int s = 0; s < 2; ++s) {
+                    if (!P[b].live) { ncnt[s][b] = 0; continue; }
+                    if (P[b].sel && P[b].sel_n[s] >= 0) ncnt[s][b] = P[b].sel_n[s];
+                    if (ncnt[s][b] > npad[s]) npad[s] = ncnt[s][b];
+                }
+            for (int b = 0; b < B; ++b) {
+                if (!P[b].live) continue;
+                for (int s = 0; s < 2; ++s) {
+                    const float* src = cur[s] + (size_t)b * pad[s] * D;
+                    float* dst = alt[s] + (size_t)b * npad[s] * D;
+                    if (P[b].sel && P[b].sel_n[s] >= 0) {
+                        const int64_t* ids = c->lu_pool + (size_t)b * pool_w + (s ? n0 : 0);
+                        HIP_TRY(launch_gather_rows(src, ids, dst, 1, pad[s], ncnt[s][b], D, st));
+                    } else {
+                        HIP_TRY(hipMemcpyAsync(dst, src, (size_t)cnt[s][b] * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+                    }
+                }
+                P[b].sel = false; P[b].sel_n[0] = P[b].sel_n[1] = -1;
+            }
+            for (int s = 0; s < 2; ++s) { std::swap(cur[s], alt[s]); pad[s] = npad[s]; cnt[s] = ncnt[s]; }
+            for (int b = 0; b < B; ++b) { c->rc.n[0][b] = cnt[0][b]; c->rc.n[1][b] = cnt[1][b]; }
+            proj_done = false;                                                     // (a projection chained before the gather saw the old rows)
+        }
+        const bool scored = ((valid_mask >> it) & 1u) != 0;
+        for (int li = 2 * it; li <= 2 * it + 1; ++li) {
+            // the last layer before a pool must not chain the next layer's projection into the q | k | v slots the pool still reads
+            const bool pool_follows = scored && li == 2 * it + 1;
+            const int chain = (li + 1 < c->cfg.n_gnn_layers && !pool_follows) ? li + 1 : -1;
+            bool chained = false;
+            const float* dr[2] = {cur[0], cur[1]};
+            if ((rc = run_layer(c, li, B, pad, dr, cur, nomask, st, proj_done, chain, &chained))) return rc;
+            proj_done = chained;
+        }
+        if (!scored) continue;
+        const float* dr[2] = {cur[0], cur[1]};
+        if ((rc = run_distance(c, it, B, pad, dr, c->dist, st))) return rc;
+        OtBuffers o;
+        bool max_done = false;
+        if ((rc = run_score(c, B, pad[0], pad[1], c->dist, bin_score, sinkhorn_iterations, 1, c->lu_scores, &o, st, &max_done))) return rc;
+        HIP_TRY(launch_mutual_matches(B, pad[0], pad[1], c->max0, c->arg0, c->max1, c->arg1, match_ratio, c->lp_idx, nullptr, c->lp_ms, nullptr,
+                                      c->range_hostdev, st, &c->rc));
+        const size_t nidx = (size_t)B * pad[0];
+        HIP_TRY(hipMemcpyAsync(h_idx, c->lp_idx, nidx * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_ms, c->lp_ms, nidx * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(c->lp_ev, st));
+        HIP_TRY(hipEventSynchronize(c->lp_ev));
+        if ((rc = resident_health(c))) return rc;                                  // a voided launch: the caller runs the group again
+        std::vector<int> work;
+        for (int b = 0; b < B; ++b) {
+            PairU& q = P[b];
+            if (!q.live) continue;
+            const int nb = cnt[0][b];
+            const int64_t* ib = h_idx + (size_t)b * pad[0];
+            const float* mb = h_ms + (size_t)b * pad[0];
+            q.last_idx.assign(ib, ib + nb);
+            q.last_ms.assign(mb, mb + nb);
+            q.scored = true;
+            q.pm0.clear(); q.pm1.clear();
+            for (int i = 0; i < nb; ++i)
+                if (ib[i] > -1) { q.pm0.push_back(i); q.pm1.push_back((int)ib[i]); }
+            if ((int)q.pm0.size() < min_kpts) { q.has_last = false; continue; }   // eval/matching.py:191-194
+            if (q.pm0.empty()) continue;
+            q.job.reset();
+            if (with_pose) {
+                auto job = std::make_shared<LoopPose>();
+                const int m = (int)q.pm0.size();
+                job->n = m;
+                job->k0.resize(2 * (size_t)m); job->k1.resize(2 * (size_t)m); job->mask.assign(m, 0);
+                for (int j = 0; j < m; ++j) {
+                    job->k0[2 * j] = q.pts[0][2 * (size_t)q.pm0[j]]; job->k0[2 * j + 1] = q.pts[0][2 * (size_t)q.pm0[j] + 1];
+                    job->k1[2 * j] = q.pts[1][2 * (size_t)q.pm1[j]]; job->k1[2 * j + 1] = q.pts[1][2 * (size_t)q.pm1[j] + 1];
+                }
+                job->fut = job->done.get_future();
+                const double* K0 = pairs[b].K0; const double* K1 = pairs[b].K1;
+                const int dev = c->device;
+                c->lp_workers->submit([job, K0, K1, error_th, pose_iterations, pose_seed, pose_flags, dev](hipStream_t ps) {
+                    job->rc = imp_estimate_pose(job->k0.data(), job->k1.data(), job->n, K0, K1, error_th, pose_iterations, pose_seed, dev, job->E, job->R,
+                                                job->t, job->mask.data(), nullptr, &job->ninl, pose_flags, ps);
+                    job->done.set_value();
+                });
+                q.job = job;
+            }
+            work.push_back(b);
+        }
+        std::vector<std::pair<int, float>> to_pool;
+        for (int b : work) {
+            PairU& q = P[b];
+            std::shared_ptr<LoopPose> job = q.job;
+            q.job.reset();
+            bool have = false;
+            if (job) { job->fut.wait(); have = job->rc == 0; }
+            double inlier_ratio = 0.0;
+            if (have) {
+                int s = 0;
+                for (unsigned char v : job->mask) s += v ? 1 : 0;
+                inlier_ratio = (double)s / (double)q.pm0.size();
+            }
+            double diff_R = INFINITY, diff_t = INFINITY;
+            if (it >= 1 && have && q.has_last) { diff_R = loop_angle_mat(q.lastR, job->R); diff_t = loop_angle_vec(q.lastT, job->t); }
+            q.has_last = have;
+            if (have) { memcpy(q.lastR, job->R, sizeof q.lastR); memcpy(q.lastT, job->t, sizeof q.lastT); }
+            const double pose_diff = diff_R > diff_t ? diff_R : diff_t;
+            if (stop_pose_deg >= 0.0 && pose_diff <= stop_pose_deg) {              // eval/matching.py:259-269
+                finish(b, q.last_idx.data(), q.last_ms.data(), job->mask.data(), job->R, job->t, it + 1);
+                q.live = false;
+                c->rc.n[0][b] = 0; c->rc.n[1][b] = 0;
+                cnt[0][b] = cnt[1][b] = 0;
+                continue;
+            }
+            // (the reference pools before it takes the exit test; a pair that exits never uses the result)
+            const float th = (with_uncertainty && inlier_ratio != 0.0) ? (float)(0.2 * inlier_ratio) : 0.2f;      // eval/matching.py:243-247
+            to_pool.emplace_back(b, th);
+        }
+        bool any = false;
+        for (int b = 0; b < B; ++b) any = any || P[b].live;
+        if (!any) break;
+        if (to_pool.empty() || it + 1 >= n_iterations) continue;
+        for (auto& pt : to_pool) {
+            const int b = pt.first;
+            const int m[2] = {cnt[0][b], cnt[1][b]};
+            int64_t* rec = c->lu_pool + (size_t)b * pool_w;
+            const float* sb = c->lu_scores + (size_t)b * (pad[0] + 1) * (pad[1] + 1);
+            if ((rc = pool_pair_impl(c, b, m, pad, sb, pt.second, n_min_tokens, rec, rec + n0, reinterpret_cast<int32_t*>(rec + n0 + n1), st))) return rc;
+        }
+        HIP_TRY(hipMemcpyAsync(c->lu_pool_pin, c->lu_pool, (size_t)B * pool_w * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(c->lp_ev, st));
+        HIP_TRY(hipEventSynchronize(c->lp_ev));
+        for (auto& pt : to_pool) {
+            const int b = pt.first;
+            PairU& q = P[b];
+            const int64_t* rec = c->lu_pool_pin + (size_t)b * pool_w;
+            const int32_t* cn = reinterpret_cast<const int32_t*>(rec + n0 + n1);
+            const int got[2] = {cn[0], cn[2]};
+            for (int s = 0; s < 2; ++s) {
+                if (got[s] < 0) continue;                                          // side skipped, or nothing confident: unchanged
+                const int64_t* ids = rec + (s ? n0 : 0);
+                std::vector<float> np(2 * (size_t)got[s]);
+                std::vector<int32_t> nk(got[s]);
+                for (int i = 0; i < got[s]; ++i) {
+                    const int64_t id = ids[i];
+                    np[2 * (size_t)i] = q.pts[s][2 * (size_t)id]; np[2 * (size_t)i + 1] = q.pts[s][2 * (size_t)id + 1];
+                    nk[i] = q.kept[s][(size_t)id];
+                }
+                q.pts[s].swap(np); q.kept[s].swap(nk);
+                q.sel_n[s] = got[s];
+                q.sel = true;
+            }
+        }
+    }
+    for (int b = 0; b < B; ++b)
+        if (P[b].live) finish(b, P[b].scored ? P[b].last_idx.data() : nullptr, P[b].last_ms.data(), nullptr, nullptr, nullptr, n_iterations);
     return IMP_OK;
 }
 

@@ -259,7 +259,7 @@ def _lockstep_group(datas, model, nI, match_ratio, min_kpts, error_th, stop_crit
     gate, pose estimate, pose-change test).  A pair that exits early is RETIRED - its counts become 0 and its workgroups leave at once -
     while the others go on.  The final ``compute_matches(pred_score, 0.2)`` of pairs that never exit (eval/matching.py:119) needs no
     second Sinkhorn: mscores0 do not depend on the threshold and indices0 at 0.2 are the indices at ``match_ratio`` <= 0.2 with
-    scores <= 0.2 cleared (nets/gm.py:312-318).  IMP / GM loop only (the EIMP loop re-slices every pair after each pool).
+    scores <= 0.2 cleared (nets/gm.py:312-318).  IMP / GM loop (the EIMP loop, which re-slices every pair after each pool: :func:`matching_iterative_uncertainty_lockstep`).
 
     ``native``: the whole loop in the library (``imp_loop_lockstep``: C++ host logic, pose workers of the context) instead of this Python
     body - same results, a fraction of the host time (a group's 9 ms were 3.5 ms of GPU time and 5.5 ms of Python).  'auto' (default): native
@@ -434,12 +434,12 @@ def _lockstep_group(datas, model, nI, match_ratio, min_kpts, error_th, stop_crit
 
 
 def matching_iterative_uncertainty_lockstep(datas, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method=None,
-                                            with_uncertainty=False, estimate_pose=None, pose_threads=4, traces=None):
+                                            with_uncertainty=False, estimate_pose=None, pose_threads=4, traces=None, native='auto'):
     """:func:`_lockstep_group_uncertainty` on all of ``datas``; a group the chip-resident Sinkhorn cannot hold as one ragged batch is
     split in halves (a single pair always fits)"""
     try:
         return _lockstep_group_uncertainty(datas, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method, with_uncertainty,
-                                           estimate_pose, pose_threads, traces)
+                                           estimate_pose, pose_threads, traces, native)
     except _lib.ImpError as e:
         if 'chip-resident' not in str(e) or len(datas) < 2:
             raise
@@ -447,11 +447,11 @@ def matching_iterative_uncertainty_lockstep(datas, model, nI, match_ratio, min_k
     tr = (None, None) if traces is None else (traces[:mid], traces[mid:])
     a = (datas[:mid], model, nI, match_ratio, min_kpts, error_th, stop_criteria, method, with_uncertainty, estimate_pose, pose_threads)
     b = (datas[mid:],) + a[1:]
-    return matching_iterative_uncertainty_lockstep(*a, tr[0]) + matching_iterative_uncertainty_lockstep(*b, tr[1])
+    return matching_iterative_uncertainty_lockstep(*a, tr[0], native) + matching_iterative_uncertainty_lockstep(*b, tr[1], native)
 
 
 def _lockstep_group_uncertainty(datas, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method=None, with_uncertainty=False,
-                                estimate_pose=None, pose_threads=4, traces=None):
+                                estimate_pose=None, pose_threads=4, traces=None, native='auto'):
     """eval/matching.py:126-276 (the EIMP loop: adaptive pooling between the iterations) on SEVERAL pairs at once ->
     [(pts0, pts1, norm_kpts0, norm_kpts1, indices0, mscores0, R, t, n_iterations)] - per pair exactly what
     :func:`matching_iterative_uncertainty` returns for it.
@@ -461,7 +461,11 @@ def _lockstep_group_uncertainty(datas, model, nI, match_ratio, min_kpts, error_t
     ``imp_match_tail_scores``; all pairs' id lists come back in one copy), and the next iteration starts by gathering every pair's kept
     rows into a batch padded to the new largest pair.  The pool threshold of a pair depends on the inlier ratio of its pose estimate
     (eval/matching.py:243-247), so - unlike the IMP loop - the estimates of an iteration cannot be deferred: they run side by side on
-    the worker threads and the group waits for the slowest."""
+    the worker threads and the group waits for the slowest.
+
+    ``native``: the whole loop in the library (``imp_loop_lockstep_uncertainty``) instead of this Python body - same results, a fraction
+    of the host time.  'auto' (default): native when the pose step is the library's own (``imp_release_amd.pose.estimate_pose``) or absent
+    and no trace is requested; the Python body takes any ``estimate_pose`` callable."""
     B = len(datas)
     if B == 0:
         return []
@@ -484,6 +488,22 @@ def _lockstep_group_uncertainty(datas, model, nI, match_ratio, min_kpts, error_t
         sc0[b, :c0[b]] = d['scores0'][0]; sc1[b, :c1[b]] = d['scores1'][0]
         de0[b, :c0[b]] = d['descriptors0'][0]; de1[b, :c1[b]] = d['descriptors1'][0]
     pts0 = [d['pts0_cpu'] for d in datas]; pts1 = [d['pts1_cpu'] for d in datas]
+    from . import pose as _gpose
+    own_pose = estimate_pose is None or estimate_pose is _gpose.estimate_pose
+    if native is True or (native == 'auto' and own_pose and traces is None and 2 * nI <= len(model.gnn.names)):
+        if not own_pose:
+            raise ValueError("native=True runs the library's own pose step: pass imp_release_amd.pose.estimate_pose or None")
+        stop = float(stop_criteria['pose']) if 'pose' in stop_criteria.keys() else -1.0
+        res = ctx.loop_lockstep_uncertainty(c0, c1, nk0, sc0, de0, nk1, sc1, de1, pts0, pts1, [d.get('K0') for d in datas], [d.get('K1') for d in datas],
+                                            model._bin(None), model.sinkhorn_iterations, nI, [i for i in VALID_ITS if i < nI], match_ratio, min_kpts,
+                                            error_th, stop, with_uncertainty, 256, pose_threads=max(pose_threads, 1) if estimate_pose is not None else 0)
+        for li in range(2 * nI):
+            model._note_layer(li, B, N0, N1)
+        out = []
+        for b, (k0, k1, i0, m0, R, t, nit) in enumerate(res):
+            a = nk[b][0][0].cpu().numpy(); c = nk[b][1][0].cpu().numpy()
+            out.append((np.asarray(pts0[b])[k0], np.asarray(pts1[b])[k1], a[k0], c[k1], i0, m0, R, t, nit))
+        return out
     kept0 = [None] * B; kept1 = [None] * B                                       # ids of the surviving keypoints in the pair's original numbering (None: all)
     sel = [None] * B                                                             # pool result waiting for the next iteration: (ids0, ids1, host0, host1)
     live = [True] * B

@@ -290,6 +290,36 @@ int imp_loop_lockstep(imp_ctx* ctx, int batch, const int32_t* n0_counts, const i
                       int sinkhorn_iterations, int n_iterations, unsigned valid_mask, float match_ratio, int min_kpts, double error_th,
                       double stop_pose_deg, int pose_threads, int pose_iterations, unsigned pose_seed, int pose_flags, imp_loop_pair* pairs,
                       void* stream);
+
+/* The EIMP loop (eval/matching.py:126-276: adaptive pooling between the iterations) on `batch` pairs in lock step, host logic included.
+ * As imp_loop_lockstep, plus: after every scored iteration each live pair is pooled on its own slice of the ragged batch (imp_pool_pair
+ * semantics; threshold 0.2, or - with_uncertainty - 0.2 x the inlier ratio of the pair's pose estimate, :243-247; n_min_tokens as
+ * AdaGMN.pool, the reference loop passes its default 256) and the next iteration runs on the kept rows.  The pose estimates of an
+ * iteration run side by side on the context's worker threads; the group waits for all of them (the pool threshold needs them).
+ * Per pair out: kept0 / kept1 = indices of the surviving keypoints in the pair's own numbering (ascending), indices0 / mscores0 = the
+ * matches among them (n_indices entries; = n_kept0 unless the loop ends on an unscored iteration after a pool).
+ * (Python twin: imp_release_amd.matching.matching_iterative_uncertainty_lockstep.) */
+typedef struct imp_loop_pair_u {
+    const float* pts0;      /* [n0[b]][2] pixel keypoints of image 0 (host) */
+    const float* pts1;      /* [n1[b]][2] */
+    const double* K0;       /* 3x3 row-major intrinsics (host) */
+    const double* K1;
+    int64_t* indices0;      /* out, capacity n0[b] (host) */
+    float* mscores0;        /* out, capacity n0[b] (host) */
+    int32_t* kept0;         /* out, capacity n0[b] (host) */
+    int32_t* kept1;         /* out, capacity n1[b] (host) */
+    double R[9];            /* out: pose of the exit iteration (found = 1) */
+    double t[3];
+    int32_t found;          /* out: 1 = the pair left the loop on pose convergence */
+    int32_t n_iterations;   /* out: eval/matching.py's n_iter */
+    int32_t n_kept0, n_kept1, n_indices, reserved;
+} imp_loop_pair_u;
+int imp_loop_lockstep_uncertainty(imp_ctx* ctx, int batch, const int32_t* n0_counts, const int32_t* n1_counts, int n0, int n1,
+                                  const float* nkpts0, const float* scores0, const float* desc0, const float* nkpts1, const float* scores1,
+                                  const float* desc1, float bin_score, int sinkhorn_iterations, int n_iterations, unsigned valid_mask,
+                                  float match_ratio, int min_kpts, double error_th, double stop_pose_deg, int with_uncertainty,
+                                  int n_min_tokens, int pose_threads, int pose_iterations, unsigned pose_seed, int pose_flags,
+                                  imp_loop_pair_u* pairs, void* stream);
 /* the fused layer MLP of csrc/gemm_wf.hip on its own (tests/test_gpu_ops.py): nets/layers.py:145-149 / :210-218 after the attention,
  *   y = x + mlp.3(relu(InstanceNorm(mlp.0(cat[x, a]))))        x, a, y: [B][M][256];  W0 [512][512], W3 [256][512]
  *   y2 = y . W2^T + b2                                         optional (W2 [N2][256], N2 % 128 == 0): the next layer's projection

@@ -349,8 +349,35 @@ def test_eimp_lockstep_reference_pair_inside_a_ragged_group():
     assert m._ensure_ctx().resident_health() == (0, 0)
 
 
-@pytest.mark.parametrize('pose_threads', [1, 4])
-def test_eimp_lockstep_loop_equals_the_pairs_one_at_a_time(pose_threads):
+def test_native_eimp_lockstep_reference_pair_inside_a_ragged_group():
+    """imp_loop_lockstep_uncertainty (the C++ driver): the reference-captured pair (no pose: 15 iterations, pooled after every scored one,
+    N = 1024 / 1000) between two pairs of other sizes: final kept sets, matches and iteration count are the reference's, strictly; all
+    three equal the Python body.  (The fixtures with pose-driven thresholds were captured with a scripted pose stand-in, which only the
+    Python body can take; the native driver's with_uncertainty path is pinned by the comparison with the single-pair loop below.)"""
+    from helpers import build_case
+    from imp_release_amd import matching as hip_matching
+    from test_gpu_parity import _loop_data
+    name = 'eimp_loop_sliced_n1024'
+    spec, z = load_golden(name)
+    cfg, sd, data = build_case(spec, DEV)
+    m = make_hip_model(spec, cfg, sd)
+    datas = [_loop_dict(synthetic.make_correlated_pair(700, 640, seed=71)), _loop_data(data), _loop_dict(synthetic.make_correlated_pair(1300, 1210, seed=72))]
+    kw = dict(with_uncertainty=bool(spec.get('with_uncertainty', False)))
+    with torch.no_grad():
+        py = hip_matching.matching_iterative_uncertainty_lockstep(datas, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, native=False, **kw)
+        nat = hip_matching.matching_iterative_uncertainty_lockstep(datas, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, native=True, **kw)
+    p0, p1, nk0, nk1, i0, ms0, R, t, nit = nat[1]
+    assert nit == int(z['n_iter']) and R is None
+    assert np.array_equal(p0, z['pts0_final']) and np.array_equal(p1, z['pts1_final']), f'{name}: final keypoint sets'
+    assert np.array_equal(i0, z['indices0']), f'{name}: returned indices ({(i0 != z["indices0"]).sum()} differ)'
+    assert np.abs(ms0.astype(np.float64) - z['mscores0']).max() <= TOL
+    for b in range(3):
+        _same_eimp_result(py[b], nat[b], f'pair {b} (Python body vs native)')
+    assert m._ensure_ctx().resident_health() == (0, 0)
+
+
+@pytest.mark.parametrize('pose_threads,native', [(1, False), (4, False), (4, True), (1, True)])
+def test_eimp_lockstep_loop_equals_the_pairs_one_at_a_time(pose_threads, native):
     """4 two-view pairs of different sizes and difficulty through the EIMP loop together (GPU pose step, with_uncertainty: the pool
     threshold of a pair follows its own inlier ratio) = each pair through matching_iterative_uncertainty alone"""
     from imp_release_amd import matching as hip_matching, pose as gpose
@@ -360,7 +387,7 @@ def test_eimp_lockstep_loop_equals_the_pairs_one_at_a_time(pose_threads):
     kw = dict(with_uncertainty=True, estimate_pose=gpose.estimate_pose)
     with torch.no_grad():
         solo = [hip_matching.matching_iterative_uncertainty(d, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, **kw) for d in datas]
-        together = hip_matching.matching_iterative_uncertainty_lockstep(datas, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, pose_threads=pose_threads, **kw)
+        together = hip_matching.matching_iterative_uncertainty_lockstep(datas, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, pose_threads=pose_threads, native=native, **kw)
     print('exit iterations:', [s_[8] for s_ in solo], 'kept:', [(s_[0].shape[0], s_[1].shape[0]) for s_ in solo])
     for b, (a, c) in enumerate(zip(solo, together)):
         _same_eimp_result(a, c, f'pair {b}')

@@ -80,8 +80,15 @@ def main():
     torch.cuda.synchronize(); t0 = time.perf_counter()
     table = eval_loop.run_pairs_sharded(m, provider, a.pairs, **kw)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    health = []
+    for r_ in reps:
+        try:
+            h_ = r_._ensure_ctx().resident_health(raise_on_timeout=False)
+            health.append(list(h_) if h_ is not False else 'voided')
+        except Exception as ex:                      # noqa: BLE001
+            health.append(str(ex)[:60])
     if rank == 0:
-        print(json.dumps({'model': a.model, 'pairs': a.pairs, 'n_gpus': world, 'kpts': a.kpts, 'workers_per_gpu': a.workers, 'pose': a.pose, 'weights': a.weights, 'pairs_per_s': a.pairs / dt,
+        print(json.dumps({'resident_health': health, 'model': a.model, 'pairs': a.pairs, 'n_gpus': world, 'kpts': a.kpts, 'workers_per_gpu': a.workers, 'pose': a.pose, 'weights': a.weights, 'pairs_per_s': a.pairs / dt,
                           'includes': 'H2D upload of every pair on the host path of each rank (pairs pre-generated)',
                           'report': eval_loop.aggregate(table)}))
     if world > 1:

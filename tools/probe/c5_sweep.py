@@ -1,0 +1,42 @@
+"""configs[4] loops on the harder synthetic set: pairs/s over (lockstep, workers) - steady state (1200+ evaluations over 96 distinct scenes)"""
+import sys, time, json
+import numpy as np
+import torch
+sys.path.insert(0, '.')
+import bench as B
+from imp_release_amd import synthetic, eval_loop, pose as gpose
+
+dev = torch.device('cuda', 0)
+n_eval, n_distinct = int(sys.argv[1]) if len(sys.argv) > 1 else 1200, 96
+host_pairs = [synthetic.make_hard_two_view_pair(seed=7000 + i) for i in range(n_distinct)]
+UP = ('keypoints0', 'keypoints1', 'scores0', 'scores1', 'descriptors0', 'descriptors1')
+pinned = [{k: torch.from_numpy(pr[k]).pin_memory() for k in UP} for pr in host_pairs]
+
+
+def provider(pid):
+    pr = host_pairs[pid % n_distinct]
+    dd = {k: pinned[pid % n_distinct][k].to(dev, non_blocking=True) for k in UP}
+    dd['image0'] = dd['image1'] = torch.empty(pr['image_shape'], device='meta')
+    dd['pts0_cpu'], dd['pts1_cpu'] = pr['keypoints0'][0], pr['keypoints1'][0]
+    dd.update({k: pr[k] for k in ('K0', 'K1', 'T_0to1', 'E')})
+    return dd
+
+
+import imp_release_amd as P
+cfg = {'descriptor_dim': 256, 'sinkhorn_iterations': 20, 'match_threshold': 0.2, 'with_sinkhorn': True, 'n_layers': 15,
+       'GNN_layers': ['self', 'cross'] * 15, 'ac_fn': 'relu', 'norm_fn': 'in', 'n_min_tokens': 256}
+grid = [(1, 3), (2, 2), (2, 3), (2, 4), (3, 2), (3, 3), (4, 1), (4, 2), (4, 3)]
+for name in ('DGNNS', 'AdaGMN'):
+    sd = synthetic.make_state_dict(cfg, name, seed=0, bin_score=synthetic.MATCHING_BIN_SCORE, style='matching')
+    mm = getattr(P, name)(cfg).eval()
+    mm.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    mm = mm.to(dev)
+    reps = eval_loop.replicate(mm, 4)
+    for ls, w in grid:
+        kw = dict(eimp=name == 'AdaGMN', estimate_pose=gpose.estimate_pose, workers=w, lockstep=ls, replicas=reps[:w])
+        eval_loop.run_pairs_sharded(mm, provider, 4 * ls * w, **kw)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        table = eval_loop.run_pairs_sharded(mm, provider, n_eval, **kw)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        rep = eval_loop.aggregate(table)
+        print(f'{name:7s} lockstep {ls} x workers {w}: {n_eval / dt:7.1f} pairs/s   auc@5 {rep["auc@5"]:.2f} n_it {rep["n_iterations"]:.2f}', flush=True)
