@@ -213,7 +213,10 @@ def batch1_latencies(dev, args):
             mm = model_of(name, eval_config(15, 20), bin_score=synthetic.MATCHING_BIN_SCORE, style='matching')
             # 4 pairs advance in lock step as one ragged batch (the native drivers imp_loop_lockstep / imp_loop_lockstep_uncertainty: one launch
             # per layer for all of them, per-pair early exit; EIMP: per-pair pooling inside the batch), 3 such groups in flight
-            kw = dict(eimp=name == 'AdaGMN', estimate_pose=gpose.estimate_pose, workers=3, lockstep=4)
+            # 4 groups in flight; the pairs of every window of n_distinct consecutive evaluations are grouped by size (a loader's look-ahead;
+            # within a window no scene repeats)
+            kw = dict(eimp=name == 'AdaGMN', estimate_pose=gpose.estimate_pose, workers=4, lockstep=4, group_similar=n_distinct,
+                      pair_cost=lambda pid: host_pairs[pid % n_distinct]['keypoints0'].shape[1] * host_pairs[pid % n_distinct]['keypoints1'].shape[1])
             reps = eval_loop.replicate(mm, kw['workers'])
             kw['replicas'] = reps
             eval_loop.run_pairs_sharded(mm, provider, 24, **kw)                                     # warm-up (workspaces)
@@ -231,7 +234,7 @@ def batch1_latencies(dev, args):
             rep['n_iterations_histogram'] = {int(k_): int(v_) for k_, v_ in zip(*np.unique(nit, return_counts=True))}
             out[f'c5_{tag}_report'] = rep
             # the round-3 schedule (single pairs, 3 in flight) on the same set, for the record
-            kw3 = dict(eimp=name == 'AdaGMN', estimate_pose=gpose.estimate_pose, workers=3, replicas=reps)
+            kw3 = dict(eimp=name == 'AdaGMN', estimate_pose=gpose.estimate_pose, workers=3, replicas=reps[:3])
             eval_loop.run_pairs_sharded(mm, provider, 12, **kw3)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -242,7 +245,7 @@ def batch1_latencies(dev, args):
             del mm, reps
         out['c5_note'] = (f'BASELINE configs[4] on ONE GPU: {n_eval} evaluations of matching_iterative (imp: DGNNS) / matching_iterative_uncertainty (eimp: AdaGMN, adaptive '
                           f'pooling, with_uncertainty as eval/eval_imp.py:95-105), 4 pairs in lock step as one ragged batch (imp_loop_lockstep / imp_loop_lockstep_uncertainty), '
-                          f'3 groups in flight; *_single_pairs_3_in_flight_* = one pair per call, 3 in flight ({n_eval // 4} evaluations); over {n_distinct} '
+                          f'4 groups in flight, groups formed by size inside windows of {n_distinct} consecutive evaluations; *_single_pairs_3_in_flight_* = one pair per call, 3 in flight ({n_eval // 4} evaluations); over {n_distinct} '
                           'distinct two-view synthetic scenes (N ~ U(1000, 2048) keypoints per image, overlap 0.2-0.8, pixel noise 0.5-2, 30-70 % look-alike '
                           'outliers, known relative pose), 15 iterations, early exit on pose convergence, pose step = csrc/pose.hip in the estimate_pose slot (NOT '
                           "OpenCV MAGSAC), H2D upload of every pair included; report = eval/eval_imp.py:213-227's numbers with the "

@@ -1828,6 +1828,12 @@ int imp_loop_lockstep(imp_ctx* c, int B, const int32_t* n0v, const int32_t* n1v,
     if (with_pose && !c->lp_workers) c->lp_workers = new PoseWorkers(pose_threads < B ? B : pose_threads, c->device);
     int64_t* const h_idx = reinterpret_cast<int64_t*>(c->lp_pin);
     float* const h_ms = reinterpret_cast<float*>(c->lp_pin + c->lp_cap * sizeof(int64_t));
+    // When does a pair's exit test see its pose estimate?  Deferred (rounds 4a: the estimate of scored iteration k runs beside the next two
+    // iterations' layers and decides at the next scored iteration - right when an estimate costs more than two iterations of layers) or
+    // immediately (the group waits for this iteration's estimates, which run side by side: nothing is computed for a pair after its exit).
+    // The results are the same; IMP_LOOP_IMMEDIATE=0 / 1 overrides the default.
+    static const int immediate_env = [] { const char* e = getenv("IMP_LOOP_IMMEDIATE"); return e ? atoi(e) : -1; }();
+    const bool immediate = with_pose && (immediate_env < 0 ? true : immediate_env != 0);
 
     std::vector<LoopPair> P(B);
     struct WaitAll {                                    // no return path may leave a pose worker behind that still reads the caller's arrays
@@ -1898,7 +1904,7 @@ int imp_loop_lockstep(imp_ctx* c, int B, const int32_t* n0v, const int32_t* n1v,
         HIP_TRY(hipMemcpyAsync(h_idx, c->lp_idx, need * sizeof(int64_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(h_ms, c->lp_ms, need * sizeof(float), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(c->lp_ev, st));
-        if (it + 1 < n_iterations && (rc = run_two_layers(it + 1))) return rc;
+        if (!immediate && it + 1 < n_iterations && (rc = run_two_layers(it + 1))) return rc;
         HIP_TRY(hipEventSynchronize(c->lp_ev));
         if ((rc = resident_health(c))) return rc;                                  // a voided launch: the caller runs the group again
         bool retired = false;
@@ -1939,6 +1945,9 @@ int imp_loop_lockstep(imp_ctx* c, int B, const int32_t* n0v, const int32_t* n1v,
                 q.pend = job;
             }
         }
+        if (immediate)                                                             // IMP_LOOP_IMMEDIATE: this iteration's estimates decide now (they ran side by side)
+            for (int b = 0; b < B; ++b)
+                if (P[b].live && resolve(b)) retired = true;
         bool any = false;
         for (int b = 0; b < B; ++b) any = any || P[b].live;
         if (!any) break;

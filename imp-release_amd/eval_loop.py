@@ -113,7 +113,8 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
                       match_ratio: float = 0.1, min_kpts: int = 25, error_th: float = 1.0,
                       stop_criteria: Optional[dict] = None, estimate_pose=None, group=None, workers: int = 1,
                       replicas: Optional[Sequence] = None, lockstep: int = 1, schedule: str = 'block',
-                      pair_cost: Optional[Callable[[int], float]] = None, with_uncertainty: Optional[bool] = None) -> np.ndarray:
+                      pair_cost: Optional[Callable[[int], float]] = None, with_uncertainty: Optional[bool] = None,
+                      group_similar: int = 0) -> np.ndarray:
     """-> [n_pairs, len(SUMMARY_COLUMNS)] summary table, identical on every rank.  ``pair_provider(pair_id)`` returns the reference's
     per-pair ``data`` dict (GPU tensors + pts*_cpu / K*), exactly what eval/matching.py consumes.
     ``workers`` > 1: that many pairs in flight on this rank (see module docstring); ``replicas`` may pass pre-built
@@ -126,6 +127,9 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
     meets a keypoint exactly on a threshold / lower-median boundary the kept set can differ by that keypoint (11 of 96 pairs of the
     harder synthetic set - tools/probe/eimp_lockstep_diff.py -; 1200 evaluations over 96 of them: AUC@5 70.28 alone, 70.01 in groups of 4,
     mean n_iterations 8.63 / 8.72; the IMP loop has no such decision and its report is identical).
+    ``group_similar`` = W > 0 (with ``lockstep`` > 1 and ``pair_cost``): every window of W consecutive pairs of this rank is taken in
+    descending cost order - what a loader with a look-ahead of W pairs can do - so that the pairs of a group have similar sizes (a group is
+    padded to its largest pair and advances at that pair's pace); rows stay in pair-id order.
     ``with_uncertainty`` (EIMP): pool threshold 0.2 x the pose estimate's inlier ratio (eval/matching.py:243-247); default = ``eimp``,
     as eval/eval_imp.py:95-105 passes its one ``use_uncertainty`` switch to both.
     ``schedule``: how pairs map to ranks - 'block' (contiguous blocks, :func:`imp_release_amd.dist.shard_range`) or 'lpt' (longest
@@ -142,6 +146,11 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
         mine = list(range(*shard_range(n_pairs, rank, world)))
     else:
         raise ValueError("schedule: 'block' or 'lpt'")
+    if group_similar and lockstep > 1:
+        if pair_cost is None:
+            raise ValueError('group_similar needs pair_cost(pair_id)')
+        W = max(1, int(group_similar))
+        mine = [i for a in range(0, len(mine), W) for i in sorted(mine[a:a + W], key=lambda i: (-pair_cost(i), i))]
     pos = {pid: i for i, pid in enumerate(mine)}
 
     class _Rows:                                  # rows[pid - s] of the block schedule, for any id list
@@ -219,7 +228,7 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
         if errors:
             raise errors[0]
     if not ddp:
-        return rows.a
+        return rows.a[np.argsort(np.asarray(mine, dtype=np.int64), kind='stable')] if len(mine) else rows.a       # rows in pair-id order
     return gather_rows_by_id(rows.a, mine, n_pairs, device=model._device() if hasattr(model, '_device') else 'cpu', group=group)
 
 

@@ -229,9 +229,27 @@ class FakeModel:
     def _device(self):
         return torch.device('cpu')
 expect = np.stack([eval_loop.summarize(fake_one(provider(i)), False, provider(i)) for i in range(len(costs))])
-for kw in (dict(), dict(schedule='lpt', pair_cost=lambda i: costs[i]), dict(schedule='lpt', pair_cost=lambda i: costs[i], lockstep=3), dict(lockstep=2)):
+groups_seen = []
+def fake_lockstep_rec(datas, m, *a, **k):
+    groups_seen.append([d['pid'] for d in datas])
+    return fake_lockstep(datas, m, *a, **k)
+for kw in (dict(), dict(schedule='lpt', pair_cost=lambda i: costs[i]), dict(schedule='lpt', pair_cost=lambda i: costs[i], lockstep=3), dict(lockstep=2),
+           dict(lockstep=2, group_similar=4, pair_cost=lambda i: costs[i]), dict(lockstep=3, group_similar=100, pair_cost=lambda i: costs[i], schedule='lpt')):
     tab = eval_loop.run_pairs_sharded(FakeModel(), provider, len(costs), **kw)
     assert tab.shape == expect.shape and np.array_equal(np.nan_to_num(tab, nan=-7.0), np.nan_to_num(expect, nan=-7.0)), (rank, kw.keys())
+# group_similar: inside every window of W pairs of a rank the groups are formed in descending cost order (world 1 here: checked on rank 0's own call)
+matching.matching_iterative_lockstep = fake_lockstep_rec
+if rank == 0:
+    import torch.distributed as _d
+    _saved = (_d.is_initialized,)
+    _d.is_initialized = lambda: False            # a single-rank call inside the 2-rank job
+    try:
+        tab = eval_loop.run_pairs_sharded(FakeModel(), provider, 8, lockstep=2, group_similar=4, pair_cost=lambda i: costs[i])
+    finally:
+        _d.is_initialized = _saved[0]
+    assert np.array_equal(np.nan_to_num(tab, nan=-7.0), np.nan_to_num(expect[:8], nan=-7.0))
+    assert groups_seen == [[1, 3], [2, 0], [4, 7], [5, 6]], groups_seen       # windows [0..3] and [4..7], each by descending cost (ties: lower id first)
+matching.matching_iterative_lockstep = fake_lockstep
 parts = pdist.lpt_assignment(costs, world)
 loads = [sum(costs[i] for i in p_) for p_ in parts]
 assert sorted(sum(parts, [])) == list(range(len(costs))) and max(loads) - min(loads) <= max(costs), loads

@@ -25,7 +25,8 @@ def provider(pid):
 import imp_release_amd as P
 cfg = {'descriptor_dim': 256, 'sinkhorn_iterations': 20, 'match_threshold': 0.2, 'with_sinkhorn': True, 'n_layers': 15,
        'GNN_layers': ['self', 'cross'] * 15, 'ac_fn': 'relu', 'norm_fn': 'in', 'n_min_tokens': 256}
-grid = [(1, 3), (2, 2), (2, 3), (2, 4), (3, 2), (3, 3), (4, 1), (4, 2), (4, 3)]
+grid = [(1, 3), (2, 3), (3, 3), (4, 2), (4, 3), (4, 4)] if len(sys.argv) < 3 else [tuple(int(v) for v in g.split('x')) for g in sys.argv[2].split(',')]
+similar = n_distinct if len(sys.argv) > 3 and sys.argv[3] == 'similar' else 0      # (a window of the distinct scenes: a repeated scene never meets itself)
 for name in ('DGNNS', 'AdaGMN'):
     sd = synthetic.make_state_dict(cfg, name, seed=0, bin_score=synthetic.MATCHING_BIN_SCORE, style='matching')
     mm = getattr(P, name)(cfg).eval()
@@ -33,10 +34,11 @@ for name in ('DGNNS', 'AdaGMN'):
     mm = mm.to(dev)
     reps = eval_loop.replicate(mm, 4)
     for ls, w in grid:
-        kw = dict(eimp=name == 'AdaGMN', estimate_pose=gpose.estimate_pose, workers=w, lockstep=ls, replicas=reps[:w])
+        kw = dict(eimp=name == 'AdaGMN', estimate_pose=gpose.estimate_pose, workers=w, lockstep=ls, replicas=reps[:w], group_similar=similar,
+                  pair_cost=lambda pid: host_pairs[pid % n_distinct]['keypoints0'].shape[1] * host_pairs[pid % n_distinct]['keypoints1'].shape[1])
         eval_loop.run_pairs_sharded(mm, provider, 4 * ls * w, **kw)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         table = eval_loop.run_pairs_sharded(mm, provider, n_eval, **kw)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         rep = eval_loop.aggregate(table)
-        print(f'{name:7s} lockstep {ls} x workers {w}: {n_eval / dt:7.1f} pairs/s   auc@5 {rep["auc@5"]:.2f} n_it {rep["n_iterations"]:.2f}', flush=True)
+        print(f'{name:7s} {"similar " if similar else ""}lockstep {ls} x workers {w}: {n_eval / dt:7.1f} pairs/s   auc@5 {rep["auc@5"]:.2f} n_it {rep["n_iterations"]:.2f}', flush=True)
