@@ -32,7 +32,7 @@ for name in ('DGNNS', 'AdaGMN'):
     mm = getattr(P, name)(cfg).eval()
     mm.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     mm = mm.to(dev)
-    reps = eval_loop.replicate(mm, 4)
+    reps = eval_loop.replicate(mm, max(w for _, w in grid))
     for ls, w in grid:
         kw = dict(eimp=name == 'AdaGMN', estimate_pose=gpose.estimate_pose, workers=w, lockstep=ls, replicas=reps[:w], group_similar=similar,
                   pair_cost=lambda pid: host_pairs[pid % n_distinct]['keypoints0'].shape[1] * host_pairs[pid % n_distinct]['keypoints1'].shape[1])
