@@ -192,6 +192,16 @@ def batch1_latencies(dev, args):
         # its estimate_pose slot and the metrics tail (AUC@5/10/20, precision) - IMP and EIMP, >= 1000 pair evaluations each,
         # 3 pairs in flight.  Pairs are two-view consistent synthetic scenes (64 distinct ones, cycled; uploaded per evaluation)
         from imp_release_amd import eval_loop, pose as gpose
+        try:      # one call of the pose step (host arrays in and out) on the planted correspondences of a two-view pair, 1024 five-point samples
+            from imp_release_amd.synthetic import make_two_view_pair as _tv
+            _p = _tv(1800, 1800, seed=77)
+            _tm = np.asarray(_p['true_matches'])                                                   # [M, 2]: the planted correspondences
+            _k0, _k1 = _p['keypoints0'][0][_tm[:, 0]], _p['keypoints1'][0][_tm[:, 1]]
+            out['pose_step_matches'] = int(_k0.shape[0])
+            out['pose_step_ms_per_call'] = timeit(lambda: gpose.estimate_pose(kpts0=_k0, kpts1=_k1, K0=_p['K0'], K1=_p['K1'], norm_thresh=1.0), 30, 3)
+        except Exception as ex:                       # noqa: BLE001 - the key is optional
+            out['pose_step_ms_per_call'] = None
+            out['pose_step_error'] = repr(ex)[:200]
         # round 4: a WORKLOAD, not a best case - 4000 evaluations (the size of YFCC-4000, configs/yfcc_eval_gm.yaml:20) over 128
         # distinct scenes with N ~ U(1000, 2048) keypoints per image, overlap ~ U(0.2, 0.8), pixel noise ~ U(0.5, 2), 30-70 % look-alike
         # outliers among the planted correspondences (synthetic.make_hard_two_view_pair); every timed section runs twice (spread)

@@ -250,6 +250,26 @@ if rank == 0:
     assert np.array_equal(np.nan_to_num(tab, nan=-7.0), np.nan_to_num(expect[:8], nan=-7.0))
     assert groups_seen == [[1, 3], [2, 0], [4, 7], [5, 6]], groups_seen       # windows [0..3] and [4..7], each by descending cost (ties: lower id first)
 matching.matching_iterative_lockstep = fake_lockstep
+# the EIMP loop through the same schedules (round 4: groups via matching_iterative_uncertainty_lockstep, with_uncertainty passed like eval_imp.py does)
+seen_unc = []
+def fake_unc_one(data):
+    idx, ms, R, t, nit = fake_one(data)
+    n = data['n']
+    keep = max(1, n - data['pid'] % 3)
+    return (np.zeros((keep, 2), np.float32), np.zeros((12, 2), np.float32), np.zeros((keep, 2), np.float32), np.zeros((12, 2), np.float32), idx[:keep], ms[:keep], R, t, nit)
+def fake_unc_loop(data, m, *a, **k):
+    seen_unc.append(k.get('with_uncertainty'))
+    return fake_unc_one(data)
+def fake_unc_lockstep(datas, m, *a, **k):
+    seen_unc.append(k.get('with_uncertainty'))
+    return [fake_unc_one(d) for d in datas]
+matching.matching_iterative_uncertainty = fake_unc_loop
+matching.matching_iterative_uncertainty_lockstep = fake_unc_lockstep
+expect_u = np.stack([eval_loop.summarize(fake_unc_one(provider(i)), True, provider(i)) for i in range(len(costs))])
+for kw in (dict(), dict(lockstep=3), dict(lockstep=2, schedule='lpt', pair_cost=lambda i: costs[i], group_similar=4)):
+    tab = eval_loop.run_pairs_sharded(FakeModel(), provider, len(costs), eimp=True, **kw)
+    assert tab.shape == expect_u.shape and np.array_equal(np.nan_to_num(tab, nan=-7.0), np.nan_to_num(expect_u, nan=-7.0)), (rank, 'eimp', kw.keys())
+assert seen_unc and all(v is True for v in seen_unc), seen_unc
 parts = pdist.lpt_assignment(costs, world)
 loads = [sum(costs[i] for i in p_) for p_ in parts]
 assert sorted(sum(parts, [])) == list(range(len(costs))) and max(loads) - min(loads) <= max(costs), loads
