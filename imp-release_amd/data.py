@@ -7,7 +7,8 @@ dataset per pair named ``str(index)``; ``kpt*`` rows are ``(x, y, score)``, ``de
 (``readers.py:28-29``, ``eval/eval_imp.py:46-48``); here the image sizes travel as two integers.
 
 Backends
-  * :class:`H5PairStore`  - the reference file itself (needs ``h5py`` on the host; imported lazily).
+  * :class:`H5PairStore`  - the reference file itself: through ``h5py`` where it is installed, else through the built-in decoder
+    :mod:`imp_release_amd.h5lite` (pure Python: the file-format subset h5py's defaults write - ``backend='h5lite'`` forces it).
   * :class:`NpzPairStore` - a directory of ``pair_<index>.npz`` files with the same field names (+ ``size1``, ``size2`` =
     (H, W) of the two images), written by :func:`write_npz_store`; what the tests and hosts without ``h5py`` use.
 
@@ -57,13 +58,20 @@ class H5PairStore:
     """the reference's ``*.hdf5`` dump; ``image_sizes`` = callable index -> ((H1, W1), (H2, W2)) or a fixed pair (the file
     stores image PATHS, not sizes: pass the sizes, or a function that looks them up, instead of decoding the JPEGs)"""
 
-    def __init__(self, path: str, num_kpt: Optional[int] = None, *, image_sizes):
-        try:
-            import h5py
-        except ImportError as ex:                                      # pragma: no cover - h5py is absent in this image
-            raise ImportError('H5PairStore needs h5py on the host; convert the dump once with '
-                              'imp_release_amd.data.convert_h5_to_npz on a machine that has it, or install h5py') from ex
-        self.f = h5py.File(path, 'r')
+    def __init__(self, path: str, num_kpt: Optional[int] = None, *, image_sizes, backend: str = 'auto'):
+        if backend not in ('auto', 'h5py', 'h5lite'):
+            raise ValueError("backend: 'auto', 'h5py' or 'h5lite'")
+        h5 = None
+        if backend in ('auto', 'h5py'):
+            try:
+                import h5py as h5
+            except ImportError:
+                if backend == 'h5py':
+                    raise
+        if h5 is None:
+            from . import h5lite as h5                                   # no h5py on this host: the built-in decoder
+        self.backend = h5.__name__.rsplit('.', 1)[-1]
+        self.f = h5.File(path, 'r')
         self.num_kpt, self.image_sizes = num_kpt, image_sizes
 
     def __len__(self):
@@ -92,8 +100,8 @@ def write_npz_store(records: Iterable[dict], directory: str) -> int:
     return n
 
 
-def convert_h5_to_npz(h5_path: str, directory: str, *, image_sizes) -> int:
-    store = H5PairStore(h5_path, None, image_sizes=image_sizes)
+def convert_h5_to_npz(h5_path: str, directory: str, *, image_sizes, backend: str = 'auto') -> int:
+    store = H5PairStore(h5_path, None, image_sizes=image_sizes, backend=backend)
     def gen():
         for i in range(len(store)):
             rec = {k: store.f[k][str(i)][()] for k in FIELDS}

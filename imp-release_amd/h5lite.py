@@ -1,0 +1,599 @@
+"""A small read-only HDF5 decoder (pure Python + numpy) for hosts without ``h5py``.
+
+The reference evaluates from ONE HDF5 file written with h5py (``dump/dumper/base_dumper.py:78-111``) and read through the slice
+of the h5py API that ``components/readers.py:8-33`` uses: ``File(path, 'r')[group][name][()]``, ``np.asarray(dataset)``,
+``len(group)``, ``close()``.  This module decodes that file format itself, restated from the published "HDF5 File Format
+Specification" (version 3.0): superblock versions 0-3, version-1 and version-2 object headers (with continuation blocks),
+old-style groups (symbol-table message -> version-1 B-tree -> symbol-table nodes + local heap: what h5py writes by default) and
+new-style compact groups (link messages), dataspaces, the datatypes such dumps hold (fixed-point, IEEE float, fixed-length
+strings, variable-length strings through the global heap: ``h5py.string_dtype``), and the dataset layouts contiguous, compact and
+chunked (version-1 B-tree index; ``deflate`` / ``shuffle`` / ``fletcher32`` filters; with the version-4 layout message of
+``libver='latest'`` files: the single-chunk, implicit and fixed-array indexes).  Anything else (dense groups in a fractal heap,
+the chunk indexes of datasets with unlimited dimensions, compound / array / reference types, external storage, virtual datasets)
+raises ``NotImplementedError`` naming
+the feature - convert such a file once with h5py.
+
+Pinned by ``tests/test_host_cpu.py``: real files written by the HDF5 C library itself (``tools/make_h5_fixture.py`` drives
+``libhdf5`` through ctypes; ``tests/golden/reader_dump*.hdf5``) decode to the arrays they were written from, and
+``imp_release_amd.data.H5PairStore`` on them returns what the reference's own reader returned (``tests/golden/reader_standard.npz``).
+"""
+from __future__ import annotations
+
+import mmap
+import struct
+import zlib
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+_SIG = b'\x89HDF\r\n\x1a\n'
+
+
+class H5FormatError(ValueError):
+    pass
+
+
+class _Datatype:
+    def __init__(self, np_dtype=None, size=0, vlen_string=False):
+        self.np_dtype, self.size, self.vlen_string = np_dtype, size, vlen_string
+
+
+class File:
+    """``File(path)`` (read-only; the mode argument is accepted for h5py compatibility)"""
+
+    def __init__(self, path: str, mode: str = 'r'):
+        if mode != 'r':
+            raise ValueError('h5lite is read-only')
+        self._fh = open(path, 'rb')
+        try:
+            self._m = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ)
+        except ValueError as ex:                                        # empty file
+            self._fh.close()
+            raise H5FormatError(f'{path}: not an HDF5 file (empty)') from ex
+        self.filename = path
+        self._gcol: Dict[int, Dict[int, bytes]] = {}
+        try:
+            self._read_superblock()
+            self._root = Group(self, self._root_addr, '/')
+        except Exception:
+            self.close()
+            raise
+
+    # ------------------------------------------------------------------------------------------------ low level
+    def _u(self, off: int, n: int) -> int:
+        return int.from_bytes(self._m[off:off + n], 'little')
+
+    def _addr(self, off: int) -> Optional[int]:
+        v = self._u(off, self._so)
+        return None if v == (1 << (8 * self._so)) - 1 else v + self._base
+
+    def _read_superblock(self):
+        m = self._m
+        pos = 0
+        while True:                                                      # the superblock may sit at 0, 512, 1024, 2048, ...
+            if pos + 8 > len(m):
+                raise H5FormatError(f'{self.filename}: HDF5 signature not found')
+            if m[pos:pos + 8] == _SIG:
+                break
+            pos = 512 if pos == 0 else pos * 2
+        ver = m[pos + 8]
+        self._base = 0
+        if ver in (0, 1):
+            self._so, self._sl = m[pos + 13], m[pos + 14]
+            p = pos + 24 + (4 if ver == 1 else 0)
+            self._so = int(self._so); self._sl = int(self._sl)
+            base = self._u(p, self._so)
+            self._base = base
+            p += 4 * self._so                                            # base, free-space info, end of file, driver info
+            # root group symbol table entry: link name offset, object header address, cache type, reserved, scratch
+            self._root_addr = self._u(p + self._so, self._so) + self._base
+        elif ver in (2, 3):
+            self._so, self._sl = int(m[pos + 9]), int(m[pos + 10])
+            p = pos + 12
+            self._base = self._u(p, self._so)
+            self._root_addr = self._u(p + 3 * self._so, self._so) + self._base
+        else:
+            raise NotImplementedError(f'{self.filename}: HDF5 superblock version {ver}')
+        if self._so not in (2, 4, 8) or self._sl not in (2, 4, 8):
+            raise H5FormatError(f'{self.filename}: offset / length sizes {self._so} / {self._sl}')
+
+    # ------------------------------------------------------------------------------------------------ object headers
+    def _messages(self, addr: int) -> List[Tuple[int, int, int]]:
+        """-> [(message type, offset of its data, size)] of the object header at `addr`, continuation blocks followed"""
+        m = self._m
+        out: List[Tuple[int, int, int]] = []
+        if m[addr:addr + 4] == b'OHDR':
+            if m[addr + 4] != 2:
+                raise NotImplementedError(f'object header version {m[addr + 4]}')
+            flags = m[addr + 5]
+            p = addr + 6
+            if flags & 0x20:
+                p += 16
+            if flags & 0x10:
+                p += 4
+            nsz = 1 << (flags & 3)
+            chunk0 = self._u(p, nsz)
+            p += nsz
+            blocks = [(p, chunk0)]
+            order = bool(flags & 0x04)
+            while blocks:
+                p, size = blocks.pop(0)
+                end = p + size
+                while p + 4 <= end:
+                    mtype, msize = m[p], self._u(p + 1, 2)
+                    p += 4 + (2 if order else 0)
+                    if p + msize > end:
+                        break
+                    if mtype == 0x10:
+                        ca, cl = self._addr(p), self._u(p + self._so, self._sl)
+                        if m[ca:ca + 4] != b'OCHK':
+                            raise H5FormatError('object header continuation without its signature')
+                        blocks.append((ca + 4, cl - 8))                  # (signature in front, checksum behind)
+                    elif mtype != 0:
+                        out.append((mtype, p, msize))
+                    p += msize
+            return out
+        if m[addr] != 1:
+            raise H5FormatError(f'no object header at {addr:#x}')
+        nmsg = self._u(addr + 2, 2)
+        size = self._u(addr + 8, 4)
+        blocks = [(addr + 16, size)]
+        while blocks and len(out) < 4096:
+            p, size = blocks.pop(0)
+            end = p + size
+            while p + 8 <= end and nmsg > 0:
+                mtype, msize = self._u(p, 2), self._u(p + 2, 2)
+                p += 8
+                nmsg -= 1
+                if mtype == 0x10:
+                    blocks.append((self._addr(p), self._u(p + self._so, self._sl)))
+                elif mtype != 0:
+                    out.append((mtype, p, msize))
+                p += msize
+        return out
+
+    # ------------------------------------------------------------------------------------------------ global heap (variable-length data)
+    def _heap_object(self, caddr: int, index: int) -> bytes:
+        col = self._gcol.get(caddr)
+        if col is None:
+            m = self._m
+            if m[caddr:caddr + 4] != b'GCOL':
+                raise H5FormatError(f'no global heap collection at {caddr:#x}')
+            size = self._u(caddr + 8, self._sl)
+            col = {}
+            p, end = caddr + 8 + self._sl, caddr + size
+            while p + 8 + self._sl <= end:
+                idx = self._u(p, 2)
+                osz = self._u(p + 8, self._sl)
+                if idx == 0:                                             # the free space behind the last object
+                    break
+                d = p + 8 + self._sl
+                col[idx] = bytes(m[d:d + osz])
+                p = d + ((osz + 7) & ~7)
+            self._gcol[caddr] = col
+        return col[index]
+
+    # ------------------------------------------------------------------------------------------------ h5py-like surface
+    def __getitem__(self, name: str):
+        return self._root[name]
+
+    def __contains__(self, name: str) -> bool:
+        return name in self._root
+
+    def keys(self):
+        return self._root.keys()
+
+    def __len__(self):
+        return len(self._root)
+
+    def close(self):
+        m, self._m = getattr(self, '_m', None), None
+        if m is not None:
+            m.close()
+        fh, self._fh = getattr(self, '_fh', None), None
+        if fh is not None:
+            fh.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class Group:
+    def __init__(self, f: File, addr: int, name: str):
+        self._f, self._addr, self.name = f, addr, name
+        self._links: Optional[Dict[str, int]] = None
+
+    def _load(self) -> Dict[str, int]:
+        if self._links is not None:
+            return self._links
+        f = self._f
+        links: Dict[str, int] = {}
+        for mtype, p, size in f._messages(self._addr):
+            if mtype == 0x11:                                            # symbol table: version-1 B-tree of symbol-table nodes + local heap
+                btree, heap = f._addr(p), f._addr(p + f._so)
+                m = f._m
+                if m[heap:heap + 4] != b'HEAP':
+                    raise H5FormatError('group without its local heap')
+                hdata = f._addr(heap + 8 + 2 * f._sl)
+                self._walk_btree(btree, hdata, links)
+            elif mtype == 0x06:                                          # link message (new-style compact group)
+                m = f._m
+                if m[p] != 1:
+                    raise NotImplementedError(f'link message version {m[p]}')
+                flags = m[p + 1]
+                q = p + 2
+                ltype = 0
+                if flags & 0x08:
+                    ltype = m[q]; q += 1
+                if flags & 0x04:
+                    q += 8
+                if flags & 0x10:
+                    q += 1
+                nsz = 1 << (flags & 3)
+                nlen = f._u(q, nsz); q += nsz
+                lname = bytes(m[q:q + nlen]).decode('utf-8'); q += nlen
+                if ltype != 0:
+                    raise NotImplementedError(f'link {lname!r}: only hard links are supported (soft / external links: resolve them with h5py)')
+                links[lname] = f._addr(q)
+            elif mtype == 0x02:                                          # link info: dense storage lives in a fractal heap
+                m = f._m
+                flags = m[p + 1]
+                q = p + 2 + (8 if flags & 1 else 0)
+                if f._addr(q) is not None:
+                    raise NotImplementedError(f'group {self.name!r} stores its links densely (fractal heap + version-2 B-tree: libver="latest" with many '
+                                              'links); h5lite reads symbol-table groups and compact link messages - convert the file with h5py')
+        self._links = links
+        return links
+
+    def _walk_btree(self, addr: Optional[int], heap_data: int, links: Dict[str, int]):
+        f = self._f
+        m = f._m
+        if addr is None:
+            return
+        if m[addr:addr + 4] == b'SNOD':
+            n = f._u(addr + 6, 2)
+            p = addr + 8
+            esz = 2 * f._so + 24
+            for _ in range(n):
+                noff = f._u(p, f._so)
+                oaddr = f._addr(p + f._so)
+                s = heap_data + noff
+                e = m.find(b'\0', s)
+                links[bytes(m[s:e]).decode('utf-8')] = oaddr
+                p += esz
+            return
+        if m[addr:addr + 4] != b'TREE' or m[addr + 4] != 0:
+            raise H5FormatError(f'no group B-tree node at {addr:#x}')
+        n = f._u(addr + 6, 2)
+        p = addr + 8 + 2 * f._so + f._sl                                 # behind the header and key 0
+        for _ in range(n):
+            self._walk_btree(f._addr(p), heap_data, links)
+            p += f._so + f._sl
+        return
+
+    def keys(self):
+        return list(self._load().keys())
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self._load())
+
+    def __contains__(self, name: str) -> bool:
+        try:
+            self[name]
+            return True
+        except KeyError:
+            return False
+
+    def __getitem__(self, name: str):
+        node = self
+        parts = [s for s in name.split('/') if s]
+        if name.startswith('/'):
+            node = self._f._root
+        for i, part in enumerate(parts):
+            if not isinstance(node, Group):
+                raise KeyError(name)
+            links = node._load()
+            if part not in links:
+                raise KeyError(f"{name!r} (no {part!r} in {node.name!r})")
+            addr = links[part]
+            path = (node.name.rstrip('/') + '/' + part)
+            types = {t for t, _, _ in self._f._messages(addr)}
+            node = Dataset(self._f, addr, path) if 0x08 in types else Group(self._f, addr, path)
+        return node
+
+
+class Dataset:
+    def __init__(self, f: File, addr: int, name: str):
+        self._f, self._addr, self.name = f, addr, name
+        self._shape: Tuple[int, ...] = ()
+        self._dt: Optional[_Datatype] = None
+        self._layout = None
+        self._filters: List[Tuple[int, Tuple[int, ...]]] = []
+        m = f._m
+        for mtype, p, size in f._messages(addr):
+            if mtype == 0x01:
+                ver, rank = m[p], m[p + 1]
+                if ver == 1:
+                    q = p + 8
+                elif ver == 2:
+                    q = p + 4
+                    if m[p + 3] == 2:                                    # null dataspace
+                        rank = 0
+                        self._shape = (0,)
+                        continue
+                else:
+                    raise NotImplementedError(f'dataspace message version {ver}')
+                self._shape = tuple(f._u(q + i * f._sl, f._sl) for i in range(rank))
+            elif mtype == 0x03:
+                self._dt = self._datatype(p)
+            elif mtype == 0x08:
+                self._layout = (p, size)
+            elif mtype == 0x0B:
+                self._filters = self._pipeline(p)
+        if self._dt is None or self._layout is None:
+            raise H5FormatError(f'{name}: dataset without a datatype or layout message')
+
+    # ---- messages -------------------------------------------------------------------------------------------------------------------
+    def _datatype(self, p: int) -> _Datatype:
+        f = self._f
+        m = f._m
+        cls, ver = m[p] & 0x0F, m[p] >> 4
+        b0, b1 = m[p + 1], m[p + 2]
+        size = f._u(p + 4, 4)
+        if cls == 0:                                                     # fixed-point
+            order = '>' if b0 & 1 else '<'
+            kind = 'i' if b0 & 0x08 else 'u'
+            if size not in (1, 2, 4, 8):
+                raise NotImplementedError(f'{size}-byte integers')
+            return _Datatype(np.dtype(f'{order}{kind}{size}'), size)
+        if cls == 1:                                                     # floating point (IEEE layouts only)
+            if b0 & 0x40:
+                raise NotImplementedError('VAX byte order')
+            order = '>' if b0 & 1 else '<'
+            if size not in (2, 4, 8):
+                raise NotImplementedError(f'{size}-byte floats')
+            return _Datatype(np.dtype(f'{order}f{size}'), size)
+        if cls == 3:                                                     # fixed-length string
+            return _Datatype(np.dtype(f'S{size}'), size)
+        if cls == 9:                                                     # variable length: strings (sequences are not needed by the dumps)
+            if (b0 & 0x0F) != 1:
+                raise NotImplementedError('variable-length sequences (only variable-length strings are supported)')
+            return _Datatype(None, size, vlen_string=True)
+        names = {2: 'time', 4: 'bit field', 5: 'opaque', 6: 'compound', 7: 'reference', 8: 'enumerated', 10: 'array'}
+        raise NotImplementedError(f'{self.name}: HDF5 datatype class {cls} ({names.get(cls, "?")}, message version {ver})')
+
+    def _pipeline(self, p: int) -> List[Tuple[int, Tuple[int, ...]]]:
+        f = self._f
+        m = f._m
+        ver, n = m[p], m[p + 1]
+        q = p + (8 if ver == 1 else 2)
+        out = []
+        for _ in range(n):
+            fid = f._u(q, 2)
+            if ver == 1 or fid >= 256:
+                nlen = f._u(q + 2, 2); q += 4
+            else:
+                nlen = 0; q += 2
+            ncd = f._u(q + 2, 2); q += 4
+            if ver == 1:
+                nlen = (nlen + 7) & ~7
+            q += nlen
+            cd = tuple(f._u(q + 4 * i, 4) for i in range(ncd))
+            q += 4 * ncd
+            if ver == 1 and ncd & 1:
+                q += 4
+            out.append((fid, cd))
+        return out
+
+    # ---- h5py-like surface ----------------------------------------------------------------------------------------------------------
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def dtype(self):
+        return np.dtype(object) if self._dt.vlen_string else self._dt.np_dtype
+
+    def __len__(self):
+        if not self._shape:
+            raise TypeError('scalar dataset')
+        return self._shape[0]
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._read()
+        return a if dtype is None else a.astype(dtype)
+
+    def __getitem__(self, key):
+        a = self._read()
+        if isinstance(key, tuple) and len(key) == 0:
+            return a
+        return a[key]
+
+    # ---- data -----------------------------------------------------------------------------------------------------------------------
+    def _unfilter(self, raw: bytes, mask: int) -> bytes:
+        for k in range(len(self._filters) - 1, -1, -1):                  # undone in reverse order; bit k of the mask: filter k was skipped
+            if mask & (1 << k):
+                continue
+            fid, cd = self._filters[k]
+            if fid == 1:
+                raw = zlib.decompress(raw)
+            elif fid == 2:
+                esz = cd[0] if cd else self._dt.size
+                n = len(raw) // esz
+                if esz > 1 and n:
+                    raw = np.frombuffer(raw[:n * esz], np.uint8).reshape(esz, n).T.tobytes() + raw[n * esz:]
+            elif fid == 3:
+                raw = raw[:-4]
+            else:
+                raise NotImplementedError(f'{self.name}: HDF5 filter {fid} (only deflate, shuffle and fletcher32 are built in)')
+        return raw
+
+    def _decode(self, raw, count: int) -> np.ndarray:
+        f = self._f
+        dt = self._dt
+        if dt.vlen_string:
+            esz = 4 + f._so + 4
+            out = np.empty(count, dtype=object)
+            for i in range(count):
+                o = i * esz
+                ln = int.from_bytes(raw[o:o + 4], 'little')
+                ca = int.from_bytes(raw[o + 4:o + 4 + f._so], 'little')
+                idx = int.from_bytes(raw[o + 4 + f._so:o + esz], 'little')
+                out[i] = b'' if ca == 0 and idx == 0 else f._heap_object(ca + f._base, idx)[:ln]
+            return out
+        return np.frombuffer(raw, dtype=dt.np_dtype, count=count).copy()
+
+    def _read(self) -> np.ndarray:
+        f = self._f
+        m = f._m
+        if m is None:
+            raise ValueError('the file is closed')
+        p, _ = self._layout
+        ver = m[p]
+        shape = self._shape
+        count = int(np.prod(shape)) if shape else 1
+        esz = (4 + f._so + 4) if self._dt.vlen_string else self._dt.size
+        if ver not in (3, 4):
+            raise NotImplementedError(f'{self.name}: data layout message version {ver} (files written before HDF5 1.6.3)')
+        cls = m[p + 1]
+        if cls == 0:                                                     # compact: the data sit in the message
+            n = f._u(p + 2, 2)
+            return self._decode(bytes(m[p + 4:p + 4 + n]), count).reshape(shape)
+        if cls == 1:                                                     # contiguous
+            addr = f._addr(p + 2)
+            if addr is None:                                             # never written: the fill value (zeros / empty strings)
+                return (np.full(shape, b'', dtype=object) if self._dt.vlen_string else np.zeros(shape, self._dt.np_dtype))
+            return self._decode(m[addr:addr + count * esz], count).reshape(shape)
+        if cls != 2:
+            raise NotImplementedError(f'{self.name}: data layout class {cls} (virtual datasets)')
+        if self._dt.vlen_string:
+            raise NotImplementedError(f'{self.name}: chunked variable-length strings')
+        if ver == 3:
+            nd = m[p + 2]                                                # dataset rank + 1
+            btree = f._addr(p + 3)
+            cdims = tuple(f._u(p + 3 + f._so + 4 * i, 4) for i in range(nd - 1))
+            out = np.zeros(shape, self._dt.np_dtype)
+            if btree is not None:
+                self._walk_chunks(btree, nd, cdims, out)
+            return out
+        # version 4 (libver = 'latest'): flags, dimensionality, dimension size encoded length, chunk dims, index type
+        flags, nd, enc = m[p + 2], m[p + 3], m[p + 4]
+        q = p + 5
+        cdims = tuple(f._u(q + enc * i, enc) for i in range(nd - 1))
+        q += enc * nd
+        itype = m[q]; q += 1
+        if itype == 3:                                                   # fixed array: one element per chunk of the (fixed-size) chunk grid
+            return self._read_fixed_array(f._addr(q + 1), cdims)
+        if itype == 2:                                                   # implicit: unfiltered chunks, all allocated, one after the other
+            addr = f._addr(q)
+            out = np.zeros(shape, self._dt.np_dtype)
+            if addr is not None:
+                cbytes = int(np.prod(cdims)) * esz
+                for k, offs in enumerate(self._chunk_grid(cdims)):
+                    self._place(out, offs, cdims, bytes(m[addr + k * cbytes:addr + (k + 1) * cbytes]))
+            return out
+        if itype != 1:
+            names = {4: 'extensible array', 5: 'version-2 B-tree'}
+            raise NotImplementedError(f'{self.name}: chunk index type {itype} ({names.get(itype, "?")}: datasets with unlimited dimensions in a '
+                                      'libver="latest" file); h5lite reads the version-1 B-tree index of default files and the single-chunk, implicit '
+                                      'and fixed-array indexes - convert the file with h5py')
+        mask = 0
+        if flags & 0x02:                                                 # the single chunk is filtered: its size and filter mask are stored
+            csize = f._u(q, f._sl); mask = f._u(q + f._sl, 4); q += f._sl + 4
+        else:
+            csize = int(np.prod(cdims)) * esz
+        addr = f._addr(q)
+        out = np.zeros(shape, self._dt.np_dtype)
+        if addr is not None:
+            raw = self._unfilter(bytes(m[addr:addr + csize]), mask)
+            blk = np.frombuffer(raw, self._dt.np_dtype, count=int(np.prod(cdims))).reshape(cdims)
+            out[...] = blk[tuple(slice(0, s) for s in shape)]
+        return out
+
+    def _chunk_grid(self, cdims):
+        """the chunk offsets in the order the version-4 indexes number them (row-major over the chunk grid)"""
+        counts = [(s + c - 1) // c for s, c in zip(self._shape, cdims)]
+        for k in range(int(np.prod(counts)) if counts else 1):
+            idx, r = [], k
+            for n in reversed(counts):
+                idx.append(r % n); r //= n
+            yield tuple(i * c for i, c in zip(reversed(idx), cdims))
+
+    def _place(self, out: np.ndarray, offs, cdims, raw: bytes):
+        blk = np.frombuffer(raw, self._dt.np_dtype, count=int(np.prod(cdims))).reshape(cdims)
+        sl = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, cdims, out.shape))
+        out[sl] = blk[tuple(slice(0, s.stop - s.start) for s in sl)]
+
+    def _read_fixed_array(self, hdr: Optional[int], cdims) -> np.ndarray:
+        f = self._f
+        m = f._m
+        out = np.zeros(self._shape, self._dt.np_dtype)
+        if hdr is None:
+            return out
+        if m[hdr:hdr + 4] != b'FAHD':
+            raise H5FormatError(f'{self.name}: no fixed-array header at {hdr:#x}')
+        client, esize, page_bits = m[hdr + 5], m[hdr + 6], m[hdr + 7]
+        nelem = f._u(hdr + 8, f._sl)
+        db = f._addr(hdr + 8 + f._sl)
+        if db is None:
+            return out
+        if m[db:db + 4] != b'FADB':
+            raise H5FormatError(f'{self.name}: no fixed-array data block at {db:#x}')
+        p = db + 6 + f._so
+        per_page = 1 << page_bits
+        csize_len = esize - f._so - 4
+        esz_bytes = int(np.prod(cdims)) * self._dt.size
+
+        def element(q):
+            addr = f._addr(q)
+            if client == 1:
+                return addr, f._u(q + f._so, csize_len), f._u(q + f._so + csize_len, 4)
+            return addr, esz_bytes, 0
+        grid = list(self._chunk_grid(cdims))
+        if nelem > per_page:                                             # paged: bitmap of initialised pages, checksum, then pages (elements + checksum)
+            npages = (nelem + per_page - 1) // per_page
+            bitmap = m[p:p + (npages + 7) // 8]
+            p += (npages + 7) // 8 + 4
+            k = 0
+            for page in range(npages):
+                n_here = min(per_page, nelem - page * per_page)
+                if bitmap[page // 8] & (0x80 >> (page % 8)):
+                    for i in range(n_here):
+                        a, sz, mask = element(p + i * esize)
+                        if a is not None and k + i < len(grid):
+                            self._place(out, grid[k + i], cdims, self._unfilter(bytes(m[a:a + sz]), mask))
+                    p += n_here * esize + 4
+                k += n_here
+            return out
+        for k in range(min(nelem, len(grid))):
+            a, sz, mask = element(p + k * esize)
+            if a is not None:
+                self._place(out, grid[k], cdims, self._unfilter(bytes(m[a:a + sz]), mask))
+        return out
+
+    def _walk_chunks(self, addr: int, nd: int, cdims: Tuple[int, ...], out: np.ndarray):
+        f = self._f
+        m = f._m
+        if m[addr:addr + 4] != b'TREE' or m[addr + 4] != 1:
+            raise H5FormatError(f'{self.name}: no chunk B-tree node at {addr:#x}')
+        level, n = m[addr + 5], f._u(addr + 6, 2)
+        p = addr + 8 + 2 * f._so
+        ksz = 8 + 8 * nd
+        for _ in range(n):
+            csize, mask = f._u(p, 4), f._u(p + 4, 4)
+            offs = tuple(f._u(p + 8 + 8 * i, 8) for i in range(nd - 1))
+            child = f._addr(p + ksz)
+            p += ksz + f._so
+            if level > 0:
+                self._walk_chunks(child, nd, cdims, out)
+                continue
+            raw = self._unfilter(bytes(m[child:child + csize]), mask)
+            blk = np.frombuffer(raw, self._dt.np_dtype, count=int(np.prod(cdims))).reshape(cdims)
+            sl = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, cdims, out.shape))
+            out[sl] = blk[tuple(slice(0, s.stop - s.start) for s in sl)]

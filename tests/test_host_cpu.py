@@ -388,6 +388,9 @@ def test_pair_store_roundtrip_and_feed_dict(tmp_path):
         import h5py  # noqa: F401
     except ImportError:
         with pytest.raises(ImportError, match='h5py'):
+            data.H5PairStore(str(tmp_path / 'x.hdf5'), image_sizes=((480, 640), (480, 640)), backend='h5py')
+        (tmp_path / 'x.hdf5').write_bytes(b'not an hdf5 file' * 64)
+        with pytest.raises(ValueError, match='signature'):
             data.H5PairStore(str(tmp_path / 'x.hdf5'), image_sizes=((480, 640), (480, 640)))
 
 
@@ -429,6 +432,74 @@ def test_pair_stores_vs_the_reference_reader(tmp_path):
             assert tuple(d['image1'].shape) == (1,) + tuple(int(v) for v in z[f'img2_shape_{i}'])
             assert np.array_equal(d['T_0to1'], np.hstack([z[f'R_{i}'], z[f't_{i}'].reshape(3, 1)]))
         assert h5.record(i)['img_path1'] == recs[i]['img_path1'] and h5.record(i)['img_path2'] == recs[i]['img_path2']
+
+
+def test_real_hdf5_dump_through_the_builtin_decoder(tmp_path):
+    """SURVEY §8 f-2, VERDICT r3 'real HDF5 decoding': tests/golden/reader_dump.hdf5 was written by the HDF5 C LIBRARY itself
+    (tools/make_h5_fixture.py drives libhdf5 through ctypes with the calls and defaults h5py makes for dump/dumper/base_dumper.py:78-111:
+    superblock 0, symbol-table groups, contiguous float32 / float64 datasets, variable-length ASCII strings in the global heap) from the
+    records the reference's own reader was run on.  imp_release_amd.h5lite decodes it to exactly those arrays, and H5PairStore on
+    the FILE returns what components/readers.py standard_reader.run returned (tests/golden/reader_standard.npz)."""
+    import os
+    from helpers import GOLD, load_golden, make_reader_records
+    from imp_release_amd import data, h5lite
+    spec, z = load_golden('reader_standard')
+    recs = make_reader_records(spec['seed'])
+    path = os.path.join(GOLD, 'reader_dump.hdf5')
+    with h5lite.File(path) as f:
+        assert sorted(f.keys()) == sorted(data.FIELDS + ('img_path1', 'img_path2')) and len(f['K1']) == len(recs) and 'desc1' in f and 'nope' not in f
+        for i, r in enumerate(recs):
+            for k in data.FIELDS:
+                a = f[k][str(i)][()]
+                assert a.dtype == np.asarray(r[k]).dtype and a.shape == np.asarray(r[k]).shape and np.array_equal(a, r[k]), (k, i)
+                assert np.array_equal(np.asarray(f[k][str(i)]), r[k]) and np.array_equal(f[f'/{k}/{i}'][:5], np.asarray(r[k])[:5])
+            assert f['img_path1'][str(i)][()][0].decode() == r['img_path1'] and f['img_path2'][str(i)].shape == (1,)
+        with pytest.raises(KeyError):
+            f['K1']['17']
+    sizes = lambda i: (recs[i]['size1'], recs[i]['size2'])             # noqa: E731
+    store = data.H5PairStore(path, spec['num_kpt'], image_sizes=sizes, backend='h5lite')
+    assert store.backend == 'h5lite' and len(store) == int(z['n_pairs'])
+    for i in range(len(store)):
+        r = store.record(i)
+        for k in ('K1', 'K2', 'R', 't', 'x1', 'x2', 'desc1', 'desc2', 'e', 'f'):
+            ref = z[f'{k}_{i}']
+            assert r[k].dtype == ref.dtype and np.array_equal(r[k], ref), (i, k)
+        assert r['img_path1'] == recs[i]['img_path1'] and r['img_path2'] == recs[i]['img_path2']
+    store.close()
+    assert data.convert_h5_to_npz(path, str(tmp_path), image_sizes=sizes, backend='h5lite') == len(recs)
+    npz = data.NpzPairStore(str(tmp_path), spec['num_kpt'])
+    assert np.array_equal(npz.record(1)['desc2'], z['desc2_1'])
+
+
+def test_builtin_hdf5_decoder_other_corners_of_the_format():
+    """files of the HDF5 C library with libver='latest' (superblock 3, version-2 object headers with checksummed chunks, compact link
+    messages, version-4 layout messages) and with chunked storage (version-1 B-tree chunk index, shuffle + deflate, edge chunks, an
+    unfiltered chunked dataset, a group spread over several symbol-table nodes); what the decoder does not read it names"""
+    import os
+    from helpers import GOLD, load_golden, make_reader_records
+    from imp_release_amd import h5lite
+    recs = make_reader_records(load_golden('reader_standard')[0]['seed'])
+    ramp = (np.arange(100 * 37, dtype=np.float32).reshape(100, 37) % 17).astype(np.float32)
+    with h5lite.File(os.path.join(GOLD, 'reader_dump_latest.hdf5')) as f:
+        g = f['pair']
+        assert sorted(f.keys()) == ['dense', 'more', 'pair'] and len(g) == 8
+        assert np.array_equal(g['K1'][()], recs[0]['K1']) and np.array_equal(np.asarray(g['kpt1']), recs[0]['kpt1'])
+        assert np.array_equal(g['ramp_single_chunk_deflate'][()], ramp)
+        assert np.array_equal(g['ids_compact_i32'][()], np.arange(-5, 20, dtype=np.int32)) and g['ids_compact_i32'].dtype == np.int32
+        assert np.array_equal(g['counts_i64'][()], np.array([[1, -2, 3], [2 ** 40, 5, -6]]))
+        assert g['path_fixed'][()][0].decode() == recs[0]['img_path1']
+        assert [v.decode() for v in g['paths_vlen'][()]] == [recs[0]['img_path1'], recs[0]['img_path2'], '']
+        assert np.array_equal(f['more/bytes_u8'][()], np.arange(200, dtype=np.uint8)) and np.array_equal(f['/more/shorts_i16'][()], [-300, 7, 300])
+        assert np.array_equal(g['ramp_chunked_shuffle_deflate'][()], ramp)                                       # fixed-array chunk index, filtered
+        assert np.array_equal(f['more/ids_1500_chunks'][()], np.arange(3000, dtype=np.int32) * 3)                # paged fixed array
+        assert np.array_equal(f['more/grid_implicit'][()], np.arange(240, dtype=np.float64).reshape(20, 12))    # implicit index, edge chunks
+        assert np.array_equal(f['more/ids_1100_chunks_deflate_fletcher'][()], np.arange(4400, dtype=np.int16))  # paged, filtered, checksummed
+        with pytest.raises(NotImplementedError, match='densely'):
+            len(f['dense'])
+    with h5lite.File(os.path.join(GOLD, 'reader_dump_chunked.hdf5')) as f:
+        assert np.array_equal(f['ramp'][()], ramp) and f['ramp'].shape == (100, 37)
+        assert np.array_equal(f['ids_chunked_unfiltered'][()], np.arange(50))
+        assert len(f['many']) == 40 and all(np.array_equal(f['many'][str(i)][()], [i, i * i]) for i in range(40))
 
 
 def test_superpoint_align_corners_rule():
