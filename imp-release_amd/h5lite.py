@@ -13,14 +13,14 @@ the chunk indexes of datasets with unlimited dimensions, compound / array / refe
 raises ``NotImplementedError`` naming
 the feature - convert such a file once with h5py.
 
-Pinned by ``tests/test_host_cpu.py``: real files written by the HDF5 C library itself (``tools/make_h5_fixture.py`` drives
-``libhdf5`` through ctypes; ``tests/golden/reader_dump*.hdf5``) decode to the arrays they were written from, and
-``imp_release_amd.data.H5PairStore`` on them returns what the reference's own reader returned (``tests/golden/reader_standard.npz``).
+Pinned by ``tests/test_host_cpu.py``: real files - the dump written by h5py itself (``tools/make_h5_fixture_h5py.py``), the other
+corners of the format by the HDF5 C library through ctypes (``tools/make_h5_fixture.py``); ``tests/golden/reader_dump*.hdf5`` - decode to
+the arrays they were written from, and ``imp_release_amd.data.H5PairStore`` on the dump returns what the reference's own reader returned
+(``tests/golden/reader_standard.npz``).
 """
 from __future__ import annotations
 
 import mmap
-import struct
 import zlib
 from typing import Dict, List, Optional, Tuple
 

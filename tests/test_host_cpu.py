@@ -435,9 +435,9 @@ def test_pair_stores_vs_the_reference_reader(tmp_path):
 
 
 def test_real_hdf5_dump_through_the_builtin_decoder(tmp_path):
-    """SURVEY §8 f-2, VERDICT r3 'real HDF5 decoding': tests/golden/reader_dump.hdf5 was written by the HDF5 C LIBRARY itself
-    (tools/make_h5_fixture.py drives libhdf5 through ctypes with the calls and defaults h5py makes for dump/dumper/base_dumper.py:78-111:
-    superblock 0, symbol-table groups, contiguous float32 / float64 datasets, variable-length ASCII strings in the global heap) from the
+    """SURVEY §8 f-2, VERDICT r3 'real HDF5 decoding': tests/golden/reader_dump.hdf5 was written by h5py ITSELF (3.3.0 / HDF5 1.10.6, found
+    under an Anaconda interpreter of the build image: tools/make_h5_fixture_h5py.py) with the statements of dump/dumper/base_dumper.py:85-111
+    (superblock 0, symbol-table groups, contiguous float32 / float64 datasets, variable-length ASCII strings in the global heap) from the
     records the reference's own reader was run on.  imp_release_amd.h5lite decodes it to exactly those arrays, and H5PairStore on
     the FILE returns what components/readers.py standard_reader.run returned (tests/golden/reader_standard.npz)."""
     import os

@@ -1,17 +1,15 @@
 """Writes REAL HDF5 files in the reference's dump layout with the HDF5 C library itself (libhdf5 through ctypes - what h5py wraps;
 h5py is not installed here), for the tests of imp_release_amd.h5lite / data.H5PairStore:
 
-    python tools/make_h5_fixture.py            ->  tests/golden/reader_dump.hdf5, tests/golden/reader_dump_latest.hdf5
+    python tools/make_h5_fixture.py            ->  tests/golden/reader_dump_latest.hdf5, tests/golden/reader_dump_chunked.hdf5
 
-* reader_dump.hdf5: the records of tests/helpers.make_reader_records(seed of tests/golden/reader_standard.npz) exactly as
-  dump/dumper/base_dumper.py:78-111 writes them with h5py's defaults: one group per field, one contiguous dataset per pair
-  named str(index), float32 features / float64 geometry, image paths as variable-length ASCII strings of shape [1]
-  (h5py.string_dtype(encoding='ascii')).  File-format defaults = libver 'earliest': superblock 0, version-1 object headers,
-  symbol-table groups.  The reference's own reader was run on these records (tools/make_golden.py case_reader ->
-  reader_standard.npz), so the file pins real HDF5 decoding against the reference's outputs.
-* reader_dump_latest.hdf5: the first pair again with libver='latest' (superblock 3, version-2 object headers, compact link
-  messages), one chunked + shuffle + deflate dataset, one single-chunk dataset, one compact dataset, one fixed-length string,
-  integer types - the other corners of the format the decoder claims.
+(The dump itself, tests/golden/reader_dump.hdf5, is written by h5py with the statements of the reference's dumper:
+tools/make_h5_fixture_h5py.py.  This script covers the corners of the format that dump does not touch.)
+* reader_dump_latest.hdf5: libver='latest' (superblock 3, version-2 object headers, compact link messages, a dense group), the
+  version-4 layout message with the single-chunk, fixed-array (plain, paged, filtered) and implicit chunk indexes, a compact dataset,
+  fixed- and variable-length strings, integer types.
+* reader_dump_chunked.hdf5: a default (libver 'earliest') file with chunked datasets (version-1 B-tree chunk index, shuffle +
+  deflate, edge chunks, an unfiltered one) and a group large enough for several symbol-table nodes.
 
 Needs a libhdf5 shared library (HDF5_LIB=<path>, default: the one under /opt/conda/lib in the build image).  The product never
 loads it: the fixtures are data."""
@@ -91,27 +89,6 @@ def main():
     from helpers import load_golden, make_reader_records
     spec, _ = load_golden('reader_standard')
     recs = make_reader_records(spec['seed'])
-    out = os.path.join(ROOT, 'tests', 'golden', 'reader_dump.hdf5')
-    f = ok(L.H5Fcreate(out.encode(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT), 'H5Fcreate')
-    for key in ('K1', 'K2', 'R', 'T', 'e', 'f'):                          # dump/dumper/base_dumper.py:86-91
-        g = ok(L.H5Gcreate2(f, key.encode(), H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT), 'H5Gcreate2')
-        for i, r in enumerate(recs):
-            write_array(g, str(i), np.asarray(r[key]))
-        L.H5Gclose(g)
-    for key in ('img_path1', 'img_path2'):                                # :92-98
-        g = ok(L.H5Gcreate2(f, key.encode(), H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT), 'H5Gcreate2')
-        for i, r in enumerate(recs):
-            write_vlen_strings(g, str(i), [r[key]])
-        L.H5Gclose(g)
-    groups = {k: ok(L.H5Gcreate2(f, k.encode(), H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT), 'H5Gcreate2') for k in ('desc1', 'desc2', 'kpt1', 'kpt2')}     # :100-111
-    for i, r in enumerate(recs):
-        for k, g in groups.items():
-            write_array(g, str(i), np.asarray(r[k]))
-    for g in groups.values():
-        L.H5Gclose(g)
-    L.H5Fclose(f)
-    print(out, os.path.getsize(out), 'bytes')
-
     # ---- the other corners ----
     out2 = os.path.join(ROOT, 'tests', 'golden', 'reader_dump_latest.hdf5')
     fapl = ok(L.H5Pcreate(G('H5P_CLS_FILE_ACCESS_ID_g')), 'H5Pcreate')
