@@ -205,6 +205,8 @@ int imp_gather_rows(imp_ctx* ctx, int batch, int n_in, int n_out, int dim, const
  * replayed: the chip-resident Sinkhorn launch is recorded too (its exchange tags live in device memory and advance with every
  * replay; IMP_OT_GRAPH=0: the streaming kernels instead).  Such a graph must not be replayed while another resident launch of the
  * process runs - a collision is reported like any voided resident launch (NaN scores, IMP_E_RESIDENT at the next entry point).
+ * A graph records the exchange protocol the context used at capture time: after an IMP_E_RESIDENT the context has stepped down to a
+ * safer one, and graphs captured before that must be captured again (replaying them would time out again on every replay).
  * Outputs: indices0 int64 [B][n0], mscores0 [B][n0] (+ optional indices1,
  * mscores1, scores [B][n0+1][n1+1], any of which may be NULL). */
 int imp_match_pair(imp_ctx* ctx, int batch, int n0, int n1,
