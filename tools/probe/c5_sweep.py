@@ -1,9 +1,8 @@
 """configs[4] loops on the harder synthetic set: pairs/s over (lockstep, workers) - steady state (1200+ evaluations over 96 distinct scenes)"""
-import sys, time, json
+import os, sys, time
 import numpy as np
 import torch
-sys.path.insert(0, '.')
-import bench as B
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from imp_release_amd import synthetic, eval_loop, pose as gpose
 
 dev = torch.device('cuda', 0)
