@@ -253,7 +253,14 @@ __global__ __launch_bounds__(64) void pose_hypotheses_kernel(const double2* __re
 // the group, its matrices live in LDS), 64 / FP_L samples per wave; up to 10 models per sample, candidate c of sample h lives at slot
 // 10 h + c.  History of this kernel at 1024 samples: one thread per sample with its arrays in scratch memory 1.84 ms, in LDS 0.65 ms,
 // blocked inner loops 0.49 ms (73 % of it the QR iteration of the 10 x 10 action matrix), groups of 16 lanes: see profiles/r03.
-constexpr int FP_L = 64;
+// lanes per minimal sample (a power of two <= 64).  Round 3 (QR iteration: samples diverge by tens of sweeps): one wave per sample was 20 %
+// faster than 16 lanes; with the root finder of round 4 the samples of a wave run nearly in step - the call takes the same 0.24-0.25 ms at
+// 64, 32 and 16 lanes (profiles/r04/pose_lanes_per_sample_r4.log) and four samples per wave load the chip with 256 waves instead of 1024
+// (the loops that run the pose step beside the matcher: +0-4 %)
+#ifndef FP_L_N
+#define FP_L_N 16
+#endif
+constexpr int FP_L = FP_L_N;
 __global__ __launch_bounds__(64) void pose_hypotheses5_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n,
                                                               int H, unsigned seed, double* __restrict__ Eh, int* __restrict__ valid) {
     __shared__ fivept::Work work[64 / FP_L];
