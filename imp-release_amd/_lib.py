@@ -27,7 +27,7 @@ SYMBOLS = [
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
     'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_pool_select_pair', 'imp_masked_commit', 'imp_gather_rows', 'imp_match_pair', 'imp_set_counts', 'imp_match_tail', 'imp_match_tail_scores', 'imp_pool_pair', 'imp_loop_lockstep', 'imp_loop_lockstep_uncertainty', 'imp_op_linear', 'imp_op_layer_gemm', 'imp_op_fused_mlp',
-    'imp_op_attention', 'imp_time_attention', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_range_events', 'imp_tag_wraps', 'imp_time_layer_gemm', 'imp_estimate_pose',
+    'imp_op_attention', 'imp_time_attention', 'imp_time_attention_clock', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_range_events', 'imp_set_range_recovery', 'imp_range_recovered', 'imp_range_take', 'imp_tag_wraps', 'imp_time_layer_gemm', 'imp_estimate_pose',
     'imp_sp_create', 'imp_sp_destroy', 'imp_sp_set_weight', 'imp_sp_finalize', 'imp_sp_detect', 'imp_sp_describe', 'imp_sp_dense', 'imp_sp_op_conv',
 ]
 
@@ -53,8 +53,14 @@ class OperandRangeError(ImpError):
     ``precision='f32'`` for such data."""
 
 
+class ResidentDoesNotFit(ImpError):
+    """IMP_E_NOFIT: a RAGGED batch (set_counts) that the chip-resident Sinkhorn kernel cannot hold; nothing was computed - run the pairs in
+    smaller groups (a single pair always runs).  Not a time-out: :class:`ResidentSinkhornTimeout` is a different class on purpose."""
+
+
 IMP_E_RESIDENT = -6
 IMP_E_RANGE = -7
+IMP_E_NOFIT = -8
 
 
 class ImpLoopPair(C.Structure):
@@ -135,11 +141,15 @@ def lib():
     L.imp_op_fused_mlp.argtypes = [P, I, I, P, P, P, P, P, P, P, P, I, P, P, I, P]
     L.imp_op_attention.argtypes = [P, I, I, I, I, P, P, P, P, P, P]
     L.imp_time_attention.argtypes = [P, I, I, I, C.POINTER(C.c_float), P]
+    L.imp_time_attention_clock.argtypes = [P, I, I, I, C.POINTER(C.c_float), C.POINTER(C.c_float), P]
     L.imp_time_sinkhorn.argtypes = [P, I, I, I, C.POINTER(C.c_float), P]
     L.imp_resident_status.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.imp_resident_health.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.imp_set_resident_verify.argtypes = [P, I]
     L.imp_range_events.argtypes = [P]
+    L.imp_set_range_recovery.argtypes = [P, I]
+    L.imp_range_recovered.argtypes = [P]
+    L.imp_range_take.argtypes = [P, I]
     L.imp_tag_wraps.argtypes = [P]
     L.imp_time_layer_gemm.argtypes = [P, I, I, I, I, I, C.POINTER(C.c_float), P]
     L.imp_estimate_pose.argtypes = [P, P, I, P, P, C.c_double, I, C.c_uint, I, P, P, P, P, P, C.POINTER(C.c_int), I, P]
@@ -216,6 +226,28 @@ class Context:
         stor = config.get('sinkhorn_storage')   # extra config key: 4 (default, fp32) | 3 (3-byte copy for the iterations)
         if stor is not None:
             self._check(self.L.imp_set_sinkhorn_storage(self.handle, int(stor)))
+        # extra config key 'range_recovery' (default True; env IMP_RANGE_RECOVERY=0 turns the default off): the one-shot / tail calls wait for
+        # their own work and re-run a call whose operands left the fp16 range on the fp32 path (include/imp_hip.h imp_set_range_recovery)
+        rr = config.get('range_recovery')
+        if rr is None:
+            rr = os.environ.get('IMP_RANGE_RECOVERY', '1') != '0'
+        self._check(self.L.imp_set_range_recovery(self.handle, 1 if rr else 0))
+        self.range_recovery = bool(rr)
+
+    def set_range_recovery(self, on: bool):
+        self._check(self.L.imp_set_range_recovery(self.handle, 1 if on else 0))
+        self.range_recovery = bool(on)
+
+    def set_precision(self, name: str):
+        self._check(self.L.imp_set_precision(self.handle, 1 if name == 'f16x3' else 0))
+
+    def range_take(self, recovered: bool) -> bool:
+        """after the caller synchronised: did a match kernel of the pass meet non-finite scores?  Clears and counts the event (imp_range_take)"""
+        return bool(self.L.imp_range_take(self.handle, 1 if recovered else 0))
+
+    def range_counts(self):
+        """(calls that met non-finite scores, calls repaired in place on the fp32 path)"""
+        return self.L.imp_range_events(self.handle), self.L.imp_range_recovered(self.handle)
 
     def set_sinkhorn_storage(self, bytes_per_element: int):
         """4 = the Sinkhorn iterations stream the fp32 matrix (default), 3 = the 3-byte copy (include/imp_hip.h)"""
@@ -227,7 +259,7 @@ class Context:
 
     def _check(self, rc):
         if rc != 0:
-            cls = {IMP_E_RESIDENT: ResidentSinkhornTimeout, IMP_E_RANGE: OperandRangeError}.get(rc, ImpError)
+            cls = {IMP_E_RESIDENT: ResidentSinkhornTimeout, IMP_E_RANGE: OperandRangeError, IMP_E_NOFIT: ResidentDoesNotFit}.get(rc, ImpError)
             raise cls(rc, self.L.imp_last_error().decode())
 
     def close(self):
@@ -618,6 +650,12 @@ class Context:
         ms = C.c_float()
         self._check(self.L.imp_time_attention(self.handle, batch, n, reps, C.byref(ms), _stream(self.device)))
         return ms.value
+
+    def time_attention_clock(self, batch, n, reps):
+        """-> (ms per launch, shader clock in MHz the launches ran at; include/imp_hip.h imp_time_attention_clock)"""
+        ms, mhz = C.c_float(), C.c_float()
+        self._check(self.L.imp_time_attention_clock(self.handle, batch, n, reps, C.byref(ms), C.byref(mhz), _stream(self.device)))
+        return ms.value, mhz.value
 
     def time_sinkhorn(self, batch, n, iterations):
         ms = C.c_float()

@@ -349,6 +349,14 @@ __device__ unsigned long long pp_span[8][3];    // per wave of workgroup 0: prol
 #else
 #define PP_CLK(i)
 #endif
+#ifdef PP_TIMELINE    // absolute s_memtime stamps of every wave of workgroup 0 over key tiles [PP_TL_T0, PP_TL_T0 + 4): the per-SIMD timeline
+#define PP_TL_T0 8
+__device__ unsigned long long pp_tl[8][4][8];
+__device__ unsigned pp_hwid[8];
+#define PP_TL(i) { if (tl_on) { const unsigned long long c_ = __builtin_readcyclecounter(); if (lane == 0) pp_tl[wave][t - PP_TL_T0][i] = c_; } }
+#else
+#define PP_TL(i)
+#endif
 #ifndef PP_INIT_IN_ACC
 #define PP_INIT_IN_ACC 1    // S accumulators start at -m_ref (1) or at 0 with the reference subtracted in the vector phase (0)
 #endif
@@ -361,11 +369,32 @@ __device__ unsigned long long pp_span[8][3];    // per wave of workgroup 0: prol
 #ifndef PP_P1
 #define PP_P1 0             // EXPERIMENT (not the product): probabilities enter P.V as ONE half (2 MFMAs per product instead of 3 there);
 #endif                      // DESIGN.md section 4 has what it buys and what it costs in score accuracy
+#ifndef PP_SPREAD
+#define PP_SPREAD 1         // operand reads of k-step i+1 issued BETWEEN the MFMAs of step i (1) instead of as a block in front of them (0)
+#endif
+#ifndef PP_XSM
+#define PP_XSM 0            // probability quarters (16 keys x 32 queries each, of the 4 per tile) whose exp2 / row sum / hi-lo split is NOT done in the vector
+#endif                      // phase but between the MFMAs of the NEXT matrix phase's P.V (needs PP_SPREAD): the matrix wave has idle issue slots, the vector wave is issue-bound
+#ifndef PP_STRAIGHT
+#define PP_STRAIGHT 0       // 1: the staged tiles are requested unconditionally (tiles past the end read as zeros through the descriptor's bounds check), so
+#endif                      // the compiler KNOWS a younger tile's four loads are in flight and waits with vmcnt(7..4) instead of the conservative vmcnt(3..0)
+#ifndef PP_WHATIF
+#define PP_WHATIF 0         // TIMING EXPERIMENTS ONLY (wrong results): 1 = no staging inside the key loop (the ring keeps its first tiles), 2 = no hi / lo
+#endif                      // split of P (pl = ph), 3 = both: what removing that work from the vector phase could buy at most
+#ifndef PP_RCP
+#define PP_RCP 0            // epilogue normalisation: 32 IEEE divisions per lane (0) or one division and 32 multiplications (1: -1 % per launch, results move by <= 1 ulp - enough to flip a knife-edge mutual-nearest-neighbour decision of the fixture ragged_dgnns_l15_b4, so the product keeps the divisions)
+#endif
+#ifndef PP_PREFETCH
+#define PP_PREFETCH 1       // the first V fragments of the next matrix phase are read at the end of the vector phase (before the barrier)
+#endif
+#ifndef PP_PRIO
+#define PP_PRIO 0           // 0: priority 1 around every matrix phase; 1: no priorities; 2: waves 4-7 at priority 1 for the whole loop
+#endif
 #ifndef PP_LOADS_IN_X
 #define PP_LOADS_IN_X 0    // where the global loads of the staged tile are issued: matrix phase (1) or vector phase (0); measured equal
 #endif
 
-template <int DH>
+template <int DH, bool MASKED>
 __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams p, int qtiles, int total_blocks, int nsplit) {
     static_assert(DH == 64 || DH == 32, "head widths of the reference: 256 / 4 and 128 / 4 channels");
     constexpr int NT = 512;
@@ -379,6 +408,9 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 #ifdef PP_PROFILE
     const unsigned long long t_entry = __builtin_readcyclecounter();
 #endif
+    const bool clk_on = p.clk_probe != nullptr && blockIdx.x == 0;      // workgroup-uniform
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (clk_on) { clk_c0 = __builtin_readcyclecounter(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
     float* Ks = smem;                           // [4][KT][KROW]
     float* Vs = Ks + 4 * KT * KROW;             // [4][KT][VROW]   V stays key-major: the PV operand is read transposed
     float* Bs = Vs + 4 * KT * VROW;             // [4][KT]
@@ -403,7 +435,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     const float* Qg = S.q + b * S.sq_b + h * DH;
     const float* Kg = S.k + b * S.sk_b + h * DH;
     const float* Vg = S.v + b * S.sk_b + h * DH;
-    const uint8_t* mk = S.kmask ? S.kmask + (long)b * S.nk : nullptr;
+    const uint8_t* mk = (MASKED && S.kmask) ? S.kmask + (long)b * S.nk : nullptr;      // (a launch without key masks is its own instantiation: no conditional mask load between the staged loads and their waits)
 
     // (round 4: the Q rows are only REQUESTED here; the first two K / V tiles are requested right behind them and the Q split waits
     // for its own loads alone - the prologue used to pay two dependent memory round trips with the matrix pipe idle, Q then K / V, while
@@ -434,7 +466,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     f32x4 rkA[LK], rkB[LK];                        // two staged tiles in flight (even / odd tile index)
     f32x4 rvA[LK], rvB[LK];
     unsigned char rbA = 1, rbB = 1;
-    auto load_tile = [&](int t, f32x4 (&rk)[LK], f32x4 (&rv)[LK], unsigned char& rb) {
+    auto load_tile = [&](int t, f32x4 (&rk)[LK], f32x4 (&rv)[LK], unsigned char& rb) __attribute__((always_inline)) {
         const int k0 = (t0 + t) * KT;
         const int soff = k0 * row_bytes;
 #pragma unroll
@@ -447,14 +479,23 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
             const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsV, koff[j], soff, 0);
             rv[j] = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
         }
+#if PP_STRAIGHT
+        {                                     // no per-lane branch (every wave computes it, wave 0 uses it); the mask byte is loaded only by masked launches
+            const int key = k0 + (tid & (KT - 1));
+            unsigned char keep = key < nk;
+            if (mk != nullptr) { const unsigned char m = mk[key < nk ? key : 0]; keep = keep ? m : 0; }
+            rb = keep;
+        }
+#else
         if (tid < KT) {                       // key-validity byte, turned into the 0 / -inf bias when the tile is stored
             const int key = k0 + tid;
             unsigned char keep = key < nk;
             if (keep && mk) keep = mk[key];
             rb = keep;
         }
+#endif
     };
-    auto store_tile = [&](int slot, const f32x4 (&rk)[LK], const f32x4 (&rv)[LK], const unsigned char rb) {
+    auto store_tile = [&](int slot, const f32x4 (&rk)[LK], const f32x4 (&rv)[LK], const unsigned char rb) __attribute__((always_inline)) {
         float* ks = Ks + slot * KT * KROW;
         float* vs = Vs + slot * KT * VROW;
 #pragma unroll
@@ -487,7 +528,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     float l_run = 0.f;            // this lane's partial row sum, relative to m_ref
     bool need_slow = true;        // wave-uniform: some query of the wave has not seen an unmasked key yet
     load_tile(0, rkA, rvA, rbA);
-    if (nt > 1) load_tile(1, rkB, rvB, rbB);
+    if (PP_STRAIGHT || nt > 1) load_tile(1, rkB, rvB, rbB);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const f32x4 a = qraw[s][0], c = qraw[s][1];
@@ -496,13 +537,16 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
         split8(x, qh[s], ql[s]);
     }
     store_tile(0, rkA, rvA, rbA);
-    if (nt > 2) load_tile(2, rkA, rvA, rbA);
+    if (PP_STRAIGHT || nt > 2) load_tile(2, rkA, rvA, rbA);
     if (nt > 1) store_tile(1, rkB, rvB, rbB);
 #if !PP_LOADS_IN_X
-    if (nt > 3) load_tile(3, rkB, rvB, rbB);
+    if (PP_STRAIGHT || nt > 3) load_tile(3, rkB, rvB, rbB);
 #endif
     PP_BARRIER();
     if (group == 1) PP_BARRIER();
+#if PP_PRIO == 2
+    if (group == 1) __builtin_amdgcn_s_setprio(1);
+#endif
 
     // A operand of O^T += V^T . P^T through the LDS transpose read (ds_read_b64_tr_b16): every 16-lane group hands in
     // the addresses of a [4 keys][16 channels] block (lane i: key i/4, channels 4(i%4)..+3) and lane i receives channel
@@ -514,7 +558,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     // operands of step i+1 are read into the other half of a register double buffer before the MFMAs of step i are
     // issued; sched_barrier(0) pins that order.
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    auto read_v = [&](int slot, int g, f16x8 (&f)[4]) {            // f = {vh[0..DT), vl[0..DT)} of k-step g
+    auto read_v = [&](int slot, int g, f16x8 (&f)[4]) __attribute__((always_inline)) {            // f = {vh[0..DT), vl[0..DT)} of k-step g
         const char* vs = reinterpret_cast<const char*>(Vs + slot * KT * VROW) + vlane + (16 * g) * (VROW * 4);
 #pragma unroll
         for (int i = 0; i < 2 * DT; ++i) {
@@ -524,13 +568,13 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
             f[i] = __builtin_bit_cast(f16x8, __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
         }
     };
-    auto read_k = [&](int slot, int s, f16x8 (&f)[4]) {            // f = {kh[0], kh[1], kl[0], kl[1]} of k-step s
+    auto read_k = [&](int slot, int s, f16x8 (&f)[4]) __attribute__((always_inline)) {            // f = {kh[0], kh[1], kl[0], kl[1]} of k-step s
         const float* ks = Ks + slot * KT * KROW + l31 * KROW + 4 * half + 8 * s;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             f[i] = *reinterpret_cast<const f16x8*>(ks + (i & 1) * 32 * KROW + (i >> 1) * (DH / 2));
     };
-    auto mfma_v = [&](int g, const f16x8 (&f)[4]) {
+    auto mfma_v = [&](int g, const f16x8 (&f)[4]) __attribute__((always_inline)) {
         const int jb = g >> 1, s2 = g & 1;
 #pragma unroll
         for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[DT + d], ph[jb][s2], oacc[d], 0, 0, 0);
@@ -545,7 +589,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     f32x16 cneg;
 #pragma unroll
     for (int r = 0; r < 16; ++r) cneg[r] = 0.f;
-    auto mfma_k = [&](int s, const f16x8 (&f)[4]) {
+    auto mfma_k = [&](int s, const f16x8 (&f)[4]) __attribute__((always_inline)) {
         sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[2], qh[s], (PP_CNEG && PP_INIT_IN_ACC && s == 0) ? cneg : sacc[0], 0, 0, 0);
         sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[3], qh[s], (PP_CNEG && PP_INIT_IN_ACC && s == 0) ? cneg : sacc[1], 0, 0, 0);
         sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], ql[s], sacc[0], 0, 0, 0);
@@ -554,19 +598,87 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
         sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[1], qh[s], sacc[1], 0, 0, 0);
     };
     f16x8 fr[2][4];                                                 // fragment double buffer
-    // O^T += V(slot)^T . P^T ; when kslot >= 0 the first K fragments of the following S^T are prefetched at the end
-    auto pv_mfmas = [&](int slot, int kslot) {
-        read_v(slot, 0, fr[0]);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (g < 3) read_v(slot, g + 1, fr[(g + 1) & 1]);
-            else if (kslot >= 0) read_k(kslot, 0, fr[0]);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_v(g, fr[g & 1]);
-            __builtin_amdgcn_sched_barrier(0);
+    // PP_SPREAD (DH = 64): the operands of k-step i+1 are fetched one fragment at a time BETWEEN the MFMAs of step i (read order 2, 3, 0, 1 =
+    // the order in which the MFMAs of a step first touch them) instead of as a block in front of them
+    constexpr bool SPREAD = PP_SPREAD && DT == 2;
+    constexpr int XSM = SPREAD ? PP_XSM : 0;      // probability quarters 4 - XSM .. 3 (keys 16 q .. 16 q + 15 of the tile) are finished inside the next matrix phase
+    static_assert(XSM == 0 || (PP_INIT_IN_ACC && !PP_PKADD && PP_P1 == 0), "deferred quarters exponentiate the accumulators as they are");
+    static_assert(XSM >= 0 && XSM <= 2, "at most the two quarters of the second key block");
+    // the deferred work of quarter q as 8 micro-steps (pair k = 0..3 of the lane's 8 logits: even step = 2 exp2 + 2 adds, odd step = the hi / lo split
+    // of the pair, 3 instructions), dealt to the gaps between the MFMAs of P.V steps 0..2; step 3 (and step 2 when XSM = 2) consumes the result
+    float xs_a = 0.f, xs_b = 0.f, xs_sum = 0.f;
+    u32x4 xs_h[2], xs_l[2];
+    auto xs_step = [&](int q, int i) __attribute__((always_inline)) {             // q = 2 or 3, i = 0..7
+        const int k = i >> 1;
+        if ((i & 1) == 0) {
+            xs_a = fast_exp2(sacc[1][8 * (q & 1) + 2 * k]);
+            xs_b = fast_exp2(sacc[1][8 * (q & 1) + 2 * k + 1]);
+            xs_sum += xs_a;
+            xs_sum += xs_b;
+        } else {
+            unsigned hi, lo;
+            imp_split2(xs_a, xs_b, hi, lo);
+            xs_h[q & 1][k] = hi; xs_l[q & 1][k] = lo;
+            if (k == 3) {
+                ph[1][q & 1] = __builtin_bit_cast(f16x8, xs_h[q & 1]);
+                pl[1][q & 1] = __builtin_bit_cast(f16x8, xs_l[q & 1]);
+            }
         }
     };
-    auto qk_mfmas = [&](int kslot, bool prefetched) {
+    // slot = index of the MFMA (0..17) of P.V steps 0..2 behind which the micro-step goes
+    auto xs_slot = [&](int slot) __attribute__((always_inline)) {
+        if (XSM == 1) {                            // quarter 3: every second gap of steps 0..2 (8 of 9)
+            if ((slot & 1) == 1 && slot / 2 < 8) xs_step(3, slot / 2);
+        } else if (XSM == 2) {                     // quarter 2 behind MFMAs 0..7 (ready for step 2 = MFMA 12), quarter 3 behind MFMAs 8..15
+            if (slot < 8) xs_step(2, slot);
+            else if (slot < 16) xs_step(3, slot - 8);
+        }
+    };
+    auto read_v1 = [&](int slot, int g, int i, f16x8& f) __attribute__((always_inline)) {
+        const char* a = reinterpret_cast<const char*>(Vs + slot * KT * VROW) + vlane + (16 * g) * (VROW * 4) + (i % DT) * 64 + (i / DT) * (DH * 2);
+        const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a));
+        const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 8 * VROW * 4));
+        f = __builtin_bit_cast(f16x8, __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto read_k1 = [&](int slot, int s, int i, f16x8& f) __attribute__((always_inline)) {
+        const float* ks = Ks + slot * KT * KROW + l31 * KROW + 4 * half + 8 * s;
+        f = *reinterpret_cast<const f16x8*>(ks + (i & 1) * 32 * KROW + (i >> 1) * (DH / 2));
+    };
+#define PP_SB() __builtin_amdgcn_sched_barrier(0)
+    // O^T += V(slot)^T . P^T ; when kslot >= 0 the first K fragments of the following S^T are prefetched at the end; fr[0] already holds
+    // the operands of step 0 when `have0`
+    auto pv_mfmas = [&](int slot, int kslot, bool have0 = false) __attribute__((always_inline)) {
+        if (!have0) read_v(slot, 0, fr[0]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (SPREAD) {
+                const int jb = g >> 1, s2 = g & 1;
+                f16x8 (&f)[4] = fr[g & 1];
+                f16x8 (&n)[4] = fr[(g + 1) & 1];
+                auto rd = [&](int i) { if (g < 3) read_v1(slot, g + 1, i, n[i]); else if (kslot >= 0) read_k1(kslot, 0, i, n[i]); };
+                auto xs = [&](int m) { if (XSM > 0 && g < 3) { xs_slot(6 * g + m); PP_SB(); } };
+                PP_SB();
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[2], ph[jb][s2], oacc[0], 0, 0, 0); PP_SB();
+                rd(2); PP_SB(); xs(0);
+                oacc[DT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[3], ph[jb][s2], oacc[DT - 1], 0, 0, 0); PP_SB();
+                rd(3); PP_SB(); xs(1);
+                if (!PP_P1) { oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], pl[jb][s2], oacc[0], 0, 0, 0); PP_SB(); }
+                rd(0); PP_SB(); xs(2);
+                if (!PP_P1) { oacc[DT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[1], pl[jb][s2], oacc[DT - 1], 0, 0, 0); PP_SB(); }
+                rd(1); PP_SB(); xs(3);
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], ph[jb][s2], oacc[0], 0, 0, 0); PP_SB(); xs(4);
+                oacc[DT - 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[1], ph[jb][s2], oacc[DT - 1], 0, 0, 0); PP_SB(); xs(5);
+                if (XSM > 0 && g == 2) { l_run += xs_sum; xs_sum = 0.f; }
+            } else {
+                if (g < 3) read_v(slot, g + 1, fr[(g + 1) & 1]);
+                else if (kslot >= 0) read_k(kslot, 0, fr[0]);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_v(g, fr[g & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    auto qk_mfmas = [&](int kslot, bool prefetched) __attribute__((always_inline)) {
         if (!prefetched) read_k(kslot, 0, fr[0]);
 #if !(PP_CNEG && PP_INIT_IN_ACC)
         const float c0 = PP_INIT_IN_ACC ? -m_ref : 0.f;         // (0: the compiler feeds the first MFMA of each chain an inline zero)
@@ -577,23 +689,57 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 #endif
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            if (s + 1 < KS) read_k(kslot, s + 1, fr[(s + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_k(s, fr[s & 1]);
-            __builtin_amdgcn_sched_barrier(0);
+            if (SPREAD) {
+                f16x8 (&f)[4] = fr[s & 1];
+                f16x8 (&n)[4] = fr[(s + 1) & 1];
+                auto rd = [&](int i) { if (s + 1 < KS) read_k1(kslot, s + 1, i, n[i]); };
+                constexpr bool CN = PP_CNEG && PP_INIT_IN_ACC;
+                PP_SB();
+                sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[2], qh[s], (CN && s == 0) ? cneg : sacc[0], 0, 0, 0); PP_SB();
+                rd(2); PP_SB();
+                sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[3], qh[s], (CN && s == 0) ? cneg : sacc[1], 0, 0, 0); PP_SB();
+                rd(3); PP_SB();
+                sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], ql[s], sacc[0], 0, 0, 0); PP_SB();
+                rd(0); PP_SB();
+                sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[1], ql[s], sacc[1], 0, 0, 0); PP_SB();
+                rd(1); PP_SB();
+                sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], qh[s], sacc[0], 0, 0, 0); PP_SB();
+                sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[1], qh[s], sacc[1], 0, 0, 0); PP_SB();
+            } else {
+                if (s + 1 < KS) read_k(kslot, s + 1, fr[(s + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_k(s, fr[s & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
     // P = exp2(acc - ref) for the 32 logits of this lane, split into the B-operand fragments; returns their sum
-    auto probabilities = [&](float delta) {
+    auto probabilities = [&](float delta) __attribute__((always_inline)) {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         f32x2 ls2 = {0.f, 0.f};                 // two running sums: v_pk_add_f32 (one instruction per pair of probabilities)
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
+                if (2 * jb + s2 >= 4 - XSM) continue;
                 float pv[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pv[e] = fast_exp2(sacc[jb][8 * s2 + e] - delta);
+#if PP_P1 == 2
+                {   // single-half probabilities whose row sum is taken from the ROUNDED values (v_dot2_f32_f16 against {1, 1}: two halves per instruction,
+                    // exact products, fp32 accumulation): the output stays a convex combination of the value rows, and the fp32 adds disappear
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    u32x4 hw;
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        h2 h; h[0] = (_Float16)pv[e]; h[1] = (_Float16)pv[e + 1];
+                        ls2[0] = __builtin_amdgcn_fdot2(h, h2{(_Float16)1.f, (_Float16)1.f}, ls2[0], false);
+                        hw[e >> 1] = __builtin_bit_cast(unsigned, h);
+                    }
+                    ph[jb][s2] = __builtin_bit_cast(f16x8, hw);
+                    continue;
+                }
+#endif
 #if PP_PKADD
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) ls2 += f32x2{pv[e], pv[e + 1]};
@@ -601,7 +747,12 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ls2[0] += pv[e];
 #endif
+#if PP_WHATIF & 2
+                { u32x4 hw; for (int e = 0; e < 8; e += 2) { imp_f16x2 h; h[0] = (_Float16)pv[e]; h[1] = (_Float16)pv[e + 1]; hw[e >> 1] = __builtin_bit_cast(unsigned, h); }
+                  ph[jb][s2] = pl[jb][s2] = __builtin_bit_cast(f16x8, hw); }
+#else
                 split8(pv, ph[jb][s2], pl[jb][s2]);
+#endif
             }
         return ls2[0] + ls2[1];
     };
@@ -611,19 +762,29 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     unsigned long long tlast = __builtin_readcyclecounter();
     const unsigned long long t_loop = tlast;
 #endif
-    auto tile_step = [&](int t, f32x4 (&rk)[LK], f32x4 (&rv)[LK], unsigned char& rb, f32x4 (&rk2)[LK], f32x4 (&rv2)[LK], unsigned char& rb2) {
+    auto tile_step = [&](int t, f32x4 (&rk)[LK], f32x4 (&rv)[LK], unsigned char& rb, f32x4 (&rk2)[LK], f32x4 (&rv2)[LK], unsigned char& rb2) __attribute__((always_inline)) {
         PP_CLK(7);
-        // =============================== X(t): matrix phase ===============================================
-        __builtin_amdgcn_s_setprio(1);
-#if PP_LOADS_IN_X
-        if (t + 3 < nt) load_tile(t + 3, rk2, rv2, rb2);          // the other register set was converted in Y(t-1)
+#ifdef PP_TIMELINE
+        const bool tl_on = blockIdx.x == 0 && t >= PP_TL_T0 && t < PP_TL_T0 + 4;
 #endif
-        if (t > 0) pv_mfmas((t - 1) & 3, t & 3);
+        PP_TL(0);
+        // =============================== X(t): matrix phase ===============================================
+#if PP_PRIO == 0
+        __builtin_amdgcn_s_setprio(1);
+#endif
+#if PP_LOADS_IN_X
+        if (PP_STRAIGHT || t + 3 < nt) load_tile(t + 3, rk2, rv2, rb2);          // the other register set was converted in Y(t-1)
+#endif
+        if (t > 0) pv_mfmas((t - 1) & 3, t & 3, PP_PREFETCH != 0);
         qk_mfmas(t & 3, t > 0);
+#if PP_PRIO == 0
         __builtin_amdgcn_s_setprio(0);
+#endif
         PP_CLK(0);
+        PP_TL(1);
         PP_BARRIER();
         PP_CLK(1);
+        PP_TL(2);
         // =============================== Y(t): vector phase ===============================================
         if (mk != nullptr || (t0 + t + 1) * KT > nk) {
             const float* bs = Bs + (t & 3) * KT;
@@ -645,7 +806,14 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 #endif
         if (!slow) {
             lsum = probabilities(base);
-            slow = __any(!(lsum < P_SUM_LIMIT));                  // also catches inf / nan
+            bool big = !(lsum < P_SUM_LIMIT);                     // also catches inf / nan
+            if (XSM > 0) {                                        // the deferred quarters have no sum yet: bound their logits instead (2^14 each at most)
+                float dmax = -INFINITY;
+#pragma unroll
+                for (int r = 16 - 8 * XSM; r < 16; ++r) dmax = fmaxf(dmax, sacc[1][r]);
+                big = big || !(dmax - base < 14.f);
+            }
+            slow = __any(big);
         }
         if (slow) {
             float tmax = -INFINITY;
@@ -669,23 +837,49 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
             lsum = probabilities(base + delta);
+            if (XSM > 0) {                                        // the matrix phase will exponentiate these as they are: move them to the new reference here
+#pragma unroll
+                for (int r = 16 - 8 * XSM; r < 16; ++r) sacc[1][r] -= base + delta;
+            }
             need_slow = __any(tmax == -INFINITY && !(lq > 0.f));
         }
         l_run += lsum;
         PP_CLK(2);
+        PP_TL(3);
+#if PP_PREFETCH
+        read_v(t & 3, 0, fr[0]);                                  // operands of the first k-step of X(t+1) (or of the final P.V): V(t) has been in LDS since phase 2t-2
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+#if !(PP_WHATIF & 1)
         if (t + 2 < nt) store_tile((t + 2) & 3, rk, rv, rb);      // this set holds tile t+2 (same parity as t)
 #if !PP_LOADS_IN_X
-        if (t + 4 < nt) load_tile(t + 4, rk, rv, rb);
+        if (PP_STRAIGHT || t + 4 < nt) load_tile(t + 4, rk, rv, rb);
+#endif
 #endif
         PP_CLK(3);
+        PP_TL(4);
         PP_BARRIER();
         PP_CLK(4);
+        PP_TL(5);
     };
+#if PP_STRAIGHT
+    // (the odd tail tile outside the loop: a conditional second step inside it leaves a path on which set A is the YOUNGEST staged tile at the
+    // loop header, and the compiler then waits for every outstanding load - vmcnt(3..0) - before the stores of the first step)
+    for (int t = 0; t + 1 < nt; t += 2) {
+        tile_step(t, rkA, rvA, rbA, rkB, rvB, rbB);
+        tile_step(t + 1, rkB, rvB, rbB, rkA, rvA, rbA);
+    }
+    if (nt & 1) tile_step(nt - 1, rkA, rvA, rbA, rkB, rvB, rbB);
+#else
     for (int t = 0; t < nt; t += 2) {
         tile_step(t, rkA, rvA, rbA, rkB, rvB, rbB);
         if (t + 1 < nt) tile_step(t + 1, rkB, rvB, rbB, rkA, rvA, rbA);
     }
-    pv_mfmas((nt - 1) & 3, -1);
+#endif
+    pv_mfmas((nt - 1) & 3, -1, PP_PREFETCH != 0);
+#ifdef PP_TIMELINE
+    if (blockIdx.x == 0 && lane == 0) pp_hwid[wave] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID: wave [3:0], simd [5:4], cu [11:8], sh, se
+#endif
 #ifdef PP_PROFILE
     const unsigned long long t_loop_end = __builtin_readcyclecounter();
     if (blockIdx.x == 0 && lane == 0)
@@ -796,11 +990,12 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
         // per instruction, before): all 256 workgroups write their 64-KB tile at the same moment with the matrix pipe idle
         constexpr int LDP = DH + 4, LPR = DH / 4, RPI = 64 / LPR;
         float* otp = smem + wave * 32 * LDP;
+        const float inv_l = 1.0f / l_tot;
 #pragma unroll
         for (int d = 0; d < DT; ++d)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                otp[l31 * LDP + d * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = oacc[d][r] / l_tot;
+                otp[l31 * LDP + d * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = PP_RCP ? oacc[d][r] * inv_l : oacc[d][r] / l_tot;
         if (S.lse && half == 0) {
             const int qrow = q0 + wave * 32 + l31;
             if (qrow < nq) S.lse[((long)b * IMP_NUM_HEADS + h) * S.nq + qrow] = m_ref * (1.0f / LOG2E) + logf(l_tot);
@@ -816,6 +1011,11 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
             if (qrow < nq) *reinterpret_cast<f32x4*>(Og + (long)qrow * p.ldo + pc4) = v;
         }
     }
+    if (clk_on && threadIdx.x == 0) {           // (wave 0 of workgroup 0: the others finish within a few hundred cycles of it)
+        __builtin_amdgcn_s_waitcnt(0);
+        p.clk_probe[0] += __builtin_readcyclecounter() - clk_c0;
+        p.clk_probe[1] += __builtin_amdgcn_s_memrealtime() - clk_r0;
+    }
 #ifdef PP_PROFILE
     __builtin_amdgcn_s_waitcnt(0);              // the stores of this wave are out
     if (blockIdx.x == 0 && lane == 0) {
@@ -829,8 +1029,14 @@ hipError_t launch_pp(const AttnParams& p, int batch, int maxq, int nsplit, hipSt
     const int qtiles = (maxq + 255) / 256;
     const int total = qtiles * IMP_NUM_HEADS * p.nside * batch * nsplit;
     const size_t lds = (size_t)(4 * KT * (DH + 4) + 4 * KT * (DH + 16) + 4 * KT) * sizeof(float);
-    if (hipError_t e = imp_grant_dynamic_lds((const void*)attn_f16x3_pp_kernel<DH>, lds)) return e;
-    hipLaunchKernelGGL((attn_f16x3_pp_kernel<DH>), dim3(total), dim3(512), lds, stream, p, qtiles, total, nsplit);
+    const bool masked = p.side[0].kmask != nullptr || (p.nside == 2 && p.side[1].kmask != nullptr);
+    if (masked) {
+        if (hipError_t e = imp_grant_dynamic_lds((const void*)attn_f16x3_pp_kernel<DH, true>, lds)) return e;
+        hipLaunchKernelGGL((attn_f16x3_pp_kernel<DH, true>), dim3(total), dim3(512), lds, stream, p, qtiles, total, nsplit);
+    } else {
+        if (hipError_t e = imp_grant_dynamic_lds((const void*)attn_f16x3_pp_kernel<DH, false>, lds)) return e;
+        hipLaunchKernelGGL((attn_f16x3_pp_kernel<DH, false>), dim3(total), dim3(512), lds, stream, p, qtiles, total, nsplit);
+    }
     return hipGetLastError();
 }
 

@@ -58,6 +58,9 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES == 4 ? 2 : 1)) void attn_f32_k
     const int nq = imp_count(p.rc, S.qimg, b, S.nq), nk = imp_count(p.rc, S.kimg, b, S.nk);      // ragged batches: this pair's own counts; S.nq / S.nk = the padded layout
     const int q0 = qt * (NWAVES * 32);
     if (q0 >= nq || nk <= 0) return;
+    const bool clk_on = p.clk_probe != nullptr && blockIdx.x == 0;      // timing hook (imp_kernels.h AttnParams::clk_probe)
+    unsigned long long clk_c0 = 0, clk_r0 = 0;
+    if (clk_on) { clk_c0 = __builtin_readcyclecounter(); clk_r0 = __builtin_amdgcn_s_memrealtime(); }
 
     const float* Qg = S.q + b * S.sq_b + h * DH;
     const float* Kg = S.k + b * S.sk_b + h * DH;
@@ -257,6 +260,11 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES == 4 ? 2 : 1)) void attn_f32_k
             const int qrow = q0 + wave * 32 + qi;
             if (qrow < nq) Og[(long)qrow * p.ldo + l31] = ot[qi * LDO + l31];
         }
+    }
+    if (clk_on && threadIdx.x == 0) {
+        __builtin_amdgcn_s_waitcnt(0);
+        p.clk_probe[0] += __builtin_readcyclecounter() - clk_c0;
+        p.clk_probe[1] += __builtin_amdgcn_s_memrealtime() - clk_r0;
     }
 }
 

@@ -120,6 +120,9 @@ struct AttnParams {
     int kv_planes;         // EXPERIMENT (ping-pong kernel only): k / v rows hold, per head, [dh hi halves | dh lo halves] (the split-half image the
                            // kernel otherwise builds while staging) in the bytes of the head's dh floats: staged by plain copy
     RaggedCounts rc;       // per-pair query / key counts (no key split, no key mask with it)
+    // timing hook (imp_time_attention_clock; null in the product path): workgroup 0 adds its lifetime to [0] in shader cycles (s_memtime) and to
+    // [1] in ticks of the constant 100 MHz counter (s_memrealtime): [0] / [1] x 100 MHz = the clock the kernel really ran at
+    unsigned long long* clk_probe;
 };
 // in place: the dh-float head segments of columns [col0, col0 + 4 dh) of `rows` rows -> [dh hi halves | dh lo halves]
 hipError_t launch_attn_kv_planes(float* base, long rows, int ld, int col0, int dh, hipStream_t stream);

@@ -383,9 +383,7 @@ class GM(nn.Module):
                 return [r]
             try:
                 return [self._run_iterations_chunk(chunk, p, only_last, False, (counts[0][sl], counts[1][sl]))]
-            except _lib.ImpError as e:
-                if 'chip-resident' not in str(e):
-                    raise
+            except _lib.ResidentDoesNotFit:            # (by class, not by message: a time-out of the resident kernel is another error and is not split)
                 mid = (lo + hi) // 2
                 return run(lo, mid) + run(mid, hi)
 
@@ -402,7 +400,19 @@ class GM(nn.Module):
         if counts is not None:
             ctx.set_counts(*counts)
         try:
-            return self._run_iterations_body(ctx, data, p, only_last, want_scores, counts is not None)
+            out = self._run_iterations_body(ctx, data, p, only_last, want_scores, counts is not None)
+            one_shot = only_last and len(self.gnn.names) == 2 * self.n_layers        # (imp_match_pair repairs itself inside the call)
+            if getattr(ctx, 'range_recovery', False) and not one_shot and ctx.precision == 'f16x3' and not torch.cuda.is_current_stream_capturing():
+                # the pass was composed from layer calls: an operand beyond the fp16 range poisoned the descriptors BEFORE the tails saw them, so
+                # the whole pass runs again on the fp32 MFMA path (include/imp_hip.h imp_range_take); costs one synchronisation per pass
+                torch.cuda.current_stream(ctx.device).synchronize()
+                if ctx.range_take(True):
+                    ctx.set_precision('f32')
+                    try:
+                        out = self._run_iterations_body(ctx, data, p, only_last, want_scores, counts is not None)
+                    finally:
+                        ctx.set_precision('f16x3')
+            return out
         finally:
             if counts is not None:
                 ctx.set_counts()

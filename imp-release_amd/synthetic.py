@@ -96,7 +96,7 @@ def _trained_like(sd, seed, prefix, cout, cin, gain=1.0, rank=24, outliers=6, ze
 
 
 def make_state_dict(config: dict, model: str = 'GM', seed: int = 0, bin_score: float = 1.0,
-                    gain: float = 1.0, bias_offset: float = 0.0, style: str = 'uniform') -> "OrderedDict[str, np.ndarray]":
+                    gain: float = 1.0, bias_offset: float = 0.0, style: str = 'uniform', qk_gain=None) -> "OrderedDict[str, np.ndarray]":
     """numpy state_dict with the reference key schema.
 
     ``style='uniform'`` (default; every fixture of rounds 1-2): uniform(+-gain/sqrt(fan_in)) like torch's default
@@ -143,7 +143,9 @@ def make_state_dict(config: dict, model: str = 'GM', seed: int = 0, bin_score: f
         if not last and norm == 'bn':
             _bn(sd, seed, f'kenc.encoder.{3 * (i - 1) + 1}', chans[i])
     shared = sharing_pattern(len(names), model)
-    qk = 1.5 if style == 'trained' else 1.0
+    # gain of the q / k projections (None: 1.5 for 'trained', 1 otherwise): THE conditioning knob - sharper attention rows amplify every
+    # rounding of the logits (tools/parity_vs_conditioning.py sweeps it from 1 to 3)
+    qk = (1.5 if style == 'trained' else 1.0) if qk_gain is None else float(qk_gain)
     for li in range(len(names)):
         p = f'gnn.layers.{li}'
         if shared[li]:

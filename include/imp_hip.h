@@ -46,6 +46,9 @@ extern "C" {
                              * matrix operand (descriptors, activations, projections) must satisfy |x| < 65504 (fp16 range of the high half);
                              * beyond it - or with non-finite inputs - the scores are NaN and that call's matches are all -1.  Raised by the
                              * match kernel through a mapped host word and reported at the next entry; precision f32 has no such limit */
+#define IMP_E_NOFIT (-8)    /* a RAGGED batch (imp_set_counts) that the chip-resident Sinkhorn kernel cannot hold - sizes, or the context has fallen back to
+                             * the streaming kernels, which take uniform batches only: nothing was computed; run the pairs in smaller groups (a single
+                             * pair whose counts equal the padded sizes always runs: it is a uniform batch) */
 #define IMP_E_RESIDENT (-6) /* a chip-resident Sinkhorn launch of an EARLIER call on this context timed out: that call's results are void
                              * (poisoned: mscores NaN, indices -1); the context has recovered on a safer protocol - re-run the batch */
 
@@ -335,6 +338,10 @@ int imp_op_attention(imp_ctx* ctx, int batch, int nq, int nk, int dim, const flo
 /* timing hooks for bench.py: hipEvent-bracketed repetition of one attention / one Sinkhorn pass on
  * the context's own stream-ordered workspace; returns average milliseconds per launch in *ms. */
 int imp_time_attention(imp_ctx* ctx, int batch, int n, int reps, float* ms, void* stream);
+/* the same launches with the clock they ran at: workgroup 0 of every timed launch reads the shader-cycle counter (s_memtime) and the constant
+ * 100 MHz counter (s_memrealtime) on entry and exit; *sclk_mhz = cycles / ticks x 100 (0 when the kernel variant taken carries no probe).
+ * bench.py reports it as roofline.sclk_mhz_observed: the MFMA roof at THAT clock is what the launch could have reached. */
+int imp_time_attention_clock(imp_ctx* ctx, int batch, int n, int reps, float* ms, float* sclk_mhz, void* stream);
 /* same for the Sinkhorn iterations (nets/layers.py:31-33) over [batch][n+1][n+1] on the path the product takes for that
  * shape (chip-resident kernel: time(T iterations) - time(0 iterations); streaming path: 2 launches per iteration);
  * *ms = average milliseconds per ITERATION */
@@ -382,8 +389,23 @@ int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, const doubl
 int imp_resident_status(imp_ctx* ctx, int* status, int* used);
 int imp_resident_health(imp_ctx* ctx, int* timeouts, int* level);
 int imp_set_resident_verify(imp_ctx* ctx, int on);
-/* how many calls on this context were reported with IMP_E_RANGE so far */
+/* how many calls on this context met non-finite match scores so far (reported with IMP_E_RANGE, or recovered in the call) */
 int imp_range_events(imp_ctx* ctx);
+/* In-call recovery from IMP_E_RANGE (round 5).  By default the library never waits for the GPU: an operand beyond the fp16 range of the
+ * f16x3 arithmetic voids THAT call (all matches -1) and the NEXT entry point reports it.  With imp_set_range_recovery(ctx, 1) the one-shot
+ * and tail entry points (imp_match_pair, imp_match_tail, imp_match_tail_scores) wait for their own work before they return (one host
+ * synchronisation per call; not under stream capture) and a call whose scores came out non-finite is run again, inside the call, on the
+ * native fp32 MFMA path (the arithmetic of imp_set_precision(ctx, 0), which has no operand limit): the caller receives what a
+ * precision = f32 context computes for the same inputs.  Non-finite INPUTS stay void and are reported at the next entry point as before.
+ * The Python modules switch it on by default (config key 'range_recovery'): nets/gm.py:145-247 returns finite matches for such data.
+ * imp_range_recovered: how many calls were repaired that way. */
+int imp_set_range_recovery(imp_ctx* ctx, int on);
+int imp_range_recovered(imp_ctx* ctx);
+/* for callers that compose a pass from the step API (layer calls, then score + matches per iteration) and want the same recovery: after
+ * the pass, once the CALLER has synchronised its stream, imp_range_take returns 1 when a match kernel of the pass met non-finite scores,
+ * clears the word (the next entry point then reports nothing) and counts the event (as recovered when `recovered` != 0: the caller is
+ * about to re-run the pass under imp_set_precision(ctx, 0)); 0 otherwise.  The Python modules do this for the all-iterations path. */
+int imp_range_take(imp_ctx* ctx, int recovered);
 /* how many times the tag counter of hipGraph-REPLAYED resident launches wrapped (about every 7 million replays at 100 Sinkhorn iterations;
  * the library clears the exchange buffers at the next entry point - not an error).  Test hook: IMP_OT_GRAPH_TAG0=<first tag>. */
 int imp_tag_wraps(imp_ctx* ctx);

@@ -468,13 +468,7 @@ def test_attention_extreme_logits(gm, scale, B, nq, nk):
     assert e_lse < 2e-5, f'attention lse rel err {e_lse:.3e}'
 
 
-@pytest.mark.parametrize('resident', ['1', '0'])
-def test_operand_beyond_the_fp16_range_is_reported_not_silent(resident):
-    """f16x3 arithmetic: |x| >= 65504 in a matrix operand makes the scores NaN.  The match kernel notices, the matches of that call
-    are void (-1) and the next entry point raises IMP_E_RANGE; precision f32 handles the same data (VERDICT r2 weak #2)"""
-    from imp_release_amd._lib import OperandRangeError
-    import os
-    os.environ['IMP_OT_RESIDENT'] = resident            # chip-resident and streaming Sinkhorn kernels: both end in the same match kernel
+def _range_case():
     cfg = eval_config(n_layers=2, sinkhorn_iterations=10)
     sd = synthetic.make_state_dict(cfg, 'GM', seed=3)
     pair = synthetic.make_correlated_pair(300, 280, seed=5)
@@ -483,8 +477,20 @@ def test_operand_beyond_the_fp16_range_is_reported_not_silent(resident):
     big = dict(data)
     big['descriptors0'] = data['descriptors0'] * 1.0
     big['descriptors0'][0, 7, 3] = 7.0e4                           # one operand beyond the fp16 range
+    return cfg, sd, data, big
+
+
+@pytest.mark.parametrize('resident', ['1', '0'])
+def test_operand_beyond_the_fp16_range_is_reported_not_silent(resident):
+    """f16x3 arithmetic WITHOUT in-call recovery (range_recovery=False: the library never waits for the GPU): |x| >= 65504 in a matrix
+    operand makes the scores NaN.  The match kernel notices, the matches of that call are void (-1) and the next entry point raises
+    IMP_E_RANGE; precision f32 handles the same data (VERDICT r2 weak #2)"""
+    from imp_release_amd._lib import OperandRangeError
+    import os
+    os.environ['IMP_OT_RESIDENT'] = resident            # chip-resident and streaming Sinkhorn kernels: both end in the same match kernel
+    cfg, sd, data, big = _range_case()
     try:
-        m = make_hip_model('GM', cfg, sd)
+        m = make_hip_model('GM', dict(cfg, range_recovery=False), sd)
         m._ensure_ctx()
     finally:
         del os.environ['IMP_OT_RESIDENT']
@@ -500,4 +506,41 @@ def test_operand_beyond_the_fp16_range_is_reported_not_silent(resident):
         o32 = m32.produce_matches(big, p=0.2, only_last=True)      # native fp32 MFMA: no such limit
         m32.produce_matches(data, p=0.2, only_last=True)           # ... and nothing to report
     torch.cuda.synchronize()
-    assert torch.isfinite(o32['mscores0'][-1]).all() and m._ensure_ctx().L.imp_range_events(m._ensure_ctx().handle) == 1
+    assert torch.isfinite(o32['mscores0'][-1]).all() and m._ensure_ctx().range_counts() == (1, 0)
+
+
+@pytest.mark.parametrize('resident', ['1', '0'])
+def test_operand_beyond_the_fp16_range_is_recovered_inside_the_call(resident):
+    """the default (config key range_recovery, include/imp_hip.h imp_set_range_recovery; VERDICT r4 #5b): the call that meets the operand
+    waits for its own work, sees the range word and runs itself again on the native fp32 MFMA path - the caller gets exactly what a
+    precision='f32' model returns for these inputs (the reference returns finite matches for such data, nets/gm.py:305-320), nothing is
+    raised at the next call, and ordinary data afterwards runs in f16x3 again"""
+    import os
+    os.environ['IMP_OT_RESIDENT'] = resident
+    cfg, sd, data, big = _range_case()
+    try:
+        m = make_hip_model('GM', cfg, sd)
+        m32 = make_hip_model('GM', cfg, sd, precision='f32')
+        mref = make_hip_model('GM', dict(cfg, range_recovery=False), sd)
+        m._ensure_ctx(); m32._ensure_ctx(); mref._ensure_ctx()      # (contexts read the environment when they are created)
+    finally:
+        del os.environ['IMP_OT_RESIDENT']
+    with torch.no_grad():
+        out = m.produce_matches(big, p=0.2, only_last=True)
+        want = m32.produce_matches(big, p=0.2, only_last=True)
+        torch.cuda.synchronize()
+        assert (want['indices0'][-1] >= 0).any() and torch.isfinite(want['mscores0'][-1]).all()
+        assert torch.equal(out['indices0'][-1], want['indices0'][-1]) and torch.equal(out['mscores0'][-1], want['mscores0'][-1])
+        assert m._ensure_ctx().range_counts() == (1, 1) and m._ensure_ctx().precision == 'f16x3'
+        good = m.produce_matches(data, p=0.2, only_last=True)      # no IMP_E_RANGE left behind; back on the split-half arithmetic
+        ref = mref.produce_matches(data, p=0.2, only_last=True)
+        torch.cuda.synchronize()
+        assert torch.equal(good['indices0'][-1], ref['indices0'][-1]) and torch.equal(good['mscores0'][-1], ref['mscores0'][-1])
+        # the all-iterations path (layer calls + tail per iteration): the NaN descriptors reach the tail from the caller's earlier calls, the tail
+        # cannot repair them - the module re-runs the whole pass on the fp32 path instead
+        alli = m.produce_matches(big, p=0.2, only_last=False)
+        want_all = m32.produce_matches(big, p=0.2, only_last=False)
+        torch.cuda.synchronize()
+        for a_, w_ in zip(alli['indices0'], want_all['indices0']):
+            assert torch.equal(a_, w_)
+    assert m._ensure_ctx().precision == 'f16x3'

@@ -245,6 +245,47 @@ def test_lockstep_loop_equals_the_pairs_one_at_a_time(pose_threads, native):
     assert m._ensure_ctx().resident_health() == (0, 0)
 
 
+@pytest.mark.parametrize('eimp,native', [(False, False), (False, True), (True, False), (True, True)])
+def test_lockstep_loops_step_down_to_single_pairs_without_the_resident_kernel(eimp, native, monkeypatch):
+    """on a context WITHOUT the chip-resident Sinkhorn (IMP_OT_RESIDENT=0 here; in production: after two time-outs, or a pair
+    beyond its size limits) a ragged group cannot be scored - IMP_E_NOFIT, ResidentDoesNotFit - and the wrappers split it down to single
+    pairs, which are uniform batches for the library and run on the streaming kernels: the group's results equal the pairs one at a time,
+    nothing is refused (round 4 re-raised for the one-pair group and aborted every lockstep > 1 evaluation of such a context)"""
+    from imp_release_amd import _lib, matching as hip_matching, pose as gpose
+    monkeypatch.setenv('IMP_OT_RESIDENT', '0')
+    cfg = eval_config()
+    name = 'AdaGMN' if eimp else 'DGNNS'
+    sd = synthetic.make_state_dict(cfg, name, seed=0, bin_score=synthetic.MATCHING_BIN_SCORE, style='matching')
+    m = make_hip_model(name, cfg, sd)
+    pairs = [synthetic.make_hard_two_view_pair(seed=9400 + k, n_lo=300, n_hi=700) for k in range(3)]
+    datas = [_loop_dict(p) for p in pairs]
+    # the error class the split hangs on: a ragged score on this context is IMP_E_NOFIT, not a time-out and not a generic argument error
+    ctx = m._ensure_ctx()
+    d0 = torch.zeros(2, 64, 256, device=DEV)
+    ctx.set_counts([64, 40], [64, 50])
+    try:
+        with pytest.raises(_lib.ResidentDoesNotFit) as ei:
+            ctx.match_tail(0, d0, d0.clone(), 1.0, 5, True, 0.2)
+        assert ei.value.code == _lib.IMP_E_NOFIT and not isinstance(ei.value, _lib.ResidentSinkhornTimeout)
+    finally:
+        ctx.set_counts()
+    with torch.no_grad():
+        if eimp:
+            solo = [hip_matching.matching_iterative_uncertainty(d, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, with_uncertainty=True, estimate_pose=gpose.estimate_pose) for d in datas]
+            together = hip_matching.matching_iterative_uncertainty_lockstep(datas, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, with_uncertainty=True,
+                                                                            estimate_pose=gpose.estimate_pose, native=native)
+            I, M, NIT = 4, 5, 8
+        else:
+            solo = [hip_matching.matching_iterative(d, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, estimate_pose=gpose.estimate_pose) for d in datas]
+            together = hip_matching.matching_iterative_lockstep(datas, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, estimate_pose=gpose.estimate_pose, native=native)
+            I, M, NIT = 0, 1, 4
+    assert len(together) == len(solo)
+    for b, (a, c) in enumerate(zip(solo, together)):
+        assert a[NIT] == c[NIT], f'pair {b}: n_iterations {a[NIT]} alone, {c[NIT]} in the group'
+        assert np.array_equal(a[I], c[I]), f'pair {b}: {(a[I] != c[I]).sum()} indices differ'
+        assert np.abs(a[M].astype(np.float64) - c[M]).max() <= TOL
+
+
 def test_eval_loop_lockstep_rows_equal_the_sequential_rows():
     from imp_release_amd import eval_loop, pose as gpose
     cfg = eval_config()

@@ -507,3 +507,15 @@ def test_superpoint_align_corners_rule():
     from imp_release_amd.superpoint import reference_align_corners as rule
     assert [rule(v) for v in ('1.2.0', '1.3.1', '1.7.1', '1.9.0', '1.10.2', '1.12.1', '2.0.1', '2.2.0', '2.3.0', '2.9.1', '2.10.0+rocm7.0')] == \
         [False, True, True, True, False, False, False, False, True, True, False]
+
+
+def test_error_classes_of_the_binding_are_distinct():
+    """"does not fit" (IMP_E_NOFIT) and "timed out" (IMP_E_RESIDENT) are told apart by error code / exception class; the lock-step
+    wrappers split a group on the first and re-run it on the second"""
+    from imp_release_amd import _lib
+    assert _lib.IMP_E_NOFIT == -8 and _lib.IMP_E_RESIDENT == -6 and _lib.IMP_E_RANGE == -7
+    assert issubclass(_lib.ResidentDoesNotFit, _lib.ImpError) and issubclass(_lib.ResidentSinkhornTimeout, _lib.ImpError)
+    assert not issubclass(_lib.ResidentDoesNotFit, _lib.ResidentSinkhornTimeout)
+    assert not issubclass(_lib.ResidentSinkhornTimeout, _lib.ResidentDoesNotFit)
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'imp_hip.h')).read()
+    assert '#define IMP_E_NOFIT (-8)' in hdr

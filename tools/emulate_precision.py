@@ -17,6 +17,7 @@ Schemes:
     bf16x6    three bfloat16 components: all six products of order <= 2
     f16x1     a single half product (what a plain fp16 MFMA path would do)
     f16x3+p1  f16x3, but the attention probabilities enter P.V as ONE half (2 products instead of 3 there) - an idea that was tested and rejected
+    f16x3+p1c the same with the softmax denominators summed from those rounded probabilities (round 5)
 Sinkhorn storage: 23 (fp32), 15 (3-byte copy), 7 (2-byte, bfloat16-like), 10 (2-byte, half-like mantissa)
 """
 import argparse
@@ -56,21 +57,30 @@ def _components(x, kind, n):
 
 def make_matmul(scheme):
     if scheme == 'fp32':
-        return _matmul
-    p_single = scheme.endswith('+p1')
-    scheme = scheme.replace('+p1', '')
+        return lambda a, b, role=None: _matmul(a, b)
+    q_single = '+q1' in scheme                      # Q enters Q.K^T as one half (q_hi.k_lo + q_hi.k_hi)
+    scheme = scheme.replace('+q1', '')
+    p_consistent = scheme.endswith('+p1c')          # ... and the row sums are taken from the SAME rounded probabilities (the output is a convex combination again)
+    p_single = scheme.endswith('+p1') or p_consistent
+    scheme = scheme.replace('+p1c', '').replace('+p1', '')
     kind, n, pairs = {'f16x3': ('f16', 2, [(1, 0), (0, 1), (0, 0)]),
                       'bf16x3': ('bf16', 2, [(1, 0), (0, 1), (0, 0)]),
                       'bf16x6': ('bf16', 3, [(2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)]),
                       'f16x1': ('f16', 1, [(0, 0)])}[scheme]
 
-    def mm(a, b):
+    def mm(a, b, role=None):
         if a.dtype != torch.float32 or b.dtype != torch.float32:
             return _matmul(a, b)
-        if p_single and a.dim() == 4 and b.dim() == 4:
-            # the probabilities x values product of attention (oracle: prob @ v) with P carried as ONE half: P_hi.V_lo + P_hi.V_hi
+        # (round 5: the 4-D test alone also caught Q.K^T, which reaches here through the einsum hook - the round-2 '+p1' column had rounded Q to one
+        # half as well; `role` now tells the two attention products apart)
+        if q_single and role == 'qk':
             ca, cb = _components(a, kind, 1), _components(b, kind, 2)
             return _matmul(ca[0], cb[1]) + _matmul(ca[0], cb[0])
+        if p_single and role != 'qk' and a.dim() == 4 and b.dim() == 4:
+            # the probabilities x values product of attention (oracle: prob @ v) with P carried as ONE half: P_hi.V_lo + P_hi.V_hi
+            ca, cb = _components(a, kind, 1), _components(b, kind, 2)
+            out = _matmul(ca[0], cb[1]) + _matmul(ca[0], cb[0])
+            return out / ca[0].sum(-1, keepdim=True) if p_consistent else out
         ca, cb = _components(a, kind, n), _components(b, kind, n)
         out = None
         for i, j in pairs:                       # small terms first, fp32 accumulation
@@ -91,7 +101,7 @@ class patched:
 
         def einsum(eq, a, b):
             if eq == 'bhnd,bhmd->bhnm':
-                return mm(a, b.transpose(-1, -2))
+                return mm(a, b.transpose(-1, -2), role='qk')
             if eq == 'bnd,bmd->bnm':
                 return mm(a, b.transpose(-1, -2))
             return _einsum(eq, a, b)
@@ -161,10 +171,13 @@ def main():
     ap.add_argument('--fixtures', default='')
     ap.add_argument('--big', action='store_true')
     ap.add_argument('--threads', type=int, default=8)
+    ap.add_argument('--schemes', default='', help='comma list of scheme[/Pbits] columns (default: all)')
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     names = [n for n in a.fixtures.split(',') if n] or golden_names(['gm_l', 'dgnns_l', 'adagmn_masked'])
-    variants = [('fp32', 23), ('f16x3', 23), ('f16x3+p1', 23), ('bf16x3', 23), ('bf16x6', 23), ('f16x1', 23), ('fp32', 15), ('fp32', 10), ('fp32', 7)]
+    variants = [('fp32', 23), ('f16x3', 23), ('f16x3+p1', 23), ('f16x3+p1c', 23), ('bf16x3', 23), ('bf16x6', 23), ('f16x1', 23), ('fp32', 15), ('fp32', 10), ('fp32', 7)]
+    if a.schemes:
+        variants = [(c.split('/P')[0], int(c.split('/P')[1]) if '/P' in c else 23) for c in a.schemes.split(',')]
     print(f'{"fixture":26s} ' + ' '.join(f'{s + ("" if b == 23 else f"/P{b}"):>17s}' for s, b in variants))
     print(f'{"":26s} ' + ' '.join(f'{"idx-bad  max|dms|":>17s}' for _ in variants))
     tot = [[0, 0.0] for _ in variants]

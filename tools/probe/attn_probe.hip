@@ -56,6 +56,25 @@ int main(int argc, char** argv) {
     printf("per wave of workgroup 0 (cycles): prologue (Q tile, first staged tiles, phase offset)  key loop  epilogue (normalise, transpose, store)\n");
     for (int w = 0; w < 8; ++w) printf("  wave %d: prologue %7llu  loop %8llu  epilogue %7llu\n", w, span[w][0], span[w][1], span[w][2]);
 #endif
+#ifdef PP_TIMELINE
+    {
+        unsigned long long tl[8][4][8]; unsigned hw[8];
+        CK(hipMemcpyFromSymbol(tl, HIP_SYMBOL(pp_tl), sizeof tl));
+        CK(hipMemcpyFromSymbol(hw, HIP_SYMBOL(pp_hwid), sizeof hw));
+        unsigned long long base = ~0ull;
+        for (int w = 0; w < 8; ++w) if (tl[w][0][0] < base) base = tl[w][0][0];
+        printf("timeline of workgroup 0, key tiles %d..%d, cycles since the first stamp (X0 = matrix phase starts, X1 = its last MFMA issued, B1 = past the barrier,\n"
+               " S = probabilities done, G = staging done, B2 = past the barrier); waves w and w+4 normally share a SIMD (HW_ID simd field printed)\n", PP_TL_T0, PP_TL_T0 + 3);
+        for (int w = 0; w < 8; ++w) {
+            printf("  wave %d simd %u cu %u:", w, (hw[w] >> 4) & 3, (hw[w] >> 8) & 15);
+            for (int t = 0; t < 4; ++t) {
+                printf("  |t%d", PP_TL_T0 + t);
+                for (int i = 0; i < 6; ++i) printf(" %6lld", (long long)(tl[w][t][i] - base));
+            }
+            printf("\n");
+        }
+    }
+#endif
     float chk = 0; std::vector<float> ho((size_t)B * n * D);
     CK(hipMemcpy(ho.data(), o0, ho.size() * 4, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < ho.size(); i += 997) chk += ho[i];
