@@ -2775,6 +2775,7 @@ int imp_set_range_recovery(imp_ctx* c, int on) {
 int imp_range_recovered(imp_ctx* c) { return c ? c->range_recovered : -1; }
 int imp_range_take(imp_ctx* c, int recovered) {
     if (!c || !c->range_host) return 0;
+    if (recovered == 2) { c->range_recovered += 1; return 0; }       // (the caller repaired a pass whose event an entry point had already reported: IMP_E_RANGE mid-pass)
     if (c->xstatus_host && *static_cast<volatile int*>(c->xstatus_host)) return 0;      // a voided resident launch is the health check's business
     if (!*static_cast<volatile int*>(c->range_host)) return 0;
     *static_cast<volatile int*>(c->range_host) = 0;

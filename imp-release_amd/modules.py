@@ -400,18 +400,32 @@ class GM(nn.Module):
         if counts is not None:
             ctx.set_counts(*counts)
         try:
-            out = self._run_iterations_body(ctx, data, p, only_last, want_scores, counts is not None)
             one_shot = only_last and len(self.gnn.names) == 2 * self.n_layers        # (imp_match_pair repairs itself inside the call)
-            if getattr(ctx, 'range_recovery', False) and not one_shot and ctx.precision == 'f16x3' and not torch.cuda.is_current_stream_capturing():
-                # the pass was composed from layer calls: an operand beyond the fp16 range poisoned the descriptors BEFORE the tails saw them, so
-                # the whole pass runs again on the fp32 MFMA path (include/imp_hip.h imp_range_take); costs one synchronisation per pass
+            recover = (getattr(ctx, 'range_recovery', False) and not one_shot and ctx.precision == 'f16x3' and
+                       not torch.cuda.is_current_stream_capturing())
+            # a pass composed from layer calls: an operand beyond the fp16 range poisons the descriptors BEFORE the tails see them, so the whole
+            # pass runs again on the fp32 MFMA path (include/imp_hip.h imp_range_take); costs one synchronisation per pass.  The event shows
+            # either after the pass (the range word, once this stream has drained) or - when an earlier iteration's match kernel has already
+            # finished - as IMP_E_RANGE from one of the pass's own later entry points
+            hit = False
+            try:
+                out = self._run_iterations_body(ctx, data, p, only_last, want_scores, counts is not None)
+                if recover:
+                    torch.cuda.current_stream(ctx.device).synchronize()
+                    hit = ctx.range_take(True)
+            except _lib.OperandRangeError:
+                if not recover:
+                    raise
                 torch.cuda.current_stream(ctx.device).synchronize()
-                if ctx.range_take(True):
-                    ctx.set_precision('f32')
-                    try:
-                        out = self._run_iterations_body(ctx, data, p, only_last, want_scores, counts is not None)
-                    finally:
-                        ctx.set_precision('f16x3')
+                ctx.range_take(False)                      # (a second iteration may have raised the word again meanwhile)
+                ctx.L.imp_range_take(ctx.handle, 2)
+                hit = True
+            if hit:
+                ctx.set_precision('f32')
+                try:
+                    out = self._run_iterations_body(ctx, data, p, only_last, want_scores, counts is not None)
+                finally:
+                    ctx.set_precision('f16x3')
             return out
         finally:
             if counts is not None:

@@ -404,7 +404,8 @@ int imp_range_recovered(imp_ctx* ctx);
 /* for callers that compose a pass from the step API (layer calls, then score + matches per iteration) and want the same recovery: after
  * the pass, once the CALLER has synchronised its stream, imp_range_take returns 1 when a match kernel of the pass met non-finite scores,
  * clears the word (the next entry point then reports nothing) and counts the event (as recovered when `recovered` != 0: the caller is
- * about to re-run the pass under imp_set_precision(ctx, 0)); 0 otherwise.  The Python modules do this for the all-iterations path. */
+ * about to re-run the pass under imp_set_precision(ctx, 0)); 0 otherwise.  recovered == 2: only counts a recovery (for a pass whose event one of
+ * its own later entry points already reported as IMP_E_RANGE).  The Python modules do this for the all-iterations path. */
 int imp_range_take(imp_ctx* ctx, int recovered);
 /* how many times the tag counter of hipGraph-REPLAYED resident launches wrapped (about every 7 million replays at 100 Sinkhorn iterations;
  * the library clears the exchange buffers at the next entry point - not an error).  Test hook: IMP_OT_GRAPH_TAG0=<first tag>. */

@@ -45,6 +45,50 @@ def test_produce_matches_vs_golden(name, precision):
     print('\n'.join(msgs))
 
 
+COND_REPORT = []
+
+
+@pytest.mark.parametrize('precision', ['f16x3', 'f32'])
+def test_parity_under_conditioning(precision):
+    """VERDICT r4 #5a: parity as the network gets worse conditioned, measured against where the REFERENCE stops defining the answer.
+    tests/golden/conditioning_n1024.npz (tools/parity_vs_conditioning.py, which imports the reference) holds, for q / k gains 1 ... 5 of
+    the trained-style weights at N = 1024 (GM, L = 9, T = 100): the fp64 run of the reference and the deviation of the reference's OWN fp32
+    evaluations (1 thread, 8 threads) from it.  At every gain the HIP path must disagree with the fp64 yardstick no more than the reference's
+    fp32 does: match indices - no more disagreements than the larger of the reference's two counts + the keypoints whose mscore an fp32
+    evaluation of the reference itself moves by more than 1e-3 (0 + 0 up to gain 3: strict there);
+    scores - within max(1e-4, 2 x the reference's larger fp32 deviation) (up to gain 3 the reference's noise is < 1e-4 and the bar is the
+    north star's 1e-4; at gain 4 two fp32 evaluations of the reference differ by 1e-3, at gain 5 by 0.1 - no implementation can be held to
+    1e-4 there).  This measurement replaces the prose justification of the `low_score_flips` tolerance."""
+    spec, z = load_golden('conditioning_n1024')
+    cfg = eval_config(**spec['config'])
+    pair = synthetic.make_correlated_pair(spec['n'], spec['n'], seed=spec['dseed'])
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+    rows = []
+    for g in spec['gains']:
+        tag = f'g{int(round(g * 10)):02d}'
+        sd = synthetic.make_state_dict(cfg, 'GM', seed=spec['wseed'], style=spec['style'], qk_gain=g)
+        m = make_hip_model('GM', cfg, sd, precision=precision)
+        with torch.no_grad():
+            out = m.produce_matches(data, **spec['call'])
+        i_hip, ms_hip = _cpu(out['indices0'][-1])[0].numpy(), _cpu(out['mscores0'][-1])[0].double().numpy()
+        i64, ms64 = z[f'{tag}_indices0'], z[f'{tag}_mscores0']
+        noise = z[f'{tag}_ref_noise']
+        bad = int((i_hip != i64).sum())
+        agree = i_hip == i64
+        dms = float(np.abs(ms_hip - ms64)[agree].max(initial=0.0))
+        ref_bad, ref_dms = int(max(noise[0], noise[2])) + int(noise[6]), float(max(noise[1], noise[3]))
+        rows.append((g, bad, dms, ref_bad, ref_dms))
+        del m
+    COND_REPORT.append((precision, rows))
+    print(f'conditioning sweep ({precision}): q/k gain | HIP vs fp64: idx, max|dms| | reference fp32 vs fp64 (worse of 1 / 8 threads): idx, max|dms|')
+    for g, bad, dms, rb, rd in rows:
+        print(f'  {g:4.1f} | {bad:4d} {dms:9.2e} | {rb:4d} {rd:9.2e}')
+    for g, bad, dms, rb, rd in rows:
+        assert bad <= rb, f'gain {g}: {bad} index disagreements with the fp64 yardstick, the reference itself has {rb}'
+        assert dms <= max(TOL, 2.0 * rd), f'gain {g}: max|dmscore| {dms:.2e} against the fp64 yardstick; the reference fp32 deviates by {rd:.2e}'
+
+
 @pytest.mark.parametrize('name', golden_names(['gm_run', 'adagmn_run']))
 def test_run_vs_golden(name):
     spec, z = load_golden(name)

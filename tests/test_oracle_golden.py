@@ -177,3 +177,25 @@ def test_superpoint_align_corners_rule():
     from imp_release_amd.superpoint import reference_align_corners
     assert [reference_align_corners(v) for v in ('1.2.0', '1.3.1', '1.7.1', '1.9.0', '1.10.2', '1.13.1', '2.0.1', '2.10.0+rocm7.0')] == \
         [False, True, True, True, False, False, False, False]
+
+
+@pytest.mark.parametrize('gain', [1.5, 3.0])
+def test_oracle_under_conditioning(gain):
+    """the conditioning sweep (tests/golden/conditioning_n1024.npz, tools/parity_vs_conditioning.py): the fp32 oracle against the fp64 run of
+    the reference - within what the reference's own fp32 evaluations deviate (same rule as the GPU test of the same name)"""
+    from imp_release_amd import synthetic
+    spec, z = load_golden('conditioning_n1024')
+    from helpers import eval_config
+    cfg = eval_config(**spec['config'])
+    pair = synthetic.make_correlated_pair(spec['n'], spec['n'], seed=spec['dseed'])
+    data = {k: torch.from_numpy(v) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'])
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=spec['wseed'], style=spec['style'], qk_gain=gain)
+    with torch.no_grad():
+        out = orc.MatcherOracle(cfg, sd, 'GM').produce_matches(data, **spec['call'])
+    tag = f'g{int(round(gain * 10)):02d}'
+    i, ms = out['indices0'][-1][0].numpy(), out['mscores0'][-1][0].double().numpy()
+    noise = z[f'{tag}_ref_noise']
+    bad = int((i != z[f'{tag}_indices0']).sum())
+    dms = float(np.abs(ms - z[f'{tag}_mscores0'])[i == z[f'{tag}_indices0']].max(initial=0.0))
+    assert bad <= max(noise[0], noise[2]) + noise[6] and dms <= max(1e-4, 2.0 * max(noise[1], noise[3])), (bad, dms, noise)

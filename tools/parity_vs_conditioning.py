@@ -13,7 +13,8 @@ q / k gain of the trained-style synthetic weights (synthetic.make_state_dict(sty
 
 into tests/golden/conditioning_n1024.npz.  tests/test_gpu_parity.py::test_parity_under_conditioning then asserts, on the GPU and in both
 precisions, that the HIP path disagrees with the fp64 yardstick NO MORE than the reference's own fp32 evaluations do (index disagreements
-<= the larger of the reference's two counts, score deviation <= the larger of the reference's two + 2e-5) - which replaces the prose
+<= the larger of the reference's two counts + the number of keypoints the reference itself leaves unstable, score deviation <=
+max(1e-4, 2 x the larger of the reference's two)) - which replaces the prose
 justification of the `low_score_flips` tolerance with a measurement of where the reference stops defining the answer.
 
     python tools/parity_vs_conditioning.py            # writes the fixture, prints the table
@@ -72,7 +73,7 @@ def main():
     data = {k: torch.from_numpy(v) for k, v in pair.items() if k != 'image_shape'}
     data['image0'] = data['image1'] = torch.zeros(pair['image_shape'])
     arrays = {}
-    print(f'{"qk gain":>8s} {"matched64":>9s} | {"ref fp32/1t vs fp64":>22s} | {"ref fp32/8t vs fp64":>22s} | {"ref 1t vs 8t":>18s} | max attention prob (mean over queries, last layer)')
+    print(f'{"qk gain":>8s} {"matched64":>9s} | {"ref fp32/1t vs fp64":>22s} | {"ref fp32/8t vs fp64":>22s} | {"ref 1t vs 8t":>18s}')
     for g in GAINS:
         sd = synthetic.make_state_dict(CFG, 'GM', seed=WSEED, style='trained', qk_gain=g)
         r64 = run(sd, data, torch.float64, 8)
@@ -81,11 +82,13 @@ def main():
         v1, v8, v18 = versus(r1, r64), versus(r8, r64), versus(r1, r8)
         tag = f'g{int(round(g * 10)):02d}'
         arrays[f'{tag}_indices0'] = r64[0]; arrays[f'{tag}_mscores0'] = r64[1]
-        arrays[f'{tag}_ref_noise'] = np.array([v1[0], v1[1], v8[0], v8[1], v18[0], v18[1]], dtype=np.float64)
-        print(f'{g:8.1f} {int((r64[0] >= 0).sum()):9d} | {v1[0]:6d} idx {v1[1]:10.2e} | {v8[0]:6d} idx {v8[1]:10.2e} | {v18[0]:4d} idx {v18[1]:9.2e}', flush=True)
+        # keypoints the reference itself does not pin down: an fp32 evaluation of it moves their mscore by more than 1e-3 (ten times the parity bar)
+        unstable = int(((np.abs(r1[1] - r64[1]) > 1e-3) | (np.abs(r8[1] - r64[1]) > 1e-3)).sum())
+        arrays[f'{tag}_ref_noise'] = np.array([v1[0], v1[1], v8[0], v8[1], v18[0], v18[1], unstable], dtype=np.float64)
+        print(f'{g:8.1f} {int((r64[0] >= 0).sum()):9d} | {v1[0]:6d} idx {v1[1]:10.2e} | {v8[0]:6d} idx {v8[1]:10.2e} | {v18[0]:4d} idx {v18[1]:9.2e} | unstable keypoints {unstable}', flush=True)
     spec = {'model': 'GM', 'config': {'n_layers': 9, 'sinkhorn_iterations': 100}, 'n': N, 'wseed': WSEED, 'dseed': DSEED, 'style': 'trained',
             'gains': GAINS, 'call': {'p': 0.2, 'only_last': True},
-            'ref_noise_columns': ['idx fp32/1t vs fp64', 'dms fp32/1t vs fp64', 'idx fp32/8t vs fp64', 'dms fp32/8t vs fp64', 'idx 1t vs 8t', 'dms 1t vs 8t']}
+            'ref_noise_columns': ['idx fp32/1t vs fp64', 'dms fp32/1t vs fp64', 'idx fp32/8t vs fp64', 'dms fp32/8t vs fp64', 'idx 1t vs 8t', 'dms 1t vs 8t', 'keypoints whose mscore an fp32 evaluation of the reference moves by > 1e-3']}
     arrays['spec_json'] = np.frombuffer(json.dumps(spec).encode(), dtype=np.uint8)
     out = os.path.join(ROOT, 'tests', 'golden', 'conditioning_n1024.npz')
     np.savez_compressed(out, **arrays)
