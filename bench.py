@@ -293,6 +293,10 @@ def main():
                          'exchange stays one ordered lane). 1 = strictly one step after the other; 0 (default) = the faster of 1 and 3, '
                          'decided by a short untimed calibration (round 4: with one step in flight every layer is ONE fused launch, with '
                          'several the two-launch layers interleave - which wins depends on the box)')
+    ap.add_argument('--exchange-every', type=int, default=0,
+                    help='steps per result exchange (one RCCL all-gather of that many steps: pipeline.StepPipeline exchange_every). 0 (default) = '
+                         '1 on one GPU, 8 on several: a collective couples the ranks - and its kernel holds CUs beside launches that need the whole '
+                         'chip while it waits for a late peer - so the multi-GPU job pays that once per 8 steps, not at every 3.7-ms step')
     ap.add_argument('--h2d', action='store_true',
                     help='additionally time the same steps with every batch uploaded from pinned host memory inside the '
                          'step (PCIe-inclusive rate, reported as value_with_h2d; never the headline value)')
@@ -363,6 +367,7 @@ def main():
             return out['indices0'][-1], out['mscores0'][-1]
         return step_fn
 
+    xk = args.exchange_every if args.exchange_every > 0 else (1 if world == 1 else 8)
     calibration = None
     if args.in_flight <= 0:
         # untimed calibration: the same steps with 1 and with 3 in flight, the faster setting is the one that gets timed
@@ -370,7 +375,7 @@ def main():
         rates = {}
         for k_ in (1, 3):
             reps_ = [model] if k_ == 1 else eval_loop.replicate(model, k_)
-            pp_ = pipeline.StepPipeline([make_step(m) for m in reps_], n_total, device=dev)
+            pp_ = pipeline.StepPipeline([make_step(m) for m in reps_], n_total, device=dev, exchange_every=xk)
             pp_.run(max(4, k_))
             torch.cuda.synchronize()
             t0_ = time.perf_counter()
@@ -386,7 +391,7 @@ def main():
     inflight = max(1, args.in_flight)
     replicas = [model] if inflight == 1 else eval_loop.replicate(model, inflight)
 
-    pipe = pipeline.StepPipeline([make_step(m) for m in replicas], n_total, device=dev)
+    pipe = pipeline.StepPipeline([make_step(m) for m in replicas], n_total, device=dev, exchange_every=xk)
 
     def fence():
         torch.cuda.synchronize()
@@ -407,7 +412,7 @@ def main():
     # the same number of steps strictly one after the other (one replica), reported next to the headline
     serial_s = None
     if True:
-        pipe1 = pipeline.StepPipeline([make_step(model)], n_total, device=dev)
+        pipe1 = pipeline.StepPipeline([make_step(model)], n_total, device=dev, exchange_every=xk)
         pipe1.run(1)
         _, dt1 = timed(pipe1, args.steps)
         serial_s = torch.tensor([dt1], dtype=torch.float64, device=dev)
@@ -429,7 +434,7 @@ def main():
                 return out['indices0'][-1], out['mscores0'][-1]
             return step_fn
 
-        pipe_h = pipeline.StepPipeline([make_h2d_step(m) for m in replicas], n_total, device=dev)
+        pipe_h = pipeline.StepPipeline([make_h2d_step(m) for m in replicas], n_total, device=dev, exchange_every=xk)
         pipe_h.run(inflight)
         _, h2d_s = timed(pipe_h, args.steps)
     elapsed = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -458,7 +463,7 @@ def main():
             m32 = P.GM(dict(cfg, precision='f32', sinkhorn_storage=args.sinkhorn_storage)).eval()
             m32.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
             m32 = m32.to(dev)
-            p32 = pipeline.StepPipeline([make_step(m32)], n_total, device=dev)
+            p32 = pipeline.StepPipeline([make_step(m32)], n_total, device=dev, exchange_every=xk)
             p32.run(2)
             k32 = max(4, args.steps // 2)
             _, dt32 = timed(p32, k32)
@@ -523,7 +528,7 @@ def main():
                                    f'{B} pairs per GPU (BASELINE configs[2]: batch 32 over 8 GPUs), norm_fn=in, '
                                    f'seeded random weights',
                        'pairs_per_gpu': B, 'keypoints': N, 'parallelism': f'pair-sharded x{world}',
-                       'steps_in_flight_per_gpu': inflight, 'steps_in_flight_calibration': calibration,
+                       'steps_in_flight_per_gpu': inflight, 'steps_in_flight_calibration': calibration, 'steps_per_result_exchange': xk,
                        'rank0_numa_cpus': None if numa_cpus is None else len(numa_cpus),
                        'sinkhorn_storage_bytes': args.sinkhorn_storage,
                        'matched_keypoints': n_matched},

@@ -59,6 +59,70 @@ def all_gather_matches(indices0: torch.Tensor, mscores0: torch.Tensor, n_total: 
     return unpack_matches(torch.cat(rows, dim=0), n)
 
 
+def all_gather_matches_steps(steps, n_total: int, group=None):
+    """the results of SEVERAL batch-steps in ONE collective: ``steps`` = [(indices0 [b, N], mscores0 [b, N]), ...] of this rank's block ->
+    [(indices0 [n_total, N], mscores0 [n_total, N]), ...] on every rank.  Every collective couples the ranks (it completes when the slowest has
+    joined) and, on the GPU, its kernel holds compute units while it waits for a late peer - beside launches that need the whole chip
+    (the chip-resident Sinkhorn, the fused layer launch) that is a stall for the fast rank; exchanging every K steps pays it once per K."""
+    if not steps:
+        return []
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and
+                                                               not os.environ.get('IMP_FORCE_COLLECTIVES')):
+        return list(steps)
+    world = dist.get_world_size(group)
+    n = steps[0][0].shape[1]
+    per, k = -(-n_total // world), len(steps)
+    pad = torch.zeros(k, per, n * 12, dtype=torch.uint8, device=steps[0][0].device)
+    for j, (i0, m0) in enumerate(steps):
+        pad[j, :i0.shape[0]] = pack_matches(i0, m0)
+    out = torch.empty(world, k, per, n * 12, dtype=torch.uint8, device=pad.device)
+    dist.all_gather_into_tensor(out.view(world * k, per, n * 12), pad, group=group)
+    res = []
+    for j in range(k):
+        rows = []
+        for r in range(world):
+            s, e = shard_range(n_total, r, world)
+            rows.append(out[r, j, :e - s])
+        res.append(unpack_matches(torch.cat(rows, dim=0), n))
+    return res
+
+
+_QUEUE_SEQ = [0]
+
+
+class DynamicPairQueue:
+    """Rank-level DYNAMIC schedule for work of unpredictable cost ("dynamic work-stealing or longest-first" - the
+    iterative loops leave after 6 ... 15 iterations, which no size-based static split can see): one shared counter, every rank pulls the
+    next ``chunk`` item ids when it runs dry - ``next()`` -> list of ids (empty = done).  The counter lives in the job's rendezvous store
+    (the TCPStore every torch.distributed job already has: ``store.add`` is an atomic fetch-and-add served by rank 0's store thread; no
+    collective, nothing on the GPU), so a pull is one small TCP round trip (~0.1 ms) per chunk.  Without an initialised process group it
+    is a local counter.  Every rank must construct its queues in the same order (the key is a per-process sequence number)."""
+
+    def __init__(self, n_items: int, chunk: int = 1, group=None):
+        import threading
+        self.n, self.chunk = int(n_items), max(1, int(chunk))
+        self._lock = threading.Lock()
+        self._local = 0
+        self._store = None
+        _QUEUE_SEQ[0] += 1
+        self._key = f'imp_pair_queue/{_QUEUE_SEQ[0]}'
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            from torch.distributed import distributed_c10d as c10d
+            self._store = c10d._get_default_store()
+        self.pulls = 0
+
+    def next(self):
+        with self._lock:
+            if self._store is not None:
+                end = int(self._store.add(self._key, self.chunk))
+                start = end - self.chunk
+            else:
+                start = self._local
+                self._local += self.chunk
+            self.pulls += 1
+        return list(range(min(start, self.n), min(start + self.chunk, self.n)))
+
+
 def lpt_assignment(costs, world: int):
     """Rank-level schedule for pairs of UNEQUAL cost (the iterative loops: cost grows with the keypoint counts, shrinks with pruning and
     early exit - SURVEY.md section 8(e) asks for "dynamic work-stealing or longest-first"): longest processing time first - pairs in

@@ -132,21 +132,31 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
     padded to its largest pair and advances at that pair's pace); rows stay in pair-id order.
     ``with_uncertainty`` (EIMP): pool threshold 0.2 x the pose estimate's inlier ratio (eval/matching.py:243-247); default = ``eimp``,
     as eval/eval_imp.py:95-105 passes its one ``use_uncertainty`` switch to both.
-    ``schedule``: how pairs map to ranks - 'block' (contiguous blocks, :func:`imp_release_amd.dist.shard_range`) or 'lpt' (longest
-    processing time first over ``pair_cost(pid)``: see :func:`imp_release_amd.dist.lpt_assignment`)."""
+    ``schedule``: how pairs map to ranks - 'block' (contiguous blocks, :func:`imp_release_amd.dist.shard_range`), 'lpt' (longest
+    processing time first over ``pair_cost(pid)``: see :func:`imp_release_amd.dist.lpt_assignment`) or 'dynamic' (round 5: every rank pulls
+    the next ``lockstep`` - or ``group_similar`` - pairs from one shared counter when it runs dry, :class:`imp_release_amd.dist.DynamicPairQueue`:
+    balances what no static split can see, the exit iteration; the table is the same whatever rank evaluated a pair)."""
     stop_criteria = {'pose': 1.5} if stop_criteria is None else stop_criteria
     ddp = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     rank = dist.get_rank(group) if ddp else 0
     world = dist.get_world_size(group) if ddp else 1
+    queue = None
     if schedule == 'lpt':
         if pair_cost is None:
             raise ValueError("schedule='lpt' needs pair_cost(pair_id) -> relative cost (e.g. n0 * n1)")
         mine = lpt_assignment([pair_cost(i) for i in range(n_pairs)], world)[rank]
     elif schedule == 'block':
         mine = list(range(*shard_range(n_pairs, rank, world)))
+    elif schedule == 'dynamic':
+        # pairs are PULLED: one shared counter in the job's store, every rank takes the next chunk when it runs dry (dist.DynamicPairQueue) -
+        # the schedule for work whose cost shows only while it runs (the loops' early exit: 6 ... 15 iterations)
+        from .dist import DynamicPairQueue
+        lk = max(1, int(lockstep))
+        queue = DynamicPairQueue(n_pairs, chunk=max(lk, int(group_similar) if (group_similar and lk > 1) else lk), group=group)
+        mine = []
     else:
-        raise ValueError("schedule: 'block' or 'lpt'")
-    if group_similar and lockstep > 1:
+        raise ValueError("schedule: 'block', 'lpt' or 'dynamic'")
+    if group_similar and lockstep > 1 and queue is None:
         if pair_cost is None:
             raise ValueError('group_similar needs pair_cost(pair_id)')
         W = max(1, int(group_similar))
@@ -156,9 +166,13 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
     class _Rows:                                  # rows[pid - s] of the block schedule, for any id list
         def __init__(self):
             self.a = np.zeros((len(mine), len(SUMMARY_COLUMNS)), dtype=np.float64)
+            self.d = {}
 
         def __setitem__(self, k, v):
-            self.a[pos[k]] = v
+            if queue is not None:
+                self.d[k] = np.asarray(v, dtype=np.float64)          # (dict stores are atomic: worker threads write disjoint keys)
+            else:
+                self.a[pos[k]] = v
     s = 0
     rows = _Rows()
     loop = matching.matching_iterative_uncertainty if eimp else matching.matching_iterative
@@ -168,6 +182,17 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
     # units of work: single pairs, or groups of `lockstep` pairs that advance together (pairs of similar cost side by side under 'lpt':
     # the list is ascending in pair id, the provider's order)
     units = [mine[a:a + lockstep] for a in range(0, len(mine), lockstep)]
+    if queue is not None:
+        def _pulled():
+            while True:
+                ids = queue.next()
+                if not ids:
+                    return
+                if group_similar and lockstep > 1 and pair_cost is not None:
+                    ids = sorted(ids, key=lambda i: (-pair_cost(i), i))
+                for a in range(0, len(ids), lockstep):
+                    yield ids[a:a + lockstep]
+        units = _pulled()
 
     def run_unit(m, pids):
         if len(pids) == 1 and lockstep == 1:
@@ -184,7 +209,7 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
         for pid, data, out in zip(pids, datas, outs):
             rows[pid - s] = summarize(out, eimp, data, estimate_pose, error_th)
 
-    workers = max(1, min(int(workers), len(units)))
+    workers = max(1, int(workers)) if queue is not None else max(1, min(int(workers), len(units)))
     if workers == 1:
         with torch.no_grad():
             for u in units:
@@ -227,6 +252,9 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
             t.join()
         if errors:
             raise errors[0]
+    if queue is not None:
+        mine = sorted(rows.d)
+        rows.a = np.stack([rows.d[i] for i in mine]) if mine else np.zeros((0, len(SUMMARY_COLUMNS)), dtype=np.float64)
     if not ddp:
         return rows.a[np.argsort(np.asarray(mine, dtype=np.int64), kind='stable')] if len(mine) else rows.a       # rows in pair-id order
     return gather_rows_by_id(rows.a, mine, n_pairs, device=model._device() if hasattr(model, '_device') else 'cpu', group=group)

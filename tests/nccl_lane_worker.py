@@ -47,6 +47,9 @@ def main():
     par = pipeline.StepPipeline([make_fn(r, i, 3) for i, r in enumerate(reps)], 2, device=dev).run(7, keep=True)
     same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(seq, par))
     distinct = not torch.equal(seq[0][0], seq[1][0])
+    # round 5: ONE collective per 3 steps (exchange_every: dist.all_gather_matches_steps on the same lane)
+    par3 = pipeline.StepPipeline([make_fn(r, i, 3) for i, r in enumerate(reps)], 2, device=dev, exchange_every=3).run(7, keep=True)
+    same3 = len(par3) == 7 and all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(seq, par3))
     # round 4: a SECOND communicator alive and busy in the same process (another process group, its own stream and host
     # thread) beside the ordered exchange lane and the spin gate of the waiting kernels: the steps must still come out identical
     import threading
@@ -77,7 +80,7 @@ def main():
     dist.barrier()
     dist.destroy_process_group()
     print(json.dumps({'steps': len(par), 'same': bool(same), 'distinct_batches': bool(distinct),
-                      'backend': 'nccl', 'matched': int((par[-1][0] >= 0).sum()), 'same_beside_a_second_process_group': bool(same2),
+                      'backend': 'nccl', 'matched': int((par[-1][0] >= 0).sum()), 'same_beside_a_second_process_group': bool(same2), 'same_with_one_exchange_per_3_steps': bool(same3),
                       'second_group_collectives': counts[0][0] if counts else -1, 'second_group_ok': bool(counts and counts[0][1]),
                       'no_waiting_kernel_timed_out': bool(healthy)}), flush=True)
 

@@ -206,6 +206,15 @@ for s_, (gi_, gm_) in enumerate(outs):
     fi = torch.randint(-1, Nk, (n_tot, Nk), generator=gen, dtype=torch.int64)
     fm = torch.rand(n_tot, Nk, generator=gen)
     assert torch.equal(gi_, fi) and torch.equal(gm_, fm), (rank, s_)
+# ... and with ONE collective per 4 steps (exchange_every: a fast rank then waits for a slow one once per 4 steps)
+pipe = pipeline.StepPipeline([make_fn(i) for i in range(3)], n_tot, exchange_every=4)
+outs = pipe.run(10, keep=True)
+assert len(outs) == 10
+for s_, (gi_, gm_) in enumerate(outs):
+    gen = torch.Generator().manual_seed(1000 + s_)
+    fi = torch.randint(-1, Nk, (n_tot, Nk), generator=gen, dtype=torch.int64)
+    fm = torch.rand(n_tot, Nk, generator=gen)
+    assert torch.equal(gi_, fi) and torch.equal(gm_, fm), (rank, s_)
 # the sharded evaluation loop under DELIBERATE imbalance (round 4, SURVEY 8e): longest-first assignment of pairs to ranks, lock-step
 # groups, and the id-based gather - the table must equal the sequential one whatever the schedule
 from imp_release_amd import matching
@@ -234,7 +243,8 @@ def fake_lockstep_rec(datas, m, *a, **k):
     groups_seen.append([d['pid'] for d in datas])
     return fake_lockstep(datas, m, *a, **k)
 for kw in (dict(), dict(schedule='lpt', pair_cost=lambda i: costs[i]), dict(schedule='lpt', pair_cost=lambda i: costs[i], lockstep=3), dict(lockstep=2),
-           dict(lockstep=2, group_similar=4, pair_cost=lambda i: costs[i]), dict(lockstep=3, group_similar=100, pair_cost=lambda i: costs[i], schedule='lpt')):
+           dict(lockstep=2, group_similar=4, pair_cost=lambda i: costs[i]), dict(lockstep=3, group_similar=100, pair_cost=lambda i: costs[i], schedule='lpt'),
+           dict(schedule='dynamic'), dict(schedule='dynamic', lockstep=3), dict(schedule='dynamic', lockstep=2, group_similar=4, pair_cost=lambda i: costs[i])):
     tab = eval_loop.run_pairs_sharded(FakeModel(), provider, len(costs), **kw)
     assert tab.shape == expect.shape and np.array_equal(np.nan_to_num(tab, nan=-7.0), np.nan_to_num(expect, nan=-7.0)), (rank, kw.keys())
 # group_similar: inside every window of W pairs of a rank the groups are formed in descending cost order (world 1 here: checked on rank 0's own call)
@@ -294,6 +304,79 @@ def test_world_size_2_all_gather_over_gloo(tmp_path):
                                       stderr=subprocess.STDOUT, text=True))
     for p in procs:
         out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, out
+
+
+_WORKER4 = r'''
+import os, sys, time, torch, torch.distributed as dist
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from imp_release_amd import dist as pdist, eval_loop, matching
+dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
+rank, world = dist.get_rank(), dist.get_world_size()
+# 48 pairs whose cost (the loop's exit iteration: 6 ... 15) is SKEWED along the list: the first quarter - one rank's contiguous block - holds
+# all the long ones.  No size-based static split sees that; the shared counter does
+nit = [15] * 12 + [6] * 36
+def provider(pid):
+    return {'pid': pid, 'n': 20, 'keypoints0': torch.zeros(1, 20, 2), 'keypoints1': torch.zeros(1, 12, 2)}
+def fake_one(data):
+    pid = data['pid']
+    idx = np.full(20, -1, dtype=np.int64); idx[:pid % 20] = np.arange(pid % 20) % 12
+    return idx, (np.arange(20) % 5).astype(np.float32) / 5, None, None, nit[pid]
+spent = [0.0]
+def fake_loop(data, m, *a, **k):
+    t = 0.002 * nit[data['pid']]
+    time.sleep(t); spent[0] += t
+    return fake_one(data)
+def fake_lockstep(datas, m, *a, **k):
+    t = 0.002 * max(nit[d['pid']] for d in datas)
+    time.sleep(t); spent[0] += t
+    return [fake_one(d) for d in datas]
+matching.matching_iterative = fake_loop
+matching.matching_iterative_lockstep = fake_lockstep
+class FakeModel:
+    def _device(self):
+        return torch.device('cpu')
+expect = np.stack([eval_loop.summarize(fake_one(provider(i)), False, provider(i)) for i in range(len(nit))])
+loads = {}
+for name, kw in (('block', dict()), ('dynamic', dict(schedule='dynamic')), ('dynamic_groups', dict(schedule='dynamic', lockstep=2))):
+    spent[0] = 0.0
+    dist.barrier()
+    tab = eval_loop.run_pairs_sharded(FakeModel(), provider, len(nit), **kw)
+    assert np.array_equal(np.nan_to_num(tab, nan=-7.0), np.nan_to_num(expect, nan=-7.0)), (rank, name)
+    t = torch.tensor([spent[0]], dtype=torch.float64)
+    allt = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(allt, t)
+    loads[name] = [float(x) for x in allt]
+total = 0.002 * sum(nit)
+assert max(loads['block']) >= 0.002 * 15 * 12 - 1e-9, loads            # rank 0's contiguous block holds every long pair
+for name in ('dynamic', 'dynamic_groups'):
+    assert max(loads[name]) <= total / world + 0.002 * 15 * 2 + 1e-9, (name, loads)      # within two of the longest items of the even split
+    assert max(loads[name]) < 0.75 * max(loads['block']), (name, loads)
+if rank == 0:
+    print('loads (s of loop time per rank):', {k: [round(v, 3) for v in x] for k, x in loads.items()})
+dist.barrier()
+dist.destroy_process_group()
+print('rank', rank, 'ok')
+'''
+
+
+def test_world_size_4_dynamic_pair_queue_over_gloo(tmp_path):
+    """VERDICT r4 #8b: configs[4] on several ranks with pairs whose exit iteration is skewed - the dynamic schedule (one shared counter in
+    the job's store, dist.DynamicPairQueue) evens the ranks' loop time out where contiguous blocks leave one rank with all the long pairs;
+    the summary table is the same under every schedule"""
+    script = tmp_path / 'worker4.py'
+    script.write_text(_WORKER4)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(4):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='4', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
         assert p.returncode == 0, out
 
 
