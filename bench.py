@@ -169,6 +169,18 @@ def batch1_latencies(dev, args):
         out['eimp_n4096_ms_per_pair'] = timeit(
             lambda: matching.matching_iterative_uncertainty(d, m, 15, 0.1, 25, 1.0, {'pose': 1.5}, trace=tr), 4, 1)
         out['eimp_n4096_trajectory'] = [(t['n0'], t['n1']) for t in tr[-7:]]
+        # AdaGMN.produce_matches, the MASKED adaptive pooling of nets/adgm.py:327-526, at N = 1024, batch 4 (never timed before):
+        # since round 5 the four pairs' kept keypoints are scored as one ragged batch per iteration
+        try:
+            mm_ = model_of('AdaGMN', eval_config(15, 20), bin_score=5.0)
+            pr_ = synthetic.make_correlated_pair(1024, 1000, seed=61, batch=4)
+            dm_ = {k: torch.from_numpy(v).to(dev) for k, v in pr_.items() if k != 'image_shape'}
+            dm_['image0'] = dm_['image1'] = torch.zeros(pr_['image_shape'], device=dev)
+            out['adagmn_masked_n1024_b4_ms_per_call'] = timeit(lambda: mm_.produce_matches(dm_, p=0.2), 5, 2)
+            del mm_
+        except Exception as ex:                       # noqa: BLE001 - the key is optional
+            out['adagmn_masked_n1024_b4_ms_per_call'] = None
+            out['adagmn_masked_error'] = repr(ex)[:200]
         # the SuperPoint front-end (image -> keypoints + descriptors) that feeds the matcher, and the chain image
         # pair -> 2 x SuperPoint -> GM (configs[1] shape: top-1024 keypoints per image), everything on the GPU
         from imp_release_amd.superpoint import SuperPoint

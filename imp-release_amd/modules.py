@@ -594,15 +594,38 @@ class AdaGMN(GM):
                 a10 = ctx.attention_received(2, nB, nK1, dev); a01 = ctx.attention_received(3, nB, nK0, dev)
                 mask0 = torch.zeros(nB, nK0, device=dev, dtype=torch.uint8)
                 mask1 = torch.zeros(nB, nK1, device=dev, dtype=torch.uint8)
+            # round 5: the pairs' kept keypoints as ONE ragged batch - gathered into a batch padded to the largest kept set,
+            # scored by one imp_match_tail_scores call under per-pair counts (one final projection, one distance GEMM, one chip-resident
+            # Sinkhorn and one match kernel for all pairs instead of one of each per pair; every pair's dense score tensor comes back in its
+            # slot for the pool).  Batch 1, the dual-softmax scorer and batches the resident kernel cannot hold keep the per-pair calls
+            batched = None
+            if nB > 1 and self.with_sinkhorn and nB <= self.RAGGED_MAX:
+                c0, c1 = [int(g.numel()) for g in gids0], [int(g.numel()) for g in gids1]
+                G0, G1 = max(c0), max(c1)
+                S0 = torch.zeros(nB, G0, d0.shape[2], device=dev); S1 = torch.zeros(nB, G1, d1.shape[2], device=dev)
+                for bi in range(nB):
+                    ctx.gather_rows(d0[bi:bi + 1], gids0[bi], out=S0[bi]); ctx.gather_rows(d1[bi:bi + 1], gids1[bi], out=S1[bi])
+                try:
+                    ctx.set_counts(c0, c1)
+                    batched = ctx.match_tail(ni, S0, S1, binv, self.sinkhorn_iterations, True, p, want_scores=True)
+                except _lib.ResidentDoesNotFit:
+                    batched = None
+                finally:
+                    ctx.set_counts()
             for bi in range(nB):
                 g0, g1 = gids0[bi], gids1[bi]
-                full = g0.numel() == nK0 and g1.numel() == nK1
-                s0 = d0[bi:bi + 1] if full else ctx.gather_rows(d0[bi:bi + 1], g0)
-                s1 = d1[bi:bi + 1] if full else ctx.gather_rows(d1[bi:bi + 1], g1)
-                # final_proj is per token, so projecting the gathered tokens == gathering the projection
-                score = ctx.compute_score(ctx.compute_distance(ni, s0, s1), binv, self.sinkhorn_iterations,
-                                          self.with_sinkhorn)
-                i0, _, m0, _ = ctx.compute_matches(score, p)
+                if batched is not None:
+                    n0b, n1b = g0.numel(), g1.numel()
+                    score = batched['scores'][bi, :(n0b + 1) * (n1b + 1)].view(1, n0b + 1, n1b + 1)
+                    i0, m0 = batched['indices0'][bi:bi + 1, :n0b], batched['mscores0'][bi:bi + 1, :n0b]
+                else:
+                    full = g0.numel() == nK0 and g1.numel() == nK1
+                    s0 = d0[bi:bi + 1] if full else ctx.gather_rows(d0[bi:bi + 1], g0)
+                    s1 = d1[bi:bi + 1] if full else ctx.gather_rows(d1[bi:bi + 1], g1)
+                    # final_proj is per token, so projecting the gathered tokens == gathering the projection
+                    score = ctx.compute_score(ctx.compute_distance(ni, s0, s1), binv, self.sinkhorn_iterations,
+                                              self.with_sinkhorn)
+                    i0, _, m0, _ = ctx.compute_matches(score, p)
                 pred_score = score
                 keep0 = keep1 = None
                 if updating:

@@ -245,6 +245,42 @@ def test_lockstep_loop_equals_the_pairs_one_at_a_time(pose_threads, native):
     assert m._ensure_ctx().resident_health() == (0, 0)
 
 
+def test_masked_adagmn_batch_scores_all_pairs_in_one_ragged_call():
+    """nets/adgm.py:327-526 (masked adaptive pooling) on a batch of 3 pairs: since round 5 the pairs' kept keypoints are scored as ONE ragged
+    batch per iteration (modules.AdaGMN.produce_matches) - per pair the result of the pair alone (the batch takes other kernel decompositions:
+    scores agree to fp32 summation order), with real pruning going on (bin_score 5)"""
+    cfg = eval_config(n_layers=9)
+    sd = synthetic.make_state_dict(cfg, 'AdaGMN', seed=2, bin_score=5.0)
+    m = make_hip_model('AdaGMN', cfg, sd)
+    pairs = [synthetic.make_correlated_pair(640, 600, seed=8300 + k) for k in range(3)]
+    datas = []
+    for pr in pairs:
+        d = {k: torch.from_numpy(v).to(DEV) for k, v in pr.items() if k != 'image_shape'}
+        d['image0'] = d['image1'] = torch.zeros(pr['image_shape'], device=DEV)
+        datas.append(d)
+    batch = {k: torch.cat([d[k] for d in datas], 0) for k in datas[0] if not k.startswith('image')}
+    batch['image0'] = batch['image1'] = datas[0]['image0']
+    with torch.no_grad():
+        solo = [m.produce_matches(d, p=0.2) for d in datas]
+        calls = []
+        ctx = m._ensure_ctx()
+        orig = ctx.match_tail
+        ctx.match_tail = lambda *a, **k: (calls.append(a[1].shape[0]), orig(*a, **k))[1]
+        try:
+            together = m.produce_matches(batch, p=0.2)
+        finally:
+            ctx.match_tail = orig
+    assert calls and all(c == 3 for c in calls), calls                      # one ragged call per pooled iteration, all three pairs in it
+    n_it = len(solo[0]['indices0'])
+    assert len(together['indices0']) == n_it
+    pruned = False
+    for it in range(n_it):
+        for b in range(3):
+            compare_matches(together['indices0'][it][b:b + 1].cpu(), together['mscores0'][it][b:b + 1].cpu(), solo[b]['indices0'][it].cpu().numpy(),
+                            solo[b]['mscores0'][it].cpu().numpy(), 0.2, TOL, f'masked AdaGMN pair {b} it {it}: batch vs alone', strict=False)
+    assert m._ensure_ctx().resident_health() == (0, 0)
+
+
 @pytest.mark.parametrize('eimp,native', [(False, False), (False, True), (True, False), (True, True)])
 def test_lockstep_loops_step_down_to_single_pairs_without_the_resident_kernel(eimp, native, monkeypatch):
     """on a context WITHOUT the chip-resident Sinkhorn (IMP_OT_RESIDENT=0 here; in production: after two time-outs, or a pair
