@@ -136,6 +136,34 @@ __device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, int q, unsigned 
     return f32x4{__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(c[0]), __uint_as_float(c[2])};
 }
 
+// TWO chunks with both loads in flight per poll round (round 5): an exchange vector is NQ = 64 NCH + 1 chunks (the dustbin column makes it odd), so
+// of 512 threads one - or, staging a slice, a few - owns two chunks; polled one after the other that is a second dependent memory round trip
+// on the critical path of every iteration
+#ifndef OTR_DUAL_POLL
+#define OTR_DUAL_POLL 0        // (measured neutral: 6.09-6.12 vs 6.11-6.14 us per iteration at B = 4, N = 2048 - the waiting dominates, not the second round trip)
+#endif
+__device__ __forceinline__ void ldg4x2(__amdgpu_buffer_rsrc_t r, int q0, int q1, bool two, unsigned tag, const Health& status, bool& dead, f32x4& o0, f32x4& o1) {
+    u32x4 a, c, a2 = {0, tag, 0, tag}, c2 = {0, tag, 0, tag};
+    int spins = 0;
+    for (;;) {
+        asm volatile("" ::: "memory");
+        a = __builtin_amdgcn_raw_buffer_load_b128(r, q0 * 32, 0, AUX_POLL);
+        c = __builtin_amdgcn_raw_buffer_load_b128(r, q0 * 32 + 16, 0, AUX_POLL);
+        if (two) {
+            a2 = __builtin_amdgcn_raw_buffer_load_b128(r, q1 * 32, 0, AUX_POLL);
+            c2 = __builtin_amdgcn_raw_buffer_load_b128(r, q1 * 32 + 16, 0, AUX_POLL);
+        }
+        const bool ok = a[1] == tag && a[3] == tag && c[1] == tag && c[3] == tag && a2[1] == tag && a2[3] == tag && c2[1] == tag && c2[3] == tag;
+        if (ok || dead) break;
+#if OTR_POLL_SLEEP
+        __builtin_amdgcn_s_sleep(OTR_POLL_SLEEP);
+#endif
+        if ((++spins & 1023) == 0) poll_health(status, spins, dead);
+    }
+    o0 = f32x4{__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(c[0]), __uint_as_float(c[2])};
+    o1 = f32x4{__uint_as_float(a2[0]), __uint_as_float(a2[2]), __uint_as_float(c2[0]), __uint_as_float(c2[2])};
+}
+
 // one granule
 __device__ __forceinline__ float ldg1(__amdgpu_buffer_rsrc_t r, int idx, unsigned tag, const Health& status, bool& dead) {
     u32x2 a;
@@ -344,25 +372,47 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         }
         if (lane == 0) *reinterpret_cast<f32x4*>(red + wave * LDX + DCOL) = f32x4{pdpart, 0.f, 0.f, 0.f};
         __syncthreads();
-        for (int q = tid; q < NQ; q += 512) {
+        for (int q = tid; q < NQ; q += 1024) {       // (two chunks per round: the one thread that owns chunk 512 too reads all 16 fragments before it adds)
+            const int q2 = q + 512;
+            const bool two = q2 < NQ;
             f32x4 s = *reinterpret_cast<const f32x4*>(red + 4 * q);
+            f32x4 s2 = two ? *reinterpret_cast<const f32x4*>(red + 4 * q2) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 1; w < 8; ++w) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(red + w * LDX + 4 * q);
                 s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+                if (two) {
+                    const f32x4 t2 = *reinterpret_cast<const f32x4*>(red + w * LDX + 4 * q2);
+                    s2[0] += t2[0]; s2[1] += t2[1]; s2[2] += t2[2]; s2[3] += t2[3];
+                }
             }
             stg4<ST_AUX>(rs_part, gl * NQ + q, s, tag_p);
+            if (two) stg4<ST_AUX>(rs_part, gl * NQ + q2, s2, tag_p);
         }
         __syncthreads();                           // everyone is done with the wave partials in `red`
         OTR_CLK(1)
         // ---- C: this workgroup's slice of columns over the G partial vectors -------------------------------------
         {
             f32x4* stage = reinterpret_cast<f32x4*>(red);             // [H][cq]
+#if OTR_DUAL_POLL
+            for (int idx = tid; idx < cq * H; idx += 1024) {
+                const int idx2 = idx + 512;
+                const int w = idx / cq, qq = idx - w * cq, q = gl * cq + qq;
+                const int w2 = idx2 / cq, qq2 = idx2 - w2 * cq, q2 = gl * cq + qq2;
+                const bool v1 = q < NQ, v2 = idx2 < cq * H && q2 < NQ;
+                f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+                if (v1) ldg4x2(rs_part, w * NQ + q, w2 * NQ + q2, v2, tag_p, health, dead, o0, o1);
+                else if (v2) o1 = ldg4(rs_part, w2 * NQ + q2, tag_p, health, dead);
+                stage[idx] = o0;
+                if (idx2 < cq * H) stage[idx2] = o1;
+            }
+#else
             for (int idx = tid; idx < cq * H; idx += 512) {
                 const int w = idx / cq, qq = idx - w * cq;
                 const int q = gl * cq + qq;
                 stage[idx] = q < NQ ? ldg4(rs_part, w * NQ + q, tag_p, health, dead) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
+#endif
             __syncthreads();
             OTR_CLK(2)
             // 8 threads per column, each over a contiguous eighth of the workgroups; then combined in order
@@ -399,7 +449,16 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         }
         OTR_CLK(3)
         // ---- D: everybody reads v -----------------------------------------------------------------------------------
+#if OTR_DUAL_POLL
+        for (int q = tid; q < NQ; q += 1024) {
+            f32x4 o0, o1;
+            ldg4x2(rs_v, q, q + 512, q + 512 < NQ, tag_v, health, dead, o0, o1);
+            *reinterpret_cast<f32x4*>(vs + 4 * q) = o0;
+            if (q + 512 < NQ) *reinterpret_cast<f32x4*>(vs + 4 * (q + 512)) = o1;
+        }
+#else
         for (int q = tid; q < NQ; q += 512) *reinterpret_cast<f32x4*>(vs + 4 * q) = ldg4(rs_v, q, tag_v, health, dead);
+#endif
         __syncthreads();
         OTR_CLK(4)
         {   // sum of v (every wave computes the same value in the same order: no further barrier)
