@@ -11,7 +11,7 @@ A "step" = produce_matches over the rank's batch with inputs already resident in
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Extra objects on the JSON line:
-  roofline      dominant kernel = the flash-attention kernel (60 % of the pair's FLOPs; attn_f16x3_pp_kernel<64> in the default
+  roofline      dominant kernel = the flash-attention kernel (60 % of the pair's FLOPs; attn_f16x3_pp_kernel<64, false> in the default
                 split-half f16x3 arithmetic, attn_f32_kernel<64, 4> with --precision f32): algorithmic FLOPs per launch
                 (4*N*M*D per image side) / average launch duration measured with HIP events on the launch
                 stream; peak = 2500 / 3 TFLOP/s (dense f16 MFMA, three executed products per algorithmic one) or the
@@ -516,7 +516,7 @@ def main():
     # profiles/; reported only when the profiled kernel and launch geometry are the ones timed here
     traffic = None
     # the f16x3 build takes the phase-staggered 8-wave kernel (256 queries per workgroup) at this size
-    kname = 'attn_f16x3_pp_kernel<64>' if f16x3 else 'attn_f32_kernel<64, 4>'
+    kname = 'attn_f16x3_pp_kernel<64, false>' if f16x3 else 'attn_f32_kernel<64, 4>'
     kgrid = -(-N // 256) * 4 * 2 * B * 512 if f16x3 else -(-N // 128) * 4 * 2 * B * 256
     import glob
     tfile = None
