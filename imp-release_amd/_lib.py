@@ -27,9 +27,17 @@ SYMBOLS = [
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
     'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_pool_select_pair', 'imp_masked_commit', 'imp_gather_rows', 'imp_match_pair', 'imp_set_counts', 'imp_match_tail', 'imp_match_tail_scores', 'imp_pool_pair', 'imp_loop_lockstep', 'imp_loop_lockstep_uncertainty', 'imp_op_linear', 'imp_op_layer_gemm', 'imp_op_fused_mlp',
-    'imp_op_attention', 'imp_time_attention', 'imp_time_attention_clock', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_range_events', 'imp_set_range_recovery', 'imp_range_recovered', 'imp_range_take', 'imp_tag_wraps', 'imp_time_layer_gemm', 'imp_estimate_pose',
+    'imp_op_attention', 'imp_time_attention', 'imp_time_attention_clock', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_range_events', 'imp_set_range_recovery', 'imp_range_recovered', 'imp_range_take', 'imp_tag_wraps', 'imp_time_layer_gemm', 'imp_estimate_pose', 'imp_pose_stats',
     'imp_sp_create', 'imp_sp_destroy', 'imp_sp_set_weight', 'imp_sp_finalize', 'imp_sp_detect', 'imp_sp_describe', 'imp_sp_dense', 'imp_sp_op_conv',
 ]
+
+
+def default_pose_flags():
+    """IMP_POSE_MAGSAC, + IMP_POSE_ADAPTIVE with IMP_POSE_ADAPTIVE=1 in the environment (include/imp_hip.h).  Adaptive termination is OFF by
+    default: measured in the configs[4] loops (profiles/r05/pose_adaptive_*.log) it LOWERS the rate - 728-742 vs 804-807 pairs/s (IMP),
+    797-831 vs 853-900 (EIMP) - because most estimates of the harder set need more than the first 128 samples and then pay a second
+    solver round (+0.1 ms of latency per estimate, 0.33 vs 0.19 ms per call) while the fixed budget's 1024 samples run side by side in one"""
+    return 1 | (4 if os.environ.get('IMP_POSE_ADAPTIVE', '0') == '1' else 0)
 
 
 class HipLibraryMissing(RuntimeError):
@@ -519,7 +527,7 @@ class Context:
         return out
 
     def loop_lockstep(self, n0, n1, nk0, sc0, de0, nk1, sc1, de1, pts0, pts1, K0, K1, bin_score, sinkhorn_iterations, n_iterations, valid_its,
-                      match_ratio, min_kpts, error_th, stop_pose_deg, pose_threads=4, pose_iterations=1024, pose_seed=1, pose_flags=1):
+                      match_ratio, min_kpts, error_th, stop_pose_deg, pose_threads=4, pose_iterations=1024, pose_seed=1, pose_flags=None):
         """the native lock-step IMP loop (include/imp_hip.h imp_loop_lockstep): padded device tensors + per-pair host arrays in,
         [(indices0, mscores0, R | None, t | None, n_iterations)] out"""
         import numpy as np
@@ -544,7 +552,7 @@ class Context:
         self._check(self.L.imp_loop_lockstep(self.handle, B, a0, a1, N0, N1, _ptr(nk0), _ptr(sc0), _ptr(de0), _ptr(nk1), _ptr(sc1), _ptr(de1),
                                              float(bin_score), int(sinkhorn_iterations), int(n_iterations), C.c_uint(mask), float(match_ratio), int(min_kpts),
                                              C.c_double(float(error_th)), C.c_double(float(stop_pose_deg)), int(pose_threads), int(pose_iterations),
-                                             C.c_uint(pose_seed), int(pose_flags), recs, _stream(self.device)))
+                                             C.c_uint(pose_seed), int(default_pose_flags() if pose_flags is None else pose_flags), recs, _stream(self.device)))
         out = []
         for b in range(B):
             found = bool(recs[b].found)
@@ -555,7 +563,7 @@ class Context:
 
     def loop_lockstep_uncertainty(self, n0, n1, nk0, sc0, de0, nk1, sc1, de1, pts0, pts1, K0, K1, bin_score, sinkhorn_iterations, n_iterations,
                                   valid_its, match_ratio, min_kpts, error_th, stop_pose_deg, with_uncertainty, n_min_tokens=256, pose_threads=4,
-                                  pose_iterations=1024, pose_seed=1, pose_flags=1):
+                                  pose_iterations=1024, pose_seed=1, pose_flags=None):
         """the native lock-step EIMP loop (include/imp_hip.h imp_loop_lockstep_uncertainty): padded device tensors + per-pair host arrays
         in, [(kept0, kept1, indices0, mscores0, R | None, t | None, n_iterations)] out (kept: indices of the surviving keypoints)"""
         import numpy as np
@@ -582,7 +590,7 @@ class Context:
         self._check(self.L.imp_loop_lockstep_uncertainty(
             self.handle, B, a0, a1, N0, N1, _ptr(nk0), _ptr(sc0), _ptr(de0), _ptr(nk1), _ptr(sc1), _ptr(de1), float(bin_score), int(sinkhorn_iterations),
             int(n_iterations), C.c_uint(mask), float(match_ratio), int(min_kpts), C.c_double(float(error_th)), C.c_double(float(stop_pose_deg)),
-            1 if with_uncertainty else 0, int(n_min_tokens), int(pose_threads), int(pose_iterations), C.c_uint(pose_seed), int(pose_flags), recs,
+            1 if with_uncertainty else 0, int(n_min_tokens), int(pose_threads), int(pose_iterations), C.c_uint(pose_seed), int(default_pose_flags() if pose_flags is None else pose_flags), recs,
             _stream(self.device)))
         out = []
         for b in range(B):

@@ -20,6 +20,7 @@
 // these kernels against their CPU twin oracle/pose_oracle.py (same samples, same algebra, every mode), the five-point header against the
 // twin on the host (tests/test_pose.py), the cheirality vote against the geometric definition, recovery of known poses.
 #include "imp_kernels.h"
+#include <atomic>
 #include "../../include/imp_hip.h"
 #include "pose_fivept.h"
 #include <cstdlib>
@@ -261,12 +262,19 @@ __global__ __launch_bounds__(64) void pose_hypotheses_kernel(const double2* __re
 #define FP_L_N 16
 #endif
 constexpr int FP_L = FP_L_N;
+// hbase / need (round 5, adaptive termination): the launch covers samples hbase .. H - 1; with `need` a sample h >= *need is not drawn at all - its
+// group marks its ten candidate slots invalid and leaves (a wave whose four samples are all beyond the bound exits at once)
 __global__ __launch_bounds__(64) void pose_hypotheses5_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n,
-                                                              int H, unsigned seed, double* __restrict__ Eh, int* __restrict__ valid) {
+                                                              int H, unsigned seed, double* __restrict__ Eh, int* __restrict__ valid,
+                                                              int hbase, const int* __restrict__ need) {
     __shared__ fivept::Work work[64 / FP_L];
     const int g = threadIdx.x / FP_L, lane = threadIdx.x % FP_L;
-    const int h = blockIdx.x * (64 / FP_L) + g;
+    const int h = hbase + blockIdx.x * (64 / FP_L) + g;
     if (h >= H) return;                                     // whole groups leave together
+    if (need != nullptr && h >= *need) {
+        if (lane < 10) valid[(long)h * 10 + lane] = 0;
+        return;
+    }
     fivept::Work& w = work[g];
     int ids[5];
     bool ok = true;
@@ -311,11 +319,11 @@ __global__ __launch_bounds__(64) void pose_hypotheses5_kernel(const double2* __r
 constexpr int SCORE_C = SCORE_C_N;
 __global__ __launch_bounds__(256) void pose_score_kernel(const double2* __restrict__ x0, const double2* __restrict__ x1, int n, int ncand,
                                                          const double* __restrict__ Eh, const int* __restrict__ valid, double thr2,
-                                                         const double* __restrict__ wlut, int* __restrict__ counts) {
+                                                         const double* __restrict__ wlut, int* __restrict__ counts, int cbase) {
     __shared__ double red[SCORE_C][4];
     const bool magsac = wlut != nullptr;
     const double inv_k2s2 = 1.0 / (MAGSAC_K * MAGSAC_K * thr2);
-    const int h0 = blockIdx.x * SCORE_C;
+    const int h0 = cbase + blockIdx.x * SCORE_C;
     double E[SCORE_C][9], c[SCORE_C];
     bool ok[SCORE_C];
     bool any = false;
@@ -360,6 +368,36 @@ __global__ __launch_bounds__(256) void pose_score_kernel(const double2* __restri
         for (int j = 0; j < SCORE_C; ++j) okk = j == k ? ok[j] : okk;
         const double q = any ? (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]) : 0.0;
         counts[h0 + k] = okk ? (magsac ? (int)floor(q * QUALITY_SCALE) : (int)q) : -1;
+    }
+}
+
+// Adaptive termination (round 5; the rule of RANSAC / USAC, which the reference reaches through cv2.findEssentialMat(..., prob = 0.99999,
+// method = USAC_MAGSAC), eval/pose_estimation.py:96-105 - OpenCV's own implementation stays unpinned): after the first H1 samples the best
+// support so far gives the inlier ratio w, and k samples contain an all-inlier one with probability 1 - (1 - w^5)^k; the smallest k
+// with (1 - w^5)^k <= 1 - 0.99999 is all that is drawn (at least H1, at most Hmax).  The bound is found by repeated multiplication in
+// IEEE doubles - no log(), so that the CPU twin (oracle/pose_oracle.py) computes the same integer bit for bit.  MAGSAC scoring: the
+// quality floor(4096 sum w_i) / 4096 is a SOFT inlier count (every weight <= 1): it under-states w, the bound errs on the side of more samples.
+constexpr int POSE_H1 = 128;
+__global__ __launch_bounds__(256) void pose_need_kernel(const int* __restrict__ counts, int ncand1, int n, int magsac, int Hmax, int* __restrict__ need) {
+    __shared__ int sm[4];
+    int best = -1;
+    for (int h = threadIdx.x; h < ncand1; h += 256) best = max(best, counts[h]);
+    for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        best = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+        int k = Hmax;
+        if (best > 0) {
+            double w = magsac ? (double)best / (QUALITY_SCALE * (double)n) : (double)best / (double)n;
+            if (w > 1.0) w = 1.0;
+            const double w5 = w * w * w * w * w;
+            const double pfail = 1.0 - w5;
+            double q = 1.0;
+            k = 0;
+            while (k < Hmax) { q = q * pfail; ++k; if (q <= 1e-5) break; }
+        }
+        *need = k < POSE_H1 ? POSE_H1 : k;
     }
 }
 
@@ -679,6 +717,7 @@ __global__ __launch_bounds__(256) void pose_cheirality_kernel(const double2* __r
 //           their early-exit indices from this mask (eval/matching.py:89-90,113), so the drop-in has to reproduce it
 __global__ __launch_bounds__(256) void pose_vote_kernel(int n, const int* __restrict__ good, const unsigned char* __restrict__ bits,
                                                         unsigned char* __restrict__ inl, unsigned char* __restrict__ refmask, double* __restrict__ out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[45] = (double)good[4];        // samples drawn (adaptive termination): travels with the results
     if (out[23] == 0.0) return;
     const int best = max(max(good[0], good[1]), max(good[2], good[3]));
     const int k = good[0] == best ? 0 : (good[1] == best ? 1 : (good[2] == best ? 2 : 3));
@@ -725,6 +764,14 @@ struct PoseWs {
 
 }  // namespace
 
+static std::atomic<long> g_pose_calls{0}, g_pose_samples{0};
+// process-wide counters of the pose step: calls and minimal samples drawn (adaptive termination: fewer than calls x iterations)
+extern "C" void imp_pose_stats(long* calls, long* samples, int reset) {
+    if (calls) *calls = g_pose_calls.load();
+    if (samples) *samples = g_pose_samples.load();
+    if (reset) { g_pose_calls.store(0); g_pose_samples.store(0); }
+}
+
 extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, const double* K0, const double* K1, double norm_thresh,
                                  int iterations, unsigned seed, int device, double* E, double* R, double* t, unsigned char* mask,
                                  unsigned char* consensus, int* n_inliers, int flags, void* stream) {
@@ -742,7 +789,7 @@ extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, 
         ws = PoseWs();
         const size_t cn = (size_t)n < 4096 ? 4096 : (size_t)n, ch = (size_t)iterations < 2048 ? 2048 : (size_t)iterations;
         if (hipMalloc(&ws.x, 2 * cn * sizeof(double2)) != hipSuccess || hipMalloc(&ws.res, 48 * sizeof(double) + 2 * cn) != hipSuccess ||
-            hipMalloc(&ws.Eh, ch * 10 * 9 * sizeof(double)) != hipSuccess || hipMalloc(&ws.good, 4 * sizeof(int)) != hipSuccess ||
+            hipMalloc(&ws.Eh, ch * 10 * 9 * sizeof(double)) != hipSuccess || hipMalloc(&ws.good, 8 * sizeof(int)) != hipSuccess ||
             hipMalloc(&ws.bits, cn) != hipSuccess || hipMalloc(&ws.valid, ch * 10 * sizeof(int)) != hipSuccess ||
             hipMalloc(&ws.counts, ch * 10 * sizeof(int)) != hipSuccess || hipHostMalloc(&ws.pin, 2 * cn * sizeof(double2)) != hipSuccess ||
             hipHostGetDevicePointer(reinterpret_cast<void**>(&ws.pin_dev), ws.pin, 0) != hipSuccess ||
@@ -769,9 +816,25 @@ extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, 
                        reinterpret_cast<const float*>(ws.pin_dev) + (size_t)n * 2, n, K0[2], K0[0], K0[5], K0[4], K1[2], K1[0], K1[5], K1[4], x0, x1);
     const double thr = norm_thresh / ((K0[0] + K0[4] + K1[0] + K1[4]) / 4.0);
     const int ncand = eight ? iterations : iterations * 10;
-    if (eight) hipLaunchKernelGGL(pose_hypotheses_kernel, dim3((iterations + 63) / 64), dim3(64), 0, st, x0, x1, n, iterations, seed, ws.Eh, ws.valid);
-    else hipLaunchKernelGGL(pose_hypotheses5_kernel, dim3((iterations + 64 / FP_L - 1) / (64 / FP_L)), dim3(64), 0, st, x0, x1, n, iterations, seed, ws.Eh, ws.valid);
-    hipLaunchKernelGGL(pose_score_kernel, dim3((ncand + SCORE_C - 1) / SCORE_C), dim3(256), 0, st, x0, x1, n, ncand, ws.Eh, ws.valid, thr * thr, (flags & 1) ? ws.wlut : nullptr, ws.counts);
+    constexpr int SPW = 64 / FP_L;                         // samples per workgroup of the five-point kernel
+    const bool adaptive = (flags & 4) != 0 && !eight && iterations > POSE_H1;
+    if (eight) {
+        hipLaunchKernelGGL(pose_hypotheses_kernel, dim3((iterations + 63) / 64), dim3(64), 0, st, x0, x1, n, iterations, seed, ws.Eh, ws.valid);
+        hipLaunchKernelGGL(pose_score_kernel, dim3((ncand + SCORE_C - 1) / SCORE_C), dim3(256), 0, st, x0, x1, n, ncand, ws.Eh, ws.valid, thr * thr, (flags & 1) ? ws.wlut : nullptr, ws.counts, 0);
+    } else if (!adaptive) {
+        hipLaunchKernelGGL(pose_hypotheses5_kernel, dim3((iterations + SPW - 1) / SPW), dim3(64), 0, st, x0, x1, n, iterations, seed, ws.Eh, ws.valid, 0, (const int*)nullptr);
+        hipLaunchKernelGGL(pose_score_kernel, dim3((ncand + SCORE_C - 1) / SCORE_C), dim3(256), 0, st, x0, x1, n, ncand, ws.Eh, ws.valid, thr * thr, (flags & 1) ? ws.wlut : nullptr, ws.counts, 0);
+    } else {
+        // IMP_POSE_ADAPTIVE: the first POSE_H1 samples and their scores, the bound from the best support (on the device: nothing here waits), then
+        // the remaining samples in launches whose groups / workgroups beyond the bound leave at once - at 70 % inliers 63 samples suffice, the
+        // fixed budget drew 1024: an eighth of the waves, and of the compute units they keep from the matcher's LDS-filling kernels
+        const int nc1 = POSE_H1 * 10;
+        hipLaunchKernelGGL(pose_hypotheses5_kernel, dim3(POSE_H1 / SPW), dim3(64), 0, st, x0, x1, n, POSE_H1, seed, ws.Eh, ws.valid, 0, (const int*)nullptr);
+        hipLaunchKernelGGL(pose_score_kernel, dim3((nc1 + SCORE_C - 1) / SCORE_C), dim3(256), 0, st, x0, x1, n, nc1, ws.Eh, ws.valid, thr * thr, (flags & 1) ? ws.wlut : nullptr, ws.counts, 0);
+        hipLaunchKernelGGL(pose_need_kernel, dim3(1), dim3(256), 0, st, ws.counts, nc1, n, (flags & 1) ? 1 : 0, iterations, ws.good + 4);
+        hipLaunchKernelGGL(pose_hypotheses5_kernel, dim3((iterations - POSE_H1 + SPW - 1) / SPW), dim3(64), 0, st, x0, x1, n, iterations, seed, ws.Eh, ws.valid, POSE_H1, (const int*)(ws.good + 4));
+        hipLaunchKernelGGL(pose_score_kernel, dim3((ncand - nc1 + SCORE_C - 1) / SCORE_C), dim3(256), 0, st, x0, x1, n, ncand, ws.Eh, ws.valid, thr * thr, (flags & 1) ? ws.wlut : nullptr, ws.counts, nc1);
+    }
     // the cheirality step of the reference normalises with K = (K0 + K1) / 2 (eval/pose_estimation.py:29-33): with K0 == K1 (every
     // caller in the repo) these are the coordinates above; a caller with two different cameras gets per-camera normalisation
     constexpr size_t consensus_lds = 2 * (size_t)CPT * CT * sizeof(double2);
@@ -783,6 +846,8 @@ extern "C" int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, 
     const size_t res_bytes = 48 * sizeof(double) + 2 * (size_t)n;
     if (hipMemcpyAsync(ws.pin, ws.res, res_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return IMP_E_HIP;
     if (hipStreamSynchronize(st) != hipSuccess) return IMP_E_HIP;
+    g_pose_calls.fetch_add(1, std::memory_order_relaxed);
+    g_pose_samples.fetch_add(adaptive ? (long)reinterpret_cast<const double*>(ws.pin)[45] : (long)iterations, std::memory_order_relaxed);
     if (hipGetLastError() != hipSuccess) return IMP_E_HIP;
     const double* out = reinterpret_cast<const double*>(ws.pin);
     memcpy(mask, ws.pin + 48 * sizeof(double), n);

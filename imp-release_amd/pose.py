@@ -25,7 +25,7 @@ from . import _lib
 
 
 def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, mask=None, iterations=None, seed=1,
-                  device=None, stream=None, return_consensus=False, scoring='magsac', sampler='5pt'):
+                  device=None, stream=None, return_consensus=False, scoring='magsac', sampler='5pt', adaptive=None):
     """eval/pose_estimation.py:92-115 -> None | (E [3,3], R [3,3], t [3], mask [n] bool).
 
     ``mask`` has the reference's semantics (:113-114: ``mask = E_mask.ravel() >= 0`` is all True, then only the consensus entries
@@ -35,8 +35,13 @@ def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, 
     reference's ``cv2.USAC_MAGSAC``; OpenCV's implementation itself stays unpinned); ``'count'``: plain inlier counting + consensus refits.
     ``sampler='5pt'`` (default): minimal samples of 5 matches through the five-point solver (Nister / Stewenius-Engels-Nister, up to
     10 models per sample; csrc/pose_fivept.h) - like the reference, fewer than 5 matches -> None (eval/pose_estimation.py:93);
-    ``'8pt'``: the linear eight-point sampler of round 2 (needs 8 matches)."""
+    ``'8pt'``: the linear eight-point sampler of round 2 (needs 8 matches).
+    ``adaptive`` (round 5; five-point sampler; default off, IMP_POSE_ADAPTIVE=1 turns the default on - see _lib.default_pose_flags for the measurement): ``iterations`` is the CAP - after 128 samples the best support fixes how many are
+    drawn at all, the smallest k with (1 - w^5)^k <= 1 - 0.99999 (include/imp_hip.h IMP_POSE_ADAPTIVE): the termination rule of the
+    reference's USAC call (eval/pose_estimation.py:96-105, ``prob=conf``) in place of a fixed budget; same seeded sample sequence."""
     import torch
+    if adaptive is None:
+        adaptive = (_lib.default_pose_flags() & 4) != 0
     k0 = np.ascontiguousarray(np.asarray(kpts0, dtype=np.float32))
     k1 = np.ascontiguousarray(np.asarray(kpts1, dtype=np.float32))
     n = k0.shape[0]
@@ -63,7 +68,7 @@ def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, 
     st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
     P = lambda a: a.ctypes.data_as(C.c_void_p)      # noqa: E731
     rc = L.imp_estimate_pose(P(k0), P(k1), n, P(Ka), P(Kb), C.c_double(float(norm_thresh)), int(iterations), C.c_uint(seed), dev,
-                             P(E), P(R), P(t), P(m), P(cons), C.byref(ninl), (1 if scoring == 'magsac' else 0) | (2 if sampler == '8pt' else 0), C.c_void_p(st))
+                             P(E), P(R), P(t), P(m), P(cons), C.byref(ninl), (1 if scoring == 'magsac' else 0) | (2 if sampler == '8pt' else 0) | (4 if adaptive and sampler == '5pt' else 0), C.c_void_p(st))
     if rc == 1:
         return None
     if rc != 0:
@@ -71,3 +76,11 @@ def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, 
     if return_consensus:
         return E.reshape(3, 3), R.reshape(3, 3), t, m.astype(bool), cons.astype(bool)
     return E.reshape(3, 3), R.reshape(3, 3), t, m.astype(bool)
+
+
+def pose_stats(reset=False):
+    """(calls, minimal samples drawn) of the pose step in this process so far (imp_pose_stats)"""
+    L = _lib.lib()
+    a, b = C.c_long(), C.c_long()
+    L.imp_pose_stats(C.byref(a), C.byref(b), 1 if reset else 0)
+    return a.value, b.value

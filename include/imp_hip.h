@@ -373,6 +373,13 @@ int imp_estimate_pose(const float* kpts0, const float* kpts1, int n, const doubl
  * five-point solver (Nister / Stewenius-Engels-Nister: up to 10 models per sample; csrc/pose_fivept.h), which is the default: like the
  * reference it then answers from 5 matches on (eval/pose_estimation.py:93) */
 #define IMP_POSE_8PT 2
+/* flags bit 2 (IMP_POSE_ADAPTIVE, round 5; five-point sampler only): adaptive termination - the rule of RANSAC / USAC that the reference reaches
+ * through cv2.findEssentialMat(..., prob = 0.99999, method = cv2.USAC_MAGSAC) (eval/pose_estimation.py:96-105; OpenCV's implementation itself
+ * stays unpinned).  The first 128 samples are drawn and scored, the best support gives the inlier ratio w, and only the smallest k with
+ * (1 - w^5)^k <= 1e-5 samples (128 <= k <= iterations) are drawn at all - decided on the device, the call still never waits in between.
+ * The samples are the same seeded sequence, so the result equals that of a fixed budget of k.  imp_pose_stats: calls / samples drawn so far. */
+#define IMP_POSE_ADAPTIVE 4
+void imp_pose_stats(long* calls, long* samples, int reset);
 /* Chip-resident Sinkhorn health (csrc/ot_resident.hip; the kernel behind compute_score, nets/gm.py:297-303).  Its workgroups
  * exchange vectors through memory with bounded waits.  A wait that times out (a second process on the GPU, a partition mode
  * that places workgroups differently) voids the launch: the kernel poisons its outputs (maxima NaN -> mscores NaN, indices -1)

@@ -322,7 +322,7 @@ def _weighted_essential(x0, x1, w):
 
 
 def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, mask=None, iterations=4096, seed=1, return_consensus=False,
-                  scoring='magsac', sampler='5pt'):
+                  scoring='magsac', sampler='5pt', adaptive=False, info=None):
     """Signature of eval/pose_estimation.py:92 -> None | (E, R, t, mask).  Threshold: norm_thresh pixels divided by the
     mean focal length, applied to the Sampson distance in normalised coordinates.  ``mask`` follows :113-114 literally: all True,
     only the consensus entries overwritten by the cheirality result; ``return_consensus`` appends the geometric mask
@@ -348,7 +348,25 @@ def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, 
 
     best, bestE = -1, None
     ns = 5 if sampler == '5pt' else 8
+    H1 = 128                                             # csrc/pose.hip POSE_H1
+    need = iterations
     for h in range(iterations):
+        if adaptive and sampler == '5pt' and iterations > H1 and h == H1:
+            # adaptive termination (csrc/pose.hip pose_need_kernel, restated): the best support of the first H1 samples gives the inlier
+            # ratio w; the smallest k with (1 - w^5)^k <= 1e-5 by repeated IEEE-double multiplication (no log: the same integer on both sides)
+            k = iterations
+            if best > 0:
+                w = min(1.0, best / (QUALITY_SCALE * float(n)) if mag else best / float(n))
+                pfail = 1.0 - w * w * w * w * w
+                q, k = 1.0, 0
+                while k < iterations:
+                    q = q * pfail
+                    k += 1
+                    if q <= 1e-5:
+                        break
+            need = max(H1, k)
+        if h >= need:
+            break
         ids = [sample_index(seed, h, k, n) for k in range(ns)]
         if len(set(ids)) < ns:
             continue
@@ -357,6 +375,8 @@ def estimate_pose(kpts0, kpts1, K0, K1, norm_thresh, conf=0.99999, method=None, 
             cnt = quality(E)
             if cnt > best:
                 best, bestE = cnt, E
+    if info is not None:
+        info['samples'] = need
     if bestE is None or best < ((ns / 2) * QUALITY_SCALE if mag else ns):
         return None
     for rnd in range(3 if n >= 8 else 0):                # (weighted) least-squares refits (need 8 points), kept while not worse

@@ -45,6 +45,30 @@ def test_gpu_pose_equals_its_cpu_twin(n, outliers, noise, seed, scoring, sampler
     assert np.allclose(Rg @ Rg.T, np.eye(3), atol=1e-9) and np.isclose(np.linalg.det(Rg), 1.0) and np.isclose(np.linalg.norm(tg), 1.0)
 
 
+@pytest.mark.parametrize('n,outliers,noise,seed', [(500, 0.2, 0.3, 7), (900, 0.45, 0.4, 8), (300, 0.7, 0.5, 9)])
+def test_adaptive_termination_equals_the_cpu_twin(n, outliers, noise, seed):
+    """round 5: adaptive termination - after 128 samples the best support fixes how many of the seeded samples are drawn
+    (smallest k with (1 - w^5)^k <= 1e-5).  The bound is computed on the device by repeated multiplication in IEEE doubles, the numpy twin
+    restates it: the SAME number of samples on both sides, hence the same models, consensus and pose; fewer samples than the cap on the
+    clean scenes, the whole cap on the 70 %-outlier one; and the result equals a FIXED budget of exactly that many samples"""
+    k0, k1, K, R, t, truth = po.synthetic_scene(n, outliers=outliers, noise=noise, seed=seed)
+    cap = 512
+    hip_pose.pose_stats(reset=True)
+    g = hip_pose.estimate_pose(k0, k1, K, K, 1.0, iterations=cap, seed=11, return_consensus=True, adaptive=True)
+    calls, drawn = hip_pose.pose_stats()
+    info = {}
+    c = po.estimate_pose(k0, k1, K, K, 1.0, iterations=cap, seed=11, return_consensus=True, adaptive=True, info=info)
+    assert calls == 1 and drawn == info['samples'], (drawn, info)
+    assert 128 <= drawn <= cap and (drawn < cap) == (outliers < 0.6), drawn
+    assert (g is None) == (c is None) and g is not None
+    Eg, Rg, tg, mrg, mg = g
+    Ec, Rc, tc, mrc, mc = c
+    assert (mg != mc).sum() <= max(1, n // 500), (mg != mc).sum()
+    assert _ang_mat(Rg, Rc) < 1e-3 and _ang_vec(tg, tc) < 1e-2
+    fixed = hip_pose.estimate_pose(k0, k1, K, K, 1.0, iterations=drawn, seed=11, return_consensus=True, adaptive=False)
+    assert np.array_equal(fixed[0], Eg) and np.array_equal(fixed[4], mg)
+
+
 @pytest.mark.parametrize('seed', range(4))
 def test_gpu_pose_recovers_known_poses(seed):
     k0, k1, K, R, t, truth = po.synthetic_scene(1200, outliers=0.35, noise=0.3, seed=20 + seed, angle_deg=8 + 5 * seed)
