@@ -244,6 +244,8 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
                             run_unit(m, unit)
             except BaseException as ex:                  # surfaced on the calling thread
                 errors.append(ex)
+            finally:
+                matching.release_thread_resources()      # this thread's pose workers / pinned staging die with it
 
         threads = [threading.Thread(target=worker, args=(m,), daemon=True) for m in models[:workers]]
         for t in threads:

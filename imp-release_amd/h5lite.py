@@ -301,10 +301,14 @@ class Group:
             links = node._load()
             if part not in links:
                 raise KeyError(f"{name!r} (no {part!r} in {node.name!r})")
-            addr = links[part]
-            path = (node.name.rstrip('/') + '/' + part)
-            types = {t for t, _, _ in self._f._messages(addr)}
-            node = Dataset(self._f, addr, path) if 0x08 in types else Group(self._f, addr, path)
+            kids = node.__dict__.setdefault('_children', {})             # (every child is parsed once per File, not once per access -
+            child = kids.get(part)                                       #  a pair record is 12 accesses of f[key][str(i)]: O(N^2) parsing before)
+            if child is None:
+                addr = links[part]
+                path = (node.name.rstrip('/') + '/' + part)
+                types = {t for t, _, _ in self._f._messages(addr)}
+                child = kids[part] = Dataset(self._f, addr, path) if 0x08 in types else Group(self._f, addr, path)
+            node = child
         return node
 
 
@@ -568,7 +572,9 @@ class Dataset:
                         a, sz, mask = element(p + i * esize)
                         if a is not None and k + i < len(grid):
                             self._place(out, grid[k + i], cdims, self._unfilter(bytes(m[a:a + sz]), mask))
-                    p += n_here * esize + 4
+                # (the pages are laid out POSITIONALLY - page address = first page + index x page size - whether initialised or
+                # not; advancing only past initialised pages decoded a sparse > 1024-chunk dataset from the wrong offsets)
+                p += n_here * esize + 4
                 k += n_here
             return out
         for k in range(min(nelem, len(grid))):

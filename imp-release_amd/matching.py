@@ -232,6 +232,16 @@ def _pose_workers(n, device):
     return pool
 
 
+def release_thread_resources():
+    """drops the CALLING thread's pose-worker pools and pinned staging buffer (ADVICE r4: both are keyed by thread and lived for the process;
+    eval_loop.run_pairs_sharded starts fresh worker threads on every call and now releases them when a worker ends)"""
+    import threading
+    me = threading.get_ident()
+    _PINNED.pop(me, None)
+    for key in [k for k in _POSE_POOLS if k[0] == me]:
+        _POSE_POOLS.pop(key).close()
+
+
 def matching_iterative_lockstep(datas, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method=None, estimate_pose=None,
                                 pose_threads=4, traces=None, native='auto'):
     """:func:`_lockstep_group` on all of ``datas``; a group the chip-resident Sinkhorn cannot hold as one ragged batch (more than 4 pairs of
@@ -461,8 +471,10 @@ def matching_iterative_uncertainty_lockstep(datas, model, nI, match_ratio, min_k
 def _lockstep_group_uncertainty(datas, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method=None, with_uncertainty=False,
                                 estimate_pose=None, pose_threads=4, traces=None, native='auto'):
     """eval/matching.py:126-276 (the EIMP loop: adaptive pooling between the iterations) on SEVERAL pairs at once ->
-    [(pts0, pts1, norm_kpts0, norm_kpts1, indices0, mscores0, R, t, n_iterations)] - per pair exactly what
-    :func:`matching_iterative_uncertainty` returns for it.
+    [(pts0, pts1, norm_kpts0, norm_kpts1, indices0, mscores0, R, t, n_iterations)] - per pair what
+    :func:`matching_iterative_uncertainty` returns for it, up to the pool's boundary cases: a batch takes other kernel decompositions than a
+    single pair (scores agree to ~2e-6), and where a keypoint sits exactly on the pool's threshold / lower-median boundary the kept set can
+    differ by that keypoint (11 of 96 pairs of the harder synthetic set; AUC@5 70.28 alone, 70.01 in groups: eval_loop.run_pairs_sharded).
 
     The pairs form one ragged batch (``imp_set_counts``) whose per-pair counts SHRINK: after every scored iteration each live pair is
     pooled on its own slice of the batch (``imp_pool_pair``: cached attention + the pair's dense score tensor from

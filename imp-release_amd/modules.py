@@ -183,10 +183,18 @@ class GM(nn.Module):
         # _version catches in-place updates (load_state_dict, optimiser steps), data_ptr catches `p.data = new_tensor`
         # (the module tree is walked once: nn.Module.parameters() costs ~1.5 ms per call for the ~350 tensors - more than a batch-1 pair's
         # whole host time; `.to()` / load_state_dict, which may replace Parameter objects, drop the list through _apply / load_state_dict)
-        ps = self.__dict__.get('_ps_cache')
-        if ps is None:
-            ps = list(self.parameters()) + list(self.buffers())
-            self.__dict__['_ps_cache'] = ps
+        # (a REPLACED Parameter object - `m.gnn.x.weight = nn.Parameter(...)`, a submodule's load_state_dict(assign=True), pruning /
+        # parametrize utilities - keeps neither hook busy: the cached list is therefore keyed on the identity of every module's current
+        # parameter / buffer objects, read from the modules' own dicts (no generator chain: ~40 us for the ~120 modules))
+        mods = self.__dict__.get('_mods_cache')
+        if mods is None:
+            mods = self.__dict__['_mods_cache'] = list(self.modules())
+        ident = tuple(id(t) for m in mods for t in (*m._parameters.values(), *m._buffers.values()) if t is not None)
+        cached = self.__dict__.get('_ps_cache')
+        if cached is None or cached[0] != ident:
+            ps = [t for m in mods for t in (*m._parameters.values(), *m._buffers.values()) if t is not None]
+            cached = self.__dict__['_ps_cache'] = (ident, ps)
+        ps = cached[1]
         return (str(self._device()), tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
 
     def refresh_weights(self):
@@ -196,9 +204,9 @@ class GM(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._ctx_key = None
-        self.__dict__.pop('_ps_cache', None)
+        self.__dict__.pop('_ps_cache', None); self.__dict__.pop('_mods_cache', None)
         r = super()._apply(fn, *a, **k)
-        self.__dict__.pop('_ps_cache', None)
+        self.__dict__.pop('_ps_cache', None); self.__dict__.pop('_mods_cache', None)
         return r
 
     def load_state_dict(self, *a, **k):

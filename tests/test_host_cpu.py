@@ -602,3 +602,21 @@ def test_error_classes_of_the_binding_are_distinct():
     assert not issubclass(_lib.ResidentSinkhornTimeout, _lib.ResidentDoesNotFit)
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'imp_hip.h')).read()
     assert '#define IMP_E_NOFIT (-8)' in hdr
+
+
+def test_weights_version_sees_a_replaced_parameter_object():
+    """the cached parameter list of GM._weights_version is keyed on the identity of the modules' current Parameter / buffer
+    objects - replacing one (not an in-place update, not load_state_dict on the top module) must change the version the HIP context is keyed on"""
+    cfg = eval_config(n_layers=2)
+    m = P.GM(cfg).eval()
+    v0 = m._weights_version()
+    assert m._weights_version() == v0
+    conv = m.final_proj[0]
+    conv.weight = torch.nn.Parameter(conv.weight.detach().clone() * 2.0)          # a NEW Parameter object on a submodule
+    v1 = m._weights_version()
+    assert v1 != v0
+    m.final_proj[1].load_state_dict({k: v.clone() + 1 for k, v in m.final_proj[1].state_dict().items()}, assign=True)      # submodule-level load, objects replaced
+    assert m._weights_version() != v1
+    with torch.no_grad():
+        m.bin_score.add_(1.0)                                                       # in-place: _version
+    assert m._weights_version()[1] != v1[1]
