@@ -4,6 +4,7 @@
 #include "../../include/imp_hip.h"
 #include "imp_kernels.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1757,6 +1758,8 @@ static int range_recover_in_call(imp_ctx* c, hipStream_t st, const std::function
     if (!c->range_recover || c->prec != 1 || !c->range_host) return IMP_OK;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return IMP_OK;      // a capture cannot wait
+    // (a polled wait - hipStreamQuery for up to 20 ms before blocking - was measured and is no faster: configs[1] 1.68-1.70 vs 1.65-1.71 ms per call; the
+    // price of the wait is the host's enqueue work no longer running ahead of the GPU, not the wake-up; profiles/r05/c2_latency_range_recovery_ab.log)
     HIP_TRY(hipStreamSynchronize(st));
     if (c->xstatus_host && *static_cast<volatile int*>(c->xstatus_host)) return IMP_OK;
     if (!*static_cast<volatile int*>(c->range_host)) return IMP_OK;
