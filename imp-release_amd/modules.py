@@ -16,6 +16,8 @@ from __future__ import annotations
 from copy import deepcopy
 from typing import Optional
 
+from itertools import chain as _chain
+
 import torch
 import torch.nn as nn
 
@@ -241,15 +243,22 @@ class GM(nn.Module):
         # whole host time; `.to()` / load_state_dict, which may replace Parameter objects, drop the list through _apply / load_state_dict)
         # (a REPLACED Parameter object - `m.gnn.x.weight = nn.Parameter(...)`, a submodule's load_state_dict(assign=True), pruning /
         # parametrize utilities - keeps neither hook busy: the cached list is therefore keyed on the identity of every module's current
-        # parameter / buffer objects, read from the modules' own dicts (no generator chain: ~40 us for the ~120 modules))
-        mods = self.__dict__.get('_mods_cache')
-        if mods is None:
-            mods = self.__dict__['_mods_cache'] = list(self.modules())
-        ident = tuple(id(t) for m in mods for t in (*m._parameters.values(), *m._buffers.values()) if t is not None)
-        cached = self.__dict__.get('_ps_cache')
-        if cached is None or cached[0] != ident:
-            ps = [t for m in mods for t in (*m._parameters.values(), *m._buffers.values()) if t is not None]
-            cached = self.__dict__['_ps_cache'] = (ident, ps)
+        # parameter / buffer objects, read from the modules' own dicts (~35 us for the ~240 modules))
+        for attempt in (0, 1):
+            dicts = self.__dict__.get('_mods_cache')
+            if dicts is None:                    # the modules' own NON-EMPTY parameter / buffer dicts (live objects: a replaced or removed entry shows at once)
+                dicts = self.__dict__['_mods_cache'] = [d for m in self.modules() for d in (m._parameters, m._buffers) if d]
+            ps = list(_chain.from_iterable(map(dict.values, dicts)))        # (None entries - bias=False - stay in: same positions every call)
+            ident = tuple(map(id, ps))
+            cached = self.__dict__.get('_ps_cache')
+            if cached is not None and cached[0] == ident:
+                break
+            if attempt == 0 and cached is not None:                       # something was replaced: the module tree may have changed too (parametrize, pruning)
+                self.__dict__.pop('_mods_cache', None)
+                self.__dict__.pop('_ps_cache', None)
+                continue
+            cached = self.__dict__['_ps_cache'] = (ident, [t for t in ps if t is not None])
+            break
         ps = cached[1]
         return (str(self._device()), tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
 
