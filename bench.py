@@ -302,7 +302,7 @@ def main():
     ap.add_argument('--no-batch1', action='store_true', help='skip the extra batch-1 latency keys (profiling runs: keeps their kernels out of the trace)')
     ap.add_argument('--in-flight', type=int, default=0,
                     help='batch-steps in flight per GPU (model replicas, one stream + host thread each; the result '
-                         'exchange stays one ordered lane). 1 = strictly one step after the other; 0 (default) = the faster of 1 and 3, '
+                         'exchange stays one ordered lane). 1 = strictly one step after the other; 0 (default) = the fastest of 1, 2 and 3, '
                          'decided by a short untimed calibration (round 4: with one step in flight every layer is ONE fused launch, with '
                          'several the two-launch layers interleave - which wins depends on the box)')
     ap.add_argument('--exchange-every', type=int, default=0,
@@ -382,10 +382,11 @@ def main():
     xk = args.exchange_every if args.exchange_every > 0 else (1 if world == 1 else 8)
     calibration = None
     if args.in_flight <= 0:
-        # untimed calibration: the same steps with 1 and with 3 in flight, the faster setting is the one that gets timed
+        # untimed calibration: the same steps with 1, 2 and 3 in flight, the fastest setting is the one that gets timed (round 5: 2 added - with the
+        # in-call range recovery every call waits for its own work, and two streams hide that wait with less interference than three: 1108-1121 vs 1101)
         cal_steps = 12
         rates = {}
-        for k_ in (1, 3):
+        for k_ in (1, 2, 3):
             reps_ = [model] if k_ == 1 else eval_loop.replicate(model, k_)
             pp_ = pipeline.StepPipeline([make_step(m) for m in reps_], n_total, device=dev, exchange_every=xk)
             pp_.run(max(4, k_))
@@ -395,11 +396,11 @@ def main():
             torch.cuda.synchronize()
             rates[k_] = cal_steps / (time.perf_counter() - t0_)
             del pp_, reps_
-        best_ = torch.tensor([rates[1], rates[3]], dtype=torch.float64, device=dev)
+        best_ = torch.tensor([rates[1], rates[2], rates[3]], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(best_, op=dist.ReduceOp.MIN)        # every rank must take the same setting
-        args.in_flight = 1 if float(best_[0]) >= float(best_[1]) else 3
-        calibration = {'steps_per_s_1_in_flight': rates[1], 'steps_per_s_3_in_flight': rates[3], 'chosen': args.in_flight}
+        args.in_flight = 1 + int(torch.argmax(best_).item())
+        calibration = {'steps_per_s_1_in_flight': rates[1], 'steps_per_s_2_in_flight': rates[2], 'steps_per_s_3_in_flight': rates[3], 'chosen': args.in_flight}
     inflight = max(1, args.in_flight)
     replicas = [model] if inflight == 1 else eval_loop.replicate(model, inflight)
 

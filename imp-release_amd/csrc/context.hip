@@ -1804,7 +1804,14 @@ static int match_pair_enqueue(imp_ctx* c, int batch, int n0, int n1, const float
     const float* sc[2] = {scores0, scores1};
     const float* de[2] = {desc0, desc1};
     float* dw[2] = {c->descw[0], c->descw[1]};
+    // host-side section timers (IMP_HOST_PROF=1: microseconds of enqueue work per section, printed every 50 calls)
+    static const bool hprof = [] { const char* e = getenv("IMP_HOST_PROF"); return e && atoi(e) != 0; }();
+    static double hp_acc[5] = {0, 0, 0, 0, 0}; static int hp_n = 0;
+    auto hp_now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double hp_t = hprof ? hp_now() : 0.0;
+    auto hp_mark = [&](int i) { if (hprof) { const double t = hp_now(); hp_acc[i] += t - hp_t; hp_t = t; } };
     if ((rc = run_kenc(c, batch, n, kp, sc, width, height, de, dw, st))) return rc;   // desc + enc (nets/gm.py:177-178)
+    hp_mark(0);
     const uint8_t* nomask[2] = {nullptr, nullptr};
     const float* dr[2] = {c->descw[0], c->descw[1]};
     bool proj_done = false;                                // inside this call the layers chain: layer i's last launch also projects for layer i + 1
@@ -1814,10 +1821,17 @@ static int match_pair_enqueue(imp_ctx* c, int batch, int n0, int n1, const float
         proj_done = chained;
     }
     if (rc) return rc;
+    hp_mark(1);
     if ((rc = run_distance(c, c->cfg.n_layers - 1, batch, n, dr, c->dist, st))) return rc;
+    hp_mark(2);
     OtBuffers o;
     bool max_done = false;
     if ((rc = run_score(c, batch, n0, n1, c->dist, bin_score, sinkhorn_iterations, with_sinkhorn, scores, &o, st, &max_done))) return rc;
+    hp_mark(3);
+    if (hprof && ++hp_n % 50 == 0) {
+        fprintf(stderr, "[IMP_HOST_PROF] enqueue us per call: encoder %.0f  layers %.0f  distance %.0f  score %.0f\n", hp_acc[0] / 50, hp_acc[1] / 50, hp_acc[2] / 50, hp_acc[3] / 50);
+        for (double& a : hp_acc) a = 0;
+    }
     if (!max_done) HIP_TRY(launch_ot_maxima(batch, n0, n1, with_sinkhorn ? 0 : 1, o, c->max0, c->arg0, c->max1, c->arg1, st));
     HIP_TRY(launch_mutual_matches(batch, n0, n1, c->max0, c->arg0, c->max1, c->arg1, p, indices0, indices1, mscores0,
                                   mscores1, c->range_hostdev, st, &c->rc));
