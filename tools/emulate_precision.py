@@ -18,6 +18,7 @@ Schemes:
     f16x1     a single half product (what a plain fp16 MFMA path would do)
     f16x3+p1  f16x3, but the attention probabilities enter P.V as ONE half (2 products instead of 3 there) - an idea that was tested and rejected
     f16x3+p1c the same with the softmax denominators summed from those rounded probabilities (round 5)
+    f16x3+h1  f16x3, but the hidden tile of a layer's MLP enters mlp.3 as ONE half (round 5)
 Sinkhorn storage: 23 (fp32), 15 (3-byte copy), 7 (2-byte, bfloat16-like), 10 (2-byte, half-like mantissa)
 """
 import argparse
@@ -60,6 +61,8 @@ def make_matmul(scheme):
         return lambda a, b, role=None: _matmul(a, b)
     q_single = '+q1' in scheme                      # Q enters Q.K^T as one half (q_hi.k_lo + q_hi.k_hi)
     scheme = scheme.replace('+q1', '')
+    h_single = '+h1' in scheme                      # the hidden tile relu(InstanceNorm(mlp.0(.))) enters mlp.3 as one half (round 5 question: -1/3 of mlp.3's MFMAs)
+    scheme = scheme.replace('+h1', '')
     p_consistent = scheme.endswith('+p1c')          # ... and the row sums are taken from the SAME rounded probabilities (the output is a convex combination again)
     p_single = scheme.endswith('+p1') or p_consistent
     scheme = scheme.replace('+p1c', '').replace('+p1', '')
@@ -73,6 +76,9 @@ def make_matmul(scheme):
             return _matmul(a, b)
         # (round 5: the 4-D test alone also caught Q.K^T, which reaches here through the einsum hook - the round-2 '+p1' column had rounded Q to one
         # half as well; `role` now tells the two attention products apart)
+        if h_single and a.dim() == 3 and b.dim() == 2 and a.shape[-1] == 2 * b.shape[-1]:
+            ca, cb = _components(a, kind, 1), _components(b, kind, 2)
+            return _matmul(ca[0], cb[1]) + _matmul(ca[0], cb[0])
         if q_single and role == 'qk':
             ca, cb = _components(a, kind, 1), _components(b, kind, 2)
             return _matmul(ca[0], cb[1]) + _matmul(ca[0], cb[0])
