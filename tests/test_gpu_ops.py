@@ -519,7 +519,7 @@ def test_operand_beyond_the_fp16_range_is_recovered_inside_the_call(resident):
     os.environ['IMP_OT_RESIDENT'] = resident
     cfg, sd, data, big = _range_case()
     try:
-        m = make_hip_model('GM', cfg, sd)
+        m = make_hip_model('GM', dict(cfg, range_recovery=True), sd)         # (explicit: the default, whatever IMP_RANGE_RECOVERY says)
         m32 = make_hip_model('GM', cfg, sd, precision='f32')
         mref = make_hip_model('GM', dict(cfg, range_recovery=False), sd)
         m._ensure_ctx(); m32._ensure_ctx(); mref._ensure_ctx()      # (contexts read the environment when they are created)
