@@ -48,6 +48,39 @@ def _normalize(model, data):
     return (ctx.normalize_keypoints(data['keypoints0'], w0, h0), ctx.normalize_keypoints(data['keypoints1'], w1, h1))
 
 
+class _PoseHistory:
+    """the pose of the previous scored iteration and how far a new one moved from it (the loops' exit test, eval/matching.py:84-108): the larger
+    of the rotation and translation-direction angles in degrees; infinite at the first iteration or while either pose is missing"""
+
+    def __init__(self):
+        self.R = self.t = None
+
+    def forget(self):
+        self.R = self.t = None
+
+    def change(self, it, R, t):
+        if it >= 1:
+            d_rot = angle_error_mat(self.R, R) if self.R is not None and R is not None else np.inf
+            d_dir = angle_error_vec(self.t, t) if self.t is not None and t is not None else np.inf
+        else:
+            d_rot = d_dir = np.inf
+        self.R, self.t = R, t
+        return np.max([d_rot, d_dir])
+
+
+def _correspondences(found):
+    """[k, 2] (keypoint of image 0, its match in image 1) for the matched keypoints, ascending"""
+    src = np.nonzero(found > -1)[0]
+    return np.stack([src, found[src]], axis=1)
+
+
+def _only_agreeing(found, pairs, agree):
+    """the index vector with every match the pose estimate does not agree with cleared"""
+    out = np.full_like(found, -1)
+    out[pairs[agree, 0]] = pairs[agree, 1]
+    return out
+
+
 def _loop(data, model, nI, match_ratio, min_kpts, error_th, stop_criteria, method, estimate_pose, uncertainty,
           with_uncertainty, trace=None):
     ctx = model._ensure_ctx(check=True)
@@ -63,7 +96,7 @@ def _loop_body(ctx, data, model, nI, match_ratio, min_kpts, error_th, stop_crite
     # desc + enc fused into the encoder's last GEMM epilogue (eval/matching.py:47-50,158-160)
     desc0, desc1 = ctx.encode_keypoints(norm_kpts0, data['scores0'], norm_kpts1, data['scores1'],
                                         data['descriptors0'], data['descriptors1'])
-    last_best_R = last_best_t = None
+    history = _PoseHistory()
     sel_ids0 = sel_ids1 = None
     sel_host0 = sel_host1 = None
     pred_score = None
@@ -102,49 +135,35 @@ def _loop_body(ctx, data, model, nI, match_ratio, min_kpts, error_th, stop_crite
         else:
             raise _lib.ResidentSinkhornTimeout(_lib.IMP_E_RESIDENT, 'the Sinkhorn score stayed void on every protocol')
         idx_h, ms_h = unpack_matches(packed, n0)
-        indices0_cpu, mscores0_cpu = idx_h[0].numpy(), ms_h[0].numpy()
+        found, confid = idx_h[0].numpy(), ms_h[0].numpy()                         # this iteration's matches of image 0 on the host
         if trace is not None:
-            trace.append({'it': it, 'n0': n0, 'n1': n1, 'indices0': indices0_cpu.copy(), 'mscores0': mscores0_cpu.copy(),
+            trace.append({'it': it, 'n0': n0, 'n1': n1, 'indices0': found.copy(), 'mscores0': confid.copy(),
                           'pts0': pts0_cpu.copy(), 'pts1': pts1_cpu.copy()})
-        matched_ids0 = np.nonzero(indices0_cpu > -1)[0]
-        if matched_ids0.shape[0] < min_kpts:                                      # eval/matching.py:63-66
-            last_best_R = last_best_t = None
+        pairs = _correspondences(found)
+        if pairs.shape[0] < min_kpts or pairs.shape[0] == 0:                      # too few matches to estimate from: the pose history starts over (eval/matching.py:63-66)
+            if pairs.shape[0] < min_kpts:
+                history.forget()
             continue
-        matched_ids1 = indices0_cpu[matched_ids0]
-        if matched_ids0.shape[0] == 0:
-            continue
-        pred_matches = np.stack([matched_ids0, matched_ids1], axis=1)
-        ret = None
+        estimate = None
         if estimate_pose is not None:
-            ret = estimate_pose(kpts0=pts0_cpu[pred_matches[:, 0]], kpts1=pts1_cpu[pred_matches[:, 1]], K0=K0, K1=K1,
-                                norm_thresh=error_th, method=method)
-        if ret is not None:
-            E, R, t, pose_inliers = ret
-            inlier_ratio = np.sum(pose_inliers) / pred_matches.shape[0]
-        else:
+            estimate = estimate_pose(kpts0=pts0_cpu[pairs[:, 0]], kpts1=pts1_cpu[pairs[:, 1]], K0=K0, K1=K1, norm_thresh=error_th, method=method)
+        if estimate is None:
             R = t = None
-            pose_inliers = np.zeros(pred_matches.shape[0], dtype=bool)
-            inlier_ratio = 0
-        if it >= 1:
-            diff_R = angle_error_mat(last_best_R, R) if last_best_R is not None and R is not None else np.inf
-            diff_t = angle_error_vec(last_best_t, t) if last_best_t is not None and t is not None else np.inf
+            agree = np.zeros(pairs.shape[0], dtype=bool)
+            support = 0
         else:
-            diff_R, diff_t = np.inf, np.inf
-        pose_diff = np.max([diff_R, diff_t])
-        last_best_R, last_best_t = R, t
-        if uncertainty:                                                           # eval/matching.py:243-257
-            mscore_th = 0.2 * inlier_ratio if (with_uncertainty and inlier_ratio != 0) else 0.2
+            _, R, t, agree = estimate
+            support = np.sum(agree) / pairs.shape[0]
+        moved = history.change(it, R, t)
+        if uncertainty:                                                           # pool threshold from the estimate's support (eval/matching.py:243-257)
+            cut = 0.2 * support if (with_uncertainty and support != 0) else 0.2
             if hasattr(model, 'pool_host'):      # ids on the host from the same copy as the counts (no extra syncs)
-                sel_ids0, sel_ids1, sel_host0, sel_host1 = model.pool_host(pred_score, mscore_th=mscore_th,
-                                                                           uncertainty_ratio=1.0)
+                sel_ids0, sel_ids1, sel_host0, sel_host1 = model.pool_host(pred_score, mscore_th=cut, uncertainty_ratio=1.0)
             else:
                 sel_ids0, sel_ids1 = model.pool(pred_score=pred_score, prob00=model.self_prob0, prob01=model.cross_prob0,
-                                                prob11=model.self_prob1, prob10=model.cross_prob1, mscore_th=mscore_th,
-                                                uncertainty_ratio=1.0)
-        if 'pose' in stop_criteria.keys() and pose_diff <= stop_criteria['pose']:  # eval/matching.py:110-117
-            output_indice0 = np.zeros_like(indices0_cpu) - 1
-            output_indice0[pred_matches[pose_inliers, 0]] = pred_matches[pose_inliers, 1]
-            return pts0_cpu, pts1_cpu, norm_kpts0, norm_kpts1, output_indice0, mscores0_cpu, R, t, it + 1
+                                                prob11=model.self_prob1, prob10=model.cross_prob1, mscore_th=cut, uncertainty_ratio=1.0)
+        if 'pose' in stop_criteria.keys() and moved <= stop_criteria['pose']:      # converged: leave with the matches the pose agrees with (eval/matching.py:110-117)
+            return pts0_cpu, pts1_cpu, norm_kpts0, norm_kpts1, _only_agreeing(found, pairs, agree), confid, R, t, it + 1
     indices0, indices1, mscores0, mscores1 = ctx.compute_matches(pred_score, 0.2)  # eval/matching.py:119,271
     return (pts0_cpu, pts1_cpu, norm_kpts0, norm_kpts1, indices0[0].cpu().numpy(), mscores0[0].cpu().numpy(),
             None, None, nI)
