@@ -299,13 +299,14 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_f16x3_kernel(const AttnPa
 
     // ---- epilogue: normalise, transpose through LDS, coalesced row stores ------------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv_l = 1.0f / l_tot;
     constexpr int LDO = DH + 1;
     float* ot = smem + wave * 32 * LDO;
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            ot[l31 * LDO + d * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = oacc[d][r] / l_tot;
+            ot[l31 * LDO + d * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = imp_div_by(oacc[d][r], l_tot, inv_l);       // == oacc / l_tot, bit for bit
     if (S.lse && half == 0) {
         const int qrow = q0 + wave * 32 + l31;
         if (qrow < nq) S.lse[((long)b * IMP_NUM_HEADS + h) * S.nq + qrow] = m_run + logf(l_tot);
@@ -381,6 +382,9 @@ __device__ unsigned pp_hwid[8];
 #ifndef PP_WHATIF
 #define PP_WHATIF 0         // TIMING EXPERIMENTS ONLY (wrong results): 1 = no staging inside the key loop (the ring keeps its first tiles), 2 = no hi / lo
 #endif                      // split of P (pl = ph), 3 = both: what removing that work from the vector phase could buy at most
+#ifndef PP_DIV3
+#define PP_DIV3 1           // epilogue normalisation O / l as ONE IEEE division y = 1 / l per lane and, per element, q0 = a y; r = fma(-q0, l, a); q = fma(r, y, q0)
+#endif                      // (Markstein's correction: BIT-IDENTICAL to a / l - tools/probe/div3_probe.hip: 0 mismatches in 5.5e11 random quotients, the bare product a y differs in 27 %)
 #ifndef PP_RCP
 #define PP_RCP 0            // epilogue normalisation: 32 IEEE divisions per lane (0) or one division and 32 multiplications (1: -1 % per launch, results move by <= 1 ulp - enough to flip a knife-edge mutual-nearest-neighbour decision of the fixture ragged_dgnns_l15_b4, so the product keeps the divisions)
 #endif
@@ -995,7 +999,13 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
         for (int d = 0; d < DT; ++d)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                otp[l31 * LDP + d * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = PP_RCP ? oacc[d][r] * inv_l : oacc[d][r] / l_tot;
+            {
+                float q;
+                if (PP_RCP) q = oacc[d][r] * inv_l;
+                else if (PP_DIV3) q = imp_div_by(oacc[d][r], l_tot, inv_l);
+                else q = oacc[d][r] / l_tot;
+                otp[l31 * LDP + d * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = q;
+            }
         if (S.lse && half == 0) {
             const int qrow = q0 + wave * 32 + l31;
             if (qrow < nq) S.lse[((long)b * IMP_NUM_HEADS + h) * S.nq + qrow] = m_ref * (1.0f / LOG2E) + logf(l_tot);

@@ -234,13 +234,14 @@ __global__ __launch_bounds__(NWAVES * 64, (NWAVES == 4 ? 2 : 1)) void attn_f32_k
 
     // ---- epilogue: normalise, transpose through LDS, coalesced row stores -------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv_l = 1.0f / l_tot;
     constexpr int LDO = DH + 1;
     float* ot = smem + wave * 32 * LDO;        // K/V tiles are dead after the loop's last barrier
 #pragma unroll
     for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            ot[l31 * LDO + d * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = oacc[d][r] / l_tot;
+            ot[l31 * LDO + d * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = imp_div_by(oacc[d][r], l_tot, inv_l);        // == oacc / l_tot, bit for bit
     if (S.lse && half == 0) {
         const int qrow = q0 + wave * 32 + l31;
         if (qrow < nq) S.lse[((long)b * IMP_NUM_HEADS + h) * S.nq + qrow] = m_run + logf(l_tot);

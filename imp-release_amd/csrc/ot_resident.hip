@@ -313,10 +313,11 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             }
         const float ed = expf(bin - mx);
         sum = wave_sum(sum) + ed;
+        const float inv_sum = 1.0f / sum;           // (sum >= 1: the row maximum contributes exp(0))
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) P[k][c][e] = rv ? P[k][c][e] / sum : 0.f;
+            for (int e = 0; e < 4; ++e) P[k][c][e] = rv ? imp_div_by(P[k][c][e], sum, inv_sum) : 0.f;      // == P / sum, bit for bit (imp_kernels.h)
         Pd[k] = rv ? ed / sum : 0.f;
     }
     const float c0 = 1.0f / (float)(n1 + 1);   // every entry of the dustbin row: softmax of n1 + 1 equal logits
