@@ -43,30 +43,32 @@ def dense_descriptors(sd, x):
     return F.normalize(_conv(sd, 'convDb', torch.relu(_conv(sd, 'convDa', x, 1)), 0), p=2, dim=1)
 
 
+def _window_max(t, radius):
+    return F.max_pool2d(t, 2 * radius + 1, 1, radius)
+
+
 def simple_nms(scores, radius):
-    """nets/superpoint.py:49-63"""
-    def mp(t):
-        return F.max_pool2d(t, kernel_size=radius * 2 + 1, stride=1, padding=radius)
-    zeros = torch.zeros_like(scores)
-    max_mask = scores == mp(scores)
+    """nets/superpoint.py:49-63, restated: a pixel survives when it is the maximum of its (2 radius + 1)^2 window; twice more, pixels
+    farther than `radius` from every survivor compete among themselves (the neighbourhoods of the survivors count as zero) and the
+    window maxima among THEM survive as well.  Everything else becomes 0."""
+    keep = scores == _window_max(scores, radius)
     for _ in range(2):
-        supp = mp(max_mask.float()) > 0
-        ss = torch.where(supp, zeros, scores)
-        new = ss == mp(ss)
-        max_mask = max_mask | (new & (~supp))
-    return torch.where(max_mask, scores, zeros)
+        taken = _window_max(keep.to(scores.dtype), radius) > 0            # within `radius` of a survivor
+        rest = scores.masked_fill(taken, 0.0)
+        keep = keep | ((rest == _window_max(rest, radius)) & ~taken)
+    return scores.masked_fill(~keep, 0.0)
 
 
 def sample_descriptors(kpts_xy, desc, s=8, align_corners=True):
-    """nets/superpoint.py:82-94: bilinear sampling of [1, D, h, w] at pixel keypoints [1, N, 2] (x, y).  align_corners: the reference
-    passes True only when int(torch.__version__[2]) > 2 (:89), i.e. torch 1.3-1.9; on torch 2.x grid_sample's default False applies."""
-    b, c, h, w = desc.shape
-    k = kpts_xy - s / 2 + 0.5
-    k = k / torch.tensor([(w * s - s / 2 - 0.5), (h * s - s / 2 - 0.5)]).to(k)[None]
-    k = k.to(desc.dtype)
-    k = k * 2 - 1
-    d = F.grid_sample(desc, k.view(b, 1, -1, 2), mode='bilinear', align_corners=align_corners)
-    return F.normalize(d.reshape(b, c, -1), p=2, dim=1)
+    """nets/superpoint.py:82-94: bilinear sampling of the coarse descriptor map [1, D, h, w] at pixel keypoints [1, N, 2] (x, y), then L2
+    normalisation.  A pixel coordinate p maps to the sampling coordinate 2 (p - s/2 + 1/2) / (n s - s/2 - 1/2) - 1 (n = w for x, h for y;
+    same operation order as the reference, so the same bits).  align_corners: the reference passes True only when
+    int(torch.__version__[2]) > 2 (:89), i.e. torch 1.3-1.9; on torch 2.x grid_sample's default False applies."""
+    n_img, depth, h, w = desc.shape
+    span = torch.tensor([w * s - s / 2 - 0.5, h * s - s / 2 - 0.5]).to(kpts_xy)
+    grid = (((kpts_xy - s / 2 + 0.5) / span[None]).to(desc.dtype) * 2 - 1).view(n_img, 1, -1, 2)
+    picked = F.grid_sample(desc, grid, mode='bilinear', align_corners=align_corners)
+    return F.normalize(picked.reshape(n_img, depth, -1), p=2, dim=1)
 
 
 def forward(sd, image, nms_radius=4, keypoint_threshold=0.0025, max_keypoints=-1, remove_borders=4, align_corners=True):
