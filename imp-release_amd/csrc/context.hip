@@ -108,7 +108,7 @@ struct imp_ctx {
     int *arg0 = nullptr, *arg1 = nullptr, *colpart_i = nullptr;
     float *colsum[4] = {}, *amass[4] = {}, *mass[2] = {};
     AttnCache cache[2];
-    float* xhalf = nullptr;  // resident Sinkhorn, two XCDs per pair: the half sums the XCDs swap
+    float* xhalf = nullptr;  // resident Sinkhorn, two XCDs per pair: the half sums the XCDs swap ([2 iteration parities][8 vectors], ot_resident.hip OTR_MERGE)
     int ot_hier = 1;         // two-XCDs-per-pair resident launches (hierarchical column sums) when a pair fits 64 CUs and B <= 4 (IMP_OT_HIER=0 disables)
     int ot_local = 1;        // XCD-local resident Sinkhorn launches when a pair fits one XCD (IMP_OT_LOCAL=0 disables)
     unsigned* stat_cnt = nullptr;   // [cap_b][2][WF_MAX_PSPLIT] tickets of the statistics merge inside the MLP0 launch (gemm_wf.hip)
@@ -899,8 +899,8 @@ int ensure_resident_buffers(imp_ctx* c, int batch) {
     }
     if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xv, 2 * (size_t)cap * kResidentMaxLdx);
     if (!rc) HIP_TRY(hipMemset(c->xv, 0, 2 * (size_t)cap * kResidentMaxLdx * sizeof(float)));
-    if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xhalf, 2 * (size_t)cap * kResidentMaxLdx);
-    if (!rc) HIP_TRY(hipMemset(c->xhalf, 0, 2 * (size_t)cap * kResidentMaxLdx * sizeof(float)));
+    if (!rc) rc = dev_alloc(c, c->allocs_x, &c->xhalf, 4 * (size_t)cap * kResidentMaxLdx);
+    if (!rc) HIP_TRY(hipMemset(c->xhalf, 0, 4 * (size_t)cap * kResidentMaxLdx * sizeof(float)));
     if (rc) return rc;
     // the clears above run on the NULL stream, which the callers' (non-blocking) streams and the lane do not wait for:
     // they must have landed before the first resident kernel writes its tags into these buffers
@@ -919,7 +919,7 @@ unsigned resident_tags(imp_ctx* c, int iterations) {
         (void)hipMemset(c->xpart, 0, 2 * wgs * kResidentMaxLdx * sizeof(float));
         (void)hipMemset(c->xmax, 0, 4 * wgs * kResidentMaxLdx * sizeof(float));
         (void)hipMemset(c->xv, 0, 2 * (size_t)c->xcap_b * kResidentMaxLdx * sizeof(float));
-        (void)hipMemset(c->xhalf, 0, 2 * (size_t)c->xcap_b * kResidentMaxLdx * sizeof(float));
+        (void)hipMemset(c->xhalf, 0, 4 * (size_t)c->xcap_b * kResidentMaxLdx * sizeof(float));
         c->xtag = 0;
     }
     const unsigned base = c->xtag;
@@ -958,7 +958,7 @@ int resident_health(imp_ctx* c) {
         if (c->xpart) (void)hipMemset(c->xpart, 0, 2 * wgs * kResidentMaxLdx * sizeof(float));
         if (c->xmax) (void)hipMemset(c->xmax, 0, 4 * wgs * kResidentMaxLdx * sizeof(float));
         if (c->xv) (void)hipMemset(c->xv, 0, 2 * (size_t)c->xcap_b * kResidentMaxLdx * sizeof(float));
-        if (c->xhalf) (void)hipMemset(c->xhalf, 0, 2 * (size_t)c->xcap_b * kResidentMaxLdx * sizeof(float));
+        if (c->xhalf) (void)hipMemset(c->xhalf, 0, 4 * (size_t)c->xcap_b * kResidentMaxLdx * sizeof(float));
         c->xtag = 0;                                       // (the eager launches' tags may start over as well: the buffers are clean)
         (void)hipDeviceSynchronize();
         static_cast<volatile int*>(c->xstatus_host)[2] = 0;

@@ -139,6 +139,12 @@ __device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, int q, unsigned 
 // TWO chunks with both loads in flight per poll round (round 5): an exchange vector is NQ = 64 NCH + 1 chunks (the dustbin column makes it odd), so
 // of 512 threads one - or, staging a slice, a few - owns two chunks; polled one after the other that is a second dependent memory round trip
 // on the critical path of every iteration
+#ifndef OTR_MERGE
+#define OTR_MERGE 0            // EXPERIMENT (round 5, measured slower, off), LOCAL = 2: two hand-offs per iteration instead of three - the slice owners publish their half
+#endif                         // sums twice (a plain store for their own XCD, a write-through store for the other, alternating between two buffers by iteration parity) and
+                               // EVERY workgroup reads both halves' sums of all columns and forms v itself; bit-identical v.  The owners' swap + the distribution of v cost
+                               // 1 600 + 2 180 cycles, the one merged hand-off 4 700: 64 workgroups polling 16 KB across the fabric each are slower than 32 owners swapping
+                               // 68 columns each and a local distribution (6.37-6.43 vs 5.99-6.01 us per iteration, profiles/r05/sinkhorn_merged_handoffs_ab.log)
 #ifndef OTR_DUAL_POLL
 #define OTR_DUAL_POLL 0        // (measured neutral: 6.09-6.12 vs 6.11-6.14 us per iteration at B = 4, N = 2048 - the waiting dominates, not the second round trip)
 #endif
@@ -153,6 +159,27 @@ __device__ __forceinline__ void ldg4x2(__amdgpu_buffer_rsrc_t r, int q0, int q1,
             a2 = __builtin_amdgcn_raw_buffer_load_b128(r, q1 * 32, 0, AUX_POLL);
             c2 = __builtin_amdgcn_raw_buffer_load_b128(r, q1 * 32 + 16, 0, AUX_POLL);
         }
+        const bool ok = a[1] == tag && a[3] == tag && c[1] == tag && c[3] == tag && a2[1] == tag && a2[3] == tag && c2[1] == tag && c2[3] == tag;
+        if (ok || dead) break;
+#if OTR_POLL_SLEEP
+        __builtin_amdgcn_s_sleep(OTR_POLL_SLEEP);
+#endif
+        if ((++spins & 1023) == 0) poll_health(status, spins, dead);
+    }
+    o0 = f32x4{__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(c[0]), __uint_as_float(c[2])};
+    o1 = f32x4{__uint_as_float(a2[0]), __uint_as_float(a2[2]), __uint_as_float(c2[0]), __uint_as_float(c2[2])};
+}
+
+// the same chunk of TWO exchange vectors, both loads in flight per poll round (OTR_MERGE: a half's own sums from its L2, the other half's across the fabric)
+__device__ __forceinline__ void ldg4_pair(__amdgpu_buffer_rsrc_t r0, __amdgpu_buffer_rsrc_t r1, int q, unsigned tag, const Health& status, bool& dead, f32x4& o0, f32x4& o1) {
+    u32x4 a, c, a2, c2;
+    int spins = 0;
+    for (;;) {
+        asm volatile("" ::: "memory");
+        a = __builtin_amdgcn_raw_buffer_load_b128(r0, q * 32, 0, AUX_POLL);
+        c = __builtin_amdgcn_raw_buffer_load_b128(r0, q * 32 + 16, 0, AUX_POLL);
+        a2 = __builtin_amdgcn_raw_buffer_load_b128(r1, q * 32, 0, AUX_POLL);
+        c2 = __builtin_amdgcn_raw_buffer_load_b128(r1, q * 32 + 16, 0, AUX_POLL);
         const bool ok = a[1] == tag && a[3] == tag && c[1] == tag && c[3] == tag && a2[1] == tag && a2[3] == tag && c2[1] == tag && c2[3] == tag;
         if (ok || dead) break;
 #if OTR_POLL_SLEEP
@@ -277,6 +304,9 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
     const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(p.xv + (size_t)(LOCAL == 2 ? 2 * b + half : b) * LDX * 2, (unsigned)(LDX * 8));
     const __amdgpu_buffer_rsrc_t rs_h_own = make_rsrc(p.xhalf + (size_t)(2 * b + half) * LDX * 2, (unsigned)(LDX * 8));
     const __amdgpu_buffer_rsrc_t rs_h_oth = make_rsrc(p.xhalf + (size_t)(2 * b + 1 - half) * LDX * 2, (unsigned)(LDX * 8));
+    // OTR_MERGE: the write-through copies of odd iterations live 8 vectors further (B <= 4: 2 B <= 8 vectors per parity)
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_h_own1 = make_rsrc(p.xhalf + (size_t)(8 + 2 * b + half) * LDX * 2, (unsigned)(LDX * 8));
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_h_oth1 = make_rsrc(p.xhalf + (size_t)(8 + 2 * b + 1 - half) * LDX * 2, (unsigned)(LDX * 8));
 
     // ---- row softmax of the dustbin-augmented matrix (nets/layers.py:39-40,28) straight into registers -----------
     f32x4 P[RPW][NCH];
@@ -434,7 +464,12 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
 #pragma unroll
                 for (int h = 1; h < 8; ++h) s += sub[h * ncol + cl];
                 const int xi = 4 * (gl * cq) + cl;                    // index in the exchange layout
-                if (xi < LDX) {
+                if (LOCAL == 2 && OTR_MERGE) {
+                    if (xi < LDX) {
+                        stg1<0>(rs_v, xi, s, tag_h);                                   // for this XCD's workgroups (stays in its L2)
+                        stg1<AUX_SC1>((it & 1) ? rs_h_own1 : rs_h_own, xi, s, tag_h);  // for the other XCD's
+                    }
+                } else if (xi < LDX) {
                     if (LOCAL == 2) {                                 // swap the half sums across the fabric; both halves add them in the same order
                         stg1<AUX_SC1>(rs_h_own, xi, s, tag_h);
                         const float o = ldg1(rs_h_oth, xi, tag_h, health, dead);
@@ -450,6 +485,25 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         }
         OTR_CLK(3)
         // ---- D: everybody reads v -----------------------------------------------------------------------------------
+#if OTR_MERGE
+        if (LOCAL == 2) {                          // ... reads both halves' sums and forms v: the arithmetic of the owners' path above, per column
+            for (int q = tid; q < NQ; q += 512) {
+                f32x4 own, oth, v4;
+                ldg4_pair(rs_v, (it & 1) ? rs_h_oth1 : rs_h_oth, q, tag_h, health, dead, own, oth);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int xi = 4 * q + e;
+                    const float s = half == 0 ? own[e] + oth[e] : oth[e] + own[e];
+                    const bool dust = xi == DCOL;
+                    const bool real = xi < n1 || dust;
+                    const float t = fmaf(c0, u_last, s);
+                    const float marg = dust ? (float)(n1 + 1) : 1.f;
+                    v4[e] = real ? marg / (t + OT_EPS) : 0.f;
+                }
+                *reinterpret_cast<f32x4*>(vs + 4 * q) = v4;
+            }
+        } else
+#endif
 #if OTR_DUAL_POLL
         for (int q = tid; q < NQ; q += 1024) {
             f32x4 o0, o1;
