@@ -46,6 +46,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -73,6 +74,25 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
+#endif
+}
+// the sums of N values at once: the DPP steps of the N chains interleaved (a chain alone waits two states after every step), every lane gets the totals
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
+#if OTR_DPP_SUM
+#define OTR_DPP_ADDN(ctrl, row_mask) _Pragma("unroll") for (int i = 0; i < N; ++i) v[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[i]), ctrl, row_mask, 0xf, false))
+    OTR_DPP_ADDN(0xB1, 0xf);
+    OTR_DPP_ADDN(0x4E, 0xf);
+    OTR_DPP_ADDN(0x141, 0xf);
+    OTR_DPP_ADDN(0x140, 0xf);
+    OTR_DPP_ADDN(0x142, 0xa);
+    OTR_DPP_ADDN(0x143, 0xc);
+#undef OTR_DPP_ADDN
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), 63));
+#else
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
 #endif
 }
 __device__ __forceinline__ float wave_max(float v) {
@@ -145,6 +165,12 @@ __device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, int q, unsigned 
                                // EVERY workgroup reads both halves' sums of all columns and forms v itself; bit-identical v.  The owners' swap + the distribution of v cost
                                // 1 600 + 2 180 cycles, the one merged hand-off 4 700: 64 workgroups polling 16 KB across the fabric each are slower than 32 owners swapping
                                // 68 columns each and a local distribution (6.37-6.43 vs 5.99-6.01 us per iteration, profiles/r05/sinkhorn_merged_handoffs_ab.log)
+#ifndef OTR_PACKED_ROWSUM
+#define OTR_PACKED_ROWSUM 1    // phase A: packed FMAs, the rows of a wave advance together (see there)
+#endif
+#ifndef OTR_VSUM_IN_D
+#define OTR_VSUM_IN_D (!OTR_MERGE && !OTR_DUAL_POLL)     // the sum of v from the registers that fetched it instead of a second pass over the LDS copy by every wave
+#endif
 #ifndef OTR_DUAL_POLL
 #define OTR_DUAL_POLL 0        // (measured neutral: 6.09-6.12 vs 6.11-6.14 us per iteration at B = 4, N = 2048 - the waiting dominates, not the second round trip)
 #endif
@@ -225,6 +251,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* vs = lds;                           // [LDX]      current v
     float* red = lds + LDX;                    // [8][LDX]   wave partials / staging (sized by the launcher)
+    __shared__ float s_vsw[8];                 // per-wave partial sums of v
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = p.G;
@@ -368,6 +395,39 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         const unsigned tag_p = tag_base + 3u * it + 1u, tag_h = tag_p + 1u, tag_v = tag_p + 2u;
         // ---- A: u for the own rows, column partials ---------------------------------------------------------------
         float acc[RPW];
+#if OTR_PACKED_ROWSUM
+        // (round 5) a lane's share of a row's dot product as TWO chains - even and odd columns - so that a step of both is one v_pk_fma_f32 on the register pair
+        // (P[k][c][0..1], x[0..1]): 64 packed instead of 128 scalar FMAs (phase B's products over a float4 were packed already).  And the RPW rows advance
+        // TOGETHER: the compiler used to finish one row - a chain of dependent FMAs, its six dependent DPP additions, its IEEE division behind a branch - before
+        // it started the next, every step waiting for the one before; sched_barrier keeps the rows interleaved, the divisions are unconditional
+        f32x4 xv[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) xv[c] = *reinterpret_cast<const f32x4*>(vs + 4 * (lane + 64 * c));
+        const float vd = vs[DCOL];
+        f32x2 acc2[RPW];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) acc2[k] = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) acc2[k] = __builtin_elementwise_fma(f32x2{P[k][c][0], P[k][c][1]}, f32x2{xv[c][0], xv[c][1]}, acc2[k]);
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) acc2[k] = __builtin_elementwise_fma(f32x2{P[k][c][2], P[k][c][3]}, f32x2{xv[c][2], xv[c][3]}, acc2[k]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) acc[k] = acc2[k][0] + acc2[k][1];
+        wave_sum_n<RPW>(acc);
+        float pdpart = 0.f;
+        float inv[RPW];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) inv[k] = 1.f / (fmaf(Pd[k], vd, acc[k]) + OT_EPS);      // real rows have marginal 1 (nets/layers.py:32,41)
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            u[k] = (r0 + k < n0) ? inv[k] : 0.f;
+            pdpart = fmaf(Pd[k], u[k], pdpart);
+        }
+#else
 #pragma unroll
         for (int k = 0; k < RPW; ++k) acc[k] = 0.f;
 #pragma unroll
@@ -389,6 +449,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             u[k] = (r0 + k < n0) ? 1.f / (s + OT_EPS) : 0.f;          // real rows have marginal 1 (nets/layers.py:32,41)
             pdpart = fmaf(Pd[k], u[k], pdpart);
         }
+#endif
         u_last = (float)(n0 + 1) / (c0 * vsum + OT_EPS);              // dustbin row: marginal n0 + 1 (nets/layers.py:42)
         OTR_CLK(0)
         // ---- B: workgroup partial vector ---------------------------------------------------------------------------
@@ -512,10 +573,26 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             if (q + 512 < NQ) *reinterpret_cast<f32x4*>(vs + 4 * (q + 512)) = o1;
         }
 #else
+#if OTR_VSUM_IN_D
+        {   // ... and the sum of v from the chunks the threads just fetched (entries that are no real column travel as zeros): a partial per wave, combined in a fixed order
+            float vpart = 0.f;
+            for (int q = tid; q < NQ; q += 512) {
+                const f32x4 o = ldg4(rs_v, q, tag_v, health, dead);
+                *reinterpret_cast<f32x4*>(vs + 4 * q) = o;
+                vpart += (o[0] + o[1]) + (o[2] + o[3]);
+            }
+            vpart = wave_sum(vpart);
+            if (lane == 0) s_vsw[wave] = vpart;
+        }
+#else
         for (int q = tid; q < NQ; q += 512) *reinterpret_cast<f32x4*>(vs + 4 * q) = ldg4(rs_v, q, tag_v, health, dead);
+#endif
 #endif
         __syncthreads();
         OTR_CLK(4)
+#if OTR_VSUM_IN_D
+        vsum = ((s_vsw[0] + s_vsw[1]) + (s_vsw[2] + s_vsw[3])) + ((s_vsw[4] + s_vsw[5]) + (s_vsw[6] + s_vsw[7]));
+#else
         {   // sum of v (every wave computes the same value in the same order: no further barrier)
             float s = 0.f;
 #pragma unroll
@@ -525,6 +602,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             }
             vsum = wave_sum(s) + vs[DCOL];
         }
+#endif
         OTR_CLK(5)
     }
     if (p.prof && b == 0 && g == 0 && tid == 0)
