@@ -394,13 +394,29 @@ __device__ unsigned pp_hwid[8];
 #ifndef PP_PRIO
 #define PP_PRIO 0           // 0: priority 1 around every matrix phase; 1: no priorities; 2: waves 4-7 at priority 1 for the whole loop
 #endif
+#ifndef PP_DMA_DEFAULT
+#define PP_DMA_DEFAULT 0    // the LDS-DMA staging variant of the kernel (template parameter DMA) as the default for split-half K / V images at DH = 64; IMP_ATTN_DMA overrides
+#endif
+#ifndef PP_DMA_SPREAD
+#define PP_DMA_SPREAD 1     // where a wave requests its pieces: 1 = every wave requests tile t + 2 inside X(t), one piece behind the MFMAs of each k-step of K.Q^T (a piece costs ~20 issue
+#endif                      // cycles + SALU: at the head of the phase it delays the MFMA stream of the pole wave); 0 = waves 0-3 at the head of X(t) (tile t + 2), waves 4-7 at the head of Y(t) (tile t + 3)
 #ifndef PP_LOADS_IN_X
 #define PP_LOADS_IN_X 0    // where the global loads of the staged tile are issued: matrix phase (1) or vector phase (0); measured equal
 #endif
 
-template <int DH, bool MASKED>
+// DMA (round 5, DH = 64, split-half K / V images only): the tiles of the ring are filled by LDS-DMA (global_load_lds_dwordx4: global -> LDS without a
+// register round trip) instead of 4 buffer loads + 4 ds_write_b128 per thread and tile.  An LDS-DMA instruction writes 64 x 16 bytes LANE-LINEAR at M0, so the
+// row-pitched image of a tile (K 64 x 272 B = 17 KB, V 64 x 320 B = 20 KB: the pads stay, every fragment read is unchanged) is cut into 1-KB PIECES and a
+// lane fetches whatever 16-byte chunk belongs at its position of the piece (a lane that lands in a pad fetches a neighbouring chunk: never read).  37 pieces
+// per tile over 8 waves = 5 per wave (3 duplicates).  Schedule, in barrier phases (phase p = between the p-th and the (p + 1)-th barrier; waves 0-3: X(t) = 2t,
+// Y(t) = 2t + 1, waves 4-7 one later): tile T is issued in phase 2T - 4 (waves 0-3 at the head of X(T - 2), waves 4-7 at the head of Y(T - 3)) - the last reads
+// of the slot's previous occupant, V(T - 4), retired with the lgkmcnt(0) of the barrier that ends phase 2T - 5 - and every wave waits for its own pieces of T
+// (counted vmcnt: the pieces of T + 1 stay in flight) before the barrier that ends phase 2T - 1; the first read of T is K(T) in phase 2T.  The compiler does not
+// see the DMA (inline asm: hipcc would drain a DMA it knows about with vmcnt(0) before the next LDS read), so every wait is written here.
+template <int DH, bool MASKED, bool DMA = false>
 __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams p, int qtiles, int total_blocks, int nsplit) {
     static_assert(DH == 64 || DH == 32, "head widths of the reference: 256 / 4 and 128 / 4 channels");
+    static_assert(!DMA || (DH == 64 && !PP_STRAIGHT && !PP_LOADS_IN_X && !PP_WHATIF), "the LDS-DMA staging is written for the product's configuration");
     constexpr int NT = 512;
     constexpr int KROW = DH + 4;                 // K row: 32 floats of hi halves, 32 of lo halves, 4 pad
     constexpr int VROW = DH + 16;                // V row: same split, padded to 320 B (conflict-free transpose reads)
@@ -472,16 +488,18 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     unsigned char rbA = 1, rbB = 1;
     auto load_tile = [&](int t, f32x4 (&rk)[LK], f32x4 (&rv)[LK], unsigned char& rb) __attribute__((always_inline)) {
         const int k0 = (t0 + t) * KT;
-        const int soff = k0 * row_bytes;
+        if constexpr (!DMA) {
+            const int soff = k0 * row_bytes;
 #pragma unroll
-        for (int j = 0; j < LK; ++j) {
-            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsK, koff[j], soff, 0);
-            rk[j] = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
-        }
+            for (int j = 0; j < LK; ++j) {
+                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsK, koff[j], soff, 0);
+                rk[j] = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
+            }
 #pragma unroll
-        for (int j = 0; j < LK; ++j) {
-            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsV, koff[j], soff, 0);
-            rv[j] = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
+            for (int j = 0; j < LK; ++j) {
+                const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsV, koff[j], soff, 0);
+                rv[j] = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
+            }
         }
 #if PP_STRAIGHT
         {                                     // no per-lane branch (every wave computes it, wave 0 uses it); the mask byte is loaded only by masked launches
@@ -500,26 +518,92 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 #endif
     };
     auto store_tile = [&](int slot, const f32x4 (&rk)[LK], const f32x4 (&rv)[LK], const unsigned char rb) __attribute__((always_inline)) {
-        float* ks = Ks + slot * KT * KROW;
-        float* vs = Vs + slot * KT * VROW;
+        if constexpr (!DMA) {
+            float* ks = Ks + slot * KT * KROW;
+            float* vs = Vs + slot * KT * VROW;
 #pragma unroll
-        for (int j = 0; j < LK; ++j) {
-            const int f = tid + j * NT;
-            const int row = f / (DH / 4), c4 = (f % (DH / 4)) * 4;
-            if (p.kv_planes) {                 // EXPERIMENT: the rows already ARE the [hi | lo] image (16-byte chunk c4 / 4 of it): plain copy
-                *reinterpret_cast<f32x4*>(ks + row * KROW + c4) = rk[j];
-                *reinterpret_cast<f32x4*>(vs + row * VROW + c4) = rv[j];
-                continue;
+            for (int j = 0; j < LK; ++j) {
+                const int f = tid + j * NT;
+                const int row = f / (DH / 4), c4 = (f % (DH / 4)) * 4;
+                if (p.kv_planes) {                 // EXPERIMENT: the rows already ARE the [hi | lo] image (16-byte chunk c4 / 4 of it): plain copy
+                    *reinterpret_cast<f32x4*>(ks + row * KROW + c4) = rk[j];
+                    *reinterpret_cast<f32x4*>(vs + row * VROW + c4) = rv[j];
+                    continue;
+                }
+                u32x2 hi, lo;
+                split4(rk[j], hi, lo);
+                *reinterpret_cast<u32x2*>(ks + row * KROW + (c4 >> 1)) = hi;
+                *reinterpret_cast<u32x2*>(ks + row * KROW + DH / 2 + (c4 >> 1)) = lo;
+                split4(rv[j], hi, lo);
+                *reinterpret_cast<u32x2*>(vs + row * VROW + (c4 >> 1)) = hi;
+                *reinterpret_cast<u32x2*>(vs + row * VROW + DH / 2 + (c4 >> 1)) = lo;
             }
-            u32x2 hi, lo;
-            split4(rk[j], hi, lo);
-            *reinterpret_cast<u32x2*>(ks + row * KROW + (c4 >> 1)) = hi;
-            *reinterpret_cast<u32x2*>(ks + row * KROW + DH / 2 + (c4 >> 1)) = lo;
-            split4(rv[j], hi, lo);
-            *reinterpret_cast<u32x2*>(vs + row * VROW + (c4 >> 1)) = hi;
-            *reinterpret_cast<u32x2*>(vs + row * VROW + DH / 2 + (c4 >> 1)) = lo;
         }
         if (tid < KT) Bs[slot * KT + tid] = rb ? 0.f : -INFINITY;
+    };
+
+    // ---- DMA staging: this wave's 5 pieces of every tile ------------------------------------------------------------
+    constexpr int DMA_NP = 5;                                          // pieces per wave and tile
+    constexpr int DMA_KP = KT * KROW * 4 / 1024, DMA_VP = KT * VROW * 4 / 1024;      // 17 + 20 pieces of 1 KB (DH = 64)
+    static_assert(!DMA || ((KT * KROW * 4) % 1024 == 0 && (KT * VROW * 4) % 1024 == 0 && 8 * DMA_NP >= DMA_KP + DMA_VP && 8 * DMA_NP - (DMA_KP + DMA_VP) <= DMA_VP),
+                  "a tile image is a whole number of 1-KB pieces and 8 waves x 5 cover them");
+    [[maybe_unused]] unsigned dma_voff[DMA_NP];                        // per lane: byte offset of its chunk inside the tile's rows (row * row_bytes + 16 * chunk)
+    [[maybe_unused]] const char* dma_base[DMA_NP];                     // wave-uniform: K or V of this (pair, head)
+    [[maybe_unused]] unsigned dma_dst[DMA_NP], dma_slot[DMA_NP];       // wave-uniform: LDS byte address of the piece in slot 0, bytes per slot
+    // piece j of this wave: is it a K piece; row pitch of its image; position P of this lane inside the image
+    auto dma_piece = [&](int j, int& pitch, int& P) __attribute__((always_inline)) {
+        int q = wave * DMA_NP + j;
+        if (q >= DMA_KP + DMA_VP) q -= DMA_VP;                         // the three spare slots repeat V pieces 0 .. 2 (the same bytes to the same place)
+        const bool isk = q < DMA_KP;
+        const int pi = isk ? q : q - DMA_KP;
+        pitch = isk ? KROW * 4 : VROW * 4;
+        P = 1024 * pi + 16 * lane;
+        return isk;
+    };
+    [[maybe_unused]] const unsigned dma_tile_bytes = __builtin_amdgcn_readfirstlane((unsigned)(KT * row_bytes));      // bytes of global memory per key tile
+    if constexpr (DMA) {
+        typedef __attribute__((address_space(3))) char lds_char;
+        const unsigned ks0 = (unsigned)(size_t)(lds_char*)reinterpret_cast<char*>(Ks), vs0 = (unsigned)(size_t)(lds_char*)reinterpret_cast<char*>(Vs);
+#pragma unroll
+        for (int j = 0; j < DMA_NP; ++j) {
+            int pitch, P;
+            const bool isk = dma_piece(j, pitch, P);
+            const int r = P / pitch, c = min((P - r * pitch) >> 4, DH / 4 - 1);
+            dma_voff[j] = (unsigned)(r * row_bytes + 16 * c);
+            dma_base[j] = reinterpret_cast<const char*>(isk ? Kg : Vg);
+            dma_dst[j] = (isk ? ks0 : vs0) + 1024u * (unsigned)(P >> 10);
+            dma_slot[j] = isk ? KT * KROW * 4 : KT * VROW * 4;
+        }
+    }
+    // request piece j of tile t (relative to t0) into the tile's ring slot; rows past nk (the last tile of a ragged key count) repeat row nk - 1: finite bytes under a -inf bias
+    auto dma_issue_piece = [&](int t, int j) __attribute__((always_inline)) {
+        if constexpr (DMA) {
+            const int k0 = (t0 + t) * KT;
+            const unsigned goff = (unsigned)(t0 + t) * dma_tile_bytes;     // (32 bits, scalar: a 64-bit or a VALU product would put the address into VGPRs)
+            unsigned vo = dma_voff[j];
+            if (k0 + KT > nk) {                                        // (workgroup-uniform; at most one tile per workgroup)
+                int pitch, P;
+                dma_piece(j, pitch, P);
+                const int r = P / pitch, c = min((P - r * pitch) >> 4, DH / 4 - 1);
+                vo = (unsigned)(min(r, nk - 1 - k0) * row_bytes + 16 * c);
+            }
+            const char* src = dma_base[j] + goff;
+            const unsigned dst = dma_dst[j] + (unsigned)(t & 3) * dma_slot[j];
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(vo), "s"(src), "s"(dst) : "memory");
+        }
+    };
+    auto dma_issue = [&](int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < DMA_NP; ++j) dma_issue_piece(t, j);
+    };
+    // this wave's pieces of every tile it requested - but, `younger`, of the last one - have landed
+    auto dma_wait = [&](bool younger) __attribute__((always_inline)) {
+        if constexpr (DMA) {
+            if (younger) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_NP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     };
 
     f32x16 oacc[DT], sacc[2];
@@ -533,6 +617,8 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     bool need_slow = true;        // wave-uniform: some query of the wave has not seen an unmasked key yet
     load_tile(0, rkA, rvA, rbA);
     if (PP_STRAIGHT || nt > 1) load_tile(1, rkB, rvB, rbB);
+    dma_issue(0);                                   // (DMA: the two tiles travel while Q is split; the registers above then carry the key-validity bytes only)
+    if (nt > 1) dma_issue(1);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const f32x4 a = qraw[s][0], c = qraw[s][1];
@@ -546,8 +632,10 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 #if !PP_LOADS_IN_X
     if (PP_STRAIGHT || nt > 3) load_tile(3, rkB, rvB, rbB);
 #endif
+    dma_wait(false);                                // tiles 0 and 1 are in the ring
     PP_BARRIER();
     if (group == 1) PP_BARRIER();
+    if (DMA && !PP_DMA_SPREAD && group == 1 && nt > 2) dma_issue(2);      // barrier phase 0 (waves 0-3 issue it at the head of X(0))
 #if PP_PRIO == 2
     if (group == 1) __builtin_amdgcn_s_setprio(1);
 #endif
@@ -682,7 +770,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
             }
         }
     };
-    auto qk_mfmas = [&](int kslot, bool prefetched) __attribute__((always_inline)) {
+    auto qk_mfmas = [&](int kslot, bool prefetched, int dma_t = -1) __attribute__((always_inline)) {
         if (!prefetched) read_k(kslot, 0, fr[0]);
 #if !(PP_CNEG && PP_INIT_IN_ACC)
         const float c0 = PP_INIT_IN_ACC ? -m_ref : 0.f;         // (0: the compiler feeds the first MFMA of each chain an inline zero)
@@ -709,6 +797,12 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
                 rd(1); PP_SB();
                 sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], qh[s], sacc[0], 0, 0, 0); PP_SB();
                 sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[1], qh[s], sacc[1], 0, 0, 0); PP_SB();
+                if (DMA && PP_DMA_SPREAD && dma_t >= 0) {           // (uniform) this wave's pieces of tile dma_t: one behind every k-step, the fifth behind the last
+                    static_assert(!DMA || DMA_NP == KS + 1, "one piece per k-step and one more");
+                    dma_issue_piece(dma_t, s);
+                    if (s == KS - 1) dma_issue_piece(dma_t, KS);
+                    PP_SB();
+                }
             } else {
                 if (s + 1 < KS) read_k(kslot, s + 1, fr[(s + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -766,6 +860,13 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     unsigned long long tlast = __builtin_readcyclecounter();
     const unsigned long long t_loop = tlast;
 #endif
+    // a counted wait assumes that nothing but the wave's own DMA pieces entered its VMEM queue behind the tile it waits for: wave 0 of a masked launch
+    // (mask bytes) and the profiling builds (stamp stores) wait for everything instead
+#if defined(PP_PROFILE) || defined(PP_TIMELINE)
+    const bool dma_counted = false;
+#else
+    const bool dma_counted = !(MASKED && wave == 0);
+#endif
     auto tile_step = [&](int t, f32x4 (&rk)[LK], f32x4 (&rv)[LK], unsigned char& rb, f32x4 (&rk2)[LK], f32x4 (&rv2)[LK], unsigned char& rb2) __attribute__((always_inline)) {
         PP_CLK(7);
 #ifdef PP_TIMELINE
@@ -779,17 +880,20 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 #if PP_LOADS_IN_X
         if (PP_STRAIGHT || t + 3 < nt) load_tile(t + 3, rk2, rv2, rb2);          // the other register set was converted in Y(t-1)
 #endif
+        if (DMA && !PP_DMA_SPREAD && group == 0 && t + 2 < nt) dma_issue(t + 2);     // barrier phase 2t = 2 (t + 2) - 4
         if (t > 0) pv_mfmas((t - 1) & 3, t & 3, PP_PREFETCH != 0);
-        qk_mfmas(t & 3, t > 0);
+        qk_mfmas(t & 3, t > 0, (DMA && PP_DMA_SPREAD && t + 2 < nt) ? t + 2 : -1);   // (PP_DMA_SPREAD: tile t + 2 in barrier phase 2t / 2t + 1: 2 (t + 2) - 4 at the earliest)
 #if PP_PRIO == 0
         __builtin_amdgcn_s_setprio(0);
 #endif
         PP_CLK(0);
         PP_TL(1);
+        if (DMA && group == 1) dma_wait(dma_counted && t + 2 < nt);              // tile t + 1 before the barrier that ends phase 2t + 1 (behind it: the pieces of t + 2, requested in Y(t - 1) or in this X(t))
         PP_BARRIER();
         PP_CLK(1);
         PP_TL(2);
         // =============================== Y(t): vector phase ===============================================
+        if (DMA && !PP_DMA_SPREAD && group == 1 && t + 3 < nt) dma_issue(t + 3);     // barrier phase 2t + 2 = 2 (t + 3) - 4
         if (mk != nullptr || (t0 + t + 1) * KT > nk) {
             const float* bs = Bs + (t & 3) * KT;
 #pragma unroll
@@ -862,6 +966,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 #endif
         PP_CLK(3);
         PP_TL(4);
+        if (DMA && group == 0) dma_wait(dma_counted && t + 2 < nt);              // tile t + 1 before the barrier that ends phase 2t + 1 (behind it: the pieces of t + 2, requested in X(t))
         PP_BARRIER();
         PP_CLK(4);
         PP_TL(5);
@@ -1034,12 +1139,33 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 #endif
 }
 
+}  // namespace
+int imp_attn_dma_override = -1;      // probes / tests: 0 | 1 forces the staging variant of the ping-pong kernel for the launches that follow (-1: IMP_ATTN_DMA or the default)
+namespace {
+
 template <int DH>
 hipError_t launch_pp(const AttnParams& p, int batch, int maxq, int nsplit, hipStream_t stream) {
     const int qtiles = (maxq + 255) / 256;
     const int total = qtiles * IMP_NUM_HEADS * p.nside * batch * nsplit;
     const size_t lds = (size_t)(4 * KT * (DH + 4) + 4 * KT * (DH + 16) + 4 * KT) * sizeof(float);
     const bool masked = p.side[0].kmask != nullptr || (p.nside == 2 && p.side[1].kmask != nullptr);
+    // LDS-DMA staging of the ring (the kernel's DMA parameter): split-half K / V images at DH = 64; IMP_ATTN_DMA=0|1 overrides the default
+    static const int dma_env = [] { const char* e = getenv("IMP_ATTN_DMA"); return e ? atoi(e) : PP_DMA_DEFAULT; }();
+    if constexpr (DH == 64) {
+        bool dma_ok = (imp_attn_dma_override >= 0 ? imp_attn_dma_override : dma_env) != 0 && p.kv_planes && (p.ldk & 3) == 0;
+        for (int s = 0; s < p.nside; ++s)          // 16-byte sources: the images of whole head segments at 16-byte aligned rows
+            dma_ok = dma_ok && ((reinterpret_cast<size_t>(p.side[s].k) | reinterpret_cast<size_t>(p.side[s].v) | (size_t)(p.side[s].sk_b * 4)) & 15) == 0;
+        if (dma_ok) {
+            if (masked) {
+                if (hipError_t e = imp_grant_dynamic_lds((const void*)attn_f16x3_pp_kernel<DH, true, true>, lds)) return e;
+                hipLaunchKernelGGL((attn_f16x3_pp_kernel<DH, true, true>), dim3(total), dim3(512), lds, stream, p, qtiles, total, nsplit);
+            } else {
+                if (hipError_t e = imp_grant_dynamic_lds((const void*)attn_f16x3_pp_kernel<DH, false, true>, lds)) return e;
+                hipLaunchKernelGGL((attn_f16x3_pp_kernel<DH, false, true>), dim3(total), dim3(512), lds, stream, p, qtiles, total, nsplit);
+            }
+            return hipGetLastError();
+        }
+    }
     if (masked) {
         if (hipError_t e = imp_grant_dynamic_lds((const void*)attn_f16x3_pp_kernel<DH, true>, lds)) return e;
         hipLaunchKernelGGL((attn_f16x3_pp_kernel<DH, true>), dim3(total), dim3(512), lds, stream, p, qtiles, total, nsplit);
