@@ -452,6 +452,9 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     const int nt_all = (nk + KT - 1) / KT, t_per = (nt_all + nsplit - 1) / nsplit;
     const int t0 = sp * t_per;
     const int nt = min(nt_all, t0 + t_per) - t0;     // >= 1: the launcher never makes more splits than it has tiles for
+    // (DMA) the same three as scalars for the request logic: a ragged batch's nk comes out of a memory load (imp_count), so everything derived from it is "divergent" to
+    // the compiler - conditions become lane masks, addresses land in VGPRs - although it is uniform
+    [[maybe_unused]] const int dnk = DMA ? __builtin_amdgcn_readfirstlane(nk) : nk, dnt = DMA ? __builtin_amdgcn_readfirstlane(nt) : nt, dt0 = DMA ? __builtin_amdgcn_readfirstlane(t0) : t0;
     const float* Qg = S.q + b * S.sq_b + h * DH;
     const float* Kg = S.k + b * S.sk_b + h * DH;
     const float* Vg = S.v + b * S.sk_b + h * DH;
@@ -542,23 +545,25 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
         if (tid < KT) Bs[slot * KT + tid] = rb ? 0.f : -INFINITY;
     };
 
-    // ---- DMA staging: this wave's 5 pieces of every tile ------------------------------------------------------------
+    // ---- DMA staging: this wave's 5 CONSECUTIVE pieces of every tile: waves 0-3 K pieces 0-4, 5-9, 10-14, 12-16 (three requested twice), waves 4-7 V pieces 0-4 .. 15-19.
+    // Consecutive, so that ONE M0 value and ONE scalar base serve the five requests of a tile: request j carries the immediate offset (j - 2) KB, which the hardware adds to
+    // the LDS AND to the global address, the lane's source offset takes it back (+ 2 KB, so that it stays positive; the scalar base is 2 KB low).  A request then is ONE
+    // instruction - the first version computed a base and an M0 per piece, ~9 scalar instructions each, and measured +400 cycles on the matrix phase it sat in
     constexpr int DMA_NP = 5;                                          // pieces per wave and tile
     constexpr int DMA_KP = KT * KROW * 4 / 1024, DMA_VP = KT * VROW * 4 / 1024;      // 17 + 20 pieces of 1 KB (DH = 64)
-    static_assert(!DMA || ((KT * KROW * 4) % 1024 == 0 && (KT * VROW * 4) % 1024 == 0 && 8 * DMA_NP >= DMA_KP + DMA_VP && 8 * DMA_NP - (DMA_KP + DMA_VP) <= DMA_VP),
-                  "a tile image is a whole number of 1-KB pieces and 8 waves x 5 cover them");
-    [[maybe_unused]] unsigned dma_voff[DMA_NP];                        // per lane: byte offset of its chunk inside the tile's rows (row * row_bytes + 16 * chunk)
-    [[maybe_unused]] const char* dma_base[DMA_NP];                     // wave-uniform: K or V of this (pair, head)
-    [[maybe_unused]] unsigned dma_dst[DMA_NP], dma_slot[DMA_NP];       // wave-uniform: LDS byte address of the piece in slot 0, bytes per slot
-    // piece j of this wave: is it a K piece; row pitch of its image; position P of this lane inside the image
-    auto dma_piece = [&](int j, int& pitch, int& P) __attribute__((always_inline)) {
-        int q = wave * DMA_NP + j;
-        if (q >= DMA_KP + DMA_VP) q -= DMA_VP;                         // the three spare slots repeat V pieces 0 .. 2 (the same bytes to the same place)
-        const bool isk = q < DMA_KP;
-        const int pi = isk ? q : q - DMA_KP;
-        pitch = isk ? KROW * 4 : VROW * 4;
-        P = 1024 * pi + 16 * lane;
-        return isk;
+    static_assert(!DMA || ((KT * KROW * 4) % 1024 == 0 && (KT * VROW * 4) % 1024 == 0 && DMA_KP > 3 * DMA_NP && DMA_KP <= 4 * DMA_NP && DMA_VP == 4 * DMA_NP),
+                  "a tile image is a whole number of 1-KB pieces; four waves x 5 consecutive pieces cover K, four cover V");
+    [[maybe_unused]] unsigned dma_voff[DMA_NP];                        // per lane: row * row_bytes + 16 * chunk of its position in piece j, + 4096 - 1024 j
+    [[maybe_unused]] const char* dma_base = nullptr;                   // wave-uniform: K or V of this (pair, head), 2 KB low
+    [[maybe_unused]] unsigned dma_m0 = 0, dma_slot = 0;                // wave-uniform: LDS byte address of the wave's third piece in slot 0; bytes per slot
+    [[maybe_unused]] const bool dma_isk = wave < 4;
+    [[maybe_unused]] const int dma_p0 = dma_isk ? min(wave * DMA_NP, DMA_KP - DMA_NP) : (wave - 4) * DMA_NP;      // the wave's first piece
+    // row and 16-byte chunk of this lane's position in piece j of the wave (a position inside a row's pad takes the row's last chunk: never read)
+    auto dma_pos = [&](int j, int& r, int& c) __attribute__((always_inline)) {
+        const int pitch = dma_isk ? KROW * 4 : VROW * 4;
+        const int P = 1024 * (dma_p0 + j) + 16 * lane;
+        r = P / pitch;
+        c = min((P - r * pitch) >> 4, DH / 4 - 1);
     };
     [[maybe_unused]] const unsigned dma_tile_bytes = __builtin_amdgcn_readfirstlane((unsigned)(KT * row_bytes));      // bytes of global memory per key tile
     if constexpr (DMA) {
@@ -566,37 +571,66 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
         const unsigned ks0 = (unsigned)(size_t)(lds_char*)reinterpret_cast<char*>(Ks), vs0 = (unsigned)(size_t)(lds_char*)reinterpret_cast<char*>(Vs);
 #pragma unroll
         for (int j = 0; j < DMA_NP; ++j) {
-            int pitch, P;
-            const bool isk = dma_piece(j, pitch, P);
-            const int r = P / pitch, c = min((P - r * pitch) >> 4, DH / 4 - 1);
-            dma_voff[j] = (unsigned)(r * row_bytes + 16 * c);
-            dma_base[j] = reinterpret_cast<const char*>(isk ? Kg : Vg);
-            dma_dst[j] = (isk ? ks0 : vs0) + 1024u * (unsigned)(P >> 10);
-            dma_slot[j] = isk ? KT * KROW * 4 : KT * VROW * 4;
+            int r, c;
+            dma_pos(j, r, c);
+            dma_voff[j] = (unsigned)(r * row_bytes + 16 * c + 4096 - 1024 * j);
         }
+        // (wave-uniform values pinned to scalar registers: a base that the compiler keeps in VGPRs cannot be the scalar address operand of the requests)
+        const unsigned long long b64 = reinterpret_cast<unsigned long long>(dma_isk ? Kg : Vg) - 2048ull;
+        dma_base = reinterpret_cast<const char*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(b64 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64));
+        dma_m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)((dma_isk ? ks0 : vs0) + 1024u * (unsigned)dma_p0 + 2048u));
+        dma_slot = dma_isk ? KT * KROW * 4 : KT * VROW * 4;
     }
-    // request piece j of tile t (relative to t0) into the tile's ring slot; rows past nk (the last tile of a ragged key count) repeat row nk - 1: finite bytes under a -inf bias
-    auto dma_issue_piece = [&](int t, int j) __attribute__((always_inline)) {
+    // the requests of tile t (relative to t0) into its ring slot, as three steps so that they can sit in different gaps of an MFMA stream: dma_open (scalar set-up, M0, piece 0),
+    // dma_piece (1 .. 3), dma_close (piece 4).  M0 is written and left: hipcc sets M0 itself before any use it makes of it and makes none in this kernel (no m0 in the ISA of the
+    // register-staged instantiations: `grep -c m0` on the -save-temps .s), so between open and close it is ours.
+    // Rows past nk (the last tile of a ragged key count) repeat row nk - 1: finite bytes under a -inf bias
+    [[maybe_unused]] const char* dma_src = nullptr;
+#define PP_GLDS(OFF) "global_load_lds_dwordx4 %0, %1 offset:" #OFF
+    // (the three steps assume a FULL tile: all 64 keys exist; the caller sends a partial last tile through dma_issue)
+    auto dma_open = [&](int t) __attribute__((always_inline)) {
         if constexpr (DMA) {
-            const int k0 = (t0 + t) * KT;
-            const unsigned goff = (unsigned)(t0 + t) * dma_tile_bytes;     // (32 bits, scalar: a 64-bit or a VALU product would put the address into VGPRs)
-            unsigned vo = dma_voff[j];
-            if (k0 + KT > nk) {                                        // (workgroup-uniform; at most one tile per workgroup)
-                int pitch, P;
-                dma_piece(j, pitch, P);
-                const int r = P / pitch, c = min((P - r * pitch) >> 4, DH / 4 - 1);
-                vo = (unsigned)(min(r, nk - 1 - k0) * row_bytes + 16 * c);
-            }
-            const char* src = dma_base[j] + goff;
-            const unsigned dst = dma_dst[j] + (unsigned)(t & 3) * dma_slot[j];
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(vo), "s"(src), "s"(dst) : "memory");
+            dma_src = dma_base + (unsigned)(dt0 + t) * dma_tile_bytes;  // (a 32-bit scalar product: a 64-bit or a VALU product would put the address into VGPRs)
+            const unsigned m0v = dma_m0 + (unsigned)(t & 3) * dma_slot;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:-2048" :: "v"(dma_voff[0]), "s"(dma_src), "s"(m0v) : "memory");
         }
     };
+    auto dma_piece = [&](int j) __attribute__((always_inline)) {      // j = 1, 2, 3 (compile time after unrolling)
+        if constexpr (DMA) {
+            if (j == 1) asm volatile(PP_GLDS(-1024) :: "v"(dma_voff[1]), "s"(dma_src) : "memory");
+            else if (j == 2) asm volatile(PP_GLDS(0) :: "v"(dma_voff[2]), "s"(dma_src) : "memory");
+            else asm volatile(PP_GLDS(1024) :: "v"(dma_voff[3]), "s"(dma_src) : "memory");
+        }
+    };
+    auto dma_close = [&]() __attribute__((always_inline)) {
+        if constexpr (DMA) asm volatile(PP_GLDS(2048) :: "v"(dma_voff[4]), "s"(dma_src) : "memory");
+    };
+#undef PP_GLDS
+    // all five requests of tile t in one place; this is also the path of a partial last tile (its missing rows repeat row nk - 1)
     auto dma_issue = [&](int t) __attribute__((always_inline)) {
+        if constexpr (DMA) {
+            const int k0 = (dt0 + t) * KT;
+            if (k0 + KT > dnk) {                                       // (workgroup-uniform; at most one tile per workgroup)
+                const char* src = dma_base + (unsigned)(dt0 + t) * dma_tile_bytes;
+                const unsigned m0v = dma_m0 + (unsigned)(t & 3) * dma_slot;
+                unsigned vo[DMA_NP];
 #pragma unroll
-        for (int j = 0; j < DMA_NP; ++j) dma_issue_piece(t, j);
+                for (int j = 0; j < DMA_NP; ++j) {
+                    int r, c;
+                    dma_pos(j, r, c);
+                    vo[j] = (unsigned)(min(r, dnk - 1 - k0) * row_bytes + 16 * c + 4096 - 1024 * j);
+                }
+                asm volatile("s_mov_b32 m0, %6\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %0, %5 offset:-2048\n\tglobal_load_lds_dwordx4 %1, %5 offset:-1024\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+                             "global_load_lds_dwordx4 %3, %5 offset:1024\n\tglobal_load_lds_dwordx4 %4, %5 offset:2048"
+                             :: "v"(vo[0]), "v"(vo[1]), "v"(vo[2]), "v"(vo[3]), "v"(vo[4]), "s"(src), "s"(m0v) : "memory");
+            } else {
+                dma_open(t);
+#pragma unroll
+                for (int j = 1; j < DMA_NP - 1; ++j) dma_piece(j);
+                dma_close();
+            }
+        }
     };
     // this wave's pieces of every tile it requested - but, `younger`, of the last one - have landed
     auto dma_wait = [&](bool younger) __attribute__((always_inline)) {
@@ -618,7 +652,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     load_tile(0, rkA, rvA, rbA);
     if (PP_STRAIGHT || nt > 1) load_tile(1, rkB, rvB, rbB);
     dma_issue(0);                                   // (DMA: the two tiles travel while Q is split; the registers above then carry the key-validity bytes only)
-    if (nt > 1) dma_issue(1);
+    if (dnt > 1) dma_issue(1);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         const f32x4 a = qraw[s][0], c = qraw[s][1];
@@ -635,7 +669,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     dma_wait(false);                                // tiles 0 and 1 are in the ring
     PP_BARRIER();
     if (group == 1) PP_BARRIER();
-    if (DMA && !PP_DMA_SPREAD && group == 1 && nt > 2) dma_issue(2);      // barrier phase 0 (waves 0-3 issue it at the head of X(0))
+    if (DMA && !PP_DMA_SPREAD && group == 1 && dnt > 2) dma_issue(2);      // barrier phase 0 (waves 0-3 issue it at the head of X(0))
 #if PP_PRIO == 2
     if (group == 1) __builtin_amdgcn_s_setprio(1);
 #endif
@@ -770,7 +804,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
             }
         }
     };
-    auto qk_mfmas = [&](int kslot, bool prefetched, int dma_t = -1) __attribute__((always_inline)) {
+    auto qk_mfmas = [&](int kslot, bool prefetched, int dma_spread = 0, int dma_t = 0) __attribute__((always_inline)) {     // dma_spread (a scalar 0 / 1): the requests of tile dma_t between the k-steps
         if (!prefetched) read_k(kslot, 0, fr[0]);
 #if !(PP_CNEG && PP_INIT_IN_ACC)
         const float c0 = PP_INIT_IN_ACC ? -m_ref : 0.f;         // (0: the compiler feeds the first MFMA of each chain an inline zero)
@@ -797,10 +831,10 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
                 rd(1); PP_SB();
                 sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], qh[s], sacc[0], 0, 0, 0); PP_SB();
                 sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[1], qh[s], sacc[1], 0, 0, 0); PP_SB();
-                if (DMA && PP_DMA_SPREAD && dma_t >= 0) {           // (uniform) this wave's pieces of tile dma_t: one behind every k-step, the fifth behind the last
+                if (DMA && PP_DMA_SPREAD && dma_spread != 0) {      // this wave's requests of tile dma_t: one behind every k-step, the fifth behind the last
                     static_assert(!DMA || DMA_NP == KS + 1, "one piece per k-step and one more");
-                    dma_issue_piece(dma_t, s);
-                    if (s == KS - 1) dma_issue_piece(dma_t, KS);
+                    if (s == 0) dma_open(dma_t); else dma_piece(s);
+                    if (s == KS - 1) dma_close();
                     PP_SB();
                 }
             } else {
@@ -861,8 +895,8 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     const unsigned long long t_loop = tlast;
 #endif
     // a counted wait assumes that nothing but the wave's own DMA pieces entered its VMEM queue behind the tile it waits for: wave 0 of a masked launch
-    // (mask bytes) and the profiling builds (stamp stores) wait for everything instead
-#if defined(PP_PROFILE) || defined(PP_TIMELINE)
+    // (mask bytes) and the timeline build (stamp stores inside the loop) wait for everything instead
+#if defined(PP_TIMELINE)
     const bool dma_counted = false;
 #else
     const bool dma_counted = !(MASKED && wave == 0);
@@ -880,20 +914,27 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 #if PP_LOADS_IN_X
         if (PP_STRAIGHT || t + 3 < nt) load_tile(t + 3, rk2, rv2, rb2);          // the other register set was converted in Y(t-1)
 #endif
-        if (DMA && !PP_DMA_SPREAD && group == 0 && t + 2 < nt) dma_issue(t + 2);     // barrier phase 2t = 2 (t + 2) - 4
+        if (DMA && !PP_DMA_SPREAD && group == 0 && t + 2 < dnt) dma_issue(t + 2);     // barrier phase 2t = 2 (t + 2) - 4
         if (t > 0) pv_mfmas((t - 1) & 3, t & 3, PP_PREFETCH != 0);
-        qk_mfmas(t & 3, t > 0, (DMA && PP_DMA_SPREAD && t + 2 < nt) ? t + 2 : -1);   // (PP_DMA_SPREAD: tile t + 2 in barrier phase 2t / 2t + 1: 2 (t + 2) - 4 at the earliest)
+        // (PP_DMA_SPREAD: tile t + 2 in barrier phase 2t / 2t + 1: 2 (t + 2) - 4 at the earliest.  The flag as an opaque scalar int: ONE copy of the MFMA stream - two call sites cost
+        // 8 register-pair copies of the prefetched fragments per phase - and a scalar compare + branch per request - a bool travels as a lane mask and is inverted on the VALU)
+        int dma_sp = 0;
+        if (DMA && PP_DMA_SPREAD && t + 2 < dnt) {
+            dma_sp = ((dnk - (dt0 + t + 3) * KT) >> 31) + 1;                      // 1: all 64 keys of tile t + 2 exist (integer arithmetic: a bool -> int conversion goes through the VALU)
+            if (dma_sp == 0) dma_issue(t + 2);                                    // a partial last tile: its five requests at once, rows clamped
+        }
+        qk_mfmas(t & 3, t > 0, dma_sp, t + 2);
 #if PP_PRIO == 0
         __builtin_amdgcn_s_setprio(0);
 #endif
         PP_CLK(0);
         PP_TL(1);
-        if (DMA && group == 1) dma_wait(dma_counted && t + 2 < nt);              // tile t + 1 before the barrier that ends phase 2t + 1 (behind it: the pieces of t + 2, requested in Y(t - 1) or in this X(t))
+        if (DMA && group == 1) dma_wait(dma_counted && t + 2 < dnt);             // tile t + 1 before the barrier that ends phase 2t + 1 (behind it: the pieces of t + 2, requested in Y(t - 1) or in this X(t))
         PP_BARRIER();
         PP_CLK(1);
         PP_TL(2);
         // =============================== Y(t): vector phase ===============================================
-        if (DMA && !PP_DMA_SPREAD && group == 1 && t + 3 < nt) dma_issue(t + 3);     // barrier phase 2t + 2 = 2 (t + 3) - 4
+        if (DMA && !PP_DMA_SPREAD && group == 1 && t + 3 < dnt) dma_issue(t + 3);     // barrier phase 2t + 2 = 2 (t + 3) - 4
         if (mk != nullptr || (t0 + t + 1) * KT > nk) {
             const float* bs = Bs + (t & 3) * KT;
 #pragma unroll
@@ -966,7 +1007,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 #endif
         PP_CLK(3);
         PP_TL(4);
-        if (DMA && group == 0) dma_wait(dma_counted && t + 2 < nt);              // tile t + 1 before the barrier that ends phase 2t + 1 (behind it: the pieces of t + 2, requested in X(t))
+        if (DMA && group == 0) dma_wait(dma_counted && t + 2 < dnt);             // tile t + 1 before the barrier that ends phase 2t + 1 (behind it: the pieces of t + 2, requested in X(t))
         PP_BARRIER();
         PP_CLK(4);
         PP_TL(5);
