@@ -1,15 +1,15 @@
 #!/bin/bash
-# A/B of the benchmark under environment switches: usage  gpurun -- bash tools/gpu_ab_env.sh TAG "ENV1=a ENV2=b" "ENV1=c" ...   ("-" = no switch)
-# every arm: python bench.py --no-cpu-baseline --no-batch1 --no-f32-mode (default steps), twice, alternating
-T=${1:-ab}; shift; mkdir -p gpurun_out; OUT=gpurun_out/ab_$T.log; : > $OUT
-for rep in 1 2; do
-  for arm in "$@"; do
-    [ "$arm" = "-" ] && envs="" || envs="$arm"
-    line=$(env $envs timeout 300 python bench.py --no-cpu-baseline --no-batch1 --no-f32-mode 2>/dev/null | tail -1)
-    echo "$line" | python -c "
+# same-box A/B of bench.py under environment switches, lean legs only:  gpurun -- bash tools/gpu_ab_env.sh TAG "ENV1=.. ENV2=.." "ENV..." ...   ("-" = no switch; REPS, STEPS)
+TAG=$1; shift
+R=$PWD; O=$R/gpurun_out; mkdir -p $O; L=$O/envab_$TAG.log; : > $L
+for rep in $(seq 1 ${REPS:-3}); do
+  for E in "$@"; do
+    [ "$E" = "-" ] && E=""
+    (env $E timeout 200 python bench.py --steps ${STEPS:-60} --warmup 10 --no-cpu-baseline --no-batch1 --no-f32-mode 2>&1 | tail -1 | python -c "
 import json,sys
-d=json.loads(sys.stdin.read())
-print('arm [%s] pass $rep: value %.1f  one_in_flight %.1f  in_flight %s  attn %.1f us  sclk %s' % ('$arm', d['value'], d['one_step_in_flight']['value'], d['config']['steps_in_flight_per_gpu'], d['roofline']['launch_ms']*1e3, d['roofline'].get('sclk_mhz_observed')))" >> $OUT 2>&1
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('%-60s pairs/s %.1f  ms/step %.3f  in-flight %d  one-in-flight %.1f  attn %.2f us  frac %.3f  sclk %.0f  sk %.2f us' % ('$E' or '(default)', d['value'], d['ms_per_step'], d['config']['steps_in_flight_per_gpu'], d['one_step_in_flight']['value'], r['launch_ms']*1e3, r['frac'], r.get('sclk_mhz_observed') or 0, r['sinkhorn_iteration']['iteration_ms']*1e3))
+") >> $L 2>&1
   done
 done
-cat $OUT
+cat $L
