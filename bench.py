@@ -384,18 +384,28 @@ def main():
     if args.in_flight <= 0:
         # untimed calibration: the same steps with 1, 2 and 3 in flight, the fastest setting is the one that gets timed (round 5: 2 added - with the
         # in-call range recovery every call waits for its own work, and two streams hide that wait with less interference than three: 1108-1121 vs 1101)
-        cal_steps = 12
-        rates = {}
+        # (round 5: the arms used to be timed once each, 12 steps, in the order 1, 2, 3 right after the model was built - the first arm ran on an idle chip at boost clock and
+        # was picked in about one run of ten, which then timed 1 020 instead of 1 110 pairs/s (profiles/r05/envab_hostknobs.log).  Now: the chip is brought to its sustained
+        # state first, and every arm is timed in two interleaved rounds)
+        cal_steps = 16
+        pipes_ = {}
         for k_ in (1, 2, 3):
             reps_ = [model] if k_ == 1 else eval_loop.replicate(model, k_)
-            pp_ = pipeline.StepPipeline([make_step(m) for m in reps_], n_total, device=dev, exchange_every=xk)
-            pp_.run(max(4, k_))
-            torch.cuda.synchronize()
-            t0_ = time.perf_counter()
-            pp_.run(cal_steps)
-            torch.cuda.synchronize()
-            rates[k_] = cal_steps / (time.perf_counter() - t0_)
-            del pp_, reps_
+            pipes_[k_] = pipeline.StepPipeline([make_step(m) for m in reps_], n_total, device=dev, exchange_every=xk)
+            pipes_[k_].run(max(4, k_))                # every replica sizes its workspace
+        pipes_[3].run(40)                             # ~0.15 s of the real load: clocks and power settle
+        torch.cuda.synchronize()
+        spent = {1: 0.0, 2: 0.0, 3: 0.0}
+        for _round in range(2):
+            for k_ in (1, 2, 3):
+                pipes_[k_].run(2)
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                pipes_[k_].run(cal_steps)
+                torch.cuda.synchronize()
+                spent[k_] += time.perf_counter() - t0_
+        rates = {k_: 2 * cal_steps / spent[k_] for k_ in spent}
+        del pipes_
         best_ = torch.tensor([rates[1], rates[2], rates[3]], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(best_, op=dist.ReduceOp.MIN)        # every rank must take the same setting
