@@ -616,6 +616,38 @@ def test_fused_layer_launch_is_bit_identical_to_the_two_launch_path(model, n0, n
     assert fused._ensure_ctx().resident_health() == (0, 0)
 
 
+@pytest.mark.parametrize('model,n0,n1,B', [('GM', 2048, 2048, 4), ('GM', 1000, 1990, 3), ('DGNNS', 700, 900, 2), ('AdaGMN', 420, 400, 1), ('GM', 130, 97, 2)])
+def test_lds_dma_staging_of_the_attention_ring_is_bit_identical(model, n0, n1, B):
+    """round 5: the ping-pong attention kernel with its K / V ring filled by LDS-DMA (attention_f16x3.hip, template parameter DMA; IMP_ATTN_DMA=1, off by
+    default) against the register-staged kernel: only the way a tile's bytes reach the LDS differs - matches, match scores and the score tensor agree bit for
+    bit (full and partial last key tiles, the masked AdaGMN loop, ragged images, attention-sharing layers; tools/probe/attn_dma_check.hip is the kernel-level twin)."""
+    import ctypes
+    from imp_release_amd import _lib
+    word = ctypes.c_int.in_dll(_lib.lib(), 'imp_attn_dma_override')
+    cfg = eval_config(n_layers=5 if model != 'GM' else 3, sinkhorn_iterations=20)
+    sd = synthetic.make_state_dict(cfg, model, seed=8, bin_score=5.0 if model == 'AdaGMN' else 1.0)
+    m = make_hip_model(model, cfg, sd)
+    pair = synthetic.make_correlated_pair(n0, n1, seed=n0 + B, batch=B)
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+    kw = dict(p=0.2) if model == 'AdaGMN' else dict(p=0.2, only_last=True)
+    out = []
+    try:
+        for v in (0, 1):
+            word.value = v
+            with torch.no_grad():
+                o = m.produce_matches(data, **kw)
+            torch.cuda.synchronize()
+            out.append(o)
+    finally:
+        word.value = -1
+    a, b = out
+    assert int((a['indices0'][-1] >= 0).sum()) > 0 and torch.isfinite(a['mscores0'][-1]).all()
+    assert torch.equal(a['indices0'][-1], b['indices0'][-1]) and torch.equal(a['mscores0'][-1], b['mscores0'][-1])
+    if a.get('scores'):
+        assert torch.equal(a['scores'][-1], b['scores'][-1])
+
+
 def test_fused_layer_time_out_voids_the_call_and_steps_the_context_down():
     """IMP_WF_FUSED_FAKE=1 (test hook): one workgroup of every fused launch withholds its statistics, so every wait on them times
     out.  The call still ends (bounded polls), the pair whose exchange failed comes back VOID (NaN descriptors -> no matches - never plausible numbers), the next
