@@ -113,7 +113,8 @@ def cpu_baseline(args, quick=False):
                       f"{ {k: round(v, 3) for k, v in probes.items()} } pairs/s probed at N={args.kpts}), host: {ncpu} x {cpu_model}"}
 
 
-def batch1_latencies(dev, args):
+def batch1_latencies(dev, args, out=None):
+    """fills (and returns) `out`: the keys measured before a failure survive it"""
     import imp_release_amd as P
     from imp_release_amd import matching, synthetic
 
@@ -139,7 +140,7 @@ def batch1_latencies(dev, args):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps * 1e3
 
-    out = {}
+    out = {} if out is None else out
     with torch.no_grad():
         m = model_of('GM', eval_config(9, 100))
         d = data_of(1024, 1024, 5)
@@ -430,11 +431,28 @@ def main():
         return r_, time.perf_counter() - t0_
 
     n_warm = max(args.warmup, inflight)              # every replica sizes its workspace before the clock starts
-    pipe.run(n_warm)
-    res, dt = timed(pipe, args.steps)
+    # A chip-resident launch that times out voids its call, the library says so at the context's next entry point (IMP_E_RESIDENT) and the documented answer
+    # is "re-run the batch".  Seen once in a full run of this file (profiles/r05/MEASURED.md): the measurement then starts over on fresh replicas (one GPU only:
+    # a rank that repeats its steps alone would leave the others' collectives unmatched) and the line says how often
+    from imp_release_amd import _lib as _plib
+    headline_retries = 0
+    while True:
+        try:
+            pipe.run(n_warm)
+            res, dt = timed(pipe, args.steps)
+            break
+        except _plib.ResidentSinkhornTimeout:
+            if world > 1 or headline_retries >= 2:
+                raise
+            headline_retries += 1
+            torch.cuda.synchronize()
+            model = eval_loop.replicate(model, 2)[1]                 # a fresh context with the same weights
+            replicas = [model] if inflight == 1 else eval_loop.replicate(model, inflight)
+            pipe = pipeline.StepPipeline([make_step(m) for m in replicas], n_total, device=dev, exchange_every=xk)
     # the same number of steps strictly one after the other (one replica), reported next to the headline
     serial_s = None
-    if True:
+    serial_error = None
+    try:
         pipe1 = pipeline.StepPipeline([make_step(model)], n_total, device=dev, exchange_every=xk)
         pipe1.run(1)
         _, dt1 = timed(pipe1, args.steps)
@@ -442,6 +460,11 @@ def main():
         if world > 1:
             dist.all_reduce(serial_s, op=dist.ReduceOp.MAX)
         serial_s = float(serial_s.item())
+    except _plib.ResidentSinkhornTimeout as e_:      # (one GPU: reported, never fatal for the headline; several: the ranks' collectives no longer match - give up)
+        if world > 1:
+            raise
+        serial_s, serial_error = None, repr(e_)[:200]
+        model = eval_loop.replicate(model, 2)[1]
     h2d_s = None
     if args.h2d:
         host = {k: v.cpu().pin_memory() for k, v in data.items() if k not in ('image0', 'image1')}
@@ -512,8 +535,13 @@ def main():
     # f16x3 executes 3 f16 MFMA flops per algorithmic (fp32-equivalent) flop: the roof for ALGORITHMIC flops is the
     # dense f16 peak / 3; the native fp32-MFMA roof (157.3) is what the same math costs without the split
     peak = PEAK_F16_MFMA_TFLOPS / 3.0 if f16x3 else PEAK_F32_MFMA_TFLOPS
-    sk_ms = ctx.time_sinkhorn(B, N, 50)             # per Sinkhorn ITERATION, on the path the product takes for this shape
-    sk_resident = ctx.resident_status()[1]
+    try:
+        sk_ms = ctx.time_sinkhorn(B, N, 50)         # per Sinkhorn ITERATION, on the path the product takes for this shape
+        sk_resident = ctx.resident_status()[1]
+    except Exception:                               # noqa: BLE001 - a secondary leg never costs the line
+        ctx = eval_loop.replicate(model, 2)[1]._ensure_ctx()
+        sk_ms = ctx.time_sinkhorn(B, N, 50)
+        sk_resident = ctx.resident_status()[1]
     ld = (N + 1 + 3) // 4 * 4
     # bytes ONE pass over the matrix moves (what an iteration costs when P is streamed: the streaming path reads P once per
     # iteration + the column partial vectors; the chip-resident kernel keeps P in registers and moves only vectors)
@@ -584,7 +612,8 @@ def main():
                              'note': 'resident: no HBM traffic per iteration; the GB/s figure is what a streaming '
                                      'implementation would need to match it' if sk_resident else ''}},
         }
-        line['one_step_in_flight'] = None if serial_s is None else {
+        line['headline_retries_after_a_voided_resident_launch'] = headline_retries
+        line['one_step_in_flight'] = ({'error': serial_error} if serial_error else None) if serial_s is None else {
             'value': n_total * args.steps / serial_s, 'ms_per_step': serial_s / args.steps * 1e3,
             'note': 'same K steps strictly sequential on one model instance (no overlap between batch-steps); since round 4 every layer of '
                     'such a step is ONE fused launch (MLP0 -> InstanceNorm statistics exchange -> MLP3 -> next projection)'}
@@ -648,9 +677,17 @@ def main():
                 line['ragged_b4_note'] = {'error': str(e_)[:300]}
             # the batch-1 configurations of BASELINE.json on the same GPU (not the metric; recorded so that every round
             # shows them): configs[1] GM N=1024 L=9 T=100 batch 1, and configs[3] the EIMP sliced loop from N=4096
-            line.update(batch1_latencies(dev, args))
+            b1_ = {}
+            try:
+                batch1_latencies(dev, args, b1_)
+            except Exception as e_:                 # noqa: BLE001 - the extra keys never cost the headline line (those measured before the failure are kept)
+                b1_['batch1_error'] = repr(e_)[:300]
+            line.update(b1_)
         if not args.no_cpu_baseline:       # rank 0 only (this branch), at every N: the other ranks wait at the final barrier meanwhile
-            line['cpu_baseline'] = cpu_baseline(args, quick=world > 1)
+            try:
+                line['cpu_baseline'] = cpu_baseline(args, quick=world > 1)
+            except Exception as e_:                 # noqa: BLE001
+                line['cpu_baseline'] = {'error': repr(e_)[:300]}
         else:
             line['cpu_baseline'] = None
         print(json.dumps(line), flush=True)
