@@ -408,11 +408,13 @@ __device__ unsigned pp_hwid[8];
 // register round trip) instead of 4 buffer loads + 4 ds_write_b128 per thread and tile.  An LDS-DMA instruction writes 64 x 16 bytes LANE-LINEAR at M0, so the
 // row-pitched image of a tile (K 64 x 272 B = 17 KB, V 64 x 320 B = 20 KB: the pads stay, every fragment read is unchanged) is cut into 1-KB PIECES and a
 // lane fetches whatever 16-byte chunk belongs at its position of the piece (a lane that lands in a pad fetches a neighbouring chunk: never read).  37 pieces
-// per tile over 8 waves = 5 per wave (3 duplicates).  Schedule, in barrier phases (phase p = between the p-th and the (p + 1)-th barrier; waves 0-3: X(t) = 2t,
-// Y(t) = 2t + 1, waves 4-7 one later): tile T is issued in phase 2T - 4 (waves 0-3 at the head of X(T - 2), waves 4-7 at the head of Y(T - 3)) - the last reads
-// of the slot's previous occupant, V(T - 4), retired with the lgkmcnt(0) of the barrier that ends phase 2T - 5 - and every wave waits for its own pieces of T
-// (counted vmcnt: the pieces of T + 1 stay in flight) before the barrier that ends phase 2T - 1; the first read of T is K(T) in phase 2T.  The compiler does not
-// see the DMA (inline asm: hipcc would drain a DMA it knows about with vmcnt(0) before the next LDS read), so every wait is written here.
+// per tile: every wave requests five consecutive ones (waves 0-3 of K, waves 4-7 of V; three K pieces twice).  Schedule, in barrier phases (phase p = between the
+// p-th and the (p + 1)-th barrier; waves 0-3: X(t) = 2t, Y(t) = 2t + 1, waves 4-7 one later): a wave requests tile T inside its X(T - 2), one piece behind each
+// k-step of K.Q^T - phase 2T - 4 for waves 0-3, 2T - 3 for waves 4-7 (PP_DMA_SPREAD = 0: waves 0-3 at the head of X(T - 2), waves 4-7 at the head of Y(T - 3), phase
+// 2T - 4 for both); the last reads of the slot's previous occupant, V(T - 4), retired with the lgkmcnt(0) of the barrier that ends phase 2T - 5.  Every wave waits for
+// its own pieces of T (counted vmcnt: the pieces of T + 1 stay in flight) before the barrier that ends phase 2T - 1; the first read of T is K(T) in phase 2T.  The
+// compiler does not see the DMA (inline asm: hipcc would drain a DMA it knows about with vmcnt(0) before the next LDS read), so every wait is written here.
+// Measured (profiles/r05/MEASURED.md): bit-identical, 21 VGPRs fewer, -2.6 % cycles per phase, equal in time (the launch is power-limited): off by default.
 template <int DH, bool MASKED, bool DMA = false>
 __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams p, int qtiles, int total_blocks, int nsplit) {
     static_assert(DH == 64 || DH == 32, "head widths of the reference: 256 / 4 and 128 / 4 channels");
