@@ -42,6 +42,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef WF_NT
+#define WF_NT 0                 // EXPERIMENT: the epilogue's output stores non-temporal (1: the chained projection's q | k | v, 2: every output) - tools/build_variant.sh nt1 -DWF_NT=1
+#endif
 #ifndef WF_PRIO
 #define WF_PRIO 1               // group 0 runs its K loops at raised wave priority (A/B: tools/build_variant.sh x -DWF_PRIO=0)
 #endif
@@ -182,10 +185,18 @@ __device__ __forceinline__ void wf_epilogue(const f32x16 (&acc)[2], unsigned cha
                         imp_split2(v[2], v[3], a, d); hi[1] = a; lo[1] = d;
                         const int col = cb + c4;                                  // head segment col & ~63, channel col & 63
                         unsigned char* seg = reinterpret_cast<unsigned char*>(Cb + (long)row * ldc + (col & ~63)) + (col & 63) * 2;
-                        *reinterpret_cast<u32x2*>(seg) = hi;
-                        *reinterpret_cast<u32x2*>(seg + 128) = lo;
+                        if (WF_NT >= 1) {
+                            __builtin_nontemporal_store(hi, reinterpret_cast<u32x2*>(seg));
+                            __builtin_nontemporal_store(lo, reinterpret_cast<u32x2*>(seg + 128));
+                        } else {
+                            *reinterpret_cast<u32x2*>(seg) = hi;
+                            *reinterpret_cast<u32x2*>(seg + 128) = lo;
+                        }
                     }
-                } else if (row < M && (!(dbg & 1) || v[0] == 123.456f)) *reinterpret_cast<f32x4*>(Cb + (long)row * ldc + cb + c4) = v;
+                } else if (row < M && (!(dbg & 1) || v[0] == 123.456f)) {
+                    if (WF_NT >= 2 || (WF_NT == 1 && !TOPLANES && !has_res)) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(Cb + (long)row * ldc + cb + c4));
+                    else *reinterpret_cast<f32x4*>(Cb + (long)row * ldc + cb + c4) = v;
+                }
                 if (TOPLANES) {                                  // (rows past M repeat row M - 1: they feed only rows that are never stored)
                     u32x2 hi, lo;
                     unsigned a, d;
