@@ -45,6 +45,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef WF_NT
 #define WF_NT 0                 // EXPERIMENT: the epilogue's output stores non-temporal (1: the chained projection's q | k | v, 2: every output) - tools/build_variant.sh nt1 -DWF_NT=1
 #endif
+#ifndef WF_XCD
+#define WF_XCD 0                // EXPERIMENT: workgroup -> tile mapping that keeps the tiles of an image on ONE XCD (block b runs on XCD b % 8 in practice), the XCD on which the
+#endif                          // attention kernel's xcd_remap places that image's workgroups: producer and consumer of q | k | v, of the attention output and of the residual stream share an L2
 #ifndef WF_PRIO
 #define WF_PRIO 1               // group 0 runs its K loops at raised wave priority (A/B: tools/build_variant.sh x -DWF_PRIO=0)
 #endif
@@ -58,6 +61,15 @@ constexpr int WF_TBUF = WF_TROWS * WF_TP;   // bytes per wave
 constexpr int AUX_SC1 = 16;     // agent-scope coherent access (write-through store / cache-bypassing load)
 
 struct WfLane { int lane, half, w4, grp; };
+
+// linear block index -> work index such that the blocks of one XCD (lin % 8) take a contiguous range of work (attention_f16x3.hip xcd_remap)
+__device__ __forceinline__ int wf_xcd_remap(int lin, int total) {
+    if (!WF_XCD) return lin;
+    const int q = total / 8, r = total % 8;
+    const int xcd = lin % 8, idx = lin / 8;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
 
 #ifdef WF_PROFILE   // tools/build_variant.sh prof -DWF_PROFILE: cycle stamps of wave 0 of each group of every workgroup (staging, K loops, epilogues, total)
 __device__ unsigned long long wf_prof[2048][2][4];
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(512) void gemm_wf_kernel(const WfParams p, int row_
     WfLane L;
     L.lane = tid & 63; L.half = L.lane >> 5; L.w4 = (tid >> 6) & 3; L.grp = tid >> 8;
     const int lane = L.lane, half = L.half, w4 = L.w4, grp = L.grp;
-    int z = blockIdx.x;
+    int z = wf_xcd_remap(blockIdx.x, gridDim.x);
     // small launches: the column passes of a tile are dealt to `psplit` workgroups (each stages the tile itself) to fill the chip
     const int psplit = p.pass_split > 1 ? p.pass_split : 1;
     const int pgrp = z % psplit; z /= psplit;
@@ -610,7 +622,7 @@ __global__ __launch_bounds__(512) void gemm_wf_fused_kernel(const WfParams p, co
     WfLane L;
     L.lane = tid & 63; L.half = L.lane >> 5; L.w4 = (tid >> 6) & 3; L.grp = tid >> 8;
     const int lane = L.lane, half = L.half, w4 = L.w4, grp = L.grp;
-    int z = blockIdx.x;
+    int z = wf_xcd_remap(blockIdx.x, gridDim.x);
     const int rtile = z % row_tiles; z /= row_tiles;
     const int sidx = z % p.nside;
     const int b = z / p.nside;
