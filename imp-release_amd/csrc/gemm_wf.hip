@@ -63,8 +63,8 @@ constexpr int AUX_SC1 = 16;     // agent-scope coherent access (write-through st
 struct WfLane { int lane, half, w4, grp; };
 
 // linear block index -> work index such that the blocks of one XCD (lin % 8) take a contiguous range of work (attention_f16x3.hip xcd_remap)
-__device__ __forceinline__ int wf_xcd_remap(int lin, int total) {
-    if (!WF_XCD) return lin;
+__device__ __forceinline__ int wf_xcd_remap(int lin, int total, bool fused = false) {      // WF_XCD = 2: the fused layer launch only (taken while a stream has the chip to itself)
+    if (!WF_XCD || (WF_XCD == 2 && !fused)) return lin;
     const int q = total / 8, r = total % 8;
     const int xcd = lin % 8, idx = lin / 8;
     const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(512) void gemm_wf_fused_kernel(const WfParams p, co
     WfLane L;
     L.lane = tid & 63; L.half = L.lane >> 5; L.w4 = (tid >> 6) & 3; L.grp = tid >> 8;
     const int lane = L.lane, half = L.half, w4 = L.w4, grp = L.grp;
-    int z = wf_xcd_remap(blockIdx.x, gridDim.x);
+    int z = wf_xcd_remap(blockIdx.x, gridDim.x, true);
     const int rtile = z % row_tiles; z /= row_tiles;
     const int sidx = z % p.nside;
     const int b = z / p.nside;
