@@ -335,6 +335,10 @@ int imp_op_fused_mlp(imp_ctx* ctx, int B, int M, const float* x, const float* a,
                      const float* b3, const float* W2, const float* b2, int N2, float* y, float* y2, int fake, void* stream);
 int imp_op_attention(imp_ctx* ctx, int batch, int nq, int nk, int dim, const float* qkv_q,
                      const float* qkv_kv, const uint8_t* key_mask, float* out, float* lse, void* stream);
+/* test / probe hook, not part of the operator interface (a plain int of the library): which staging variant of the ping-pong attention kernel the launches that follow take
+ * when K / V are split-half images at head width 64 - 1: the ring is filled by LDS-DMA, 0: through registers, -1 (default): the environment (IMP_ATTN_DMA) or the build's default
+ * (off).  Same bits either way (tests/test_gpu_parity.py test_lds_dma_staging_of_the_attention_ring_is_bit_identical, tools/probe/attn_dma_check.hip). */
+extern int imp_attn_dma_override;
 /* timing hooks for bench.py: hipEvent-bracketed repetition of one attention / one Sinkhorn pass on
  * the context's own stream-ordered workspace; returns average milliseconds per launch in *ms. */
 int imp_time_attention(imp_ctx* ctx, int batch, int n, int reps, float* ms, void* stream);
