@@ -195,13 +195,16 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
         units = _pulled()
 
     def run_unit(m, pids):
+        from . import _lib
         if len(pids) == 1 and lockstep == 1:
             data = pair_provider(pids[0])
-            out = loop(data, m, nI, match_ratio, min_kpts, error_th, stop_criteria, estimate_pose=estimate_pose, **unc)
+            try:
+                out = loop(data, m, nI, match_ratio, min_kpts, error_th, stop_criteria, estimate_pose=estimate_pose, **unc)
+            except _lib.ResidentSinkhornTimeout:      # a voided waiting launch outside the score step (a fused layer, an entry check): the pair once more, on the protocol the context stepped down to
+                out = loop(data, m, nI, match_ratio, min_kpts, error_th, stop_criteria, estimate_pose=estimate_pose, **unc)
             rows[pids[0] - s] = summarize(out, eimp, data, estimate_pose, error_th)
             return
         datas = [pair_provider(pid) for pid in pids]
-        from . import _lib
         try:
             outs = group_loop(datas, m, nI, match_ratio, min_kpts, error_th, stop_criteria, estimate_pose=estimate_pose, **unc)
         except _lib.ResidentSinkhornTimeout:          # a voided launch inside the pipelined group: once more, on the protocol the context stepped down to
