@@ -651,3 +651,19 @@ def test_attention_handle_behaves_like_the_probability_tensor():
     assert torch.equal(h.cpu(), t)
     with pytest.raises(RuntimeError):
         AttentionHandle(FakeModel(), 0, 3, (1, 4, 3, 5)).materialize()
+
+
+def test_bench_cli_parses_the_drivers_command_line_and_refuses_to_run_without_a_gpu():
+    """bench.py is what the driver runs (`python bench.py --gpus N --steps K --warmup W`): the file must compile, know those flags, and - on a host
+    without a GPU - stop with a clear message instead of measuring anything else (the matching hot path has no CPU fallback)."""
+    import ast
+    import sys
+    path = os.path.join(ROOT, 'bench.py')
+    ast.parse(open(path).read())
+    out = subprocess.run([sys.executable, path, '--help'], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ('--gpus', '--steps', '--warmup', '--in-flight', '--exchange-every', '--no-cpu-baseline'):
+        assert flag in out.stdout, flag
+    if not torch.cuda.is_available():
+        run = subprocess.run([sys.executable, path, '--gpus', '1', '--steps', '20', '--warmup', '5'], capture_output=True, text=True, timeout=300)
+        assert run.returncode != 0 and 'needs a GPU' in (run.stderr + run.stdout)
