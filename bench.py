@@ -408,9 +408,10 @@ def main():
         # state first, and every arm is timed in two interleaved rounds)
         cal_steps = 16
         try:
-            pipes_ = {}
+            pipes_, reps_by_k = {}, {}
             for k_ in (1, 2, 3):
                 reps_ = [model] if k_ == 1 else eval_loop.replicate(model, k_)
+                reps_by_k[k_] = reps_
                 pipes_[k_] = pipeline.StepPipeline([make_step(m) for m in reps_], n_total, device=dev, exchange_every=xk)
                 pipes_[k_].run(max(4, k_))                # every replica sizes its workspace
             pipes_[3].run(40)                             # ~0.15 s of the real load: clocks and power settle
@@ -425,11 +426,10 @@ def main():
                     torch.cuda.synchronize()
                     spent[k_] += time.perf_counter() - t0_
             rates = {k_: 2 * cal_steps / spent[k_] for k_ in spent}
-            del pipes_
         except Exception as e_:                           # noqa: BLE001 - (one GPU) a voided waiting launch during the untimed calibration: take the usual winner on a fresh model
             if world > 1:
                 raise
-            pipes_ = None
+            pipes_, reps_by_k = None, None
             torch.cuda.synchronize()
             model = eval_loop.replicate(model, 2)[1]
             rates = {1: 0.0, 2: 0.0, 3: 1.0}
@@ -442,9 +442,14 @@ def main():
         if calibration_error:
             calibration['error'] = calibration_error
     inflight = max(1, args.in_flight)
-    replicas = [model] if inflight == 1 else eval_loop.replicate(model, inflight)
-
-    pipe = pipeline.StepPipeline([make_step(m) for m in replicas], n_total, device=dev, exchange_every=xk)
+    if calibration is not None and not calibration_error and pipes_ is not None:
+        # the timed steps run on the calibrated pipeline itself (its replicas have their workspaces, streams and kernel-choice history from ~70 untimed steps: the driver's
+        # `--warmup 5` on FRESH replicas timed ~3 % below the rate the calibration had just measured); the other arms are dropped
+        replicas, pipe = reps_by_k[inflight], pipes_[inflight]
+        pipes_, reps_by_k = None, None
+    else:
+        replicas = [model] if inflight == 1 else eval_loop.replicate(model, inflight)
+        pipe = pipeline.StepPipeline([make_step(m) for m in replicas], n_total, device=dev, exchange_every=xk)
 
     def fence():
         torch.cuda.synchronize()
