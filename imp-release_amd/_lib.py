@@ -27,7 +27,7 @@ SYMBOLS = [
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
     'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_pool_select_pair', 'imp_masked_commit', 'imp_gather_rows', 'imp_match_pair', 'imp_set_counts', 'imp_match_tail', 'imp_match_tail_scores', 'imp_pool_pair', 'imp_loop_lockstep', 'imp_loop_lockstep_uncertainty', 'imp_op_linear', 'imp_op_layer_gemm', 'imp_op_fused_mlp',
-    'imp_op_attention', 'imp_time_attention', 'imp_time_attention_clock', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_range_events', 'imp_set_range_recovery', 'imp_range_recovered', 'imp_range_take', 'imp_tag_wraps', 'imp_time_layer_gemm', 'imp_estimate_pose', 'imp_pose_stats',
+    'imp_op_attention', 'imp_time_attention', 'imp_time_attention_clock', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_resident_repaired', 'imp_resident_postmortem', 'imp_debug_hold_cus', 'imp_range_events', 'imp_set_range_recovery', 'imp_range_recovered', 'imp_range_take', 'imp_tag_wraps', 'imp_time_layer_gemm', 'imp_estimate_pose', 'imp_pose_stats',
     'imp_sp_create', 'imp_sp_destroy', 'imp_sp_set_weight', 'imp_sp_finalize', 'imp_sp_detect', 'imp_sp_describe', 'imp_sp_dense', 'imp_sp_op_conv',
 ]
 
@@ -154,6 +154,9 @@ def lib():
     L.imp_resident_status.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.imp_resident_health.argtypes = [P, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.imp_set_resident_verify.argtypes = [P, I]
+    L.imp_resident_repaired.argtypes = [P]
+    L.imp_debug_hold_cus.argtypes = [I, I, I, P]
+    L.imp_resident_postmortem.argtypes = [P, C.POINTER(C.c_int32), I]
     L.imp_range_events.argtypes = [P]
     L.imp_set_range_recovery.argtypes = [P, I]
     L.imp_range_recovered.argtypes = [P]
@@ -686,6 +689,24 @@ class Context:
             return False
         self._check(rc)
         return n.value, lvl.value
+
+    def resident_repaired(self):
+        """calls whose own voided waiting launch (resident Sinkhorn, fused layer) was repaired inside the call (include/imp_hip.h imp_resident_repaired)"""
+        return int(self.L.imp_resident_repaired(self.handle))
+
+    POSTMORTEM_FIELDS = ('kind', 'launch_tag', 'block', 'hw_id', 'xcc', 'phase', 'waited_for', 'tag_expected', 'tag_seen', 'iteration', 'pair', 'group',
+                         'groups', 'placement', 'pairs', None, 'status_word', 'gate_multi_stream', 'several_streams_choosing', 'gate_same_stream_run',
+                         'level_before', 'fused_layers_on', 'next_sinkhorn_tag', 'last_fused_tag', 'voided_so_far')
+
+    def resident_postmortem(self):
+        """record of the LAST voided waiting launch of this context as a dict (include/imp_hip.h imp_resident_postmortem), or None"""
+        buf = (C.c_int32 * 40)()
+        if self.L.imp_resident_postmortem(self.handle, buf, 40) != 1:
+            return None
+        rec = {k: int(buf[i]) for i, k in enumerate(self.POSTMORTEM_FIELDS) if k}
+        hw = rec['hw_id']
+        rec['waiter'] = {'wave': hw & 15, 'simd': (hw >> 4) & 3, 'cu': (hw >> 8) & 15, 'sh': (hw >> 12) & 1, 'se': (hw >> 13) & 7}
+        return rec
 
     def tag_wraps(self):
         """how often the tag counter of hipGraph-replayed resident launches wrapped (the library then cleared the exchange buffers)"""

@@ -49,7 +49,6 @@ __device__ __forceinline__ void split4(const f32x4 x, u32x2& hi, u32x2& lo) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) { unsigned a, b; imp_split2(x[2 * i], x[2 * i + 1], a, b); hi[i] = a; lo[i] = b; }
 }
-__device__ __forceinline__ int swap23(int k) { return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1); }
 
 // a wave's 32 output rows (staged in LDS as ot[row][DH]) -> memory as fp32 rows
 template <int DH>
@@ -66,259 +65,10 @@ __device__ __forceinline__ void store_attention_rows(const AttnParams& p, const 
     }
 }
 
-template <int DH, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64, 2) void attn_f16x3_kernel(const AttnParams p, int qtiles, int total_blocks) {
-    constexpr int NT = NWAVES * 64;
-    constexpr int KROW = DH + 4;                // floats per K row:  DH/2 (hi) + DH/2 (lo) + 4 pad
-    constexpr int VROW = KT + 4;                // floats per V^T row: 32 (hi) + 32 (lo) + 4 pad
-    constexpr int KF4 = KT * DH / 4, KLPT = KF4 / NT;          // float4 loads of K per thread
-    constexpr int VG = KT * DH / 16, VGPT = (VG + NT - 1) / NT; // 16-key groups of V per thread
-    constexpr int DT = DH / 32, KS = DH / 16;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Ks = smem;                           // [2][KT][KROW]
-    float* Vs = Ks + 2 * KT * KROW;             // [2][DH][VROW]
-    float* Bs = Vs + 2 * DH * VROW;             // [2][KT]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    int id = xcd_remap(blockIdx.x, total_blocks);
-    const int qt = id % qtiles; id /= qtiles;
-    const int h = id % IMP_NUM_HEADS; id /= IMP_NUM_HEADS;
-    const int sidx = id % p.nside;
-    const int b = id / p.nside;
-    const AttnSide& S = p.side[sidx];
-    const int nq = imp_count(p.rc, S.qimg, b, S.nq), nk = imp_count(p.rc, S.kimg, b, S.nk);      // ragged batches: this pair's own counts; S.nq / S.nk = the padded layout
-    const int q0 = qt * (NWAVES * 32);
-    if (q0 >= nq || nk <= 0) return;
-
-    const float* Qg = S.q + b * S.sq_b + h * DH;
-    const float* Kg = S.k + b * S.sk_b + h * DH;
-    const float* Vg = S.v + b * S.sk_b + h * DH;
-    const uint8_t* mk = S.kmask ? S.kmask + (long)b * S.nk : nullptr;
-
-    // Q fragments: lane (query l31, half) holds d = 16 s + 8 half .. + 7 for k-step s, as hi / lo halves
-    f16x8 qh[KS], ql[KS];
-    {
-        const int qrow = q0 + wave * 32 + l31;
-        const float* src = Qg + (long)(qrow < nq ? qrow : nq - 1) * p.ldq + 8 * half;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(src + 16 * s);
-            const f32x4 c = *reinterpret_cast<const f32x4*>(src + 16 * s + 4);
-            const float x[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
-            split8(x, qh[s], ql[s]);
-        }
-    }
-
-    f32x4 rk[KLPT];
-    float rv[VGPT][16];
-    float rb = 0.f;
-    // Staging loads go through raw buffer loads: SGPR descriptor (wave-uniform K / V base of this batch/head),
-    // 32-bit per-lane byte offset (loop invariant), scalar byte offset for the tile / key row: no 64-bit VALU address
-    // arithmetic in the loop, and rows past nk read as ZERO by the hardware bounds check (they are neutralised by the
-    // -inf key bias anyway), so there is no clamped tail path.
-    const unsigned kv_bytes = (unsigned)(((long)(nk - 1) * p.ldk + DH) * 4);
-    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kg, 0, kv_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)Vg, 0, kv_bytes, 0x00020000);
-    int koff[KLPT], voff[VGPT];
-#pragma unroll
-    for (int j = 0; j < KLPT; ++j) {
-        const int f = tid + j * NT;
-        koff[j] = ((f / (DH / 4)) * p.ldk + (f % (DH / 4)) * 4) * 4;
-    }
-#pragma unroll
-    for (int i = 0; i < VGPT; ++i) {
-        const int g = tid + i * NT;
-        voff[i] = (((g / DH) * 16) * p.ldk + (g % DH)) * 4;
-    }
-    const int row_bytes = p.ldk * 4;
-    auto load_tile = [&](int t) {
-        const int k0 = t * KT;
-        const int soff = k0 * row_bytes;                    // uniform
-#pragma unroll
-        for (int j = 0; j < KLPT; ++j) {
-            const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rsK, koff[j], soff, 0);
-            rk[j] = f32x4{__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3])};
-        }
-#pragma unroll
-        for (int i = 0; i < VGPT; ++i) {
-            if (VG % NT == 0 || tid + i * NT < VG) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    rv[i][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsV, voff[i], soff + e * row_bytes, 0));
-            }
-        }
-        if (tid < KT) {
-            const int key = k0 + tid;
-            bool ok = key < nk;
-            if (ok && mk) ok = mk[key] != 0;
-            rb = ok ? 0.f : -INFINITY;
-        }
-    };
-    auto store_tile = [&](int buf) {
-        float* ks = Ks + buf * KT * KROW;
-        float* vs = Vs + buf * DH * VROW;
-#pragma unroll
-        for (int j = 0; j < KLPT; ++j) {
-            const int f = tid + j * NT;
-            const int row = f / (DH / 4), c4 = (f % (DH / 4)) * 4;
-            u32x2 hi, lo;
-            split4(rk[j], hi, lo);
-            *reinterpret_cast<u32x2*>(ks + row * KROW + (c4 >> 1)) = hi;
-            *reinterpret_cast<u32x2*>(ks + row * KROW + DH / 2 + (c4 >> 1)) = lo;
-        }
-#pragma unroll
-        for (int i = 0; i < VGPT; ++i) {
-            const int g = tid + i * NT;
-            if (VG % NT == 0 || g < VG) {
-                const int d = g % DH, kg = g / DH;
-                f16x8 hi[2], lo[2];
-#pragma unroll
-                for (int g8 = 0; g8 < 2; ++g8) {              // position pos holds key swap23(pos) of this 16-key group
-                    float x[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) x[e] = rv[i][swap23(8 * g8 + e)];
-                    split8(x, hi[g8], lo[g8]);
-                }
-                float* row = vs + d * VROW + kg * 8;          // 16 halves = 8 floats per group
-                *reinterpret_cast<f16x8*>(row) = hi[0];
-                *reinterpret_cast<f16x8*>(row + 4) = hi[1];
-                *reinterpret_cast<f16x8*>(row + KT / 2) = lo[0];
-                *reinterpret_cast<f16x8*>(row + KT / 2 + 4) = lo[1];
-            }
-        }
-        if (tid < KT) Bs[buf * KT + tid] = rb;
-    };
-
-    f32x16 oacc[DT];
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    const float scale = DH == 64 ? 0.125f : 0.17677669529663687f;
-    const float SL2E = scale * LOG2E;
-
-    const int nt = (nk + KT - 1) / KT;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) load_tile(t + 1);
-        const float* ks = Ks + buf * KT * KROW + l31 * KROW + 4 * half;
-        const float* vs = Vs + buf * DH * VROW + l31 * VROW + 4 * half;
-        const float* bs = Bs + buf * KT;
-
-        // ---- S^T = K . Q^T : 3 f16 MFMAs per 16-deep k-step, the two key blocks interleaved ------------------
-        f32x16 sacc[2];
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[jb][r] = 0.f;
-        {
-            f16x8 kh[2][KS], kl[2][KS];
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    kh[jb][s] = *reinterpret_cast<const f16x8*>(ks + jb * 32 * KROW + 8 * s);
-                    kl[jb][s] = *reinterpret_cast<const f16x8*>(ks + jb * 32 * KROW + DH / 2 + 8 * s);
-                }
-            // product-major order: consecutive MFMAs alternate between the two accumulators (no dependent pairs)
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[0][s], qh[s], sacc[0], 0, 0, 0);
-                sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[1][s], qh[s], sacc[1], 0, 0, 0);
-                sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[0][s], ql[s], sacc[0], 0, 0, 0);
-                sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[1][s], ql[s], sacc[1], 0, 0, 0);
-                sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[0][s], qh[s], sacc[0], 0, 0, 0);
-                sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[1][s], qh[s], sacc[1], 0, 0, 0);
-            }
-        }
-        // ---- online softmax on the raw dot products (scale folded into the exp2 constant) ---------------------
-        if (mk != nullptr || (t + 1) * KT > nk) {
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 bias = *reinterpret_cast<const f32x4*>(bs + jb * 32 + 8 * g + 4 * half);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) sacc[jb][4 * g + e] += bias[e];
-                }
-        }
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[jb][r]);
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * scale;
-        const float m_new = fmaxf(m_run, tmax);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = fast_exp2((m_run - m_use) * LOG2E);
-        const float mneg = -m_use * LOG2E;
-        if (__any(alpha != 1.f)) {
-#pragma unroll
-            for (int d = 0; d < DT; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
-        }
-        // ---- P = exp(S - m) (split to hi/lo halves in registers) and O^T += V^T . P^T -------------------------
-        float lsum = 0.f;
-#pragma unroll
-        for (int jb = 0; jb < 2; ++jb) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                f16x8 vh[DT], vl[DT];
-#pragma unroll
-                for (int d = 0; d < DT; ++d) {
-                    vh[d] = *reinterpret_cast<const f16x8*>(vs + d * 32 * VROW + jb * 16 + 8 * s2);
-                    vl[d] = *reinterpret_cast<const f16x8*>(vs + d * 32 * VROW + KT / 2 + jb * 16 + 8 * s2);
-                }
-                f16x8 ph, pl;
-                float pv[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    pv[e] = fast_exp2(fmaf(sacc[jb][8 * s2 + e], SL2E, mneg));
-                    lsum += pv[e];
-                }
-                split8(pv, ph, pl);
-#pragma unroll
-                for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[d], ph, oacc[d], 0, 0, 0);
-#pragma unroll
-                for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[d], pl, oacc[d], 0, 0, 0);
-#pragma unroll
-                for (int d = 0; d < DT; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[d], ph, oacc[d], 0, 0, 0);
-            }
-        }
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
-        if (t + 1 < nt) store_tile(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue: normalise, transpose through LDS, coalesced row stores ------------------------------------
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv_l = 1.0f / l_tot;
-    constexpr int LDO = DH + 1;
-    float* ot = smem + wave * 32 * LDO;
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            ot[l31 * LDO + d * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = imp_div_by(oacc[d][r], l_tot, inv_l);       // == oacc / l_tot, bit for bit
-    if (S.lse && half == 0) {
-        const int qrow = q0 + wave * 32 + l31;
-        if (qrow < nq) S.lse[((long)b * IMP_NUM_HEADS + h) * S.nq + qrow] = m_run + logf(l_tot);
-    }
-    __syncthreads();
-    store_attention_rows<DH>(p, S, b, h, q0 + wave * 32, nq, ot, LDO, lane);
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // Ping-pong variant (DH = 64, 8 waves = 256 queries per workgroup, one workgroup per CU).
 //
-// In the kernel above the two waves that share a SIMD run in lock step (one barrier per key tile), so the matrix
+// When the two waves that share a SIMD run in lock step (one barrier per key tile: the kernel of rounds 1-5 for small launches), the matrix
 // pipe idles while both do their softmax / split VALU work and the VALU idles while both issue MFMAs - and with
 // the split-precision scheme the vector work is the larger half (measured on gfx950: a VALU instruction of a wave
 // whose SIMD partner streams MFMAs costs ~6 cycles, v_exp_f32 / v_fma_mix ~10; 48 MFMAs = 1536 pipe cycles).
@@ -441,7 +191,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int group = wave >> 2;                // 0: waves 0-3, 1: waves 4-7 (one phase behind)
     int id = xcd_remap(blockIdx.x, total_blocks);
-    const int sp = id % nsplit; id /= nsplit;   // key split: this workgroup walks over tiles [t0, t0 + nt) of the keys
+    const int sp = id % nsplit; id /= nsplit;   // key split: this workgroup walks over tiles [t0, t0 + nt) of the keys (nsplit = the launch's largest split)
     const int qt = id % qtiles; id /= qtiles;
     const int h = id % IMP_NUM_HEADS; id /= IMP_NUM_HEADS;
     const int sidx = id % p.nside;
@@ -450,8 +200,11 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     const int nq = imp_count(p.rc, S.qimg, b, S.nq), nk = imp_count(p.rc, S.kimg, b, S.nk);      // ragged batches: this pair's own counts; S.nq / S.nk = the padded layout
     const int q0 = qt * 256;
     if (q0 >= nq || nk <= 0) return;
+    // the split of THIS (pair, side): a function of its own counts (imp_kernels.h attn_side_splits), whatever else the launch holds
+    const int ns = nsplit > 1 ? attn_side_splits(nq, nk) : 1;
+    if (sp >= ns) return;
 
-    const int nt_all = (nk + KT - 1) / KT, t_per = (nt_all + nsplit - 1) / nsplit;
+    const int nt_all = (nk + KT - 1) / KT, t_per = (nt_all + ns - 1) / ns;
     const int t0 = sp * t_per;
     const int nt = min(nt_all, t0 + t_per) - t0;     // >= 1: the launcher never makes more splits than it has tiles for
     // (DMA) the same three as scalars for the request logic: a ragged batch's nk comes out of a memory load (imp_count), so everything derived from it is "divergent" to
@@ -1043,7 +796,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     constexpr int LDO = DH + 1;
     float* ot = smem + wave * 32 * LDO;
-    if (nsplit > 1) {
+    if (ns > 1) {
         // ---- key split: this workgroup holds a PARTIAL result (O relative to its own m_ref, l, m_ref).  It goes to scratch
         // with agent-coherent write-through stores; a ticket per (pair, side, head, query tile) tells the LAST of the nsplit
         // workgroups to arrive, and that one merges: m = max m_s, O = sum_s 2^(m_s - m) O_s, l likewise, out = O / l.
@@ -1077,7 +830,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
         __shared__ int s_last;
         if (tid == 0) {
             const unsigned old = __hip_atomic_fetch_add(p.split_cnt + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = old == (unsigned)nsplit - 1;
+            s_last = old == (unsigned)ns - 1;
             if (s_last) __hip_atomic_store(p.split_cnt + unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
         }
         __syncthreads();
@@ -1087,13 +840,13 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
         {
             const int moff = (256 * DH + wave * 32 + l31) * 4, loff = moff + 256 * 4;
             float mmax = -INFINITY;
-            for (int s2 = 0; s2 < nsplit; ++s2) {
+            for (int s2 = 0; s2 < ns; ++s2) {
                 const float ms = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsW, s2 * PART * 4 + moff, 0, 16));
                 const float ls = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsW, s2 * PART * 4 + loff, 0, 16));
                 if (ls > 0.f) mmax = fmaxf(mmax, ms);
             }
             float L = 0.f;
-            for (int s2 = 0; s2 < nsplit; ++s2) {
+            for (int s2 = 0; s2 < ns; ++s2) {
                 const float ms = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsW, s2 * PART * 4 + moff, 0, 16));
                 const float ls = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsW, s2 * PART * 4 + loff, 0, 16));
                 const float w = ls > 0.f ? fast_exp2(ms - mmax) : 0.f;
@@ -1113,7 +866,7 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
             f32x4 acc[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int s2 = 0; s2 < nsplit; ++s2) {
+            for (int s2 = 0; s2 < ns; ++s2) {
                 u32x4 v[NJ];
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
@@ -1183,6 +936,10 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 }
 
 }  // namespace
+#ifndef IMP_ATTN_W4_DEFAULT
+#define IMP_ATTN_W4_DEFAULT 0     // the one-wave-per-SIMD kernel (attention_f16x3_w4.hip) for the launches it can take
+#endif
+int imp_attn_w4_override = -1;
 int imp_attn_dma_override = -1;      // probes / tests: 0 | 1 forces the staging variant of the ping-pong kernel for the launches that follow (-1: IMP_ATTN_DMA or the default)
 namespace {
 
@@ -1219,34 +976,25 @@ hipError_t launch_pp(const AttnParams& p, int batch, int maxq, int nsplit, hipSt
     return hipGetLastError();
 }
 
-template <int DH, int NWAVES>
-hipError_t launch_one(const AttnParams& p, int batch, int maxq, hipStream_t stream) {
-    const int qtiles = (maxq + NWAVES * 32 - 1) / (NWAVES * 32);
-    const int total = qtiles * IMP_NUM_HEADS * p.nside * batch;
-    const size_t lds = (size_t)(2 * KT * (DH + 4) + 2 * DH * (KT + 4) + 2 * KT) * sizeof(float);
-    if (hipError_t e = imp_grant_dynamic_lds((const void*)attn_f16x3_kernel<DH, NWAVES>, lds)) return e;
-    hipLaunchKernelGGL((attn_f16x3_kernel<DH, NWAVES>), dim3(total), dim3(NWAVES * 64), lds, stream, p, qtiles, total);
-    return hipGetLastError();
-}
-
 }  // namespace
 
-// Key split of the ping-pong kernel for launches that leave most of the chip idle (one pair of ~1000-4000 keypoints = 32-128
-// workgroups on 256 CUs, each walking serially over all keys: 37 us at N = 1024 however the queries are tiled,
-// tools/probe/attn_small.py): nsplit workgroups share a query tile's keys and the last one to finish merges the partials.
-// Needs the scratch of AttnParams (split_ws / split_cnt); 1 = no split.
+// Key split of the ping-pong kernel for (pair, side) units that would leave most of the chip idle on their own (one pair of ~1000 keypoints =
+// 32 workgroups on 256 CUs, each walking serially over all keys: 37 us at N = 1024 however the queries are tiled, tools/probe/attn_small.py):
+// ns workgroups share a query tile's keys and the last one to finish merges the partials.  Round 6: the split of a unit is a function of the
+// unit's OWN query / key counts (attn_side_splits, imp_kernels.h) - a split changes the order in which a query's keys are summed, so a rule that
+// looked at the launch (batch size, the other pairs) made a pair's result depend on the batch it travelled in.  The launch
+// is sized for the largest split of its units; workgroups beyond a unit's own split leave at once.
+// Needs the scratch of AttnParams (split_ws / split_cnt); without it nothing is split.
 int attention_f16x3_splits(const AttnParams& p, int batch) {
-    static const int force = [] { const char* e = getenv("IMP_ATTN_SPLIT"); return e ? atoi(e) : 0; }();
-    int maxq = p.side[0].nq, mink = p.side[0].nk;
-    if (p.nside == 2) { if (p.side[1].nq > maxq) maxq = p.side[1].nq; if (p.side[1].nk < mink) mink = p.side[1].nk; }
-    if (!p.split_ws || !p.split_cnt || maxq <= 192 || force == 1 || p.rc.on) return 1;       // (ragged batches: a pair's key range may be shorter than a split's share)
-    const long wg = (long)((maxq + 255) / 256) * IMP_NUM_HEADS * p.nside * batch;
-    const int tiles = (mink + KT - 1) / KT;
+    if (!p.split_ws || !p.split_cnt) return 1;
     int s = 1;
-    if (force > 1) s = force;
-    else if (wg <= 128) s = wg <= 32 ? 4 : (wg <= 64 ? 3 : 2);
-    while (s > 1 && tiles < 4 * s) --s;            // at least 4 key tiles per split
-    if (s > 7) s = 7;
+    for (int sd = 0; sd < p.nside; ++sd)
+        for (int b = 0; b < (p.rc.on ? batch : 1); ++b) {
+            const int nq = p.rc.on ? p.rc.n[p.side[sd].qimg][b] : p.side[sd].nq, nk = p.rc.on ? p.rc.n[p.side[sd].kimg][b] : p.side[sd].nk;
+            if (nq <= 0 || nk <= 0) continue;                       // retired pair
+            const int u = attn_side_splits(nq, nk);
+            if (u > s) s = u;
+        }
     return s;
 }
 size_t attention_f16x3_split_floats(const AttnParams& p, int batch, int nsplit) {
@@ -1305,30 +1053,12 @@ hipError_t launch_attention_f16x3(const AttnParams& p, int batch, hipStream_t st
     if (p.nside == 2 && p.side[1].nq > maxq) maxq = p.side[1].nq;
     if (maxq <= 0 || batch <= 0) return hipSuccess;
     if (p.dh != 64 && p.dh != 32) return hipErrorInvalidValue;
-    const long units = (long)IMP_NUM_HEADS * p.nside * batch;        // (head, side, pair) combinations
-    auto wgs = [&](int qpw) { return (long)((maxq + qpw - 1) / qpw) * units; };
-    // A/B switches: IMP_ATTN_VARIANT 1 = lock-step kernels only, 2 = ping-pong at any size; IMP_ATTN_WAVES = waves (x 32
-    // queries) per lock-step workgroup
-    static const int variant = [] { const char* e = getenv("IMP_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
-    static const int force_waves = [] { const char* e = getenv("IMP_ATTN_WAVES"); return e ? atoi(e) : 0; }();
-    auto lockstep = [&](int nw) -> hipError_t {
-        if (p.dh == 64) {
-            if (nw >= 8) return launch_one<64, 8>(p, batch, maxq, stream);
-            return nw >= 4 ? launch_one<64, 4>(p, batch, maxq, stream) : launch_one<64, 2>(p, batch, maxq, stream);
-        }
-        return nw >= 4 ? launch_one<32, 4>(p, batch, maxq, stream) : launch_one<32, 2>(p, batch, maxq, stream);
-    };
-    if (force_waves) return lockstep(force_waves);
+    // Round 6: ONE kernel for every size - the phase-staggered 256-query kernel (rows past nq / nk are clamped / masked).  Rounds 1-5 sent launches
+    // whose largest side had <= 192 queries to the lock-step kernels (attn_f16x3_kernel, removed): a choice per LAUNCH, so a small pair took another
+    // kernel - another order of summation - beside a large pair than alone.  What a small pair loses (a few microseconds at D = 128 or
+    // IMP_KV_IMAGE=0; split-half K / V images always ran here) is the price of results that depend on the pair alone.
     const int nsplit = attention_f16x3_splits(p, batch);
-    if (p.kv_planes)              // split-half K / V images are staged by the ping-pong kernel only (any size: rows past nq / nk are clamped / masked)
-        return p.dh == 64 ? launch_pp<64>(p, batch, maxq, nsplit, stream) : launch_pp<32>(p, batch, maxq, nsplit, stream);
-    if (variant == 2) return p.dh == 64 ? launch_pp<64>(p, batch, maxq, nsplit, stream) : launch_pp<32>(p, batch, maxq, nsplit, stream);
-    // The phase-staggered 256-query kernel wins whenever its workgroups cover a good part of the chip (measured equal or
-    // faster than the lock-step kernels from 64 workgroups up: 78 vs 101 us at B = 3, N = 2048).  Below that (one pair of
-    // ~1000 keypoints = 32 workgroups on 256 CUs) the launch is latency-bound by the serial walk over the keys of a few
-    // workgroups: smaller query tiles put 2-4x more CUs to work (tools/probe/attn_small.py).
-    if (maxq > 192 && variant != 1)
-        return p.dh == 64 ? launch_pp<64>(p, batch, maxq, nsplit, stream) : launch_pp<32>(p, batch, maxq, nsplit, stream);
-    if (variant == 1 && p.dh == 64 && maxq > 192) return launch_one<64, 8>(p, batch, maxq, stream);
-    return lockstep(wgs(128) >= 192 ? 4 : 2);
+    static const int w4_env = [] { const char* e = getenv("IMP_ATTN_W4"); return e ? atoi(e) : IMP_ATTN_W4_DEFAULT; }();
+    if ((imp_attn_w4_override >= 0 ? imp_attn_w4_override : w4_env) != 0 && attention_f16x3_w4_ok(p, nsplit)) return launch_attention_f16x3_w4(p, batch, maxq, stream);
+    return p.dh == 64 ? launch_pp<64>(p, batch, maxq, nsplit, stream) : launch_pp<32>(p, batch, maxq, nsplit, stream);
 }

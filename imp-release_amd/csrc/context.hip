@@ -99,6 +99,9 @@ struct imp_ctx {
     int ot_verify = 0;       // IMP_OT_VERIFY=1 / imp_set_resident_verify: wait for every resident launch and re-run a voided one inside the call
     int ot_fake = 0;         // TEST HOOK IMP_OT_FAKE_PLACEMENT=1: LOCAL workgroups lie about their XCC (forces the time-out path)
     int resident_timeouts = 0;
+    int resident_repaired = 0;   // voided waiting launches whose call was run again INSIDE the call (range_recover_in_call)
+    int postmortem[40] = {};     // the last voided launch's record: [0..14] the kernel's (imp_kernels.h imp_postmortem_write), [16..] what the host knew when it noticed
+    int postmortem_valid = 0;
     int range_events = 0;
     int range_recover = 0;                         // imp_set_range_recovery: the one-shot / tail entry points wait for their own work and re-run a call whose operands left the fp16 range on the fp32 MFMA path
     int range_recovered = 0;
@@ -968,6 +971,22 @@ int resident_health(imp_ctx* c) {
     if (st) {
         (void)hipSetDevice(c->device);                     // (the caller's thread may have another device current: imp_resident_health)
         (void)hipDeviceSynchronize();
+        {   // post-mortem (round 6): the first timed-out waiter's record + the host's view at the moment it noticed
+            volatile int* pm = static_cast<volatile int*>(c->xstatus_host) + IMP_PM_BASE;
+            for (int i = 0; i < 15; ++i) c->postmortem[i] = pm[i];
+            for (int i = 0; i < 15; ++i) pm[i] = 0;
+            SpinGate* g = spin_gate(c->device);
+            c->postmortem[16] = st;
+            c->postmortem[17] = g ? (g->multi ? 1 : 0) : -1;              // gate was recording cross-stream events (several streams took sections)
+            c->postmortem[18] = g ? (g->query_multi ? 1 : 0) : -1;        // several streams were choosing kernels
+            c->postmortem[19] = g ? g->same_run : -1;
+            c->postmortem[20] = c->ot_degrade;
+            c->postmortem[21] = c->wf_fused;
+            c->postmortem[22] = (int)c->xtag;                             // next Sinkhorn tag base / last fused tag: places the voided launch in the context's sequence
+            c->postmortem[23] = (int)c->fx_tag;
+            c->postmortem[24] = c->resident_timeouts + 1;
+            c->postmortem_valid = 1;
+        }
         if (c->xstatus) (void)hipMemset(c->xstatus, 0, 64);
         if (c->xstatus) (void)hipMemset(c->xstatus + 17, 0, 44);           // graph launches: ticket base, done counter, tickets (their tag base [16] keeps counting)
         if (c->fx_status) (void)hipMemset(c->fx_status, 0, 64);
@@ -1013,18 +1032,22 @@ int plan_resident(imp_ctx* c, int batch, int n0, int n1, int max_wgs, int* nch, 
     // ever timed out (ot_degrade)
     const bool hw_local = c->num_xccs == 8 && c->num_cus == 256 && c->ot_degrade == 0;
     const bool allow_local = c->ot_local != 0 && hw_local;
+    // (round 6) WHICH decomposition a launch gets may depend on the batch - the column sums come out bit-identical in all of them (the canonical tree
+    // of ot_resident.hip) - with one exception: the two wide shapes (n1 > 2048) sum in another order and are planned only for ONE pair at its own sizes
+    const int single = batch == 1 && !(c->rc.on && (c->rc.n[0][0] != n0 || c->rc.n[1][0] != n1));
     *local = 0;
     const int per_xcd = (batch + 7) / 8;
-    if (allow_local && max_wgs >= c->num_cus && per_xcd <= 32 && ot_resident_plan(1, n0, n1, 32 / per_xcd, nch, rpw, G)) {
+    if (allow_local && max_wgs >= c->num_cus && per_xcd <= 32 && ot_resident_plan(1, n0, n1, 32 / per_xcd, nch, rpw, G, single)) {
         *local = 1;
         return 1;
     }
-    // two XCDs per pair: one fabric crossing per iteration instead of two (ot_resident.hip, LOCAL = 2)
-    if (c->ot_hier && hw_local && max_wgs >= c->num_cus && batch <= 4 && ot_resident_plan(1, n0, n1, 64, nch, rpw, G) && ot_resident_hier_ok(*nch, *rpw, *G, batch)) {
-        *local = 2;
-        return 1;
+    // two XCDs per pair: one fabric crossing per iteration instead of two (ot_resident.hip, LOCAL = 2).  Always 64 workgroups per pair - the halves
+    // meet at row 1024, a node of the tree, whatever n0 is (workgroups past n0 hold no rows and still own a column slice of the exchange)
+    if (c->ot_hier && hw_local && max_wgs >= c->num_cus && batch <= 4 && ot_resident_plan(1, n0, n1, 64, nch, rpw, G, 0)) {
+        *G = 64;
+        if (ot_resident_hier_ok(*nch, *rpw, *G, batch)) { *local = 2; return 1; }
     }
-    return ot_resident_plan(batch, n0, n1, max_wgs, nch, rpw, G);
+    return ot_resident_plan(batch, n0, n1, max_wgs, nch, rpw, G, single);
 }
 
 // one resident launch over the pairs [b0, b0 + nb) of a batch (all per-pair arrays are indexed b * stride inside the kernel)
@@ -1161,6 +1184,17 @@ const float* cached_k_fp32(imp_ctx* c, int kind, int side, long* ld, hipStream_t
     *err = launch_attn_kv_unplanes(c->qkv[kind][side], (long)cache.batch * cache.n[side], 3 * D, D, c->dh, c->kf32[side], D, st);
     *ld = D;
     return c->kf32[side];
+}
+
+// TEST HOOK (imp_debug_hold_cus): `workgroups` workgroups that each keep 96 KB of LDS - no waiting kernel of this library fits beside one on a CU - for
+// `ticks` ticks of the constant 100 MHz counter: what an RCCL kernel waiting for a slower peer looks like to the launches that need every CU
+__global__ __launch_bounds__(256) void hold_cus_kernel(unsigned long long ticks, unsigned* sink) {
+    extern __shared__ unsigned hold_lds[];
+    hold_lds[threadIdx.x] = threadIdx.x;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (sink && hold_lds[(threadIdx.x + 1) & 255] == 0xFFFFFFFFu) *sink = 1;        // (keeps the LDS allocation alive)
 }
 
 struct ProbSpec { int kind, qside, kside; };
@@ -1324,11 +1358,11 @@ int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     {   // health words in mapped host memory: the kernels raise them, the entry points read them without synchronising
         void* h = nullptr;
         void* d = nullptr;
-        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+        if (hipHostMalloc(&h, 256, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
             delete c;
             return fail(IMP_E_NOMEM, "imp_create: cannot allocate the mapped health words");
         }
-        memset(h, 0, 64);
+        memset(h, 0, 256);                                 // 64 ints: [0] waiting-launch status, [1] range word, [2] graph tag wrap, [16..] post-mortem record (imp_kernels.h IMP_PM_BASE)
         c->xstatus_host = static_cast<int*>(h);
         c->xstatus_hostdev = static_cast<int*>(d);
         c->range_host = c->xstatus_host + 1;
@@ -1749,27 +1783,49 @@ int imp_masked_commit(imp_ctx* c, int n0sel, const int64_t* gids0, const int64_t
     return IMP_OK;
 }
 
-// In-call recovery from an operand beyond the fp16 range (imp_set_range_recovery; VERDICT r4 #5b): after a call's work is enqueued the entry
-// point WAITS for it (one host synchronisation per call), looks at the range word the match kernel raises in mapped host memory, and when
-// it is set runs `again` - the same work on the native fp32 MFMA path (c->prec = 0), which has no operand limit - before it returns.
-// Returns IMP_OK (nothing happened, or recovered: the outputs hold the fp32 path's results once the stream drains) or an error.  A voided
-// RESIDENT launch is not a range event: its word is left for the health check of the next entry point, as before.
-static int range_recover_in_call(imp_ctx* c, hipStream_t st, const std::function<int()>& again) {
-    if (!c->range_recover || c->prec != 1 || !c->range_host) return IMP_OK;
+// In-call recovery (imp_set_range_recovery; VERDICT r4 #5b, r5 #2a): after a call's work is enqueued the entry point WAITS for it (one host
+// synchronisation per call) and looks at the two words the kernels raise in mapped host memory:
+//   * the range word (a match kernel met non-finite scores: an operand left the fp16 range of the f16x3 arithmetic): `run` is executed again on the
+//     native fp32 MFMA path (c->prec = 0), which has no operand limit;
+//   * the waiting-launch word (round 6: a chip-resident Sinkhorn or a fused layer launch of THIS call timed out in an exchange and voided its outputs):
+//     the context takes its usual step down (resident_health: chip-wide exchange / streaming kernels / two-launch layers) and `run` is executed
+//     again - the caller never sees the void answer (the reference's calls always answer: nets/gm.py:145-247).  Whether the voided launch is this
+//     call's is read from its tag in the post-mortem record; an OLDER launch's time-out (a step call nobody waited for) is reported as before:
+//     IMP_E_RESIDENT, that earlier call is void.
+// Returns IMP_OK (nothing happened, or recovered: the outputs hold the repaired results) or an error.
+static int run_with_recovery(imp_ctx* c, hipStream_t st, const std::function<int()>& run) {
+    const unsigned sk0 = c->xtag, fx0 = c->fx_tag;         // tags this call's waiting launches will draw from
+    int rc = run();
+    if (rc) return rc;
+    if (!c->range_recover || !c->range_host) return IMP_OK;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return IMP_OK;      // a capture cannot wait
     // (a polled wait - hipStreamQuery for up to 20 ms before blocking - was measured and is no faster: configs[1] 1.68-1.70 vs 1.65-1.71 ms per call; the
     // price of the wait is the host's enqueue work no longer running ahead of the GPU, not the wake-up; profiles/r05/c2_latency_range_recovery_ab.log)
-    HIP_TRY(hipStreamSynchronize(st));
-    if (c->xstatus_host && *static_cast<volatile int*>(c->xstatus_host)) return IMP_OK;
-    if (!*static_cast<volatile int*>(c->range_host)) return IMP_OK;
-    *static_cast<volatile int*>(c->range_host) = 0;
-    c->range_events += 1;
-    c->prec = 0;
-    const int rc = again();
-    c->prec = 1;
-    if (rc == IMP_OK) c->range_recovered += 1;
-    return rc;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        HIP_TRY(hipStreamSynchronize(st));
+        const int wst = c->xstatus_host ? *static_cast<volatile int*>(c->xstatus_host) : 0;
+        if (wst) {
+            const unsigned vt = (unsigned)static_cast<volatile int*>(c->xstatus_host)[IMP_PM_BASE + 1];
+            const int kind = static_cast<volatile int*>(c->xstatus_host)[IMP_PM_BASE];
+            const bool ours = kind == 3 ? (vt > fx0 && vt <= c->fx_tag) : (vt >= sk0 && vt < c->xtag && c->xtag >= sk0);
+            const int hrc = resident_health(c);             // waits, resets the exchange state, steps the context down; IMP_E_RESIDENT
+            if (!ours || hrc != IMP_E_RESIDENT || attempt == 3) return hrc;
+            c->resident_repaired += 1;
+            if ((rc = run())) return rc;
+            continue;
+        }
+        if (c->prec != 1 || !*static_cast<volatile int*>(c->range_host)) return IMP_OK;
+        *static_cast<volatile int*>(c->range_host) = 0;
+        c->range_events += 1;
+        c->prec = 0;
+        rc = run();
+        c->prec = 1;
+        if (rc) return rc;
+        c->range_recovered += 1;
+        // (the fp32 pass may itself meet a voided waiting launch: look again)
+    }
+    return IMP_OK;
 }
 
 static int match_pair_enqueue(imp_ctx* c, int batch, int n0, int n1, const float* kpts0, const float* scores0, const float* desc0,
@@ -1790,8 +1846,7 @@ int imp_match_pair(imp_ctx* c, int batch, int n0, int n1, const float* kpts0, co
         return match_pair_enqueue(c, batch, n0, n1, kpts0, scores0, desc0, kpts1, scores1, desc1, width, height, bin_score, sinkhorn_iterations,
                                   with_sinkhorn, p, indices0, mscores0, indices1, mscores1, scores, st);
     };
-    if ((rc = run())) return rc;
-    return range_recover_in_call(c, st, run);
+    return run_with_recovery(c, st, run);
 }
 
 static int match_pair_enqueue(imp_ctx* c, int batch, int n0, int n1, const float* kpts0, const float* scores0, const float* desc0,
@@ -1866,10 +1921,9 @@ int imp_match_tail_scores(imp_ctx* c, int layer_id, int batch, int n0, int n1, c
                                       mscores1, c->range_hostdev, st, &c->rc));
         return IMP_OK;
     };
-    if ((rc = run())) return rc;
-    // (recovery mode: an overflow INSIDE the tail - final projection, distance - is repaired here; descriptors that arrive non-finite from the
-    // caller's earlier layer calls stay void and are reported at the next entry point, as without the mode)
-    return range_recover_in_call(c, st, run);
+    // (recovery mode: an overflow or a voided resident launch INSIDE the tail - final projection, distance, Sinkhorn - is repaired here; descriptors that
+    // arrive non-finite from the caller's earlier layer calls stay void and are reported at the next entry point, as without the mode)
+    return run_with_recovery(c, st, run);
 }
 
 int imp_loop_lockstep(imp_ctx* c, int B, const int32_t* n0v, const int32_t* n1v, int n0, int n1, const float* nkpts0, const float* scores0,
@@ -2346,6 +2400,16 @@ int imp_loop_lockstep_uncertainty(imp_ctx* c, int B, const int32_t* n0v, const i
     return IMP_OK;
 }
 
+int imp_debug_hold_cus(int device, int workgroups, int microseconds, void* stream) {
+    if (workgroups < 1 || workgroups > 1024 || microseconds < 1 || microseconds > 1000000) return fail(IMP_E_ARG, "imp_debug_hold_cus: 1..1024 workgroups, 1..1e6 microseconds");
+    HIP_TRY(hipSetDevice(device));
+    const size_t lds = 96 * 1024;
+    if (hipError_t e = imp_grant_dynamic_lds((const void*)hold_cus_kernel, lds)) return fail(IMP_E_HIP, hipGetErrorString(e));
+    hipLaunchKernelGGL(hold_cus_kernel, dim3(workgroups), dim3(256), lds, S(stream), (unsigned long long)microseconds * 100ull, (unsigned*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return IMP_OK;
+}
+
 int imp_set_counts(imp_ctx* c, int batch, const int32_t* n0, const int32_t* n1) {
     if (!c) return fail(IMP_E_ARG, "null context");
     if (!n0 && !n1) { c->rc.on = 0; c->rc_batch = 0; return IMP_OK; }
@@ -2781,6 +2845,15 @@ int imp_resident_health(imp_ctx* c, int* timeouts, int* level) {
     if (timeouts) *timeouts = c->resident_timeouts;
     if (level) *level = c->ot_degrade;
     return rc;
+}
+
+int imp_resident_repaired(imp_ctx* c) { return c ? c->resident_repaired : -1; }
+
+int imp_resident_postmortem(imp_ctx* c, int32_t* out, int n) {
+    if (!c || !out || n < 1) return fail(IMP_E_ARG, "imp_resident_postmortem: bad argument");
+    if (!c->postmortem_valid) return 0;
+    for (int i = 0; i < n && i < 40; ++i) out[i] = c->postmortem[i];
+    return 1;
 }
 
 int imp_range_events(imp_ctx* c) { return c ? c->range_events : -1; }

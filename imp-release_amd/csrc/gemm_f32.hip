@@ -382,36 +382,36 @@ __global__ __launch_bounds__(256, DEEP ? 2 : 3) void gemm_f32_kernel(const GemmP
         }
     }
     if (flags & GEMM_EPI_STATS) {
-        // per column and per WAVE-ROW-BLOCK (WM rows = one statistics tile): (sum, M2 about the block mean) over the valid
-        // rows, two passes over the accumulators: in-lane over the 16 x TM registers, then the lane pair (l, l ^ 32).  No
+        // per column and per 32-ROW BLOCK (one MFMA row tile of the wave = one statistics block): (sum, M2 about the block mean) over the valid
+        // rows, two passes over the accumulators: in-lane over the 16 registers, then the lane pair (l, l ^ 32).  No
         // LDS, no cross-wave step; launch_stats_finalize merges the blocks with Chan's formula in fp64, so a channel
         // whose |mean| is far above its standard deviation keeps its digits (E[x^2] - mean^2 would cancel them).
-        const int blk_row0 = row0 + wm * WM;
-        const int cnt = min(WM, M - blk_row0);                    // valid rows of this block (<= 0: nothing to report)
-        if (cnt > 0) {
-            const int tiles_side = (Mpad + WM - 1) / WM;          // dense per side: [b][block][N][2]
-            float* os = S.out_stats + ((long)b * tiles_side + (rtile * 2 + wm)) * N * 2;
+        // Round 6: the block is 32 rows for EVERY tile shape (it was the wave's WM = 32 or 64 rows: the tile - chosen from the launch's workgroup
+        // count, i.e. from the batch - decided how a pair's rows were grouped, and the InstanceNorm statistics moved in the last bits with it)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int blk_row0 = row0 + wm * WM + i * 32;
+            const int cnt = min(32, M - blk_row0);                    // valid rows of this block (<= 0: nothing to report)
+            if (cnt <= 0) continue;                                   // (uniform per wave)
+            const int tiles_side = (Mpad + 31) / 32;                  // dense per side: [b][block][N][2]
+            float* os = S.out_stats + ((long)b * tiles_side + ((rtile * 2 + wm) * TM + i)) * N * 2;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float s = 0.f;
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const bool ok = interior || (rbase + i * 32 + (r & 3) + 8 * (r >> 2) < M);
-                        s += ok ? acc[i][j][r] : 0.f;
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = interior || (rbase + i * 32 + (r & 3) + 8 * (r >> 2) < M);
+                    s += ok ? acc[i][j][r] : 0.f;
+                }
                 s += __shfl_xor(s, 32);
                 const float mean = s / (float)cnt;
                 float m2 = 0.f;
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const bool ok = interior || (rbase + i * 32 + (r & 3) + 8 * (r >> 2) < M);
-                        const float d = acc[i][j][r] - mean;
-                        m2 = fmaf(ok ? d : 0.f, d, m2);
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = interior || (rbase + i * 32 + (r & 3) + 8 * (r >> 2) < M);
+                    const float d = acc[i][j][r] - mean;
+                    m2 = fmaf(ok ? d : 0.f, d, m2);
+                }
                 m2 += __shfl_xor(m2, 32);
                 const int col = cbase + j * 32;
                 if (lane < 32 && col < N) {
@@ -528,7 +528,7 @@ int gemm_tile_m(int M, int N, int total_z) {
 }
 
 // rows per statistics block (= rows of one wave's accumulator tile) of the launch the parameters will get
-int gemm_stats_rows(int M, int N, int total_z) { return gemm_tile_m(M, N, total_z) / 2; }
+int gemm_stats_rows(int, int, int) { return 32; }      // (round 6: one MFMA row tile, whatever tile shape the launch gets)
 
 hipError_t launch_gemm_f32(const GemmParams& p, int batch, hipStream_t stream) {
     const int maxM = p.nside == 2 ? (p.side[0].M > p.side[1].M ? p.side[0].M : p.side[1].M) : p.side[0].M;

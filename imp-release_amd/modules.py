@@ -336,11 +336,26 @@ class GM(nn.Module):
         e0, e1 = ctx.encode_keypoints(norm_kpts0, scores0, norm_kpts1, scores1)
         return e0.transpose(1, 2), e1.transpose(1, 2)
 
+    def _verified(self, ctx, call):
+        """step API: a call that launches a WAITING kernel (fused layer, chip-resident Sinkhorn) is awaited and, when that launch was voided, made again
+        on the protocol the context stepped down to - the drop-in caller (eval/matching.py's own loops) gets valid tensors from the same call
+        (VERDICT r5 #2a).  One host synchronisation per such call; config key ``verify_steps`` (default True; the library's own loops in
+        imp_release_amd.matching keep their one synchronisation per scored iteration and never come through here)"""
+        if not self.config.get('verify_steps', True) or torch.cuda.is_current_stream_capturing():
+            return call()
+        stream = torch.cuda.current_stream(ctx.device)
+        for _ in range(4):
+            out = call()
+            stream.synchronize()
+            if ctx.resident_health(raise_on_timeout=False) is not False:
+                return out
+        raise _lib.ResidentSinkhornTimeout(_lib.IMP_E_RESIDENT, 'the call stayed void on every protocol of the context')
+
     def forward_one_layer(self, desc0, desc1, M0, M1, layer_i):
         """nets/gm.py:263-285 / nets/gms.py:260-282 / nets/adgm.py:528-550 (M0, M1 are ignored there too)."""
         ctx = self._ensure_ctx()
         d0, d1 = _token_major(desc0), _token_major(desc1)
-        o0, o1 = ctx.forward_layer(layer_i, d0, d1)
+        o0, o1 = self._verified(ctx, lambda: ctx.forward_layer(layer_i, d0, d1))
         self._note_layer(layer_i, d0.shape[0], d0.shape[1], d1.shape[1])
         return o0.transpose(1, 2), o1.transpose(1, 2)
 
@@ -352,7 +367,8 @@ class GM(nn.Module):
     def compute_score(self, dist, dustbin, iteration):
         """nets/gm.py:297-303"""
         ctx = self._ensure_ctx()
-        return ctx.compute_score(dist, self._bin(dustbin), iteration, self.with_sinkhorn)
+        binv = self._bin(dustbin)
+        return self._verified(ctx, lambda: ctx.compute_score(dist, binv, iteration, self.with_sinkhorn))
 
     def compute_matches(self, scores, p=0.2):
         """nets/gm.py:305-320"""
@@ -468,38 +484,54 @@ class GM(nn.Module):
         out['scores'] = []
         return out
 
+    def _guarded_pass(self, ctx, body, composed=True):
+        """Runs ``body()`` - a whole pass over a batch - so that THIS call hands back a valid answer, like every call of the reference does
+        (nets/gm.py:145-247; VERDICT r5 #2a).  Two things can void a pass after it was enqueued: a waiting launch (chip-resident Sinkhorn, fused
+        layer) whose exchange timed out - the context then steps down to the next protocol - and, in the f16x3 arithmetic, an operand beyond the
+        fp16 range - the pass then runs on the native fp32 MFMA path.  Either way the pass is run AGAIN here, inside the call; the price is one
+        host synchronisation per pass (config key ``range_recovery``, default True; never under stream capture, where nothing may wait).
+        An event that an EARLIER call left behind (a step-API sequence nobody waited for) is that call's: it is raised before this pass starts
+        and never counted as this pass's."""
+        if not getattr(ctx, 'range_recovery', False) or torch.cuda.is_current_stream_capturing():
+            return body()
+        stream = torch.cuda.current_stream(ctx.device)
+        ctx.resident_health()                       # pending ResidentSinkhornTimeout / OperandRangeError of an earlier call: raised here, outside the loop
+        f32 = False
+        for _ in range(6):
+            try:
+                if composed:
+                    ctx.set_range_recovery(False)   # (the tails of a composed pass do not wait one by one: ONE synchronisation per pass, below)
+                if f32:
+                    ctx.set_precision('f32')
+                try:
+                    out = body()
+                finally:
+                    if f32:
+                        ctx.set_precision('f16x3')
+                    if composed:
+                        ctx.set_range_recovery(True)
+                stream.synchronize()
+                if ctx.resident_health(raise_on_timeout=False) is False:
+                    continue                        # a waiting launch of this pass was voided; the context stepped down: once more
+                return out
+            except _lib.ResidentSinkhornTimeout:    # noticed by one of the pass's own later entry points
+                continue
+            except _lib.OperandRangeError:          # ... likewise (or by the health check above, which reports the range word as well)
+                if f32 or ctx.precision != 'f16x3':
+                    raise
+                stream.synchronize()
+                ctx.range_take(False)               # (a second iteration may have raised the word again meanwhile)
+                ctx.L.imp_range_take(ctx.handle, 2)
+                f32 = True
+        raise _lib.ResidentSinkhornTimeout(_lib.IMP_E_RESIDENT, 'the pass stayed void on every protocol of the context')
+
     def _run_iterations_chunk(self, data, p, only_last, want_scores, counts):
         ctx = self._ensure_ctx(check=True)
         if counts is not None:
             ctx.set_counts(*counts)
         try:
             one_shot = only_last and len(self.gnn.names) == 2 * self.n_layers        # (imp_match_pair repairs itself inside the call)
-            recover = (getattr(ctx, 'range_recovery', False) and not one_shot and ctx.precision == 'f16x3' and
-                       not torch.cuda.is_current_stream_capturing())
-            # a pass composed from layer calls: an operand beyond the fp16 range poisons the descriptors BEFORE the tails see them, so the whole
-            # pass runs again on the fp32 MFMA path (include/imp_hip.h imp_range_take); costs one synchronisation per pass.  The event shows
-            # either after the pass (the range word, once this stream has drained) or - when an earlier iteration's match kernel has already
-            # finished - as IMP_E_RANGE from one of the pass's own later entry points
-            hit = False
-            try:
-                out = self._run_iterations_body(ctx, data, p, only_last, want_scores, counts is not None)
-                if recover:
-                    torch.cuda.current_stream(ctx.device).synchronize()
-                    hit = ctx.range_take(True)
-            except _lib.OperandRangeError:
-                if not recover:
-                    raise
-                torch.cuda.current_stream(ctx.device).synchronize()
-                ctx.range_take(False)                      # (a second iteration may have raised the word again meanwhile)
-                ctx.L.imp_range_take(ctx.handle, 2)
-                hit = True
-            if hit:
-                ctx.set_precision('f32')
-                try:
-                    out = self._run_iterations_body(ctx, data, p, only_last, want_scores, counts is not None)
-                finally:
-                    ctx.set_precision('f16x3')
-            return out
+            return self._guarded_pass(ctx, lambda: self._run_iterations_body(ctx, data, p, only_last, want_scores, counts is not None), composed=not one_shot)
         finally:
             if counts is not None:
                 ctx.set_counts()
@@ -632,6 +664,9 @@ class AdaGMN(GM):
         """nets/adgm.py:327-526: *masked* adaptive pooling (tensors keep their size; pruned keypoints are
         masked out as attention keys and excluded from scoring)."""
         ctx = self._ensure_ctx(check=True)
+        return self._guarded_pass(ctx, lambda: self._masked_pass(ctx, data, p, mscore_th, uncertainty_ratio))
+
+    def _masked_pass(self, ctx, data, p, mscore_th, uncertainty_ratio):
         k0, k1, w, h = self._inputs(data)
         if w > 0:
             k0, k1 = ctx.normalize_keypoints(k0, w, h), ctx.normalize_keypoints(k1, w, h)

@@ -400,6 +400,24 @@ void imp_pose_stats(long* calls, long* samples, int reset);
 int imp_resident_status(imp_ctx* ctx, int* status, int* used);
 int imp_resident_health(imp_ctx* ctx, int* timeouts, int* level);
 int imp_set_resident_verify(imp_ctx* ctx, int on);
+/* Round 6.  With in-call recovery on (imp_set_range_recovery, the default of the Python modules) imp_match_pair / imp_match_tail[_scores]
+ * also repair a waiting launch of THEIR OWN that was voided: after the call's one synchronisation the context takes its step down and the call's work is
+ * enqueued again - the caller receives valid results from the same call, like every call of the reference does (nets/gm.py:145-247).
+ *  imp_resident_repaired: how many calls were repaired that way.
+ *  imp_resident_postmortem: the record of the LAST voided waiting launch, n <= 40 ints, returns 1 when there is one (0: none so far):
+ *    [0] kind (1 Sinkhorn wait timed out, 2 Sinkhorn workgroups not spread evenly over the XCCs, 3 fused layer statistics exchange timed out)
+ *    [1] tag of the launch  [2] blockIdx.x of the first waiter that gave up  [3] its HW_ID register (wave [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13])
+ *    [4] its XCC  [5] phase (Sinkhorn: 1 partial column vectors, 2 half-sum swap between the two XCDs of a pair, 3 v, 4 column maxima; fused layer:
+ *    1 block statistics, 2 finalised statistics)  [6] index of the granule / chunk it waited for  [7] tag it expected  [8] tag it saw
+ *    [9] Sinkhorn iteration  [10] pair  [11] row group / tile  [12] groups / tiles per pair  [13] placement (0 chip-wide, 1 one XCD, 2 two XCDs per pair)
+ *    [14] pairs in the launch; host side, at the moment the library noticed: [16] status word  [17] the device's spin gate was ordering several streams
+ *    [18] several streams were choosing kernels  [19] consecutive sections of one stream  [20] step-down level before  [21] fused layers enabled
+ *    [22] next Sinkhorn tag  [23] last fused-layer tag  [24] voided launches so far. */
+/* TEST HOOK (tests/test_gpu_rehearsal.py): `workgroups` workgroups that each hold 96 KB of a CU's LDS for `microseconds` on `stream` -
+ * what a collective's kernel waiting for a slower peer looks like to the launches of this library that need every CU (no reference counterpart) */
+int imp_debug_hold_cus(int device, int workgroups, int microseconds, void* stream);
+int imp_resident_repaired(imp_ctx* ctx);
+int imp_resident_postmortem(imp_ctx* ctx, int32_t* out, int n);
 /* how many calls on this context met non-finite match scores so far (reported with IMP_E_RANGE, or recovered in the call) */
 int imp_range_events(imp_ctx* ctx);
 /* In-call recovery from IMP_E_RANGE (round 5).  By default the library never waits for the GPU: an operand beyond the fp16 range of the

@@ -207,3 +207,36 @@ def make_reader_records(seed: int = 0, n_pairs: int = 3, desc_dim: int = 32):
                      'img_path1': f'seq{i}/images/a_{i}.jpg', 'img_path2': f'seq{i}/images/b_{i}.jpg',
                      'size1': (480 - 8 * i, 640), 'size2': (360, 500 + 4 * i)})
     return recs
+
+
+class ReplayPose:
+    """The pose step of the hard-set loop fixtures (tests/golden/hard_loops.npz; tools/make_golden.py RecordedPose): answers a call with the answer
+    the deterministic CPU twin gave the imported REFERENCE loop for the same matched coordinates (key = SHA-1 of the two float32 coordinate arrays).
+    A call with other coordinates means the matches handed to the pose step differ from the reference's: there is no recorded answer and the
+    test fails there.  Stateless after construction (the lock-step loops call it from worker threads)."""
+
+    def __init__(self, z, pid, loop):
+        import hashlib
+        self._sha1 = hashlib.sha1
+        pre = f'p{pid}_{loop}_'
+        self.what = f'pair {pid} {loop}'
+        self.memo = {}
+        for j in range(int(z[pre + 'n_pose'])):
+            key = bytes(z[pre + f'pose{j}_key'])
+            if bool(z[pre + f'pose{j}_none']):
+                self.memo[key] = None
+            else:
+                n = int(z[pre + f'pose{j}_n'])
+                mask = np.unpackbits(z[pre + f'pose{j}_mask'])[:n].astype(bool)
+                self.memo[key] = (z[pre + f'pose{j}_E'], z[pre + f'pose{j}_R'], z[pre + f'pose{j}_t'], mask)
+        self.calls = 0
+
+    def __call__(self, kpts0, kpts1, K0=None, K1=None, norm_thresh=1.0, method=None, **kw):
+        h = self._sha1()
+        h.update(np.ascontiguousarray(np.asarray(kpts0, dtype=np.float32)).tobytes())
+        h.update(np.ascontiguousarray(np.asarray(kpts1, dtype=np.float32)).tobytes())
+        key = h.digest()
+        assert key in self.memo, (f'{self.what}: the {len(kpts0)} matches handed to the pose step are not the ones the reference loop handed to it '
+                                  f'(recorded calls: {len(self.memo)})')
+        self.calls += 1
+        return self.memo[key]

@@ -48,8 +48,9 @@ def test_produce_matches_vs_golden(name, precision):
 COND_REPORT = []
 
 
+@pytest.mark.parametrize('fixture', ['conditioning_n1024', 'conditioning_n2048'])
 @pytest.mark.parametrize('precision', ['f16x3', 'f32'])
-def test_parity_under_conditioning(precision):
+def test_parity_under_conditioning(precision, fixture):
     """VERDICT r4 #5a: parity as the network gets worse conditioned, measured against where the REFERENCE stops defining the answer.
     tests/golden/conditioning_n1024.npz (tools/parity_vs_conditioning.py, which imports the reference) holds, for q / k gains 1 ... 5 of
     the trained-style weights at N = 1024 (GM, L = 9, T = 100): the fp64 run of the reference and the deviation of the reference's OWN fp32
@@ -58,8 +59,10 @@ def test_parity_under_conditioning(precision):
     evaluation of the reference itself moves by more than 1e-3 (0 + 0 up to gain 3: strict there);
     scores - within max(1e-4, 2 x the reference's larger fp32 deviation) (up to gain 3 the reference's noise is < 1e-4 and the bar is the
     north star's 1e-4; at gain 4 two fp32 evaluations of the reference differ by 1e-3, at gain 5 by 0.1 - no implementation can be held to
-    1e-4 there).  This measurement replaces the prose justification of the `low_score_flips` tolerance."""
-    spec, z = load_golden('conditioning_n1024')
+    1e-4 there).  This measurement replaces the prose justification of the `low_score_flips` tolerance.
+    Round 6: the same sweep at the HEADLINE size, N = 2048, gains 1 / 2 / 3 (conditioning_n2048.npz) - the 1e-4 margin there is thin
+    (two fp32 CPU evaluations, reference and oracle, differ by 2.4e-4 in mscores0 on gm_l9_t100_n2048_b4) and is now measured, not met by luck."""
+    spec, z = load_golden(fixture)
     cfg = eval_config(**spec['config'])
     pair = synthetic.make_correlated_pair(spec['n'], spec['n'], seed=spec['dseed'])
     data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
@@ -81,7 +84,7 @@ def test_parity_under_conditioning(precision):
         rows.append((g, bad, dms, ref_bad, ref_dms))
         del m
     COND_REPORT.append((precision, rows))
-    print(f'conditioning sweep ({precision}): q/k gain | HIP vs fp64: idx, max|dms| | reference fp32 vs fp64 (worse of 1 / 8 threads): idx, max|dms|')
+    print(f'conditioning sweep at N = {spec["n"]} ({precision}): q/k gain | HIP vs fp64: idx, max|dms| | reference fp32 vs fp64 (worse of 1 / 8 threads): idx, max|dms|')
     for g, bad, dms, rb, rd in rows:
         print(f'  {g:4.1f} | {bad:4d} {dms:9.2e} | {rb:4d} {rd:9.2e}')
     for g, bad, dms, rb, rd in rows:
@@ -656,7 +659,7 @@ def test_fused_layer_time_out_voids_the_call_and_steps_the_context_down():
     from imp_release_amd import _lib
     cfg = eval_config(n_layers=3, sinkhorn_iterations=20)
     sd = synthetic.make_state_dict(cfg, 'GM', seed=8)
-    fake, plain = _two_models('GM', cfg, sd, {'IMP_WF_FUSED_FAKE': '1'}, {'IMP_WF_FUSED': '0'})
+    fake, plain = _two_models('GM', dict(cfg, range_recovery=False), sd, {'IMP_WF_FUSED_FAKE': '1'}, {'IMP_WF_FUSED': '0'})      # (range_recovery=False: the never-waiting library; the default repairs the call - next test)
     pair = synthetic.make_correlated_pair(2048, 2048, seed=5, batch=4)
     data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
     data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
@@ -671,6 +674,46 @@ def test_fused_layer_time_out_voids_the_call_and_steps_the_context_down():
         good = fake.produce_matches(data, p=0.2, only_last=True)
         want = plain.produce_matches(data, p=0.2, only_last=True)
     assert torch.equal(good['indices0'][-1], want['indices0'][-1]) and torch.equal(good['mscores0'][-1], want['mscores0'][-1])
+    assert fake._ensure_ctx().resident_health()[0] == 1
+
+
+def test_fused_layer_time_out_is_repaired_inside_the_same_call():
+    """round 6 (VERDICT r5 #2a): default configuration (in-call recovery on).  The call whose fused layer launch timed out waits for its own
+    work, sees the word, lets the context step down to the two-launch layers and enqueues its work again: the SAME call returns what a
+    context without the fused kernel returns, bit for bit - one-shot call, composed pass (all iterations) and the step API alike."""
+    cfg = eval_config(n_layers=3, sinkhorn_iterations=20)
+    sd = synthetic.make_state_dict(cfg, 'GM', seed=8)
+    pair = synthetic.make_correlated_pair(2048, 2048, seed=5, batch=4)
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
+    for only_last in (True, False):
+        fake, plain = _two_models('GM', cfg, sd, {'IMP_WF_FUSED_FAKE': '1'}, {'IMP_WF_FUSED': '0'})
+        with torch.no_grad():
+            got = fake.produce_matches(data, p=0.2, only_last=only_last)
+            want = plain.produce_matches(data, p=0.2, only_last=only_last)
+        assert len(got['indices0']) == (1 if only_last else 3)
+        for a, b in zip(got['indices0'] + got['mscores0'] + got['scores'], want['indices0'] + want['mscores0'] + want['scores']):
+            assert torch.equal(a, b)
+        ctx = fake._ensure_ctx()
+        assert ctx.resident_health()[0] == 1
+        pm = ctx.resident_postmortem()
+        assert pm is not None and pm['kind'] == 3 and pm['phase'] in (1, 2) and pm['fused_layers_on'] == 1, pm
+        if only_last:
+            assert ctx.resident_repaired() == 1
+            print('post-mortem of the withheld statistics record:', pm)
+    # step API: the layer call itself is repaired
+    fake, plain = _two_models('GM', cfg, sd, {'IMP_WF_FUSED_FAKE': '1'}, {'IMP_WF_FUSED': '0'})
+    outs = []
+    for m in (fake, plain):
+        with torch.no_grad():
+            ctx = m._ensure_ctx(check=True)
+            e0, e1 = m.encode_keypoint(ctx.normalize_keypoints(data['keypoints0'], 640.0, 480.0), ctx.normalize_keypoints(data['keypoints1'], 640.0, 480.0),
+                                       data['scores0'], data['scores1'])
+            d0, d1 = data['descriptors0'].transpose(1, 2) + e0, data['descriptors1'].transpose(1, 2) + e1
+            for li in range(2):
+                d0, d1 = m.forward_one_layer(d0, d1, None, None, li)
+            outs.append((d0.clone(), d1.clone()))
+    assert torch.isfinite(outs[0][0]).all() and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert fake._ensure_ctx().resident_health()[0] == 1
 
 

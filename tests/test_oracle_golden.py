@@ -199,3 +199,30 @@ def test_oracle_under_conditioning(gain):
     bad = int((i != z[f'{tag}_indices0']).sum())
     dms = float(np.abs(ms - z[f'{tag}_mscores0'])[i == z[f'{tag}_indices0']].max(initial=0.0))
     assert bad <= max(noise[0], noise[2]) + noise[6] and dms <= max(1e-4, 2.0 * max(noise[1], noise[3])), (bad, dms, noise)
+
+
+@pytest.mark.parametrize('loop', ['imp', 'eimp'])
+def test_oracle_loops_on_a_hard_set_pair_with_the_recorded_pose(loop):
+    """round 6: the loops on the harder two-view set with a real (recorded) pose step - tests/golden/hard_loops.npz holds the imported reference's
+    trajectory, matches and exit on 24 such pairs (tools/make_golden.py case_hard_loops asserted oracle == reference on all of them); one pair is
+    re-checked here on every CPU run, the GPU suite takes all of them (tests/test_gpu_hard_loops.py)"""
+    from helpers import ReplayPose, eval_config
+    spec, z = load_golden('hard_loops')
+    pid = spec['pairs'][3]
+    model = {'imp': 'DGNNS', 'eimp': 'AdaGMN'}[loop]
+    cfg = eval_config()
+    sd = synthetic.make_state_dict(cfg, model, seed=spec['weights']['seed'], bin_score=spec['weights']['bin_score'], style=spec['weights']['style'])
+    pair = synthetic.make_hard_two_view_pair(seed=spec['seed_base'] + pid)
+    data = {k: torch.from_numpy(pair[k]) for k in ('keypoints0', 'keypoints1', 'scores0', 'scores1', 'descriptors0', 'descriptors1')}
+    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'])
+    data.update({'K0': pair['K0'], 'K1': pair['K1']})
+    trace = []
+    with torch.no_grad():
+        o = orc.matching_iterative(data, orc.MatcherOracle(cfg, sd, model=model), nI=15, match_ratio=0.1, min_kpts=25, estimate_pose=ReplayPose(z, pid, loop),
+                                   uncertainty=loop == 'eimp', with_uncertainty=loop == 'eimp', trace=trace, error_th=1.0)
+    pre = f'p{pid}_{loop}_'
+    assert o['n_iter'] == int(z[pre + 'n_iter']) and np.array_equal(o['indices0'].numpy(), z[pre + 'indices0'])
+    assert np.array_equal(o['keep0'].numpy(), z[pre + 'keep0']) and np.array_equal(o['keep1'].numpy(), z[pre + 'keep1'])
+    for k, (n0, n1) in enumerate(z[pre + 'trajectory']):
+        assert (trace[k]['n0'], trace[k]['n1']) == (int(n0), int(n1)) and np.array_equal(trace[k]['indices0'].numpy(), z[pre + f'it{k}_indices0'])
+    np.testing.assert_allclose(o['mscores0'].numpy(), z[pre + 'mscores0'], atol=2e-5, rtol=0)

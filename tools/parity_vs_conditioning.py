@@ -17,7 +17,7 @@ precisions, that the HIP path disagrees with the fp64 yardstick NO MORE than the
 max(1e-4, 2 x the larger of the reference's two)) - which replaces the prose
 justification of the `low_score_flips` tolerance with a measurement of where the reference stops defining the answer.
 
-    python tools/parity_vs_conditioning.py            # writes the fixture, prints the table
+    python tools/parity_vs_conditioning.py [N]        # writes tests/golden/conditioning_n<N>.npz (default 1024; 2048: gains 1, 2, 3), prints the table
 """
 import json
 import os
@@ -45,8 +45,9 @@ sys.modules['cv2'] = cv2
 from nets.gm import GM                        # noqa: E402  (the reference)
 from imp_release_amd import synthetic         # noqa: E402
 
-GAINS = [1.0, 1.5, 2.0, 2.5, 3.0, 4.0, 5.0]
-N, WSEED, DSEED = 1024, 21, 511
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024          # round 6: `python tools/parity_vs_conditioning.py 2048` = the sweep at the headline size (gains 1 ... 3)
+GAINS = [1.0, 1.5, 2.0, 2.5, 3.0, 4.0, 5.0] if N <= 1024 else [1.0, 2.0, 3.0]
+WSEED, DSEED = 21, 511
 CFG = {'descriptor_dim': 256, 'sinkhorn_iterations': 100, 'match_threshold': 0.2, 'with_sinkhorn': True, 'n_layers': 9,
        'GNN_layers': ['self', 'cross'] * 9, 'ac_fn': 'relu', 'norm_fn': 'in', 'n_min_tokens': 256}
 
@@ -90,7 +91,7 @@ def main():
             'gains': GAINS, 'call': {'p': 0.2, 'only_last': True},
             'ref_noise_columns': ['idx fp32/1t vs fp64', 'dms fp32/1t vs fp64', 'idx fp32/8t vs fp64', 'dms fp32/8t vs fp64', 'idx 1t vs 8t', 'dms 1t vs 8t', 'keypoints whose mscore an fp32 evaluation of the reference moves by > 1e-3']}
     arrays['spec_json'] = np.frombuffer(json.dumps(spec).encode(), dtype=np.uint8)
-    out = os.path.join(ROOT, 'tests', 'golden', 'conditioning_n1024.npz')
+    out = os.path.join(ROOT, 'tests', 'golden', f'conditioning_n{N}.npz')
     np.savez_compressed(out, **arrays)
     print(f'wrote {out} ({os.path.getsize(out) / 1024:.1f} KiB)')
 
