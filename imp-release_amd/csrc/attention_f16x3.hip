@@ -936,10 +936,6 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 }
 
 }  // namespace
-#ifndef IMP_ATTN_W4_DEFAULT
-#define IMP_ATTN_W4_DEFAULT 0     // the one-wave-per-SIMD kernel (attention_f16x3_w4.hip) for the launches it can take
-#endif
-int imp_attn_w4_override = -1;
 int imp_attn_dma_override = -1;      // probes / tests: 0 | 1 forces the staging variant of the ping-pong kernel for the launches that follow (-1: IMP_ATTN_DMA or the default)
 namespace {
 
@@ -1058,7 +1054,5 @@ hipError_t launch_attention_f16x3(const AttnParams& p, int batch, hipStream_t st
     // kernel - another order of summation - beside a large pair than alone.  What a small pair loses (a few microseconds at D = 128 or
     // IMP_KV_IMAGE=0; split-half K / V images always ran here) is the price of results that depend on the pair alone.
     const int nsplit = attention_f16x3_splits(p, batch);
-    static const int w4_env = [] { const char* e = getenv("IMP_ATTN_W4"); return e ? atoi(e) : IMP_ATTN_W4_DEFAULT; }();
-    if ((imp_attn_w4_override >= 0 ? imp_attn_w4_override : w4_env) != 0 && attention_f16x3_w4_ok(p, nsplit)) return launch_attention_f16x3_w4(p, batch, maxq, stream);
     return p.dh == 64 ? launch_pp<64>(p, batch, maxq, nsplit, stream) : launch_pp<32>(p, batch, maxq, nsplit, stream);
 }

@@ -171,11 +171,7 @@ int attention_f16x3_splits(const AttnParams& p, int batch);                     
 size_t attention_f16x3_split_floats(const AttnParams& p, int batch, int nsplit);   // floats of split_ws it needs
 size_t attention_f16x3_split_units(const AttnParams& p, int batch);                // tickets it needs
 hipError_t launch_attention_f32(const AttnParams& p, int batch, hipStream_t stream);
-// split-precision variant (hi/lo halves, 3 f16 MFMAs per fp32 product): attention_f16x3.hip; launches it can take go to the one-wave-per-SIMD kernel of
-// attention_f16x3_w4.hip (bit-identical results)
-bool attention_f16x3_w4_ok(const AttnParams& p, int nsplit);
-hipError_t launch_attention_f16x3_w4(const AttnParams& p, int batch, int maxq, hipStream_t stream);
-extern int imp_attn_w4_override;      // -1: IMP_ATTN_W4 or the default; 0 / 1: tests and probes force the kernel choice
+// split-precision variant (hi/lo halves, 3 f16 MFMAs per fp32 product): attention_f16x3.hip
 hipError_t launch_attention_f16x3(const AttnParams& p, int batch, hipStream_t stream);
 
 // column sums of the probability matrix: colsum[b][side][h][key] = sum_q exp(q.k*scale - lse[q])

@@ -132,20 +132,22 @@ __device__ __forceinline__ void stg1(__amdgpu_buffer_rsrc_t r, int idx, float v,
     __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(v), tag}, r, idx * 8, 0, AUX);
 }
 // poll until all four granules carry `tag`; `dead` (per thread) short-circuits every wait after a time-out
-// phase / it / pair / group say where the waiter stands (set by the kernel before each wait): the first waiter of a launch whose wait times out leaves a
+// the first waiter of a launch whose wait times out leaves a
 // POST-MORTEM record in the mapped host page (imp_kernels.h imp_postmortem_write; read back by imp_resident_postmortem)
-struct Health { int* status; int* host; unsigned launch_tag; int phase, it, pair, group, G, local, B; };
-__device__ __forceinline__ void poll_health(const Health& h, int spins, bool& dead, int idx, unsigned want, unsigned seen) {
+// (kept small: this kernel lives at the register limit - `packed` = pair | group << 6 | G << 14 | placement << 22 | pairs << 24 in ONE scalar register, the
+// phase and the iteration arrive as `where` = phase | iteration << 8 from values the call site has anyway)
+struct Health { int* status; int* host; unsigned launch_tag; unsigned packed; };
+__device__ __forceinline__ void poll_health(const Health& h, int spins, bool& dead, int idx, unsigned want, unsigned seen, int where) {
     if (spins > SPIN_LIMIT) {
         __hip_atomic_store(h.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (h.host) {
-            imp_postmortem_write(h.host, 1, h.launch_tag, h.phase, idx, want, seen, h.it, h.pair, h.group, h.G, h.local, h.B);
+            imp_postmortem_write(h.host, 1, h.launch_tag, where & 255, idx, want, seen, where >> 8, h.packed & 63, (h.packed >> 6) & 255, (h.packed >> 14) & 255, (h.packed >> 22) & 3, h.packed >> 24);
             __hip_atomic_store(h.host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     if (__hip_atomic_load(h.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) dead = true;
 }
-__device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, int q, unsigned tag, const Health& status, bool& dead) {
+__device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, int q, unsigned tag, const Health& status, bool& dead, int where) {
     u32x4 a, c;
     int spins = 0;
     for (;;) {
@@ -156,7 +158,7 @@ __device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, int q, unsigned 
 #if OTR_POLL_SLEEP
         __builtin_amdgcn_s_sleep(OTR_POLL_SLEEP);             // back off: failed polls compete with the stores they wait for
 #endif
-        if ((++spins & 1023) == 0) poll_health(status, spins, dead, q, tag, a[1]);
+        if ((++spins & 1023) == 0) poll_health(status, spins, dead, q, tag, a[1], where);
     }
     return f32x4{__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(c[0]), __uint_as_float(c[2])};
 }
@@ -179,7 +181,7 @@ __device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, int q, unsigned 
 #ifndef OTR_DUAL_POLL
 #define OTR_DUAL_POLL 0        // (measured neutral: 6.09-6.12 vs 6.11-6.14 us per iteration at B = 4, N = 2048 - the waiting dominates, not the second round trip)
 #endif
-__device__ __forceinline__ void ldg4x2(__amdgpu_buffer_rsrc_t r, int q0, int q1, bool two, unsigned tag, const Health& status, bool& dead, f32x4& o0, f32x4& o1) {
+__device__ __forceinline__ void ldg4x2(__amdgpu_buffer_rsrc_t r, int q0, int q1, bool two, unsigned tag, const Health& status, bool& dead, f32x4& o0, f32x4& o1, int where = 0) {
     u32x4 a, c, a2 = {0, tag, 0, tag}, c2 = {0, tag, 0, tag};
     int spins = 0;
     for (;;) {
@@ -195,14 +197,14 @@ __device__ __forceinline__ void ldg4x2(__amdgpu_buffer_rsrc_t r, int q0, int q1,
 #if OTR_POLL_SLEEP
         __builtin_amdgcn_s_sleep(OTR_POLL_SLEEP);
 #endif
-        if ((++spins & 1023) == 0) poll_health(status, spins, dead, q0, tag, a[1]);
+        if ((++spins & 1023) == 0) poll_health(status, spins, dead, q0, tag, a[1], where);
     }
     o0 = f32x4{__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(c[0]), __uint_as_float(c[2])};
     o1 = f32x4{__uint_as_float(a2[0]), __uint_as_float(a2[2]), __uint_as_float(c2[0]), __uint_as_float(c2[2])};
 }
 
 // the same chunk of TWO exchange vectors, both loads in flight per poll round (OTR_MERGE: a half's own sums from its L2, the other half's across the fabric)
-__device__ __forceinline__ void ldg4_pair(__amdgpu_buffer_rsrc_t r0, __amdgpu_buffer_rsrc_t r1, int q, unsigned tag, const Health& status, bool& dead, f32x4& o0, f32x4& o1) {
+__device__ __forceinline__ void ldg4_pair(__amdgpu_buffer_rsrc_t r0, __amdgpu_buffer_rsrc_t r1, int q, unsigned tag, const Health& status, bool& dead, f32x4& o0, f32x4& o1, int where = 0) {
     u32x4 a, c, a2, c2;
     int spins = 0;
     for (;;) {
@@ -216,21 +218,21 @@ __device__ __forceinline__ void ldg4_pair(__amdgpu_buffer_rsrc_t r0, __amdgpu_bu
 #if OTR_POLL_SLEEP
         __builtin_amdgcn_s_sleep(OTR_POLL_SLEEP);
 #endif
-        if ((++spins & 1023) == 0) poll_health(status, spins, dead, q, tag, a[1]);
+        if ((++spins & 1023) == 0) poll_health(status, spins, dead, q, tag, a[1], where);
     }
     o0 = f32x4{__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(c[0]), __uint_as_float(c[2])};
     o1 = f32x4{__uint_as_float(a2[0]), __uint_as_float(a2[2]), __uint_as_float(c2[0]), __uint_as_float(c2[2])};
 }
 
 // one granule
-__device__ __forceinline__ float ldg1(__amdgpu_buffer_rsrc_t r, int idx, unsigned tag, const Health& status, bool& dead) {
+__device__ __forceinline__ float ldg1(__amdgpu_buffer_rsrc_t r, int idx, unsigned tag, const Health& status, bool& dead, int where) {
     u32x2 a;
     int spins = 0;
     for (;;) {
         asm volatile("" ::: "memory");
         a = __builtin_amdgcn_raw_buffer_load_b64(r, idx * 8, 0, AUX_POLL);
         if (a[1] == tag || dead) break;
-        if ((++spins & 1023) == 0) poll_health(status, spins, dead, idx, tag, a[1]);
+        if ((++spins & 1023) == 0) poll_health(status, spins, dead, idx, tag, a[1], where);
     }
     return __uint_as_float(a[0]);
 }
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             s_place[1] = (int)(ticket - ticket_base);
         }
         __syncthreads();
-        const int xcc = s_place[0], slot = s_place[1];
+        const int xcc = __builtin_amdgcn_readfirstlane(s_place[0]), slot = __builtin_amdgcn_readfirstlane(s_place[1]);      // (workgroup-uniform: scalar registers - pair, group and everything derived from them)
         const int cap = LOCAL == 1 ? G * ((p.B + 7) >> 3) : (G >> 1);
         if (slot < 0 || slot >= cap) {             // this XCC received more workgroups than its share: the launch is void
             if (tid == 0) {
@@ -331,8 +333,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
     if (n0 <= 0 || n1 <= 0) { leave(); return; }       // retired pair: all its workgroups leave here, before any exchange
     const int r0 = g * ROWS + wave * RPW;
     bool dead = false;
-    // (the post-mortem fields are wave-uniform: pinned to scalar registers - b and g come out of LDS and would otherwise hold vector registers to the kernel's end)
-    Health health{p.status, p.host_status, tag_base, 0, -1, __builtin_amdgcn_readfirstlane(b), __builtin_amdgcn_readfirstlane(g), G, LOCAL, p.B};
+    const Health health{p.status, p.host_status, tag_base, (unsigned)__builtin_amdgcn_readfirstlane((b & 63) | ((g & 255) << 6) | ((G & 255) << 14) | (LOCAL << 22) | (p.B << 24))};
 
     // exchange buffers hold granules: 8 bytes per float
     const int gl = g - half * H;
@@ -389,7 +390,12 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
     const float c0 = 1.0f / (float)(n1 + 1);   // every entry of the dustbin row: softmax of n1 + 1 equal logits
 
     // start vectors (nets/layers.py:29-30): u = 1, v = 1
-    for (int j = tid; j < LDX; j += 512) vs[j] = (j < n1 || j == DCOL) ? 1.f : 0.f;
+    // (uniform trip counts for the thread-strided loops outside the iteration loop: hipcc of ROCm 7.2 put register spills into the exit block of a loop with a
+    // divergent trip count BEFORE the instruction that restores the execution mask - stores with no lane enabled; found as row arg-maxima that read back zero)
+    for (int j0 = 0; j0 < LDX; j0 += 512) {
+        const int j = j0 + tid;
+        if (j < LDX) vs[j] = (j < n1 || j == DCOL) ? 1.f : 0.f;
+    }
     float vsum = (float)(n1 + 1);              // sum of v over the n1 + 1 real columns
     float u[RPW];
 #pragma unroll
@@ -432,9 +438,17 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
 #pragma unroll
         for (int k = 0; k < RPW; ++k) inv[k] = 1.f / (fmaf(Pd[k], vd, acc[k]) + OT_EPS);      // real rows have marginal 1 (nets/layers.py:32,41)
 #pragma unroll
-        for (int k = 0; k < RPW; ++k) {
-            u[k] = (r0 + k < n0) ? inv[k] : 0.f;
-            pdpart = fmaf(Pd[k], u[k], pdpart);
+        for (int k = 0; k < RPW; ++k) u[k] = (r0 + k < n0) ? inv[k] : 0.f;
+        {   // the dustbin column's partial like every other column's: 4-row leaves, RPW = 8 adds its two leaves (CANONICAL COLUMN SUMS below)
+            constexpr int LEAFD = RPW < 4 ? RPW : 4;
+#pragma unroll
+            for (int k = 0; k < LEAFD; ++k) pdpart = fmaf(Pd[k], u[k], pdpart);
+            if constexpr (RPW == 8) {
+                float pd2 = 0.f;
+#pragma unroll
+                for (int k = 4; k < 8; ++k) pd2 = fmaf(Pd[k], u[k], pd2);
+                pdpart += pd2;
+            }
         }
 #else
 #pragma unroll
@@ -508,7 +522,6 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         __syncthreads();                           // everyone is done with the wave partials in `red`
         OTR_CLK(1)
         // ---- C: this workgroup's slice of columns over the G partial vectors -------------------------------------
-        health.it = it; health.phase = 1;        // (post-mortem: waiting for the partial vectors)
         {
             f32x4* stage = reinterpret_cast<f32x4*>(red);             // [H][cq]
 #if OTR_DUAL_POLL
@@ -519,7 +532,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
                 const bool v1 = q < NQ, v2 = idx2 < cq * H && q2 < NQ;
                 f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
                 if (v1) ldg4x2(rs_part, w * NQ + q, w2 * NQ + q2, v2, tag_p, health, dead, o0, o1);
-                else if (v2) o1 = ldg4(rs_part, w2 * NQ + q2, tag_p, health, dead);
+                else if (v2) o1 = ldg4(rs_part, w2 * NQ + q2, tag_p, health, dead, 1 | (it << 8));
                 stage[idx] = o0;
                 if (idx2 < cq * H) stage[idx2] = o1;
             }
@@ -527,7 +540,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             for (int idx = tid; idx < cq * H; idx += 512) {
                 const int w = idx / cq, qq = idx - w * cq;
                 const int q = gl * cq + qq;
-                stage[idx] = q < NQ ? ldg4(rs_part, w * NQ + q, tag_p, health, dead) : f32x4{0.f, 0.f, 0.f, 0.f};
+                stage[idx] = q < NQ ? ldg4(rs_part, w * NQ + q, tag_p, health, dead, 1 | (it << 8)) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #endif
             __syncthreads();
@@ -578,9 +591,8 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
                     }
                 } else if (xi < LDX) {
                     if (LOCAL == 2) {                                 // swap the half sums across the fabric; both halves add them in the same order
-                        health.phase = 2;
                         stg1<AUX_SC1>(rs_h_own, xi, s, tag_h);
-                        const float o = ldg1(rs_h_oth, xi, tag_h, health, dead);
+                        const float o = ldg1(rs_h_oth, xi, tag_h, health, dead, 2 | (it << 8));
                         s = half == 0 ? s + o : o + s;
                     }
                     const bool dust = xi == DCOL;
@@ -593,7 +605,6 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         }
         OTR_CLK(3)
         // ---- D: everybody reads v -----------------------------------------------------------------------------------
-        health.phase = 3;
 #if OTR_MERGE
         if (LOCAL == 2) {                          // ... reads both halves' sums and forms v: the arithmetic of the owners' path above, per column
             for (int q = tid; q < NQ; q += 512) {
@@ -627,7 +638,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             // the pair's own n1 alone; inner chunk q belongs to thread q mod 512 in every class, and chunks past n1 are zeros)
             float vpart = 0.f;
             for (int q = tid; q < NQ; q += 512) {
-                const f32x4 o = ldg4(rs_v, q, tag_v, health, dead);
+                const f32x4 o = ldg4(rs_v, q, tag_v, health, dead, 3 | (it << 8));
                 *reinterpret_cast<f32x4*>(vs + 4 * q) = o;
                 if (q != NQ - 1) vpart += (o[0] + o[1]) + (o[2] + o[3]);
             }
@@ -635,7 +646,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             if (lane == 0) s_vsw[wave] = vpart;
         }
 #else
-        for (int q = tid; q < NQ; q += 512) *reinterpret_cast<f32x4*>(vs + 4 * q) = ldg4(rs_v, q, tag_v, health, dead);
+        for (int q = tid; q < NQ; q += 512) *reinterpret_cast<f32x4*>(vs + 4 * q) = ldg4(rs_v, q, tag_v, health, dead, 3 | (it << 8));
 #endif
 #endif
         __syncthreads();
@@ -659,12 +670,16 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         for (int i = 0; i < 6; ++i) p.prof[i] = prof_acc[i];
 
     // ---- outputs ----------------------------------------------------------------------------------------------------
+    // (the row base is laundered through an empty asm: every output address is then computed HERE, after the iteration loop - the compiler otherwise forms
+    // them before the loop and, at this kernel's register limit, parks them in scratch across it; see the note on spills at the start vectors)
+    int r0o = r0;
+    asm volatile("" : "+v"(r0o));
     const float vd = vs[DCOL];
     if (p.u) {
         if (lane == 0)
 #pragma unroll
             for (int k = 0; k < RPW; ++k)
-                if (r0 + k < n0) p.u[(size_t)b * p.ldu + r0 + k] = u[k];
+                if (r0o + k < n0) p.u[(size_t)b * p.ldu + r0o + k] = u[k];
         if (g == 0) {
             if (tid == 0) p.u[(size_t)b * p.ldu + n0] = u_last;
             for (int j = tid; j < n1; j += 512) p.v[(size_t)b * p.ldv + j] = vs[j];
@@ -676,22 +691,24 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
     __syncthreads();                                   // `red` is free again
 #pragma unroll
     for (int k = 0; k < RPW; ++k) {
-        const int r = r0 + k;
+        const int r = r0o + k;
         if (r >= n0) continue;                         // wave-uniform
         float best = -INFINITY;
-        int bi = 0x7fffffff;
+        int code = 4 * NCH;                            // which of the lane's 4 NCH scores is its first maximum: 4 c + e (an inline constant per candidate - the 32
+                                                       // column indices themselves cost registers this kernel does not have: round 6 found them spilled)
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const f32x4 x = *reinterpret_cast<const f32x4*>(vs + 4 * (lane + 64 * c));
+            const int rem = n1 - 4 * (lane + 64 * c);  // columns of this chunk that exist
             f32x4 s;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 s[e] = (P[k][c][e] * u[k]) * x[e];     // (p * u) * v as nets/layers.py:34
-                const int j = 4 * (lane + 64 * c) + e;
-                if (j < n1 && s[e] > best) { best = s[e]; bi = j; }      // ascending j inside the lane: first wins
+                if (rem > e && s[e] > best) { best = s[e]; code = 4 * c + e; }      // ascending j inside the lane: first wins
             }
             if (p.scores) *reinterpret_cast<f32x4*>(rowbuf + 4 * (lane + 64 * c)) = s;
         }
+        int bi = code == 4 * NCH ? 0x7fffffff : 4 * (lane + 64 * (code >> 2)) + (code & 3);
         if (want_max) {
             wave_argmax(best, bi);
             if (lane == 0) { p.max0[(size_t)b * ld0 + r] = best; p.arg0[(size_t)b * ld0 + r] = bi; }
@@ -738,7 +755,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float sv = (P[k][c][e] * u[k]) * x[e];
-                            if (r0 + k < n0 && sv > cb[e]) { cb[e] = sv; ci[e] = r0 + k; }
+                            if (r0o + k < n0 && sv > cb[e]) { cb[e] = sv; ci[e] = r0o + k; }
                         }
                     *reinterpret_cast<f32x4*>(mv + 4 * (lane + 64 * c)) = cb;
 #pragma unroll
@@ -748,7 +765,6 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             __syncthreads();
         }
         const unsigned tag_m = tag_base + 3u * p.T + 1u;
-        health.phase = 4; health.it = p.T;
         const __amdgpu_buffer_rsrc_t rs_mx = make_rsrc(p.xmax + (size_t)b * G * 4 * LDX, (unsigned)((size_t)G * 2 * LDX * 8));
         for (int q = tid; q < DCOL / 4; q += 512) {
             stg4<MX_AUX>(rs_mx, g * 2 * NQ + q, *reinterpret_cast<const f32x4*>(mv + 4 * q), tag_m);
@@ -761,7 +777,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             const int which = idx / (ncq * G), rem = idx - which * ncq * G;
             const int w = rem / ncq, qq = rem - w * ncq;
             const int q = g * ncq + qq;
-            stage[idx] = q < DCOL / 4 ? ldg4(rs_mx, w * 2 * NQ + which * NQ + q, tag_m, health, dead) : f32x4{0.f, 0.f, 0.f, 0.f};
+            stage[idx] = q < DCOL / 4 ? ldg4(rs_mx, w * 2 * NQ + which * NQ + q, tag_m, health, dead, 4 | (p.T << 8)) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();
         for (int cl = tid; cl < 4 * ncq; cl += 512) {

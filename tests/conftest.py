@@ -54,3 +54,7 @@ def pytest_terminal_summary(terminalreporter):
                                     f'score tolerance, {cut} keypoints swapped with an equally scored one at the cut; everything else identical')
         for what, _, _ in helpers.SP_MOVED:
             terminalreporter.write_line(f'  {what}')
+    if getattr(helpers, 'HARD_SET', None):
+        terminalreporter.write_line('harder two-view set (tests/golden/hard_loops.npz, loops vs the imported reference):')
+        for line in helpers.HARD_SET:
+            terminalreporter.write_line('  ' + line)

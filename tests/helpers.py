@@ -209,6 +209,9 @@ def make_reader_records(seed: int = 0, n_pairs: int = 3, desc_dim: int = 32):
     return recs
 
 
+HARD_SET = []      # summary lines of tests/test_gpu_hard_loops.py (conftest prints them at the end of the run)
+
+
 class ReplayPose:
     """The pose step of the hard-set loop fixtures (tests/golden/hard_loops.npz; tools/make_golden.py RecordedPose): answers a call with the answer
     the deterministic CPU twin gave the imported REFERENCE loop for the same matched coordinates (key = SHA-1 of the two float32 coordinate arrays).
@@ -230,13 +233,19 @@ class ReplayPose:
                 mask = np.unpackbits(z[pre + f'pose{j}_mask'])[:n].astype(bool)
                 self.memo[key] = (z[pre + f'pose{j}_E'], z[pre + f'pose{j}_R'], z[pre + f'pose{j}_t'], mask)
         self.calls = 0
+        self.off_record = 0      # calls with matches the reference loop never made
 
     def __call__(self, kpts0, kpts1, K0=None, K1=None, norm_thresh=1.0, method=None, **kw):
         h = self._sha1()
         h.update(np.ascontiguousarray(np.asarray(kpts0, dtype=np.float32)).tobytes())
         h.update(np.ascontiguousarray(np.asarray(kpts1, dtype=np.float32)).tobytes())
         key = h.digest()
-        assert key in self.memo, (f'{self.what}: the {len(kpts0)} matches handed to the pose step are not the ones the reference loop handed to it '
-                                  f'(recorded calls: {len(self.memo)})')
         self.calls += 1
+        if key not in self.memo:
+            # the loop under test has left the reference's trajectory (the test decides whether it was allowed to - a pool decision inside fp32
+            # noise of its threshold): it goes on with what the generator's pose step (tools/make_golden.py RecordedPose: the CPU twin,
+            # 1024 samples, seed 1) answers for THESE matches, so that the pair - and a lock-step group around it - still runs to its end
+            from oracle import pose_oracle
+            self.off_record += 1
+            return pose_oracle.estimate_pose(np.asarray(kpts0, dtype=np.float32), np.asarray(kpts1, dtype=np.float32), K0, K1, norm_thresh, iterations=1024, seed=1)
         return self.memo[key]

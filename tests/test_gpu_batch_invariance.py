@@ -154,7 +154,7 @@ def test_sinkhorn_decompositions_agree_bit_for_bit():
         d1 = torch.nn.functional.normalize(torch.randn(1, n1, 256, generator=g), dim=-1).to(DEV) * 3
         with torch.no_grad():
             ref = ctx.compute_score(ctx.compute_distance(0, d0, d1), 1.0, 50, True)[0]
-            for pad0, pad1, B in ((2048, 2048, 4), (n0 + 7, n1 + 300, 3), (n0, n1, 2), (n0, n1, 9)):
+            for pad0, pad1, B in ((2048, 2048, 4), (n0 + 7, min(n1 + 300, 2048), 3), (n0, n1, 2), (n0, n1, 9)):      # (padded n1 > 2048: the wide shapes, planned for one pair at its own sizes only)
                 if B == 9 and (n0 > 1024 or n1 > 1024):
                     continue
                 D0 = torch.randn(B, pad0, 256, device=DEV); D1 = torch.randn(B, pad1, 256, device=DEV)

@@ -287,6 +287,59 @@ class RecordedPose:
         return self.memo[k]
 
 
+EDGE = 4e-6          # relative distance to a pool threshold below which a keypoint is recorded as "near the edge" (the tests use their own, smaller, bound)
+
+
+def pool_margins(pred_score, prob00, prob01, prob11, prob10, mscore_th, uncertainty_ratio=1.0):
+    """How far the reference's pool (nets/adgm.py:552-605) stands from deciding otherwise, from the reference's own quantities (the same torch calls).
+    Per keypoint of side s: the smallest RELATIVE distance of (a) its score mass to the threshold, (b) / (c) its received self / cross attention to the
+    lower median of the confident keypoints (the median element itself apart).  -> per side (ids, margins) of the keypoints closer than EDGE, in the
+    index space of this iteration, and the six smallest margins a0 b0 c0 a1 b1 c1.  A margin inside fp32 summation noise means the reference's kept
+    set is one of several that an fp32 evaluation of the same formulas can produce (another order of the same sums moves the keypoint across)."""
+    out, sides = [], []
+    thr = float(torch.tensor(mscore_th * uncertainty_ratio, dtype=torch.float32))
+    for side, (ps, pc, dim) in enumerate(((prob00, prob01, -1), (prob11, prob10, 1))):
+        mass = torch.sum(pred_score[:, :-1, :-1], dim=dim)[0]
+        elem = (mass.double() - thr).abs() / abs(thr)
+        out.append(float(elem.min()))
+        conf = torch.where(mass >= thr)[0]
+        for prob in (ps, pc):
+            sp = torch.sum(prob, dim=1).sum(dim=1)
+            v = (sp / torch.sum(sp, dim=1, keepdim=True))[0]
+            if conf.numel() == 0:
+                out.append(float('inf'))
+                continue
+            md, at = torch.median(v[conf], dim=0)
+            d = ((v.double() - float(md)).abs() / float(md))
+            d[conf[at]] = float('inf')
+            out.append(float(d.min()))
+            elem = torch.minimum(elem, d)
+        ids = torch.where(elem < EDGE)[0]
+        sides.append((ids.numpy().astype(np.int32), elem[ids].numpy().astype(np.float32)))
+    return np.array(out), sides
+
+
+def match_margins(scores, p):
+    """the same for compute_matches (nets/gm.py:305-320): smallest relative distance of a mutual maximum to the threshold p, and the smallest relative
+    gap between the two largest scores of a row / a column that holds a match (an arg-max that another fp32 evaluation may move)"""
+    inner = scores[0, :-1, :-1].double()
+    r2, c2 = inner.topk(2, dim=1).values, inner.topk(2, dim=0).values
+    i0 = inner.argmax(1); i1 = inner.argmax(0)
+    mutual = i1[i0] == torch.arange(inner.shape[0])
+    mv = r2[mutual, 0]
+    a = float(((mv - p).abs() / p).min()) if mv.numel() else float('inf')
+    valid = mutual & (r2[:, 0] > p)
+    if valid.any():
+        gr = ((r2[valid, 0] - r2[valid, 1]) / r2[valid, 0]).min()
+        cols = i0[valid]
+        gc = ((c2[0, cols] - c2[1, cols]) / c2[0, cols]).min()
+        g = float(min(gr, gc))
+    else:
+        g = float('inf')
+    return np.array([a, g])
+
+
+
 def hard_pair_data(pid):
     pair = synthetic.make_hard_two_view_pair(seed=1000 + pid)
     data = {k: torch.from_numpy(pair[k]) for k in ('keypoints0', 'keypoints1', 'scores0', 'scores1', 'descriptors0', 'descriptors1')}
@@ -333,12 +386,24 @@ def case_hard_loops(name, pids, want=12):
             trace = []
             orig_cm = ref.compute_matches
 
-            def rec_cm(scores, p=0.2, _t=trace, _o=orig_cm):
+            match_marg, pool_marg = [], {}
+
+            def rec_cm(scores, p=0.2, _t=trace, _o=orig_cm, _mm=match_marg):
                 out = _o(scores=scores, p=p)
                 _t.append((scores.shape[1] - 1, scores.shape[2] - 1, out[0][0].clone(), out[2][0].clone()))
+                _mm.append(match_margins(scores, p))
                 return out
 
             ref.compute_matches = rec_cm
+            if unc:
+                orig_pool = ref.pool
+
+                def rec_pool(pred_score, prob00, prob01, prob11, prob10, mscore_th=0.1, uncertainty_ratio=1.0, _t=trace, _o=orig_pool, _pm=pool_marg):
+                    _pm[len(_t) - 1] = pool_margins(pred_score, prob00, prob01, prob11, prob10, mscore_th, uncertainty_ratio)
+                    return _o(pred_score=pred_score, prob00=prob00, prob01=prob01, prob11=prob11, prob10=prob10, mscore_th=mscore_th,
+                              uncertainty_ratio=uncertainty_ratio)
+
+                ref.pool = rec_pool
             n_before = len(pose.log)
             with torch.no_grad():
                 if unc:
@@ -353,6 +418,8 @@ def case_hard_loops(name, pids, want=12):
                 o = orc.matching_iterative(data, oracle, nI=15, match_ratio=0.1, min_kpts=25, estimate_pose=pose, uncertainty=unc, with_uncertainty=unc,
                                            trace=otrace, error_th=1.0, method=38)
             ref.compute_matches = orig_cm
+            if unc:
+                ref.pool = orig_pool
             exited = R is not None
             scored = trace if exited else trace[:-1]
             ok = nit == o['n_iter'] and exited == (o['R'] is not None) and len(otrace) == len(scored) and len(pose.order) == n_mid
@@ -374,6 +441,12 @@ def case_hard_loops(name, pids, want=12):
                 a[pre + f'it{k}_mscores0'] = tm.numpy()
                 a[pre + f'it{k}_keep0'] = otrace[k]['keep0'].numpy().astype(np.int32)
                 a[pre + f'it{k}_keep1'] = otrace[k]['keep1'].numpy().astype(np.int32)
+                a[pre + f'it{k}_match_margin'] = match_marg[k]
+                if k in pool_marg:
+                    a[pre + f'it{k}_pool_margin'], near = pool_marg[k]
+                    for sd in (0, 1):      # the keypoints near an edge of THIS iteration's pool, as ids of the pair's original keypoints
+                        a[pre + f'it{k}_edge{sd}'] = otrace[k][f'keep{sd}'].numpy().astype(np.int32)[near[sd][0]]
+                        a[pre + f'it{k}_edge{sd}_margin'] = near[sd][1]
             a[pre + 'max_dms_oracle'] = np.array(float(np.abs(np.asarray(m0) - o['mscores0'].numpy()).max()))
             a[pre + 'n_pose'] = np.array(len(ref_calls))
             for j, kk in enumerate(ref_calls):
@@ -392,6 +465,8 @@ def case_hard_loops(name, pids, want=12):
             arrays.update(per_pair)
             print(f'[hard] pair {pid} ({n0} x {n1}): kept  imp n_iter={int(per_pair[f"p{pid}_imp_n_iter"])} eimp n_iter={int(per_pair[f"p{pid}_eimp_n_iter"])} '
                   f'eimp traj={per_pair[f"p{pid}_eimp_trajectory"].tolist()}  ({time.time() - t0:.0f} s)', flush=True)
+            for key in sorted(k for k in per_pair if k.endswith('_pool_margin')):
+                print(f'        {key}: ' + ' '.join(f'{v:.2e}' for v in per_pair[key]) + '   match ' + ' '.join(f'{v:.2e}' for v in per_pair[key.replace('_pool_margin', '_match_margin')]), flush=True)
         else:
             skipped.append(pid)
             print(f'[hard] pair {pid} ({n0} x {n1}): SKIPPED - reference and oracle (two fp32 evaluations) disagree in the {why} loop  ({time.time() - t0:.0f} s)', flush=True)

@@ -20,6 +20,7 @@
 // test_one_wave_per_simd_attention_kernel_is_bit_identical_to_the_ping_pong_kernel).
 #include "imp_kernels.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -45,7 +46,20 @@ __device__ __forceinline__ int xcd_remap(int lin, int total) {
     return base + idx;
 }
 #define W4_SB() __builtin_amdgcn_sched_barrier(0)
-#define W4_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+// The MFMAs are written as inline asm with REGISTER-CLASS constraints: one wave per SIMD owns 256 architectural + 256 accumulator registers, and only
+// the former can be VALU operands.  Left to the allocator (builtin MFMAs) the logits landed in accumulator registers and every exp2 / split paid a
+// v_accvgpr_read / _write (1 900 such moves in the loop body of the first build).  Here: the logits / probabilities S (VALU reads and writes them) and the
+// P fragments (VALU writes them) are VGPRs; O (touched by the VALU only on the slow path and in the epilogue), Q and the K / V fragments (ds_read can
+// target accumulator registers directly) are AGPRs.  C and D of an MFMA share one class bit (ACC_CD), so S chains start from a VGPR pre-set to
+// -m_ref (no separate constant C operand).  Hazards: every consumer of an MFMA result sits >= 4 independent MFMAs (128 cycles) behind it or behind
+// an explicit drain (w4_drain).
+__device__ __forceinline__ void mfma_s(f32x16& acc, const f16x8& kfrag, const f16x8& q) {          // S += K . Q^T : acc VGPR, operands AGPR
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(kfrag), "a"(q));
+}
+__device__ __forceinline__ void mfma_o(f32x16& acc, const f16x8& vfrag, const f16x8& pf) {         // O += V^T . P^T : acc AGPR, V fragment AGPR, P fragment VGPR
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "a"(vfrag), "v"(pf));
+}
+__device__ __forceinline__ void w4_drain() { asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory"); }     // the last MFMAs of a block have written back
 
 __global__ __launch_bounds__(NT, 1) void attn_f16x3_w4_kernel(const AttnParams p, int qtiles, int total_blocks) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -125,17 +139,20 @@ __global__ __launch_bounds__(NT, 1) void attn_f16x3_w4_kernel(const AttnParams p
     f32x16 sA[2][2], sB[2][2];             // [qb][key block of 32]: logits of the tile being accumulated / probabilities of the tile being finished
     f16x8 qh[2][KS], ql[2][KS];
     f16x8 ph[2][2][2], pl[2][2][2];        // [qb][jb][s2]: B operands of O^T += V^T . P^T
-    f32x16 cneg[2];                        // -m_ref in all 16 registers: the C operand of the first MFMA of each S chain
     float m_ref[2] = {0.f, 0.f}, l_run[2] = {0.f, 0.f};
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int d = 0; d < DT; ++d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[qb][d][r] = 0.f;
+    // a logits buffer starts a tile at -m_ref (the accumulators then deliver log2-domain logits relative to the reference: P = exp2(acc))
+    auto init_s = [&](f32x16 (&sb)[2][2], int qb) __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cneg[qb][r] = 0.f;
-    }
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sb[qb][jb][r] = -m_ref[qb];
+    };
 
     load_tile(0);
     // (Q split: the ping-pong kernel's, per 32-query block)
@@ -150,6 +167,7 @@ __global__ __launch_bounds__(NT, 1) void attn_f16x3_w4_kernel(const AttnParams p
             for (int i = 0; i < 4; ++i) { unsigned u, v; imp_split2(x[2 * i], x[2 * i + 1], u, v); hh[i] = u; ll[i] = v; }
             qh[qb][s] = __builtin_bit_cast(f16x8, hh);
             ql[qb][s] = __builtin_bit_cast(f16x8, ll);
+            asm volatile("" : "+a"(qh[qb][s]), "+a"(ql[qb][s]));        // pinned to accumulator-register tuples once (else every use copies the fragment into a fresh tuple)
         }
     store_tile(0);
     if (nt > 1) { load_tile(1); store_tile(1); }
@@ -171,7 +189,7 @@ __global__ __launch_bounds__(NT, 1) void attn_f16x3_w4_kernel(const AttnParams p
     };
     f16x8 fr[2][4];                                   // fragment double buffer
 
-    // ---- S(slot)^T = K . Q^T for the blocks in `mask` (bit qb) into s[qb][jb]; `fill(gap)` is dealt one call per MFMA gap (gap = 12 s + i)
+    // ---- S(slot)^T += K . Q^T for the blocks in `mask` (bit qb) into s[qb][jb], which the caller has pre-set to -m_ref; `fill(gap)` is dealt one call per MFMA gap (gap = 12 s + i)
     auto qk_block = [&](int slot, f32x16 (&s)[2][2], int mask, auto&& fill) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) read_k1(slot, 0, i, fr[0][i]);
@@ -190,10 +208,7 @@ __global__ __launch_bounds__(NT, 1) void attn_f16x3_w4_kernel(const AttnParams p
 #pragma unroll
                     for (int jb = 0; jb < 2; ++jb) {
                         if (mask & (1 << qb)) {
-                            const f16x8& a = prod == 0 ? f[2 + jb] : f[jb];
-                            const f16x8& bq = prod == 1 ? ql[qb][ks] : qh[qb][ks];
-                            if (prod == 0 && ks == 0) s[qb][jb] = W4_MFMA(a, bq, cneg[qb]);
-                            else s[qb][jb] = W4_MFMA(a, bq, s[qb][jb]);
+                            mfma_s(s[qb][jb], prod == 0 ? f[2 + jb] : f[jb], prod == 1 ? ql[qb][ks] : qh[qb][ks]);
                             W4_SB();
                         }
                         const int g4 = prod * 4 + qb * 2 + jb;
@@ -221,9 +236,7 @@ __global__ __launch_bounds__(NT, 1) void attn_f16x3_w4_kernel(const AttnParams p
                 for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
                     for (int d = 0; d < DT; ++d) {
-                        const f16x8& a = prod == 0 ? f[DT + d] : f[d];
-                        const f16x8& bp = prod == 1 ? pl[qb][jb][s2] : ph[qb][jb][s2];
-                        oacc[qb][d] = W4_MFMA(a, bp, oacc[qb][d]);
+                        mfma_o(oacc[qb][d], prod == 0 ? f[DT + d] : f[d], prod == 1 ? pl[qb][jb][s2] : ph[qb][jb][s2]);
                         W4_SB();
                         const int g4 = prod * 4 + qb * 2 + d;
                         if (g4 < 4) { rd((g4 + 2) & 3); W4_SB(); }
@@ -246,10 +259,11 @@ __global__ __launch_bounds__(NT, 1) void attn_f16x3_w4_kernel(const AttnParams p
     };
     // hi / lo split of two finished probabilities into the P fragments
     u32x4 sph[2][2][2], spl[2][2][2];
-    auto split_pair = [&](const f32x16 (&s)[2][2], int qb, int i) __attribute__((always_inline)) {
+    auto split_pair = [&](f32x16 (&s)[2][2], int qb, int i) __attribute__((always_inline)) {
         const int jb = i >> 3, s2 = (i >> 2) & 1, k = i & 3, r = 8 * s2 + 2 * k;
         unsigned hi, lo;
         imp_split2(s[qb][jb][r], s[qb][jb][r + 1], hi, lo);
+        s[qb][jb][r] = -m_ref[qb]; s[qb][jb][r + 1] = -m_ref[qb];            // this buffer's next tile (t + 2) accumulates from the reference
         sph[qb][jb][s2][k] = hi; spl[qb][jb][s2][k] = lo;
         if (k == 3) {
             ph[qb][jb][s2] = __builtin_bit_cast(f16x8, sph[qb][jb][s2]);
@@ -272,7 +286,7 @@ __global__ __launch_bounds__(NT, 1) void attn_f16x3_w4_kernel(const AttnParams p
     };
     // the slow path of one block on INTACT logits (relative to the current reference): exact tile maximum, reference raised, O and l rescaled,
     // probabilities relative to the new reference in place; returns whether the block still waits for its first unmasked key
-    auto slow_path = [&](f32x16 (&s)[2][2], int qb) __attribute__((always_inline)) -> bool {
+    auto slow_path = [&](f32x16 (&s)[2][2], f32x16 (&other)[2][2], int qb) __attribute__((always_inline)) -> bool {
         float tmax = -INFINITY;
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
@@ -283,8 +297,6 @@ __global__ __launch_bounds__(NT, 1) void attn_f16x3_w4_kernel(const AttnParams p
         const float delta = (tmax == -INFINITY) ? 0.f : (lq > 0.f ? fmaxf(tmax, 0.f) : tmax);
         const float alpha = lq > 0.f ? fast_exp2(-delta) : 0.f;
         m_ref[qb] += delta;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) cneg[qb][r] = -m_ref[qb];
         l_run[qb] *= alpha;
 #pragma unroll
         for (int d = 0; d < DT; ++d)
@@ -300,20 +312,23 @@ __global__ __launch_bounds__(NT, 1) void attn_f16x3_w4_kernel(const AttnParams p
                 ls += v;
             }
         lsum[qb] = ls;
+        init_s(other, qb);                                    // the buffer of the next tile was pre-set to the OLD reference
         return __any(tmax == -INFINITY && !(lq > 0.f)) != 0;
     };
 
     // ---- tile 0: plain (every block takes the slow path on its first tile)
     const bool partial_last = nt * KT > nk;
     bool need_slow[2];
+    init_s(sA, 0); init_s(sA, 1);
     qk_block(0, sA, 3, nofill);
+    w4_drain();
     if (nt == 1 && partial_last) add_bias(sA, 0);
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) need_slow[qb] = slow_path(sA, qb);
+    for (int qb = 0; qb < 2; ++qb) need_slow[qb] = slow_path(sA, sB, qb);
 
     // one iteration: `cur` holds the probabilities of tile t (finished but for the split), `nxt` receives the logits of tile t + 1
-    auto iteration = [&](int t, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2]) __attribute__((always_inline)) {
-        if (t > 0) {
+    auto iteration = [&](auto first, int t, f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2]) __attribute__((always_inline)) {
+        if constexpr (!decltype(first)::value) {
             // ======== B(t): O^T += V(t - 1)^T . P(t - 1)^T  ||  exp2 + row sums of tile t ========
             if (t == nt - 1 && partial_last) add_bias(cur, t & 3);
             const bool fast0 = !need_slow[0], fast1 = !need_slow[1];               // wave-uniform (false only while a block has seen no key at all: never past tile 0 without masks)
@@ -342,9 +357,14 @@ __global__ __launch_bounds__(NT, 1) void attn_f16x3_w4_kernel(const AttnParams p
                 const bool fast = qb == 0 ? fast0 : fast1;
                 bool redo = !fast;
                 if (fast) redo = __any(!(lsum[qb] < P_SUM_LIMIT)) != 0;             // (also catches inf / nan)
+#ifdef W4_PROBE_HOT
+                redo = false;                                                      // (ISA inspection only: the loop without its cold paths)
+#endif
                 if (redo) {
                     if (fast) {
+                        init_s(cur, qb);
                         qk_block(t & 3, cur, 1 << qb, nofill);
+                        w4_drain();
                         if (t == nt - 1 && partial_last) {
                             const float* bs = Bs + (t & 3) * KT;
 #pragma unroll
@@ -357,7 +377,7 @@ __global__ __launch_bounds__(NT, 1) void attn_f16x3_w4_kernel(const AttnParams p
                                 }
                         }
                     }
-                    need_slow[qb] = slow_path(cur, qb);
+                    need_slow[qb] = slow_path(cur, nxt, qb);
                 }
             }
         }
@@ -380,11 +400,13 @@ __global__ __launch_bounds__(NT, 1) void attn_f16x3_w4_kernel(const AttnParams p
         __syncthreads();
     };
     // (tile 0's row sums come out of its slow path above: iteration 0 adds them like any other's)
-    for (int t = 0; t < nt; t += 2) {
-        iteration(t, sA, sB);
-        if (t + 1 < nt) iteration(t + 1, sB, sA);
+    iteration(std::true_type{}, 0, sA, sB);           // (peeled: no P.V yet - the loop body then has no conditional around its matrix blocks)
+    for (int t = 1; t < nt; t += 2) {
+        iteration(std::false_type{}, t, sB, sA);
+        if (t + 1 < nt) iteration(std::false_type{}, t + 1, sA, sB);
     }
     pv_block((nt - 1) & 3, nofill);
+    w4_drain();
     __syncthreads();                                  // everyone is done with the ring: reuse it for the transposition
 
     // ---- epilogue per 32-query block: O / l (one IEEE division + Markstein's correction per element: bit-identical to the division), rows through LDS
