@@ -27,7 +27,7 @@ SYMBOLS = [
     'imp_set_precision', 'imp_get_precision', 'imp_set_sinkhorn_storage', 'imp_num_keys', 'imp_key_name', 'imp_normalize_keypoints', 'imp_encode_keypoints', 'imp_forward_layer',
     'imp_attention_prob', 'imp_attention_received', 'imp_compute_distance', 'imp_compute_score',
     'imp_compute_matches', 'imp_pool', 'imp_score_mass', 'imp_pool_select', 'imp_pool_select_pair', 'imp_masked_commit', 'imp_gather_rows', 'imp_match_pair', 'imp_set_counts', 'imp_match_tail', 'imp_match_tail_scores', 'imp_pool_pair', 'imp_loop_lockstep', 'imp_loop_lockstep_uncertainty', 'imp_op_linear', 'imp_op_layer_gemm', 'imp_op_fused_mlp',
-    'imp_op_attention', 'imp_time_attention', 'imp_time_attention_clock', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_resident_repaired', 'imp_resident_postmortem', 'imp_debug_hold_cus', 'imp_range_events', 'imp_set_range_recovery', 'imp_range_recovered', 'imp_range_take', 'imp_tag_wraps', 'imp_time_layer_gemm', 'imp_estimate_pose', 'imp_pose_stats',
+    'imp_op_attention', 'imp_time_attention', 'imp_time_attention_clock', 'imp_time_sinkhorn', 'imp_resident_status', 'imp_resident_health', 'imp_set_resident_verify', 'imp_resident_repaired', 'imp_resident_postmortem', 'imp_ctx_option', 'imp_debug_hold_cus', 'imp_range_events', 'imp_set_range_recovery', 'imp_range_recovered', 'imp_range_take', 'imp_tag_wraps', 'imp_time_layer_gemm', 'imp_estimate_pose', 'imp_pose_stats',
     'imp_sp_create', 'imp_sp_destroy', 'imp_sp_set_weight', 'imp_sp_finalize', 'imp_sp_detect', 'imp_sp_describe', 'imp_sp_dense', 'imp_sp_op_conv',
 ]
 
@@ -689,6 +689,10 @@ class Context:
             return False
         self._check(rc)
         return n.value, lvl.value
+
+    def option(self, name, value):
+        """a named switch of the context, before its first compute call (include/imp_hip.h imp_ctx_option: step-down paths forced for A/B tests, fault hooks)"""
+        self._check(self.L.imp_ctx_option(self.handle, name.encode(), C.c_long(int(value))))
 
     def resident_repaired(self):
         """calls whose own voided waiting launch (resident Sinkhorn, fused layer) was repaired inside the call (include/imp_hip.h imp_resident_repaired)"""

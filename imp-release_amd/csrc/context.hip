@@ -61,8 +61,8 @@ struct imp_ctx {
     std::map<std::string, HostTensor> raw;
     bool finalized = false;
     int prec = 1;             // matrix arithmetic: 1 = f16x3 split (default), 0 = native fp32 MFMA (imp_set_precision / IMP_PRECISION=f32)
-    int ot_compact = 0;       // Sinkhorn iterations stream the 3-byte copy of P (imp_set_sinkhorn_storage / IMP_OT_COMPACT=1)
-    bool fuse_merge = true;   // fold attn.merge into mlp.0 (one GEMM and one launch less per layer); IMP_NO_FUSE_MERGE=1 disables
+    int ot_compact = 0;       // Sinkhorn iterations stream the 3-byte copy of P (imp_set_sinkhorn_storage)
+    bool fuse_merge = true;   // fold attn.merge into mlp.0 (one GEMM and one launch less per layer) (always on since round 4)
     float bin_score = 1.f;
     std::vector<void*> allocs_w, allocs_ws, allocs_x;   // weights / workspace (regrown) / resident-Sinkhorn exchange
     // packed weights
@@ -91,13 +91,13 @@ struct imp_ctx {
     int* xstatus_hostdev = nullptr;                //   its device address
     int* range_host = nullptr;                     // word 1 of the same page: a match kernel saw non-finite scores (IMP_E_RANGE)
     int* range_hostdev = nullptr;
-    unsigned graph_tag0 = 0x80000000u;             // first tag of the graph launches (IMP_OT_GRAPH_TAG0: a test starts close to the wrap)
+    unsigned graph_tag0 = 0x80000000u;             // first tag of the graph launches (option ot_graph_tag0: a test starts close to the wrap)
     int tag_wraps = 0;                             // word 2 of the page: the graph launches' tag counter wrapped (resident_health clears the buffers)
     unsigned ticket_base = 0;                      // value of the per-XCC ticket counters before the next LOCAL launch
     int num_xccs = 0;
     int ot_degrade = 0;      // raised by a time-out: 1 = no XCD-local launches any more (chip-wide exchange only), 2 = streaming kernels only
-    int ot_verify = 0;       // IMP_OT_VERIFY=1 / imp_set_resident_verify: wait for every resident launch and re-run a voided one inside the call
-    int ot_fake = 0;         // TEST HOOK IMP_OT_FAKE_PLACEMENT=1: LOCAL workgroups lie about their XCC (forces the time-out path)
+    int ot_verify = 0;       // option ot_verify = 1 / imp_set_resident_verify: wait for every resident launch and re-run a voided one inside the call
+    int ot_fake = 0;         // TEST HOOK option ot_fake_placement = 1: LOCAL workgroups lie about their XCC (forces the time-out path)
     int resident_timeouts = 0;
     int resident_repaired = 0;   // voided waiting launches whose call was run again INSIDE the call (range_recover_in_call)
     int postmortem[40] = {};     // the last voided launch's record: [0..14] the kernel's (imp_kernels.h imp_postmortem_write), [16..] what the host knew when it noticed
@@ -112,16 +112,17 @@ struct imp_ctx {
     float *colsum[4] = {}, *amass[4] = {}, *mass[2] = {};
     AttnCache cache[2];
     float* xhalf = nullptr;  // resident Sinkhorn, two XCDs per pair: the half sums the XCDs swap ([2 iteration parities][8 vectors], ot_resident.hip OTR_MERGE)
-    int ot_hier = 1;         // two-XCDs-per-pair resident launches (hierarchical column sums) when a pair fits 64 CUs and B <= 4 (IMP_OT_HIER=0 disables)
-    int ot_local = 1;        // XCD-local resident Sinkhorn launches when a pair fits one XCD (IMP_OT_LOCAL=0 disables)
+    int ot_hier = 1;         // two-XCDs-per-pair resident launches (hierarchical column sums) when a pair fits 64 CUs and B <= 4 (option ot_hier = 0 disables)
+    int ot_local = 1;        // XCD-local resident Sinkhorn launches when a pair fits one XCD (option ot_local = 0 disables)
     unsigned* stat_cnt = nullptr;   // [cap_b][2][WF_MAX_PSPLIT] tickets of the statistics merge inside the MLP0 launch (gemm_wf.hip)
-    int kv_image = 1;        // IMP_KV_IMAGE=0: projections write K / V as fp32 (round-2 format) instead of the split-half image attention copies
+    int kv_image = 1;        // option kv_image = 0: projections write K / V as fp32 (round-2 format) instead of the split-half image attention copies
     float* kf32[2] = {};     // per image: K of a cached attention converted back to fp32 [B][n][D] (pooling / probability readers)
-    int wf_chain = 1;        // IMP_WF_CHAIN=0: never compute the next layer's projection inside the MLP3 launch
-    long wf_chain_min_tiles = 160, wf_max_tiles = 640, wf_proj_max_tiles = 40;     // IMP_WF_CHAIN_MIN / IMP_WF_MAX / IMP_WF_PROJ_MAX
+    int wf_chain = 1;        // option wf_chain = 0: never compute the next layer's projection inside the MLP3 launch
+    long wf_chain_min_tiles = 160, wf_max_tiles = 640, wf_proj_max_tiles = 40;     // (option wf_chain_min; the other two are fixed)
     int wf_fused = 1;        // IMP_WF_FUSED=0: never run a layer's MLP0 -> InstanceNorm -> MLP3 (-> next projection) as ONE launch (gemm_wf.hip fused kernel)
-    long wf_fused_min_tiles = 100;   // IMP_WF_FUSED_MIN (measured: the fused launch wins from ~64 tiles up - 128 tiles: -7..-9 %, 64: +-1 % - and loses 12-18 % at 16-32)
-    int wf_fused_fake = 0;   // TEST HOOK IMP_WF_FUSED_FAKE=1: one workgroup of every fused launch withholds its statistics (forces the time-out path)
+    long wf_fused_min_tiles = 100;   // option wf_fused_min (measured: the fused launch wins from ~64 tiles up - 128 tiles: -7..-9 %, 64: +-1 % - and loses 12-18 % at 16-32)
+    int probe_prof = 0;      // option probe_prof
+    int wf_fused_fake = 0;   // TEST HOOK (option wf_fused_fake): one workgroup of every fused launch withholds its statistics (forces the time-out path)
     float *fx_rec[2] = {}, *fx_fin[2] = {};   // fused layer: statistics granules [B][tiles][512] x 16 B and (mean, rstd) granules [B][512] x 16 B per image
     unsigned fx_tag = 0;     // tag of the last fused launch (tags never repeat on fx_rec / fx_fin)
     size_t fx_rec_floats = 0, fx_fin_floats = 0;
@@ -137,8 +138,8 @@ struct imp_ctx {
     float* lu_alt[2] = {nullptr, nullptr}; size_t lu_alt_cap[2] = {0, 0};
     RaggedCounts rc{};       // imp_set_counts: per-pair keypoint counts of the NEXT calls (rc.on = 0: uniform batches); rc_batch pairs
     int rc_batch = 0;
-    int ot_lane = 0;         // IMP_OT_LANE=1: resident Sinkhorn launches go through the device's lane stream (rounds 2-3) instead of the caller's stream under the spin gate
-    int use_wf = 1;          // weight-fragment GEMMs (gemm_wf.hip) for the layer convolutions when f16x3, D = 256, relu + InstanceNorm; IMP_GEMM_WF=0 disables
+    int ot_lane = 0;         // (rounds 2-3, kept for the graph-free fallback, never set:) resident Sinkhorn launches go through the device's lane stream (rounds 2-3) instead of the caller's stream under the spin gate
+    int use_wf = 1;          // weight-fragment GEMMs (gemm_wf.hip) for the layer convolutions when f16x3, D = 256, relu + InstanceNorm; option gemm_wf = 0 disables
     float* attn_split_ws = nullptr;        // key-split scratch of the attention kernel (grown on demand, allocs_x)
     unsigned* attn_split_cnt = nullptr;
     size_t attn_split_cap = 0, attn_split_units = 0;
@@ -570,7 +571,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
     }
     // weight-fragment GEMMs: the default for the f16x3 arithmetic (gemm_wf.hip)
     // (64-row tiles with the whole K in LDS, 8 waves in two groups that alternate between K loop and epilogue; small launches deal
-    // the column passes of a tile to several workgroups, wf_pass_split.  IMP_GEMM_WF: 0 never, 1 by this rule (default), 2 always)
+    // the column passes of a tile to several workgroups, wf_pass_split.  option gemm_wf: 0 never, 1 by this rule (default), 2 always)
     const long wf_tiles = (long)batch * ((n[0] + 63) / 64 + (n[1] + 63) / 64);
     const bool wf = c->prec == 1 && c->use_wf && (c->use_wf > 1 || wf_tiles <= c->wf_max_tiles);
     // K / V as split-half images (round 3): the projection's epilogue writes, per 64-channel head segment, [64 hi halves | 64 lo halves]
@@ -1026,7 +1027,7 @@ int resident_health(imp_ctx* c) {
 
 // the resident launch on the device's lane, joined to `st` on both sides; returns IMP_OK, or >0 when not applicable
 // chooses the decomposition of a resident launch.  XCD-local (every pair on the 32 CUs of one XCD, exchanges through that XCD's
-// L2 instead of across the fabric) whenever a pair fits there: IMP_OT_LOCAL=0 disables.  Returns 0 when nothing fits.
+// L2 instead of across the fabric) whenever a pair fits there: option ot_local = 0 disables.  Returns 0 when nothing fits.
 int plan_resident(imp_ctx* c, int batch, int n0, int n1, int max_wgs, int* nch, int* rpw, int* G, int* local) {
     // XCD-local protocols: only on the layout they were written for (8 XCCs x 32 CUs, SPX) and while no launch of this context
     // ever timed out (ot_degrade)
@@ -1308,6 +1309,29 @@ extern "C" {
 const char* imp_last_error(void) { return g_err.c_str(); }
 const char* imp_version(void) { return "imp_hip 0.3 gfx950 f16x3-mfma|f32-mfma"; }
 
+// named switches of a context (include/imp_hip.h imp_ctx_option): the step-down paths a context takes by itself after a voided waiting launch, forced for A/B tests,
+// and the fault-injection hooks of the test suite.  Set before the first compute call.
+static int ctx_option(imp_ctx* c, const char* name, long v) {
+    const std::string n(name ? name : "");
+    if (n == "ot_resident") c->ot_resident = v != 0;                  // 0: streaming Sinkhorn kernels (ot.hip)
+    else if (n == "ot_local") c->ot_local = v != 0;                   // 0: no XCD-local decomposition of the resident kernel
+    else if (n == "ot_hier") c->ot_hier = v != 0;                     // 0: no two-XCDs-per-pair decomposition
+    else if (n == "ot_verify") c->ot_verify = v != 0;                 // 1: every resident launch is waited for and repaired inside the call
+    else if (n == "ot_graph") c->ot_graph = v != 0;                   // 0: hipGraph captures record the streaming Sinkhorn
+    else if (n == "ot_fake_placement") c->ot_fake = v != 0;           // TEST HOOK: XCD-local workgroups report a wrong XCC
+    else if (n == "ot_graph_tag0") { if ((unsigned long)v >= 0x80000000ul && (unsigned long)v <= 0xFFFFF000ul) c->graph_tag0 = (unsigned)v; }   // TEST HOOK: tag wrap-around
+    else if (n == "gemm_wf") c->use_wf = (int)v;                      // 0: plain tiled GEMMs, 1: weight-fragment GEMMs for large launches, 2: always
+    else if (n == "wf_chain") c->wf_chain = (int)v;                   // 0: MLP3 and the next projection as two launches
+    else if (n == "wf_chain_min") c->wf_chain_min_tiles = v;
+    else if (n == "wf_fused") c->wf_fused = (int)v;                   // 0: the layer's MLP as two launches (no in-kernel statistics exchange)
+    else if (n == "wf_fused_min") c->wf_fused_min_tiles = v;
+    else if (n == "wf_fused_fake") c->wf_fused_fake = v != 0;         // TEST HOOK: one workgroup withholds its statistics
+    else if (n == "probe_prof") c->probe_prof = v != 0;               // probes: the timing entry points also print the phase cycle stamps of a profiling build
+    else if (n == "kv_image") c->kv_image = (int)v;                   // 0: the projection writes fp32 k | v, the attention kernel splits them while staging
+    else return IMP_E_ARG;
+    return IMP_OK;
+}
+
 int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     if (!out || !cfg) return fail(IMP_E_ARG, "imp_create: null argument");
     if (cfg->descriptor_dim != 256 && cfg->descriptor_dim != 128)
@@ -1324,26 +1348,29 @@ int imp_create(imp_ctx** out, const imp_config* cfg, int device) {
     c->device = device;
     c->D = cfg->descriptor_dim;
     c->dh = c->D / IMP_NUM_HEADS;
-    { const char* e = getenv("IMP_NO_FUSE_MERGE"); c->fuse_merge = !(e && e[0] == '1'); }
+    c->fuse_merge = 1; c->ot_compact = 0; c->ot_lane = 0;
+    c->ot_resident = c->ot_local = c->ot_hier = c->ot_graph = 1; c->ot_verify = c->ot_fake = 0;
+    c->use_wf = c->wf_chain = c->wf_fused = c->kv_image = 1; c->wf_fused_fake = 0;
+    // the environment knows THREE switches of a context - the arithmetic, and the two kernels that wait for the whole chip (a process that shares the GPU turns them off) ...
     { const char* e = getenv("IMP_PRECISION"); c->prec = (e && !strcmp(e, "f32")) ? 0 : 1; }
-    { const char* e = getenv("IMP_OT_COMPACT"); c->ot_compact = (e && atoi(e) != 0) ? 1 : 0; }
-    { const char* e = getenv("IMP_OT_RESIDENT"); c->ot_resident = (e && atoi(e) == 0) ? 0 : 1; }
-    { const char* e = getenv("IMP_OT_LOCAL"); c->ot_local = (e && atoi(e) == 0) ? 0 : 1; }
-    { const char* e = getenv("IMP_OT_HIER"); c->ot_hier = (e && atoi(e) == 0) ? 0 : 1; }
-    { const char* e = getenv("IMP_OT_VERIFY"); c->ot_verify = (e && atoi(e) != 0) ? 1 : 0; }
-    { const char* e = getenv("IMP_OT_GRAPH"); c->ot_graph = (e && atoi(e) == 0) ? 0 : 1; }      // 0: hipGraph captures record the streaming Sinkhorn (round 2 / 3)
-    { const char* e = getenv("IMP_OT_FAKE_PLACEMENT"); c->ot_fake = (e && atoi(e) != 0) ? 1 : 0; }
-    { const char* e = getenv("IMP_OT_GRAPH_TAG0"); if (e) { const unsigned long v = strtoul(e, nullptr, 0); if (v >= 0x80000000ul && v <= 0xFFFFF000ul) c->graph_tag0 = (unsigned)v; } }   // TEST HOOK
-    { const char* e = getenv("IMP_GEMM_WF"); c->use_wf = e ? atoi(e) : 1; }     // 0 off, 1 default (large launches), 2 always
-    { const char* e = getenv("IMP_WF_CHAIN"); c->wf_chain = e ? atoi(e) : 1; }
-    { const char* e = getenv("IMP_WF_FUSED"); c->wf_fused = e ? atoi(e) : 1; }
-    { const char* e = getenv("IMP_WF_FUSED_MIN"); if (e) c->wf_fused_min_tiles = atol(e); }
-    { const char* e = getenv("IMP_WF_FUSED_FAKE"); c->wf_fused_fake = (e && atoi(e) != 0) ? 1 : 0; }
-    { const char* e = getenv("IMP_OT_LANE"); c->ot_lane = (e && atoi(e) != 0) ? 1 : 0; }
-    { const char* e = getenv("IMP_KV_IMAGE"); c->kv_image = e ? atoi(e) : 1; }
-    { const char* e = getenv("IMP_WF_CHAIN_MIN"); if (e) c->wf_chain_min_tiles = atol(e); }
-    { const char* e = getenv("IMP_WF_MAX"); if (e) c->wf_max_tiles = atol(e); }
-    { const char* e = getenv("IMP_WF_PROJ_MAX"); if (e) c->wf_proj_max_tiles = atol(e); }
+    { const char* e = getenv("IMP_OT_RESIDENT"); if (e) c->ot_resident = atoi(e) != 0; }
+    { const char* e = getenv("IMP_WF_FUSED"); if (e) c->wf_fused = atoi(e); }
+    // ... everything else (step-down paths forced for A/B tests, fault-injection hooks) goes through imp_ctx_option; IMP_OPTIONS="name=value,..." applies a list at creation
+    if (const char* e = getenv("IMP_OPTIONS")) {
+        std::string list(e);
+        size_t pos = 0;
+        while (pos < list.size()) {
+            size_t end = list.find(',', pos);
+            if (end == std::string::npos) end = list.size();
+            const std::string item = list.substr(pos, end - pos);
+            const size_t eq = item.find('=');
+            if (eq == std::string::npos || ctx_option(c, item.substr(0, eq).c_str(), strtol(item.c_str() + eq + 1, nullptr, 0)) != IMP_OK) {
+                delete c;
+                return fail(IMP_E_ARG, "IMP_OPTIONS: unknown option or missing value in '" + item + "'");
+            }
+            pos = end + 1;
+        }
+    }
     {   // CU count: sizes the resident Sinkhorn launches and the column-pass split of small weight-fragment GEMM launches
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) {
@@ -1859,8 +1886,8 @@ static int match_pair_enqueue(imp_ctx* c, int batch, int n0, int n1, const float
     const float* sc[2] = {scores0, scores1};
     const float* de[2] = {desc0, desc1};
     float* dw[2] = {c->descw[0], c->descw[1]};
-    // host-side section timers (IMP_HOST_PROF=1: microseconds of enqueue work per section, printed every 50 calls)
-    static const bool hprof = [] { const char* e = getenv("IMP_HOST_PROF"); return e && atoi(e) != 0; }();
+    // host-side section timers (a development build flips this: microseconds of enqueue work per section, printed every 50 calls)
+    constexpr bool hprof = false;
     static double hp_acc[5] = {0, 0, 0, 0, 0}; static int hp_n = 0;
     auto hp_now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double hp_t = hprof ? hp_now() : 0.0;
@@ -1884,7 +1911,7 @@ static int match_pair_enqueue(imp_ctx* c, int batch, int n0, int n1, const float
     if ((rc = run_score(c, batch, n0, n1, c->dist, bin_score, sinkhorn_iterations, with_sinkhorn, scores, &o, st, &max_done))) return rc;
     hp_mark(3);
     if (hprof && ++hp_n % 50 == 0) {
-        fprintf(stderr, "[IMP_HOST_PROF] enqueue us per call: encoder %.0f  layers %.0f  distance %.0f  score %.0f\n", hp_acc[0] / 50, hp_acc[1] / 50, hp_acc[2] / 50, hp_acc[3] / 50);
+        fprintf(stderr, "[host prof] enqueue us per call: encoder %.0f  layers %.0f  distance %.0f  score %.0f\n", hp_acc[0] / 50, hp_acc[1] / 50, hp_acc[2] / 50, hp_acc[3] / 50);
         for (double& a : hp_acc) a = 0;
     }
     if (!max_done) HIP_TRY(launch_ot_maxima(batch, n0, n1, with_sinkhorn ? 0 : 1, o, c->max0, c->arg0, c->max1, c->arg1, st));
@@ -1962,9 +1989,8 @@ int imp_loop_lockstep(imp_ctx* c, int B, const int32_t* n0v, const int32_t* n1v,
     // When does a pair's exit test see its pose estimate?  Deferred (rounds 4a: the estimate of scored iteration k runs beside the next two
     // iterations' layers and decides at the next scored iteration - right when an estimate costs more than two iterations of layers) or
     // immediately (the group waits for this iteration's estimates, which run side by side: nothing is computed for a pair after its exit).
-    // The results are the same; IMP_LOOP_IMMEDIATE=0 / 1 overrides the default.
-    static const int immediate_env = [] { const char* e = getenv("IMP_LOOP_IMMEDIATE"); return e ? atoi(e) : -1; }();
-    const bool immediate = with_pose && (immediate_env < 0 ? true : immediate_env != 0);
+    // The results are the same; immediate is the faster one on the harder set (profiles/r05/MEASURED.md) and the only one kept reachable.
+    const bool immediate = with_pose;
 
     std::vector<LoopPair> P(B);
     struct WaitAll {                                    // no return path may leave a pose worker behind that still reads the caller's arrays
@@ -2077,7 +2103,7 @@ int imp_loop_lockstep(imp_ctx* c, int B, const int32_t* n0v, const int32_t* n1v,
                 q.pend = job;
             }
         }
-        if (immediate)                                                             // IMP_LOOP_IMMEDIATE: this iteration's estimates decide now (they ran side by side)
+        if (immediate)                                                             // this iteration's estimates decide now (they ran side by side)
             for (int b = 0; b < B; ++b)
                 if (P[b].live && resolve(b)) retired = true;
         bool any = false;
@@ -2400,6 +2426,12 @@ int imp_loop_lockstep_uncertainty(imp_ctx* c, int B, const int32_t* n0v, const i
     return IMP_OK;
 }
 
+int imp_ctx_option(imp_ctx* c, const char* name, long value) {
+    if (!c) return fail(IMP_E_ARG, "imp_ctx_option: no context");
+    if (ctx_option(c, name, value) != IMP_OK) return fail(IMP_E_ARG, std::string("imp_ctx_option: unknown option '") + (name ? name : "") + "'");
+    return IMP_OK;
+}
+
 int imp_debug_hold_cus(int device, int workgroups, int microseconds, void* stream) {
     if (workgroups < 1 || workgroups > 1024 || microseconds < 1 || microseconds > 1000000) return fail(IMP_E_ARG, "imp_debug_hold_cus: 1..1024 workgroups, 1..1e6 microseconds");
     HIP_TRY(hipSetDevice(device));
@@ -2568,22 +2600,6 @@ int imp_op_attention(imp_ctx* c, int batch, int nq, int nk, int dim, const float
     g.q = qkv_q; g.k = qkv_kv + dim; g.v = qkv_kv + 2 * dim; g.out = out; g.lse = lse; g.kmask = key_mask;
     g.sq_b = (long)nq * 3 * dim; g.sk_b = (long)nk * 3 * dim; g.so_b = (long)nq * dim;
     g.nq = nq; g.nk = nk;
-    // EXPERIMENT (IMP_ATTN_KV_PLANES=1): the same call on a pre-split copy of k | v (only launches the ping-pong kernel takes; synchronises)
-    static const bool kvp = [] { const char* e = getenv("IMP_ATTN_KV_PLANES"); return e && atoi(e) != 0; }();
-    if (kvp && c->prec == 1 && nq > 192) {
-        float* tmp = nullptr;
-        const size_t bytes = (size_t)batch * nk * 3 * dim * sizeof(float);
-        HIP_TRY(hipMalloc(&tmp, bytes));
-        HIP_TRY(hipMemcpyAsync(tmp, qkv_kv, bytes, hipMemcpyDeviceToDevice, S(stream)));
-        HIP_TRY(launch_attn_kv_planes(tmp, (long)batch * nk, 3 * dim, dim, a.dh, S(stream)));
-        HIP_TRY(launch_attn_kv_planes(tmp, (long)batch * nk, 3 * dim, 2 * dim, a.dh, S(stream)));
-        g.k = tmp + dim; g.v = tmp + 2 * dim;
-        a.kv_planes = 1;
-        const int arc = launch_attention(c, a, batch, S(stream));
-        (void)hipStreamSynchronize(S(stream));
-        (void)hipFree(tmp);
-        return arc;
-    }
     if (int arc = launch_attention(c, a, batch, S(stream))) return arc;
     return IMP_OK;
 }
@@ -2607,12 +2623,9 @@ int imp_time_attention_clock(imp_ctx* c, int batch, int n, int reps, float* ms, 
         g.sq_b = g.sk_b = (long)n * 3 * D; g.so_b = (long)n * D; g.nq = g.nk = n;
     }
     // the launch the product makes: with K / V as split-half images (default in f16x3 mode, D = 256) the q | k | v slots are first filled by
-    // the layer-0 projection kernel itself from whatever descriptors the workspace holds.  IMP_ATTN_KV_PLANES=0|1 forces either staging
-    // path for A/B timing (tools/probe/attn_kv_planes.py)
+    // the layer-0 projection kernel itself from whatever descriptors the workspace holds (option kv_image = 0: fp32 k | v, split while staging)
     {
-        const char* e = getenv("IMP_ATTN_KV_PLANES");
-        const bool img_ok = c->prec == 1 && c->kv_image && c->use_wf && D == 256 && !c->layers.empty() && c->layers[0].proj_wf && !c->layers[0].shared;
-        const bool kvp = c->prec == 1 && D == 256 && !c->layers.empty() && c->layers[0].proj_wf && !c->layers[0].shared && (e ? atoi(e) != 0 : img_ok);
+        const bool kvp = c->prec == 1 && c->kv_image && c->use_wf && D == 256 && !c->layers.empty() && c->layers[0].proj_wf && !c->layers[0].shared;
         if (c->prec == 1 && D == 256 && !c->layers.empty() && c->layers[0].proj_wf && !c->layers[0].shared) {
             const GnnLayer& L = c->layers[0];
             WfParams p = wf_defaults();
@@ -2695,7 +2708,7 @@ int imp_time_sinkhorn(imp_ctx* c, int batch, int n, int iterations, float* ms, v
             HIP_TRY(hipEventElapsedTime(&tt[k], e0, e1));
         }
         t = (tt[1] - tt[0]) / 3.f / iterations;
-        if (getenv("IMP_OTR_PROF")) {              // probe: phase cycles of workgroup 0 over one launch of `iterations`
+        if (c->probe_prof) {              // probe: phase cycles of workgroup 0 over one launch of `iterations`
             unsigned long long* dprof = nullptr;
             HIP_TRY(hipMalloc(&dprof, 6 * sizeof(unsigned long long)));
             p.prof = dprof; p.T = iterations; p.tag_base = resident_tags(c, p.T);
@@ -2704,7 +2717,7 @@ int imp_time_sinkhorn(imp_ctx* c, int batch, int n, int iterations, float* ms, v
             unsigned long long hp[6];
             HIP_TRY(hipMemcpy(hp, dprof, sizeof hp, hipMemcpyDeviceToHost));
             (void)hipFree(dprof);
-            fprintf(stderr, "[IMP_OTR_PROF] B=%d n=%d G=%d iterations=%d cycles per iteration (100 MHz-domain counter x?): A %.0f  B %.0f  wait+stage %.0f  reduce+store %.0f  wait+read v %.0f  vsum %.0f\n",
+            fprintf(stderr, "[otr prof] B=%d n=%d G=%d iterations=%d cycles per iteration (100 MHz-domain counter x?): A %.0f  B %.0f  wait+stage %.0f  reduce+store %.0f  wait+read v %.0f  vsum %.0f\n",
                     batch, n, G, iterations, (double)hp[0] / iterations, (double)hp[1] / iterations, (double)hp[2] / iterations,
                     (double)hp[3] / iterations, (double)hp[4] / iterations, (double)hp[5] / iterations);
         }
@@ -2790,7 +2803,7 @@ int imp_time_layer_gemm(imp_ctx* c, int batch, int n, int which, int dbg, int re
         return hipErrorInvalidValue;                            // (dbg >= 0 selected the retired planes kernel: tools/probe/gemm_planes.hip)
     };
     HIP_TRY(launch());
-    if (which == 4 && getenv("IMP_WF_PROF")) {       // probe (a -DWF_PROFILE build of the library): phase cycle stamps of every workgroup of one fused launch
+    if (which == 4 && c->probe_prof) {       // probe (a -DWF_PROFILE build of the library): phase cycle stamps of every workgroup of one fused launch
         const int grid = batch * 2 * ((n + 63) / 64);
         unsigned long long* dprof = nullptr;
         HIP_TRY(hipMalloc(&dprof, (size_t)grid * 12 * sizeof(unsigned long long)));

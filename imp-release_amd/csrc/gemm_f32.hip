@@ -503,8 +503,7 @@ hipError_t gemm_launch_pro(const GemmParams& p, int pro, dim3 grid, hipStream_t 
     if (p.prec == 1) {
         // two register sets (prefetch distance 2) where they are free: the 128x64 and 64x64 tiles stay under 168 VGPRs
         // with them (still 3 waves per SIMD); measured 31.0 -> 28.7 us on the MLP3 GEMM, no gain on 128x128 tiles
-        static const int deep_mode = [] { const char* e = getenv("IMP_GEMM_DEEP"); return e ? atoi(e) : -1; }();
-        const bool deep = deep_mode >= 0 ? deep_mode != 0 : (BM * BN <= 128 * 64);
+        const bool deep = BM * BN <= 128 * 64;
         if (deep) {
             if (pro == 0) return gemm_launch_one<BM, BN, 0, 1, 1>(p, grid, stream);
             if (pro == 1) return gemm_launch_one<BM, BN, 1, 1, 1>(p, grid, stream);

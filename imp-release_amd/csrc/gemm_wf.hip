@@ -42,15 +42,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef WF_NT
-#define WF_NT 0                 // EXPERIMENT: the epilogue's output stores non-temporal (1: the chained projection's q | k | v, 2: every output) - tools/build_variant.sh nt1 -DWF_NT=1
-#endif
-#ifndef WF_XCD
-#define WF_XCD 0                // EXPERIMENT: workgroup -> tile mapping that keeps the tiles of an image on ONE XCD (block b runs on XCD b % 8 in practice), the XCD on which the
-#endif                          // attention kernel's xcd_remap places that image's workgroups: producer and consumer of q | k | v, of the attention output and of the residual stream share an L2
-#ifndef WF_PRIO
-#define WF_PRIO 1               // group 0 runs its K loops at raised wave priority (A/B: tools/build_variant.sh x -DWF_PRIO=0)
-#endif
 
 namespace {
 
@@ -62,14 +53,7 @@ constexpr int AUX_SC1 = 16;     // agent-scope coherent access (write-through st
 
 struct WfLane { int lane, half, w4, grp; };
 
-// linear block index -> work index such that the blocks of one XCD (lin % 8) take a contiguous range of work (attention_f16x3.hip xcd_remap)
-__device__ __forceinline__ int wf_xcd_remap(int lin, int total, bool fused = false) {      // WF_XCD = 2: the fused layer launch only (taken while a stream has the chip to itself)
-    if (!WF_XCD || (WF_XCD == 2 && !fused)) return lin;
-    const int q = total / 8, r = total % 8;
-    const int xcd = lin % 8, idx = lin / 8;
-    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + idx;
-}
+// (rounds 4-5 measured non-temporal output stores and an image-per-XCD tile mapping as build switches: -1 % / -0.8 % on the pipeline; removed, logs in profiles/r05/envab_*.log)
 
 #ifdef WF_PROFILE   // tools/build_variant.sh prof -DWF_PROFILE: cycle stamps of wave 0 of each group of every workgroup (staging, K loops, epilogues, total)
 __device__ unsigned long long wf_prof[2048][2][4];
@@ -197,17 +181,11 @@ __device__ __forceinline__ void wf_epilogue(const f32x16 (&acc)[2], unsigned cha
                         imp_split2(v[2], v[3], a, d); hi[1] = a; lo[1] = d;
                         const int col = cb + c4;                                  // head segment col & ~63, channel col & 63
                         unsigned char* seg = reinterpret_cast<unsigned char*>(Cb + (long)row * ldc + (col & ~63)) + (col & 63) * 2;
-                        if (WF_NT >= 1) {
-                            __builtin_nontemporal_store(hi, reinterpret_cast<u32x2*>(seg));
-                            __builtin_nontemporal_store(lo, reinterpret_cast<u32x2*>(seg + 128));
-                        } else {
-                            *reinterpret_cast<u32x2*>(seg) = hi;
-                            *reinterpret_cast<u32x2*>(seg + 128) = lo;
-                        }
+                        *reinterpret_cast<u32x2*>(seg) = hi;
+                        *reinterpret_cast<u32x2*>(seg + 128) = lo;
                     }
                 } else if (row < M && (!(dbg & 1) || v[0] == 123.456f)) {
-                    if (WF_NT >= 2 || (WF_NT == 1 && !TOPLANES && !has_res)) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(Cb + (long)row * ldc + cb + c4));
-                    else *reinterpret_cast<f32x4*>(Cb + (long)row * ldc + cb + c4) = v;
+                    *reinterpret_cast<f32x4*>(Cb + (long)row * ldc + cb + c4) = v;
                 }
                 if (TOPLANES) {                                  // (rows past M repeat row M - 1: they feed only rows that are never stored)
                     u32x2 hi, lo;
@@ -293,7 +271,7 @@ __global__ __launch_bounds__(512) void gemm_wf_kernel(const WfParams p, int row_
     WfLane L;
     L.lane = tid & 63; L.half = L.lane >> 5; L.w4 = (tid >> 6) & 3; L.grp = tid >> 8;
     const int lane = L.lane, half = L.half, w4 = L.w4, grp = L.grp;
-    int z = wf_xcd_remap(blockIdx.x, gridDim.x);
+    int z = blockIdx.x;
     // small launches: the column passes of a tile are dealt to `psplit` workgroups (each stages the tile itself) to fill the chip
     const int psplit = p.pass_split > 1 ? p.pass_split : 1;
     const int pgrp = z % psplit; z /= psplit;
@@ -407,9 +385,7 @@ __global__ __launch_bounds__(512) void gemm_wf_kernel(const WfParams p, int row_
         for (int i = 0; i < 2; ++i) aoff2[i] = (32 * i + (lane & 31)) * PITCH2 + half * 16;
         float* const C2 = S.C2 + b * S.sC2_b;
         const f32x4 (&nores)[2][4] = rres;
-#if WF_PRIO
         if (grp == 0) __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll 1
         for (int t = 0; t < mine2; ++t) {
             const int ps = grp + 2 * t;
@@ -430,9 +406,7 @@ __global__ __launch_bounds__(512) void gemm_wf_kernel(const WfParams p, int row_
 #pragma unroll
         for (int c = 0; c < 4; ++c) { bh[c] = w0[c * 128]; bl[c] = w0[c * 128 + 64]; }
     }
-#if WF_PRIO
     if (grp == 0) __builtin_amdgcn_s_setprio(1);
-#endif
     float st_sum[4], st_m2[4];                      // STATS: (sum, M2) of this wave's passes, stored after the last one (N <= 1024: 4 passes per group)
     int st_cb[4];
 #pragma unroll 1
@@ -627,7 +601,7 @@ __global__ __launch_bounds__(512) void gemm_wf_fused_kernel(const WfParams p, co
     WfLane L;
     L.lane = tid & 63; L.half = L.lane >> 5; L.w4 = (tid >> 6) & 3; L.grp = tid >> 8;
     const int lane = L.lane, half = L.half, w4 = L.w4, grp = L.grp;
-    int z = wf_xcd_remap(blockIdx.x, gridDim.x, true);
+    int z = blockIdx.x;
     const int rtile = z % row_tiles; z /= row_tiles;
     const int sidx = z % p.nside;
     const int b = z / p.nside;
@@ -708,20 +682,14 @@ __global__ __launch_bounds__(512) void gemm_wf_fused_kernel(const WfParams p, co
             __syncthreads();
             if (h == 0) {
                 WF_TP(1);
-#if WF_PRIO
                 if (grp == 0) __builtin_amdgcn_s_setprio(1);
-#endif
                 // k-steps 0 .. 15 of the first pass (weights of k-steps 16 .. follow in the fragment stream)
                 wf_kloop<KH, 0, K>(accA, wf_smem, aoff, wptr(passA), wptr(passA) + (KH / 16) * 128, bh, bl);
-#if WF_PRIO
                 if (grp == 0) __builtin_amdgcn_s_setprio(0);
-#endif
             }
         }
     }
-#if WF_PRIO
     if (grp == 0) __builtin_amdgcn_s_setprio(1);
-#endif
     float sumA, m2A, sumB, m2B;
     {
         int aoff_h[2];
@@ -732,9 +700,7 @@ __global__ __launch_bounds__(512) void gemm_wf_fused_kernel(const WfParams p, co
     wf_block_stats(accA, p.bias, row0, M, cbA, L, sumA, m2A);
     wf_kloop<K, 0>(accB, wf_smem, aoff, wptr(passB), wptr(passB), bh, bl);      // (after the last pass: a harmless reload - mlp.3's first fragments
     wf_block_stats(accB, p.bias, row0, M, cbB, L, sumB, m2B);                   //  are requested after the exchange: 32 registers less to hold across it)
-#if WF_PRIO
     if (grp == 0) __builtin_amdgcn_s_setprio(0);
-#endif
     WF_TP(2);
     float* const Cb = S.C + b * S.sC_b;
     const float* const Rb = S.R ? S.R + b * S.sR_b : nullptr;
@@ -868,9 +834,7 @@ __global__ __launch_bounds__(512) void gemm_wf_fused_kernel(const WfParams p, co
 #pragma unroll
         for (int i = 0; i < 2; ++i) aoff2[i] = (32 * i + (lane & 31)) * PITCH2 + half * 16;
         float* const C2 = S.C2 + b * S.sC2_b;
-#if WF_PRIO
         if (grp == 0) __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll 1
         for (int t = 0; t < mine2; ++t) {
             const int ps = grp + 2 * t;

@@ -164,7 +164,6 @@ struct AttnParams {
     unsigned long long* clk_probe;
 };
 // in place: the dh-float head segments of columns [col0, col0 + 4 dh) of `rows` rows -> [dh hi halves | dh lo halves]
-hipError_t launch_attn_kv_planes(float* base, long rows, int ld, int col0, int dh, hipStream_t stream);
 // ... and back: out[row][h * dh + ch] = hi + lo (exact in fp32)
 hipError_t launch_attn_kv_unplanes(const float* base, long rows, int ld, int col0, int dh, float* out, int ldo, hipStream_t stream);
 int attention_f16x3_splits(const AttnParams& p, int batch);                        // splits launch_attention_f16x3 will use
@@ -276,7 +275,7 @@ struct OtResidentParams {
     unsigned* dev_base;       // launches recorded into a hipGraph: {tag base, ticket base, workgroups done} in DEVICE memory - a replay must not
                               //   reuse its tags, so the launch takes both bases from here and its last workgroup advances them (tag_base /
                               //   ticket_base above are ignored); null for ordinary launches
-    int fake_placement;       // TEST HOOK (IMP_OT_FAKE_PLACEMENT=1): workgroups lie about the XCC they run on
+    int fake_placement;       // TEST HOOK (option ot_fake_placement = 1): workgroups lie about the XCC they run on
     unsigned long long* prof; // optional [6]: phase cycle counts of workgroup 0 (probe), null in the product
     int local;                // 1: XCD-local launch: every pair's G <= 32 workgroups on one XCD (plain stores, L2-served polls);
                               // 2: two XCDs per pair (B <= 4), hierarchical column sums: one fabric crossing per iteration

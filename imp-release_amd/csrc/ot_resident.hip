@@ -56,11 +56,7 @@ constexpr int SPIN_LIMIT = 1 << 21;   // polls of one wait before it is declared
 
 // sum over the 64 lanes with DPP row operations (6 VALU instructions, no LDS crossbar round trips: the __shfl_xor butterfly costs
 // six dependent ds_bpermute per sum, ~2400 cycles of an iteration's phase A); fixed order, the total is broadcast from lane 63
-#ifndef OTR_DPP_SUM
-#define OTR_DPP_SUM 1
-#endif
 __device__ __forceinline__ float wave_sum(float v) {
-#if OTR_DPP_SUM
 #define OTR_DPP_ADD(ctrl, row_mask) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, row_mask, 0xf, false))
     OTR_DPP_ADD(0xB1, 0xf);          // quad_perm [1,0,3,2]
     OTR_DPP_ADD(0x4E, 0xf);          // quad_perm [2,3,0,1]
@@ -70,16 +66,10 @@ __device__ __forceinline__ float wave_sum(float v) {
     OTR_DPP_ADD(0x143, 0xc);         // row_bcast:31 into rows 2 and 3: lane 63 holds the total
 #undef OTR_DPP_ADD
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-#else
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-#endif
 }
 // the sums of N values at once: the DPP steps of the N chains interleaved (a chain alone waits two states after every step), every lane gets the totals
 template <int N>
 __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
-#if OTR_DPP_SUM
 #define OTR_DPP_ADDN(ctrl, row_mask) _Pragma("unroll") for (int i = 0; i < N; ++i) v[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[i]), ctrl, row_mask, 0xf, false))
     OTR_DPP_ADDN(0xB1, 0xf);
     OTR_DPP_ADDN(0x4E, 0xf);
@@ -90,10 +80,6 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
 #undef OTR_DPP_ADDN
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), 63));
-#else
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = wave_sum(v[i]);
-#endif
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -111,9 +97,6 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {     // first ind
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
-#ifndef OTR_POLL_SLEEP
-#define OTR_POLL_SLEEP 0
-#endif
 #ifndef OTR_POLL_AUX
 #define OTR_POLL_AUX (AUX_SC1 | (int)0x80000000)      // + volatile: a poll must not be hoisted out of its loop (the compiler then also sets sc0: system scope)
 #endif
@@ -155,74 +138,14 @@ __device__ __forceinline__ f32x4 ldg4(__amdgpu_buffer_rsrc_t r, int q, unsigned 
         a = __builtin_amdgcn_raw_buffer_load_b128(r, q * 32, 0, AUX_POLL);
         c = __builtin_amdgcn_raw_buffer_load_b128(r, q * 32 + 16, 0, AUX_POLL);
         if ((a[1] == tag && a[3] == tag && c[1] == tag && c[3] == tag) || dead) break;
-#if OTR_POLL_SLEEP
-        __builtin_amdgcn_s_sleep(OTR_POLL_SLEEP);             // back off: failed polls compete with the stores they wait for
-#endif
         if ((++spins & 1023) == 0) poll_health(status, spins, dead, q, tag, a[1], where);
     }
     return f32x4{__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(c[0]), __uint_as_float(c[2])};
 }
 
-// TWO chunks with both loads in flight per poll round (round 5): an exchange vector is NQ = 64 NCH + 1 chunks (the dustbin column makes it odd), so
-// of 512 threads one - or, staging a slice, a few - owns two chunks; polled one after the other that is a second dependent memory round trip
-// on the critical path of every iteration
-#ifndef OTR_MERGE
-#define OTR_MERGE 0            // EXPERIMENT (round 5, measured slower, off), LOCAL = 2: two hand-offs per iteration instead of three - the slice owners publish their half
-#endif                         // sums twice (a plain store for their own XCD, a write-through store for the other, alternating between two buffers by iteration parity) and
-                               // EVERY workgroup reads both halves' sums of all columns and forms v itself; bit-identical v.  The owners' swap + the distribution of v cost
-                               // 1 600 + 2 180 cycles, the one merged hand-off 4 700: 64 workgroups polling 16 KB across the fabric each are slower than 32 owners swapping
-                               // 68 columns each and a local distribution (6.37-6.43 vs 5.99-6.01 us per iteration, profiles/r05/sinkhorn_merged_handoffs_ab.log)
-#ifndef OTR_PACKED_ROWSUM
-#define OTR_PACKED_ROWSUM 1    // phase A: packed FMAs, the rows of a wave advance together (see there)
-#endif
-#ifndef OTR_VSUM_IN_D
-#define OTR_VSUM_IN_D (!OTR_MERGE && !OTR_DUAL_POLL)     // the sum of v from the registers that fetched it instead of a second pass over the LDS copy by every wave
-#endif
-#ifndef OTR_DUAL_POLL
-#define OTR_DUAL_POLL 0        // (measured neutral: 6.09-6.12 vs 6.11-6.14 us per iteration at B = 4, N = 2048 - the waiting dominates, not the second round trip)
-#endif
-__device__ __forceinline__ void ldg4x2(__amdgpu_buffer_rsrc_t r, int q0, int q1, bool two, unsigned tag, const Health& status, bool& dead, f32x4& o0, f32x4& o1, int where = 0) {
-    u32x4 a, c, a2 = {0, tag, 0, tag}, c2 = {0, tag, 0, tag};
-    int spins = 0;
-    for (;;) {
-        asm volatile("" ::: "memory");
-        a = __builtin_amdgcn_raw_buffer_load_b128(r, q0 * 32, 0, AUX_POLL);
-        c = __builtin_amdgcn_raw_buffer_load_b128(r, q0 * 32 + 16, 0, AUX_POLL);
-        if (two) {
-            a2 = __builtin_amdgcn_raw_buffer_load_b128(r, q1 * 32, 0, AUX_POLL);
-            c2 = __builtin_amdgcn_raw_buffer_load_b128(r, q1 * 32 + 16, 0, AUX_POLL);
-        }
-        const bool ok = a[1] == tag && a[3] == tag && c[1] == tag && c[3] == tag && a2[1] == tag && a2[3] == tag && c2[1] == tag && c2[3] == tag;
-        if (ok || dead) break;
-#if OTR_POLL_SLEEP
-        __builtin_amdgcn_s_sleep(OTR_POLL_SLEEP);
-#endif
-        if ((++spins & 1023) == 0) poll_health(status, spins, dead, q0, tag, a[1], where);
-    }
-    o0 = f32x4{__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(c[0]), __uint_as_float(c[2])};
-    o1 = f32x4{__uint_as_float(a2[0]), __uint_as_float(a2[2]), __uint_as_float(c2[0]), __uint_as_float(c2[2])};
-}
-
-// the same chunk of TWO exchange vectors, both loads in flight per poll round (OTR_MERGE: a half's own sums from its L2, the other half's across the fabric)
-__device__ __forceinline__ void ldg4_pair(__amdgpu_buffer_rsrc_t r0, __amdgpu_buffer_rsrc_t r1, int q, unsigned tag, const Health& status, bool& dead, f32x4& o0, f32x4& o1, int where = 0) {
-    u32x4 a, c, a2, c2;
-    int spins = 0;
-    for (;;) {
-        asm volatile("" ::: "memory");
-        a = __builtin_amdgcn_raw_buffer_load_b128(r0, q * 32, 0, AUX_POLL);
-        c = __builtin_amdgcn_raw_buffer_load_b128(r0, q * 32 + 16, 0, AUX_POLL);
-        a2 = __builtin_amdgcn_raw_buffer_load_b128(r1, q * 32, 0, AUX_POLL);
-        c2 = __builtin_amdgcn_raw_buffer_load_b128(r1, q * 32 + 16, 0, AUX_POLL);
-        const bool ok = a[1] == tag && a[3] == tag && c[1] == tag && c[3] == tag && a2[1] == tag && a2[3] == tag && c2[1] == tag && c2[3] == tag;
-        if (ok || dead) break;
-#if OTR_POLL_SLEEP
-        __builtin_amdgcn_s_sleep(OTR_POLL_SLEEP);
-#endif
-        if ((++spins & 1023) == 0) poll_health(status, spins, dead, q, tag, a[1], where);
-    }
-    o0 = f32x4{__uint_as_float(a[0]), __uint_as_float(a[2]), __uint_as_float(c[0]), __uint_as_float(c[2])};
-    o1 = f32x4{__uint_as_float(a2[0]), __uint_as_float(a2[2]), __uint_as_float(c2[0]), __uint_as_float(c2[2])};
-}
+// (round 5 measured two variants of these hand-offs as build switches - both chunks of a two-chunk owner polled in one round trip: neutral, 6.09-6.12 vs 6.11-6.14 us
+// per iteration; the owners' swap and the distribution of v merged into one hand-off read by every workgroup: slower, 6.37-6.43 vs 5.99-6.01 - removed in round 6:
+// profiles/r05/sinkhorn_dual_poll_ab.log, sinkhorn_merged_handoffs_ab.log)
 
 // one granule
 __device__ __forceinline__ float ldg1(__amdgpu_buffer_rsrc_t r, int idx, unsigned tag, const Health& status, bool& dead, int where) {
@@ -410,7 +333,6 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         const unsigned tag_p = tag_base + 3u * it + 1u, tag_h = tag_p + 1u, tag_v = tag_p + 2u;
         // ---- A: u for the own rows, column partials ---------------------------------------------------------------
         float acc[RPW];
-#if OTR_PACKED_ROWSUM
         // (round 5) a lane's share of a row's dot product as TWO chains - even and odd columns - so that a step of both is one v_pk_fma_f32 on the register pair
         // (P[k][c][0..1], x[0..1]): 64 packed instead of 128 scalar FMAs (phase B's products over a float4 were packed already).  And the RPW rows advance
         // TOGETHER: the compiler used to finish one row - a chain of dependent FMAs, its six dependent DPP additions, its IEEE division behind a branch - before
@@ -450,29 +372,6 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
                 pdpart += pd2;
             }
         }
-#else
-#pragma unroll
-        for (int k = 0; k < RPW; ++k) acc[k] = 0.f;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(vs + 4 * (lane + 64 * c));
-#pragma unroll
-            for (int k = 0; k < RPW; ++k) {
-                acc[k] = fmaf(P[k][c][0], x[0], acc[k]);
-                acc[k] = fmaf(P[k][c][1], x[1], acc[k]);
-                acc[k] = fmaf(P[k][c][2], x[2], acc[k]);
-                acc[k] = fmaf(P[k][c][3], x[3], acc[k]);
-            }
-        }
-        const float vd = vs[DCOL];
-        float pdpart = 0.f;
-#pragma unroll
-        for (int k = 0; k < RPW; ++k) {
-            const float s = fmaf(Pd[k], vd, wave_sum(acc[k]));
-            u[k] = (r0 + k < n0) ? 1.f / (s + OT_EPS) : 0.f;          // real rows have marginal 1 (nets/layers.py:32,41)
-            pdpart = fmaf(Pd[k], u[k], pdpart);
-        }
-#endif
         u_last = (float)(n0 + 1) / (c0 * vsum + OT_EPS);              // dustbin row: marginal n0 + 1 (nets/layers.py:42)
         OTR_CLK(0)
         // ---- B: workgroup partial vector ---------------------------------------------------------------------------
@@ -524,25 +423,11 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         // ---- C: this workgroup's slice of columns over the G partial vectors -------------------------------------
         {
             f32x4* stage = reinterpret_cast<f32x4*>(red);             // [H][cq]
-#if OTR_DUAL_POLL
-            for (int idx = tid; idx < cq * H; idx += 1024) {
-                const int idx2 = idx + 512;
-                const int w = idx / cq, qq = idx - w * cq, q = gl * cq + qq;
-                const int w2 = idx2 / cq, qq2 = idx2 - w2 * cq, q2 = gl * cq + qq2;
-                const bool v1 = q < NQ, v2 = idx2 < cq * H && q2 < NQ;
-                f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
-                if (v1) ldg4x2(rs_part, w * NQ + q, w2 * NQ + q2, v2, tag_p, health, dead, o0, o1);
-                else if (v2) o1 = ldg4(rs_part, w2 * NQ + q2, tag_p, health, dead, 1 | (it << 8));
-                stage[idx] = o0;
-                if (idx2 < cq * H) stage[idx2] = o1;
-            }
-#else
             for (int idx = tid; idx < cq * H; idx += 512) {
                 const int w = idx / cq, qq = idx - w * cq;
                 const int q = gl * cq + qq;
                 stage[idx] = q < NQ ? ldg4(rs_part, w * NQ + q, tag_p, health, dead, 1 | (it << 8)) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
-#endif
             __syncthreads();
             OTR_CLK(2)
             // the tree goes on over the workgroups (index = row block): 8 threads per column, each the subtree of an aligned run of `seg` workgroups
@@ -584,7 +469,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
                 float s = ((sub[cl] + sub[ncol + cl]) + (sub[2 * ncol + cl] + sub[3 * ncol + cl])) +
                           ((sub[4 * ncol + cl] + sub[5 * ncol + cl]) + (sub[6 * ncol + cl] + sub[7 * ncol + cl]));
                 const int xi = 4 * (gl * cq) + cl;                    // index in the exchange layout
-                if (LOCAL == 2 && OTR_MERGE) {
+                if (LOCAL == 2 && 0) {
                     if (xi < LDX) {
                         stg1<0>(rs_v, xi, s, tag_h);                                   // for this XCD's workgroups (stays in its L2)
                         stg1<AUX_SC1>((it & 1) ? rs_h_own1 : rs_h_own, xi, s, tag_h);  // for the other XCD's
@@ -605,34 +490,6 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
         }
         OTR_CLK(3)
         // ---- D: everybody reads v -----------------------------------------------------------------------------------
-#if OTR_MERGE
-        if (LOCAL == 2) {                          // ... reads both halves' sums and forms v: the arithmetic of the owners' path above, per column
-            for (int q = tid; q < NQ; q += 512) {
-                f32x4 own, oth, v4;
-                ldg4_pair(rs_v, (it & 1) ? rs_h_oth1 : rs_h_oth, q, tag_h, health, dead, own, oth);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int xi = 4 * q + e;
-                    const float s = half == 0 ? own[e] + oth[e] : oth[e] + own[e];
-                    const bool dust = xi == DCOL;
-                    const bool real = xi < n1 || dust;
-                    const float t = fmaf(c0, u_last, s);
-                    const float marg = dust ? (float)(n1 + 1) : 1.f;
-                    v4[e] = real ? marg / (t + OT_EPS) : 0.f;
-                }
-                *reinterpret_cast<f32x4*>(vs + 4 * q) = v4;
-            }
-        } else
-#endif
-#if OTR_DUAL_POLL
-        for (int q = tid; q < NQ; q += 1024) {
-            f32x4 o0, o1;
-            ldg4x2(rs_v, q, q + 512, q + 512 < NQ, tag_v, health, dead, o0, o1);
-            *reinterpret_cast<f32x4*>(vs + 4 * q) = o0;
-            if (q + 512 < NQ) *reinterpret_cast<f32x4*>(vs + 4 * (q + 512)) = o1;
-        }
-#else
-#if OTR_VSUM_IN_D
         {   // ... and the sum of v from the chunks the threads just fetched (entries that are no real column travel as zeros): a partial per wave, combined in a fixed order
             // (the dustbin entry - chunk NQ - 1, whose owner thread depends on the column class NCH - is added apart below, so that the sum depends on
             // the pair's own n1 alone; inner chunk q belongs to thread q mod 512 in every class, and chunks past n1 are zeros)
@@ -645,25 +502,9 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             vpart = wave_sum(vpart);
             if (lane == 0) s_vsw[wave] = vpart;
         }
-#else
-        for (int q = tid; q < NQ; q += 512) *reinterpret_cast<f32x4*>(vs + 4 * q) = ldg4(rs_v, q, tag_v, health, dead, 3 | (it << 8));
-#endif
-#endif
         __syncthreads();
         OTR_CLK(4)
-#if OTR_VSUM_IN_D
         vsum = (((s_vsw[0] + s_vsw[1]) + (s_vsw[2] + s_vsw[3])) + ((s_vsw[4] + s_vsw[5]) + (s_vsw[6] + s_vsw[7]))) + vs[DCOL];
-#else
-        {   // sum of v (every wave computes the same value in the same order: no further barrier)
-            float s = 0.f;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(vs + 4 * (lane + 64 * c));
-                s += (x[0] + x[1]) + (x[2] + x[3]);
-            }
-            vsum = wave_sum(s) + vs[DCOL];
-        }
-#endif
         OTR_CLK(5)
     }
     if (p.prof && b == 0 && g == 0 && tid == 0)

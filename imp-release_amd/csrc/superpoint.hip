@@ -6,17 +6,11 @@
 // GEMM whose K runs over (tap, channel) with 16-channel MFMA k-steps reading contiguous channels of a shifted pixel:
 //
 //   sp_conv1a_kernel     1 -> 64 channels, 9 taps on the VALU (K = 9 is no matrix shape), fused bias + ReLU
-//   sp_conv_kernel       every other convolution: split-half f16x3 MFMA (v_mfma_f32_32x32x16_f16, x = hi + lo, products
-//                        lo.hi + hi.lo + hi.hi, fp32 accumulate - the arithmetic of gemm_f32.hip, fp32-level results).
-//                        Workgroup = 8 x 16 output pixels x 64 output channels, 4 waves as 2 (pixels) x 2 (channels).  The input
-//                        tile with its halo is split once into hi / lo half planes in LDS (64 input channels at a time, 52.5 KB);
-//                        A fragments are ds_read_b128 of 8 consecutive channels of the lane's pixel shifted by the tap; the weights
-//                        are pre-split and pre-ordered on the host into MFMA B-fragment order, so a wave fetches a whole fragment
-//                        as ONE coalesced 1-KB load straight from L2 (every workgroup reads the same few hundred KB), prefetched
-//                        one tap (4 k-steps) ahead - the K loop has no barrier.  Epilogue: bias, ReLU and the 2x2 max-pool
-//                        (tile row m = 4 q + r puts the four pixels of pooling window q into ONE lane's four consecutive
-//                        accumulator registers, so pooling is three v_max per value and only the pooled map is written).
-//   sp_detector_kernel   convPb (256 -> 65, 1x1) + softmax over the 65 bins + drop the dustbin + 8x8 pixel shuffle, fp32 VALU
+//   sp_convp_kernel      every other convolution: split-half f16x3 MFMA (v_mfma_f32_32x32x16_f16, x = hi + lo, products lo.hi + hi.lo + hi.hi, fp32
+//                        accumulate - the arithmetic of gemm_f32.hip, fp32-level results) as a persistent producer / consumer kernel (see there); the first layer
+//                        computes conv1a on the way; epilogue: bias, ReLU and the 2x2 max-pool.  (Rounds 3-4 also kept the one-tile-per-workgroup kernel, a
+//                        VALU detector head and the unfused first layer behind environment switches: removed in round 6, profiles/r04.)
+//   sp_softmax_shuffle   softmax over the 65 bins of the convPb logits, dustbin dropped, 8x8 pixel shuffle
 //   sp_nms_kernel        the whole simple_nms chain (5 max-pools of radius R) for a 32 x 32 tile out of one LDS image with a 5R halo
 //   sp_rowcount / sp_scan / sp_compact   ordered compaction = torch.nonzero order (row major) with the border filter folded in
 //   sp_topk_select / sp_topk_rank   top_k_keypoints: radix select of the k-th score on one CU, rank sort of the survivors on many
@@ -86,202 +80,6 @@ __device__ __forceinline__ int xcd_remap(int lin, int total) {
     return base + idx;
 }
 
-template <int TAPS, int POOL, int FIRST>
-__global__ __launch_bounds__(256) void sp_conv_kernel(const SpConvParams p, int total) {
-    using G = Geo<TAPS>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5;
-    int z = xcd_remap(blockIdx.x, total);
-    const int nt = p.cout >> 6;
-    const int ntile = z % nt; z /= nt;
-    const int tx = z % p.tiles_x; z /= p.tiles_x;
-    const int ty = z % p.tiles_y;
-    const int b = z / p.tiles_y;
-    const int y0 = ty * TH, x0 = tx * TW;
-    const int H = p.H, W = p.W;
-    unsigned long long t_start = 0, t_staged = 0, t_kdone = 0, t_stage_acc = 0, t_k_acc = 0;
-    if (p.prof) t_start = __builtin_readcyclecounter();
-
-    // the lane's A rows: fragment i covers tile rows m = 64 wm + 32 i + (lane & 31), m = 4 q + r, q = pooling window (4 x 8 per tile)
-    int aoff[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = 64 * wm + 32 * i + (lane & 31);
-        const int q = m >> 2, r = m & 3;
-        const int py = 2 * (q >> 3) + (r >> 1), px = 2 * (q & 7) + (r & 1);
-        aoff[i] = (py * G::ROW_SLOTS + px * PSLOT) * 16 + half * 16;
-    }
-    const int nchunk = p.cin >> 6;
-    const int ksteps = nchunk * TAPS * 4;
-    const u32x4* wp = p.wf + (size_t)(ntile * 2 + wn) * ksteps * 128 + lane;
-
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-    u32x4 bh[4], bl[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) { bh[c] = wp[c * 128]; bl[c] = wp[c * 128 + 64]; }
-
-    // staging geometry: 16 threads per pixel (one float4 = 4 channels each), 16 pixels per pass
-    constexpr int NPIX = G::LH * G::LW;
-    constexpr int NPASS = (NPIX + 15) / 16;
-    const int sp_pix = tid >> 4, sp_c = (tid & 15) * 4;
-
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        if (chunk > 0) __syncthreads();                    // every wave has read the previous chunk
-        if (FIRST) {
-            // conv1a (nets/superpoint.py:120,172) on the fly: this thread's 4 channels of pixel pix from the 3 x 3 image patch, same
-            // fmaf order as sp_conv1a_kernel; pixels outside the image are conv1b's zero padding, not relu(bias)
-            f32x4 wv[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const f32x4*>(p.w1a + t * 64 + sp_c);
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.b1a + sp_c);
-            // the (LH + 2) x (LW + 2) image patch under the tile, zero outside the image (conv1a's own padding), through LDS
-            constexpr int PW = G::LW + 2, PH = G::LH + 2;
-            float* patch = reinterpret_cast<float*>(sp_smem + G::LDS);
-            const float* im = p.img + (size_t)b * H * W;
-            if (tid < PW * PH) {
-                const int py = tid / PW, px = tid - py * PW;
-                const int yy = y0 - G::HALO - 1 + py, xx = x0 - G::HALO - 1 + px;
-                patch[tid] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? im[(size_t)yy * W + xx] : 0.f;
-            }
-            __syncthreads();
-#pragma unroll 2
-            for (int s = 0; s < NPASS; ++s) {
-                const int pix = s * 16 + sp_pix;
-                if (pix >= NPIX) break;
-                const int ly = pix / G::LW, lx = pix - ly * G::LW;
-                const int gy = y0 - G::HALO + ly, gx = x0 - G::HALO + lx;
-                f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                    a = bb;
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) {
-                        const float v = patch[(ly + t / 3) * PW + lx + t % 3];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) a[e] = fmaf(v, wv[t][e], a[e]);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.f);
-                }
-                u32x2 hi, lo;
-                unsigned ua, uc;
-                imp_split2(a[0], a[1], ua, uc); hi[0] = ua; lo[0] = uc;
-                imp_split2(a[2], a[3], ua, uc); hi[1] = ua; lo[1] = uc;
-                unsigned char* dst = sp_smem + (ly * G::ROW_SLOTS + lx * PSLOT) * 16 + sp_c * 2;
-                *reinterpret_cast<u32x2*>(dst) = hi;
-                *reinterpret_cast<u32x2*>(dst + G::PLANE) = lo;
-            }
-        } else
-        {
-            const float* src = p.in + p.in_c0 + chunk * 64 + sp_c;
-            f32x4 v[NPASS];
-#pragma unroll
-            for (int s = 0; s < NPASS; ++s) {
-                const int pix = s * 16 + sp_pix;
-                const int ly = pix / G::LW, lx = pix - ly * G::LW;
-                const int gy = y0 - G::HALO + ly, gx = x0 - G::HALO + lx;
-                const bool ok = pix < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
-                v[s] = f32x4{0.f, 0.f, 0.f, 0.f};                                   // zero padding of the convolution
-                if (ok) v[s] = *reinterpret_cast<const f32x4*>(src + ((size_t)(b * H + gy) * W + gx) * p.in_ld);
-            }
-#pragma unroll
-            for (int s = 0; s < NPASS; ++s) {
-                const int pix = s * 16 + sp_pix;
-                if (pix < NPIX) {
-                    const int ly = pix / G::LW, lx = pix - ly * G::LW;
-                    u32x2 hi, lo;
-                    unsigned a, c;
-                    imp_split2(v[s][0], v[s][1], a, c); hi[0] = a; lo[0] = c;
-                    imp_split2(v[s][2], v[s][3], a, c); hi[1] = a; lo[1] = c;
-                    unsigned char* dst = sp_smem + (ly * G::ROW_SLOTS + lx * PSLOT) * 16 + sp_c * 2;
-                    *reinterpret_cast<u32x2*>(dst) = hi;
-                    *reinterpret_cast<u32x2*>(dst + G::PLANE) = lo;
-                }
-            }
-        }
-        __syncthreads();
-        if (p.prof) { t_staged = __builtin_readcyclecounter(); t_stage_acc += t_staged - (chunk ? t_kdone : t_start); }
-        // K loop of this chunk, software pipelined by hand: the A fragments of k-step s + 1 are requested from LDS before the six
-        // MFMAs of k-step s are issued (sched_barrier keeps the compiler from sinking the reads behind them), the B fragments
-        // of the next tap are requested from L2 at the start of each tap
-        constexpr int NS = TAPS * 4;
-        f16x8 fah[2][2], fal[2][2];
-        auto load_frag = [&](int st, int buf) {
-            const int tap = st >> 2, c = st & 3;
-            const int toff = TAPS == 9 ? ((tap / 3) * G::ROW_SLOTS + (tap % 3) * PSLOT) * 16 : 0;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fah[buf][i] = *reinterpret_cast<const f16x8*>(sp_smem + aoff[i] + toff + c * 32);
-                fal[buf][i] = *reinterpret_cast<const f16x8*>(sp_smem + G::PLANE + aoff[i] + toff + c * 32);
-            }
-        };
-        load_frag(0, 0);
-        u32x4 nh[4], nl[4];
-#pragma unroll
-        for (int st = 0; st < NS; ++st) {
-            const int c = st & 3;
-            if (st + 1 < NS) load_frag(st + 1, (st + 1) & 1);
-            if (c == 0) {
-                const bool last = chunk == nchunk - 1 && st == NS - 4;
-                const u32x4* wnext = wp + (last ? 0 : 512);      // (last tap: harmless re-load)
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) { nh[cc] = wnext[cc * 128]; nl[cc] = wnext[cc * 128 + 64]; }
-                wp = wnext;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            const f16x8 wh = __builtin_bit_cast(f16x8, bh[c]), wl = __builtin_bit_cast(f16x8, bl[c]);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[st & 1][i], wh, acc[i], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[st & 1][i], wl, acc[i], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[st & 1][i], wh, acc[i], 0, 0, 0);
-            if (c == 3) {
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) { bh[cc] = nh[cc]; bl[cc] = nl[cc]; }
-            }
-        }
-        if (p.prof) { t_kdone = __builtin_readcyclecounter(); t_k_acc += t_kdone - t_staged; }
-    }
-
-    // epilogue: accumulator register r of fragment i holds tile row 64 wm + 32 i + 4 half + (r & 3) + 8 (r >> 2), column lane & 31
-    const int ch = ntile * 64 + wn * 32 + (lane & 31);
-    const float bv = p.bias[ch];
-    const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int q = 16 * wm + 8 * i + half + 2 * g;
-            const int qy = q >> 3, qx = q & 7;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[i][4 * g + r] + bv;
-                if (p.relu) v[r] = fmaxf(v[r], 0.f);
-            }
-            if (POOL) {
-                const int py = y0 / 2 + qy, px = x0 / 2 + qx;
-                if (py < Ho && px < Wo) p.out[((size_t)(b * Ho + py) * Wo + px) * p.out_ld + ch] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int y = y0 + 2 * qy + (r >> 1), x = x0 + 2 * qx + (r & 1);
-                    if (y < H && x < W) p.out[((size_t)(b * H + y) * W + x) * p.out_ld + ch] = v[r];
-                }
-            }
-        }
-    if (p.prof && tid == 0) {
-        const unsigned long long t_end = __builtin_readcyclecounter();
-        unsigned long long* o = p.prof + (size_t)blockIdx.x * 4;
-        o[0] = t_stage_acc; o[1] = t_k_acc; o[2] = t_end - t_kdone; o[3] = t_end - t_start;
-    }
-}
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -582,50 +380,6 @@ __global__ __launch_bounds__(256) void sp_conv1a_kernel(const float* __restrict_
 }
 
 // detector head tail (nets/superpoint.py:193-198): convPb (1x1, 256 -> 65) + softmax(65) + drop the dustbin + 8x8 pixel shuffle
-constexpr int DPX = 8;
-__global__ __launch_bounds__(256) void sp_detector_kernel(const float* __restrict__ in, int in_ld, const float* __restrict__ wt /*[256][65]*/,
-                                                          const float* __restrict__ bias, float* __restrict__ scores, int npix, int h, int w) {
-    __shared__ __attribute__((aligned(16))) float xs[DPX][256];
-    __shared__ float lg[DPX][68];
-    __shared__ float red[DPX][2];
-    const int tid = threadIdx.x;
-    const int p0 = blockIdx.x * DPX;
-    for (int i = tid; i < DPX * 64; i += 256) {
-        const int px = i >> 6, k4 = (i & 63) * 4;
-        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p0 + px < npix) v = *reinterpret_cast<const f32x4*>(in + (size_t)(p0 + px) * in_ld + k4);
-        *reinterpret_cast<f32x4*>(&xs[px][k4]) = v;
-    }
-    __syncthreads();
-    for (int o = tid; o < DPX * 65; o += 256) {
-        const int px = o / 65, c = o - px * 65;
-        float s = bias[c];
-        for (int k = 0; k < 256; ++k) s = fmaf(xs[px][k], wt[k * 65 + c], s);
-        lg[px][c] = s;
-    }
-    __syncthreads();
-    if (tid < DPX) {
-        float mx = lg[tid][0];
-        for (int c = 1; c < 65; ++c) mx = fmaxf(mx, lg[tid][c]);
-        float sum = 0.f;
-        for (int c = 0; c < 65; ++c) sum += expf(lg[tid][c] - mx);
-        red[tid][0] = mx;
-        red[tid][1] = sum;
-    }
-    __syncthreads();
-    for (int o = tid; o < DPX * 64; o += 256) {
-        const int px = o >> 6, c = o & 63;
-        const int pi = p0 + px;
-        if (pi >= npix) continue;
-        const int xx = pi % w, yy = (pi / w) % h, b = pi / (w * h);
-        const float v = expf(lg[px][c] - red[px][0]) / red[px][1];
-        scores[((size_t)b * h * 8 + yy * 8 + (c >> 3)) * (size_t)(w * 8) + xx * 8 + (c & 7)] = v;
-    }
-}
-
-
-// detector tail after the MFMA 1x1 convolution (convPb, 65 outputs padded to 128): softmax over the 65 bins, dustbin dropped, 8x8
-// pixel shuffle (nets/superpoint.py:194-198).  One wave per cell of the h x w grid: lane c holds bin c, the dustbin is read by all.
 __global__ __launch_bounds__(256) void sp_softmax_shuffle_kernel(const float* __restrict__ logits /*[npix][128]*/, float* __restrict__ scores,
                                                                  int npix, int h, int w) {
     const int lane = threadIdx.x & 63;
@@ -1171,26 +925,6 @@ __global__ __launch_bounds__(256) void sp_dense_desc_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------------------ host side
-// A/B and probe switches, read from the environment once per process (README: knobs)
-struct SpSwitches {
-    bool prof, conv_v1, unfused_conv1a, detector_valu, nms_generic;
-    int tile;   // 0 = by rule, 8 or 16 forced
-};
-const SpSwitches& sp_switches() {
-    static const SpSwitches sw = [] {
-        SpSwitches x;
-        x.prof = getenv("IMP_SP_PROF") != nullptr;
-        x.conv_v1 = getenv("IMP_SP_CONV_V1") != nullptr;
-        x.unfused_conv1a = getenv("IMP_SP_UNFUSED_CONV1A") != nullptr;
-        x.detector_valu = getenv("IMP_SP_DETECTOR_VALU") != nullptr;
-        x.nms_generic = getenv("IMP_SP_NMS_GENERIC") != nullptr;
-        const char* t = getenv("IMP_SP_TILE");
-        x.tile = t ? atoi(t) : 0;
-        return x;
-    }();
-    return sw;
-}
-
 struct ConvW {
     u32x4* wf = nullptr;
     float* bias = nullptr;
@@ -1294,22 +1028,6 @@ int launch_convp(SpConvParams p, int total, int tiles_x, int ncu, hipStream_t st
     constexpr size_t ldsp = 2 * GeoT<TAPS, TWc>::LDS + (FIRST ? 2048 : 0);
     const void* fnp = reinterpret_cast<const void*>(&sp_convp_kernel<TAPS, POOL, FIRST, TWc>);
     SP_TRY(imp_grant_dynamic_lds(fnp, ldsp));
-    if (sp_switches().prof) {                                           // probe: phase cycle counts per workgroup, printed per launch
-        SpConvParams q = p;
-        SP_TRY(hipMalloc(&q.prof, (size_t)nwg * 8 * sizeof(unsigned long long)));
-        hipLaunchKernelGGL((sp_convp_kernel<TAPS, POOL, FIRST, TWc>), dim3(nwg), dim3(512), ldsp, st, q, total);
-        SP_TRY(hipStreamSynchronize(st));
-        std::vector<unsigned long long> h((size_t)nwg * 8);
-        SP_TRY(hipMemcpy(h.data(), q.prof, h.size() * 8, hipMemcpyDeviceToHost));
-        (void)hipFree(q.prof);
-        double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < nwg; ++i)
-            for (int j = 0; j < 8; ++j) a[j] += (double)h[(size_t)i * 8 + j] / nwg;
-        fprintf(stderr, "[sp_convp<%d,%d,%d,%d> %dx%d cin %d cout %d: %d jobs on %d workgroups, %.1f units each] mean cycles PER UNIT: consumer K loop %.0f "
-                "epilogue %.0f barrier wait %.0f | loader staging %.0f barrier wait %.0f\n", TAPS, POOL, FIRST, TWc, p.H, p.W, p.cin, p.cout, total, nwg, a[3],
-                a[0] / a[3], a[1] / a[3], a[2] / a[3], a[4] / a[7], a[6] / a[7]);
-        return IMP_OK;
-    }
     hipLaunchKernelGGL((sp_convp_kernel<TAPS, POOL, FIRST, TWc>), dim3(nwg), dim3(512), ldsp, st, p, total);
     SP_TRY(hipGetLastError());
     return IMP_OK;
@@ -1318,7 +1036,7 @@ int launch_convp(SpConvParams p, int total, int tiles_x, int ncu, hipStream_t st
 template <int TAPS, int POOL, int FIRST>
 int launch_conv_t(const SpConvParams& p, hipStream_t st) {
     const int total = p.B * p.tiles_x * p.tiles_y * (p.cout / 64);
-    if (!sp_switches().conv_v1) {                                       // (A/B: IMP_SP_CONV_V1 = the one-tile-per-workgroup kernel)
+    {
         int dev = 0;
         SP_TRY(hipGetDevice(&dev));
         static int ncu_of[64] = {0};                                      // CU count per device, looked up once
@@ -1334,31 +1052,9 @@ int launch_conv_t(const SpConvParams& p, hipStream_t st) {
         const int tx8 = (p.W + 7) / 8;
         const int jobs16 = total, jobs8 = p.B * tx8 * p.tiles_y * (p.cout / 64);
         const double t16 = (double)((jobs16 + ncu - 1) / ncu), t8 = 0.55 * (double)((jobs8 + ncu - 1) / ncu);
-        const int force = sp_switches().tile;
-        const bool narrow = force ? force == 8 : t8 < t16;
+        const bool narrow = t8 < t16;
         return narrow ? launch_convp<TAPS, POOL, FIRST, 8>(p, jobs8, tx8, ncu, st) : launch_convp<TAPS, POOL, FIRST, 16>(p, jobs16, p.tiles_x, ncu, st);
     }
-    const void* fn = reinterpret_cast<const void*>(&sp_conv_kernel<TAPS, POOL, FIRST>);
-    constexpr size_t lds = Geo<TAPS>::LDS + (FIRST ? 1024 : 0);       // + the image patch of the fused conv1a
-    SP_TRY(imp_grant_dynamic_lds(fn, lds));
-    if (sp_switches().prof) {                                           // probe: phase cycle counts per workgroup, printed per launch
-        SpConvParams q = p;
-        SP_TRY(hipMalloc(&q.prof, (size_t)total * 4 * sizeof(unsigned long long)));
-        hipLaunchKernelGGL((sp_conv_kernel<TAPS, POOL, FIRST>), dim3(total), dim3(256), lds, st, q, total);
-        SP_TRY(hipStreamSynchronize(st));
-        std::vector<unsigned long long> h((size_t)total * 4);
-        SP_TRY(hipMemcpy(h.data(), q.prof, h.size() * 8, hipMemcpyDeviceToHost));
-        (void)hipFree(q.prof);
-        double a[4] = {0, 0, 0, 0};
-        for (int i = 0; i < total; ++i)
-            for (int j = 0; j < 4; ++j) a[j] += (double)h[(size_t)i * 4 + j] / total;
-        fprintf(stderr, "[sp_conv<%d,%d,%d> %dx%d cin %d cout %d: %d workgroups] mean cycles: staging %.0f  K loop %.0f  epilogue %.0f  total %.0f\n", TAPS, POOL,
-                FIRST, p.H, p.W, p.cin, p.cout, total, a[0], a[1], a[2], a[3]);
-        return IMP_OK;
-    }
-    hipLaunchKernelGGL((sp_conv_kernel<TAPS, POOL, FIRST>), dim3(total), dim3(256), lds, st, p, total);
-    SP_TRY(hipGetLastError());
-    return IMP_OK;
 }
 
 int launch_conv(const ConvW& w, const float* in, int in_ld, int in_c0, int B, int H, int W, float* out, int out_ld, int relu, int pool, hipStream_t st) {
@@ -1541,12 +1237,7 @@ int imp_sp_detect(imp_sp_ctx* c, const float* image, int B, int H, int W, int nm
     c->align_corners = align_corners ? 1 : 0;
     int rc;
     // encoder (nets/superpoint.py:172-183)
-    if (sp_switches().unfused_conv1a) {
-        const size_t nthr = (size_t)B * H * W * 16;
-        hipLaunchKernelGGL(sp_conv1a_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, image, c->w1a, c->b1a, c->bufA, B, H, W);
-        SP_TRY(hipGetLastError());
-        if ((rc = launch_conv(c->c1b, c->bufA, 64, 0, B, H, W, c->bufB, 64, 1, 1, st))) return rc;
-    } else if ((rc = launch_conv_first(c, image, B, H, W, c->bufB, st))) return rc;                     // conv1a + conv1b -> [H2][W2][64]
+    if ((rc = launch_conv_first(c, image, B, H, W, c->bufB, st))) return rc;                     // conv1a + conv1b -> [H2][W2][64]
     if ((rc = launch_conv(c->c2a, c->bufB, 64, 0, B, H2, W2, c->bufA, 64, 1, 0, st))) return rc;
     if ((rc = launch_conv(c->c2b, c->bufA, 64, 0, B, H2, W2, c->bufB, 64, 1, 1, st))) return rc;        // -> [H4][W4][64]
     if ((rc = launch_conv(c->c3a, c->bufB, 64, 0, B, H4, W4, c->bufA, 128, 1, 0, st))) return rc;
@@ -1557,14 +1248,10 @@ int imp_sp_detect(imp_sp_ctx* c, const float* image, int B, int H, int W, int nm
     if ((rc = launch_conv(c->heads, c->bufB, 128, 0, B, h, w, c->bufA, 512, 1, 0, st))) return rc;
     if ((rc = launch_conv(c->db, c->bufA, 512, 256, B, h, w, c->dmap, c->ddim, 0, 0, st))) return rc;   // raw convDb (:224)
     const int npix = B * h * w;
-    if (sp_switches().detector_valu) {
-        hipLaunchKernelGGL(sp_detector_kernel, dim3((npix + DPX - 1) / DPX), dim3(256), 0, st, c->bufA, 512, c->wpb, c->bpb, c->scores, npix, h, w);
-    } else {
-        if ((rc = launch_conv(c->pb, c->bufA, 512, 0, B, h, w, c->logits, 128, 0, 0, st))) return rc;     // convPb logits (:193)
-        hipLaunchKernelGGL(sp_softmax_shuffle_kernel, dim3((npix + 3) / 4), dim3(256), 0, st, c->logits, c->scores, npix, h, w);
-    }
+    if ((rc = launch_conv(c->pb, c->bufA, 512, 0, B, h, w, c->logits, 128, 0, 0, st))) return rc;     // convPb logits (:193)
+    hipLaunchKernelGGL(sp_softmax_shuffle_kernel, dim3((npix + 3) / 4), dim3(256), 0, st, c->logits, c->scores, npix, h, w);
     SP_TRY(hipGetLastError());
-    const bool nms_fast = nms_radius >= 1 && nms_radius <= 6 && !sp_switches().nms_generic;
+    const bool nms_fast = nms_radius >= 1 && nms_radius <= 6;      // (larger radii: the generic kernel)
     if (nms_fast) {
         switch (nms_radius) {
             case 1: rc = launch_nms_fast<1>(c->scores, c->nms, B, Hs, Ws, keypoint_threshold, remove_borders, c->tilecount, st); break;

@@ -107,7 +107,7 @@ int imp_get_precision(imp_ctx* ctx);
  * (sign, exponent, 15 mantissa bits, round to nearest even) - 3/4 of the bytes of the HBM-bound loop.  The returned
  * scores p.u.v and the match maxima are formed from the fp32 matrix either way; with 3, u and v (and so every score)
  * move by ~1e-5 RELATIVE (measured: match scores <= 1.2e-5 from the reference, indices identical), i.e. O(N)-sized
- * dustbin entries move by ~1e-5 N.  Environment default at imp_create: IMP_OT_COMPACT=1 selects 3. */
+ * dustbin entries move by ~1e-5 N. */
 int imp_set_sinkhorn_storage(imp_ctx* ctx, int bytes_per_element);
 
 /* number of schema keys / i-th key (so a host can enumerate what strict loading expects) */
@@ -206,7 +206,7 @@ int imp_gather_rows(imp_ctx* ctx, int batch, int n_in, int n_out, int dim, const
  * normalised), encode, all GNN layers, final_proj[n_layers-1], Sinkhorn / dual-softmax, mutual matches.
  * Nothing is synchronised or allocated once the workspace is sized, so the call can be recorded into a hipGraph (stream capture) and
  * replayed: the chip-resident Sinkhorn launch is recorded too (its exchange tags live in device memory and advance with every
- * replay; IMP_OT_GRAPH=0: the streaming kernels instead).  Such a graph must not be replayed while another resident launch of the
+ * replay; option ot_graph = 0: the streaming kernels instead).  Such a graph must not be replayed while another resident launch of the
  * process runs - a collision is reported like any voided resident launch (NaN scores, IMP_E_RESIDENT at the next entry point).
  * A graph records the exchange protocol the context used at capture time: after an IMP_E_RESIDENT the context has stepped down to a
  * safer one, and graphs captured before that must be captured again (replaying them would time out again on every replay).
@@ -335,10 +335,17 @@ int imp_op_fused_mlp(imp_ctx* ctx, int B, int M, const float* x, const float* a,
                      const float* b3, const float* W2, const float* b2, int N2, float* y, float* y2, int fake, void* stream);
 int imp_op_attention(imp_ctx* ctx, int batch, int nq, int nk, int dim, const float* qkv_q,
                      const float* qkv_kv, const uint8_t* key_mask, float* out, float* lse, void* stream);
-/* test / probe hook, not part of the operator interface (a plain int of the library): which staging variant of the ping-pong attention kernel the launches that follow take
- * when K / V are split-half images at head width 64 - 1: the ring is filled by LDS-DMA, 0: through registers, -1 (default): the environment (IMP_ATTN_DMA) or the build's default
- * (off).  Same bits either way (tests/test_gpu_parity.py test_lds_dma_staging_of_the_attention_ring_is_bit_identical, tools/probe/attn_dma_check.hip). */
-extern int imp_attn_dma_override;
+/* Named switches of a context, to be set before its first compute call; not part of the reference's operator interface (the reference's eval scripts know nothing like it).  The
+ * paths they select are the ones a context steps down to BY ITSELF after a voided waiting launch - forced here for A/B tests - and the test suite's fault hooks:
+ *   ot_resident 0|1   chip-resident Sinkhorn kernel (0: streaming kernels)          ot_local / ot_hier 0|1   its XCD-local / two-XCD decompositions
+ *   ot_verify 0|1     wait for every resident launch and repair it inside the call   ot_graph 0|1             0: hipGraph captures record the streaming Sinkhorn
+ *   gemm_wf 0|1|2     weight-fragment GEMMs (0: plain tiled GEMMs, 2: at every size)  wf_chain 0|1, wf_chain_min   MLP3 + next projection in one launch
+ *   wf_fused 0|1, wf_fused_min   the layer's MLP in one launch with the in-kernel InstanceNorm statistics exchange
+ *   kv_image 0|1      k | v written as split-half images by the projection          probe_prof 0|1           timing entry points print a profiling build's stamps
+ *   ot_fake_placement, wf_fused_fake, ot_graph_tag0       fault injection (tests/test_gpu_resident_ot.py, tests/test_gpu_parity.py)
+ * The environment knows three switches only - IMP_PRECISION=f32, IMP_OT_RESIDENT=0, IMP_WF_FUSED=0 (a process that shares the GPU turns the two waiting kernels
+ * off) - plus IMP_OPTIONS="name=value,..." which applies a list of the above to every context the process creates.  Unknown name: IMP_E_ARG. */
+int imp_ctx_option(imp_ctx* ctx, const char* name, long value);
 /* timing hooks for bench.py: hipEvent-bracketed repetition of one attention / one Sinkhorn pass on
  * the context's own stream-ordered workspace; returns average milliseconds per launch in *ms. */
 int imp_time_attention(imp_ctx* ctx, int batch, int n, int reps, float* ms, void* stream);
@@ -393,7 +400,7 @@ void imp_pose_stats(long* calls, long* samples, int reset);
  * earlier call are void, re-run the batch.
  *  imp_resident_health: the same check on demand (after the caller synchronised, e.g. after its D2H copy of the matches);
  *    *timeouts = voided launches so far, *level = 0 all protocols / 1 chip-wide exchange only / 2 streaming kernels only.
- *  imp_set_resident_verify(1) (or IMP_OT_VERIFY=1): every resident launch is awaited inside the call and a voided one is
+ *  imp_set_resident_verify(1) (or option ot_verify = 1): every resident launch is awaited inside the call and a voided one is
  *    re-run there on the next protocol down - calls then always return valid results, at the price of one host
  *    synchronisation per score.
  *  imp_resident_status: raw flag after a device synchronisation (tests / bench). */
@@ -437,7 +444,7 @@ int imp_range_recovered(imp_ctx* ctx);
  * its own later entry points already reported as IMP_E_RANGE).  The Python modules do this for the all-iterations path. */
 int imp_range_take(imp_ctx* ctx, int recovered);
 /* how many times the tag counter of hipGraph-REPLAYED resident launches wrapped (about every 7 million replays at 100 Sinkhorn iterations;
- * the library clears the exchange buffers at the next entry point - not an error).  Test hook: IMP_OT_GRAPH_TAG0=<first tag>. */
+ * the library clears the exchange buffers at the next entry point - not an error).  Test hook: option ot_graph_tag0=<first tag>. */
 int imp_tag_wraps(imp_ctx* ctx);
 
 /* ---------------------------------------------------------------------------------------------------------------------------

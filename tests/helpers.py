@@ -209,6 +209,27 @@ def make_reader_records(seed: int = 0, n_pairs: int = 3, desc_dim: int = 32):
     return recs
 
 
+class lib_options:
+    """contexts created inside the block take these named switches (include/imp_hip.h imp_ctx_option; IMP_OPTIONS is read when a context is created):
+    with lib_options(gemm_wf=2, wf_chain_min=1): m = make_hip_model(...); m._ensure_ctx()"""
+
+    def __init__(self, **opts):
+        self.value = ','.join(f'{k}={v}' for k, v in opts.items())
+
+    def __enter__(self):
+        self.old = os.environ.get('IMP_OPTIONS')
+        if self.value:
+            os.environ['IMP_OPTIONS'] = self.value
+        return self
+
+    def __exit__(self, *exc):
+        if self.old is None:
+            os.environ.pop('IMP_OPTIONS', None)
+        else:
+            os.environ['IMP_OPTIONS'] = self.old
+        return False
+
+
 HARD_SET = []      # summary lines of tests/test_gpu_hard_loops.py (conftest prints them at the end of the run)
 
 

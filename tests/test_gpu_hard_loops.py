@@ -71,7 +71,7 @@ def _done(n, label):
     import helpers
     helpers.HARD_SET.append(f'{label}: {n - len(on_edge)} of {n} pairs = the reference in every decision and index; {len(on_edge)} leave its trajectory at a pool '
                             f'decision closer than {TIE:g} to the threshold' + (f'; {len(msgs)} FAIL' if msgs else ''))
-    helpers.HARD_SET.extend('    ' + text for _, text in edge)
+    helpers.HARD_SET.extend('    ' + text for text in dict.fromkeys(t for _, t in edge))
     assert not msgs, f'{len(msgs)} of {n} pairs differ from the reference:\n  ' + '\n  '.join(msgs)
     assert len(on_edge) <= n // 3, f'{len(on_edge)} of {n} pairs leave the reference at an edge decision: too many for fp32 noise'
 

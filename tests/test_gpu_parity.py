@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import build_case, compare_matches, eval_config, golden_names, load_golden, make_hip_model
+from helpers import build_case, compare_matches, eval_config, golden_names, lib_options, load_golden, make_hip_model
 from imp_release_amd import eval_loop, matching as hip_matching, synthetic
 from oracle import imp_oracle as orc
 
@@ -431,7 +431,7 @@ def test_fused_call_is_hip_graph_capturable():
     graph and replayed.  Since round 3 a capture records the chip-resident Sinkhorn too - on the capturing stream itself, with its
     exchange tags and XCC tickets taken from device memory and advanced by the launch's last workgroup, so that every replay
     exchanges under fresh tags: five replays, each bitwise equal to the eager resident call, then an eager call,
-    then a replay again (both kinds of launch share the exchange buffers).  IMP_OT_GRAPH=0 keeps the round-2 behaviour (the capture
+    then a replay again (both kinds of launch share the exchange buffers).  option ot_graph = 0 keeps the round-2 behaviour (the capture
     records the streaming kernels): bitwise equal to the eager streaming path."""
     import os
     cfg = eval_config(n_layers=3)
@@ -443,12 +443,9 @@ def test_fused_call_is_hip_graph_capturable():
         ms._ensure_ctx()
     finally:
         del os.environ['IMP_OT_RESIDENT']
-    os.environ['IMP_OT_GRAPH'] = '0'
-    try:
+    with lib_options(ot_graph=0):
         mg0 = make_hip_model('DGNNS', cfg, sd)
         mg0._ensure_ctx()
-    finally:
-        del os.environ['IMP_OT_GRAPH']
     pair = synthetic.make_correlated_pair(300, 280, seed=9, batch=2)
     d = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
     args = (d['keypoints0'], d['scores0'], d['descriptors0'], d['keypoints1'], d['scores1'], d['descriptors1'],
@@ -486,17 +483,14 @@ def test_fused_call_is_hip_graph_capturable():
 def test_graph_replays_survive_the_tag_wrap():
     """the replayed resident launches take their exchange tags from a device-side counter in the upper half of the 32-bit
     space; after ~7 million replays it starts over.  The launch that wraps it tells the library (word 2 of the mapped health page), and
-    the next entry point clears the exchange buffers so that no old tag can be met again.  IMP_OT_GRAPH_TAG0 (test hook) starts the
+    the next entry point clears the exchange buffers so that no old tag can be met again.  option ot_graph_tag0 (test hook) starts the
     counter two launches short of the wrap: replays before, across and after it - and eager calls in between - stay bitwise equal."""
     import os
     cfg = eval_config(n_layers=3)
     sd = synthetic.make_state_dict(cfg, 'DGNNS', seed=2)
-    os.environ['IMP_OT_GRAPH_TAG0'] = hex(0xFFFFF000 - 2 * (3 * 20 + 4) - 8)
-    try:
+    with lib_options(ot_graph_tag0=hex(0xFFFFF000 - 2 * (3 * 20 + 4) - 8)):
         m = make_hip_model('DGNNS', cfg, sd)
         ctx = m._ensure_ctx()
-    finally:
-        del os.environ['IMP_OT_GRAPH_TAG0']
     pair = synthetic.make_correlated_pair(300, 280, seed=9, batch=2)
     d = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
     args = (d['keypoints0'], d['scores0'], d['descriptors0'], d['keypoints1'], d['scores1'], d['descriptors1'],
@@ -529,20 +523,15 @@ WF_FIXTURES = ['gm_l3_alliters_b2', 'gm_l3_bigmean', 'gm_l9_t100_ragged', 'dgnns
 
 @pytest.mark.parametrize('name', WF_FIXTURES)
 def test_weight_fragment_gemms_forced_vs_golden(name):
-    """csrc/gemm_wf.hip takes over the layer convolutions only for launches that cover the chip (IMP_GEMM_WF=1, default); forced
+    """csrc/gemm_wf.hip takes over the layer convolutions only for launches that cover the chip (option gemm_wf = 1, default); forced
     on everywhere (=2) it has to reproduce the reference fixtures like the default kernels do: ragged row counts, batch 2,
     |mean| >> std channels in front of the InstanceNorm (its per-block (sum, M2) statistics), attention-sharing layers"""
     import os
     spec, z = load_golden(name)
     cfg, sd, data = build_case(spec, device=DEV)
-    os.environ['IMP_GEMM_WF'] = '2'
-    os.environ['IMP_WF_CHAIN_MIN'] = '1'        # ... and the chained launch (conv 3 + the next layer's projection) at every size
-    try:
+    with lib_options(gemm_wf=2, wf_chain_min=1):        # ... and the chained launch (conv 3 + the next layer's projection) at every size
         m = make_hip_model(spec, cfg, sd)
         m._ensure_ctx()
-    finally:
-        del os.environ['IMP_GEMM_WF']
-        del os.environ['IMP_WF_CHAIN_MIN']
     with torch.no_grad():
         out = m.produce_matches(data, **spec.get('call', {}))
     for i in range(int(z['n_emitted'])):
@@ -559,17 +548,11 @@ def test_chained_projection_is_bit_identical_to_the_separate_launches(model, n0,
     cfg = eval_config(n_layers=5 if model == 'DGNNS' else 3, sinkhorn_iterations=20)
     sd = synthetic.make_state_dict(cfg, model, seed=8)
     models = []
-    for chain in ('1', '0'):
-        os.environ['IMP_GEMM_WF'] = '2'
-        os.environ['IMP_WF_CHAIN'] = chain
-        os.environ['IMP_WF_CHAIN_MIN'] = '1'
-        try:
+    for chain in (1, 0):
+        with lib_options(gemm_wf=2, wf_chain=chain, wf_chain_min=1):
             m = make_hip_model(model, cfg, sd)
             m._ensure_ctx()
             models.append(m)
-        finally:
-            for k in ('IMP_GEMM_WF', 'IMP_WF_CHAIN', 'IMP_WF_CHAIN_MIN'):
-                del os.environ[k]
     pair = synthetic.make_correlated_pair(n0, n1, seed=n0 + B, batch=B)
     data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
     data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
@@ -579,18 +562,13 @@ def test_chained_projection_is_bit_identical_to_the_separate_launches(model, n0,
     assert torch.equal(a['indices0'][-1], b['indices0'][-1]) and torch.equal(a['mscores0'][-1], b['mscores0'][-1])
 
 
-def _two_models(model, cfg, sd, env_a, env_b):
-    import os
+def _two_models(model, cfg, sd, opts_a, opts_b):
     out = []
-    for env in (env_a, env_b):
-        os.environ.update(env)
-        try:
+    for opts in (opts_a, opts_b):
+        with lib_options(**opts):
             m = make_hip_model(model, cfg, sd)
             m._ensure_ctx()
             out.append(m)
-        finally:
-            for k in env:
-                del os.environ[k]
     return out
 
 
@@ -600,11 +578,11 @@ def test_fused_layer_launch_is_bit_identical_to_the_two_launch_path(model, n0, n
     """round 4: a layer's MLP0 -> InstanceNorm -> MLP3 (-> next projection) as ONE launch with an in-kernel statistics exchange
     (gemm_wf.hip gemm_wf_fused_kernel) against the round-3 path (MLP0 with last-arriver statistics, then MLP3 + chain): the same
     arithmetic on the same operands in the same order - matches, match scores and the whole score tensor must agree bit for bit.
-    Forced on for the small shapes (IMP_WF_FUSED_MIN=1; attention-sharing layers, the masked AdaGMN loop, ragged images)."""
+    Forced on for the small shapes (option wf_fused_min = 1; attention-sharing layers, the masked AdaGMN loop, ragged images)."""
     cfg = eval_config(n_layers=5 if model != 'GM' else 3, sinkhorn_iterations=20)
     sd = synthetic.make_state_dict(cfg, model, seed=8, bin_score=5.0 if model == 'AdaGMN' else 1.0)
-    base = {'IMP_GEMM_WF': '2', 'IMP_WF_CHAIN_MIN': '1'}
-    fused, plain = _two_models(model, cfg, sd, dict(base, IMP_WF_FUSED='1', IMP_WF_FUSED_MIN='1'), dict(base, IMP_WF_FUSED='0'))
+    base = {'gemm_wf': 2, 'wf_chain_min': 1}
+    fused, plain = _two_models(model, cfg, sd, dict(base, wf_fused=1, wf_fused_min=1), dict(base, wf_fused=0))
     pair = synthetic.make_correlated_pair(n0, n1, seed=n0 + B, batch=B)
     data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
     data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
@@ -619,47 +597,15 @@ def test_fused_layer_launch_is_bit_identical_to_the_two_launch_path(model, n0, n
     assert fused._ensure_ctx().resident_health() == (0, 0)
 
 
-@pytest.mark.parametrize('model,n0,n1,B', [('GM', 2048, 2048, 4), ('GM', 1000, 1990, 3), ('DGNNS', 700, 900, 2), ('AdaGMN', 420, 400, 1), ('GM', 130, 97, 2)])
-def test_lds_dma_staging_of_the_attention_ring_is_bit_identical(model, n0, n1, B):
-    """round 5: the ping-pong attention kernel with its K / V ring filled by LDS-DMA (attention_f16x3.hip, template parameter DMA; IMP_ATTN_DMA=1, off by
-    default) against the register-staged kernel: only the way a tile's bytes reach the LDS differs - matches, match scores and the score tensor agree bit for
-    bit (full and partial last key tiles, the masked AdaGMN loop, ragged images, attention-sharing layers; tools/probe/attn_dma_check.hip is the kernel-level twin)."""
-    import ctypes
-    from imp_release_amd import _lib
-    word = ctypes.c_int.in_dll(_lib.lib(), 'imp_attn_dma_override')
-    cfg = eval_config(n_layers=5 if model != 'GM' else 3, sinkhorn_iterations=20)
-    sd = synthetic.make_state_dict(cfg, model, seed=8, bin_score=5.0 if model == 'AdaGMN' else 1.0)
-    m = make_hip_model(model, cfg, sd)
-    pair = synthetic.make_correlated_pair(n0, n1, seed=n0 + B, batch=B)
-    data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
-    data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
-    kw = dict(p=0.2) if model == 'AdaGMN' else dict(p=0.2, only_last=True)
-    out = []
-    try:
-        for v in (0, 1):
-            word.value = v
-            with torch.no_grad():
-                o = m.produce_matches(data, **kw)
-            torch.cuda.synchronize()
-            out.append(o)
-    finally:
-        word.value = -1
-    a, b = out
-    assert int((a['indices0'][-1] >= 0).sum()) > 0 and torch.isfinite(a['mscores0'][-1]).all()
-    assert torch.equal(a['indices0'][-1], b['indices0'][-1]) and torch.equal(a['mscores0'][-1], b['mscores0'][-1])
-    if a.get('scores'):
-        assert torch.equal(a['scores'][-1], b['scores'][-1])
-
-
 def test_fused_layer_time_out_voids_the_call_and_steps_the_context_down():
-    """IMP_WF_FUSED_FAKE=1 (test hook): one workgroup of every fused launch withholds its statistics, so every wait on them times
+    """option wf_fused_fake = 1 (test hook): one workgroup of every fused launch withholds its statistics, so every wait on them times
     out.  The call still ends (bounded polls), the pair whose exchange failed comes back VOID (NaN descriptors -> no matches - never plausible numbers), the next
     entry point on the context reports it (IMP_E_RESIDENT -> ResidentSinkhornTimeout), and from then on the context runs the
     two-launch path: identical to a context that never used the fused kernel."""
     from imp_release_amd import _lib
     cfg = eval_config(n_layers=3, sinkhorn_iterations=20)
     sd = synthetic.make_state_dict(cfg, 'GM', seed=8)
-    fake, plain = _two_models('GM', dict(cfg, range_recovery=False), sd, {'IMP_WF_FUSED_FAKE': '1'}, {'IMP_WF_FUSED': '0'})      # (range_recovery=False: the never-waiting library; the default repairs the call - next test)
+    fake, plain = _two_models('GM', dict(cfg, range_recovery=False), sd, {'wf_fused_fake': 1}, {'wf_fused': 0})      # (range_recovery=False: the never-waiting library; the default repairs the call - next test)
     pair = synthetic.make_correlated_pair(2048, 2048, seed=5, batch=4)
     data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
     data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
@@ -687,7 +633,7 @@ def test_fused_layer_time_out_is_repaired_inside_the_same_call():
     data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
     data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
     for only_last in (True, False):
-        fake, plain = _two_models('GM', cfg, sd, {'IMP_WF_FUSED_FAKE': '1'}, {'IMP_WF_FUSED': '0'})
+        fake, plain = _two_models('GM', cfg, sd, {'wf_fused_fake': 1}, {'wf_fused': 0})
         with torch.no_grad():
             got = fake.produce_matches(data, p=0.2, only_last=only_last)
             want = plain.produce_matches(data, p=0.2, only_last=only_last)
@@ -702,7 +648,7 @@ def test_fused_layer_time_out_is_repaired_inside_the_same_call():
             assert ctx.resident_repaired() == 1
             print('post-mortem of the withheld statistics record:', pm)
     # step API: the layer call itself is repaired
-    fake, plain = _two_models('GM', cfg, sd, {'IMP_WF_FUSED_FAKE': '1'}, {'IMP_WF_FUSED': '0'})
+    fake, plain = _two_models('GM', cfg, sd, {'wf_fused_fake': 1}, {'wf_fused': 0})
     outs = []
     for m in (fake, plain):
         with torch.no_grad():
@@ -723,12 +669,9 @@ def test_weight_fragment_gemms_default_rule_agrees_with_gemm_f32():
     cfg = eval_config(n_layers=3, sinkhorn_iterations=20)
     sd = synthetic.make_state_dict(cfg, 'GM', seed=3)
     on = make_hip_model('GM', cfg, sd)
-    os.environ['IMP_GEMM_WF'] = '0'
-    try:
+    with lib_options(gemm_wf=0):
         off = make_hip_model('GM', cfg, sd)
         off._ensure_ctx()
-    finally:
-        del os.environ['IMP_GEMM_WF']
     pair = synthetic.make_correlated_pair(2048, 2048, seed=77, batch=4)
     data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
     data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)
@@ -911,19 +854,16 @@ def test_odd_and_tiny_shapes_vs_oracle(model, precision):
 @pytest.mark.parametrize('model,n0,n1,B', [('GM', 1024, 1000, 2), ('DGNNS', 300, 280, 1), ('GM', 150, 97, 3)])
 def test_kv_split_half_images_do_not_change_the_matches(model, n0, n1, B):
     """round 3: the projections write K / V as the split-half image [hi | lo] the attention kernel used to build while staging.  The
-    matrix pipe sees bit-identical operands either way, so a one-shot match is IDENTICAL with the round-2 format (IMP_KV_IMAGE=0);
+    matrix pipe sees bit-identical operands either way, so a one-shot match is IDENTICAL with the round-2 format (option kv_image = 0);
     (sizes <= 192 queries additionally move from the lock-step kernels to the ping-pong kernel: another summation order)"""
     import os
     cfg = eval_config(n_layers=5 if model == 'DGNNS' else 3, sinkhorn_iterations=20)
     sd = synthetic.make_state_dict(cfg, model, seed=12)
     on = make_hip_model(model, cfg, sd)
     on._ensure_ctx()
-    os.environ['IMP_KV_IMAGE'] = '0'
-    try:
+    with lib_options(kv_image=0):
         off = make_hip_model(model, cfg, sd)
         off._ensure_ctx()
-    finally:
-        del os.environ['IMP_KV_IMAGE']
     pair = synthetic.make_correlated_pair(n0, n1, seed=n0 + B, batch=B)
     data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}
     data['image0'] = data['image1'] = torch.zeros(pair['image_shape'], device=DEV)

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import compare_matches, eval_config, make_hip_model
+from helpers import compare_matches, eval_config, lib_options, make_hip_model
 from imp_release_amd import synthetic
 from oracle import imp_oracle as orc
 
@@ -163,17 +163,14 @@ def test_pairs_in_flight_share_the_resident_lane():
 @pytest.mark.parametrize('n0,n1,B,T', [(1024, 1024, 1, 100), (1024, 1000, 4, 50), (700, 760, 8, 20), (512, 519, 3, 100), (1024, 1300, 2, 20)])
 def test_xcd_local_launch_agrees_with_the_chip_wide_one(n0, n1, B, T):
     """pairs that fit the 32 CUs of one XCD run XCD-local (plain stores, L2-served polls, pair = block % 8); the same shapes with
-    IMP_OT_LOCAL=0 spread every pair over the chip.  Another decomposition (fewer, taller workgroups) = another summation order:
+    option ot_local = 0 spread every pair over the chip.  Another decomposition (fewer, taller workgroups) = another summation order:
     scores agree to 1e-6, the exchange never times out"""
     cfg = eval_config(n_layers=1, sinkhorn_iterations=T)
     sd = synthetic.make_state_dict(cfg, 'GM', seed=7)
     loc = make_hip_model('GM', cfg, sd)
-    os.environ['IMP_OT_LOCAL'] = '0'
-    try:
+    with lib_options(ot_local=0):
         glob = make_hip_model('GM', cfg, sd)
         glob._ensure_ctx()
-    finally:
-        del os.environ['IMP_OT_LOCAL']
     dist = _dist(B, n0, n1, n0 + B).to(DEV)
     with torch.no_grad():
         a = loc.compute_score(dist, loc.bin_score, T)
@@ -192,12 +189,9 @@ def _fake_placement_model(recovery=False, model='GM', n_layers=2):
     sd = synthetic.make_state_dict(cfg, model, seed=5)
     good = make_hip_model(model, cfg, sd)
     good._ensure_ctx()
-    os.environ['IMP_OT_FAKE_PLACEMENT'] = '1'            # LOCAL workgroups lie about the XCC they run on (ot_resident.hip)
-    try:
+    with lib_options(ot_fake_placement=1):            # LOCAL workgroups lie about the XCC they run on (ot_resident.hip)
         bad = make_hip_model(model, dict(cfg, range_recovery=recovery), sd)
         bad._ensure_ctx()
-    finally:
-        del os.environ['IMP_OT_FAKE_PLACEMENT']
     return good, bad
 
 
@@ -302,12 +296,9 @@ def test_the_loop_recomputes_a_voided_score():
     cfg = eval_config(n_layers=15, sinkhorn_iterations=20)
     sd = synthetic.make_state_dict(cfg, 'DGNNS', seed=3)
     good = make_hip_model('DGNNS', cfg, sd)
-    os.environ['IMP_OT_FAKE_PLACEMENT'] = '1'
-    try:
+    with lib_options(ot_fake_placement=1):
         bad = make_hip_model('DGNNS', cfg, sd)
         bad._ensure_ctx()
-    finally:
-        del os.environ['IMP_OT_FAKE_PLACEMENT']
     pair = synthetic.make_correlated_pair(600, 580, seed=9)
     def run(m):
         data = {k: torch.from_numpy(v).to(DEV) for k, v in pair.items() if k != 'image_shape'}

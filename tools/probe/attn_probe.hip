@@ -10,7 +10,6 @@ hipError_t imp_grant_dynamic_lds(const void* kernel, size_t bytes) { return byte
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 4, n = argc > 2 ? atoi(argv[2]) : 2048, D = 256;
     const int kvp = argc > 3 ? atoi(argv[3]) : 1;            // K / V as split-half images staged by plain copy (the product's format)
-    if (argc > 4) imp_attn_dma_override = atoi(argv[4]);     // 1: the LDS-DMA staging variant of the kernel, 0: the register-staged one (default: IMP_ATTN_DMA or the build's default)
     const size_t qkv = (size_t)B * n * 3 * D;
     std::vector<float> h(qkv);
     unsigned s = 12345;

@@ -1,5 +1,5 @@
-"""one-shot latency by (B, N) with the fused layer launch forced on for every tile count (IMP_WF_FUSED_MIN=1) or at its default threshold:
-    IMP_WF_FUSED_MIN=1 python tools/probe/fused_min_sweep.py"""
+"""one-shot latency by (B, N) with the fused layer launch forced on for every tile count (IMP_OPTIONS=wf_fused_min=1) or at its default threshold:
+    IMP_OPTIONS=wf_fused_min=1 python tools/probe/fused_min_sweep.py"""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -19,4 +19,4 @@ for B, N in ((1, 512), (1, 1024), (2, 1024), (1, 2048), (4, 1024), (2, 2048), (1
         m.produce_matches(d, p=0.2, only_last=True)
     torch.cuda.synchronize()
     out.append(f'B={B} N={N} ({2 * B * ((N + 63) // 64)} tiles): {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms')
-print('IMP_WF_FUSED_MIN=' + os.environ.get('IMP_WF_FUSED_MIN', 'default'), ' | '.join(out))
+print('IMP_OPTIONS=' + os.environ.get('IMP_OPTIONS', 'default'), ' | '.join(out))

@@ -1,5 +1,5 @@
 """Layer GEMMs at the bench geometry: the two launches of round 3 against the fused launch of round 4 (HIP events, 20 launches each;
-with IMP_WF_PROF=1 and a -DWF_PROFILE build of the library: phase cycle stamps of the fused kernel).   python tools/probe/fused_time.py [B N]"""
+with IMP_OPTIONS=probe_prof=1 and a -DWF_PROFILE build of the library: phase cycle stamps of the fused kernel).   python tools/probe/fused_time.py [B N]"""
 import os
 import sys
 

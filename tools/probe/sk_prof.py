@@ -1,5 +1,5 @@
-"""Phase profile of the resident Sinkhorn kernel (IMP_OTR_PROF=1 prints cycles per iteration of workgroup 0 per phase):
-    IMP_OTR_PROF=1 python tools/probe/sk_prof.py [B N]..."""
+"""Phase profile of the resident Sinkhorn kernel (IMP_OPTIONS=probe_prof=1 prints cycles per iteration of workgroup 0 per phase):
+    IMP_OPTIONS=probe_prof=1 python tools/probe/sk_prof.py [B N]..."""
 import os
 import sys
 
