@@ -96,7 +96,7 @@ __device__ __forceinline__ void store_attention_rows(const AttnParams& p, const 
 // (round 5 measured a variant whose ring is filled by LDS-DMA - global_load_lds_dwordx4 - instead of through registers: bit-identical, 21 VGPRs fewer, -2.6 % cycles
 // per phase, EQUAL in time, the launch being power-limited; removed from the product in round 6: tools/probe/attn_dma/, profiles/r05/attn_lds_dma_*.log)
 template <int DH, bool MASKED>
-__global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams p, int qtiles, int total_blocks, int nsplit) {
+__global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams p, int qtiles, int total_blocks, int nsplit, int serial) {
     static_assert(DH == 64 || DH == 32, "head widths of the reference: 256 / 4 and 128 / 4 channels");
     constexpr int NT = 512;
     constexpr int KROW = DH + 4;                 // K row: 32 floats of hi halves, 32 of lo halves, 4 pad
@@ -117,7 +117,12 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int group = wave >> 2;                // 0: waves 0-3, 1: waves 4-7 (one phase behind)
     int id = xcd_remap(blockIdx.x, total_blocks);
-    const int sp = id % nsplit; id /= nsplit;   // key split: this workgroup walks over tiles [t0, t0 + nt) of the keys (nsplit = the launch's largest split)
+    // key split: a unit's keys are cut into ns SHARES (a function of the unit's own counts), every share gives a partial result, the partials are merged in a fixed
+    // order.  WHO computes the shares is the launch's choice and changes no bit: one workgroup per share (the grid carries nsplit = the launch's largest split; the last
+    // workgroup of a unit to finish merges) when the launch would otherwise leave most of the chip idle, or - `serial` - ONE workgroup all shares of its unit, one after
+    // the other, when the launch fills the chip without them (a ragged batch of four: parallel shares doubled its workgroups, 95 against 66 us per launch on the harder set)
+    const int gs = serial ? 1 : nsplit;
+    const int sp = id % gs; id /= gs;
     const int qt = id % qtiles; id /= qtiles;
     const int h = id % IMP_NUM_HEADS; id /= IMP_NUM_HEADS;
     const int sidx = id % p.nside;
@@ -131,8 +136,8 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     if (sp >= ns) return;
 
     const int nt_all = (nk + KT - 1) / KT, t_per = (nt_all + ns - 1) / ns;
-    const int t0 = sp * t_per;
-    const int nt = min(nt_all, t0 + t_per) - t0;     // >= 1: the launcher never makes more splits than it has tiles for
+    int t0 = sp * t_per;                             // this share: tiles [t0, t0 + nt) of the keys
+    int nt = min(nt_all, t0 + t_per) - t0;           // >= 1: the rule never makes more shares than it has tiles for
     const float* Qg = S.q + b * S.sq_b + h * DH;
     const float* Kg = S.k + b * S.sk_b + h * DH;
     const float* Vg = S.v + b * S.sk_b + h * DH;
@@ -212,28 +217,9 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 
     f32x16 oacc[DT], sacc[2];
     f16x8 ph[2][2], pl[2][2];
-#pragma unroll
-    for (int d = 0; d < DT; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
     float m_ref = 0.f;            // log2-domain reference exponent of this lane's query (identical in both lane halves)
     float l_run = 0.f;            // this lane's partial row sum, relative to m_ref
     bool need_slow = true;        // wave-uniform: some query of the wave has not seen an unmasked key yet
-    load_tile(0, rkA, rvA, rbA);
-    if (nt > 1) load_tile(1, rkB, rvB, rbB);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const f32x4 a = qraw[s][0], c = qraw[s][1];
-        const float x[8] = {a[0] * SL2E, a[1] * SL2E, a[2] * SL2E, a[3] * SL2E,
-                            c[0] * SL2E, c[1] * SL2E, c[2] * SL2E, c[3] * SL2E};
-        split8(x, qh[s], ql[s]);
-    }
-    store_tile(0, rkA, rvA, rbA);
-    if (nt > 2) load_tile(2, rkA, rvA, rbA);
-    if (nt > 1) store_tile(1, rkB, rvB, rbB);
-    if (nt > 3) load_tile(3, rkB, rvB, rbB);
-    PP_BARRIER();
-    if (group == 1) PP_BARRIER();
 
     // A operand of O^T += V^T . P^T through the LDS transpose read (ds_read_b64_tr_b16): every 16-lane group hands in
     // the addresses of a [4 keys][16 channels] block (lane i: key i/4, channels 4(i%4)..+3) and lane i receives channel
@@ -431,53 +417,94 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
         if (t + 4 < nt) load_tile(t + 4, rk, rv, rb);
         PP_BARRIER();
     };
-    for (int t = 0; t < nt; t += 2) {
-        tile_step(t, rkA, rvA, rbA, rkB, rvB, rbB);
-        if (t + 1 < nt) tile_step(t + 1, rkB, rvB, rbB, rkA, rvA, rbA);
-    }
-    pv_mfmas((nt - 1) & 3, -1, true);
-    if (group == 0) PP_BARRIER();               // balance the extra barrier of waves 4-7
-    PP_BARRIER();                               // everyone is done with the ring: reuse it for the transposition
-
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
     constexpr int LDO = DH + 1;
-    float* ot = smem + wave * 32 * LDO;
-    if (ns > 1) {
-        // ---- key split: this workgroup holds a PARTIAL result (O relative to its own m_ref, l, m_ref).  It goes to scratch
-        // with agent-coherent write-through stores; a ticket per (pair, side, head, query tile) tells the LAST of the nsplit
-        // workgroups to arrive, and that one merges: m = max m_s, O = sum_s 2^(m_s - m) O_s, l likewise, out = O / l.
-        // Nobody waits for anybody (no spin): the ticket is a relaxed agent-scope atomic taken after the stores are acknowledged.
-        constexpr int PART = 256 * DH + 512;                  // floats per partial: O [256][DH] | m [256] | l [256]
-        const long unit = (((long)b * p.nside + sidx) * IMP_NUM_HEADS + h) * qtiles + qt;
-        float* wsu = p.split_ws + unit * nsplit * PART;
-        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)wsu, 0, (unsigned)(nsplit * PART * 4), 0x00020000);
-        // rows staged with a 16-byte aligned pitch: 128-bit write-through stores, LPR lanes per row, RPI rows per instruction
-        constexpr int LDP = DH + 4, LPR = DH / 4, RPI = 64 / LPR;
-        float* otp = smem + wave * 32 * LDP;
-        const int prow = lane / LPR, pc4 = (lane % LPR) * 4;
+    // scratch of a split unit: floats per partial: O [256][DH] | m [256] | l [256]
+    constexpr int PART = 256 * DH + 512;
+    // rows staged with a 16-byte aligned pitch: 128-bit write-through stores, LPR lanes per row, RPI rows per instruction
+    constexpr int LDP = DH + 4, LPR = DH / 4, RPI = 64 / LPR;
+    float l_tot = 0.f;
+    const int sp_end = serial ? ns : sp + 1;
+    // (the first share's first tiles are requested in front of the Q split - round 4: the Q rows were only REQUESTED above - so that the split waits for
+    // its own loads alone; the raw Q registers are dead before the loop over the shares begins)
+    load_tile(0, rkA, rvA, rbA);
+    if (nt > 1) load_tile(1, rkB, rvB, rbB);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const f32x4 a = qraw[s][0], c = qraw[s][1];
+        const float x[8] = {a[0] * SL2E, a[1] * SL2E, a[2] * SL2E, a[3] * SL2E,
+                            c[0] * SL2E, c[1] * SL2E, c[2] * SL2E, c[3] * SL2E};
+        split8(x, qh[s], ql[s]);
+    }
+    for (int spi = sp; spi < sp_end; ++spi) {
+        if (spi != sp) {
+            t0 = spi * t_per;
+            nt = min(nt_all, t0 + t_per) - t0;
+            load_tile(0, rkA, rvA, rbA);
+            if (nt > 1) load_tile(1, rkB, rvB, rbB);
+        }
 #pragma unroll
         for (int d = 0; d < DT; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) otp[l31 * LDP + d * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = oacc[d][r];
-        __syncthreads();
+            for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 32 / RPI; ++j) {
-            const int qi = j * RPI + prow;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(otp + qi * LDP + pc4);
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
-                                                   rsW, ((sp * PART) + (wave * 32 + qi) * DH + pc4) * 4, 0, 16);
+        for (int r = 0; r < 16; ++r) cneg[r] = 0.f;
+        m_ref = 0.f; l_run = 0.f; need_slow = true;
+        store_tile(0, rkA, rvA, rbA);
+        if (nt > 2) load_tile(2, rkA, rvA, rbA);
+        if (nt > 1) store_tile(1, rkB, rvB, rbB);
+        if (nt > 3) load_tile(3, rkB, rvB, rbB);
+        PP_BARRIER();
+        if (group == 1) PP_BARRIER();
+        for (int t = 0; t < nt; t += 2) {
+            tile_step(t, rkA, rvA, rbA, rkB, rvB, rbB);
+            if (t + 1 < nt) tile_step(t + 1, rkB, rvB, rbB, rkA, rvA, rbA);
         }
-        if (half == 0) {
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m_ref), rsW, (sp * PART + 256 * DH + wave * 32 + l31) * 4, 0, 16);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l_tot), rsW, (sp * PART + 256 * DH + 256 + wave * 32 + l31) * 4, 0, 16);
+        pv_mfmas((nt - 1) & 3, -1, true);
+        if (group == 0) PP_BARRIER();               // balance the extra barrier of waves 4-7
+        PP_BARRIER();                               // everyone is done with the ring: reuse it for the transposition
+        l_tot = l_run + __shfl_xor(l_run, 32);
+        if (ns > 1) {
+            // ---- this share's PARTIAL result (O relative to its own m_ref, l, m_ref) goes to scratch with agent-coherent write-through stores
+            const long unit = (((long)b * p.nside + sidx) * IMP_NUM_HEADS + h) * qtiles + qt;
+            const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.split_ws + unit * nsplit * PART), 0, (unsigned)(nsplit * PART * 4), 0x00020000);
+            float* otp = smem + wave * 32 * LDP;
+            const int prow = lane / LPR, pc4 = (lane % LPR) * 4;
+#pragma unroll
+            for (int d = 0; d < DT; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) otp[l31 * LDP + d * 32 + (r & 3) + 8 * (r >> 2) + 4 * half] = oacc[d][r];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 32 / RPI; ++j) {
+                const int qi = j * RPI + prow;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(otp + qi * LDP + pc4);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])},
+                                                       rsW, ((spi * PART) + (wave * 32 + qi) * DH + pc4) * 4, 0, 16);
+            }
+            if (half == 0) {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m_ref), rsW, (spi * PART + 256 * DH + wave * 32 + l31) * 4, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l_tot), rsW, (spi * PART + 256 * DH + 256 + wave * 32 + l31) * 4, 0, 16);
+            }
+            __builtin_amdgcn_s_waitcnt(0);                         // the write-through stores are acknowledged
+            __syncthreads();                                       // ... and nobody reads the staging rows any more (a next share refills the ring)
         }
-        __builtin_amdgcn_s_waitcnt(0);                         // the write-through stores are acknowledged
-        __syncthreads();
+    }
+    if (ns > 1) {
+        // ---- merge: m = max m_s, O = sum_s 2^(m_s - m) O_s, l likewise, out = O / l - by the workgroup that computed all shares (serial), or by the LAST of the
+        // unit's workgroups to arrive: a ticket per (pair, side, head, query tile), nobody waits for anybody (no spin): the ticket is a relaxed agent-scope atomic
+        // taken after the stores are acknowledged
+        const long unit = (((long)b * p.nside + sidx) * IMP_NUM_HEADS + h) * qtiles + qt;
+        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.split_ws + unit * nsplit * PART), 0, (unsigned)(nsplit * PART * 4), 0x00020000);
+        float* ot = smem + wave * 32 * LDO;
+        const int prow = lane / LPR, pc4 = (lane % LPR) * 4;
         __shared__ int s_last;
         if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(p.split_cnt + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = old == (unsigned)ns - 1;
-            if (s_last) __hip_atomic_store(p.split_cnt + unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+            if (serial) s_last = 1;
+            else {
+                const unsigned old = __hip_atomic_fetch_add(p.split_cnt + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = old == (unsigned)ns - 1;
+                if (s_last) __hip_atomic_store(p.split_cnt + unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+            }
         }
         __syncthreads();
         if (!s_last) return;
@@ -539,7 +566,6 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
     {
         // round 4: the wave's 32 output rows leave as 16-byte stores of full 256-byte rows (4 rows per instruction; 4-byte stores, one row
         // per instruction, before): all 256 workgroups write their 64-KB tile at the same moment with the matrix pipe idle
-        constexpr int LDP = DH + 4, LPR = DH / 4, RPI = 64 / LPR;
         float* otp = smem + wave * 32 * LDP;
         const float inv_l = 1.0f / l_tot;
 #pragma unroll
@@ -573,17 +599,17 @@ __global__ __launch_bounds__(512, 2) void attn_f16x3_pp_kernel(const AttnParams 
 }
 
 template <int DH>
-hipError_t launch_pp(const AttnParams& p, int batch, int maxq, int nsplit, hipStream_t stream) {
+hipError_t launch_pp(const AttnParams& p, int batch, int maxq, int nsplit, int serial, hipStream_t stream) {
     const int qtiles = (maxq + 255) / 256;
-    const int total = qtiles * IMP_NUM_HEADS * p.nside * batch * nsplit;
+    const int total = qtiles * IMP_NUM_HEADS * p.nside * batch * (serial ? 1 : nsplit);
     const size_t lds = (size_t)(4 * KT * (DH + 4) + 4 * KT * (DH + 16) + 4 * KT) * sizeof(float);
     const bool masked = p.side[0].kmask != nullptr || (p.nside == 2 && p.side[1].kmask != nullptr);
     if (masked) {
         if (hipError_t e = imp_grant_dynamic_lds((const void*)attn_f16x3_pp_kernel<DH, true>, lds)) return e;
-        hipLaunchKernelGGL((attn_f16x3_pp_kernel<DH, true>), dim3(total), dim3(512), lds, stream, p, qtiles, total, nsplit);
+        hipLaunchKernelGGL((attn_f16x3_pp_kernel<DH, true>), dim3(total), dim3(512), lds, stream, p, qtiles, total, nsplit, serial);
     } else {
         if (hipError_t e = imp_grant_dynamic_lds((const void*)attn_f16x3_pp_kernel<DH, false>, lds)) return e;
-        hipLaunchKernelGGL((attn_f16x3_pp_kernel<DH, false>), dim3(total), dim3(512), lds, stream, p, qtiles, total, nsplit);
+        hipLaunchKernelGGL((attn_f16x3_pp_kernel<DH, false>), dim3(total), dim3(512), lds, stream, p, qtiles, total, nsplit, serial);
     }
     return hipGetLastError();
 }
@@ -647,5 +673,19 @@ hipError_t launch_attention_f16x3(const AttnParams& p, int batch, hipStream_t st
     // kernel - another order of summation - beside a large pair than alone.  What a small pair loses (a few microseconds at D = 128 or
     // option kv_image = 0; split-half K / V images always ran here) is the price of results that depend on the pair alone.
     const int nsplit = attention_f16x3_splits(p, batch);
-    return p.dh == 64 ? launch_pp<64>(p, batch, maxq, nsplit, stream) : launch_pp<32>(p, batch, maxq, nsplit, stream);
+    // who computes the shares of a split unit (no bit depends on it): one workgroup each while all of them fit the chip at once or the units alone would leave
+    // more than half of it idle, else one workgroup per query tile all of its shares in turn
+    int serial = 0;
+    if (nsplit > 1) {
+        int live = 0, shares = 0;                  // workgroups with work: one per query tile and head / one per share of it
+        for (int sd = 0; sd < p.nside; ++sd)
+            for (int b = 0; b < batch; ++b) {
+                const int nq = p.rc.on ? p.rc.n[p.side[sd].qimg][b] : p.side[sd].nq, nk = p.rc.on ? p.rc.n[p.side[sd].kimg][b] : p.side[sd].nk;
+                if (nq <= 0 || nk <= 0) continue;
+                live += ((nq + 255) / 256) * IMP_NUM_HEADS;
+                shares += ((nq + 255) / 256) * IMP_NUM_HEADS * attn_side_splits(nq, nk);
+            }
+        serial = shares > 256 && live >= 128;      // the shares do not fit the chip at once and the units alone fill half of it
+    }
+    return p.dh == 64 ? launch_pp<64>(p, batch, maxq, nsplit, serial, stream) : launch_pp<32>(p, batch, maxq, nsplit, serial, stream);
 }

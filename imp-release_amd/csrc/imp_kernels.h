@@ -275,6 +275,7 @@ struct OtResidentParams {
     unsigned* dev_base;       // launches recorded into a hipGraph: {tag base, ticket base, workgroups done} in DEVICE memory - a replay must not
                               //   reuse its tags, so the launch takes both bases from here and its last workgroup advances them (tag_base /
                               //   ticket_base above are ignored); null for ordinary launches
+    int h1;                   // (set by the launcher) LOCAL = 2: workgroups of the second half that take part, 8 .. 32
     int fake_placement;       // TEST HOOK (option ot_fake_placement = 1): workgroups lie about the XCC they run on
     unsigned long long* prof; // optional [6]: phase cycle counts of workgroup 0 (probe), null in the product
     int local;                // 1: XCD-local launch: every pair's G <= 32 workgroups on one XCD (plain stores, L2-served polls);

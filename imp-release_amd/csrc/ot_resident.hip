@@ -211,7 +211,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             }
         }
     };
-    int b, g, half = 0, H = G;                 // H workgroups exchange through one L2; this one is number gl = g - half * H of them
+    int b, g, half = 0, H = G;                 // H workgroups exchange through one L2; this one is number gl of them
     if (LOCAL) {
         // the XCC this workgroup really runs on, and its ticket among the workgroups of the launch that landed there
         __shared__ int s_place[2];
@@ -240,10 +240,15 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             b = xcc + 8 * (slot / G);
             g = slot % G;
         } else {
+            // the first half - rows 0 .. 1023, G / 2 = 32 workgroups - is always complete; of the second half only the first p.h1 workgroups (the rows
+            // the LAUNCH's largest pair needs; >= 8) take part: the others leave at once and give their CUs back to whatever else runs on the chip (with
+            // several batches in flight a launch that holds all 256 CUs waits long for the last of them and starves its neighbours meanwhile).  The
+            // column sums of a half are a perfect binary tree over its 32 slots in which an absent workgroup is an exact zero: any h1 gives the same bits
             b = xcc >> 1;
             half = xcc & 1;
-            H = G >> 1;
-            g = half * H + slot;
+            H = half ? p.h1 : (G >> 1);
+            g = half * (G >> 1) + slot;
+            if (slot >= H) { leave(); return; }
         }
         if (b >= p.B) { leave(); return; }     // uniform per workgroup, before any exchange
     } else {
@@ -259,8 +264,9 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
     const Health health{p.status, p.host_status, tag_base, (unsigned)__builtin_amdgcn_readfirstlane((b & 63) | ((g & 255) << 6) | ((G & 255) << 14) | (LOCAL << 22) | (p.B << 24))};
 
     // exchange buffers hold granules: 8 bytes per float
-    const int gl = g - half * H;
-    const __amdgpu_buffer_rsrc_t rs_part = make_rsrc(p.xpart + ((size_t)b * G + (size_t)half * H) * LDX * 2, (unsigned)((size_t)H * LDX * 8));
+    const int gl = LOCAL == 2 ? g - half * (G >> 1) : g;
+    const int GP = LOCAL == 2 ? (G >> 1) + p.h1 : G;       // workgroups of the pair that take part: g = 0 .. GP - 1
+    const __amdgpu_buffer_rsrc_t rs_part = make_rsrc(p.xpart + ((size_t)b * G + (size_t)(g - gl)) * LDX * 2, (unsigned)((size_t)H * LDX * 8));
     const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(p.xv + (size_t)(LOCAL == 2 ? 2 * b + half : b) * LDX * 2, (unsigned)(LDX * 8));
     const __amdgpu_buffer_rsrc_t rs_h_own = make_rsrc(p.xhalf + (size_t)(2 * b + half) * LDX * 2, (unsigned)(LDX * 8));
     const __amdgpu_buffer_rsrc_t rs_h_oth = make_rsrc(p.xhalf + (size_t)(2 * b + 1 - half) * LDX * 2, (unsigned)(LDX * 8));
@@ -606,16 +612,16 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
             __syncthreads();
         }
         const unsigned tag_m = tag_base + 3u * p.T + 1u;
-        const __amdgpu_buffer_rsrc_t rs_mx = make_rsrc(p.xmax + (size_t)b * G * 4 * LDX, (unsigned)((size_t)G * 2 * LDX * 8));
+        const __amdgpu_buffer_rsrc_t rs_mx = make_rsrc(p.xmax + (size_t)b * G * 4 * LDX, (unsigned)((size_t)GP * 2 * LDX * 8));
         for (int q = tid; q < DCOL / 4; q += 512) {
             stg4<MX_AUX>(rs_mx, g * 2 * NQ + q, *reinterpret_cast<const f32x4*>(mv + 4 * q), tag_m);
             stg4<MX_AUX>(rs_mx, g * 2 * NQ + NQ + q, *reinterpret_cast<const f32x4*>(red + LDX + 4 * q), tag_m);
         }
         __syncthreads();                           // mv / mi are about to be overwritten by the staging
-        const int ncq = (DCOL / 4 + G - 1) / G;        // float4 column chunks per workgroup
-        f32x4* stage = reinterpret_cast<f32x4*>(red);  // [2][G][ncq]
-        for (int idx = tid; idx < 2 * ncq * G; idx += 512) {
-            const int which = idx / (ncq * G), rem = idx - which * ncq * G;
+        const int ncq = (DCOL / 4 + GP - 1) / GP;      // float4 column chunks per workgroup
+        f32x4* stage = reinterpret_cast<f32x4*>(red);  // [2][GP][ncq]
+        for (int idx = tid; idx < 2 * ncq * GP; idx += 512) {
+            const int which = idx / (ncq * GP), rem = idx - which * ncq * GP;
             const int w = rem / ncq, qq = rem - w * ncq;
             const int q = g * ncq + qq;
             stage[idx] = q < DCOL / 4 ? ldg4(rs_mx, w * 2 * NQ + which * NQ + q, tag_m, health, dead, 4 | (p.T << 8)) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -627,9 +633,9 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
                 const int qq = cl >> 2, e = cl & 3;
                 float best = -INFINITY;
                 int bi = 0x7fffffff;
-                for (int w = 0; w < G; ++w) {          // ascending workgroups = ascending rows
+                for (int w = 0; w < GP; ++w) {         // ascending workgroups = ascending rows
                     const float ov = red[(size_t)(w * ncq + qq) * 4 + e];
-                    const int oi = __float_as_int(red[(size_t)((G + w) * ncq + qq) * 4 + e]);
+                    const int oi = __float_as_int(red[(size_t)((GP + w) * ncq + qq) * 4 + e]);
                     if (ov > best) { best = ov; bi = oi; }
                 }
                 p.max1[(size_t)b * ld1 + j] = best;
@@ -651,7 +657,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
                 for (int j = lane; j <= n1; j += 64) srow[j] = nanv;
             }
         if (want_max) {
-            const int ncq = (DCOL / 4 + G - 1) / G;
+            const int ncq = (DCOL / 4 + GP - 1) / GP;
             for (int cl = tid; cl < 4 * ncq; cl += 512) {
                 const int j = 4 * (g * ncq) + cl;
                 if (j < n1) { p.max1[(size_t)b * ld1 + j] = nanv; p.arg1[(size_t)b * ld1 + j] = 0x7fffffff; }
@@ -662,15 +668,21 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
 }
 
 template <int NCH, int RPW>
-hipError_t launch_one(const OtResidentParams& p, hipStream_t stream) {
+hipError_t launch_one(const OtResidentParams& p_in, hipStream_t stream) {
     constexpr int LDX = 256 * NCH + 4;
-    const int Hh = p.local == 2 ? p.G / 2 : p.G;
-    const int cq = (LDX / 4 + Hh - 1) / Hh;
+    OtResidentParams p = p_in;
+    // two XCDs per pair: how many workgroups of the second half (rows 1024 ...) take part - those the largest pair of the launch has rows for, at least 8
+    // (fewer would make a workgroup's column slice of the half's exchange long)
+    p.h1 = p.local == 2 ? std::min(32, std::max(8, (p.n0 - 1024 + 8 * RPW - 1) / (8 * RPW))) : 0;
+    const int GP = p.local == 2 ? p.G / 2 + p.h1 : p.G;
     // vs + max(8 wave vectors, slice staging [H][cq] float4 + [8][4 cq])
     size_t red = (size_t)8 * LDX;
-    const size_t stage = (size_t)cq * Hh * 4 + (size_t)8 * 4 * cq;
-    if (stage > red) red = stage;
-    const size_t stage2 = (size_t)2 * p.G * ((256 * NCH / 4 + p.G - 1) / p.G) * 4;     // column-maxima staging
+    for (int Hh : {p.local == 2 ? p.G / 2 : p.G, p.local == 2 ? p.h1 : p.G}) {
+        const int cq = (LDX / 4 + Hh - 1) / Hh;
+        const size_t stage = (size_t)cq * Hh * 4 + (size_t)8 * 4 * cq;
+        if (stage > red) red = stage;
+    }
+    const size_t stage2 = (size_t)2 * GP * ((256 * NCH / 4 + GP - 1) / GP) * 4;     // column-maxima staging
     if (stage2 > red) red = stage2;
     const size_t lds = (LDX + red) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;

@@ -1,0 +1,57 @@
+"""configs[4] loops alone (the c5_* block of bench.py), for A/B runs:   cd <tree root> && python <this file> imp|eimp WORKERS N_EVAL [LOCKSTEP]
+prints pairs/s of two timed runs.  Imports the package of the CURRENT DIRECTORY (so the same file measures an older tree)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.getcwd())
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from imp_release_amd import eval_loop, synthetic  # noqa: E402
+from imp_release_amd import pose as gpose  # noqa: E402
+import imp_release_amd as P  # noqa: E402
+
+tag = sys.argv[1] if len(sys.argv) > 1 else 'imp'
+workers = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+n_eval = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+lockstep = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+dev = torch.device('cuda:0')
+n_distinct = 128
+cfg = {'descriptor_dim': 256, 'sinkhorn_iterations': 20, 'match_threshold': 0.2, 'with_sinkhorn': True, 'n_layers': 15, 'GNN_layers': ['self', 'cross'] * 15,
+       'ac_fn': 'relu', 'norm_fn': 'in', 'n_min_tokens': 256}
+name = 'DGNNS' if tag == 'imp' else 'AdaGMN'
+sd = synthetic.make_state_dict(cfg, name, seed=0, bin_score=synthetic.MATCHING_BIN_SCORE, style='matching')
+mm = getattr(P, name)(dict(cfg, precision='f16x3')).eval()
+mm.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+mm = mm.to(dev)
+host_pairs = [synthetic.make_hard_two_view_pair(seed=7000 + i) for i in range(n_distinct)]
+UP = ('keypoints0', 'keypoints1', 'scores0', 'scores1', 'descriptors0', 'descriptors1')
+pinned = [{k: torch.from_numpy(pr[k]).pin_memory() for k in UP} for pr in host_pairs]
+
+
+def provider(pid):
+    pr = host_pairs[pid % n_distinct]
+    dd = {k: pinned[pid % n_distinct][k].to(dev, non_blocking=True) for k in UP}
+    dd['image0'] = dd['image1'] = torch.empty(pr['image_shape'], device='meta')
+    dd['pts0_cpu'], dd['pts1_cpu'] = pr['keypoints0'][0], pr['keypoints1'][0]
+    dd.update({k: pr[k] for k in ('K0', 'K1', 'T_0to1', 'E')})
+    return dd
+
+
+kw = dict(eimp=tag == 'eimp', estimate_pose=gpose.estimate_pose, workers=workers)
+if lockstep > 1:
+    kw.update(lockstep=lockstep, group_similar=n_distinct,
+              pair_cost=lambda pid: host_pairs[pid % n_distinct]['keypoints0'].shape[1] * host_pairs[pid % n_distinct]['keypoints1'].shape[1])
+reps = eval_loop.replicate(mm, workers)
+kw['replicas'] = reps
+with torch.no_grad():
+    eval_loop.run_pairs_sharded(mm, provider, 24, **kw)
+    rates = []
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eval_loop.run_pairs_sharded(mm, provider, n_eval, **kw)
+        torch.cuda.synchronize()
+        rates.append(n_eval / (time.perf_counter() - t0))
+print(f'c5 {tag} workers={workers} lockstep={lockstep} n_eval={n_eval}: ' + ' '.join(f'{r:.1f}' for r in rates) + ' pairs/s')
