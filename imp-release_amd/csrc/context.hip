@@ -819,10 +819,10 @@ struct SpinGate {
     bool has_last = false, multi = false;
     // the kernel-choice hint (spin_gate_shared) keeps its own history of who ASKED: the two-launch layers it selects enter no section, so
     // with sections alone a stream that took over the device (a new pipeline, the bench's one-in-flight leg) saw "shared" until seven of its
-    // Sinkhorn launches - seven whole steps - had passed (round 5: found in a kernel trace, tools/trace_sequence.py)
+    // Sinkhorn launches - seven whole steps - had passed (round 5: found in a kernel trace, tools/trace_sequence.py); round 6: by time, see spin_gate_shared
     hipStream_t last_query = nullptr;
     bool has_query = false, query_multi = false;
-    int query_run = 0;
+    std::chrono::steady_clock::time_point query_switch;      // when a query last came from another stream than the one before
 };
 SpinGate* spin_gate(int device) {
     static std::mutex mu;
@@ -841,8 +841,12 @@ bool spin_gate_shared(int device, hipStream_t st) {
     SpinGate* g = spin_gate(device);
     if (!g) return false;
     std::lock_guard<std::mutex> lock(g->mu);
-    if (g->has_query && g->last_query != st) { g->query_multi = true; g->query_run = 0; }        // another stream is choosing kernels right now
-    else if (g->query_multi && ++g->query_run > 6) g->query_multi = false;                       // seven layers in a row from one stream: it is alone
+    // "shared" = another stream asked within the last 8 ms (about two batch-steps).  Round 5 counted consecutive queries of one stream instead (seven =
+    // alone) - but one imp_match_pair asks 18 times inside a single call, so a stream whose neighbours were blocked in a synchronisation flipped to "alone"
+    // in mid-call and took the waiting launch beside their kernels
+    const auto now = std::chrono::steady_clock::now();
+    if (g->has_query && g->last_query != st) { g->query_multi = true; g->query_switch = now; }
+    else if (g->query_multi && now - g->query_switch > std::chrono::milliseconds(8)) g->query_multi = false;
     g->last_query = st; g->has_query = true;
     return g->query_multi;
 }

@@ -87,7 +87,7 @@ def all_gather_matches_steps(steps, n_total: int, group=None):
     return res
 
 
-_QUEUE_SEQ = [0]
+_QUEUE_SEQ = {}      # ranks of a group -> queues constructed for it so far
 
 
 class DynamicPairQueue:
@@ -96,7 +96,8 @@ class DynamicPairQueue:
     next ``chunk`` item ids when it runs dry - ``next()`` -> list of ids (empty = done).  The counter lives in the job's rendezvous store
     (the TCPStore every torch.distributed job already has: ``store.add`` is an atomic fetch-and-add served by rank 0's store thread; no
     collective, nothing on the GPU), so a pull is one small TCP round trip (~0.1 ms) per chunk.  Without an initialised process group it
-    is a local counter.  Every rank must construct its queues in the same order (the key is a per-process sequence number)."""
+    is a local counter.  Every rank of a group must construct that group's queues in the same order (the key holds the group's ranks and a per-group
+    sequence number)."""
 
     def __init__(self, n_items: int, chunk: int = 1, group=None):
         import threading
@@ -104,11 +105,17 @@ class DynamicPairQueue:
         self._lock = threading.Lock()
         self._local = 0
         self._store = None
-        _QUEUE_SEQ[0] += 1
-        self._key = f'imp_pair_queue/{_QUEUE_SEQ[0]}'
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             from torch.distributed import distributed_c10d as c10d
             self._store = c10d._get_default_store()
+            # the counter's key: the ranks of the group (two subgroups scheduling at the same time must not share a counter) and a per-group sequence number
+            # (every rank of a group constructs that group's queues in the same order; a rank outside the group never touches the key)
+            ranks = tuple(dist.get_process_group_ranks(group)) if group is not None else tuple(range(dist.get_world_size()))
+            _QUEUE_SEQ[ranks] = _QUEUE_SEQ.get(ranks, 0) + 1
+            import zlib
+            self._key = f'imp_pair_queue/{zlib.crc32(repr(ranks).encode()):08x}/{len(ranks)}/{_QUEUE_SEQ[ranks]}'
+        else:
+            self._key = None
         self.pulls = 0
 
     def next(self):

@@ -122,11 +122,9 @@ def run_pairs_sharded(model, pair_provider: Callable[[int], dict], n_pairs: int,
     ``lockstep`` > 1 (round 4): that many pairs advance TOGETHER through ``matching.matching_iterative_lockstep`` (IMP) /
     ``matching.matching_iterative_uncertainty_lockstep`` (EIMP: per-pair pooling inside the ragged batch) - one ragged batch, one kernel
     launch per layer for all of them, per-pair early exit (at most 4 pairs of ~2048 keypoints, 8 of <= 1024: the batch must fit the
-    chip-resident Sinkhorn); with ``workers`` > 1 several such groups are in flight.  A pair's row is the row of the pair run alone up to
-    fp32 summation order: a batch takes other kernel decompositions than a single pair (scores agree to ~2e-6), and where the EIMP pool
-    meets a keypoint exactly on a threshold / lower-median boundary the kept set can differ by that keypoint (11 of 96 pairs of the
-    harder synthetic set - tools/probe/eimp_lockstep_diff.py -; 1200 evaluations over 96 of them: AUC@5 70.28 alone, 70.01 in groups of 4,
-    mean n_iterations 8.63 / 8.72; the IMP loop has no such decision and its report is identical).
+    chip-resident Sinkhorn); with ``workers`` > 1 several such groups are in flight.  A pair's row is the row of the pair run alone, bit for
+    bit (round 6: every reduction order is a function of the pair's own sizes - tests/test_gpu_batch_invariance.py, tests/test_gpu_hard_loops.py;
+    tools/probe/eimp_lockstep_diff.py: 0 of 96 pairs of the harder set differ; rounds 4-5: 11 of 96 kept another keypoint set in a group).
     ``group_similar`` = W > 0 (with ``lockstep`` > 1 and ``pair_cost``): every window of W consecutive pairs of this rank is taken in
     descending cost order - what a loader with a look-ahead of W pairs can do - so that the pairs of a group have similar sizes (a group is
     padded to its largest pair and advances at that pair's pace); rows stay in pair-id order.
@@ -282,7 +280,13 @@ def gather_rows_by_id(rows: np.ndarray, ids, n_total: int, device='cpu', group=N
     out = out.cpu().numpy()
     table = np.full((n_total, width), np.nan)
     valid = out[:, 0] >= 0
-    table[out[valid, 0].astype(np.int64)] = out[valid, 1:]
+    got = out[valid, 0].astype(np.int64)
+    # every pair exactly once: a schedule whose ranks disagree (two groups on one counter, queues built in different orders) skips or repeats pairs
+    counts = np.bincount(got, minlength=n_total)
+    if (counts != 1).any():
+        raise RuntimeError(f'gather_rows_by_id: {int((counts == 0).sum())} of {n_total} pairs were evaluated by no rank, {int((counts > 1).sum())} by several - '
+                           f'the ranks did not agree on the schedule')
+    table[got] = out[valid, 1:]
     return table
 
 

@@ -491,9 +491,8 @@ def _lockstep_group_uncertainty(datas, model, nI, match_ratio, min_kpts, error_t
                                 estimate_pose=None, pose_threads=4, traces=None, native='auto'):
     """eval/matching.py:126-276 (the EIMP loop: adaptive pooling between the iterations) on SEVERAL pairs at once ->
     [(pts0, pts1, norm_kpts0, norm_kpts1, indices0, mscores0, R, t, n_iterations)] - per pair what
-    :func:`matching_iterative_uncertainty` returns for it, up to the pool's boundary cases: a batch takes other kernel decompositions than a
-    single pair (scores agree to ~2e-6), and where a keypoint sits exactly on the pool's threshold / lower-median boundary the kept set can
-    differ by that keypoint (11 of 96 pairs of the harder synthetic set; AUC@5 70.28 alone, 70.01 in groups: eval_loop.run_pairs_sharded).
+    :func:`matching_iterative_uncertainty` returns for it, bit for bit (round 6: a pair's reduction orders depend on its own sizes alone, so the
+    pool's threshold / lower-median decisions see the same bits in a group as alone; tests/test_gpu_hard_loops.py, tests/test_gpu_batch_invariance.py).
 
     The pairs form one ragged batch (``imp_set_counts``) whose per-pair counts SHRINK: after every scored iteration each live pair is
     pooled on its own slice of the batch (``imp_pool_pair``: cached attention + the pair's dense score tensor from
