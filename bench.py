@@ -113,6 +113,20 @@ def cpu_baseline(args, quick=False):
                       f"{ {k: round(v, 3) for k, v in probes.items()} } pairs/s probed at N={args.kpts}), host: {ncpu} x {cpu_model}"}
 
 
+def postmortems(models):
+    """the post-mortem record of the last voided waiting launch of every context that has one (include/imp_hip.h imp_resident_postmortem: which wait of which
+    workgroup gave up, on which CU, what it had seen, what the host knew) - the evidence for a time-out whose cause is not known"""
+    out = []
+    for m in models:
+        try:
+            pm = m._ensure_ctx().resident_postmortem()
+            if pm:
+                out.append(pm)
+        except Exception:                                # noqa: BLE001
+            pass
+    return out
+
+
 def voided_launches(models):
     """launches of the waiting kernels (chip-resident Sinkhorn, fused layer MLP) that timed out on these models' contexts so far (the library voids such a
     call and the loops re-run it: include/imp_hip.h IMP_E_RESIDENT)"""
@@ -286,6 +300,8 @@ def batch1_latencies(dev, args, out=None):
             out[f'c5_{tag}_single_pairs_3_in_flight_pairs_per_s'] = (n_eval // 4) / (time.perf_counter() - t0)
             out[f'c5_{tag}_single_pairs_auc5'] = eval_loop.aggregate(t3)['auc@5']
             out[f'c5_{tag}_voided_launches'] = voided_launches(reps)        # time-outs of waiting kernels that the loops met and re-ran (0 = none)
+            if out[f'c5_{tag}_voided_launches']:
+                out[f'c5_{tag}_postmortems'] = postmortems(reps)
             del mm, reps
         out['c5_note'] = (f'BASELINE configs[4] on ONE GPU: {n_eval} evaluations of matching_iterative (imp: DGNNS) / matching_iterative_uncertainty (eimp: AdaGMN, adaptive '
                           f'pooling, with_uncertainty as eval/eval_imp.py:95-105), 4 pairs in lock step as one ragged batch (imp_loop_lockstep / imp_loop_lockstep_uncertainty), '
@@ -664,6 +680,8 @@ def main():
         }
         line['headline_retries_after_a_voided_resident_launch'] = headline_retries
         line['voided_launches_on_the_headline_replicas'] = voided_launches(replicas)
+        if line['voided_launches_on_the_headline_replicas']:
+            line['headline_postmortems'] = postmortems(replicas)
         line['one_step_in_flight'] = ({'error': serial_error} if serial_error else None) if serial_s is None else {
             'value': n_total * args.steps / serial_s, 'ms_per_step': serial_s / args.steps * 1e3,
             'note': 'same K steps strictly sequential on one model instance (no overlap between batch-steps); since round 4 every layer of '
