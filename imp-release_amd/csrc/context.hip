@@ -111,7 +111,7 @@ struct imp_ctx {
     int *arg0 = nullptr, *arg1 = nullptr, *colpart_i = nullptr;
     float *colsum[4] = {}, *amass[4] = {}, *mass[2] = {};
     AttnCache cache[2];
-    float* xhalf = nullptr;  // resident Sinkhorn, two XCDs per pair: the half sums the XCDs swap ([2 iteration parities][8 vectors], ot_resident.hip OTR_MERGE)
+    float* xhalf = nullptr;  // resident Sinkhorn, two XCDs per pair: the half sums the XCDs swap ([2 iteration parities][8 vectors]: ot_resident.hip, phase C)
     int ot_hier = 1;         // two-XCDs-per-pair resident launches (hierarchical column sums) when a pair fits 64 CUs and B <= 4 (option ot_hier = 0 disables)
     int ot_local = 1;        // XCD-local resident Sinkhorn launches when a pair fits one XCD (option ot_local = 0 disables)
     unsigned* stat_cnt = nullptr;   // [cap_b][2][WF_MAX_PSPLIT] tickets of the statistics merge inside the MLP0 launch (gemm_wf.hip)

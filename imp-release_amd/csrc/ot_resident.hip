@@ -270,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
     const __amdgpu_buffer_rsrc_t rs_v = make_rsrc(p.xv + (size_t)(LOCAL == 2 ? 2 * b + half : b) * LDX * 2, (unsigned)(LDX * 8));
     const __amdgpu_buffer_rsrc_t rs_h_own = make_rsrc(p.xhalf + (size_t)(2 * b + half) * LDX * 2, (unsigned)(LDX * 8));
     const __amdgpu_buffer_rsrc_t rs_h_oth = make_rsrc(p.xhalf + (size_t)(2 * b + 1 - half) * LDX * 2, (unsigned)(LDX * 8));
-    // OTR_MERGE: the write-through copies of odd iterations live 8 vectors further (B <= 4: 2 B <= 8 vectors per parity)
+    // the vectors of odd iterations live 8 vectors further (B <= 4: 2 B <= 8 vectors per parity)
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_h_own1 = make_rsrc(p.xhalf + (size_t)(8 + 2 * b + half) * LDX * 2, (unsigned)(LDX * 8));
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_h_oth1 = make_rsrc(p.xhalf + (size_t)(8 + 2 * b + 1 - half) * LDX * 2, (unsigned)(LDX * 8));
 
@@ -475,15 +475,16 @@ __global__ __launch_bounds__(512, 2) void ot_resident_kernel(const OtResidentPar
                 float s = ((sub[cl] + sub[ncol + cl]) + (sub[2 * ncol + cl] + sub[3 * ncol + cl])) +
                           ((sub[4 * ncol + cl] + sub[5 * ncol + cl]) + (sub[6 * ncol + cl] + sub[7 * ncol + cl]));
                 const int xi = 4 * (gl * cq) + cl;                    // index in the exchange layout
-                if (LOCAL == 2 && 0) {
-                    if (xi < LDX) {
-                        stg1<0>(rs_v, xi, s, tag_h);                                   // for this XCD's workgroups (stays in its L2)
-                        stg1<AUX_SC1>((it & 1) ? rs_h_own1 : rs_h_own, xi, s, tag_h);  // for the other XCD's
-                    }
-                } else if (xi < LDX) {
+                if (xi < LDX) {
                     if (LOCAL == 2) {                                 // swap the half sums across the fabric; both halves add them in the same order
-                        stg1<AUX_SC1>(rs_h_own, xi, s, tag_h);
-                        const float o = ldg1(rs_h_oth, xi, tag_h, health, dead, 2 | (it << 8));
+                        // TWO granule vectors, by iteration parity (round 6: the cause of the rare time-out, read off three post-mortem records - a waiter in phase 2
+                        // that found the tag of iteration it + 1 where it expected it).  A half needs the OTHER half's sums of iteration it to go on, not that the
+                        // other half has READ its own: it could run a whole iteration ahead and publish its sums of it + 1 over those of it before a slow poll of
+                        // the other half (a fabric crossing beside other streams' write bursts) had seen them - the value was gone, the poll never ended.  With two
+                        // vectors the sums of it are overwritten by those of it + 2, which need the other half's sums of it + 1, which the SAME thread of the other
+                        // half publishes only after it has read ours of it
+                        stg1<AUX_SC1>((it & 1) ? rs_h_own1 : rs_h_own, xi, s, tag_h);
+                        const float o = ldg1((it & 1) ? rs_h_oth1 : rs_h_oth, xi, tag_h, health, dead, 2 | (it << 8));
                         s = half == 0 ? s + o : o + s;
                     }
                     const bool dust = xi == DCOL;

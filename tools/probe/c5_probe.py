@@ -55,3 +55,10 @@ with torch.no_grad():
         torch.cuda.synchronize()
         rates.append(n_eval / (time.perf_counter() - t0))
 print(f'c5 {tag} workers={workers} lockstep={lockstep} n_eval={n_eval}: ' + ' '.join(f'{r:.1f}' for r in rates) + ' pairs/s')
+for i, m in enumerate(reps):          # voided waiting launches met (and repaired) on the way, with their post-mortem records
+    ctx = m._ensure_ctx()
+    h = ctx.resident_health(False)
+    if h is False:
+        h = ctx.resident_health(False)
+    if h and h[0]:
+        print(f'replica {i}: {h[0]} voided waiting launch(es), protocol level {h[1]}; last post-mortem: {ctx.resident_postmortem() if hasattr(ctx, "resident_postmortem") else None}')
