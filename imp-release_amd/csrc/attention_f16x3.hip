@@ -686,6 +686,7 @@ hipError_t launch_attention_f16x3(const AttnParams& p, int batch, hipStream_t st
                 shares += ((nq + 255) / 256) * IMP_NUM_HEADS * attn_side_splits(nq, nk);
             }
         serial = shares > 256 && live >= 128;      // the shares do not fit the chip at once and the units alone fill half of it
+        if (p.share_mode) serial = p.share_mode == 2;
     }
     return p.dh == 64 ? launch_pp<64>(p, batch, maxq, nsplit, serial, stream) : launch_pp<32>(p, batch, maxq, nsplit, serial, stream);
 }

@@ -122,6 +122,7 @@ struct imp_ctx {
     int wf_fused = 1;        // IMP_WF_FUSED=0: never run a layer's MLP0 -> InstanceNorm -> MLP3 (-> next projection) as ONE launch (gemm_wf.hip fused kernel)
     long wf_fused_min_tiles = 100;   // option wf_fused_min (measured: the fused launch wins from ~64 tiles up - 128 tiles: -7..-9 %, 64: +-1 % - and loses 12-18 % at 16-32)
     int probe_prof = 0;      // option probe_prof
+    int attn_share_mode = 0; // option attn_shares (AttnParams::share_mode)
     int wf_fused_fake = 0;   // TEST HOOK (option wf_fused_fake): one workgroup of every fused launch withholds its statistics (forces the time-out path)
     float *fx_rec[2] = {}, *fx_fin[2] = {};   // fused layer: statistics granules [B][tiles][512] x 16 B and (mean, rstd) granules [B][512] x 16 B per image
     unsigned fx_tag = 0;     // tag of the last fused launch (tags never repeat on fx_rec / fx_fin)
@@ -370,6 +371,7 @@ template <typename P> void apply_ragged(const imp_ctx* c, P& p) {
 // attention launch; in f16x3 mode the context lends its key-split scratch (grown on demand) for launches too small to fill the chip
 int launch_attention(imp_ctx* c, AttnParams& a, int batch, hipStream_t st) {
     if (c->prec != 1) { HIP_TRY(launch_attention_f32(a, batch, st)); return IMP_OK; }
+    a.share_mode = c->attn_share_mode;
     // size the scratch for the largest split the launcher may choose (it decides with the pointers set)
     float dummy_ws; unsigned dummy_cnt;
     a.split_ws = &dummy_ws; a.split_cnt = &dummy_cnt;
@@ -1331,6 +1333,7 @@ static int ctx_option(imp_ctx* c, const char* name, long v) {
     else if (n == "wf_fused_min") c->wf_fused_min_tiles = v;
     else if (n == "wf_fused_fake") c->wf_fused_fake = v != 0;         // TEST HOOK: one workgroup withholds its statistics
     else if (n == "probe_prof") c->probe_prof = v != 0;               // probes: the timing entry points also print the phase cycle stamps of a profiling build
+    else if (n == "attn_shares") c->attn_share_mode = (int)v;          // key shares of a split attention unit: 0 launcher's choice, 1 one workgroup each, 2 one workgroup all (same bits)
     else if (n == "kv_image") c->kv_image = (int)v;                   // 0: the projection writes fp32 k | v, the attention kernel splits them while staging
     else return IMP_E_ARG;
     return IMP_OK;

@@ -159,6 +159,7 @@ struct AttnParams {
     int kv_planes;         // EXPERIMENT (ping-pong kernel only): k / v rows hold, per head, [dh hi halves | dh lo halves] (the split-half image the
                            // kernel otherwise builds while staging) in the bytes of the head's dh floats: staged by plain copy
     RaggedCounts rc;       // per-pair query / key counts (no key mask with it)
+    int share_mode;        // who computes the key shares of a split unit: 0 = the launcher decides (attention_f16x3.hip), 1 = one workgroup per share, 2 = one workgroup all of them (tests: same bits)
     // timing hook (imp_time_attention_clock; null in the product path): workgroup 0 adds its lifetime to [0] in shader cycles (s_memtime) and to
     // [1] in ticks of the constant 100 MHz counter (s_memrealtime): [0] / [1] x 100 MHz = the clock the kernel really ran at
     unsigned long long* clk_probe;

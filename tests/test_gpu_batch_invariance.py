@@ -168,3 +168,31 @@ def test_sinkhorn_decompositions_agree_bit_for_bit():
                 got = r['scores'][B - 1, :(n0 + 1) * (n1 + 1)].view(n0 + 1, n1 + 1)
                 d = (got - ref).abs().max().item()
                 assert torch.equal(got, ref), f'({n0}, {n1}) padded to ({pad0}, {pad1}) in a batch of {B}: scores differ by {d:.3g}'
+
+
+@pytest.mark.parametrize('pairs', [PAIRS_BIG, [(1100, 1300, 31), (1250, 1200, 32), (1024, 1500, 33), (1400, 1111, 34)], [(900, 1000, 41)]])
+def test_key_shares_of_an_attention_unit_one_workgroup_each_or_all_by_one_same_bits(pairs):
+    """WHO computes the key shares of a split attention unit is the launcher's choice (attention_f16x3.hip: one workgroup per share while they fit the chip at
+    once, one workgroup all shares of its unit in turn in full launches); option attn_shares forces either: every emitted iteration bit-identical"""
+    from helpers import lib_options
+    outs = []
+    for mode in (1, 2):
+        with lib_options(attn_shares=mode):
+            m = _model('GM', 3, 'f16x3')
+            m._ensure_ctx()
+        data, _ = _batch(pairs)
+        with torch.no_grad():
+            outs.append(m.produce_matches(data, p=0.2, only_last=False))
+    a, b = outs
+    assert int((a['indices0'][-1] >= 0).sum()) > 0
+    for it in range(len(a['indices0'])):
+        assert torch.equal(a['indices0'][it], b['indices0'][it]) and torch.equal(a['mscores0'][it], b['mscores0'][it]), f'iteration {it}'
+
+
+def test_unknown_context_option_is_an_error():
+    from imp_release_amd import _lib
+    m = _model('GM', 1, 'f16x3')
+    ctx = m._ensure_ctx()
+    ctx.option('attn_shares', 0)
+    with pytest.raises(_lib.ImpError):
+        ctx.option('no_such_switch', 1)
