@@ -1,6 +1,7 @@
 #!/bin/bash
+# (needs the round-5 tree beside this one: mkdir _r5tree && git archive d6c23dd | tar -x -C _r5tree && make -C _r5tree/imp-release_amd/csrc)
 # c5 loops: r6 tree vs r5 tree, groups in flight 1 / 2 / 4, lock step 4 and single pairs
-R=$PWD; O=$R/gpurun_out/r6j; mkdir -p $O; : > $O/c5.log
+R=$PWD; O=$R/gpurun_out/run; mkdir -p $O; : > $O/c5.log
 for T in r6 r5; do
   D=$R; [ $T = r5 ] && D=$R/_r5tree
   for L in imp eimp; do

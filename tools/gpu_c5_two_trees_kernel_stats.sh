@@ -1,6 +1,7 @@
 #!/bin/bash
+# (needs the round-5 tree beside this one: mkdir _r5tree && git archive d6c23dd | tar -x -C _r5tree && make -C _r5tree/imp-release_amd/csrc)
 # c5 loops, one group in flight: kernel stats on both trees
-R=$PWD; O=$R/gpurun_out/r6k; mkdir -p $O
+R=$PWD; O=$R/gpurun_out/run; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for T in r6 r5; do
   D=$R; [ $T = r5 ] && D=$R/_r5tree
@@ -21,8 +22,8 @@ def load(f):
         d[n]=(int(r['Calls']),float(r['TotalDurationNs'])/1e6)
     return d
 for L in ('imp','eimp'):
-    a=load(f'gpurun_out/r6k/kernel_stats_r6_{L}.csv'); b=load(f'gpurun_out/r6k/kernel_stats_r5_{L}.csv')
-    print(L, open(f'gpurun_out/r6k/line_r6_{L}.txt').read().strip(), '|', open(f'gpurun_out/r6k/line_r5_{L}.txt').read().strip())
+    a=load(f'gpurun_out/run/kernel_stats_r6_{L}.csv'); b=load(f'gpurun_out/run/kernel_stats_r5_{L}.csv')
+    print(L, open(f'gpurun_out/run/line_r6_{L}.txt').read().strip(), '|', open(f'gpurun_out/run/line_r5_{L}.txt').read().strip())
     print(L,'total ms r6 %.1f r5 %.1f'%(sum(v[1] for v in a.values()),sum(v[1] for v in b.values())))
     keys=sorted(set(a)|set(b),key=lambda k:-abs(a.get(k,(0,0))[1]-b.get(k,(0,0))[1]))
     for k in keys[:18]:

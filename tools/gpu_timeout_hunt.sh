@@ -1,6 +1,6 @@
 #!/bin/bash
-# after the fix of the half-sum exchange: Sinkhorn tests, timing, and the same hunt as tools/gpu_r6_r.sh (3 voided launches in 12 runs before)
-R=$PWD; O=$R/gpurun_out/r6s; mkdir -p $O; : > $O/hunt.log
+# after the fix of the half-sum exchange: Sinkhorn tests, timing, and the hunt that met 3 voided launches in 12 runs before the fix
+R=$PWD; O=$R/gpurun_out/run; mkdir -p $O; : > $O/hunt.log
 (timeout 900 python -m pytest tests/test_gpu_resident_ot.py tests/test_gpu_batch_invariance.py -m gpu -q --no-header -p no:cacheprovider 2>&1 | tail -2) > $O/tests.log 2>&1
 (IMP_OPTIONS=probe_prof=1 timeout 200 python tools/probe/sk_prof.py 4 2048 2>&1 | grep -v amdgpu.ids | tr '\n' ' '; echo) >> $O/tests.log
 cat $O/tests.log | cut -c1-400
