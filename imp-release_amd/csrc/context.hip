@@ -821,10 +821,11 @@ struct SpinGate {
     bool has_last = false, multi = false;
     // the kernel-choice hint (spin_gate_shared) keeps its own history of who ASKED: the two-launch layers it selects enter no section, so
     // with sections alone a stream that took over the device (a new pipeline, the bench's one-in-flight leg) saw "shared" until seven of its
-    // Sinkhorn launches - seven whole steps - had passed (round 5: found in a kernel trace, tools/trace_sequence.py); round 6: by time, see spin_gate_shared
+    // Sinkhorn launches - seven whole steps - had passed (round 5: found in a kernel trace, tools/trace_sequence.py)
     hipStream_t last_query = nullptr;
     bool has_query = false, query_multi = false;
-    std::chrono::steady_clock::time_point query_switch;      // when a query last came from another stream than the one before
+    int query_run = 0;                                       // consecutive queries of one stream
+    std::chrono::steady_clock::time_point query_switch;      // (option fused_choice = 1) when a query last came from another stream than the one before
 };
 SpinGate* spin_gate(int device) {
     static std::mutex mu;
@@ -839,16 +840,26 @@ SpinGate* spin_gate(int device) {
     return g;
 }
 // do sections of other streams alternate with `st`'s on this device at the moment?  (a hint for choosing kernels, not a guarantee)
+static int imp_fused_choice_by_time = 0;          // A/B hook (option fused_choice = 1): the rule the round-5 advisor proposed, below
 bool spin_gate_shared(int device, hipStream_t st) {
     SpinGate* g = spin_gate(device);
     if (!g) return false;
     std::lock_guard<std::mutex> lock(g->mu);
-    // "shared" = another stream asked within the last 8 ms (about two batch-steps).  Round 5 counted consecutive queries of one stream instead (seven =
-    // alone) - but one imp_match_pair asks 18 times inside a single call, so a stream whose neighbours were blocked in a synchronisation flipped to "alone"
-    // in mid-call and took the waiting launch beside their kernels
-    const auto now = std::chrono::steady_clock::now();
-    if (g->has_query && g->last_query != st) { g->query_multi = true; g->query_switch = now; }
-    else if (g->query_multi && now - g->query_switch > std::chrono::milliseconds(8)) g->query_multi = false;
+    // "shared" = another stream is choosing kernels right now.  A stream counts as alone again after seven queries in a row (round 5).  One imp_match_pair
+    // asks 18 times inside a single call, so with three steps in flight a stream whose neighbours are blocked in a synchronisation flips to "alone" in
+    // mid-call and takes the fused launch for the rest of it - ADVICE r5 called that a risk and proposed a rule by time (alone = nobody else asked for
+    // 8 ms).  Round 6 built it and measured it: with three steps in flight it never takes the fused launch (1 040-1 062 pairs/s on three boxes against
+    // 1 085-1 098 with this rule; round 5's own A/B: mixed 1 121, always fused 1 094, never fused 1 065 - profiles/r05/envab_fused_policy_three_in_flight.log).
+    // The mix IS the optimum: the fused launch where a stream happens to have the chip, the two-launch layers where it shares it; the gate's sections keep
+    // it correct either way.  The count stays; the rule by time is kept behind option fused_choice = 1 for the A/B (profiles/r06/fused_choice_ab.log)
+    if (imp_fused_choice_by_time) {
+        const auto now = std::chrono::steady_clock::now();
+        if (g->has_query && g->last_query != st) { g->query_multi = true; g->query_switch = now; }
+        else if (g->query_multi && now - g->query_switch > std::chrono::milliseconds(8)) g->query_multi = false;
+    } else {
+        if (g->has_query && g->last_query != st) { g->query_multi = true; g->query_run = 0; }
+        else if (g->query_multi && ++g->query_run > 6) g->query_multi = false;
+    }
     g->last_query = st; g->has_query = true;
     return g->query_multi;
 }
@@ -1333,6 +1344,7 @@ static int ctx_option(imp_ctx* c, const char* name, long v) {
     else if (n == "wf_fused_min") c->wf_fused_min_tiles = v;
     else if (n == "wf_fused_fake") c->wf_fused_fake = v != 0;         // TEST HOOK: one workgroup withholds its statistics
     else if (n == "probe_prof") c->probe_prof = v != 0;               // probes: the timing entry points also print the phase cycle stamps of a profiling build
+    else if (n == "fused_choice") imp_fused_choice_by_time = v != 0;  // A/B: 1 = a stream is alone when nobody else asked for 8 ms (process-wide; measured slower: spin_gate_shared)
     else if (n == "attn_shares") c->attn_share_mode = (int)v;          // key shares of a split attention unit: 0 launcher's choice, 1 one workgroup each, 2 one workgroup all (same bits)
     else if (n == "kv_image") c->kv_image = (int)v;                   // 0: the projection writes fp32 k | v, the attention kernel splits them while staging
     else return IMP_E_ARG;
