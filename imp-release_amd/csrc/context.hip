@@ -840,7 +840,8 @@ SpinGate* spin_gate(int device) {
     return g;
 }
 // do sections of other streams alternate with `st`'s on this device at the moment?  (a hint for choosing kernels, not a guarantee)
-static int imp_fused_choice_by_time = 0;          // A/B hook (option fused_choice = 1): the rule the round-5 advisor proposed, below
+static int imp_fused_choice_by_time = 0;
+static int imp_fused_alone_after = 6;      // a stream counts as alone once MORE than this many kernel choices in a row were its own (option fused_alone_after)          // A/B hook (option fused_choice = 1): the rule the round-5 advisor proposed, below
 bool spin_gate_shared(int device, hipStream_t st) {
     SpinGate* g = spin_gate(device);
     if (!g) return false;
@@ -858,7 +859,7 @@ bool spin_gate_shared(int device, hipStream_t st) {
         else if (g->query_multi && now - g->query_switch > std::chrono::milliseconds(8)) g->query_multi = false;
     } else {
         if (g->has_query && g->last_query != st) { g->query_multi = true; g->query_run = 0; }
-        else if (g->query_multi && ++g->query_run > 6) g->query_multi = false;
+        else if (g->query_multi && ++g->query_run > imp_fused_alone_after) g->query_multi = false;
     }
     g->last_query = st; g->has_query = true;
     return g->query_multi;
@@ -1345,6 +1346,7 @@ static int ctx_option(imp_ctx* c, const char* name, long v) {
     else if (n == "wf_fused_fake") c->wf_fused_fake = v != 0;         // TEST HOOK: one workgroup withholds its statistics
     else if (n == "probe_prof") c->probe_prof = v != 0;               // probes: the timing entry points also print the phase cycle stamps of a profiling build
     else if (n == "fused_choice") imp_fused_choice_by_time = v != 0;  // A/B: 1 = a stream is alone when nobody else asked for 8 ms (process-wide; measured slower: spin_gate_shared)
+    else if (n == "fused_alone_after") imp_fused_alone_after = (int)v; // sweep hook for the count rule (process-wide)
     else if (n == "attn_shares") c->attn_share_mode = (int)v;          // key shares of a split attention unit: 0 launcher's choice, 1 one workgroup each, 2 one workgroup all (same bits)
     else if (n == "kv_image") c->kv_image = (int)v;                   // 0: the projection writes fp32 k | v, the attention kernel splits them while staging
     else return IMP_E_ARG;
