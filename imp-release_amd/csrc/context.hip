@@ -660,7 +660,7 @@ int run_layer(imp_ctx* c, int li, int batch, const int n[2], const float* const 
     // ... and only while this stream has the device's waiting kernels to itself: sections of several streams (batch-steps in flight on replicas)
     // run strictly one after the other behind cross-stream events, and a waiting kernel that shares the chip with another stream's
     // ordinary kernel spins on the CUs it got until the rest of its workgroups find room - measured: three steps in flight with fused
-    // layers 985 pairs/s, 1019 with the two-launch layers (which interleave freely), one step in flight 982 vs 957.  IMP_WF_FUSED=2: always
+    // layers 985 pairs/s, 1019 with the two-launch layers (which interleave freely), one step in flight 982 vs 957.  option wf_fused = 2: always
     if (wf_mlp && c->wf_fused && D == 256 && wf_tiles >= c->wf_fused_min_tiles && wf_tiles <= (long)c->num_cus && c->fx_rec[0] &&
         (c->wf_fused > 1 || !spin_gate_shared(c->device, st))) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;

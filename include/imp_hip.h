@@ -340,7 +340,7 @@ int imp_op_attention(imp_ctx* ctx, int batch, int nq, int nk, int dim, const flo
  *   ot_resident 0|1   chip-resident Sinkhorn kernel (0: streaming kernels)          ot_local / ot_hier 0|1   its XCD-local / two-XCD decompositions
  *   ot_verify 0|1     wait for every resident launch and repair it inside the call   ot_graph 0|1             0: hipGraph captures record the streaming Sinkhorn
  *   gemm_wf 0|1|2     weight-fragment GEMMs (0: plain tiled GEMMs, 2: at every size)  wf_chain 0|1, wf_chain_min   MLP3 + next projection in one launch
- *   wf_fused 0|1, wf_fused_min   the layer's MLP in one launch with the in-kernel InstanceNorm statistics exchange
+ *   wf_fused 0|1|2, wf_fused_min   the layer's MLP in one launch with the in-kernel InstanceNorm statistics exchange (1: while the stream has the chip, 2: always)
  *   fused_choice 0|1  when a stream counts as alone and takes the fused layer launch: 0 after seven kernel choices in a row (default), 1 after 8 ms (A/B; process-wide);
  *                     fused_alone_after K: the count of that rule (default 6: more than six in a row)
  *   attn_shares 0|1|2 key shares of a split attention unit by one workgroup each (1) or all by one (2); 0: the launcher decides - same bits either way
