@@ -759,9 +759,19 @@ def main():
                 line['cpu_baseline'] = {'error': repr(e_)[:300]}
         else:
             line['cpu_baseline'] = None
-        print(json.dumps(line), flush=True)
+    # the line must be the LAST thing on stdout: RCCL's version banner sits in the C library's stdio buffer of the ranks (stdout is a pipe) and would otherwise
+    # be flushed behind it at exit - every rank flushes, the ranks meet, then rank 0 prints
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                    # noqa: BLE001
+        pass
+    sys.stdout.flush()
     if use_pg:
         dist.barrier()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if use_pg:
         dist.destroy_process_group()
 
 
